@@ -1,0 +1,176 @@
+"""ctypes front-end of the CPU oracle (oracle/daco_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  The product package (deepaco_amd) never imports it and has no CPU fallback.
+
+All functions take / return numpy arrays in the reference's layouts
+(paths: (n, A) int64; log_probs: (n-1, A) float32; costs: (A,) float32).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ORC_INFEASIBLE = 1
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libdaco_oracle.so")
+    src = os.path.join(_HERE, "daco_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libdaco_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_u01.restype = C.c_float
+        _LIB.orc_neg_log2_1m.restype = C.c_float
+        _LIB.orc_neg_log2_1m.argtypes = [C.c_float]
+        _LIB.orc_two_opt_once.restype = C.c_float
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def vec_for_n(n):
+    return lib().orc_vec_for_n(int(n))
+
+
+def ld_for_n(n):
+    return lib().orc_ld_for_n(int(n))
+
+
+def philox4x32_10(ctr, key):
+    ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(ctr), _p(key), _p(out))
+    return out
+
+
+def u01(x):
+    return float(lib().orc_u01(C.c_uint32(int(x))))
+
+
+def neg_log2_1m(w):
+    return float(lib().orc_neg_log2_1m(C.c_float(float(w))))
+
+
+def prob_matrix(tau, eta, alpha=1.0, beta=1.0):
+    tau, eta = _f32(tau), _f32(eta)
+    n = tau.shape[0]
+    P = np.empty((n, n), dtype=np.float32)
+    lib().orc_prob_matrix(n, _p(tau), _p(eta), C.c_float(alpha), C.c_float(beta), _p(P))
+    return P
+
+
+def tsp_sample_noise(P, start, noise, norm_passes=1, require_prob=True):
+    P, noise, start = _f32(P), _f32(noise), _i64(start)
+    n, A = P.shape[0], start.shape[0]
+    assert noise.shape == (n - 1, A, n)
+    paths = np.zeros((n, A), dtype=np.int64)
+    logp = np.zeros((n - 1, A), dtype=np.float32) if require_prob else None
+    rc = lib().orc_tsp_sample_noise(n, A, _p(P), _p(start), _p(noise), int(norm_passes), _p(paths),
+                                    _p(logp) if require_prob else None)
+    return paths, logp, rc
+
+
+def _sample_rng(fn, P, A, seed, it, ant_gid0, fixed_start, require_prob):
+    P = _f32(P)
+    n = P.shape[0]
+    paths = np.zeros((n, A), dtype=np.int64)
+    logp = np.zeros((n - 1, A), dtype=np.float32) if require_prob else None
+    rc = fn(n, A, _p(P), C.c_uint64(seed), C.c_uint64(it), C.c_uint32(ant_gid0), int(fixed_start),
+            _p(paths), _p(logp) if require_prob else None)
+    return paths, logp, rc
+
+
+def tsp_sample_race(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=False):
+    return _sample_rng(lib().orc_tsp_sample_race, P, A, seed, it, ant_gid0, fixed_start, require_prob)
+
+
+def tsp_sample_scan(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=False):
+    return _sample_rng(lib().orc_tsp_sample_scan, P, A, seed, it, ant_gid0, fixed_start, require_prob)
+
+
+def tour_costs(dist, paths, closed=True):
+    dist, paths = _f32(dist), _i64(paths)
+    n, (length, A) = dist.shape[0], paths.shape
+    costs = np.zeros(A, dtype=np.float32)
+    lib().orc_tour_costs(n, length, A, _p(dist), _p(paths), int(closed), _p(costs))
+    return costs
+
+
+def pheromone_update_tsp(tau, paths, costs, decay, elitist=False, clamp_min=0.0, clamp_max=0.0):
+    tau = _f32(tau).copy()
+    paths, costs = _i64(paths), _f32(costs)
+    n, A = paths.shape
+    lib().orc_pheromone_update_tsp(n, A, _p(tau), _p(paths), _p(costs), C.c_float(decay), int(elitist),
+                                   C.c_float(clamp_min), C.c_float(clamp_max))
+    return tau
+
+
+def pheromone_update_cvrp(tau, paths, costs, decay, elitist=False, clamp_min=0.0, clamp_max=0.0):
+    tau = _f32(tau).copy()
+    paths, costs = _i64(paths), _f32(costs)
+    n = tau.shape[0]
+    length, A = paths.shape
+    lib().orc_pheromone_update_cvrp(n, length, A, _p(tau), _p(paths), _p(costs), C.c_float(decay),
+                                    int(elitist), C.c_float(clamp_min), C.c_float(clamp_max))
+    return tau
+
+
+def two_opt_once(dist, tour):
+    dist = _f32(dist)
+    t = np.ascontiguousarray(tour, dtype=np.uint16).copy()
+    delta = lib().orc_two_opt_once(dist.shape[0], _p(dist), _p(t))
+    return t, float(delta)
+
+
+def two_opt_batch(dist, tours, max_iterations=1000):
+    dist = _f32(dist)
+    t = np.ascontiguousarray(tours, dtype=np.uint16).copy()
+    T, n = t.shape
+    sweeps = np.zeros(T, dtype=np.int32)
+    lib().orc_two_opt_batch(n, T, _p(dist), _p(t), C.c_long(int(max_iterations)), _p(sweeps))
+    return t, sweeps
+
+
+def roulette_route(probmat, uniforms, start=0):
+    probmat = _f32(probmat)
+    uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)
+    n = probmat.shape[0]
+    route = np.zeros(n, dtype=np.uint16)
+    lib().orc_roulette_route(n, _p(probmat), _p(uniforms), int(start), _p(route))
+    return route
+
+
+def cvrp_sample_noise(P, demand, capacity, noise, Lmax=None, require_prob=True):
+    P, demand, noise = _f32(P), _f32(demand), _f32(noise)
+    n1 = P.shape[0]
+    steps, A = noise.shape[0], noise.shape[1]
+    Lmax = Lmax or 2 * n1 + 1
+    paths = np.zeros((Lmax, A), dtype=np.int64)
+    logp = np.zeros((Lmax - 1, A), dtype=np.float32) if require_prob else None
+    L = lib().orc_cvrp_sample_noise(n1, A, _p(P), _p(demand), C.c_float(capacity), _p(noise), steps,
+                                    Lmax, _p(paths), _p(logp) if require_prob else None)
+    if L < 0:
+        return None, None, L
+    return paths[:L], (logp[:L - 1] if require_prob else None), L

@@ -1,0 +1,514 @@
+/*
+ * daco_oracle.c -- CPU restatement (plain C, scalar, single thread) of DeepACO's ant-rollout
+ * hot path.  TEST INFRASTRUCTURE ONLY: it is the checker for the HIP kernels.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product package
+ * (deepaco_amd/) never does.
+ *
+ * Parity status: PINNED.  Every function below is checked in tests/test_oracle_golden.py
+ * against vectors captured by importing the reference in the build container
+ * (tests/golden/gen_golden.py; fixtures: the .npz files under tests/golden).
+ *
+ * Each function cites the reference lines (henry-yeh/DeepACO @ /root/reference) it restates.
+ * Arithmetic that must agree bit-for-bit with the HIP kernels (summation trees, Philox
+ * counters, the -log2 polynomial) is restated here independently from the written
+ * specification in DESIGN.md section 4, not shared as code with deepaco_amd/csrc.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_OK 0
+#define ORC_INFEASIBLE 1 /* a row had no feasible candidate (reference: Categorical raises) */
+
+/* ------------------------------------------------------------------ lane layout */
+/* A row of n candidates is dealt to 64 lanes in vectors of VEC: candidate k of lane l is
+ * k = (c*64 + l)*VEC + v, c = chunk, v = 0..VEC-1.  Row sums follow this layout. */
+int orc_vec_for_n(int n) { return n > 128 ? 4 : (n > 64 ? 2 : 1); }
+int orc_ld_for_n(int n) { int w = 64 * orc_vec_for_n(n); return (n + w - 1) / w * w; }
+
+/* lane-partial sums (c ascending, v ascending, from +0.0f) followed by a 6-level butterfly
+ * partial[l] += partial[l ^ off], off = 32,16,8,4,2,1.  All lanes end with the same value. */
+static float row_sum_tree(const float *p, int n) {
+  int vec = orc_vec_for_n(n), ld = orc_ld_for_n(n), ch = ld / (64 * vec);
+  float part[64], tmp[64];
+  for (int l = 0; l < 64; ++l) {
+    float s = 0.0f;
+    for (int c = 0; c < ch; ++c)
+      for (int v = 0; v < vec; ++v) {
+        int k = (c * 64 + l) * vec + v;
+        s = s + (k < n ? p[k] : 0.0f);
+      }
+    part[l] = s;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    for (int l = 0; l < 64; ++l) tmp[l] = part[l] + part[l ^ off];
+    memcpy(part, tmp, sizeof part);
+  }
+  return part[0];
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 (Salmon et al. 2011) */
+static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  memcpy(out, ctr, 16);
+  philox4x32_10(out, key[0], key[1]);
+}
+
+/* stream ids (counter word 3, top byte) */
+enum { STREAM_START = 1, STREAM_RACE = 2, STREAM_SCAN = 3 };
+
+static inline void rng_block(uint64_t seed, uint64_t iter, uint32_t stream, uint32_t ant_gid,
+                             uint32_t idx, uint32_t out[4]) {
+  out[0] = idx; out[1] = ant_gid; out[2] = (uint32_t)iter;
+  out[3] = (stream << 24) | (uint32_t)((iter >> 32) & 0xFFFFFFu);
+  philox4x32_10(out, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+/* uniform in (0,1), exactly representable: (2m+1) * 2^-24 with m the top 23 bits */
+static inline float u01(uint32_t x) { return (float)(2u * (x >> 9) + 1u) * 0x1p-24f; }
+
+/* -log2(1 - w), w = u01(x): exponential variate scaled by 1/ln2.  Polynomial with explicit
+ * fmaf so CPU and GPU agree bit for bit.  Relative error < 1e-7. */
+static inline float neg_log2_1m(float w) {
+  float y = 1.0f - w;                         /* exact */
+  uint32_t b; memcpy(&b, &y, 4);
+  int e = (int)(b >> 23) - 127;
+  b = (b & 0x007FFFFFu) | 0x3F800000u;
+  float t; memcpy(&t, &b, 4);
+  if (t > 1.41421354f) { t = t * 0.5f; e += 1; }
+  float s = t - 1.0f;
+  float q = 0x1.025a2p-3f;
+  q = fmaf(q, s, -0x1.a8cc5cp-3f);
+  q = fmaf(q, s, 0x1.b9b11ep-3f);
+  q = fmaf(q, s, -0x1.e94f12p-3f);
+  q = fmaf(q, s, 0x1.26d41p-2f);
+  q = fmaf(q, s, -0x1.715c9cp-2f);
+  q = fmaf(q, s, 0x1.ec73d4p-2f);
+  q = fmaf(q, s, -0x1.71547p-1f);
+  q = fmaf(q, s, 0x1.715476p+0f);
+  return -fmaf(s, q, (float)e);
+}
+float orc_u01(uint32_t x) { return u01(x); }
+float orc_neg_log2_1m(float w) { return neg_log2_1m(w); }
+
+/* ------------------------------------------------------------------ T2: transition weights */
+/* P[i][k] = tau[i][k]^alpha * eta[i][k]^beta   (tsp/aco.py:173, tsp_nls/aco.py:195).
+ * x**1 is x, x**2 is x*x, x**0 is 1 (all exact, as in torch); other exponents use powf and
+ * are outside the bit-exact claim. */
+static inline float pw(float x, float a) {
+  if (a == 1.0f) return x;
+  if (a == 2.0f) return x * x;
+  if (a == 0.0f) return 1.0f;
+  return powf(x, a);
+}
+void orc_prob_matrix(int n, const float *tau, const float *eta, float alpha, float beta, float *P) {
+  for (long i = 0; i < (long)n * n; ++i) P[i] = pw(tau[i], alpha) * pw(eta[i], beta);
+}
+
+#define EPS_F32 1.1920928955078125e-07f /* torch.finfo(float32).eps, clamp in probs_to_logits */
+
+static inline float clamp_log(float pr) {
+  if (pr < EPS_F32) pr = EPS_F32;
+  if (pr > 1.0f - EPS_F32) pr = 1.0f - EPS_F32;
+  return logf(pr);
+}
+
+/* ------------------------------------------------------------------ T1/T2/T3: race sampler, recorded noise
+ * tsp/aco.py:134-177 (norm_passes = 1: Categorical normalises once) and
+ * tsp_nls/aco.py:184-220 (norm_passes = 2: explicit dist/dist.sum(), then Categorical again).
+ * action = argmax_k ((p_k / S) [/ S']) / q_k, first maximum wins (torch.argmax).
+ * noise: [n-1][A][n]; paths: [n][A] int64; logp: [n-1][A] or NULL. */
+int orc_tsp_sample_noise(int n, int A, const float *P, const int64_t *start, const float *noise,
+                         int norm_passes, int64_t *paths, float *logp) {
+  int rc = ORC_OK;
+  float *p = (float *)malloc(sizeof(float) * n);
+  unsigned char *vis = (unsigned char *)malloc(n);
+  for (int a = 0; a < A; ++a) {
+    memset(vis, 0, n);
+    int prev = (int)start[a];
+    vis[prev] = 1;
+    paths[a] = prev;
+    for (int t = 1; t < n; ++t) {
+      const float *row = P + (long)prev * n;
+      const float *q = noise + ((long)(t - 1) * A + a) * n;
+      for (int k = 0; k < n; ++k) p[k] = vis[k] ? 0.0f : row[k];   /* row * mask, mask in {0,1} */
+      for (int pass = 0; pass < norm_passes; ++pass) {
+        float S = row_sum_tree(p, n);
+        for (int k = 0; k < n; ++k) p[k] = p[k] / S;
+      }
+      int best = -1; float bk = -INFINITY;
+      for (int k = 0; k < n; ++k) {
+        float key = p[k] / q[k];
+        if (key > bk) { bk = key; best = k; }
+      }
+      if (best < 0 || !(bk > 0.0f)) { rc = ORC_INFEASIBLE; best = best < 0 ? 0 : best; }
+      if (logp) logp[(long)(t - 1) * A + a] = clamp_log(norm_passes ? p[best] : p[best] / row_sum_tree(p, n));
+      vis[best] = 1;
+      paths[(long)t * A + a] = best;
+      prev = best;
+    }
+  }
+  free(p); free(vis);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ race sampler, in-kernel Philox noise
+ * Same race, written division-free: argmin_k L_k * R[prev][k], R = 1/P, L_k = -log2(1-u_k),
+ * u_k = component (k&3) of Philox(ctr = ((t<<12)|(k>>2), ant_gid, iter, STREAM_RACE), key = seed).
+ * Ties -> smallest k.  start: fixed_start >= 0, else floor(n * u32 / 2^32) from STREAM_START. */
+int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t iter,
+                        uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
+  int rc = ORC_OK;
+  float *p = (float *)malloc(sizeof(float) * n);
+  unsigned char *vis = (unsigned char *)malloc(n);
+  for (int a = 0; a < A; ++a) {
+    uint32_t gid = ant_gid0 + (uint32_t)a, r4[4];
+    int prev = fixed_start;
+    if (prev < 0) {
+      rng_block(seed, iter, STREAM_START, gid, 0, r4);
+      prev = (int)(((uint64_t)r4[0] * (uint64_t)n) >> 32);
+    }
+    memset(vis, 0, n);
+    vis[prev] = 1;
+    paths[a] = prev;
+    for (int t = 1; t < n; ++t) {
+      const float *row = P + (long)prev * n;
+      int best = -1; float bk = INFINITY;
+      for (int g = 0; g * 4 < n; ++g) {
+        rng_block(seed, iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)g, r4);
+        for (int v = 0; v < 4; ++v) {
+          int k = g * 4 + v;
+          if (k >= n || vis[k]) continue;
+          float key = neg_log2_1m(u01(r4[v])) * (1.0f / row[k]);
+          if (key < bk) { bk = key; best = k; }
+        }
+      }
+      if (best < 0) { rc = ORC_INFEASIBLE; best = 0; }
+      if (logp) {
+        for (int k = 0; k < n; ++k) p[k] = vis[k] ? 0.0f : row[k];
+        logp[(long)(t - 1) * A + a] = clamp_log(row[best] / row_sum_tree(p, n));
+      }
+      vis[best] = 1;
+      paths[(long)t * A + a] = best;
+      prev = best;
+    }
+  }
+  free(p); free(vis);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ I1 analogue: prefix-scan (roulette) sampler
+ * tsp_nls/aco.py:260-275 draws r = U * sum(prob*mask) and walks the row until the running
+ * sum reaches r.  Here the walk is a wave-shaped scan with a defined order:
+ *   part[l]  = lane-partial sum (c asc, v asc) of masked p
+ *   incl     = Kogge-Stone inclusive scan over lanes (d = 1,2,4,8,16,32; x[l] += x[l-d])
+ *   S = incl[63];  r = u * S,  u = component (t&3) of Philox(ctr=(t>>2, gid, iter, STREAM_SCAN))
+ *   L = first lane with incl[L] >= r and part[L] > 0
+ *   inside lane L: run = incl[L-1] (0 for L=0); walk its candidates in (c,v) order adding
+ *   unvisited p>0; pick the first with run >= r, else the last unvisited p>0 of the lane. */
+int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t iter,
+                        uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
+  int rc = ORC_OK;
+  int vec = orc_vec_for_n(n), ld = orc_ld_for_n(n), ch = ld / (64 * vec);
+  unsigned char *vis = (unsigned char *)malloc(n);
+  for (int a = 0; a < A; ++a) {
+    uint32_t gid = ant_gid0 + (uint32_t)a, r4[4];
+    int prev = fixed_start;
+    if (prev < 0) {
+      rng_block(seed, iter, STREAM_START, gid, 0, r4);
+      prev = (int)(((uint64_t)r4[0] * (uint64_t)n) >> 32);
+    }
+    memset(vis, 0, n);
+    vis[prev] = 1;
+    paths[a] = prev;
+    for (int t = 1; t < n; ++t) {
+      const float *row = P + (long)prev * n;
+      float part[64], incl[64], tmp[64];
+      for (int l = 0; l < 64; ++l) {
+        float s = 0.0f;
+        for (int c = 0; c < ch; ++c)
+          for (int v = 0; v < vec; ++v) {
+            int k = (c * 64 + l) * vec + v;
+            s = s + ((k < n && !vis[k]) ? row[k] : 0.0f);
+          }
+        part[l] = s; incl[l] = s;
+      }
+      for (int d = 1; d < 64; d <<= 1) {
+        for (int l = 0; l < 64; ++l) tmp[l] = l >= d ? incl[l] + incl[l - d] : incl[l];
+        memcpy(incl, tmp, sizeof incl);
+      }
+      float S = incl[63];
+      rng_block(seed, iter, STREAM_SCAN, gid, (uint32_t)t >> 2, r4);
+      float r = u01(r4[t & 3]) * S;
+      int L = -1;
+      for (int l = 0; l < 64; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
+      int best = -1;
+      if (L >= 0) {
+        float run = L ? incl[L - 1] : 0.0f;
+        int last = -1;
+        for (int c = 0; c < ch && best < 0; ++c)
+          for (int v = 0; v < vec; ++v) {
+            int k = (c * 64 + L) * vec + v;
+            if (k >= n || vis[k] || !(row[k] > 0.0f)) continue;
+            run = run + row[k];
+            last = k;
+            if (run >= r) { best = k; break; }
+          }
+        if (best < 0) best = last;
+      }
+      if (best < 0) { rc = ORC_INFEASIBLE; best = 0; }
+      if (logp) logp[(long)(t - 1) * A + a] = clamp_log(row[best] / S);
+      vis[best] = 1;
+      paths[(long)t * A + a] = best;
+      prev = best;
+    }
+  }
+  free(vis);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ T4 / C5: tour costs
+ * closed: sum_k dist[u_k][u_{k-1 mod n}]  (tsp/aco.py:121-132)
+ * open:   sum_{k<len-1} dist[u_k][u_{k+1}] (cvrp/aco.py:133-136)
+ * Order: sequential in k from +0.0f (the reference's torch.sum order is unspecified; agreement
+ * with it is to 1e-5 relative, agreement with the HIP kernel is bitwise). */
+void orc_tour_costs(int n, int len, int A, const float *dist, const int64_t *paths, int closed,
+                    float *costs) {
+  for (int a = 0; a < A; ++a) {
+    float s = 0.0f;
+    if (closed) {
+      for (int k = 0; k < len; ++k) {
+        long u = paths[(long)k * A + a], v = paths[(long)((k + len - 1) % len) * A + a];
+        s = s + dist[u * n + v];
+      }
+    } else {
+      for (int k = 0; k + 1 < len; ++k) {
+        long u = paths[(long)k * A + a], v = paths[(long)(k + 1) * A + a];
+        s = s + dist[u * n + v];
+      }
+    }
+    costs[a] = s;
+  }
+}
+
+/* ------------------------------------------------------------------ U1: pheromone update, TSP
+ * tsp/aco.py:95-118.  tau <- tau*decay; for each ant in index order (or only the best ant if
+ * elitist; torch.min returns the first minimum): w = 1/cost;
+ * tau[path, roll(path,1)] += w, then tau[roll(path,1), path] += w (non-accumulating
+ * index_put: gather old values, add, scatter).  MMAS clamp if clamp_max > 0. */
+static void deposit_tsp(int n, int A, float *tau, const int64_t *paths, int a, float w, float *buf) {
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int k = 0; k < n; ++k) {
+      long u = paths[(long)k * A + a], v = paths[(long)((k + n - 1) % n) * A + a];
+      buf[k] = (pass == 0 ? tau[u * n + v] : tau[v * n + u]) + w;
+    }
+    for (int k = 0; k < n; ++k) {
+      long u = paths[(long)k * A + a], v = paths[(long)((k + n - 1) % n) * A + a];
+      if (pass == 0) tau[u * n + v] = buf[k]; else tau[v * n + u] = buf[k];
+    }
+  }
+}
+void orc_pheromone_update_tsp(int n, int A, float *tau, const int64_t *paths, const float *costs,
+                              float decay, int elitist, float clamp_min, float clamp_max) {
+  float *buf = (float *)malloc(sizeof(float) * n);
+  for (long i = 0; i < (long)n * n; ++i) tau[i] = tau[i] * decay;
+  if (elitist) {
+    int b = 0;
+    for (int a = 1; a < A; ++a) if (costs[a] < costs[b]) b = a;
+    deposit_tsp(n, A, tau, paths, b, 1.0f / costs[b], buf);
+  } else {
+    for (int a = 0; a < A; ++a) deposit_tsp(n, A, tau, paths, a, 1.0f / costs[a], buf);
+  }
+  if (clamp_max > 0.0f) {
+    for (long i = 0; i < (long)n * n; ++i) {
+      if (tau[i] < clamp_min) tau[i] = clamp_min;   /* ((tau>1e-9)*tau < min) == (tau < min) */
+      if (tau[i] > clamp_max) tau[i] = clamp_max;
+    }
+  }
+  free(buf);
+}
+
+/* ------------------------------------------------------------------ C5: pheromone update, CVRP
+ * cvrp/aco.py:107-130.  Directed: tau[path[:-1], path[1:]] += w, duplicates of an index pair
+ * (the padding edge (0,0)) collapse to one add; floor tau < 1e-10 -> 1e-10. */
+void orc_pheromone_update_cvrp(int n, int len, int A, float *tau, const int64_t *paths,
+                               const float *costs, float decay, int elitist, float clamp_min,
+                               float clamp_max) {
+  float *buf = (float *)malloc(sizeof(float) * (len > 0 ? len : 1));
+  for (long i = 0; i < (long)n * n; ++i) tau[i] = tau[i] * decay;
+  int lo = 0, hi = A;
+  if (elitist) {
+    int b = 0;
+    for (int a = 1; a < A; ++a) if (costs[a] < costs[b]) b = a;
+    lo = b; hi = b + 1;
+  }
+  for (int a = lo; a < hi; ++a) {
+    float w = 1.0f / costs[a];
+    for (int k = 0; k + 1 < len; ++k)
+      buf[k] = tau[paths[(long)k * A + a] * n + paths[(long)(k + 1) * A + a]] + w;
+    for (int k = 0; k + 1 < len; ++k)
+      tau[paths[(long)k * A + a] * n + paths[(long)(k + 1) * A + a]] = buf[k];
+  }
+  if (clamp_max > 0.0f)
+    for (long i = 0; i < (long)n * n; ++i) {
+      if (tau[i] < clamp_min) tau[i] = clamp_min;
+      if (tau[i] > clamp_max) tau[i] = clamp_max;
+    }
+  for (long i = 0; i < (long)n * n; ++i) if (tau[i] < 1e-10f) tau[i] = 1e-10f;
+  free(buf);
+}
+
+/* ------------------------------------------------------------------ O1/O2: 2-opt
+ * tsp_nls/two_opt.py:6-39.  Best-improvement sweep over 1 <= i < j <= n-1 with
+ * change = d[t[i-1]][t[j]] + d[t[i]][t[(j+1)%n]] - d[t[i-1]][t[i]] - d[t[j]][t[(j+1)%n]]
+ * evaluated left to right in f32; strict '<' keeps the first minimum in row-major (i,j)
+ * order; reverse t[i..j] if delta < -1e-6.  Returns delta (0 if no move). */
+float orc_two_opt_once(int n, const float *d, uint16_t *t) {
+  int p = 0, q = 0;
+  float delta = 0.0f;
+  for (int i = 1; i < n - 1; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      int ni = t[i], nj = t[j], np_ = t[i - 1], nn = t[(j + 1) % n];
+      if (np_ == nj || nn == ni) continue;
+      float change = d[(long)np_ * n + nj] + d[(long)ni * n + nn];
+      change = change - d[(long)np_ * n + ni];
+      change = change - d[(long)nj * n + nn];
+      if (change < delta) { p = i; q = j; delta = change; }
+    }
+  if ((double)delta < -1e-6) {           /* numba compares the f32 delta with the f64 literal */
+    for (int i = p, j = q; i < j; ++i, --j) { uint16_t x = t[i]; t[i] = t[j]; t[j] = x; }
+    return delta;
+  }
+  return 0.0f;
+}
+/* returns the number of sweeps performed */
+int orc_two_opt(int n, const float *d, uint16_t *t, long max_iterations) {
+  long it = 0;
+  float mc = -1.0f;
+  while ((double)mc < -1e-6 && it < max_iterations) {
+    mc = orc_two_opt_once(n, d, t);
+    ++it;
+  }
+  return (int)it;
+}
+void orc_two_opt_batch(int n, int T, const float *d, uint16_t *tours, long max_iterations,
+                       int32_t *sweeps) {
+  for (int r = 0; r < T; ++r) {
+    int s = orc_two_opt(n, d, tours + (long)r * n, max_iterations);
+    if (sweeps) sweeps[r] = s;
+  }
+}
+
+/* ------------------------------------------------------------------ I1: roulette sampler, literal restatement
+ * tsp_nls/aco.py:260-275 with an injected uniform stream (the reference's RNG is numba's
+ * private generator and cannot be seeded): rand = U * sum_f32(prob*mask) (numpy's pairwise
+ * float32 sum), then rand -= prob[k] in float64 (numba types U as float64) until rand <= 0. */
+static float np_pairwise_sum_f32(const float *a, int n) {
+  /* numpy's FLOAT_pairwise_sum (contiguous float32 .sum()) */
+  if (n < 8) { float s = 0.0f; for (int i = 0; i < n; ++i) s += a[i]; return s; }
+  if (n <= 128) {
+    float r[8], sum; int i;
+    for (i = 0; i < 8; ++i) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int u = 0; u < 8; ++u) r[u] += a[i + u];
+    sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) sum += a[i];
+    return sum;
+  }
+  int n2 = n / 2; n2 -= n2 % 8;
+  return np_pairwise_sum_f32(a, n2) + np_pairwise_sum_f32(a + n2, n - n2);
+}
+void orc_roulette_route(int n, const float *probmat, const double *uniforms, int start,
+                        uint16_t *route) {
+  unsigned char *mask = (unsigned char *)malloc(n);
+  float *prob = (float *)malloc(sizeof(float) * n);
+  memset(mask, 1, n);
+  int last = start;
+  route[0] = (uint16_t)start;
+  for (int j = 1; j < n; ++j) {
+    mask[last] = 0;
+    for (int k = 0; k < n; ++k) prob[k] = probmat[(long)last * n + k] * (float)mask[k];
+    float sum = np_pairwise_sum_f32(prob, n);
+    double rnd = uniforms[j - 1] * (double)sum;
+    int k;
+    for (k = 0; k < n; ++k) { rnd -= (double)prob[k]; if (rnd <= 0) break; }
+    if (k == n) k = n - 1;
+    last = k;
+    route[j] = (uint16_t)k;
+  }
+  free(mask); free(prob);
+}
+
+/* ------------------------------------------------------------------ C1-C4: CVRP sampler, recorded noise
+ * cvrp/aco.py:138-205.  Node 0 is the depot; n1 = customers + 1.  Every ant starts at the
+ * depot; each step: p = P[prev] * visit_mask * capacity_mask, Categorical -> race as in TSP
+ * (norm_passes = 1).  visit mask: visited customers 0; depot 1 unless the ant is at the depot
+ * and customers remain (C2).  capacity: used = 0 at depot; used += demand[cur]; candidates
+ * with demand > capacity - used masked (strict, C3).  An ant is done when it is at the depot
+ * with every customer visited (C4); the reference keeps stepping until all ants are done, so a
+ * done ant keeps choosing the depot (its only candidate) and its column is padded with 0.
+ * noise: [Lmax-1][A][n1]; paths: [Lmax][A] zero-initialised by the caller.
+ * Returns L (number of rows used, max over ants) or -1 on infeasible/overflow. */
+int orc_cvrp_sample_noise(int n1, int A, const float *P, const float *demand, float capacity,
+                          const float *noise, int noise_steps, int Lmax, int64_t *paths,
+                          float *logp) {
+  float *p = (float *)malloc(sizeof(float) * n1);
+  unsigned char *vis = (unsigned char *)malloc(n1);
+  int *lens = (int *)malloc(sizeof(int) * A);
+  int L = 1;
+  for (int a = 0; a < A; ++a) {
+    memset(vis, 0, n1);
+    int prev = 0, remaining = n1 - 1, len = 1;
+    float used = 0.0f;
+    used = used + demand[0];
+    paths[a] = 0;
+    while (!(remaining == 0 && prev == 0)) {
+      if (len >= Lmax || len - 1 >= noise_steps) { free(p); free(vis); free(lens); return -1; }
+      const float *row = P + (long)prev * n1;
+      const float *q = noise + ((long)(len - 1) * A + a) * n1;
+      float rem = capacity - used;
+      for (int k = 0; k < n1; ++k) {
+        float vm = (k == 0) ? ((prev == 0 && remaining > 0) ? 0.0f : 1.0f) : (vis[k] ? 0.0f : 1.0f);
+        float cm = (demand[k] > rem) ? 0.0f : 1.0f;
+        p[k] = row[k] * vm * cm;
+      }
+      float S = row_sum_tree(p, n1);
+      int best = -1; float bk = -INFINITY;
+      for (int k = 0; k < n1; ++k) {
+        float key = (p[k] / S) / q[k];
+        if (key > bk) { bk = key; best = k; }
+      }
+      if (best < 0 || !(bk > 0.0f)) { free(p); free(vis); free(lens); return -1; }
+      if (logp) logp[(long)(len - 1) * A + a] = clamp_log(p[best] / S);
+      if (best != 0) { vis[best] = 1; --remaining; }
+      if (best == 0) used = 0.0f;
+      used = used + demand[best];
+      paths[(long)len * A + a] = best;
+      prev = best;
+      ++len;
+    }
+    lens[a] = len;
+    if (len > L) L = len;
+  }
+  /* a done ant keeps drawing the depot with probability 1 -> log(clamp(1)) = log(1-eps) */
+  if (logp)
+    for (int a = 0; a < A; ++a)
+      for (int k = lens[a]; k < L; ++k) logp[(long)(k - 1) * A + a] = clamp_log(1.0f);
+  free(p); free(vis); free(lens);
+  return L;
+}

@@ -1,0 +1,137 @@
+"""The CPU oracle (oracle/daco_oracle.c) against the golden vectors captured from the reference.
+
+This is what pins the oracle: every fixture under tests/golden/ was produced by importing
+/root/reference (tests/golden/gen_golden.py).  Integer outputs (tours, 2-opt results) and the
+pheromone update must match bit for bit; float outputs to the stated tolerance.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, load_golden
+
+RTOL_COST = 1e-5      # north_star: tour costs within 1e-5 relative
+ATOL_LOGP = 2e-6      # logf differs by <= 1 ulp between libm builds; |logp| < 20
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32-10
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, exp in kat:
+        assert [int(x) for x in oracle.philox4x32_10(ctr, key)] == exp
+
+
+def test_exponential_transform():
+    # u01 in (0,1), exactly (2m+1)/2^24; -log2(1-w) accurate to 2e-7 relative over the range
+    assert oracle.u01(0) == 2.0 ** -24 and oracle.u01(0xFFFFFFFF) == 1 - 2.0 ** -24
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.integers(0, 2 ** 32, 4000, dtype=np.uint64),
+                         np.arange(0, 2048, dtype=np.uint64) << 9,
+                         (np.uint64(2 ** 32 - 1) - (np.arange(0, 2048, dtype=np.uint64) << 9))])
+    for x in xs:
+        w = oracle.u01(int(x))
+        ref = -np.log2(1.0 - np.float64(w))
+        assert abs(oracle.neg_log2_1m(w) - ref) <= 2e-7 * ref
+
+
+@pytest.mark.parametrize("name", names("g1_tsp") + names("g1_nls"))
+def test_tsp_sampler_bit_exact(name):
+    g = load_golden(name)
+    P = oracle.prob_matrix(g["pheromone"], g["heuristic"])
+    passes = 2 if "nls" in name else 1
+    paths, logp, rc = oracle.tsp_sample_noise(P, g["start"], g["noise"], norm_passes=passes)
+    assert rc == 0
+    assert np.array_equal(paths, g["paths"])
+    np.testing.assert_allclose(logp, g["log_probs"], atol=ATOL_LOGP, rtol=1e-5)
+    # the race is scale-invariant: without the reference's normalisation the tours are the same
+    paths0, _, _ = oracle.tsp_sample_noise(P, g["start"], g["noise"], norm_passes=0)
+    assert np.array_equal(paths0, g["paths"])
+    costs = oracle.tour_costs(g["distances"], paths)
+    np.testing.assert_allclose(costs, g["costs"], rtol=RTOL_COST)
+
+
+@pytest.mark.parametrize("name", names("g2_tsp"))
+def test_tsp_update_bitwise(name):
+    g = load_golden(name)
+    out = oracle.pheromone_update_tsp(g["pheromone_in"], g["paths"], g["costs"], float(g["decay"]),
+                                      bool(g["elitist"]), float(g.get("clamp_min", 0)),
+                                      float(g.get("clamp_max", 0)))
+    assert np.array_equal(out.view(np.uint32), g["pheromone_out"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", names("u2_tsp"))
+def test_tsp_run_trace(name):
+    """Each iteration of run() (tsp/aco.py:75-92) pinned independently on (tau_in, noise)."""
+    g = load_golden(name)
+    dist = g["distances"]
+    eta = (1.0 / dist).astype(np.float32)
+    T = g["tau_in"].shape[0]
+    n = dist.shape[0]
+    lowest, cmax = np.inf, 0.0
+    for it in range(T):
+        P = oracle.prob_matrix(g["tau_in"][it], eta)
+        paths, _, rc = oracle.tsp_sample_noise(P, g["start"][it], g["noise"][it], require_prob=False)
+        assert rc == 0 and np.array_equal(paths, g["paths"][it])
+        np.testing.assert_allclose(oracle.tour_costs(dist, paths), g["costs"][it], rtol=RTOL_COST)
+        # feed the reference's own costs so the update is compared bitwise
+        costs = g["costs"][it]
+        tau = g["tau_in"][it].copy()
+        if costs.min() < lowest:
+            lowest = costs.min()
+            if g["min_max"]:
+                # int / tensor is Tensor.__rtruediv__ = reciprocal(tensor) * int: two roundings
+                new_max = (np.float32(1.0) / np.float32(lowest)) * np.float32(n)
+                if cmax == 0.0:
+                    tau = tau * (new_max / tau.max())
+                cmax = new_max
+        out = oracle.pheromone_update_tsp(tau, paths, costs, float(g["decay"]), bool(g["elitist"]),
+                                          float(g["clamp_min"]), float(cmax) if g["min_max"] else 0.0)
+        assert np.array_equal(out.view(np.uint32), g["tau_out"][it].view(np.uint32)), it
+        assert np.float32(lowest) == g["lowest"][it]
+
+
+@pytest.mark.parametrize("name", names("g4_twoopt"))
+def test_two_opt_bit_exact(name):
+    g = load_golden(name)
+    for r, tour in enumerate(g["tours"]):
+        t1, d1 = oracle.two_opt_once(g["dist"], tour)
+        assert np.array_equal(t1, g["after_one"][r])
+        assert np.float32(d1) == g["delta_one"][r]
+    full, sweeps = oracle.two_opt_batch(g["dist"], g["tours"], 10000)
+    assert np.array_equal(full, g["after_full"])
+    assert np.array_equal(sweeps, g["sweeps"])
+    cap, _ = oracle.two_opt_batch(g["dist"], g["tours"], 5)
+    assert np.array_equal(cap, g["after_cap5"])
+
+
+def test_roulette_literal():
+    g = load_golden("g6_roulette_n30")
+    for u, route in zip(g["uniforms"], g["routes"]):
+        assert np.array_equal(oracle.roulette_route(g["probmat"], u, 0), route)
+
+
+@pytest.mark.parametrize("name", names("g1_cvrp"))
+def test_cvrp_sampler_and_update(name):
+    g = load_golden(name)
+    P = oracle.prob_matrix(g["pheromone"], g["heuristic"])
+    paths, logp, L = oracle.cvrp_sample_noise(P, g["demand"], float(g["capacity"]), g["noise"])
+    assert L == g["paths"].shape[0]
+    assert np.array_equal(paths, g["paths"])
+    np.testing.assert_allclose(logp, g["log_probs"], atol=ATOL_LOGP, rtol=1e-5)
+    costs = oracle.tour_costs(g["distances"], paths, closed=False)
+    np.testing.assert_allclose(costs, g["costs"], rtol=RTOL_COST)
+    for key, el in (("pheromone_as", False), ("pheromone_elitist", True)):
+        out = oracle.pheromone_update_cvrp(g["pheromone"], paths, g["costs"], float(g["decay"]), el)
+        assert np.array_equal(out.view(np.uint32), g[key].view(np.uint32)), key
