@@ -1,0 +1,59 @@
+"""ctypes binding of libdeepaco_hip.so (include/deepaco_hip.h).  Fails loudly if absent."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must be loaded first: libdeepaco_hip.so then binds to the HIP runtime
+#                              (libamdhip64.so.7) torch already mapped, so streams/pointers are shared
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdeepaco_hip.so")
+
+RACE_NOISE, RACE_PHILOX, SCAN = 0, 1, 2
+MAX_NODES = 4096
+
+_lib = None
+
+_vp, _i, _l, _f, _u64, _u32, _sz = (C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64, C.c_uint32,
+                                     C.c_size_t)
+
+# name -> (restype, argtypes); must list every symbol include/deepaco_hip.h declares
+SIGNATURES = {
+    "daco_version": (_i, []),
+    "daco_last_error": (C.c_char_p, []),
+    "daco_vec_for_n": (_i, [_i]),
+    "daco_ld_for_n": (_i, [_i]),
+    "daco_tsp_sample_workspace_bytes": (_sz, [_i, _i, _i]),
+    "daco_tsp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _i, _vp, _i, _vp, _u64, _u64,
+                             _u32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "daco_tour_costs": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp]),
+    "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "daco_pheromone_update": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _f, _vp, _sz]),
+}
+
+
+class DacoError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DacoError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(make -C deepaco_amd/csrc, or __graft_entry__.build()). deepaco_amd has no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().daco_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise ValueError(f"{what}: {msg}")
+        raise DacoError(f"{what} failed (code {rc}): {msg}")

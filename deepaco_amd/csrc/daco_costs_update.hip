@@ -1,0 +1,175 @@
+// daco_costs_update.hip -- tour costs and the fused evaporate + deposit + clamp kernel.
+//
+// Reference behaviour replaced: ACO.gen_path_costs (tsp/aco.py:121-132, cvrp/aco.py:133-136)
+// and ACO.update_pheronome (tsp/aco.py:95-118, cvrp/aco.py:107-130).
+//
+// The reference deposits with a sequential Python loop over ants, so the f32 result depends
+// on ant order.  Here every row i of tau is owned by one lane pair: lane 2r adds w_a to column
+// prev_a(i), lane 2r+1 to column next_a(i), for a = 0..A-1 in order, on a copy of the row
+// held in LDS.  Adds to one tau element therefore happen in ant order exactly as in the
+// reference, adds to different elements never interact, and no atomics are needed
+// (probe-verified bit-identical).  Evaporation is fused into the
+// LDS fill and the MMAS clamp / floor into the write-back, so tau makes one round trip.
+#include "daco_device.h"
+#include "../../include/deepaco_hip.h"
+
+namespace daco {
+
+__global__ void __launch_bounds__(256)
+tour_costs_kernel(int B, int n, int len, int A, const float *dist, long dist_bs, const int64_t *paths,
+                  int closed, float *costs) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * A) return;
+  const int b = idx / A, a = idx - b * A;
+  const int64_t *p = paths + (size_t)b * len * A + a;
+  const float *d = dist + b * dist_bs;
+  float s = 0.0f;
+  if (closed) {
+    long prev = p[(size_t)(len - 1) * A];
+    for (int k = 0; k < len; ++k) {
+      const long u = p[(size_t)k * A];
+      s = s + d[u * n + prev];
+      prev = u;
+    }
+  } else {
+    long u = p[0];
+    for (int k = 0; k + 1 < len; ++k) {
+      const long v = p[(size_t)(k + 1) * A];
+      s = s + d[u * n + v];
+      u = v;
+    }
+  }
+  costs[idx] = s;
+}
+
+// nbr[b][a][node] = prev(node) | next(node) << 16 along ant a's closed tour
+__global__ void __launch_bounds__(256)
+build_nbr_kernel(int B, int n, int A, const int64_t *paths, uint32_t *nbr) {
+  const long total = (long)B * n * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const long r = i / A;
+    const int k = (int)(r % n), b = (int)(r / n);
+    const int64_t *p = paths + (size_t)b * n * A + a;
+    const uint32_t u = (uint32_t)p[(size_t)k * A];
+    const uint32_t up = (uint32_t)p[(size_t)(k ? k - 1 : n - 1) * A];
+    const uint32_t un = (uint32_t)p[(size_t)(k + 1 < n ? k + 1 : 0) * A];
+    nbr[((size_t)b * A + a) * n + u] = up | (un << 16);
+  }
+}
+
+// first index of the minimum cost per instance (torch.min(dim=0) semantics)
+__global__ void __launch_bounds__(64) argmin_cost_kernel(int A, const float *costs, int *best) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float bk = __builtin_inff();
+  int bi = 0x7fffffff;
+  for (int a = lane; a < A; a += 64) {
+    const float c = costs[(size_t)b * A + a];
+    if (c < bk) { bk = c; bi = a; }
+  }
+  const KeyIdx r = wave_arg<false>(bk, bi);
+  if (lane == 0) best[b] = r.idx == 0x7fffffff ? 0 : r.idx;
+}
+
+__global__ void __launch_bounds__(256)
+deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, float decay,
+                   const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];
+  const int bpi = (n + R - 1) / R;
+  const int b = blockIdx.x / bpi;
+  const int i0 = (blockIdx.x - b * bpi) * R;
+  const int Rv = min(R, n - i0);
+  float *g = tau + ((size_t)b * n + i0) * n;
+  const int cnt = Rv * n;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) rows[i] = g[i] * decay;
+  __syncthreads();
+  const int r = threadIdx.x >> 1, role = threadIdx.x & 1;
+  if (r < Rv) {
+    const uint32_t *nb = nbr + (size_t)b * A * n + i0 + r;
+    const float *cs = costs + (size_t)b * A;
+    float *row = rows + r * n;
+    int alo = 0, ahi = A;
+    if (best) { alo = best[b]; ahi = alo + 1; }
+#pragma unroll 4
+    for (int a = alo; a < ahi; ++a) {
+      const uint32_t v = nb[(size_t)a * n];
+      const int col = role ? (int)(v >> 16) : (int)(v & 0xFFFFu);
+      const float w = 1.0f / cs[a];
+      row[col] = row[col] + w;
+    }
+  }
+  __syncthreads();
+  const bool clamp = clamp_max != nullptr;
+  const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    float x = rows[i];
+    if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
+    if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
+    g[i] = x;
+  }
+}
+
+}  // namespace daco
+
+using namespace daco;
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dist,
+                               long dist_bstride, const int64_t *paths, int closed, float *costs) {
+  if (B <= 0 || n <= 0 || len <= 0 || A <= 0 || !dist || !paths || !costs) {
+    set_error("daco_tour_costs: bad argument");
+    return DACO_E_BADARG;
+  }
+  const int total = B * A;
+  hipLaunchKernelGGL(tour_costs_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n,
+                     len, A, dist, dist_bstride, paths, closed, costs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("tour_costs_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A) {
+  if (B <= 0 || n <= 0 || A <= 0) return 0;
+  (void)len;
+  return align256((size_t)B * A * n * sizeof(uint32_t)) + align256((size_t)B * sizeof(int));
+}
+
+static int rows_per_block(int n) {
+  int R = (64 * 1024) / (4 * n);      // keep the LDS image <= 64 KiB: two workgroups per CU
+  if (R > 32) R = 32;                  // 2 lanes per row, chain runs in one wave
+  return R;
+}
+
+extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
+                                     const int64_t *paths, const float *costs, float decay, int elitist,
+                                     int symmetric, const float *clamp_min, const float *clamp_max,
+                                     float floor_val, void *workspace, size_t workspace_bytes) {
+  if (B <= 0 || n < 3 || A <= 0 || !tau || !paths || !costs || !workspace) {
+    set_error("daco_pheromone_update: bad argument (B=%d n=%d A=%d)", B, n, A);
+    return DACO_E_BADARG;
+  }
+  if ((clamp_min == nullptr) != (clamp_max == nullptr)) { set_error("daco_pheromone_update: clamp_min/clamp_max must both be given"); return DACO_E_BADARG; }
+  if (n > DACO_MAX_NODES) { set_error("daco_pheromone_update: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
+  if (!symmetric) { set_error("daco_pheromone_update: directed (CVRP) deposit not built yet"); return DACO_E_BADARG; }
+  if (len != n) { set_error("daco_pheromone_update: symmetric deposit needs len == n"); return DACO_E_BADARG; }
+  const size_t need = daco_pheromone_update_workspace_bytes(B, n, len, A);
+  if (workspace_bytes < need) { set_error("daco_pheromone_update: workspace %zu < %zu", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *nbr = (uint32_t *)workspace;
+  int *best = (int *)((char *)workspace + align256((size_t)B * A * n * sizeof(uint32_t)));
+  {
+    const long total = (long)B * n * A;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(build_nbr_kernel, dim3(blocks), dim3(256), 0, s, B, n, A, paths, nbr);
+  }
+  if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
+  const int R = rows_per_block(n);
+  const int bpi = (n + R - 1) / R;
+  hipLaunchKernelGGL(deposit_tsp_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, tau,
+                     nbr, costs, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("pheromone update launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}

@@ -1,0 +1,346 @@
+// daco_tsp_sample.hip -- tour construction (ACO.gen_path / pick_move) for gfx950.
+//
+// Reference behaviour replaced: tsp/aco.py:134-177, tsp_nls/aco.py:184-220 (torch path) and,
+// for the prefix-scan mode, the roulette sampler tsp_nls/aco.py:260-275.
+//
+// Design: one wavefront per (instance, ant) for the whole tour -- the
+// n-1 dependent draws never leave the wave.  Each step streams ONE padded row of the fused
+// transition matrix P = tau^alpha * eta^beta (built once per call by prob_matrix_kernel, so
+// the per-step traffic is 4*ld bytes instead of the reference's 8n) with 16-byte loads, lane
+// l owning candidates (c*64+l)*VEC+v.  The visited set is a per-lane 64-bit register bitset;
+// the draw is a DPP reduction / prefix scan; nothing is staged through LDS because no lane
+// consumes another lane's candidates.  Workgroups are remapped so each XCD walks whole
+// instances (rows stay in its private L2).
+#include "daco_device.h"
+#include "../../include/deepaco_hip.h"
+
+namespace daco {
+
+struct SampleParams {
+  int B, n, A, ld, CH;
+  const float *P;      // [B][n][ld] fused transition weights (0 in padding)
+  const float *R;      // [B][n][ld] 1/P (+inf in padding) -- RACE_PHILOX only
+  int norm_passes;
+  const int64_t *start;  // [B][A] or null
+  int fixed_start;
+  const float *noise;    // [B][n-1][A][n] RACE_NOISE
+  uint64_t seed, iter;
+  uint32_t ant_gid0;
+  int64_t *paths;        // [B][n][A]
+  float *logp;           // [B][n-1][A] or null
+  float *rowsum;         // [B][n-1][A] or null
+  int32_t *flags;        // [B] or null
+};
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { float v[1]; };
+template <> struct Vec<2> { float v[2]; };
+template <> struct Vec<4> { float v[4]; };
+
+template <int VEC>
+__device__ inline void load_vec(const float *p, float (&out)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    out[0] = t.x; out[1] = t.y;
+  } else {
+    out[0] = *p;
+  }
+}
+
+// P = tau^alpha * eta^beta with zero padding; R = 1/P with +inf padding (optional)
+__global__ void __launch_bounds__(256)
+prob_matrix_kernel(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs,
+                   float alpha, float beta, float *P, float *R) {
+  const long total = (long)B * n * ld;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % ld);
+    const long row = i / ld;            // b*n + r
+    const int b = (int)(row / n), r = (int)(row % n);
+    float p = 0.0f;
+    if (k < n) {
+      const float t = tau[b * tau_bs + (long)r * n + k];
+      const float e = eta[b * eta_bs + (long)r * n + k];
+      p = pw(t, alpha) * pw(e, beta);
+    }
+    P[i] = p;
+    if (R) R[i] = k < n ? 1.0f / p : __builtin_inff();
+  }
+}
+
+template <int VEC, int MAXCH, int MODE, bool LOGP>
+__global__ void __launch_bounds__(256)
+tsp_sample_kernel(const SampleParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bpi = (p.A + 3) >> 2;                       // workgroups per instance (4 ants each)
+  const int b = w / bpi;
+  const int a = (w - b * bpi) * 4 + wave;
+  if (a >= p.A) return;                                 // no barriers below: safe
+  const int n = p.n, A = p.A, ld = p.ld, CH = p.CH;
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const float *Pb = p.P + (size_t)b * n * ld + lane * VEC;
+  const float *Rb = (MODE == DACO_RACE_PHILOX) ? p.R + (size_t)b * n * ld + lane * VEC : nullptr;
+  int64_t *path_out = p.paths + (size_t)b * n * A + a;
+  float *logp_out = LOGP ? p.logp + (size_t)b * (n - 1) * A + a : nullptr;
+  float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (n - 1) * A + a : nullptr;
+
+  // ---- start node
+  int prev;
+  if (p.start) prev = (int)p.start[(size_t)b * A + a];
+  else if (p.fixed_start >= 0) prev = p.fixed_start;
+  else {
+    const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0);
+    prev = (int)__umulhi(r.x, (uint32_t)n);
+  }
+  prev = __builtin_amdgcn_readfirstlane(prev);
+
+  uint64_t vis = 0;                                     // bit (c*VEC+v): candidate visited
+  auto mark = [&](int k) {
+    const int vi = k / VEC;
+    if (lane == (vi & 63)) vis |= 1ull << ((vi >> 6) * VEC + (k % VEC));
+  };
+  mark(prev);
+  if (lane == 0) path_out[0] = prev;
+
+  u32x4 ublk = {0, 0, 0, 0};                            // SCAN: 256 cached uniforms per wave
+  int ublk_base = -1;
+  bool infeasible = false;
+
+  for (int t = 1; t < n; ++t) {
+    // ---- stream the row of `prev`
+    float row[MAXCH][VEC];
+    const float *rp = (MODE == DACO_RACE_PHILOX ? Rb : Pb) + (size_t)prev * ld;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c)
+      if (c < CH) load_vec<VEC>(rp + c * 64 * VEC, row[c]);
+
+    int choice;
+    float pchoice = 0.0f, S = 0.0f;
+
+    if constexpr (MODE == DACO_SCAN) {
+      float part = 0.0f;
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c)
+        if (c < CH) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            row[c][v] = ((vis >> (c * VEC + v)) & 1) ? 0.0f : row[c][v];
+            part = part + row[c][v];
+          }
+        }
+      const float incl = wave_scan_add(part);
+      S = readlane_f(incl, 63);
+      // one uniform per step, refilled 256 at a time (lane l holds Philox block base+l)
+      const int blk = t >> 2;
+      if ((blk >> 6) != ublk_base) {
+        ublk_base = blk >> 6;
+        ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)((ublk_base << 6) + lane));
+      }
+      const uint32_t ux = readlane_i((int)comp(ublk, t & 3), blk & 63);
+      const float r = u01(ux) * S;
+      const uint64_t m = __ballot(incl >= r && part > 0.0f);
+      if (m == 0) { infeasible = true; choice = 0; }
+      else {
+        const int L = __builtin_ctzll(m);
+        const float excl = L ? readlane_f(incl, L - 1) : 0.0f;
+        float run = excl;
+        int best = -1, last = -1;
+        float pbest = 0.0f, plast = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+          if (c < CH) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              const float x = row[c][v];
+              if (x > 0.0f) {
+                run = run + x;
+                const int k = (c * 64 + lane) * VEC + v;
+                last = k; plast = x;
+                if (best < 0 && run >= r) { best = k; pbest = x; }
+              }
+            }
+          }
+        if (best < 0) { best = last; pbest = plast; }
+        choice = readlane_i(best, L);
+        pchoice = readlane_f(pbest, L);
+      }
+    } else if constexpr (MODE == DACO_RACE_PHILOX) {
+      float bk = __builtin_inff();
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c)
+        if (c < CH) {
+          const int k0 = (c * 64 + lane) * VEC;
+          const u32x4 r4 = rng_block(p.seed, p.iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k0 >> 2));
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const int k = k0 + v;
+            const float L = neg_log2_1m(u01(comp(r4, k & 3)));
+            const float key = ((vis >> (c * VEC + v)) & 1) ? __builtin_inff() : L * row[c][v];
+            if (key < bk) { bk = key; bi = k; }
+          }
+        }
+      const KeyIdx r = wave_arg<false>(bk, bi);
+      if (!(r.key < __builtin_inff())) { infeasible = true; choice = 0; }
+      else choice = r.idx;
+      if constexpr (LOGP) {
+        // S over unvisited P (second matrix), p of the chosen candidate
+        const float *pp = Pb + (size_t)prev * ld;
+        float part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+          if (c < CH) {
+            float pr[VEC];
+            load_vec<VEC>(pp + c * 64 * VEC, pr);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) part = part + (((vis >> (c * VEC + v)) & 1) ? 0.0f : pr[v]);
+          }
+        S = wave_sum(part);
+        pchoice = p.P[((size_t)b * n + prev) * ld + choice];
+      }
+    } else {  // DACO_RACE_NOISE: the arithmetic of torch.multinomial's one-sample path
+      const float *q = p.noise + (((size_t)b * (n - 1) + (t - 1)) * A + a) * n;
+      float part = 0.0f;
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c)
+        if (c < CH) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            row[c][v] = ((vis >> (c * VEC + v)) & 1) ? 0.0f : row[c][v];
+            part = part + row[c][v];
+          }
+        }
+      for (int pass = 0; pass < p.norm_passes; ++pass) {
+        S = wave_sum(part);
+        part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+          if (c < CH) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              row[c][v] = row[c][v] / S;
+              part = part + row[c][v];
+            }
+          }
+      }
+      float bk = -__builtin_inff(), bp = 0.0f;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c)
+        if (c < CH) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const int k = (c * 64 + lane) * VEC + v;
+            if (k < n) {
+              const float key = row[c][v] / q[k];
+              if (key > bk) { bk = key; bi = k; bp = row[c][v]; }
+            }
+          }
+        }
+      const KeyIdx r = wave_arg<true>(bk, bi);
+      if (!(r.key > 0.0f)) infeasible = true;
+      choice = r.idx == 0x7fffffff ? 0 : r.idx;
+      if constexpr (LOGP) {
+        // lane owning the winner broadcasts its (normalised) p
+        const int own = (choice / VEC) & 63;
+        pchoice = readlane_f(bp, own);
+        if (p.norm_passes == 0) S = wave_sum(part); else { S = 1.0f; }
+      }
+    }
+
+    choice = __builtin_amdgcn_readfirstlane(choice);
+    if constexpr (LOGP) {
+      if (lane == 0) {
+        const float pr = (MODE == DACO_RACE_NOISE && p.norm_passes > 0) ? pchoice : pchoice / S;
+        logp_out[(size_t)(t - 1) * A] = clamp_log(pr);
+        if (rs_out) rs_out[(size_t)(t - 1) * A] = S;
+      }
+    }
+    mark(choice);
+    if (lane == 0) path_out[(size_t)t * A] = choice;
+    prev = choice;
+  }
+  if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+}
+
+// ------------------------------------------------------------------ host dispatch
+template <int VEC, int MAXCH>
+static hipError_t launch_sample(const SampleParams &sp, int mode, bool logp, hipStream_t s) {
+  const int bpi = (sp.A + 3) / 4;
+  dim3 grid((unsigned)(sp.B * bpi)), block(256);
+#define DACO_LAUNCH(M, L) hipLaunchKernelGGL((tsp_sample_kernel<VEC, MAXCH, M, L>), grid, block, 0, s, sp)
+  if (mode == DACO_SCAN) { if (logp) DACO_LAUNCH(DACO_SCAN, true); else DACO_LAUNCH(DACO_SCAN, false); }
+  else if (mode == DACO_RACE_PHILOX) { if (logp) DACO_LAUNCH(DACO_RACE_PHILOX, true); else DACO_LAUNCH(DACO_RACE_PHILOX, false); }
+  else { if (logp) DACO_LAUNCH(DACO_RACE_NOISE, true); else DACO_LAUNCH(DACO_RACE_NOISE, false); }
+#undef DACO_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace daco
+
+using namespace daco;
+
+extern "C" int daco_vec_for_n(int n) { return vec_for_n(n); }
+extern "C" int daco_ld_for_n(int n) { return ld_for_n(n); }
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t daco_tsp_sample_workspace_bytes(int B, int n, int mode) {
+  if (B <= 0 || n <= 0) return 0;
+  const size_t mat = align256((size_t)B * n * ld_for_n(n) * sizeof(float));
+  return mode == DACO_RACE_PHILOX ? 2 * mat : mat;
+}
+
+extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *tau, long tau_bstride,
+                               const float *eta, long eta_bstride, float alpha, float beta, int mode,
+                               int norm_passes, const int64_t *start, int fixed_start,
+                               const float *noise, uint64_t seed, uint64_t iter, uint32_t ant_gid0,
+                               int64_t *paths, float *logp, float *rowsum, int32_t *flags,
+                               void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end) {
+  if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !paths || !workspace) {
+    set_error("daco_tsp_sample: bad argument (B=%d n=%d A=%d tau=%p eta=%p paths=%p ws=%p)", B, n, A,
+              (const void *)tau, (const void *)eta, (void *)paths, workspace);
+    return DACO_E_BADARG;
+  }
+  if (n > DACO_MAX_NODES) { set_error("daco_tsp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
+  if (mode < 0 || mode > 2 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
+  if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
+  if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
+  const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
+  if (workspace_bytes < need) { set_error("daco_tsp_sample: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int ld = ld_for_n(n), vec = vec_for_n(n), CH = ld / (64 * vec);
+  float *P = (float *)workspace;
+  float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
+  {
+    const long total = (long)B * n * ld;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta,
+                       eta_bstride, alpha, beta, P, R);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("prob_matrix_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  }
+  SampleParams sp;
+  sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
+  sp.P = P; sp.R = R; sp.norm_passes = norm_passes; sp.start = start; sp.fixed_start = fixed_start;
+  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
+  sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
+  const bool lp = logp != nullptr;
+  hipError_t e;
+  if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
+  if (vec == 1) e = launch_sample<1, 1>(sp, mode, lp, s);
+  else if (vec == 2) e = launch_sample<2, 1>(sp, mode, lp, s);
+  else if (CH <= 1) e = launch_sample<4, 1>(sp, mode, lp, s);
+  else if (CH <= 2) e = launch_sample<4, 2>(sp, mode, lp, s);
+  else if (CH <= 4) e = launch_sample<4, 4>(sp, mode, lp, s);
+  else if (CH <= 8) e = launch_sample<4, 8>(sp, mode, lp, s);
+  else e = launch_sample<4, 16>(sp, mode, lp, s);
+  if (e != hipSuccess) { set_error("tsp_sample_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
+  return DACO_OK;
+}

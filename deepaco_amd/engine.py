@@ -1,0 +1,199 @@
+"""Batched functional layer over the C ABI: B instances x A ants per call.
+
+Every function takes torch tensors that live on a HIP device, enqueues the kernels on the
+current torch stream and returns torch tensors; nothing here synchronises with the host.
+Layouts follow the reference with a leading batch dimension:
+paths [B, n, A] int64, log_probs [B, n-1, A] f32, costs [B, A] f32.
+"""
+import torch
+
+from . import _lib
+from ._lib import RACE_NOISE, RACE_PHILOX, SCAN  # noqa: F401
+
+MODES = {"race_noise": RACE_NOISE, "race": RACE_PHILOX, "scan": SCAN}
+
+_workspaces = {}
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.DacoError(
+                "deepaco_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU fallback")
+
+
+def _workspace(device, nbytes, tag):
+    """Per (device, stream, tag) scratch buffer, grown on demand (owned by the caller side of the ABI)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def _bstride(t, n):
+    """(tensor, element stride between instances) for a [n,n] (shared) or [B,n,n] matrix."""
+    t = _f32c(t)
+    return (t, 0) if t.dim() == 2 else (t, n * n)
+
+
+def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1, start=None,
+               fixed_start=-1, noise=None, seed=0, it=0, ant_gid0=0, require_prob=False, batch=None,
+               events=None):
+    """ACO.gen_path for a batch (tsp/aco.py:134-177, tsp_nls/aco.py:184-220).
+
+    tau, eta: [B,n,n] or [n,n] (shared).  Returns (paths, log_probs|None, rowsum|None, flags).
+    events: optional (begin, end) torch.cuda.Event pair (already recorded once, so the handles
+    exist) re-recorded around the tour-construction kernel only."""
+    _require_gpu(tau, eta, start, noise)
+    n = tau.shape[-1]
+    B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
+    dev = tau.device
+    tau, tbs = _bstride(tau, n)
+    eta, ebs = _bstride(eta, n)
+    m = MODES[mode] if isinstance(mode, str) else int(mode)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        paths = torch.empty((B, n, n_ants), dtype=torch.int64, device=dev)
+        logp = torch.empty((B, n - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
+        rowsum = torch.empty((B, n - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
+        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if start is not None:
+            start = start.to(torch.int64).contiguous().view(B, n_ants)
+        if noise is not None:
+            noise = _f32c(noise).view(B, n - 1, n_ants, n)
+        nbytes = L.daco_tsp_sample_workspace_bytes(B, n, m)
+        ws = _workspace(dev, nbytes, "sample")
+        rc = L.daco_tsp_sample(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs,
+                               float(alpha), float(beta), m, int(norm_passes),
+                               start.data_ptr() if start is not None else None, int(fixed_start),
+                               noise.data_ptr() if noise is not None else None,
+                               int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF,
+                               paths.data_ptr(), logp.data_ptr() if require_prob else None,
+                               rowsum.data_ptr() if require_prob else None, flags.data_ptr(),
+                               ws.data_ptr(), ws.numel(),
+                               events[0].cuda_event if events else None,
+                               events[1].cuda_event if events else None)
+    _lib.check(rc, "daco_tsp_sample")
+    return paths, logp, rowsum, flags
+
+
+def tour_costs(dist, paths, closed=True):
+    """ACO.gen_path_costs for a batch (tsp/aco.py:121-132; closed=False: cvrp/aco.py:133-136)."""
+    _require_gpu(dist, paths)
+    n = dist.shape[-1]
+    B, length, A = paths.shape
+    dist, dbs = _bstride(dist, n)
+    paths = paths.contiguous()
+    dev = paths.device
+    with torch.cuda.device(dev):
+        costs = torch.empty((B, A), dtype=torch.float32, device=dev)
+        rc = _lib.lib().daco_tour_costs(_stream(dev), B, n, length, A, dist.data_ptr(), dbs, paths.data_ptr(),
+                                        int(closed), costs.data_ptr())
+    _lib.check(rc, "daco_tour_costs")
+    return costs
+
+
+def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, clamp_min=None,
+                      clamp_max=None, floor=0.0):
+    """In-place ACO.update_pheronome for a batch (tsp/aco.py:95-118, cvrp/aco.py:107-130).
+
+    tau [B,n,n] f32 contiguous (modified in place); clamp_min/clamp_max: [B] f32 tensors or None."""
+    _require_gpu(tau, paths, costs, clamp_min, clamp_max)
+    assert tau.dim() == 3 and tau.dtype == torch.float32 and tau.is_contiguous()
+    B, n, _ = tau.shape
+    _, length, A = paths.shape
+    paths = paths.contiguous()
+    costs = _f32c(costs)
+    dev = tau.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        nbytes = L.daco_pheromone_update_workspace_bytes(B, n, length, A)
+        ws = _workspace(dev, nbytes, "update")
+        rc = L.daco_pheromone_update(_stream(dev), B, n, length, A, tau.data_ptr(), paths.data_ptr(),
+                                     costs.data_ptr(), float(decay), int(bool(elitist)), int(bool(symmetric)),
+                                     clamp_min.data_ptr() if clamp_min is not None else None,
+                                     clamp_max.data_ptr() if clamp_max is not None else None,
+                                     float(floor), ws.data_ptr(), ws.numel())
+    _lib.check(rc, "daco_pheromone_update")
+    return tau
+
+
+class BatchedTSP:
+    """B independent TSP colonies advanced in lock-step on one GPU (the throughput path).
+
+    Semantics per instance are those of tsp/aco.py ACO.run (AS / elitist / MMAS); best-so-far
+    tracking is done on the device, so an iteration never synchronises with the host."""
+
+    def __init__(self, distances, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
+                 pheromone=None, heuristic=None, min=None, sampler="scan", seed=None, ant_gid0=0,
+                 fixed_start=-1):
+        _require_gpu(distances)
+        assert distances.dim() == 3
+        self.distances = _f32c(distances)
+        self.B, self.n = distances.shape[0], distances.shape[1]
+        self.n_ants, self.decay, self.alpha, self.beta = n_ants, decay, alpha, beta
+        self.elitist, self.min_max = elitist, min_max
+        dev = distances.device
+        if min_max:
+            self.min = 0.1 if min is None else min
+            assert self.min > 1e-9
+            self.max = None
+        self.pheromone = torch.ones_like(self.distances) if pheromone is None else _f32c(pheromone).clone()
+        if min_max and pheromone is None:
+            self.pheromone = self.pheromone * self.min
+        self.heuristic = (1 / self.distances) if heuristic is None else heuristic
+        self.lowest_cost = torch.full((self.B,), float("inf"), device=dev)
+        self.shortest_path = torch.zeros((self.B, self.n), dtype=torch.int64, device=dev)
+        self.sampler = sampler
+        self.seed = torch.initial_seed() if seed is None else seed
+        self.iteration = 0
+        self.ant_gid0 = ant_gid0
+        self.fixed_start = fixed_start
+
+    @torch.no_grad()
+    def sparsify(self, k_sparse):
+        """tsp/aco.py:52-67 for a batch: 1/dist on each node's k nearest edges, 1e-10 elsewhere."""
+        _, idx = torch.topk(self.distances, k=k_sparse, dim=2, largest=False)
+        sparse = torch.full_like(self.distances, 1e10)
+        sparse.scatter_(2, idx, torch.gather(self.distances, 2, idx))
+        self.heuristic = 1 / sparse
+
+    @torch.no_grad()
+    def step(self, events=None):
+        paths, _, _, _ = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha, self.beta,
+                                    mode=self.sampler, seed=self.seed, it=self.iteration,
+                                    ant_gid0=self.ant_gid0, fixed_start=self.fixed_start, batch=self.B,
+                                    events=events)
+        self.iteration += 1
+        costs = tour_costs(self.distances, paths)
+        best_cost, best_idx = costs.min(dim=1)
+        improved = best_cost < self.lowest_cost
+        best_path = torch.gather(paths, 2, best_idx.view(self.B, 1, 1).expand(self.B, self.n, 1)).squeeze(2)
+        self.shortest_path = torch.where(improved.unsqueeze(1), best_path, self.shortest_path)
+        self.lowest_cost = torch.where(improved, best_cost, self.lowest_cost)
+        cmin = cmax = None
+        if self.min_max:
+            new_max = self.lowest_cost.reciprocal() * self.n          # n / lowest_cost (rtruediv)
+            if self.max is None:
+                self.pheromone *= (new_max / self.pheromone.amax(dim=(1, 2))).view(self.B, 1, 1)
+            self.max = new_max
+            cmin = torch.full_like(new_max, self.min)
+            cmax = new_max.contiguous()
+        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax)
+        return paths, costs
+
+    @torch.no_grad()
+    def run(self, n_iterations):
+        for _ in range(n_iterations):
+            self.step()
+        return self.lowest_cost

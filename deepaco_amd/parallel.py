@@ -1,0 +1,95 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm).
+
+The rollout path shards two ways:
+
+* instance-sharded (primary): colonies are independent, each rank owns B/N instances and its own
+  pheromone; there is NO data-path collective -- only a final gather of the [B] best costs.
+* ant-sharded: every rank runs A/N ants of the SAME instances with a replicated pheromone; each
+  iteration the ranks' deposits (delta-tau, [B, n, n] f32) are summed with ONE all-reduce and
+  every rank applies tau <- decay*tau + delta.  The sum order across ranks differs from the
+  single-GPU ant order, so pheromone agrees to ~1e-6 relative, not bitwise.
+
+Everything here is host logic over torch.distributed and is exercised on CPU with the gloo
+backend (tests/test_parallel_gloo.py); the kernels are injected as callables.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous, balanced [lo, hi) slice of `total` items for `rank` (first ranks get the extra)."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def barrier_max_time(fn, device, distributed):
+    """Time fn() bracketed by barrier + device sync on both sides; return the MAX over ranks (s)."""
+    def fence():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if distributed:
+            dist.barrier()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+    fence()
+    t0 = time.perf_counter()
+    fn()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+    return dt
+
+
+def gather_best(lowest_cost, total, rank, world):
+    """Instance-sharded epilogue: all ranks' per-instance best costs -> one [total] tensor (all ranks)."""
+    if world == 1:
+        return lowest_cost
+    q = -(-total // world)
+    pad = torch.full((q,), float("inf"), dtype=lowest_cost.dtype, device=lowest_cost.device)
+    pad[: lowest_cost.numel()] = lowest_cost
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        parts.append(out[r][: hi - lo])
+    return torch.cat(parts)
+
+
+class AntShardedColony:
+    """Ant-sharded AS colony: replicated pheromone, local deposits summed by one all-reduce.
+
+    sample_fn(tau, ant_gid0, n_local, it) -> paths [B, n, A_local]
+    cost_fn(paths) -> costs [B, A_local]
+    deposit_fn(zeros_like_tau, paths, costs) -> delta (deposit with decay = 1 onto zeros, in place)
+    The callables are the engine's kernels on a GPU and plain torch on CPU in the gloo tests."""
+
+    def __init__(self, tau, n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn):
+        self.tau = tau
+        self.n_ants, self.decay, self.rank, self.world = n_ants, decay, rank, world
+        self.lo, self.hi = shard_range(n_ants, rank, world)
+        self.sample_fn, self.cost_fn, self.deposit_fn = sample_fn, cost_fn, deposit_fn
+        self.lowest_cost = torch.full((tau.shape[0],), float("inf"), device=tau.device)
+        self.iteration = 0
+
+    @torch.no_grad()
+    def step(self):
+        paths = self.sample_fn(self.tau, self.lo, self.hi - self.lo, self.iteration)
+        costs = self.cost_fn(paths)
+        delta = self.deposit_fn(torch.zeros_like(self.tau), paths, costs)
+        best = costs.min(dim=1).values
+        if self.world > 1:
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the one data-path collective
+            dist.all_reduce(best, op=dist.ReduceOp.MIN)
+        self.tau = self.tau * self.decay + delta
+        self.lowest_cost = torch.minimum(self.lowest_cost, best)
+        self.iteration += 1
+        return paths, costs

@@ -1,0 +1,189 @@
+"""ACO for TSP with the class surface of the reference's tsp/aco.py, running on MI355X.
+
+Import it either as `from deepaco_amd.tsp.aco import ACO` or, like the reference's scripts
+do (tsp/train.ipynb:14-16 `from aco import ACO`), by putting this directory on sys.path.
+
+Constructor arguments, method names (including the reference's spelling `update_pheronome`),
+return layouts and attributes follow tsp/aco.py:4-177.  What differs is underneath: tour
+construction, costing and the pheromone update are single launches of hand-written HIP
+kernels (libdeepaco_hip.so) instead of ~20 aten ops per step.  Extra keyword-only arguments:
+
+  sampler  'scan' (default): roulette draw by wavefront prefix scan, one Philox uniform per step
+           'race': the exponential race torch.multinomial runs, noise from Philox in-kernel
+  seed     Philox key (default: torch.initial_seed(), so torch.manual_seed() governs the run)
+
+Both samplers draw from exactly the reference's categorical distribution
+p_k ~ tau^alpha * eta^beta * mask.  For bit-exact comparison with the reference pass the
+reference's own noise: gen_path(..., _start=start, _noise=q) with q of shape [n-1, A, n].
+"""
+import os
+import sys
+
+import torch
+
+try:
+    from deepaco_amd import engine
+except ImportError:  # imported as a bare module from this directory, like the reference's layout
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd import engine
+
+
+class ACO():
+
+    NORM_PASSES = 1      # Categorical(dist) normalises once (tsp/aco.py:174)
+    FIXED_START = -1     # random start node per ant (tsp/aco.py:141)
+
+    def __init__(self,
+                 distances,
+                 n_ants=20,
+                 decay=0.9,
+                 alpha=1,
+                 beta=1,
+                 elitist=False,
+                 min_max=False,
+                 pheromone=None,
+                 heuristic=None,
+                 min=None,
+                 device='cpu',
+                 *,
+                 sampler='scan',
+                 seed=None,
+                 ):
+        if not distances.is_cuda:
+            raise engine._lib.DacoError(
+                "deepaco_amd.ACO needs `distances` on a HIP device (e.g. device='cuda:0'); "
+                "there is no CPU path in this package")
+        self.problem_size = len(distances)
+        self.distances = distances
+        self.n_ants = n_ants
+        self.decay = decay
+        self.alpha = alpha
+        self.beta = beta
+        self.elitist = elitist
+        self.min_max = min_max
+
+        if min_max:
+            if min is not None:
+                assert min > 1e-9
+            else:
+                min = 0.1
+            self.min = min
+            self.max = None
+
+        if pheromone is None:
+            self.pheromone = torch.ones_like(self.distances)
+            if min_max:
+                self.pheromone = self.pheromone * self.min
+        else:
+            self.pheromone = pheromone
+
+        self.heuristic = 1 / distances if heuristic is None else heuristic
+
+        self.shortest_path = None
+        self.lowest_cost = float('inf')
+
+        self.device = distances.device
+        self.sampler = sampler
+        self.seed = torch.initial_seed() if seed is None else seed
+        self._calls = 0
+
+    # ------------------------------------------------------------------ tsp/aco.py:52-67
+    @torch.no_grad()
+    def sparsify(self, k_sparse):
+        '''Heuristic = 1/dist on each node's k nearest neighbours, 1e-10 elsewhere
+        (vanilla-ACO baseline).'''
+        _, topk_indices = torch.topk(self.distances, k=k_sparse, dim=1, largest=False)
+        sparse_distances = torch.full_like(self.distances, 1e10)
+        sparse_distances.scatter_(1, topk_indices, torch.gather(self.distances, 1, topk_indices))
+        self.heuristic = 1 / sparse_distances
+
+    # ------------------------------------------------------------------ tsp/aco.py:69-72
+    def sample(self):
+        paths, log_probs = self.gen_path(require_prob=True)
+        costs = self.gen_path_costs(paths)
+        return costs, log_probs
+
+    # ------------------------------------------------------------------ tsp/aco.py:75-92
+    @torch.no_grad()
+    def run(self, n_iterations):
+        for _ in range(n_iterations):
+            paths = self.gen_path(require_prob=False)
+            costs = self.gen_path_costs(paths)
+
+            best_cost, best_idx = costs.min(dim=0)
+            if best_cost < self.lowest_cost:
+                self.shortest_path = paths[:, best_idx]
+                self.lowest_cost = best_cost
+                if self.min_max:
+                    max = self.problem_size / self.lowest_cost
+                    if self.max is None:
+                        self.pheromone *= max / self.pheromone.max()
+                    self.max = max
+
+            self.update_pheronome(paths, costs)
+
+        return self.lowest_cost
+
+    # ------------------------------------------------------------------ tsp/aco.py:95-118
+    @torch.no_grad()
+    def update_pheronome(self, paths, costs):
+        '''
+        Args:
+            paths: torch tensor with shape (problem_size, n_ants)
+            costs: torch tensor with shape (n_ants,)
+        '''
+        tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+        cmin = cmax = None
+        if self.min_max:
+            cmin = torch.full((1,), float(self.min), device=tau.device)
+            cmax = torch.as_tensor(self.max, dtype=torch.float32, device=tau.device).reshape(1).contiguous()
+        engine.pheromone_update_(tau, paths.unsqueeze(0), costs.unsqueeze(0), self.decay, self.elitist, True,
+                                 cmin, cmax)
+        self.pheromone = tau[0]          # the reference rebinds too (tsp/aco.py:101)
+
+    update_pheromone = update_pheronome  # correctly spelled alias
+
+    # ------------------------------------------------------------------ tsp/aco.py:121-132
+    @torch.no_grad()
+    def gen_path_costs(self, paths):
+        '''
+        Args:
+            paths: torch tensor with shape (problem_size, n_ants)
+        Returns:
+            Lengths of paths: torch tensor with shape (n_ants,)
+        '''
+        assert paths.shape == (self.problem_size, self.n_ants)
+        return engine.tour_costs(self.distances, paths.unsqueeze(0))[0]
+
+    # ------------------------------------------------------------------ tsp/aco.py:134-177
+    def gen_path(self, require_prob=False, *, _start=None, _noise=None):
+        '''
+        Tour construction for all ants
+        Returns:
+            paths: torch tensor with shape (problem_size, n_ants), paths[:, i] is the tour of ant i
+            log_probs: torch tensor with shape (problem_size-1, n_ants) (only if require_prob)
+        '''
+        if _noise is not None:
+            mode, start = "race_noise", _start
+        else:
+            mode, start = self.sampler, _start
+        fixed = self.FIXED_START
+        if _noise is not None and start is None and fixed < 0:
+            raise ValueError("noise injection needs the start nodes too (_start)")
+        paths, logp, rowsum, flags = engine.tsp_sample(
+            self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha, self.beta, mode=mode,
+            norm_passes=self.NORM_PASSES, start=None if start is None else start.view(1, -1),
+            fixed_start=fixed, noise=None if _noise is None else _noise.unsqueeze(0),
+            seed=self.seed, it=self._calls, require_prob=require_prob, batch=1)
+        self._calls += 1
+        self._last_flags = flags
+        if require_prob:
+            return paths[0], logp[0]
+        return paths[0]
+
+    def check_feasible(self):
+        """Raise like torch.distributions.Categorical does when some draw had no candidate
+        (host sync; the kernels only set a flag)."""
+        if getattr(self, "_last_flags", None) is not None and bool(self._last_flags.any()):
+            raise ValueError("ACO.gen_path: a transition row had no feasible candidate "
+                             "(all probabilities zero)")

@@ -1,0 +1,131 @@
+/*
+ * deepaco_hip.h -- C ABI of libdeepaco_hip.so: DeepACO's ant-rollout hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference (henry-yeh/DeepACO) has no native boundary for
+ * this path: its ACO classes issue stock PyTorch ops.  Each entry point below replaces the
+ * body of one reference method and is bound from Python with ctypes and tensor.data_ptr(),
+ * the same mechanism the reference already uses for its one native dependency
+ * (cvrp_nls/swapstar.py:134-185 loads libhgscvrp.so with ctypes).  INTEGRATION.md shows the
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless stated; arrays are dense, row-major;
+ *  - B = instances in the batch (the reference always runs B = 1), n = nodes, A = ants;
+ *  - `stream` is a hipStream_t (void* here so the header needs no HIP include); all work is
+ *    enqueued on it and no entry point synchronises with the host;
+ *  - return value: 0 = ok, < 0 = error (see DACO_E_*); the message is in daco_last_error()
+ *    (thread-local).  No entry point ever falls back to a CPU path.
+ *  - the library keeps no global mutable state: entry points are re-entrant across streams
+ *    and devices; scratch memory is the caller's (size from the *_workspace_bytes queries).
+ */
+#ifndef DEEPACO_HIP_H
+#define DEEPACO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DACO_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define DACO_OK 0
+#define DACO_E_BADARG (-1)   /* null pointer, size out of range */
+#define DACO_E_TOOLARGE (-2) /* n exceeds what the kernel's register/LDS plan supports */
+#define DACO_E_HIP (-3)      /* a HIP runtime call failed */
+#define DACO_E_WORKSPACE (-4)/* workspace too small */
+
+/* sampler modes */
+#define DACO_RACE_NOISE 0  /* exponential race, noise read from memory (bit-exact parity mode) */
+#define DACO_RACE_PHILOX 1 /* exponential race, Philox4x32-10 noise generated in-kernel */
+#define DACO_SCAN 2        /* roulette / inverse-CDF by wavefront prefix scan, one uniform per step */
+
+/* limits */
+#define DACO_MAX_NODES 4096
+
+int daco_version(void);
+const char *daco_last_error(void);
+
+/* Layout helpers (the padded leading dimension the sampler uses internally; exported so the
+ * oracle-side tests can state the summation order). */
+int daco_vec_for_n(int n);
+int daco_ld_for_n(int n);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_tsp_sample -- replaces ACO.gen_path + ACO.pick_move
+ *   tsp/aco.py:134-177 (random start, Categorical normalises once -> norm_passes = 1)
+ *   tsp_nls/aco.py:184-220 (start 0, explicit renormalisation  -> norm_passes = 2)
+ *
+ * For every instance b and ant a builds a tour of n nodes: start node, then n-1 draws from
+ * p_k = tau[prev][k]^alpha * eta[prev][k]^beta * [k unvisited].
+ *
+ *   tau, eta   [B][n][n] f32.  tau_bstride / eta_bstride: element stride between instances
+ *              (n*n for dense batches, 0 to share one matrix across the batch).
+ *   mode       DACO_RACE_NOISE: action = argmax_k ((p_k/S)/q_k) with q = noise, exactly the
+ *              arithmetic of torch.multinomial's one-sample path (first maximum wins);
+ *              norm_passes in {0,1,2} = how many times p is divided by its row sum first.
+ *              DACO_RACE_PHILOX: the same race with q_k = -log2(1-u_k), u from Philox.
+ *              DACO_SCAN: r = u*S, first candidate (lane-major order) whose running sum >= r.
+ *   start      [B][A] int64 or NULL.  If NULL: fixed_start >= 0 -> every ant starts there,
+ *              fixed_start < 0 -> start = floor(n * u32 / 2^32) from the Philox stream.
+ *   noise      DACO_RACE_NOISE only: [B][n-1][A][n] f32 (the reference's q tensors, step-major).
+ *   seed, iter, ant_gid0   Philox key and counter words: ant (b,a) uses global ant id
+ *              ant_gid0 + b*A + a; `iter` must differ between calls that should be independent.
+ *   paths      out [B][n][A] int64  (reference layout: paths[:, i] is ant i's tour)
+ *   logp       out [B][n-1][A] f32 or NULL: log(clamp(p_chosen/S, eps, 1-eps)), eps = 2^-23
+ *   rowsum     out [B][n-1][A] f32 or NULL: S at each step (saved for daco_tsp_sample_backward)
+ *   flags      out [B] int32 or NULL: set to 1 if some draw had no feasible candidate
+ *              (the reference's Categorical raises ValueError there); caller zeroes it.
+ *   workspace  daco_tsp_sample_workspace_bytes(B, n, mode) bytes of device scratch.
+ *   ev_begin, ev_end   optional hipEvent_t pair (NULL to skip) recorded on `stream` immediately
+ *              before and after the tour-construction kernel itself (not the P = tau^a*eta^b
+ *              pre-pass), so a caller can time the dominant kernel without a profiler.
+ */
+size_t daco_tsp_sample_workspace_bytes(int B, int n, int mode);
+int daco_tsp_sample(void *stream, int B, int n, int A,
+                    const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                    float alpha, float beta, int mode, int norm_passes,
+                    const int64_t *start, int fixed_start, const float *noise,
+                    uint64_t seed, uint64_t iter, uint32_t ant_gid0,
+                    int64_t *paths, float *logp, float *rowsum, int32_t *flags,
+                    void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_tour_costs -- replaces ACO.gen_path_costs
+ *   closed = 1: sum_k dist[u_k][u_{k-1}] over the closed tour     (tsp/aco.py:121-132)
+ *   closed = 0: sum_{k < len-1} dist[u_k][u_{k+1}]                  (cvrp/aco.py:133-136)
+ * paths [B][len][A] int64, dist [B][n][n] (dist_bstride as above), costs out [B][A] f32.
+ * Summation is sequential in k from +0.0f (documented order; the reference's torch.sum order
+ * is unspecified and agreement with it is 1e-5 relative).
+ */
+int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dist,
+                    long dist_bstride, const int64_t *paths, int closed, float *costs);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_pheromone_update -- replaces ACO.update_pheronome
+ *   tsp/aco.py:95-118   (symmetric = 1: both directions of every tour edge, closed tour)
+ *   cvrp/aco.py:107-130 (symmetric = 0: directed path[k] -> path[k+1], k < len-1; duplicate
+ *                        index pairs of one ant collapse to a single add; floor applied)
+ * tau <- tau*decay, then for each ant in index order (elitist = 1: only the first-minimum-cost
+ * ant) w = 1/cost and every edge of its tour receives += w; then optional MMAS clamp
+ * (clamp_max > 0: tau < clamp_min -> clamp_min, tau > clamp_max -> clamp_max) and optional
+ * floor (floor_val > 0: tau < floor_val -> floor_val).  Bit-identical to the reference's
+ * sequential loop: each row of tau is owned by one lane-pair and receives its adds in ant
+ * order (no atomics).
+ *   tau   in/out [B][n][n] f32 (dense, stride n*n)
+ *   paths [B][len][A] int64, costs [B][A] f32
+ *   clamp_min/clamp_max: [B] f32 device arrays or NULL (per-instance MMAS bounds)
+ *   workspace: daco_pheromone_update_workspace_bytes(B, n, len, A)
+ */
+size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A);
+int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
+                          const int64_t *paths, const float *costs, float decay, int elitist,
+                          int symmetric, const float *clamp_min, const float *clamp_max,
+                          float floor_val, void *workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPACO_HIP_H */

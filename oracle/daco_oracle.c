@@ -30,11 +30,26 @@
 int orc_vec_for_n(int n) { return n > 128 ? 4 : (n > 64 ? 2 : 1); }
 int orc_ld_for_n(int n) { int w = 64 * orc_vec_for_n(n); return (n + w - 1) / w * w; }
 
-/* lane-partial sums (c ascending, v ascending, from +0.0f) followed by a 6-level butterfly
- * partial[l] += partial[l ^ off], off = 32,16,8,4,2,1.  All lanes end with the same value. */
+/* Inclusive scan over the 64 lanes in the order the hardware's DPP network offers
+ * (DESIGN 4.2): Kogge-Stone inside each row of 16 lanes (d = 1,2,4,8), then rows 1 and 3
+ * add the total of the row before them (lane 15 / 47), then lanes 32..63 add lane 31. */
+static void lane_scan(float x[64]) {
+  float t[64];
+  for (int d = 1; d < 16; d <<= 1) {
+    for (int l = 0; l < 64; ++l) t[l] = x[l] + ((l & 15) >= d ? x[l - d] : 0.0f);
+    memcpy(x, t, sizeof t);
+  }
+  for (int l = 0; l < 64; ++l) t[l] = x[l] + (((l >> 4) & 1) ? x[(l & ~15) - 1] : 0.0f);
+  memcpy(x, t, sizeof t);
+  for (int l = 0; l < 64; ++l) t[l] = x[l] + (l >= 32 ? x[31] : 0.0f);
+  memcpy(x, t, sizeof t);
+}
+
+/* row sum = lane-partial sums (c ascending, v ascending, from +0.0f), then lane 63 of the
+ * inclusive lane scan. */
 static float row_sum_tree(const float *p, int n) {
   int vec = orc_vec_for_n(n), ld = orc_ld_for_n(n), ch = ld / (64 * vec);
-  float part[64], tmp[64];
+  float part[64];
   for (int l = 0; l < 64; ++l) {
     float s = 0.0f;
     for (int c = 0; c < ch; ++c)
@@ -44,11 +59,8 @@ static float row_sum_tree(const float *p, int n) {
       }
     part[l] = s;
   }
-  for (int off = 32; off >= 1; off >>= 1) {
-    for (int l = 0; l < 64; ++l) tmp[l] = part[l] + part[l ^ off];
-    memcpy(part, tmp, sizeof part);
-  }
-  return part[0];
+  lane_scan(part);
+  return part[63];
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 (Salmon et al. 2011) */
@@ -216,7 +228,7 @@ int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t it
  * tsp_nls/aco.py:260-275 draws r = U * sum(prob*mask) and walks the row until the running
  * sum reaches r.  Here the walk is a wave-shaped scan with a defined order:
  *   part[l]  = lane-partial sum (c asc, v asc) of masked p
- *   incl     = Kogge-Stone inclusive scan over lanes (d = 1,2,4,8,16,32; x[l] += x[l-d])
+ *   incl     = lane_scan(part) (the DPP-shaped inclusive scan above)
  *   S = incl[63];  r = u * S,  u = component (t&3) of Philox(ctr=(t>>2, gid, iter, STREAM_SCAN))
  *   L = first lane with incl[L] >= r and part[L] > 0
  *   inside lane L: run = incl[L-1] (0 for L=0); walk its candidates in (c,v) order adding
@@ -238,7 +250,7 @@ int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t it
     paths[a] = prev;
     for (int t = 1; t < n; ++t) {
       const float *row = P + (long)prev * n;
-      float part[64], incl[64], tmp[64];
+      float part[64], incl[64];
       for (int l = 0; l < 64; ++l) {
         float s = 0.0f;
         for (int c = 0; c < ch; ++c)
@@ -248,10 +260,7 @@ int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t it
           }
         part[l] = s; incl[l] = s;
       }
-      for (int d = 1; d < 64; d <<= 1) {
-        for (int l = 0; l < 64; ++l) tmp[l] = l >= d ? incl[l] + incl[l - d] : incl[l];
-        memcpy(incl, tmp, sizeof incl);
-      }
+      lane_scan(incl);
       float S = incl[63];
       rng_block(seed, iter, STREAM_SCAN, gid, (uint32_t)t >> 2, r4);
       float r = u01(r4[t & 3]) * S;

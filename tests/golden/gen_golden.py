@@ -132,7 +132,8 @@ def gen_tsp_sampler(tsp_aco):
         assert torch.equal(build().gen_path(require_prob=False), ref_paths)
         q = torch.stack(tap.q)                                   # [n-1, A, n]
         save("g1_" + name, distances=dist, heuristic=aco2.heuristic, pheromone=aco2.pheromone,
-             alpha=np.float32(1), beta=np.float32(1), start=ref_paths[0], noise=q,
+             alpha=np.float32(1), beta=np.float32(1), start=ref_paths[0], noise=q, seed=np.int64(seed),
+             sparsify_k=np.int32(max(5, n // 5) if hk == "sparse" else 0),
              paths=ref_paths, log_probs=ref_logp, costs=ref_costs)
 
 

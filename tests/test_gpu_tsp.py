@@ -1,0 +1,241 @@
+"""GPU parity tests for the TSP rollout path, through the C ABI (deepaco_amd.engine -> ctypes ->
+libdeepaco_hip.so).  Three layers:
+  1. golden vectors captured from the reference (recorded-noise race): tours bit-exact,
+     pheromone update bitwise, costs/log-probs to tolerance;
+  2. the CPU oracle on seeded inputs in the Philox modes: tours, costs and pheromone bit-exact;
+  3. size-independent properties at BASELINE.json's full sizes (TSP-500 x 512 ants).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL_COST = 1e-5   # north_star: costs within 1e-5 relative
+ATOL_LOGP = 2e-6
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def make_instance(n, seed, B=1):
+    g = torch.Generator().manual_seed(seed)
+    coords = torch.rand(B, n, 2, generator=g)
+    dist = torch.cdist(coords, coords)
+    idx = torch.arange(n)
+    dist[:, idx, idx] = 1e9
+    tau = torch.rand(B, n, n, generator=g) + 0.1
+    tau = (tau + tau.transpose(1, 2)) / 2
+    eta = torch.rand(B, n, n, generator=g) ** 2 + 1e-10
+    return dist, tau, eta
+
+
+# ------------------------------------------------------------------ 1. golden vectors
+@pytest.mark.parametrize("name", names("g1_tsp") + names("g1_nls"))
+def test_sampler_recorded_noise_bit_exact(name):
+    from deepaco_amd import engine
+    g = load_golden(name)
+    passes = 2 if "nls" in name else 1
+    paths, logp, _, flags = engine.tsp_sample(T(g["pheromone"])[None], T(g["heuristic"])[None], g["paths"].shape[1],
+                                              mode="race_noise", norm_passes=passes, start=T(g["start"])[None],
+                                              noise=T(g["noise"])[None], require_prob=True)
+    assert int(flags.sum()) == 0
+    assert np.array_equal(paths[0].cpu().numpy(), g["paths"])
+    np.testing.assert_allclose(logp[0].cpu().numpy(), g["log_probs"], atol=ATOL_LOGP, rtol=1e-5)
+    # the un-normalised race picks the same tours
+    p0, _, _, _ = engine.tsp_sample(T(g["pheromone"])[None], T(g["heuristic"])[None], g["paths"].shape[1],
+                                    mode="race_noise", norm_passes=0, start=T(g["start"])[None],
+                                    noise=T(g["noise"])[None])
+    assert np.array_equal(p0[0].cpu().numpy(), g["paths"])
+    costs = engine.tour_costs(T(g["distances"])[None], paths)[0].cpu().numpy()
+    np.testing.assert_allclose(costs, g["costs"], rtol=RTOL_COST)
+    assert np.array_equal(costs, oracle.tour_costs(g["distances"], g["paths"]))
+
+
+@pytest.mark.parametrize("name", names("g2_tsp"))
+def test_update_bitwise_vs_reference(name):
+    from deepaco_amd import engine
+    g = load_golden(name)
+    tau = T(g["pheromone_in"])[None].clone().contiguous()
+    cmin = cmax = None
+    if "clamp_max" in g:
+        cmin, cmax = T(g["clamp_min"]).reshape(1), T(g["clamp_max"]).reshape(1)
+    engine.pheromone_update_(tau, T(g["paths"])[None], T(g["costs"])[None], float(g["decay"]),
+                             bool(g["elitist"]), True, cmin, cmax)
+    assert np.array_equal(tau[0].cpu().numpy().view(np.uint32), g["pheromone_out"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", names("u2_tsp"))
+def test_aco_class_run_trace(name):
+    """ACO.run (tsp/aco.py:75-92) through the drop-in class, the reference's noise injected."""
+    from deepaco_amd.tsp.aco import ACO
+    g = load_golden(name)
+    dist = T(g["distances"])
+    kw = dict(elitist=bool(g["elitist"]), min_max=bool(g["min_max"]))
+    aco = ACO(dist, n_ants=g["paths"].shape[2], device="cuda:0", **kw)
+    for it in range(g["tau_in"].shape[0]):
+        # start every iteration from the reference's pheromone: one differing ulp in a cost
+        # would otherwise make later iterations incomparable (SURVEY.md 7 'chaos')
+        aco.pheromone = T(g["tau_in"][it]).clone()
+        orig = aco.gen_path
+        start, noise = T(g["start"][it]), T(g["noise"][it])
+        aco.gen_path = lambda require_prob=False, _o=orig, _s=start, _q=noise: _o(require_prob, _start=_s, _noise=_q)
+        aco.run(1)
+        aco.gen_path = orig
+        np.testing.assert_allclose(aco.pheromone.cpu().numpy(), g["tau_out"][it], rtol=2e-6)
+        np.testing.assert_allclose(float(aco.lowest_cost), float(g["lowest"][it]), rtol=RTOL_COST)
+    assert sorted(aco.shortest_path.cpu().tolist()) == list(range(dist.shape[0]))
+    ref_sp = g["shortest_path"]
+    assert np.array_equal(aco.shortest_path.cpu().numpy(), ref_sp)
+
+
+# ------------------------------------------------------------------ 2. oracle, Philox modes
+SHAPES = [(2, 1, 1), (3, 2, 1), (5, 4, 1), (20, 7, 2), (63, 5, 1), (64, 9, 1), (65, 5, 2), (100, 33, 1),
+          (128, 6, 1), (129, 6, 1), (200, 17, 2), (256, 4, 1), (257, 4, 1), (500, 12, 1), (777, 5, 1),
+          (1000, 6, 1), (1025, 3, 1)]
+
+
+@pytest.mark.parametrize("mode", ["scan", "race"])
+@pytest.mark.parametrize("n,A,B", SHAPES)
+def test_sampler_philox_bit_exact_vs_oracle(mode, n, A, B):
+    from deepaco_amd import engine
+    dist, tau, eta = make_instance(n, 100 + n, B)
+    seed, it, gid0 = 0xDEADBEEF1234, 3, 1000
+    paths, logp, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=seed, it=it,
+                                              ant_gid0=gid0, require_prob=True)
+    fn = oracle.tsp_sample_scan if mode == "scan" else oracle.tsp_sample_race
+    assert int(flags.sum()) == 0
+    for b in range(B):
+        P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+        rp, rl, rc = fn(P, A, seed, it, gid0 + b * A, require_prob=True)
+        assert rc == 0
+        assert np.array_equal(paths[b].cpu().numpy(), rp), (mode, n, b)
+        if n > 2:
+            np.testing.assert_allclose(logp[b].cpu().numpy(), rl, atol=ATOL_LOGP, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["scan", "race"])
+def test_fixed_start_and_no_logp(mode):
+    from deepaco_amd import engine
+    n, A = 150, 10
+    dist, tau, eta = make_instance(n, 5)
+    paths, logp, _, _ = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=9, it=0, fixed_start=0)
+    assert logp is None and bool((paths[0, 0] == 0).all())
+    fn = oracle.tsp_sample_scan if mode == "scan" else oracle.tsp_sample_race
+    rp, _, _ = fn(oracle.prob_matrix(tau[0].numpy(), eta[0].numpy()), A, 9, 0, 0, fixed_start=0)
+    assert np.array_equal(paths[0].cpu().numpy(), rp)
+
+
+@pytest.mark.parametrize("elitist,mmas", [(False, False), (True, False), (False, True)])
+def test_batched_run_bit_exact_vs_oracle(elitist, mmas):
+    """Multi-iteration colony (sample -> costs -> best -> update) == the same loop on the oracle."""
+    from deepaco_amd import engine
+    B, n, A, iters, seed = 2, 50, 24, 5, 77
+    dist, _, _ = make_instance(n, 42, B)
+    col = engine.BatchedTSP(dist.to(dev()), n_ants=A, elitist=elitist, min_max=mmas, seed=seed)
+    col.run(iters)
+    for b in range(B):
+        d = dist[b].numpy()
+        eta = (1.0 / dist[b]).numpy()
+        tau = np.ones((n, n), np.float32) * (np.float32(0.1) if mmas else np.float32(1))
+        lowest, cmax = np.float32(np.inf), None
+        for it in range(iters):
+            paths, _, rc = oracle.tsp_sample_scan(oracle.prob_matrix(tau, eta), A, seed, it, b * A)
+            costs = oracle.tour_costs(d, paths)
+            if costs.min() < lowest:
+                lowest = costs.min()
+            if mmas:
+                new_max = (np.float32(1) / lowest) * np.float32(n)
+                if cmax is None:
+                    tau = tau * (new_max / tau.max())
+                cmax = new_max
+            tau = oracle.pheromone_update_tsp(tau, paths, costs, 0.9, elitist, 0.1 if mmas else 0.0,
+                                              float(cmax) if mmas else 0.0)
+        assert np.array_equal(col.pheromone[b].cpu().numpy().view(np.uint32), tau.view(np.uint32))
+        assert np.float32(col.lowest_cost[b].item()) == lowest
+
+
+def test_sampler_distribution_chi_square():
+    """Both samplers draw the first move from p_k ~ P[start][k] (exact categorical)."""
+    from deepaco_amd import engine
+    n, A, B = 12, 4096, 8
+    g = torch.Generator().manual_seed(1)
+    tau = torch.rand(n, n, generator=g) + 0.05
+    eta = torch.rand(n, n, generator=g) ** 2 + 1e-3
+    p = (tau[0] * eta[0]).double()
+    p[0] = 0
+    p = p / p.sum()
+    for mode in ("scan", "race"):
+        paths, _, _, _ = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=5, fixed_start=0, batch=B)
+        first = paths[:, 1, :].reshape(-1).cpu()
+        N = first.numel()
+        obs = torch.bincount(first, minlength=n).double()
+        chi2 = float((((obs - N * p) ** 2) / (N * p).clamp(min=1e-12))[1:].sum())
+        assert chi2 < 40.0, (mode, chi2)     # dof = 10: P(chi2 > 40) ~ 2e-5
+        # and the second move, conditioned on the first, is uniform-free of bias too: all tours valid
+        assert bool((paths.sort(dim=1).values == torch.arange(n, device=dev()).view(1, n, 1)).all())
+
+
+# ------------------------------------------------------------------ 3. properties at full size
+@pytest.mark.parametrize("mode", ["scan", "race"])
+def test_full_size_properties_tsp500(mode):
+    from deepaco_amd import engine
+    B, n, A = 4, 500, 512
+    dist, tau, eta = make_instance(n, 2024, B)
+    d, t, e = dist.to(dev()), tau.to(dev()), eta.to(dev())
+    paths, _, _, flags = engine.tsp_sample(t, e, A, mode=mode, seed=11, it=0)
+    assert int(flags.sum()) == 0
+    # every tour is a permutation of the nodes
+    assert bool((paths.sort(dim=1).values == torch.arange(n, device=dev()).view(1, n, 1)).all())
+    # different ants build different tours; different iterations differ
+    assert len({tuple(paths[0, :, a].tolist()) for a in range(32)}) > 16
+    p2, _, _, _ = engine.tsp_sample(t, e, A, mode=mode, seed=11, it=1)
+    assert not torch.equal(paths, p2)
+    # same (seed, it) reproduces the tours exactly
+    p3, _, _, _ = engine.tsp_sample(t, e, A, mode=mode, seed=11, it=0)
+    assert torch.equal(paths, p3)
+    # costs against an independent torch gather-sum
+    costs = engine.tour_costs(d, paths)
+    u = paths.transpose(1, 2)
+    v = torch.roll(u, 1, dims=2)
+    ref = torch.stack([d[b][u[b], v[b]].double().sum(1) for b in range(B)])
+    torch.testing.assert_close(costs.double(), ref, rtol=RTOL_COST, atol=0)
+    # update: symmetric stays symmetric; deposited mass = 2n * sum(1/c)
+    t2 = t.clone().contiguous()
+    engine.pheromone_update_(t2, paths, costs, 0.9)
+    assert torch.equal(t2, t2.transpose(1, 2))
+    mass = (t2.double() - 0.9 * t.double()).sum(dim=(1, 2))
+    torch.testing.assert_close(mass, 2 * n * (1 / costs.double()).sum(1), rtol=1e-4, atol=0)
+    # one instance cross-checked bit-exactly against the oracle at full size
+    b = 1
+    P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+    fn = oracle.tsp_sample_scan if mode == "scan" else oracle.tsp_sample_race
+    rp, _, _ = fn(P, 64, 11, 0, b * A)
+    assert np.array_equal(paths[b, :, :64].cpu().numpy(), rp)
+    rt = oracle.pheromone_update_tsp(tau[b].numpy(), paths[b].cpu().numpy(), costs[b].cpu().numpy(), 0.9)
+    assert np.array_equal(t2[b].cpu().numpy().view(np.uint32), rt.view(np.uint32))
+
+
+def test_infeasible_row_sets_flag():
+    from deepaco_amd import engine
+    n, A = 10, 4
+    tau = torch.ones(n, n)
+    eta = torch.zeros(n, n)
+    for mode in ("scan", "race"):
+        _, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=1)
+        assert int(flags[0]) == 1
