@@ -25,12 +25,27 @@ tour_costs_kernel(int B, int n, int len, int A, const float *dist, long dist_bs,
   const float *d = dist + b * dist_bs;
   float s = 0.0f;
   if (closed) {
-    long prev = p[(size_t)(len - 1) * A];
-    for (int k = 0; k < len; ++k) {
+    // edges k = 1..len-1 in order, closing edge last (the order the fused sampler produces)
+    const long first = p[0];
+    long prev = first;
+    int k = 1;
+    for (; k + 8 <= len; k += 8) {
+      long u[8];
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[j] = p[(size_t)(k + j) * A];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = d[u[j] * n + (j ? u[j - 1] : prev)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = s + e[j];
+      prev = u[7];
+    }
+    for (; k < len; ++k) {
       const long u = p[(size_t)k * A];
       s = s + d[u * n + prev];
       prev = u;
     }
+    s = s + d[first * n + prev];
   } else {
     long u = p[0];
     for (int k = 0; k + 1 < len; ++k) {
@@ -144,7 +159,8 @@ static int rows_per_block(int n) {
 extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
                                      const int64_t *paths, const float *costs, float decay, int elitist,
                                      int symmetric, const float *clamp_min, const float *clamp_max,
-                                     float floor_val, void *workspace, size_t workspace_bytes) {
+                                     float floor_val, const uint32_t *nbr_in, void *workspace,
+                                     size_t workspace_bytes) {
   if (B <= 0 || n < 3 || A <= 0 || !tau || !paths || !costs || !workspace) {
     set_error("daco_pheromone_update: bad argument (B=%d n=%d A=%d)", B, n, A);
     return DACO_E_BADARG;
@@ -156,13 +172,13 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   const size_t need = daco_pheromone_update_workspace_bytes(B, n, len, A);
   if (workspace_bytes < need) { set_error("daco_pheromone_update: workspace %zu < %zu", workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  uint32_t *nbr = (uint32_t *)workspace;
+  const uint32_t *nbr = nbr_in ? nbr_in : (const uint32_t *)workspace;
   int *best = (int *)((char *)workspace + align256((size_t)B * A * n * sizeof(uint32_t)));
-  {
+  if (!nbr_in) {
     const long total = (long)B * n * A;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(build_nbr_kernel, dim3(blocks), dim3(256), 0, s, B, n, A, paths, nbr);
+    hipLaunchKernelGGL(build_nbr_kernel, dim3(blocks), dim3(256), 0, s, B, n, A, paths, (uint32_t *)workspace);
   }
   if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
   const int R = rows_per_block(n);

@@ -11,6 +11,9 @@
 // the draw is a DPP reduction / prefix scan; nothing is staged through LDS because no lane
 // consumes another lane's candidates.  Workgroups are remapped so each XCD walks whole
 // instances (rows stay in its private L2).
+#include <type_traits>
+#include <utility>
+
 #include "daco_device.h"
 #include "../../include/deepaco_hip.h"
 
@@ -30,7 +33,19 @@ struct SampleParams {
   float *logp;           // [B][n-1][A] or null
   float *rowsum;         // [B][n-1][A] or null
   int32_t *flags;        // [B] or null
+  const float *dist;     // [B][n][n] (fused costs) or null
+  long dist_bs;
+  float *costs;          // [B][A] or null
+  uint32_t *nbr;         // [B][A][n] prev | next << 16 (for the pheromone update) or null
 };
+
+template <class F, int... I>
+__device__ inline void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time loop: f receives std::integral_constant<int, j>, j = 0..N-1
+template <int N, class F>
+__device__ inline void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int VEC> struct Vec;
 template <> struct Vec<1> { float v[1]; };
@@ -70,9 +85,22 @@ prob_matrix_kernel(int B, int n, int ld, const float *tau, long tau_bs, const fl
   }
 }
 
-template <int VEC, int MAXCH, int MODE, bool LOGP>
+// visited bitset: bit (c*VEC+v) of a 64-bit word kept as two 32-bit halves so every test is a
+// single 32-bit v_and/v_cmp (the upper half folds away when CH*VEC <= 32)
+struct Visited {
+  uint32_t lo = 0, hi = 0;
+  template <int BIT> __device__ inline bool test() const {
+    if constexpr (BIT < 32) return (lo >> BIT) & 1u; else return (hi >> (BIT - 32)) & 1u;
+  }
+  __device__ inline void set(int bit) {       // bit is wave-uniform
+    if (bit < 32) lo |= 1u << bit; else hi |= 1u << (bit - 32);
+  }
+};
+
+template <int VEC, int CH, int MODE, bool LOGP>
 __global__ void __launch_bounds__(256)
 tsp_sample_kernel(const SampleParams p) {
+  constexpr int NJ = CH * VEC;                          // candidates per lane
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -80,13 +108,15 @@ tsp_sample_kernel(const SampleParams p) {
   const int b = w / bpi;
   const int a = (w - b * bpi) * 4 + wave;
   if (a >= p.A) return;                                 // no barriers below: safe
-  const int n = p.n, A = p.A, ld = p.ld, CH = p.CH;
+  const int n = p.n, A = p.A, ld = p.ld;
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
   const float *Pb = p.P + (size_t)b * n * ld + lane * VEC;
   const float *Rb = (MODE == DACO_RACE_PHILOX) ? p.R + (size_t)b * n * ld + lane * VEC : nullptr;
   int64_t *path_out = p.paths + (size_t)b * n * A + a;
   float *logp_out = LOGP ? p.logp + (size_t)b * (n - 1) * A + a : nullptr;
   float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (n - 1) * A + a : nullptr;
+  const float *dist_b = p.costs ? p.dist + (size_t)b * p.dist_bs : nullptr;
+  uint16_t *nbr_a = p.nbr ? reinterpret_cast<uint16_t *>(p.nbr + ((size_t)b * A + a) * n) : nullptr;
 
   // ---- start node
   int prev;
@@ -97,158 +127,151 @@ tsp_sample_kernel(const SampleParams p) {
     prev = (int)__umulhi(r.x, (uint32_t)n);
   }
   prev = __builtin_amdgcn_readfirstlane(prev);
+  const int first = prev;
 
-  uint64_t vis = 0;                                     // bit (c*VEC+v): candidate visited
-  auto mark = [&](int k) {
+  Visited vis;
+  auto mark = [&](int k) {                              // k wave-uniform
     const int vi = k / VEC;
-    if (lane == (vi & 63)) vis |= 1ull << ((vi >> 6) * VEC + (k % VEC));
+    const int bit = (vi >> 6) * VEC + (k % VEC);
+    if (lane == (vi & 63)) vis.set(bit);
   };
   mark(prev);
   if (lane == 0) path_out[0] = prev;
 
   u32x4 ublk = {0, 0, 0, 0};                            // SCAN: 256 cached uniforms per wave
-  int ublk_base = -1;
+  uint32_t ucur = 0;
   bool infeasible = false;
+  float cost = 0.0f, dpend = 0.0f;                      // fused tour length (edge added one step late)
 
   for (int t = 1; t < n; ++t) {
     // ---- stream the row of `prev`
-    float row[MAXCH][VEC];
+    float row[CH][VEC];
     const float *rp = (MODE == DACO_RACE_PHILOX ? Rb : Pb) + (size_t)prev * ld;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c)
-      if (c < CH) load_vec<VEC>(rp + c * 64 * VEC, row[c]);
+    for (int c = 0; c < CH; ++c) load_vec<VEC>(rp + c * 64 * VEC, row[c]);
 
     int choice;
     float pchoice = 0.0f, S = 0.0f;
 
     if constexpr (MODE == DACO_SCAN) {
+      // uniform for step t: lane (t&63), component (t>>6)&3 of the Philox block (t>>8)*64 + lane
+      if ((t & 63) == 0 || t == 1) {
+        if ((t & 255) == 0 || t == 1) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 8) << 6) + lane));
+        ucur = comp(ublk, (t >> 6) & 3);
+      }
+      const uint32_t ux = (uint32_t)readlane_i((int)ucur, t & 63);
+      // masked candidates become +0.0f, so every later add is a no-op for them
       float part = 0.0f;
-#pragma unroll
-      for (int c = 0; c < MAXCH; ++c)
-        if (c < CH) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            row[c][v] = ((vis >> (c * VEC + v)) & 1) ? 0.0f : row[c][v];
-            part = part + row[c][v];
-          }
-        }
+      static_for<NJ>([&](auto J) {
+        constexpr int j = J, c = j / VEC, v = j % VEC;
+        row[c][v] = vis.test<j>() ? 0.0f : row[c][v];
+        part = part + row[c][v];
+      });
       const float incl = wave_scan_add(part);
       S = readlane_f(incl, 63);
-      // one uniform per step, refilled 256 at a time (lane l holds Philox block base+l)
-      const int blk = t >> 2;
-      if ((blk >> 6) != ublk_base) {
-        ublk_base = blk >> 6;
-        ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)((ublk_base << 6) + lane));
-      }
-      const uint32_t ux = readlane_i((int)comp(ublk, t & 3), blk & 63);
-      const float r = u01(ux) * S;
+      float r = u01(ux) * S;
+      r = r > 0.0f ? r : 1.401298464e-45f;               // keep r > 0 if u*S underflows
       const uint64_t m = __ballot(incl >= r && part > 0.0f);
       if (m == 0) { infeasible = true; choice = 0; }
       else {
         const int L = __builtin_ctzll(m);
         const float excl = L ? readlane_f(incl, L - 1) : 0.0f;
+        // running sums inside the lane are non-decreasing, so the first index whose running
+        // sum reaches r is the count of those still below r (branch-free)
         float run = excl;
-        int best = -1, last = -1;
-        float pbest = 0.0f, plast = 0.0f;
+        int cnt = 0;
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c)
-          if (c < CH) {
+        for (int c = 0; c < CH; ++c) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-              const float x = row[c][v];
-              if (x > 0.0f) {
-                run = run + x;
-                const int k = (c * 64 + lane) * VEC + v;
-                last = k; plast = x;
-                if (best < 0 && run >= r) { best = k; pbest = x; }
-              }
-            }
+          for (int v = 0; v < VEC; ++v) {
+            run = run + row[c][v];
+            cnt += run < r ? 1 : 0;
           }
-        if (best < 0) { best = last; pbest = plast; }
-        choice = readlane_i(best, L);
-        pchoice = readlane_f(pbest, L);
+        }
+        int jsel = readlane_i(cnt, L);
+        if (jsel >= NJ) {
+          // rounding: the in-lane running sum fell short of the scan's value -> last candidate
+          // of the lane with p > 0 (rare; wave-uniform branch)
+          int last = 0;
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) last = row[c][v] > 0.0f ? c * VEC + v : last;
+          }
+          jsel = readlane_i(last, L);
+        }
+        choice = ((jsel / VEC) * 64 + L) * VEC + (jsel % VEC);
+        if constexpr (LOGP) pchoice = p.P[((size_t)b * n + prev) * ld + choice];
       }
     } else if constexpr (MODE == DACO_RACE_PHILOX) {
       float bk = __builtin_inff();
       int bi = 0x7fffffff;
-#pragma unroll
-      for (int c = 0; c < MAXCH; ++c)
-        if (c < CH) {
-          const int k0 = (c * 64 + lane) * VEC;
-          const u32x4 r4 = rng_block(p.seed, p.iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k0 >> 2));
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const int k = k0 + v;
-            const float L = neg_log2_1m(u01(comp(r4, k & 3)));
-            const float key = ((vis >> (c * VEC + v)) & 1) ? __builtin_inff() : L * row[c][v];
-            if (key < bk) { bk = key; bi = k; }
-          }
-        }
+      u32x4 r4{};
+      static_for<NJ>([&](auto J) {
+        constexpr int j = J, c = j / VEC, v = j % VEC;
+        const int k = (c * 64 + lane) * VEC + v;
+        // one Philox block serves candidates 4g..4g+3; a lane's VEC candidates share a block
+        if (v == 0) r4 = rng_block(p.seed, p.iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
+        const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
+        const float key = vis.test<j>() ? __builtin_inff() : Lk * row[c][v];
+        if (key < bk) { bk = key; bi = k; }
+      });
       const KeyIdx r = wave_arg<false>(bk, bi);
       if (!(r.key < __builtin_inff())) { infeasible = true; choice = 0; }
       else choice = r.idx;
       if constexpr (LOGP) {
-        // S over unvisited P (second matrix), p of the chosen candidate
         const float *pp = Pb + (size_t)prev * ld;
         float part = 0.0f;
+        float pr[CH][VEC];
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c)
-          if (c < CH) {
-            float pr[VEC];
-            load_vec<VEC>(pp + c * 64 * VEC, pr);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) part = part + (((vis >> (c * VEC + v)) & 1) ? 0.0f : pr[v]);
-          }
+        for (int c = 0; c < CH; ++c) load_vec<VEC>(pp + c * 64 * VEC, pr[c]);
+        static_for<NJ>([&](auto J) {
+          constexpr int j = J;
+          part = part + (vis.test<j>() ? 0.0f : pr[j / VEC][j % VEC]);
+        });
         S = wave_sum(part);
         pchoice = p.P[((size_t)b * n + prev) * ld + choice];
       }
     } else {  // DACO_RACE_NOISE: the arithmetic of torch.multinomial's one-sample path
       const float *q = p.noise + (((size_t)b * (n - 1) + (t - 1)) * A + a) * n;
       float part = 0.0f;
-#pragma unroll
-      for (int c = 0; c < MAXCH; ++c)
-        if (c < CH) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            row[c][v] = ((vis >> (c * VEC + v)) & 1) ? 0.0f : row[c][v];
-            part = part + row[c][v];
-          }
-        }
+      static_for<NJ>([&](auto J) {
+        constexpr int j = J, c = j / VEC, v = j % VEC;
+        row[c][v] = vis.test<j>() ? 0.0f : row[c][v];
+        part = part + row[c][v];
+      });
       for (int pass = 0; pass < p.norm_passes; ++pass) {
         S = wave_sum(part);
         part = 0.0f;
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c)
-          if (c < CH) {
+        for (int c = 0; c < CH; ++c) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-              row[c][v] = row[c][v] / S;
-              part = part + row[c][v];
-            }
+          for (int v = 0; v < VEC; ++v) {
+            row[c][v] = row[c][v] / S;
+            part = part + row[c][v];
           }
+        }
       }
       float bk = -__builtin_inff(), bp = 0.0f;
       int bi = 0x7fffffff;
 #pragma unroll
-      for (int c = 0; c < MAXCH; ++c)
-        if (c < CH) {
+      for (int c = 0; c < CH; ++c) {
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const int k = (c * 64 + lane) * VEC + v;
-            if (k < n) {
-              const float key = row[c][v] / q[k];
-              if (key > bk) { bk = key; bi = k; bp = row[c][v]; }
-            }
+        for (int v = 0; v < VEC; ++v) {
+          const int k = (c * 64 + lane) * VEC + v;
+          if (k < n) {
+            const float key = row[c][v] / q[k];
+            if (key > bk) { bk = key; bi = k; bp = row[c][v]; }
           }
         }
+      }
       const KeyIdx r = wave_arg<true>(bk, bi);
       if (!(r.key > 0.0f)) infeasible = true;
       choice = r.idx == 0x7fffffff ? 0 : r.idx;
       if constexpr (LOGP) {
-        // lane owning the winner broadcasts its (normalised) p
         const int own = (choice / VEC) & 63;
         pchoice = readlane_f(bp, own);
-        if (p.norm_passes == 0) S = wave_sum(part); else { S = 1.0f; }
+        if (p.norm_passes == 0) S = wave_sum(part); else S = 1.0f;
       }
     }
 
@@ -262,17 +285,29 @@ tsp_sample_kernel(const SampleParams p) {
     }
     mark(choice);
     if (lane == 0) path_out[(size_t)t * A] = choice;
+    if (dist_b) {                                        // fused gen_path_costs (wave-uniform)
+      cost = cost + dpend;
+      dpend = dist_b[(size_t)choice * n + prev];         // d[u_t][u_{t-1}], scalar load
+    }
+    if (nbr_a && lane < 2)                               // lane 0: next(prev)=choice, lane 1: prev(choice)=prev
+      nbr_a[lane == 0 ? 2 * prev + 1 : 2 * choice] = (uint16_t)(lane == 0 ? choice : prev);
     prev = choice;
   }
+  if (dist_b) {
+    cost = cost + dpend;
+    cost = cost + dist_b[(size_t)first * n + prev];      // closing edge d[u_0][u_{n-1}] last
+    if (lane == 0) p.costs[(size_t)b * A + a] = cost;
+  }
+  if (nbr_a && lane < 2) nbr_a[lane == 0 ? 2 * prev + 1 : 2 * first] = (uint16_t)(lane == 0 ? first : prev);
   if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
 }
 
 // ------------------------------------------------------------------ host dispatch
-template <int VEC, int MAXCH>
+template <int VEC, int CH>
 static hipError_t launch_sample(const SampleParams &sp, int mode, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 3) / 4;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
-#define DACO_LAUNCH(M, L) hipLaunchKernelGGL((tsp_sample_kernel<VEC, MAXCH, M, L>), grid, block, 0, s, sp)
+#define DACO_LAUNCH(M, L) hipLaunchKernelGGL((tsp_sample_kernel<VEC, CH, M, L>), grid, block, 0, s, sp)
   if (mode == DACO_SCAN) { if (logp) DACO_LAUNCH(DACO_SCAN, true); else DACO_LAUNCH(DACO_SCAN, false); }
   else if (mode == DACO_RACE_PHILOX) { if (logp) DACO_LAUNCH(DACO_RACE_PHILOX, true); else DACO_LAUNCH(DACO_RACE_PHILOX, false); }
   else { if (logp) DACO_LAUNCH(DACO_RACE_NOISE, true); else DACO_LAUNCH(DACO_RACE_NOISE, false); }
@@ -289,9 +324,19 @@ extern "C" int daco_ld_for_n(int n) { return ld_for_n(n); }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// chunks per lane actually instantiated (compile-time loop bounds): the row is padded with
+// zeros up to the next instantiated size; zero padding never changes a sum or a draw.
+static int inst_chunks(int n) {
+  const int vec = vec_for_n(n), need = ld_for_n(n) / (64 * vec);
+  static const int avail[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  for (int c : avail) if (c >= need) return c;
+  return -1;
+}
+static int ld_alloc(int n) { return inst_chunks(n) * 64 * vec_for_n(n); }
+
 extern "C" size_t daco_tsp_sample_workspace_bytes(int B, int n, int mode) {
-  if (B <= 0 || n <= 0) return 0;
-  const size_t mat = align256((size_t)B * n * ld_for_n(n) * sizeof(float));
+  if (B <= 0 || n <= 0 || n > DACO_MAX_NODES) return 0;
+  const size_t mat = align256((size_t)B * n * ld_alloc(n) * sizeof(float));
   return mode == DACO_RACE_PHILOX ? 2 * mat : mat;
 }
 
@@ -300,6 +345,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
                                int norm_passes, const int64_t *start, int fixed_start,
                                const float *noise, uint64_t seed, uint64_t iter, uint32_t ant_gid0,
                                int64_t *paths, float *logp, float *rowsum, int32_t *flags,
+                               const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                                void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end) {
   if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !paths || !workspace) {
     set_error("daco_tsp_sample: bad argument (B=%d n=%d A=%d tau=%p eta=%p paths=%p ws=%p)", B, n, A,
@@ -310,10 +356,11 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   if (mode < 0 || mode > 2 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
+  if (costs && !dist) { set_error("daco_tsp_sample: fused costs need the distance matrix"); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
   if (workspace_bytes < need) { set_error("daco_tsp_sample: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  const int ld = ld_for_n(n), vec = vec_for_n(n), CH = ld / (64 * vec);
+  const int vec = vec_for_n(n), CH = inst_chunks(n), ld = ld_alloc(n);
   float *P = (float *)workspace;
   float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
   {
@@ -330,16 +377,22 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   sp.P = P; sp.R = R; sp.norm_passes = norm_passes; sp.start = start; sp.fixed_start = fixed_start;
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
+  sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
   const bool lp = logp != nullptr;
   hipError_t e;
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   if (vec == 1) e = launch_sample<1, 1>(sp, mode, lp, s);
   else if (vec == 2) e = launch_sample<2, 1>(sp, mode, lp, s);
-  else if (CH <= 1) e = launch_sample<4, 1>(sp, mode, lp, s);
-  else if (CH <= 2) e = launch_sample<4, 2>(sp, mode, lp, s);
-  else if (CH <= 4) e = launch_sample<4, 4>(sp, mode, lp, s);
-  else if (CH <= 8) e = launch_sample<4, 8>(sp, mode, lp, s);
-  else e = launch_sample<4, 16>(sp, mode, lp, s);
+  else switch (CH) {
+    case 1: e = launch_sample<4, 1>(sp, mode, lp, s); break;
+    case 2: e = launch_sample<4, 2>(sp, mode, lp, s); break;
+    case 3: e = launch_sample<4, 3>(sp, mode, lp, s); break;
+    case 4: e = launch_sample<4, 4>(sp, mode, lp, s); break;
+    case 6: e = launch_sample<4, 6>(sp, mode, lp, s); break;
+    case 8: e = launch_sample<4, 8>(sp, mode, lp, s); break;
+    case 12: e = launch_sample<4, 12>(sp, mode, lp, s); break;
+    default: e = launch_sample<4, 16>(sp, mode, lp, s); break;
+  }
   if (e != hipSuccess) { set_error("tsp_sample_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
   return DACO_OK;

@@ -48,12 +48,15 @@ def _bstride(t, n):
 
 def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1, start=None,
                fixed_start=-1, noise=None, seed=0, it=0, ant_gid0=0, require_prob=False, batch=None,
-               events=None):
+               events=None, dist=None, want_nbr=False):
     """ACO.gen_path for a batch (tsp/aco.py:134-177, tsp_nls/aco.py:184-220).
 
     tau, eta: [B,n,n] or [n,n] (shared).  Returns (paths, log_probs|None, rowsum|None, flags).
     events: optional (begin, end) torch.cuda.Event pair (already recorded once, so the handles
-    exist) re-recorded around the tour-construction kernel only."""
+    exist) re-recorded around the tour-construction kernel only.
+    dist: if given, tour costs are fused into the kernel and returned; want_nbr: also return the
+    neighbour table the pheromone update consumes.  With either, the return value is
+    (paths, log_probs, rowsum, flags, costs|None, nbr|None)."""
     _require_gpu(tau, eta, start, noise)
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
@@ -71,6 +74,14 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
             start = start.to(torch.int64).contiguous().view(B, n_ants)
         if noise is not None:
             noise = _f32c(noise).view(B, n - 1, n_ants, n)
+        costs = nbr = None
+        dbs = 0
+        if dist is not None:
+            _require_gpu(dist)
+            dist, dbs = _bstride(dist, n)
+            costs = torch.empty((B, n_ants), dtype=torch.float32, device=dev)
+        if want_nbr:
+            nbr = torch.empty((B, n_ants, n), dtype=torch.int32, device=dev)
         nbytes = L.daco_tsp_sample_workspace_bytes(B, n, m)
         ws = _workspace(dev, nbytes, "sample")
         rc = L.daco_tsp_sample(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs,
@@ -80,10 +91,15 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
                                int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF,
                                paths.data_ptr(), logp.data_ptr() if require_prob else None,
                                rowsum.data_ptr() if require_prob else None, flags.data_ptr(),
+                               dist.data_ptr() if dist is not None else None, dbs,
+                               costs.data_ptr() if costs is not None else None,
+                               nbr.data_ptr() if nbr is not None else None,
                                ws.data_ptr(), ws.numel(),
                                events[0].cuda_event if events else None,
                                events[1].cuda_event if events else None)
     _lib.check(rc, "daco_tsp_sample")
+    if dist is not None or want_nbr:
+        return paths, logp, rowsum, flags, costs, nbr
     return paths, logp, rowsum, flags
 
 
@@ -104,7 +120,7 @@ def tour_costs(dist, paths, closed=True):
 
 
 def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, clamp_min=None,
-                      clamp_max=None, floor=0.0):
+                      clamp_max=None, floor=0.0, nbr=None):
     """In-place ACO.update_pheronome for a batch (tsp/aco.py:95-118, cvrp/aco.py:107-130).
 
     tau [B,n,n] f32 contiguous (modified in place); clamp_min/clamp_max: [B] f32 tensors or None."""
@@ -123,7 +139,8 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
                                      costs.data_ptr(), float(decay), int(bool(elitist)), int(bool(symmetric)),
                                      clamp_min.data_ptr() if clamp_min is not None else None,
                                      clamp_max.data_ptr() if clamp_max is not None else None,
-                                     float(floor), ws.data_ptr(), ws.numel())
+                                     float(floor), nbr.data_ptr() if nbr is not None else None,
+                                     ws.data_ptr(), ws.numel())
     _lib.check(rc, "daco_pheromone_update")
     return tau
 
@@ -170,12 +187,11 @@ class BatchedTSP:
 
     @torch.no_grad()
     def step(self, events=None):
-        paths, _, _, _ = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha, self.beta,
-                                    mode=self.sampler, seed=self.seed, it=self.iteration,
-                                    ant_gid0=self.ant_gid0, fixed_start=self.fixed_start, batch=self.B,
-                                    events=events)
+        paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
+                                                self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,
+                                                ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
+                                                batch=self.B, events=events, dist=self.distances, want_nbr=True)
         self.iteration += 1
-        costs = tour_costs(self.distances, paths)
         best_cost, best_idx = costs.min(dim=1)
         improved = best_cost < self.lowest_cost
         best_path = torch.gather(paths, 2, best_idx.view(self.B, 1, 1).expand(self.B, self.n, 1)).squeeze(2)
@@ -189,7 +205,7 @@ class BatchedTSP:
             self.max = new_max
             cmin = torch.full_like(new_max, self.min)
             cmax = new_max.contiguous()
-        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax)
+        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
         return paths, costs
 
     @torch.no_grad()

@@ -78,6 +78,11 @@ int daco_ld_for_n(int n);
  *   rowsum     out [B][n-1][A] f32 or NULL: S at each step (saved for daco_tsp_sample_backward)
  *   flags      out [B] int32 or NULL: set to 1 if some draw had no feasible candidate
  *              (the reference's Categorical raises ValueError there); caller zeroes it.
+ *   dist, costs   optional fusion of ACO.gen_path_costs: if costs != NULL, dist [B][n][n]
+ *              (dist_bstride as for tau) is read once per step and costs [B][A] receives the
+ *              closed-tour length in daco_tour_costs' summation order.
+ *   nbr        optional out [B][A][n] uint32: prev(node) | next(node) << 16 along each tour, the
+ *              form daco_pheromone_update consumes (saves its own pass over `paths`).
  *   workspace  daco_tsp_sample_workspace_bytes(B, n, mode) bytes of device scratch.
  *   ev_begin, ev_end   optional hipEvent_t pair (NULL to skip) recorded on `stream` immediately
  *              before and after the tour-construction kernel itself (not the P = tau^a*eta^b
@@ -90,15 +95,17 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
                     const int64_t *start, int fixed_start, const float *noise,
                     uint64_t seed, uint64_t iter, uint32_t ant_gid0,
                     int64_t *paths, float *logp, float *rowsum, int32_t *flags,
+                    const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                     void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_tour_costs -- replaces ACO.gen_path_costs
- *   closed = 1: sum_k dist[u_k][u_{k-1}] over the closed tour     (tsp/aco.py:121-132)
+ *   closed = 1: sum_k dist[u_k][u_{k-1}] over the closed tour     (tsp/aco.py:121-132),
+ *               added in the order k = 1..len-1 and the closing edge dist[u_0][u_{len-1}] last
  *   closed = 0: sum_{k < len-1} dist[u_k][u_{k+1}]                  (cvrp/aco.py:133-136)
  * paths [B][len][A] int64, dist [B][n][n] (dist_bstride as above), costs out [B][A] f32.
- * Summation is sequential in k from +0.0f (documented order; the reference's torch.sum order
- * is unspecified and agreement with it is 1e-5 relative).
+ * Summation is sequential from +0.0f (documented order; the reference's torch.sum order is
+ * unspecified and agreement with it is 1e-5 relative).
  */
 int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dist,
                     long dist_bstride, const int64_t *paths, int closed, float *costs);
@@ -117,13 +124,16 @@ int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dis
  *   tau   in/out [B][n][n] f32 (dense, stride n*n)
  *   paths [B][len][A] int64, costs [B][A] f32
  *   clamp_min/clamp_max: [B] f32 device arrays or NULL (per-instance MMAS bounds)
+ *   nbr   optional [B][A][n] uint32 as written by daco_tsp_sample (symmetric only); if NULL it
+ *         is rebuilt from `paths` in the workspace
  *   workspace: daco_pheromone_update_workspace_bytes(B, n, len, A)
  */
 size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A);
 int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
                           const int64_t *paths, const float *costs, float decay, int elitist,
                           int symmetric, const float *clamp_min, const float *clamp_max,
-                          float floor_val, void *workspace, size_t workspace_bytes);
+                          float floor_val, const uint32_t *nbr, void *workspace,
+                          size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -229,7 +229,8 @@ int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t it
  * sum reaches r.  Here the walk is a wave-shaped scan with a defined order:
  *   part[l]  = lane-partial sum (c asc, v asc) of masked p
  *   incl     = lane_scan(part) (the DPP-shaped inclusive scan above)
- *   S = incl[63];  r = u * S,  u = component (t&3) of Philox(ctr=(t>>2, gid, iter, STREAM_SCAN))
+ *   S = incl[63];  r = u * S,  u = component ((t>>6)&3) of
+ *       Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))   [256 uniforms per wave refill]
  *   L = first lane with incl[L] >= r and part[L] > 0
  *   inside lane L: run = incl[L-1] (0 for L=0); walk its candidates in (c,v) order adding
  *   unvisited p>0; pick the first with run >= r, else the last unvisited p>0 of the lane. */
@@ -262,8 +263,9 @@ int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t it
       }
       lane_scan(incl);
       float S = incl[63];
-      rng_block(seed, iter, STREAM_SCAN, gid, (uint32_t)t >> 2, r4);
-      float r = u01(r4[t & 3]) * S;
+      rng_block(seed, iter, STREAM_SCAN, gid, (((uint32_t)t >> 8) << 6) + ((uint32_t)t & 63u), r4);
+      float r = u01(r4[(t >> 6) & 3]) * S;
+      if (!(r > 0.0f)) r = 1.401298464e-45f;               /* keep r > 0 if u*S underflows */
       int L = -1;
       for (int l = 0; l < 64; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
       int best = -1;
@@ -294,17 +296,19 @@ int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t it
 /* ------------------------------------------------------------------ T4 / C5: tour costs
  * closed: sum_k dist[u_k][u_{k-1 mod n}]  (tsp/aco.py:121-132)
  * open:   sum_{k<len-1} dist[u_k][u_{k+1}] (cvrp/aco.py:133-136)
- * Order: sequential in k from +0.0f (the reference's torch.sum order is unspecified; agreement
+ * Order: sequential from +0.0f, closed tours add the closing edge last (the reference's
+ * torch.sum order is unspecified; agreement
  * with it is to 1e-5 relative, agreement with the HIP kernel is bitwise). */
 void orc_tour_costs(int n, int len, int A, const float *dist, const int64_t *paths, int closed,
                     float *costs) {
   for (int a = 0; a < A; ++a) {
     float s = 0.0f;
-    if (closed) {
-      for (int k = 0; k < len; ++k) {
-        long u = paths[(long)k * A + a], v = paths[(long)((k + len - 1) % len) * A + a];
+    if (closed) {      /* edges k = 1..len-1 in order, then the closing edge d[u_0][u_{len-1}] */
+      for (int k = 1; k < len; ++k) {
+        long u = paths[(long)k * A + a], v = paths[(long)(k - 1) * A + a];
         s = s + dist[u * n + v];
       }
+      s = s + dist[paths[a] * n + paths[(long)(len - 1) * A + a]];
     } else {
       for (int k = 0; k + 1 < len; ++k) {
         long u = paths[(long)k * A + a], v = paths[(long)(k + 1) * A + a];
