@@ -124,6 +124,101 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
   }
 }
 
+// ------------------------------------------------------------------ CVRP (directed) deposit
+// cvrp/aco.py:107-130: tau[path[:-1], path[1:]] += 1/cost per ant, duplicates of an index pair
+// within one ant (the padding edge (0,0)) collapse to ONE add.  Row i >= 1 (a customer) is
+// left exactly once per ant -> one lane per row walks the ants in order.  Row 0 (the depot) is
+// left once per route: build_next_kernel also collects, per ant, the list of nodes that
+// follow the depot; the depot workgroup applies each ant's list (distinct columns -> parallel
+// lanes) in ant order, and the (0,0) edge once per ant if it occurs.
+__global__ void __launch_bounds__(256)
+build_next_kernel(int B, int n, int len, int A, const int64_t *paths, uint32_t *nbr, uint16_t *dlist, int *dcnt) {
+  const long total = (long)B * (len - 1) * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const long r = i / A;
+    const int k = (int)(r % (len - 1)), b = (int)(r / (len - 1));
+    const int64_t *p = paths + (size_t)b * len * A + a;
+    const uint32_t u = (uint32_t)p[(size_t)k * A], v = (uint32_t)p[(size_t)(k + 1) * A];
+    if (u != 0) nbr[((size_t)b * A + a) * n + u] = v << 16;
+    else {
+      const int pos = atomicAdd(dcnt + (size_t)b * A + a, 1);
+      dlist[((size_t)b * A + a) * len + pos] = (uint16_t)v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+deposit_directed_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, float decay,
+                        const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];
+  const int bpi = (n - 1 + R - 1) / R;                 // rows 1..n-1
+  const int b = blockIdx.x / bpi;
+  const int i0 = 1 + (blockIdx.x - b * bpi) * R;
+  const int Rv = min(R, n - i0);
+  float *g = tau + ((size_t)b * n + i0) * n;
+  const int cnt = Rv * n;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) rows[i] = g[i] * decay;
+  __syncthreads();
+  const int r = threadIdx.x;
+  if (r < Rv) {
+    const uint32_t *nb = nbr + (size_t)b * A * n + i0 + r;
+    const float *cs = costs + (size_t)b * A;
+    float *row = rows + r * n;
+    int alo = 0, ahi = A;
+    if (best) { alo = best[b]; ahi = alo + 1; }
+#pragma unroll 4
+    for (int a = alo; a < ahi; ++a) {
+      const int col = (int)(nb[(size_t)a * n] >> 16);
+      const float w = 1.0f / cs[a];
+      row[col] = row[col] + w;
+    }
+  }
+  __syncthreads();
+  const bool clamp = clamp_max != nullptr;
+  const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    float x = rows[i];
+    if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
+    if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
+    g[i] = x;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+deposit_depot_kernel(int n, int len, int A, float *tau, const uint16_t *dlist, const int *dcnt, const float *costs,
+                     float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float *g = tau + (size_t)b * n * n;                   // row 0 of instance b
+  for (int i = lane; i < n; i += 64) row[i] = g[i] * decay;
+  __syncthreads();
+  int alo = 0, ahi = A;
+  if (best) { alo = best[b]; ahi = alo + 1; }
+  for (int a = alo; a < ahi; ++a) {
+    const int c = dcnt[(size_t)b * A + a];
+    const float w = 1.0f / costs[(size_t)b * A + a];
+    const uint16_t *lst = dlist + ((size_t)b * A + a) * len;
+    bool self = false;
+    for (int j0 = 0; j0 < c; j0 += 64) {
+      const int j = j0 + lane;
+      const int v = j < c ? (int)lst[j] : -1;
+      if (v > 0) row[v] = row[v] + w;                   // distinct customers: no conflicts
+      self = self || v == 0;
+    }
+    if (__ballot(self) != 0 && lane == 0) row[0] = row[0] + w;   // (0,0) collapses to one add
+    __syncthreads();
+  }
+  const bool clamp = clamp_max != nullptr;
+  const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
+  for (int i = lane; i < n; i += 64) {
+    float x = row[i];
+    if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
+    if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
+    g[i] = x;
+  }
+}
+
 }  // namespace daco
 
 using namespace daco;
@@ -145,9 +240,10 @@ extern "C" int daco_tour_costs(void *stream, int B, int n, int len, int A, const
 }
 
 extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A) {
-  if (B <= 0 || n <= 0 || A <= 0) return 0;
-  (void)len;
-  return align256((size_t)B * A * n * sizeof(uint32_t)) + align256((size_t)B * sizeof(int));
+  if (B <= 0 || n <= 0 || A <= 0 || len <= 0) return 0;
+  // nbr table | best-ant index | (directed) depot successor lists + their counters
+  return align256((size_t)B * A * n * sizeof(uint32_t)) + align256((size_t)B * sizeof(int)) +
+         align256((size_t)B * A * len * sizeof(uint16_t)) + align256((size_t)B * A * sizeof(int));
 }
 
 static int rows_per_block(int n) {
@@ -167,13 +263,34 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   }
   if ((clamp_min == nullptr) != (clamp_max == nullptr)) { set_error("daco_pheromone_update: clamp_min/clamp_max must both be given"); return DACO_E_BADARG; }
   if (n > DACO_MAX_NODES) { set_error("daco_pheromone_update: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
-  if (!symmetric) { set_error("daco_pheromone_update: directed (CVRP) deposit not built yet"); return DACO_E_BADARG; }
-  if (len != n) { set_error("daco_pheromone_update: symmetric deposit needs len == n"); return DACO_E_BADARG; }
+  if (symmetric && len != n) { set_error("daco_pheromone_update: symmetric deposit needs len == n"); return DACO_E_BADARG; }
+  if (!symmetric && len < 2) { set_error("daco_pheromone_update: directed deposit needs len >= 2"); return DACO_E_BADARG; }
+  if (!symmetric && nbr_in) { set_error("daco_pheromone_update: nbr input is for the symmetric deposit only"); return DACO_E_BADARG; }
   const size_t need = daco_pheromone_update_workspace_bytes(B, n, len, A);
   if (workspace_bytes < need) { set_error("daco_pheromone_update: workspace %zu < %zu", workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   const uint32_t *nbr = nbr_in ? nbr_in : (const uint32_t *)workspace;
   int *best = (int *)((char *)workspace + align256((size_t)B * A * n * sizeof(uint32_t)));
+  if (!symmetric) {
+    uint16_t *dlist = (uint16_t *)((char *)best + align256((size_t)B * sizeof(int)));
+    int *dcnt = (int *)((char *)dlist + align256((size_t)B * A * len * sizeof(uint16_t)));
+    if (hipMemsetAsync(dcnt, 0, (size_t)B * A * sizeof(int), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+    const long total = (long)B * (len - 1) * A;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, paths, (uint32_t *)workspace, dlist, dcnt);
+    if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
+    int R = (64 * 1024) / (4 * n);
+    if (R > 256) R = 256;
+    const int bpi = (n - 1 + R - 1) / R;
+    hipLaunchKernelGGL(deposit_directed_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, tau,
+                       (const uint32_t *)workspace, costs, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+    hipLaunchKernelGGL(deposit_depot_kernel, dim3(B), dim3(64), (size_t)n * sizeof(float), s, n, len, A, tau, dlist, dcnt,
+                       costs, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) { set_error("directed pheromone update launch: %s", hipGetErrorString(e2)); return DACO_E_HIP; }
+    return DACO_OK;
+  }
   if (!nbr_in) {
     const long total = (long)B * n * A;
     int blocks = (int)((total + 255) / 256);

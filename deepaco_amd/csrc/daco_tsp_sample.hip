@@ -37,6 +37,12 @@ struct SampleParams {
   long dist_bs;
   float *costs;          // [B][A] or null
   uint32_t *nbr;         // [B][A][n] prev | next << 16 (for the pheromone update) or null
+  // CVRP (cvrp/aco.py:138-205): node 0 = depot, variable-length routes
+  const float *demand;   // [B][n]
+  float capacity;
+  int Lmax;              // rows of paths (and Lmax-1 rows of logp)
+  int noise_steps;       // rows of the noise tensor
+  int32_t *lens;         // [B][A] rows used by each ant
 };
 
 template <class F, int... I>
@@ -95,9 +101,12 @@ struct Visited {
   __device__ inline void set(int bit) {       // bit is wave-uniform
     if (bit < 32) lo |= 1u << bit; else hi |= 1u << (bit - 32);
   }
+  template <int BIT> __device__ inline void set_if(bool c) {
+    if constexpr (BIT < 32) lo |= (c ? 1u : 0u) << BIT; else hi |= (c ? 1u : 0u) << (BIT - 32);
+  }
 };
 
-template <int VEC, int CH, int MODE, bool LOGP>
+template <int VEC, int CH, int MODE, bool LOGP, bool CVRP>
 __global__ void __launch_bounds__(256)
 tsp_sample_kernel(const SampleParams p) {
   constexpr int NJ = CH * VEC;                          // candidates per lane
@@ -112,15 +121,18 @@ tsp_sample_kernel(const SampleParams p) {
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
   const float *Pb = p.P + (size_t)b * n * ld + lane * VEC;
   const float *Rb = (MODE == DACO_RACE_PHILOX) ? p.R + (size_t)b * n * ld + lane * VEC : nullptr;
-  int64_t *path_out = p.paths + (size_t)b * n * A + a;
-  float *logp_out = LOGP ? p.logp + (size_t)b * (n - 1) * A + a : nullptr;
-  float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (n - 1) * A + a : nullptr;
-  const float *dist_b = p.costs ? p.dist + (size_t)b * p.dist_bs : nullptr;
-  uint16_t *nbr_a = p.nbr ? reinterpret_cast<uint16_t *>(p.nbr + ((size_t)b * A + a) * n) : nullptr;
+  const int rows = CVRP ? p.Lmax : n;                    // rows of paths for one instance
+  int64_t *path_out = p.paths + (size_t)b * rows * A + a;
+  float *logp_out = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
+  float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
+  const float *dist_b = (!CVRP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
+  uint16_t *nbr_a = (!CVRP && p.nbr) ? reinterpret_cast<uint16_t *>(p.nbr + ((size_t)b * A + a) * n) : nullptr;
+  const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
 
   // ---- start node
   int prev;
-  if (p.start) prev = (int)p.start[(size_t)b * A + a];
+  if constexpr (CVRP) prev = 0;
+  else if (p.start) prev = (int)p.start[(size_t)b * A + a];
   else if (p.fixed_start >= 0) prev = p.fixed_start;
   else {
     const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0);
@@ -135,15 +147,40 @@ tsp_sample_kernel(const SampleParams p) {
     const int bit = (vi >> 6) * VEC + (k % VEC);
     if (lane == (vi & 63)) vis.set(bit);
   };
-  mark(prev);
+  if constexpr (!CVRP) mark(prev);
   if (lane == 0) path_out[0] = prev;
+
+  // CVRP state: this lane's candidates' demands, customers left, load on the current route
+  float dem[CH][VEC];
+  int remaining = n - 1;
+  float used = 0.0f;
+  if constexpr (CVRP) {
+    static_for<NJ>([&](auto J) {
+      constexpr int j = J, c = j / VEC, v = j % VEC;
+      const int k = (c * 64 + lane) * VEC + v;
+      dem[c][v] = k < n ? demand_b[k] : __builtin_inff();
+    });
+    used = used + demand_b[0];
+  }
 
   u32x4 ublk = {0, 0, 0, 0};                            // SCAN: 256 cached uniforms per wave
   uint32_t ucur = 0;
-  bool infeasible = false;
+  bool infeasible = false, overflow = false;
   float cost = 0.0f, dpend = 0.0f;                      // fused tour length (edge added one step late)
 
-  for (int t = 1; t < n; ++t) {
+  int t = 1;
+  for (; CVRP ? (t < p.Lmax && !(remaining == 0 && prev == 0)) : (t < n); ++t) {
+    // ---- candidates closed at this step: visited, plus (CVRP) over capacity / depot rule
+    Visited blk = vis;
+    if constexpr (CVRP) {
+      if (MODE == DACO_RACE_NOISE && t - 1 >= p.noise_steps) { overflow = true; break; }
+      const float rem = p.capacity - used;
+      static_for<NJ>([&](auto J) {
+        constexpr int j = J;
+        blk.template set_if<j>(dem[j / VEC][j % VEC] > rem);          // strict, cvrp/aco.py:200
+      });
+      if (lane == 0 && prev == 0 && remaining > 0) blk.lo |= 1u;       // cvrp/aco.py:179
+    }
     // ---- stream the row of `prev`
     float row[CH][VEC];
     const float *rp = (MODE == DACO_RACE_PHILOX ? Rb : Pb) + (size_t)prev * ld;
@@ -164,7 +201,7 @@ tsp_sample_kernel(const SampleParams p) {
       float part = 0.0f;
       static_for<NJ>([&](auto J) {
         constexpr int j = J, c = j / VEC, v = j % VEC;
-        row[c][v] = vis.test<j>() ? 0.0f : row[c][v];
+        row[c][v] = blk.template test<j>() ? 0.0f : row[c][v];
         part = part + row[c][v];
       });
       const float incl = wave_scan_add(part);
@@ -213,7 +250,7 @@ tsp_sample_kernel(const SampleParams p) {
         // one Philox block serves candidates 4g..4g+3; a lane's VEC candidates share a block
         if (v == 0) r4 = rng_block(p.seed, p.iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
         const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
-        const float key = vis.test<j>() ? __builtin_inff() : Lk * row[c][v];
+        const float key = blk.template test<j>() ? __builtin_inff() : Lk * row[c][v];
         if (key < bk) { bk = key; bi = k; }
       });
       const KeyIdx r = wave_arg<false>(bk, bi);
@@ -227,17 +264,17 @@ tsp_sample_kernel(const SampleParams p) {
         for (int c = 0; c < CH; ++c) load_vec<VEC>(pp + c * 64 * VEC, pr[c]);
         static_for<NJ>([&](auto J) {
           constexpr int j = J;
-          part = part + (vis.test<j>() ? 0.0f : pr[j / VEC][j % VEC]);
+          part = part + (blk.template test<j>() ? 0.0f : pr[j / VEC][j % VEC]);
         });
         S = wave_sum(part);
         pchoice = p.P[((size_t)b * n + prev) * ld + choice];
       }
     } else {  // DACO_RACE_NOISE: the arithmetic of torch.multinomial's one-sample path
-      const float *q = p.noise + (((size_t)b * (n - 1) + (t - 1)) * A + a) * n;
+      const float *q = p.noise + (((size_t)b * (CVRP ? p.noise_steps : n - 1) + (t - 1)) * A + a) * n;
       float part = 0.0f;
       static_for<NJ>([&](auto J) {
         constexpr int j = J, c = j / VEC, v = j % VEC;
-        row[c][v] = vis.test<j>() ? 0.0f : row[c][v];
+        row[c][v] = blk.template test<j>() ? 0.0f : row[c][v];
         part = part + row[c][v];
       });
       for (int pass = 0; pass < p.norm_passes; ++pass) {
@@ -283,7 +320,13 @@ tsp_sample_kernel(const SampleParams p) {
         if (rs_out) rs_out[(size_t)(t - 1) * A] = S;
       }
     }
-    mark(choice);
+    if constexpr (CVRP) {
+      if (choice != 0) { mark(choice); --remaining; }
+      else used = 0.0f;
+      used = used + demand_b[choice];                  // scalar load
+    } else {
+      mark(choice);
+    }
     if (lane == 0) path_out[(size_t)t * A] = choice;
     if (dist_b) {                                        // fused gen_path_costs (wave-uniform)
       cost = cost + dpend;
@@ -292,6 +335,20 @@ tsp_sample_kernel(const SampleParams p) {
     if (nbr_a && lane < 2)                               // lane 0: next(prev)=choice, lane 1: prev(choice)=prev
       nbr_a[lane == 0 ? 2 * prev + 1 : 2 * choice] = (uint16_t)(lane == 0 ? choice : prev);
     prev = choice;
+  }
+  if constexpr (CVRP) {
+    // the reference steps every ant until the slowest one is done: a done ant keeps drawing
+    // the depot (probability 1), so its column is padded with 0 / log(1-eps)
+    if (!(remaining == 0 && prev == 0)) overflow = true;
+    if (lane == 0) {
+      if (p.lens) p.lens[(size_t)b * A + a] = t;
+      const float lp1 = clamp_log(1.0f);
+      for (int tt = t; tt < p.Lmax; ++tt) {
+        path_out[(size_t)tt * A] = 0;
+        if constexpr (LOGP) logp_out[(size_t)(tt - 1) * A] = lp1;
+      }
+    }
+    if (overflow && p.flags && lane == 0) atomicOr(p.flags + b, 2);
   }
   if (dist_b) {
     cost = cost + dpend;
@@ -303,16 +360,32 @@ tsp_sample_kernel(const SampleParams p) {
 }
 
 // ------------------------------------------------------------------ host dispatch
-template <int VEC, int CH>
+template <int VEC, int CH, bool CVRP>
 static hipError_t launch_sample(const SampleParams &sp, int mode, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 3) / 4;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
-#define DACO_LAUNCH(M, L) hipLaunchKernelGGL((tsp_sample_kernel<VEC, CH, M, L>), grid, block, 0, s, sp)
+#define DACO_LAUNCH(M, L) hipLaunchKernelGGL((tsp_sample_kernel<VEC, CH, M, L, CVRP>), grid, block, 0, s, sp)
   if (mode == DACO_SCAN) { if (logp) DACO_LAUNCH(DACO_SCAN, true); else DACO_LAUNCH(DACO_SCAN, false); }
   else if (mode == DACO_RACE_PHILOX) { if (logp) DACO_LAUNCH(DACO_RACE_PHILOX, true); else DACO_LAUNCH(DACO_RACE_PHILOX, false); }
   else { if (logp) DACO_LAUNCH(DACO_RACE_NOISE, true); else DACO_LAUNCH(DACO_RACE_NOISE, false); }
 #undef DACO_LAUNCH
   return hipGetLastError();
+}
+
+template <bool CVRP>
+static hipError_t dispatch_sample(const SampleParams &sp, int vec, int CH, int mode, bool lp, hipStream_t s) {
+  if (vec == 1) return launch_sample<1, 1, CVRP>(sp, mode, lp, s);
+  if (vec == 2) return launch_sample<2, 1, CVRP>(sp, mode, lp, s);
+  switch (CH) {
+    case 1: return launch_sample<4, 1, CVRP>(sp, mode, lp, s);
+    case 2: return launch_sample<4, 2, CVRP>(sp, mode, lp, s);
+    case 3: return launch_sample<4, 3, CVRP>(sp, mode, lp, s);
+    case 4: return launch_sample<4, 4, CVRP>(sp, mode, lp, s);
+    case 6: return launch_sample<4, 6, CVRP>(sp, mode, lp, s);
+    case 8: return launch_sample<4, 8, CVRP>(sp, mode, lp, s);
+    case 12: return launch_sample<4, 12, CVRP>(sp, mode, lp, s);
+    default: return launch_sample<4, 16, CVRP>(sp, mode, lp, s);
+  }
 }
 
 }  // namespace daco
@@ -378,22 +451,50 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
+  sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 0; sp.lens = nullptr;
   const bool lp = logp != nullptr;
   hipError_t e;
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
-  if (vec == 1) e = launch_sample<1, 1>(sp, mode, lp, s);
-  else if (vec == 2) e = launch_sample<2, 1>(sp, mode, lp, s);
-  else switch (CH) {
-    case 1: e = launch_sample<4, 1>(sp, mode, lp, s); break;
-    case 2: e = launch_sample<4, 2>(sp, mode, lp, s); break;
-    case 3: e = launch_sample<4, 3>(sp, mode, lp, s); break;
-    case 4: e = launch_sample<4, 4>(sp, mode, lp, s); break;
-    case 6: e = launch_sample<4, 6>(sp, mode, lp, s); break;
-    case 8: e = launch_sample<4, 8>(sp, mode, lp, s); break;
-    case 12: e = launch_sample<4, 12>(sp, mode, lp, s); break;
-    default: e = launch_sample<4, 16>(sp, mode, lp, s); break;
-  }
+  e = dispatch_sample<false>(sp, vec, CH, mode, lp, s);
   if (e != hipSuccess) { set_error("tsp_sample_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *tau, long tau_bstride,
+                                const float *eta, long eta_bstride, float alpha, float beta,
+                                const float *demand, float capacity, int mode, const float *noise,
+                                int noise_steps, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int Lmax,
+                                int64_t *paths, float *logp, int32_t *lens, int32_t *flags,
+                                void *workspace, size_t workspace_bytes) {
+  if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !demand || !paths || !workspace || Lmax < 2) {
+    set_error("daco_cvrp_sample: bad argument (B=%d n=%d A=%d Lmax=%d)", B, n, A, Lmax);
+    return DACO_E_BADARG;
+  }
+  if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
+  if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
+  if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
+  const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
+  if (workspace_bytes < need) { set_error("daco_cvrp_sample: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int vec = vec_for_n(n), CH = inst_chunks(n), ld = ld_alloc(n);
+  float *P = (float *)workspace;
+  float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
+  {
+    const long total = (long)B * n * ld;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta,
+                       eta_bstride, alpha, beta, P, R);
+  }
+  SampleParams sp;
+  sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
+  sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = nullptr; sp.fixed_start = 0;
+  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
+  sp.paths = paths; sp.logp = logp; sp.rowsum = nullptr; sp.flags = flags;
+  sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
+  sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
+  hipError_t e = dispatch_sample<true>(sp, vec, CH, mode, logp != nullptr, s);
+  if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }

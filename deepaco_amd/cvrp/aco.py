@@ -1,0 +1,156 @@
+"""ACO for CVRP with the class surface of the reference's cvrp/aco.py (and the sampler half of
+cvrp_nls/aco.py, which is the same code), running on MI355X.
+
+Node 0 is the depot.  Constructor arguments, method names and return layouts follow
+cvrp/aco.py:9-205: `gen_path` returns `paths` of shape (L, n_ants) where L is the length of the
+longest ant's route sequence (shorter ones are padded with the depot), `gen_path_costs` sums
+the open sequence, `update_pheronome` deposits on directed edges and floors at 1e-10.  The
+"adaptive elitist" baseline that shares the reference file (cvrp/aco.py:207-383, declared
+unrelated to DeepACO there) is out of scope: adaptive=True raises.
+Extra keyword-only arguments `sampler`, `seed` as in deepaco_amd/tsp/aco.py.
+"""
+import os
+import sys
+
+import torch
+
+try:
+    from deepaco_amd import engine
+except ImportError:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd import engine
+
+CAPACITY = 50
+
+
+class ACO():
+
+    def __init__(self,  # 0: depot
+                 distances,  # (n, n)
+                 demand,  # (n, )
+                 n_ants=20,
+                 decay=0.9,
+                 alpha=1,
+                 beta=1,
+                 elitist=False,
+                 min_max=False,
+                 pheromone=None,
+                 heuristic=None,
+                 min=None,
+                 device='cpu',
+                 adaptive=False,
+                 capacity=CAPACITY,
+                 *,
+                 sampler='scan',
+                 seed=None,
+                 ):
+        if adaptive:
+            raise NotImplementedError("the adaptive elitist baseline (cvrp/aco.py:207-383) is out of scope")
+        if not distances.is_cuda:
+            raise engine._lib.DacoError("deepaco_amd.cvrp.ACO needs tensors on a HIP device; there is no CPU path")
+        self.problem_size = len(distances)
+        self.distances = distances
+        self.capacity = capacity
+        self.demand = demand
+
+        self.n_ants = n_ants
+        self.decay = decay
+        self.alpha = alpha
+        self.beta = beta
+        self.elitist = elitist
+        self.min_max = min_max
+        self.adaptive = False
+
+        if min_max:
+            if min is not None:
+                assert min > 1e-9
+            else:
+                min = 0.1
+            self.min = min
+            self.max = None
+
+        if pheromone is None:
+            self.pheromone = torch.ones_like(self.distances)
+            if min_max:
+                self.pheromone = self.pheromone * self.min
+        else:
+            self.pheromone = pheromone
+
+        self.heuristic = 1 / distances if heuristic is None else heuristic
+
+        self.shortest_path = None
+        self.lowest_cost = float('inf')
+
+        self.device = distances.device
+        self.sampler = sampler
+        self.seed = torch.initial_seed() if seed is None else seed
+        self._calls = 0
+
+    # ------------------------------------------------------------------ cvrp/aco.py:66-69
+    def sample(self):
+        paths, log_probs = self.gen_path(require_prob=True)
+        costs = self.gen_path_costs(paths)
+        return costs, log_probs
+
+    # ------------------------------------------------------------------ cvrp/aco.py:72-104
+    @torch.no_grad()
+    def run(self, n_iterations):
+        for _ in range(n_iterations):
+            paths = self.gen_path(require_prob=False)
+            costs = self.gen_path_costs(paths)
+
+            best_cost, best_idx = costs.min(dim=0)
+            if best_cost < self.lowest_cost:
+                self.shortest_path = paths[:, best_idx]
+                self.lowest_cost = best_cost
+                if self.min_max:
+                    max = self.problem_size / self.lowest_cost
+                    if self.max is None:
+                        self.pheromone *= max / self.pheromone.max()
+                    self.max = max
+
+            self.update_pheronome(paths, costs)
+
+        return self.lowest_cost
+
+    # ------------------------------------------------------------------ cvrp/aco.py:106-130
+    @torch.no_grad()
+    def update_pheronome(self, paths, costs):
+        '''
+        Args:
+            paths: torch tensor with shape (seq_len, n_ants)
+            costs: torch tensor with shape (n_ants,)
+        '''
+        tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+        cmin = cmax = None
+        if self.min_max:
+            cmin = torch.full((1,), float(self.min), device=tau.device)
+            cmax = torch.as_tensor(self.max, dtype=torch.float32, device=tau.device).reshape(1).contiguous()
+        engine.pheromone_update_(tau, paths.contiguous().unsqueeze(0), costs.unsqueeze(0), self.decay, self.elitist,
+                                 False, cmin, cmax, floor=1e-10)
+        self.pheromone = tau[0]
+
+    update_pheromone = update_pheronome
+
+    # ------------------------------------------------------------------ cvrp/aco.py:132-136
+    @torch.no_grad()
+    def gen_path_costs(self, paths):
+        return engine.tour_costs(self.distances, paths.contiguous().unsqueeze(0), closed=False)[0]
+
+    # ------------------------------------------------------------------ cvrp/aco.py:138-205
+    def gen_path(self, require_prob=False, *, _noise=None):
+        mode = "race_noise" if _noise is not None else self.sampler
+        paths, logp, lens, flags = engine.cvrp_sample(
+            self.pheromone.detach(), self.heuristic.detach(), self.demand, self.capacity, self.n_ants, self.alpha,
+            self.beta, mode=mode, noise=None if _noise is None else _noise.unsqueeze(0), seed=self.seed,
+            it=self._calls, require_prob=require_prob, batch=1)
+        self._calls += 1
+        L = int(lens.max())                      # host sync (the reference syncs every step: check_done)
+        fl = int(flags[0])
+        if fl & 1:
+            raise ValueError("ACO.gen_path: a transition row had no feasible candidate")
+        if fl & 2:
+            raise RuntimeError("ACO.gen_path: route buffer / noise tensor too short")
+        if require_prob:
+            return paths[0, :L], logp[0, :L - 1]
+        return paths[0, :L]

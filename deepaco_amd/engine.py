@@ -103,6 +103,45 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
     return paths, logp, rowsum, flags
 
 
+def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
+                it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None):
+    """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
+    or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, lens [B,A], flags [B]); the
+    reference's result is paths[:, :lens.max()]."""
+    _require_gpu(tau, eta, demand, noise)
+    n = tau.shape[-1]
+    B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
+    dev = tau.device
+    tau, tbs = _bstride(tau, n)
+    eta, ebs = _bstride(eta, n)
+    demand = _f32c(demand)
+    if demand.dim() == 1:
+        demand = demand.unsqueeze(0).expand(B, n).contiguous()
+    m = MODES[mode] if isinstance(mode, str) else int(mode)
+    Lmax = Lmax or 2 * n + 1
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        paths = torch.empty((B, Lmax, n_ants), dtype=torch.int64, device=dev)
+        logp = torch.empty((B, Lmax - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
+        lens = torch.empty((B, n_ants), dtype=torch.int32, device=dev)
+        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        steps = 0
+        if noise is not None:
+            noise = _f32c(noise)
+            steps = noise.shape[-3]
+            noise = noise.view(B, steps, n_ants, n)
+        nbytes = L.daco_tsp_sample_workspace_bytes(B, n, m)
+        ws = _workspace(dev, nbytes, "sample")
+        rc = L.daco_cvrp_sample(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+                                float(beta), demand.data_ptr(), float(capacity), m,
+                                noise.data_ptr() if noise is not None else None, steps,
+                                int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF, Lmax,
+                                paths.data_ptr(), logp.data_ptr() if require_prob else None, lens.data_ptr(),
+                                flags.data_ptr(), ws.data_ptr(), ws.numel())
+    _lib.check(rc, "daco_cvrp_sample")
+    return paths, logp, lens, flags
+
+
 def tour_costs(dist, paths, closed=True):
     """ACO.gen_path_costs for a batch (tsp/aco.py:121-132; closed=False: cvrp/aco.py:133-136)."""
     _require_gpu(dist, paths)
@@ -143,6 +182,24 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
                                      ws.data_ptr(), ws.numel())
     _lib.check(rc, "daco_pheromone_update")
     return tau
+
+
+def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False):
+    """In-place batched 2-opt (tsp_nls/two_opt.py:41-49).  dist [B,n,n] or [n,n];
+    tours [B,T,n] or [T,n] int16/uint16 storage (values < 65536), one ROW per tour."""
+    _require_gpu(dist, tours)
+    n = dist.shape[-1]
+    assert tours.dtype in (torch.int16, torch.uint16) and tours.is_contiguous()
+    t3 = tours if tours.dim() == 3 else tours.unsqueeze(0)
+    B, T, _ = t3.shape
+    dist, dbs = _bstride(dist, n)
+    dev = tours.device
+    with torch.cuda.device(dev):
+        sweeps = torch.empty((B, T), dtype=torch.int32, device=dev) if want_sweeps else None
+        rc = _lib.lib().daco_two_opt(_stream(dev), B, T, n, dist.data_ptr(), dbs, t3.data_ptr(),
+                                     int(max_iterations), sweeps.data_ptr() if want_sweeps else None)
+    _lib.check(rc, "daco_two_opt")
+    return (tours, sweeps) if want_sweeps else tours
 
 
 class BatchedTSP:

@@ -1,0 +1,158 @@
+"""ACO for TSP + neural-guided local search with the class surface of the reference's
+tsp_nls/aco.py, running on MI355X.
+
+Differences from deepaco_amd/tsp/aco.py follow the reference: every ant starts at node 0
+(tsp_nls/aco.py:191), the transition row is renormalised explicitly before Categorical
+normalises it again (:206-207 -> norm_passes = 2 in parity mode), `sample()` returns
+`(costs, log_probs, paths)` (:80-90), `run()` applies the local search before costing (:114)
+and keeps `lowest_cost` as a Python float (:120).  The local search (2-opt and the NLS driver,
+:234-258) runs on the device: tours never make the reference's `.cpu().numpy()` round trip
+(:236-237).  `inference=True` selects, like the reference, the roulette sampler (:260-297) --
+here the wavefront prefix-scan kernel -- and `maxt = 10000` sweeps.
+"""
+import os
+import sys
+
+import torch
+
+try:
+    from deepaco_amd import engine
+except ImportError:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd import engine
+from deepaco_amd.tsp.aco import ACO as _TspACO
+from deepaco_amd.tsp_nls.two_opt import two_opt_device
+
+
+class ACO(_TspACO):
+
+    NORM_PASSES = 2
+    FIXED_START = 0
+
+    def __init__(self,
+                 distances,
+                 n_ants=20,
+                 decay=0.9,
+                 alpha=1,
+                 beta=1,
+                 elitist=False,
+                 min_max=False,
+                 pheromone=None,
+                 heuristic=None,
+                 min=None,
+                 two_opt=False,  # for compatibility
+                 device='cpu',
+                 local_search='nls',
+                 *,
+                 sampler='scan',
+                 seed=None,
+                 ):
+        if not distances.is_cuda and str(device) != 'cpu':
+            distances = distances.to(device)            # the reference moves them too (:29)
+        if pheromone is not None and not pheromone.is_cuda:
+            pheromone = pheromone.to(distances.device)
+        super().__init__(distances, n_ants, decay, alpha, beta, elitist, min_max, pheromone, heuristic, min,
+                         device, sampler=sampler, seed=seed)
+        assert local_search in [None, "2opt", "nls"]
+        self.local_search_type = '2opt' if two_opt else local_search
+        self._heuristic_dist = None
+
+    # ------------------------------------------------------------------ tsp_nls/aco.py:80-95
+    def sample(self, inference=False):
+        if inference:
+            paths = self.gen_path(require_prob=False, _sampler='scan')
+            costs = self.gen_path_costs(paths)
+            return costs, None, paths
+        paths, log_probs = self.gen_path(require_prob=True)
+        costs = self.gen_path_costs(paths)
+        return costs, log_probs, paths
+
+    def sample_2opt(self, paths):
+        paths = self.local_search(paths)
+        costs = self.gen_path_costs(paths)
+        return costs, paths
+
+    def local_search(self, paths, inference=False):
+        if self.local_search_type == "2opt":
+            paths = self.two_opt(paths, inference)
+        elif self.local_search_type == "nls":
+            paths = self.nls(paths, inference)
+        return paths
+
+    # ------------------------------------------------------------------ tsp_nls/aco.py:104-129
+    @torch.no_grad()
+    def run(self, n_iterations, inference=False):
+        for _ in range(n_iterations):
+            if inference:
+                paths = self.gen_path(require_prob=False, _sampler='scan')
+            else:
+                paths = self.gen_path(require_prob=False)
+
+            paths = self.local_search(paths, inference)
+            costs = self.gen_path_costs(paths)
+
+            best_cost, best_idx = costs.min(dim=0)
+            if best_cost < self.lowest_cost:
+                self.shortest_path = paths[:, best_idx]
+                self.lowest_cost = best_cost.item()
+                if self.min_max:
+                    max = self.problem_size / self.lowest_cost
+                    if self.max is None:
+                        self.pheromone *= max / self.pheromone.max()
+                    self.max = max
+
+            self.update_pheronome(paths, costs)
+
+        return self.lowest_cost
+
+    def gen_path(self, require_prob=False, *, _start=None, _noise=None, _sampler=None):
+        if _sampler is not None and _noise is None:
+            keep, self.sampler = self.sampler, _sampler
+            try:
+                return super().gen_path(require_prob, _start=_start, _noise=_noise)
+            finally:
+                self.sampler = keep
+        return super().gen_path(require_prob, _start=_start, _noise=_noise)
+
+    # ------------------------------------------------------------------ tsp_nls/aco.py:222-258
+    @property
+    def heuristic_dist(self):
+        """1 / (eta / rowmax(eta) + 1e-5): the perturbation matrix of the NLS (tsp_nls/aco.py:230-232)."""
+        if self._heuristic_dist is None:
+            h = self.heuristic.detach().to(torch.float32)
+            self._heuristic_dist = (1 / (h / h.max(-1, keepdim=True).values + 1e-5)).contiguous()
+        return self._heuristic_dist
+
+    def _tours(self, paths):
+        return paths.T.contiguous().to(torch.int16)
+
+    def _paths(self, tours):
+        return tours.T.contiguous().to(torch.int64)
+
+    def _tour_costs(self, tours):
+        return engine.tour_costs(self.distances, self._paths(tours).unsqueeze(0))[0]
+
+    @torch.no_grad()
+    def two_opt(self, paths, inference=False):
+        maxt = 10000 if inference else self.problem_size // 4
+        best = two_opt_device(self.distances, self._tours(paths), maxt)
+        return self._paths(best)
+
+    @torch.no_grad()
+    def nls(self, paths, inference=False, T_nls=10, T_p=20):
+        maxt = 10000 if inference else self.problem_size // 4
+        dist = self.distances.to(torch.float32)
+        best_paths = two_opt_device(dist, self._tours(paths), maxt)
+        best_costs = self._tour_costs(best_paths)
+        new_paths = best_paths
+
+        for _ in range(T_nls):
+            perturbed_paths = two_opt_device(self.heuristic_dist, new_paths, T_p)
+            new_paths = two_opt_device(dist, perturbed_paths, maxt)
+            new_costs = self._tour_costs(new_paths)
+
+            improved = new_costs < best_costs
+            best_paths = torch.where(improved.unsqueeze(1), new_paths, best_paths)
+            best_costs = torch.where(improved, new_costs, best_costs)
+
+        return self._paths(best_paths)

@@ -99,6 +99,33 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
                     void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
 
 /* ---------------------------------------------------------------------------------------------
+ * daco_cvrp_sample -- replaces the CVRP ACO.gen_path / pick_move / update_visit_mask /
+ * update_capacity_mask / check_done  (cvrp/aco.py:138-205 = cvrp_nls/aco.py:205-272)
+ *
+ * Node 0 is the depot, n counts the depot.  Every ant starts at the depot and draws from
+ * p_k = tau[prev][k]^alpha * eta[prev][k]^beta * visit_mask_k * capacity_mask_k until it is back
+ * at the depot with every customer served.  Masks as in the reference: visited customers
+ * closed; the depot closed only while the ant stands on it with customers left; candidates with
+ * demand_k > capacity - used closed (strict); used resets to 0 at the depot.
+ *   demand   [B][n] f32 (demand[0] = 0), capacity scalar
+ *   mode     as daco_tsp_sample (DACO_RACE_NOISE: noise [B][noise_steps][A][n], Categorical's
+ *            single normalisation)
+ *   paths    out [B][Lmax][A] int64; rows past an ant's route are 0 (the reference pads with the
+ *            depot until the slowest ant is done); Lmax <= 2n+1 always suffices
+ *   logp     out [B][Lmax-1][A] f32 or NULL (padding rows = log(1-eps), as in the reference)
+ *   lens     out [B][A] int32 or NULL: rows used by each ant; the reference's L = max(lens)
+ *   flags    out [B] int32 or NULL: bit 0 = a draw had no feasible candidate, bit 1 = Lmax or
+ *            the noise tensor was too short; caller zeroes it.
+ *   workspace daco_tsp_sample_workspace_bytes(B, n, mode)
+ */
+int daco_cvrp_sample(void *stream, int B, int n, int A,
+                     const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                     float alpha, float beta, const float *demand, float capacity, int mode,
+                     const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
+                     uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, int32_t *lens,
+                     int32_t *flags, void *workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
  * daco_tour_costs -- replaces ACO.gen_path_costs
  *   closed = 1: sum_k dist[u_k][u_{k-1}] over the closed tour     (tsp/aco.py:121-132),
  *               added in the order k = 1..len-1 and the closing edge dist[u_0][u_{len-1}] last
@@ -134,6 +161,22 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
                           int symmetric, const float *clamp_min, const float *clamp_max,
                           float floor_val, const uint32_t *nbr, void *workspace,
                           size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_two_opt -- replaces batched_two_opt_python / _two_opt_python / two_opt_once
+ *   tsp_nls/two_opt.py:6-49
+ * Best-improvement 2-opt on every tour until no move improves by more than 1e-6 or
+ * max_iterations sweeps were done (the reference's loop, including the final non-improving
+ * sweep in the count).  Bit-identical to the reference: same f32 expression order, strict
+ * minimum with ties to the first (i,j) in row-major order.
+ *   dist   [B][n][n] f32 (dist_bstride as above; need not be symmetric -- the NLS driver also
+ *          runs it on the perturbed matrix, tsp_nls/aco.py:230-232,248)
+ *   tours  in/out [B][T][n] uint16, one row per tour (the reference's numpy layout, note: the
+ *          transpose of `paths`)
+ *   sweeps out [B][T] int32 or NULL: sweeps performed per tour
+ */
+int daco_two_opt(void *stream, int B, int T, int n, const float *dist, long dist_bstride,
+                 uint16_t *tours, long max_iterations, int32_t *sweeps);
 
 #ifdef __cplusplus
 }

@@ -140,109 +140,117 @@ static inline float clamp_log(float pr) {
   return logf(pr);
 }
 
-/* ------------------------------------------------------------------ T1/T2/T3: race sampler, recorded noise
- * tsp/aco.py:134-177 (norm_passes = 1: Categorical normalises once) and
- * tsp_nls/aco.py:184-220 (norm_passes = 2: explicit dist/dist.sum(), then Categorical again).
- * action = argmax_k ((p_k / S) [/ S']) / q_k, first maximum wins (torch.argmax).
- * noise: [n-1][A][n]; paths: [n][A] int64; logp: [n-1][A] or NULL. */
-int orc_tsp_sample_noise(int n, int A, const float *P, const int64_t *start, const float *noise,
-                         int norm_passes, int64_t *paths, float *logp) {
-  int rc = ORC_OK;
-  float *p = (float *)malloc(sizeof(float) * n);
-  unsigned char *vis = (unsigned char *)malloc(n);
-  for (int a = 0; a < A; ++a) {
-    memset(vis, 0, n);
-    int prev = (int)start[a];
-    vis[prev] = 1;
-    paths[a] = prev;
-    for (int t = 1; t < n; ++t) {
-      const float *row = P + (long)prev * n;
-      const float *q = noise + ((long)(t - 1) * A + a) * n;
-      for (int k = 0; k < n; ++k) p[k] = vis[k] ? 0.0f : row[k];   /* row * mask, mask in {0,1} */
-      for (int pass = 0; pass < norm_passes; ++pass) {
-        float S = row_sum_tree(p, n);
-        for (int k = 0; k < n; ++k) p[k] = p[k] / S;
-      }
-      int best = -1; float bk = -INFINITY;
-      for (int k = 0; k < n; ++k) {
-        float key = p[k] / q[k];
-        if (key > bk) { bk = key; best = k; }
-      }
-      if (best < 0 || !(bk > 0.0f)) { rc = ORC_INFEASIBLE; best = best < 0 ? 0 : best; }
-      if (logp) logp[(long)(t - 1) * A + a] = clamp_log(norm_passes ? p[best] : p[best] / row_sum_tree(p, n));
-      vis[best] = 1;
-      paths[(long)t * A + a] = best;
-      prev = best;
-    }
+/* ------------------------------------------------------------------ the three draws
+ * Each takes the row of `prev` and a per-candidate `blocked` flag (visited / infeasible) and
+ * returns the chosen candidate (or -1: no feasible candidate).  *pr receives the probability
+ * of the choice as the reference's Categorical would report it (p_k / S, or the twice
+ * normalised value for the tsp_nls variant). */
+
+/* recorded noise: argmax_k ((p_k / S) [/ S']) / q_k, first maximum wins (torch.argmax);
+ * tsp/aco.py:171-177 (norm_passes = 1), tsp_nls/aco.py:205-211 (norm_passes = 2) */
+static int draw_noise(int n, const float *row, const unsigned char *blocked, const float *q,
+                      int norm_passes, float *p, float *pr) {
+  for (int k = 0; k < n; ++k) p[k] = blocked[k] ? 0.0f : row[k];   /* row * mask, mask in {0,1} */
+  for (int pass = 0; pass < norm_passes; ++pass) {
+    float S = row_sum_tree(p, n);
+    for (int k = 0; k < n; ++k) p[k] = p[k] / S;
   }
-  free(p); free(vis);
-  return rc;
+  int best = -1; float bk = -INFINITY;
+  for (int k = 0; k < n; ++k) {
+    float key = p[k] / q[k];
+    if (key > bk) { bk = key; best = k; }
+  }
+  if (best < 0 || !(bk > 0.0f)) return -1;
+  if (pr) *pr = norm_passes ? p[best] : p[best] / row_sum_tree(p, n);
+  return best;
 }
 
-/* ------------------------------------------------------------------ race sampler, in-kernel Philox noise
- * Same race, written division-free: argmin_k L_k * R[prev][k], R = 1/P, L_k = -log2(1-u_k),
- * u_k = component (k&3) of Philox(ctr = ((t<<12)|(k>>2), ant_gid, iter, STREAM_RACE), key = seed).
- * Ties -> smallest k.  start: fixed_start >= 0, else floor(n * u32 / 2^32) from STREAM_START. */
-int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t iter,
-                        uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
-  int rc = ORC_OK;
-  float *p = (float *)malloc(sizeof(float) * n);
-  unsigned char *vis = (unsigned char *)malloc(n);
-  for (int a = 0; a < A; ++a) {
-    uint32_t gid = ant_gid0 + (uint32_t)a, r4[4];
-    int prev = fixed_start;
-    if (prev < 0) {
-      rng_block(seed, iter, STREAM_START, gid, 0, r4);
-      prev = (int)(((uint64_t)r4[0] * (uint64_t)n) >> 32);
-    }
-    memset(vis, 0, n);
-    vis[prev] = 1;
-    paths[a] = prev;
-    for (int t = 1; t < n; ++t) {
-      const float *row = P + (long)prev * n;
-      int best = -1; float bk = INFINITY;
-      for (int g = 0; g * 4 < n; ++g) {
-        rng_block(seed, iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)g, r4);
-        for (int v = 0; v < 4; ++v) {
-          int k = g * 4 + v;
-          if (k >= n || vis[k]) continue;
-          float key = neg_log2_1m(u01(r4[v])) * (1.0f / row[k]);
-          if (key < bk) { bk = key; best = k; }
-        }
-      }
-      if (best < 0) { rc = ORC_INFEASIBLE; best = 0; }
-      if (logp) {
-        for (int k = 0; k < n; ++k) p[k] = vis[k] ? 0.0f : row[k];
-        logp[(long)(t - 1) * A + a] = clamp_log(row[best] / row_sum_tree(p, n));
-      }
-      vis[best] = 1;
-      paths[(long)t * A + a] = best;
-      prev = best;
+/* in-kernel Philox race, division-free: argmin_k L_k * (1/row[k]), L_k = -log2(1-u_k),
+ * u_k = component (k&3) of Philox(ctr = ((t<<12)|(k>>2), ant_gid, iter, STREAM_RACE)); ties ->
+ * smallest k. */
+static int draw_race(int n, const float *row, const unsigned char *blocked, uint64_t seed,
+                     uint64_t iter, uint32_t gid, int t, float *p, float *pr) {
+  uint32_t r4[4];
+  int best = -1; float bk = INFINITY;
+  for (int g = 0; g * 4 < n; ++g) {
+    rng_block(seed, iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)g, r4);
+    for (int v = 0; v < 4; ++v) {
+      int k = g * 4 + v;
+      if (k >= n || blocked[k]) continue;
+      float key = neg_log2_1m(u01(r4[v])) * (1.0f / row[k]);
+      if (key < bk) { bk = key; best = k; }
     }
   }
-  free(p); free(vis);
-  return rc;
+  if (best < 0) return -1;
+  if (pr) {
+    for (int k = 0; k < n; ++k) p[k] = blocked[k] ? 0.0f : row[k];
+    *pr = row[best] / row_sum_tree(p, n);
+  }
+  return best;
 }
 
-/* ------------------------------------------------------------------ I1 analogue: prefix-scan (roulette) sampler
- * tsp_nls/aco.py:260-275 draws r = U * sum(prob*mask) and walks the row until the running
- * sum reaches r.  Here the walk is a wave-shaped scan with a defined order:
- *   part[l]  = lane-partial sum (c asc, v asc) of masked p
- *   incl     = lane_scan(part) (the DPP-shaped inclusive scan above)
- *   S = incl[63];  r = u * S,  u = component ((t>>6)&3) of
- *       Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))   [256 uniforms per wave refill]
+/* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274:
+ *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane_scan(part)
+ *   S = incl[63];  r = max(u * S, denorm_min),  u = component ((t>>6)&3) of
+ *       Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))   [256 uniforms per refill]
  *   L = first lane with incl[L] >= r and part[L] > 0
  *   inside lane L: run = incl[L-1] (0 for L=0); walk its candidates in (c,v) order adding
- *   unvisited p>0; pick the first with run >= r, else the last unvisited p>0 of the lane. */
-int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t iter,
-                        uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
-  int rc = ORC_OK;
+ *   unblocked p>0; pick the first with run >= r, else the last unblocked p>0 of the lane. */
+static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
+                     uint64_t iter, uint32_t gid, int t, float *pr) {
   int vec = orc_vec_for_n(n), ld = orc_ld_for_n(n), ch = ld / (64 * vec);
+  float part[64], incl[64];
+  uint32_t r4[4];
+  for (int l = 0; l < 64; ++l) {
+    float s = 0.0f;
+    for (int c = 0; c < ch; ++c)
+      for (int v = 0; v < vec; ++v) {
+        int k = (c * 64 + l) * vec + v;
+        s = s + ((k < n && !blocked[k]) ? row[k] : 0.0f);
+      }
+    part[l] = s; incl[l] = s;
+  }
+  lane_scan(incl);
+  float S = incl[63];
+  rng_block(seed, iter, STREAM_SCAN, gid, (((uint32_t)t >> 8) << 6) + ((uint32_t)t & 63u), r4);
+  float r = u01(r4[(t >> 6) & 3]) * S;
+  if (!(r > 0.0f)) r = 1.401298464e-45f;               /* keep r > 0 if u*S underflows */
+  int L = -1;
+  for (int l = 0; l < 64; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
+  if (L < 0) return -1;
+  float run = L ? incl[L - 1] : 0.0f;
+  int best = -1, last = -1;
+  for (int c = 0; c < ch && best < 0; ++c)
+    for (int v = 0; v < vec; ++v) {
+      int k = (c * 64 + L) * vec + v;
+      if (k >= n || blocked[k] || !(row[k] > 0.0f)) continue;
+      run = run + row[k];
+      last = k;
+      if (run >= r) { best = k; break; }
+    }
+  if (best < 0) best = last;
+  if (best >= 0 && pr) *pr = row[best] / S;
+  return best;
+}
+
+enum { MODE_NOISE = 0, MODE_RACE = 1, MODE_SCAN = 2 };
+
+/* ------------------------------------------------------------------ T1/T2/T3: TSP tour construction
+ * tsp/aco.py:134-177 and tsp_nls/aco.py:184-220.  start: given array (noise mode), else
+ * fixed_start >= 0, else floor(n * u32 / 2^32) from STREAM_START.
+ * noise: [n-1][A][n]; paths: [n][A] int64; logp: [n-1][A] or NULL. */
+static int tsp_sample(int mode, int n, int A, const float *P, const int64_t *start,
+                      const float *noise, int norm_passes, uint64_t seed, uint64_t iter,
+                      uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
+  int rc = ORC_OK;
+  float *p = (float *)malloc(sizeof(float) * n);
   unsigned char *vis = (unsigned char *)malloc(n);
   for (int a = 0; a < A; ++a) {
     uint32_t gid = ant_gid0 + (uint32_t)a, r4[4];
-    int prev = fixed_start;
-    if (prev < 0) {
+    int prev;
+    if (start) prev = (int)start[a];
+    else if (fixed_start >= 0) prev = fixed_start;
+    else {
       rng_block(seed, iter, STREAM_START, gid, 0, r4);
       prev = (int)(((uint64_t)r4[0] * (uint64_t)n) >> 32);
     }
@@ -251,46 +259,32 @@ int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t it
     paths[a] = prev;
     for (int t = 1; t < n; ++t) {
       const float *row = P + (long)prev * n;
-      float part[64], incl[64];
-      for (int l = 0; l < 64; ++l) {
-        float s = 0.0f;
-        for (int c = 0; c < ch; ++c)
-          for (int v = 0; v < vec; ++v) {
-            int k = (c * 64 + l) * vec + v;
-            s = s + ((k < n && !vis[k]) ? row[k] : 0.0f);
-          }
-        part[l] = s; incl[l] = s;
-      }
-      lane_scan(incl);
-      float S = incl[63];
-      rng_block(seed, iter, STREAM_SCAN, gid, (((uint32_t)t >> 8) << 6) + ((uint32_t)t & 63u), r4);
-      float r = u01(r4[(t >> 6) & 3]) * S;
-      if (!(r > 0.0f)) r = 1.401298464e-45f;               /* keep r > 0 if u*S underflows */
-      int L = -1;
-      for (int l = 0; l < 64; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
-      int best = -1;
-      if (L >= 0) {
-        float run = L ? incl[L - 1] : 0.0f;
-        int last = -1;
-        for (int c = 0; c < ch && best < 0; ++c)
-          for (int v = 0; v < vec; ++v) {
-            int k = (c * 64 + L) * vec + v;
-            if (k >= n || vis[k] || !(row[k] > 0.0f)) continue;
-            run = run + row[k];
-            last = k;
-            if (run >= r) { best = k; break; }
-          }
-        if (best < 0) best = last;
-      }
-      if (best < 0) { rc = ORC_INFEASIBLE; best = 0; }
-      if (logp) logp[(long)(t - 1) * A + a] = clamp_log(row[best] / S);
+      float pr = 0.0f;
+      int best;
+      if (mode == MODE_NOISE) best = draw_noise(n, row, vis, noise + ((long)(t - 1) * A + a) * n, norm_passes, p, &pr);
+      else if (mode == MODE_RACE) best = draw_race(n, row, vis, seed, iter, gid, t, p, logp ? &pr : NULL);
+      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr);
+      if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
+      if (logp) logp[(long)(t - 1) * A + a] = clamp_log(pr);
       vis[best] = 1;
       paths[(long)t * A + a] = best;
       prev = best;
     }
   }
-  free(vis);
+  free(p); free(vis);
   return rc;
+}
+int orc_tsp_sample_noise(int n, int A, const float *P, const int64_t *start, const float *noise,
+                         int norm_passes, int64_t *paths, float *logp) {
+  return tsp_sample(MODE_NOISE, n, A, P, start, noise, norm_passes, 0, 0, 0, -1, paths, logp);
+}
+int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t iter,
+                        uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
+  return tsp_sample(MODE_RACE, n, A, P, NULL, NULL, 0, seed, iter, ant_gid0, fixed_start, paths, logp);
+}
+int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t iter,
+                        uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
+  return tsp_sample(MODE_SCAN, n, A, P, NULL, NULL, 0, seed, iter, ant_gid0, fixed_start, paths, logp);
 }
 
 /* ------------------------------------------------------------------ T4 / C5: tour costs
@@ -467,47 +461,48 @@ void orc_roulette_route(int n, const float *probmat, const double *uniforms, int
   free(mask); free(prob);
 }
 
-/* ------------------------------------------------------------------ C1-C4: CVRP sampler, recorded noise
+/* ------------------------------------------------------------------ C1-C4: CVRP tour construction
  * cvrp/aco.py:138-205.  Node 0 is the depot; n1 = customers + 1.  Every ant starts at the
- * depot; each step: p = P[prev] * visit_mask * capacity_mask, Categorical -> race as in TSP
- * (norm_passes = 1).  visit mask: visited customers 0; depot 1 unless the ant is at the depot
- * and customers remain (C2).  capacity: used = 0 at depot; used += demand[cur]; candidates
- * with demand > capacity - used masked (strict, C3).  An ant is done when it is at the depot
- * with every customer visited (C4); the reference keeps stepping until all ants are done, so a
- * done ant keeps choosing the depot (its only candidate) and its column is padded with 0.
- * noise: [Lmax-1][A][n1]; paths: [Lmax][A] zero-initialised by the caller.
+ * depot; each step: p = P[prev] * visit_mask * capacity_mask, Categorical -> one of the draws
+ * above (noise mode: norm_passes = 1).  visit mask: visited customers 0; depot 1 unless the
+ * ant is at the depot and customers remain (C2).  capacity: used = 0 at depot;
+ * used += demand[cur]; candidates with demand > capacity - used masked (strict, C3).  An ant
+ * is done when it is at the depot with every customer visited (C4); the reference keeps
+ * stepping until all ants are done, so a done ant keeps choosing the depot (its only
+ * candidate, probability 1) and its column is padded with 0.
+ * noise: [noise_steps][A][n1]; paths: [Lmax][A] zero-initialised by the caller.
  * Returns L (number of rows used, max over ants) or -1 on infeasible/overflow. */
-int orc_cvrp_sample_noise(int n1, int A, const float *P, const float *demand, float capacity,
-                          const float *noise, int noise_steps, int Lmax, int64_t *paths,
-                          float *logp) {
+int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand, float capacity,
+                    const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
+                    uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp) {
   float *p = (float *)malloc(sizeof(float) * n1);
   unsigned char *vis = (unsigned char *)malloc(n1);
+  unsigned char *blocked = (unsigned char *)malloc(n1);
   int *lens = (int *)malloc(sizeof(int) * A);
-  int L = 1;
-  for (int a = 0; a < A; ++a) {
+  int L = 1, fail = 0;
+  for (int a = 0; a < A && !fail; ++a) {
+    uint32_t gid = ant_gid0 + (uint32_t)a;
     memset(vis, 0, n1);
     int prev = 0, remaining = n1 - 1, len = 1;
     float used = 0.0f;
     used = used + demand[0];
     paths[a] = 0;
     while (!(remaining == 0 && prev == 0)) {
-      if (len >= Lmax || len - 1 >= noise_steps) { free(p); free(vis); free(lens); return -1; }
+      if (len >= Lmax || (mode == MODE_NOISE && len - 1 >= noise_steps)) { fail = 1; break; }
       const float *row = P + (long)prev * n1;
-      const float *q = noise + ((long)(len - 1) * A + a) * n1;
       float rem = capacity - used;
       for (int k = 0; k < n1; ++k) {
-        float vm = (k == 0) ? ((prev == 0 && remaining > 0) ? 0.0f : 1.0f) : (vis[k] ? 0.0f : 1.0f);
-        float cm = (demand[k] > rem) ? 0.0f : 1.0f;
-        p[k] = row[k] * vm * cm;
+        int visit_ok = (k == 0) ? !(prev == 0 && remaining > 0) : !vis[k];
+        int cap_ok = !(demand[k] > rem);
+        blocked[k] = !(visit_ok && cap_ok);
       }
-      float S = row_sum_tree(p, n1);
-      int best = -1; float bk = -INFINITY;
-      for (int k = 0; k < n1; ++k) {
-        float key = (p[k] / S) / q[k];
-        if (key > bk) { bk = key; best = k; }
-      }
-      if (best < 0 || !(bk > 0.0f)) { free(p); free(vis); free(lens); return -1; }
-      if (logp) logp[(long)(len - 1) * A + a] = clamp_log(p[best] / S);
+      float pr = 0.0f;
+      int best;
+      if (mode == MODE_NOISE) best = draw_noise(n1, row, blocked, noise + ((long)(len - 1) * A + a) * n1, 1, p, &pr);
+      else if (mode == MODE_RACE) best = draw_race(n1, row, blocked, seed, iter, gid, len, p, logp ? &pr : NULL);
+      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr);
+      if (best < 0) { fail = 1; break; }
+      if (logp) logp[(long)(len - 1) * A + a] = clamp_log(pr);
       if (best != 0) { vis[best] = 1; --remaining; }
       if (best == 0) used = 0.0f;
       used = used + demand[best];
@@ -519,9 +514,14 @@ int orc_cvrp_sample_noise(int n1, int A, const float *P, const float *demand, fl
     if (len > L) L = len;
   }
   /* a done ant keeps drawing the depot with probability 1 -> log(clamp(1)) = log(1-eps) */
-  if (logp)
+  if (logp && !fail)
     for (int a = 0; a < A; ++a)
       for (int k = lens[a]; k < L; ++k) logp[(long)(k - 1) * A + a] = clamp_log(1.0f);
-  free(p); free(vis); free(lens);
-  return L;
+  free(p); free(vis); free(blocked); free(lens);
+  return fail ? -1 : L;
+}
+int orc_cvrp_sample_noise(int n1, int A, const float *P, const float *demand, float capacity,
+                          const float *noise, int noise_steps, int Lmax, int64_t *paths,
+                          float *logp) {
+  return orc_cvrp_sample(MODE_NOISE, n1, A, P, demand, capacity, noise, noise_steps, 0, 0, 0, Lmax, paths, logp);
 }

@@ -1,0 +1,135 @@
+"""GPU parity tests for the CVRP rollout path (cvrp/aco.py:107-205) through the C ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def cvrp_instance(n, seed, B=1):
+    """cvrp/utils.py:9-22: depot (0.5,0.5), demands 1..9, diag 1e-10."""
+    g = torch.Generator().manual_seed(seed)
+    loc = torch.rand(B, n, 2, generator=g)
+    dem = torch.randint(1, 10, (B, n), generator=g).float()
+    allloc = torch.cat((torch.full((B, 1, 2), 0.5), loc), 1)
+    demand = torch.cat((torch.zeros(B, 1), dem), 1)
+    d = torch.cdist(allloc, allloc)
+    i = torch.arange(n + 1)
+    d[:, i, i] = 1e-10
+    tau = torch.rand(B, n + 1, n + 1, generator=g) + 0.1
+    eta = torch.rand(B, n + 1, n + 1, generator=g) + 1e-10
+    return d, demand, tau, eta
+
+
+@pytest.mark.parametrize("name", names("g1_cvrp"))
+def test_cvrp_golden(name):
+    from deepaco_amd.cvrp.aco import ACO
+    g = load_golden(name)
+    A = g["paths"].shape[1]
+    aco = ACO(T(g["distances"]), T(g["demand"]), n_ants=A, heuristic=T(g["heuristic"]), pheromone=T(g["pheromone"]),
+              capacity=float(g["capacity"]), device="cuda:0")
+    paths, logp = aco.gen_path(True, _noise=T(g["noise"]))
+    assert np.array_equal(paths.cpu().numpy(), g["paths"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    costs = aco.gen_path_costs(paths)
+    np.testing.assert_allclose(costs.cpu().numpy(), g["costs"], rtol=1e-5)
+    assert np.array_equal(costs.cpu().numpy(), oracle.tour_costs(g["distances"], g["paths"], closed=False))
+    # directed deposit (AS and elitist) bitwise vs the reference, fed the reference's costs
+    aco.update_pheronome(paths, T(g["costs"]))
+    assert np.array_equal(aco.pheromone.cpu().numpy().view(np.uint32), g["pheromone_as"].view(np.uint32))
+    el = ACO(T(g["distances"]), T(g["demand"]), n_ants=A, pheromone=T(g["pheromone"]), elitist=True,
+             capacity=float(g["capacity"]), device="cuda:0")
+    el.update_pheronome(paths, T(g["costs"]))
+    assert np.array_equal(el.pheromone.cpu().numpy().view(np.uint32), g["pheromone_elitist"].view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["scan", "race"])
+@pytest.mark.parametrize("n,A,B,cap", [(5, 3, 1, 50), (20, 9, 2, 50), (63, 5, 1, 30), (64, 5, 1, 50), (100, 17, 2, 50),
+                                        (128, 4, 1, 50), (200, 6, 1, 40), (300, 4, 1, 50)])
+def test_cvrp_philox_bit_exact_vs_oracle(mode, n, A, B, cap):
+    from deepaco_amd import engine
+    d, demand, tau, eta = cvrp_instance(n, 50 + n, B)
+    seed, it, gid0 = 987654321, 2, 77
+    paths, logp, lens, flags = engine.cvrp_sample(tau.to(dev()), eta.to(dev()), demand.to(dev()), cap, A, mode=mode,
+                                                  seed=seed, it=it, ant_gid0=gid0, require_prob=True)
+    assert int(flags.sum()) == 0
+    for b in range(B):
+        P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+        rp, rl, L = oracle.cvrp_sample_rng(P, demand[b].numpy(), cap, A, mode, seed, it, gid0 + b * A, require_prob=True)
+        assert L == int(lens[b].max())
+        assert np.array_equal(paths[b, :L].cpu().numpy(), rp), (mode, n, b)
+        assert bool((paths[b, L:] == 0).all())
+        np.testing.assert_allclose(logp[b, :L - 1].cpu().numpy(), rl, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["scan", "race"])
+def test_cvrp_full_size_properties(mode):
+    """CVRP-100 (config 4 shape): feasibility of every route, costs, deposit vs oracle."""
+    from deepaco_amd import engine
+    B, n, A, cap = 4, 100, 512, 50.0
+    d, demand, tau, eta = cvrp_instance(n, 4242, B)
+    D, DM, TA, ET = d.to(dev()), demand.to(dev()), tau.to(dev()), eta.to(dev())
+    paths, _, lens, flags = engine.cvrp_sample(TA, ET, DM, cap, A, mode=mode, seed=3, it=0)
+    assert int(flags.sum()) == 0
+    L = int(lens.max())
+    p = paths[:, :L]
+    # starts and ends at the depot; every customer exactly once
+    assert bool((p[:, 0] == 0).all()) and bool((p[:, -1] == 0).all())
+    counts = torch.zeros(B, A, n + 1, device=dev()).scatter_add_(2, p.transpose(1, 2), torch.ones(B, A, L, device=dev()))
+    assert bool((counts[:, :, 1:] == 1).all())
+    # capacity respected on every route: running load resets at the depot
+    dm = torch.gather(DM.unsqueeze(1).expand(B, A, n + 1), 2, p.transpose(1, 2))      # [B,A,L]
+    load = torch.zeros(B, A, device=dev())
+    worst = torch.zeros(B, A, device=dev())
+    for k in range(L):
+        at_depot = p[:, k] == 0
+        load = torch.where(at_depot, torch.zeros_like(load), load + dm[:, :, k])
+        worst = torch.maximum(worst, load)
+    assert float(worst.max()) <= cap
+    # no two consecutive depot visits before the ant is done
+    inner = (p[:, :-1] == 0) & (p[:, 1:] == 0)
+    ks = torch.arange(L - 1, device=dev()).view(1, L - 1, 1)
+    assert bool((~inner | (ks >= (lens.unsqueeze(1) - 1))).all())
+    costs = engine.tour_costs(D, p.contiguous(), closed=False)
+    ref = torch.stack([D[b][p[b, :-1], p[b, 1:]].double().sum(0) for b in range(B)])
+    torch.testing.assert_close(costs.double(), ref, rtol=1e-5, atol=0)
+    t2 = TA.clone().contiguous()
+    engine.pheromone_update_(t2, p.contiguous(), costs, 0.9, symmetric=False, floor=1e-10)
+    b = 2
+    rt = oracle.pheromone_update_cvrp(tau[b].numpy(), p[b].cpu().numpy(), costs[b].cpu().numpy(), 0.9)
+    assert np.array_equal(t2[b].cpu().numpy().view(np.uint32), rt.view(np.uint32))
+    # one instance bit-exact against the oracle at full size
+    P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+    rp, _, Lb = oracle.cvrp_sample_rng(P, demand[b].numpy(), cap, 64, mode, 3, 0, b * A)
+    assert np.array_equal(paths[b, :Lb, :64].cpu().numpy(), rp)
+
+
+def test_cvrp_class_run():
+    from deepaco_amd.cvrp.aco import ACO
+    d, demand, _, _ = cvrp_instance(50, 9)
+    aco = ACO(d[0].to(dev()), demand[0].to(dev()), n_ants=32, device="cuda:0")
+    costs, logp = aco.sample()
+    assert costs.shape == (32,) and logp.shape[1] == 32
+    first = float(costs.min())
+    low = aco.run(5)
+    assert float(low) <= first * 1.2 and aco.shortest_path[0] == 0
+    with pytest.raises(NotImplementedError):
+        ACO(d[0].to(dev()), demand[0].to(dev()), adaptive=True)

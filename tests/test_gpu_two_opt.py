@@ -1,0 +1,116 @@
+"""GPU parity tests for 2-opt / NLS (tsp_nls/two_opt.py, tsp_nls/aco.py:234-258) via the C ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def tsp_instance(n, seed, B=1):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand(B, n, 2, generator=g)
+    d = torch.cdist(c, c)
+    i = torch.arange(n)
+    d[:, i, i] = 1e9
+    return d
+
+
+@pytest.mark.parametrize("name", names("g4_twoopt"))
+def test_two_opt_golden(name):
+    from deepaco_amd import engine
+    g = load_golden(name)
+    d = T(g["dist"])
+    tours = T(g["tours"].astype(np.int16))
+    one = engine.two_opt_(d, tours.clone(), 1)
+    assert np.array_equal(one.cpu().numpy().astype(np.uint16), g["after_one"])
+    full, sweeps = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True)
+    assert np.array_equal(full.cpu().numpy().astype(np.uint16), g["after_full"])
+    assert np.array_equal(sweeps[0].cpu().numpy(), g["sweeps"])
+    cap = engine.two_opt_(d, tours.clone(), 5)
+    assert np.array_equal(cap.cpu().numpy().astype(np.uint16), g["after_cap5"])
+    # the module-level drop-in entry point with numpy in / numpy out, as the reference is called
+    from deepaco_amd.tsp_nls.two_opt import batched_two_opt_python
+    out = batched_two_opt_python(g["dist"], g["tours"], max_iterations=10000)
+    assert out.dtype == np.uint16 and np.array_equal(out, g["after_full"])
+
+
+@pytest.mark.parametrize("n,Tn,B,maxit", [(4, 3, 1, 50), (5, 4, 2, 50), (33, 6, 1, 1000), (128, 5, 1, 7), (129, 5, 2, 1000),
+                                           (257, 4, 1, 30), (500, 6, 1, 125)])
+def test_two_opt_vs_oracle(n, Tn, B, maxit):
+    from deepaco_amd import engine
+    d = tsp_instance(n, 7 + n, B)
+    rng = np.random.default_rng(n)
+    tours = np.stack([[rng.permutation(n) for _ in range(Tn)] for _ in range(B)]).astype(np.int16)
+    out, sweeps = engine.two_opt_(d.to(dev()), T(tours), maxit, want_sweeps=True)
+    for b in range(B):
+        ref, rs = oracle.two_opt_batch(d[b].numpy(), tours[b].astype(np.uint16), maxit)
+        assert np.array_equal(out[b].cpu().numpy().astype(np.uint16), ref), (n, b)
+        assert np.array_equal(sweeps[b].cpu().numpy(), rs)
+
+
+def test_two_opt_asymmetric_matrix_and_properties():
+    """The NLS runs 2-opt on a non-symmetric perturbation matrix; results stay permutations and
+    a converged tour is a fixed point."""
+    from deepaco_amd import engine
+    n, Tn = 200, 64
+    g = torch.Generator().manual_seed(5)
+    d = torch.rand(n, n, generator=g) + 0.01
+    rng = np.random.default_rng(1)
+    tours = np.stack([rng.permutation(n) for _ in range(Tn)]).astype(np.int16)
+    out = engine.two_opt_(d.to(dev()), T(tours), 10000).cpu().numpy().astype(np.int64)
+    ref, _ = oracle.two_opt_batch(d.numpy(), tours.astype(np.uint16), 10000)
+    assert np.array_equal(out.astype(np.uint16), ref)
+    assert np.array_equal(np.sort(out, axis=1), np.tile(np.arange(n), (Tn, 1)))
+    again = engine.two_opt_(d.to(dev()), T(out.astype(np.int16)), 10000).cpu().numpy()
+    assert np.array_equal(again, out)
+
+
+def test_nls_driver_matches_reference():
+    """ACO.nls / ACO.two_opt (tsp_nls/aco.py:234-258) against outputs captured from the reference."""
+    from deepaco_amd.tsp_nls.aco import ACO
+    g = load_golden("o4_nls_n40_a6")
+    aco = ACO(T(g["distances"]), n_ants=g["paths"].shape[1], heuristic=T(g["heuristic"]), device="cuda:0")
+    np.testing.assert_array_equal(aco.heuristic_dist.cpu().numpy(), g["heuristic_dist"])
+    out2 = aco.two_opt(T(g["paths"]))
+    assert np.array_equal(out2.cpu().numpy(), g["twoopt_paths"])
+    out = aco.nls(T(g["paths"]))
+    assert np.array_equal(out.cpu().numpy(), g["nls_paths"])
+    np.testing.assert_allclose(aco.gen_path_costs(out).cpu().numpy(), g["nls_costs"], rtol=1e-5)
+
+
+def test_nls_class_surface_and_recorded_noise():
+    """tsp_nls sampler through the class: start 0, double normalisation, (costs, log_probs, paths)."""
+    from deepaco_amd.tsp_nls.aco import ACO
+    g = load_golden("g1_nls_n50_a16")
+    aco = ACO(T(g["distances"]), n_ants=16, heuristic=T(g["heuristic"]), pheromone=T(g["pheromone"]),
+              device="cuda:0")
+    paths, logp = aco.gen_path(True, _start=T(g["start"]), _noise=T(g["noise"]))
+    assert np.array_equal(paths.cpu().numpy(), g["paths"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    costs, log_probs, p2 = aco.sample()
+    assert costs.shape == (16,) and log_probs.shape == (49, 16) and p2.shape == (50, 16)
+    assert bool((p2[0] == 0).all())
+    c2, p3 = aco.sample_2opt(p2)
+    assert bool((c2 <= costs + 1e-4).all())
+    low = aco.run(2)
+    assert isinstance(low, float) and low <= float(c2.min()) + 1e-3
+    low_inf = aco.run(1, inference=True)
+    assert low_inf <= low
