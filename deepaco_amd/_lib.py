@@ -29,7 +29,8 @@ SIGNATURES = {
     "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "daco_pheromone_update": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _f, _vp, _vp, _sz]),
     "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _u32, _i,
-                              _vp, _vp, _vp, _vp, _vp, _sz]),
+                              _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
 }
 

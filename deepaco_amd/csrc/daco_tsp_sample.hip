@@ -277,6 +277,8 @@ tsp_sample_kernel(const SampleParams p) {
         row[c][v] = blk.template test<j>() ? 0.0f : row[c][v];
         part = part + row[c][v];
       });
+      float S0 = 0.0f;                                    // un-normalised row sum (for backward)
+      if (LOGP && p.norm_passes > 0) S0 = wave_sum(part);
       for (int pass = 0; pass < p.norm_passes; ++pass) {
         S = wave_sum(part);
         part = 0.0f;
@@ -308,13 +310,14 @@ tsp_sample_kernel(const SampleParams p) {
       if constexpr (LOGP) {
         const int own = (choice / VEC) & 63;
         pchoice = readlane_f(bp, own);
-        if (p.norm_passes == 0) S = wave_sum(part); else S = 1.0f;
+        if (p.norm_passes == 0) S = wave_sum(part); else S = S0;
       }
     }
 
     choice = __builtin_amdgcn_readfirstlane(choice);
     if constexpr (LOGP) {
       if (lane == 0) {
+        // (noise mode with normalisation passes: pchoice is already the normalised probability)
         const float pr = (MODE == DACO_RACE_NOISE && p.norm_passes > 0) ? pchoice : pchoice / S;
         logp_out[(size_t)(t - 1) * A] = clamp_log(pr);
         if (rs_out) rs_out[(size_t)(t - 1) * A] = S;
@@ -465,7 +468,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
                                 const float *eta, long eta_bstride, float alpha, float beta,
                                 const float *demand, float capacity, int mode, const float *noise,
                                 int noise_steps, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int Lmax,
-                                int64_t *paths, float *logp, int32_t *lens, int32_t *flags,
+                                int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
                                 void *workspace, size_t workspace_bytes) {
   if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !demand || !paths || !workspace || Lmax < 2) {
     set_error("daco_cvrp_sample: bad argument (B=%d n=%d A=%d Lmax=%d)", B, n, A, Lmax);
@@ -491,7 +494,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
   sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = nullptr; sp.fixed_start = 0;
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
-  sp.paths = paths; sp.logp = logp; sp.rowsum = nullptr; sp.flags = flags;
+  sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
   hipError_t e = dispatch_sample<true>(sp, vec, CH, mode, logp != nullptr, s);

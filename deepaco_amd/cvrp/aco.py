@@ -140,11 +140,20 @@ class ACO():
     # ------------------------------------------------------------------ cvrp/aco.py:138-205
     def gen_path(self, require_prob=False, *, _noise=None):
         mode = "race_noise" if _noise is not None else self.sampler
-        paths, logp, lens, flags = engine.cvrp_sample(
-            self.pheromone.detach(), self.heuristic.detach(), self.demand, self.capacity, self.n_ants, self.alpha,
-            self.beta, mode=mode, noise=None if _noise is None else _noise.unsqueeze(0), seed=self.seed,
-            it=self._calls, require_prob=require_prob, batch=1)
+        noise = None if _noise is None else _noise.unsqueeze(0)
+        it = self._calls
         self._calls += 1
+        if require_prob and torch.is_grad_enabled() and self.heuristic.requires_grad:
+            from deepaco_amd.autograd import CvrpSampleFn
+            p_, lp_, lens, flags = CvrpSampleFn.apply(self.heuristic, self.pheromone.detach(), self.demand,
+                                                      float(self.capacity), self.n_ants, self.alpha, self.beta, mode,
+                                                      noise, self.seed, it)
+            paths, logp, lens = p_.unsqueeze(0), lp_.unsqueeze(0), lens.unsqueeze(0)
+        else:
+            paths, logp, _, lens, flags = engine.cvrp_sample(
+                self.pheromone.detach(), self.heuristic.detach(), self.demand, self.capacity, self.n_ants,
+                self.alpha, self.beta, mode=mode, noise=noise, seed=self.seed, it=it, require_prob=require_prob,
+                batch=1)
         L = int(lens.max())                      # host sync (the reference syncs every step: check_done)
         fl = int(flags[0])
         if fl & 1:

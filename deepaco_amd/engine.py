@@ -107,7 +107,7 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
                 it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None):
     """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
     or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, lens [B,A], flags [B]); the
-    reference's result is paths[:, :lens.max()]."""
+    reference's result is paths[:, :lens.max()].  Returns (paths, log_probs|None, rowsum|None, lens, flags)."""
     _require_gpu(tau, eta, demand, noise)
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
@@ -123,6 +123,7 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
     with torch.cuda.device(dev):
         paths = torch.empty((B, Lmax, n_ants), dtype=torch.int64, device=dev)
         logp = torch.empty((B, Lmax - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
+        rowsum = torch.ones((B, Lmax - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
         lens = torch.empty((B, n_ants), dtype=torch.int32, device=dev)
         flags = torch.zeros((B,), dtype=torch.int32, device=dev)
         steps = 0
@@ -136,10 +137,38 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
                                 float(beta), demand.data_ptr(), float(capacity), m,
                                 noise.data_ptr() if noise is not None else None, steps,
                                 int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF, Lmax,
-                                paths.data_ptr(), logp.data_ptr() if require_prob else None, lens.data_ptr(),
+                                paths.data_ptr(), logp.data_ptr() if require_prob else None,
+                                rowsum.data_ptr() if require_prob else None, lens.data_ptr(),
                                 flags.data_ptr(), ws.data_ptr(), ws.numel())
     _lib.check(rc, "daco_cvrp_sample")
-    return paths, logp, lens, flags
+    return paths, logp, rowsum, lens, flags
+
+
+def sample_backward(tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, demand=None, capacity=0.0):
+    """Gradient of sum(grad_logp * log_probs) w.r.t. eta -> [B,n,n] (autograd through
+    Categorical.log_prob in tsp/aco.py:174-176 / cvrp/aco.py:171-173).  CVRP: pass lens, demand, capacity."""
+    _require_gpu(tau, eta, paths, rowsum, grad_logp)
+    n = tau.shape[-1]
+    B, rows, A = paths.shape
+    tau, tbs = _bstride(tau, n)
+    eta, ebs = _bstride(eta, n)
+    paths = paths.contiguous()
+    rowsum, grad_logp = _f32c(rowsum), _f32c(grad_logp)
+    dev = paths.device
+    if demand is not None:
+        demand = _f32c(demand)
+        if demand.dim() == 1:
+            demand = demand.unsqueeze(0).expand(B, n).contiguous()
+        lens = lens.contiguous()
+    with torch.cuda.device(dev):
+        grad = torch.zeros((B, n, n), dtype=torch.float32, device=dev)
+        rc = _lib.lib().daco_sample_backward(_stream(dev), B, n, A, rows, tau.data_ptr(), tbs, eta.data_ptr(), ebs,
+                                             float(alpha), float(beta), paths.data_ptr(), rowsum.data_ptr(),
+                                             grad_logp.data_ptr(), lens.data_ptr() if demand is not None else None,
+                                             demand.data_ptr() if demand is not None else None, float(capacity),
+                                             grad.data_ptr())
+    _lib.check(rc, "daco_sample_backward")
+    return grad
 
 
 def tour_costs(dist, paths, closed=True):

@@ -170,12 +170,22 @@ class ACO():
         fixed = self.FIXED_START
         if _noise is not None and start is None and fixed < 0:
             raise ValueError("noise injection needs the start nodes too (_start)")
+        start = None if start is None else start.view(1, -1)
+        noise = None if _noise is None else _noise.unsqueeze(0)
+        it = self._calls
+        self._calls += 1
+        if require_prob and torch.is_grad_enabled() and self.heuristic.requires_grad:
+            # log_probs carry gradient to the heuristic (the reference: autograd through Categorical)
+            from deepaco_amd.autograd import TspSampleFn
+            paths, logp, flags = TspSampleFn.apply(self.heuristic, self.pheromone.detach(), self.n_ants, self.alpha,
+                                                   self.beta, mode, self.NORM_PASSES, start, fixed, noise,
+                                                   self.seed, it)
+            self._last_flags = flags
+            return paths, logp
         paths, logp, rowsum, flags = engine.tsp_sample(
             self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha, self.beta, mode=mode,
-            norm_passes=self.NORM_PASSES, start=None if start is None else start.view(1, -1),
-            fixed_start=fixed, noise=None if _noise is None else _noise.unsqueeze(0),
-            seed=self.seed, it=self._calls, require_prob=require_prob, batch=1)
-        self._calls += 1
+            norm_passes=self.NORM_PASSES, start=start, fixed_start=fixed, noise=noise,
+            seed=self.seed, it=it, require_prob=require_prob, batch=1)
         self._last_flags = flags
         if require_prob:
             return paths[0], logp[0]

@@ -113,6 +113,7 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *   paths    out [B][Lmax][A] int64; rows past an ant's route are 0 (the reference pads with the
  *            depot until the slowest ant is done); Lmax <= 2n+1 always suffices
  *   logp     out [B][Lmax-1][A] f32 or NULL (padding rows = log(1-eps), as in the reference)
+ *   rowsum   out [B][Lmax-1][A] f32 or NULL (with logp): S per draw, for daco_sample_backward
  *   lens     out [B][A] int32 or NULL: rows used by each ant; the reference's L = max(lens)
  *   flags    out [B] int32 or NULL: bit 0 = a draw had no feasible candidate, bit 1 = Lmax or
  *            the noise tensor was too short; caller zeroes it.
@@ -122,8 +123,24 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                      float alpha, float beta, const float *demand, float capacity, int mode,
                      const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
-                     uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, int32_t *lens,
-                     int32_t *flags, void *workspace, size_t workspace_bytes);
+                     uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
+                     int32_t *lens, int32_t *flags, void *workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_sample_backward -- replaces autograd through ACO.gen_path(require_prob=True)
+ *   (tsp/aco.py:154-176, cvrp/aco.py:153-173; consumed by the REINFORCE losses in
+ *    tsp/train.ipynb:45-49, tsp_nls/train.py:31-44, cvrp/train.ipynb:45-51)
+ * grad_eta[b][i][k] += sum over draws (t,a) made from node i of
+ *     grad_logp[t][a] * beta * ( [k = action] / eta_ik - p_k / (eta_ik * S_ta) ),  0 where the
+ * probability was clamped.  rows = n (TSP) or Lmax (CVRP: pass demand, capacity and lens; NULL
+ * demand selects TSP).  rowsum is what the sampler wrote.  grad_eta [B][n][n] must be zeroed (or
+ * hold a gradient to accumulate into).  f32 hardware atomics: reproducible to rounding.
+ */
+int daco_sample_backward(void *stream, int B, int n, int A, int rows,
+                         const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                         float alpha, float beta, const int64_t *paths, const float *rowsum,
+                         const float *grad_logp, const int32_t *lens, const float *demand,
+                         float capacity, float *grad_eta);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_tour_costs -- replaces ACO.gen_path_costs

@@ -322,6 +322,49 @@ def gen_cvrp(cvrp_aco):
              decay=np.float32(aco.decay), pheromone_as=tau_as, pheromone_elitist=el.pheromone)
 
 
+def gen_grads(tsp_aco, cvrp_aco):
+    """G3: gradient of the REINFORCE loss (tsp/train.ipynb:45-49) w.r.t. the heuristic matrix."""
+    for name, n, A, seed, beta in [("tsp_n20_a8", 20, 8, 91, 1), ("tsp_n40_a10_beta2", 40, 10, 92, 2)]:
+        coords = rand_instance(n, seed)
+        dist = tsp_dist(coords)
+        g = torch.Generator().manual_seed(seed + 1000)
+        heu = (torch.rand(n, n, generator=g) ** 2 + 1e-3).requires_grad_(True)
+        phe = torch.rand(n, n, generator=g) + 0.2
+        torch.manual_seed(seed)
+        aco = tsp_aco.ACO(dist, n_ants=A, heuristic=heu, pheromone=phe, beta=beta)
+        with NoiseTap() as tap:
+            costs, logp = aco.sample()
+        paths_q = torch.stack(tap.q)
+        loss = torch.sum((costs - costs.mean()) * logp.sum(dim=0)) / A
+        loss.backward()
+        # recover the tours (sample() does not return them): replay with the recorded noise
+        torch.manual_seed(seed)
+        aco2 = tsp_aco.ACO(dist, n_ants=A, heuristic=heu.detach(), pheromone=phe, beta=beta)
+        paths = aco2.gen_path()
+        save("g3_grad_" + name, distances=dist, heuristic=heu.detach(), pheromone=phe, beta=np.float32(beta),
+             start=paths[0], noise=paths_q, paths=paths, log_probs=logp.detach(), costs=costs,
+             loss=loss.detach(), grad=heu.grad)
+    n, A, seed, cap = 20, 8, 95, 30
+    g = torch.Generator().manual_seed(seed)
+    loc = torch.rand(n, 2, generator=g)
+    dem = torch.randint(1, 10, (n,), generator=g)
+    allloc = torch.cat((torch.tensor([[0.5, 0.5]]), loc), 0)
+    demand = torch.cat((torch.zeros(1), dem.float()))
+    dist = torch.norm(allloc[:, None] - allloc, dim=2, p=2)
+    dist[torch.arange(n + 1), torch.arange(n + 1)] = 1e-10
+    heu = (torch.rand(n + 1, n + 1, generator=g) + 1e-3).requires_grad_(True)
+    torch.manual_seed(seed)
+    aco = cvrp_aco.ACO(dist, demand, n_ants=A, heuristic=heu, capacity=cap)
+    with NoiseTap() as tap:
+        paths, logp = aco.gen_path(True)
+    costs = aco.gen_path_costs(paths)
+    loss = torch.sum((costs - costs.mean()) * logp.sum(dim=0)) / A
+    loss.backward()
+    save("g3_grad_cvrp_n20_a8", distances=dist, demand=demand, capacity=np.float32(cap), heuristic=heu.detach(),
+         pheromone=aco.pheromone, noise=torch.stack(tap.q), paths=paths, log_probs=logp.detach(), costs=costs,
+         loss=loss.detach(), grad=heu.grad)
+
+
 def main():
     torch.set_num_threads(1)
     print("reference:", REF)
@@ -334,6 +377,7 @@ def main():
     print("tsp_nls (G1/G4/O4/G6)"); gen_nls(nls_aco, two_opt)
     cvrp_aco = load_ref("cvrp", "aco", "ref_cvrp_aco")
     print("CVRP (G1/G2)"); gen_cvrp(cvrp_aco)
+    print("gradients (G3)"); gen_grads(tsp_aco, cvrp_aco)
 
 
 if __name__ == "__main__":

@@ -68,7 +68,7 @@ def test_cvrp_philox_bit_exact_vs_oracle(mode, n, A, B, cap):
     from deepaco_amd import engine
     d, demand, tau, eta = cvrp_instance(n, 50 + n, B)
     seed, it, gid0 = 987654321, 2, 77
-    paths, logp, lens, flags = engine.cvrp_sample(tau.to(dev()), eta.to(dev()), demand.to(dev()), cap, A, mode=mode,
+    paths, logp, _, lens, flags = engine.cvrp_sample(tau.to(dev()), eta.to(dev()), demand.to(dev()), cap, A, mode=mode,
                                                   seed=seed, it=it, ant_gid0=gid0, require_prob=True)
     assert int(flags.sum()) == 0
     for b in range(B):
@@ -87,7 +87,7 @@ def test_cvrp_full_size_properties(mode):
     B, n, A, cap = 4, 100, 512, 50.0
     d, demand, tau, eta = cvrp_instance(n, 4242, B)
     D, DM, TA, ET = d.to(dev()), demand.to(dev()), tau.to(dev()), eta.to(dev())
-    paths, _, lens, flags = engine.cvrp_sample(TA, ET, DM, cap, A, mode=mode, seed=3, it=0)
+    paths, _, _, lens, flags = engine.cvrp_sample(TA, ET, DM, cap, A, mode=mode, seed=3, it=0)
     assert int(flags.sum()) == 0
     L = int(lens.max())
     p = paths[:, :L]

@@ -135,3 +135,25 @@ def test_cvrp_sampler_and_update(name):
     for key, el in (("pheromone_as", False), ("pheromone_elitist", True)):
         out = oracle.pheromone_update_cvrp(g["pheromone"], paths, g["costs"], float(g["decay"]), el)
         assert np.array_equal(out.view(np.uint32), g[key].view(np.uint32)), key
+
+
+@pytest.mark.parametrize("name", names("g3_grad_tsp"))
+def test_grad_closed_form_tsp(name):
+    """The closed-form gradient (oracle/grad.py) equals heu_mat.grad captured from the reference."""
+    from oracle import grad as ograd
+    g = load_golden(name)
+    A = g["paths"].shape[1]
+    G = np.tile(((g["costs"] - g["costs"].mean()) / A)[None, :], (g["paths"].shape[0] - 1, 1))
+    out = ograd.tsp_grad(g["pheromone"], g["heuristic"], 1, float(g["beta"]), g["paths"], G)
+    scale = np.abs(g["grad"]).max()
+    np.testing.assert_allclose(out, g["grad"], rtol=2e-4, atol=2e-6 * scale)
+
+
+def test_grad_closed_form_cvrp():
+    from oracle import grad as ograd
+    g = load_golden("g3_grad_cvrp_n20_a8")
+    A = g["paths"].shape[1]
+    G = np.tile(((g["costs"] - g["costs"].mean()) / A)[None, :], (g["paths"].shape[0] - 1, 1))
+    out = ograd.cvrp_grad(g["pheromone"], g["heuristic"], 1, 1, g["demand"], float(g["capacity"]), g["paths"], G)
+    scale = np.abs(g["grad"]).max()
+    np.testing.assert_allclose(out, g["grad"], rtol=2e-4, atol=2e-6 * scale)
