@@ -1,0 +1,231 @@
+// daco_gnn.hip -- heuristic network forward (inference): 12-layer edge GNN + MLP head.
+//
+// Reference behaviour replaced: EmbNet.forward tsp/net.py:27-45, MLP/ParNet.forward :59-66,74-75,
+// Net.forward :84-88 (and the feats=1 variants in tsp_nls/net.py, cvrp/net.py), eval mode
+// (BatchNorm with running statistics, folded into a per-channel scale/shift by the host).
+//
+// The reference issues ~25 aten/PyG ops per layer.  Here one launch per layer does everything:
+//   edge workgroups : w1 = We*w0 + be on the matrix cores (v_mfma_f32_32x32x2_f32: a 32-edge x
+//                     32-channel tile per wave, K = 32 -> 16 MFMAs, exact f32), then in the MFMA
+//                     output layout  w' = w0 + silu(bn_e(w1 + x3[src] + x4[dst]))
+//   node workgroups : agg_i = mean over i's out-edges of sigmoid(w0_e)*x2[dst_e] (CSR order, no
+//                     atomics), x' = x0 + silu(bn_v(x1 + agg)), and -- fused -- the NEXT layer's
+//                     four node linears x1..x4 = W*x' + b, so no separate node-linear launch.
+// Activations ping-pong between two workspace buffers.  The head (3 linears, silu, silu, sigmoid)
+// chains three MFMA GEMMs per 32-edge tile with an LDS transpose between them.
+// Everything is f32 (bf16/fp16 MFMA would break 1e-5 parity through 12 residual layers).
+#include "daco_device.h"
+#include "../../include/deepaco_hip.h"
+
+namespace daco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int U = 32;                       // units
+
+// ---- parameter block layout (floats), built by the host (deepaco_amd/net.py pack_params)
+// [0]               v_lin0.W [32][feats] | v_lin0.b [32]
+// then              e_lin0.W [32]        | e_lin0.b [32]
+// then 12 x layer:  WvT [32 c][128 c']  (x1|x2|x3|x4 outputs, transposed) | bv [128]
+//                   We [32 o][32 c] | be [32] | bn_v scale[32] shift[32] | bn_e scale[32] shift[32]
+// then head:        W1 [32][32] b1 [32] W2 [32][32] b2 [32] W3 [32] b3 [1]
+constexpr int LAYER_FLOATS = 32 * 128 + 128 + 32 * 32 + 32 + 4 * 32;
+__host__ __device__ inline size_t off_layer(int feats, int l) { return (size_t)32 * feats + 32 + 64 + (size_t)l * LAYER_FLOATS; }
+__host__ __device__ inline size_t off_head(int feats) { return off_layer(feats, 12); }
+constexpr int HEAD_FLOATS = 2 * (32 * 32 + 32) + 32 + 1;
+
+__device__ inline float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// x = silu(v_lin0(x)); X1234(0) = layer-0 node linears.  8 nodes per 256-thread workgroup.
+__global__ void __launch_bounds__(256)
+gnn_node_init_kernel(int n, int feats, const float *xin, const float *params, float *x, float *X) {
+  __shared__ float xs[8][U];
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  const float *W = params, *b = params + 32 * feats;
+  float v = 0.0f;
+  if (i < n) {
+    v = b[o];
+    for (int f = 0; f < feats; ++f) v = fmaf(xin[(size_t)i * feats + f], W[o * feats + f], v);
+    v = silu(v);
+    x[(size_t)i * U + o] = v;
+  }
+  xs[il][o] = v;
+  __syncthreads();
+  if (i >= n) return;
+  const float *WT = params + off_layer(feats, 0), *bv = WT + 32 * 128;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float acc = bv[q * 32 + o];
+    for (int c = 0; c < U; ++c) acc = fmaf(xs[il][c], WT[c * 128 + q * 32 + o], acc);
+    X[(size_t)i * 128 + q * 32 + o] = acc;
+  }
+}
+
+// w = silu(e_lin0(edge_attr))
+__global__ void __launch_bounds__(256)
+gnn_edge_init_kernel(int E, int feats, const float *attr, const float *params, float *w) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)E * U) return;
+  const int e = (int)(idx >> 5), o = (int)(idx & 31);
+  const float *W = params + 32 * feats + 32, *b = W + 32;
+  w[idx] = silu(fmaf(attr[e], W[o], b[o]));
+}
+
+// one 32-edge x 32-channel tile: acc = Wm * a-rows, with the K split (0..15 | 16..31) over the two
+// lane halves.  `rowptr_` points at this lane's edge row (32 floats).
+__device__ inline f32x16 tile_gemm(const float *row, const float *Wm, int lane) {
+  const int h = lane >> 5, o = lane & 31;
+  float a[16], bw[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4 *>(row + h * 16 + q * 4);
+    a[q * 4 + 0] = t.x; a[q * 4 + 1] = t.y; a[q * 4 + 2] = t.z; a[q * 4 + 3] = t.w;
+    const float4 u = *reinterpret_cast<const float4 *>(Wm + o * U + h * 16 + q * 4);
+    bw[q * 4 + 0] = u.x; bw[q * 4 + 1] = u.y; bw[q * 4 + 2] = u.z; bw[q * 4 + 3] = u.w;
+  }
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bw[kk], acc, 0, 0, 0);
+  return acc;
+}
+// MFMA 32x32 output layout: register r of lane l holds D[row][col], col = l & 31,
+__device__ inline int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__global__ void __launch_bounds__(256)
+gnn_layer_kernel(int n, int E, int feats, int layer, int edge_blocks, const int *src, const int *dst, const int *rowptr,
+                 const int *perm, const float *params, const float *x0, const float *X, const float *w0,
+                 float *x1out, float *Xnext, float *w1out) {
+  const float *lp = params + off_layer(feats, layer);
+  const float *We = lp + 32 * 128 + 128, *be = We + 32 * 32;
+  const float *sv = be + 32, *tv = sv + 32, *se = tv + 32, *te = se + 32;
+  if ((int)blockIdx.x < edge_blocks) {
+    // ---------------- edge update: 4 waves, one 32-edge tile each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = (blockIdx.x * 4 + wave) * 32;
+    if (e0 >= E) return;
+    const int o = lane & 31;
+    const int er = min(e0 + o, E - 1);
+    const f32x16 acc = tile_gemm(w0 + (size_t)er * U, We, lane);
+    const int s_l = src[er], d_l = dst[er];              // lane (l&31) holds its edge's endpoints
+    const float bo = be[o], sc = se[o], sh = te[o];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = drow(r, lane), e = e0 + row;
+      const int s = __shfl(s_l, row), d = __shfl(d_l, row);
+      if (e < E) {
+        const float z = acc[r] + bo + X[(size_t)s * 128 + 64 + o] + X[(size_t)d * 128 + 96 + o];
+        const float y = fmaf(z, sc, sh);
+        w1out[(size_t)e * U + o] = w0[(size_t)e * U + o] + silu(y);
+      }
+    }
+    return;
+  }
+  // ---------------- node update (+ next layer's node linears): 8 nodes per workgroup
+  __shared__ float xs[8][U];
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = ((int)blockIdx.x - edge_blocks) * 8 + il;
+  float xn = 0.0f;
+  if (i < n) {
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    float agg = 0.0f;
+    for (int q = lo; q < hi; ++q) {
+      const int e = perm ? perm[q] : q;
+      agg = fmaf(sigmoidf(w0[(size_t)e * U + o]), X[(size_t)dst[e] * 128 + 32 + o], agg);
+    }
+    agg = agg / (float)max(hi - lo, 1);
+    const float y = fmaf(X[(size_t)i * 128 + o] + agg, sv[o], tv[o]);
+    xn = x0[(size_t)i * U + o] + silu(y);
+    x1out[(size_t)i * U + o] = xn;
+  }
+  if (layer == 11) return;
+  xs[il][o] = xn;
+  __syncthreads();
+  if (i >= n) return;
+  const float *WT = params + off_layer(feats, layer + 1), *bv = WT + 32 * 128;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float acc = bv[q * 32 + o];
+    for (int c = 0; c < U; ++c) acc = fmaf(xs[il][c], WT[c * 128 + q * 32 + o], acc);
+    Xnext[(size_t)i * 128 + q * 32 + o] = acc;
+  }
+}
+
+// head: heu = sigmoid(W3 silu(W2 silu(W1 w + b1) + b2) + b3), three chained tile GEMMs
+__global__ void __launch_bounds__(256)
+gnn_head_kernel(int E, int feats, const float *params, const float *w, float *heu) {
+  __shared__ __attribute__((aligned(16))) float tile[4][32][36];   // 36: keeps float4 rows 16-B aligned
+  const float *hp = params + off_head(feats);
+  const float *W1 = hp, *b1 = W1 + 1024, *W2 = b1 + 32, *b2 = W2 + 1024, *W3 = b2 + 32, *b3 = W3 + 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e0 = (blockIdx.x * 4 + wave) * 32;
+  if (e0 >= E) return;
+  const int o = lane & 31;
+  const int er = min(e0 + o, E - 1);
+  f32x16 acc = tile_gemm(w + (size_t)er * U, W1, lane);
+  float (*t)[36] = tile[wave];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[drow(r, lane)][o] = silu(acc[r] + b1[o]);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): LDS writes of this wave landed
+  acc = tile_gemm(&t[o][0], W2, lane);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[drow(r, lane)][o] = silu(acc[r] + b2[o]) * W3[o];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  // final 32 -> 1: row sums of the tile, one edge per lane (lanes 0..31), fixed channel order
+  if (lane < 32) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < U; ++c) s = s + t[lane][c];
+    const int e = e0 + lane;
+    if (e < E) heu[e] = sigmoidf(s + b3[0]);
+  }
+}
+
+}  // namespace daco
+
+using namespace daco;
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t daco_gnn_param_floats(int feats) { return off_head(feats) + HEAD_FLOATS; }
+
+extern "C" size_t daco_gnn_workspace_bytes(int n, int E) {
+  if (n <= 0 || E <= 0) return 0;
+  return 2 * align256((size_t)n * 32 * 4) + 2 * align256((size_t)n * 128 * 4) + 2 * align256((size_t)E * 32 * 4);
+}
+
+extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, const int32_t *src,
+                                const int32_t *dst, const int32_t *rowptr, const int32_t *perm,
+                                const float *edge_attr, const float *params, float *heu, float *emb,
+                                void *workspace, size_t workspace_bytes) {
+  if (n <= 0 || E <= 0 || feats < 1 || feats > 8 || !x || !src || !dst || !rowptr || !edge_attr || !params || !heu || !workspace) {
+    set_error("daco_gnn_forward: bad argument (n=%d E=%d feats=%d)", n, E, feats);
+    return DACO_E_BADARG;
+  }
+  const size_t need = daco_gnn_workspace_bytes(n, E);
+  if (workspace_bytes < need) { set_error("daco_gnn_forward: workspace %zu < %zu", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  char *p = (char *)workspace;
+  float *xb[2], *Xb[2], *wb[2];
+  for (int k = 0; k < 2; ++k) { xb[k] = (float *)p; p += align256((size_t)n * 32 * 4); }
+  for (int k = 0; k < 2; ++k) { Xb[k] = (float *)p; p += align256((size_t)n * 128 * 4); }
+  for (int k = 0; k < 2; ++k) { wb[k] = (float *)p; p += align256((size_t)E * 32 * 4); }
+  const int node_blocks = (n + 7) / 8, edge_blocks = (E + 127) / 128;
+  hipLaunchKernelGGL(gnn_node_init_kernel, dim3(node_blocks), dim3(256), 0, s, n, feats, x, params, xb[0], Xb[0]);
+  hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 32 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
+  int cur = 0;
+  for (int l = 0; l < 12; ++l) {
+    float *wout = (l == 11 && emb) ? emb : wb[cur ^ 1];
+    hipLaunchKernelGGL(gnn_layer_kernel, dim3(edge_blocks + node_blocks), dim3(256), 0, s, n, E, feats, l, edge_blocks, src,
+                       dst, rowptr, perm, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
+    if (l == 11 && emb) { wb[cur ^ 1] = emb; }
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(gnn_head_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, params, wb[cur], heu);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("gnn kernels launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}

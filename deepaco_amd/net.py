@@ -1,0 +1,211 @@
+"""Heuristic network (edge GNN + MLP head) with the module tree of the reference's net.py.
+
+`Net` keeps the reference's parameter names, so its checkpoints load unchanged
+(tsp/net.py:78-102: emb_net.{v_lin0, v_lins1..4.{i}, v_bns.{i}.module.*, e_lin0, e_lins0.{i},
+e_bns.{i}.module.*}, par_net_heu.{_dummy, lins.{i}}, and the unused par_net_phe of tsp/).
+
+forward(pyg):
+  * inference (module in eval mode and no gradient required) -> one call into
+    libdeepaco_hip.so (daco_gnn_forward: 14 kernel launches, MFMA edge linears, BatchNorm folded);
+  * training (train mode or autograd on) -> the same math as torch ops on the HIP device, so
+    autograd provides the backward.  Train-mode BatchNorm uses the statistics of the single
+    graph, as in the reference (tsp/net.py:21,24,43-44).
+`pyg` only needs `.x`, `.edge_index`, `.edge_attr` (torch_geometric is not required).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import _lib
+from . import engine
+
+DEPTH = 12
+UNITS = 32
+
+
+class GraphData:
+    """Minimal stand-in for torch_geometric.data.Data: an attribute bag (x, edge_index, edge_attr)."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def to(self, device):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        return self
+
+
+class GraphBatchNorm(nn.Module):
+    """Same parameter path as torch_geometric.nn.BatchNorm: the BatchNorm1d lives at `.module`."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.module = nn.BatchNorm1d(channels)
+
+    def forward(self, x):
+        return self.module(x)
+
+
+def mean_by_source(values, src, n):
+    """global_mean_pool(values, src): mean of the rows of `values` grouped by `src` (0 for empty groups)."""
+    total = torch.zeros((n, values.shape[1]), dtype=values.dtype, device=values.device).index_add_(0, src, values)
+    count = torch.bincount(src, minlength=n).clamp_(min=1).to(values.dtype)
+    return total / count.unsqueeze(1)
+
+
+class EmbNet(nn.Module):
+    """12 residual layers updating node states x and edge states w (tsp/net.py:8-45)."""
+
+    def __init__(self, depth=DEPTH, feats=2, units=UNITS, act_fn='silu', agg_fn='mean'):
+        super().__init__()
+        assert act_fn == 'silu' and agg_fn == 'mean' and units == UNITS and depth == DEPTH
+        self.depth, self.feats, self.units = depth, feats, units
+        self.v_lin0 = nn.Linear(feats, units)
+        self.v_lins1 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
+        self.v_lins2 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
+        self.v_lins3 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
+        self.v_lins4 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
+        self.v_bns = nn.ModuleList([GraphBatchNorm(units) for _ in range(depth)])
+        self.e_lin0 = nn.Linear(1, units)
+        self.e_lins0 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
+        self.e_bns = nn.ModuleList([GraphBatchNorm(units) for _ in range(depth)])
+
+    def forward(self, x, edge_index, edge_attr):
+        src, dst = edge_index[0], edge_index[1]
+        n = x.shape[0]
+        x = F.silu(self.v_lin0(x))
+        w = F.silu(self.e_lin0(edge_attr))
+        for i in range(self.depth):
+            gate = torch.sigmoid(w)
+            msg = mean_by_source(gate * self.v_lins2[i](x)[dst], src, n)
+            w_new = w + F.silu(self.e_bns[i](self.e_lins0[i](w) + self.v_lins3[i](x)[src] + self.v_lins4[i](x)[dst]))
+            x = x + F.silu(self.v_bns[i](self.v_lins1[i](x) + msg))
+            w = w_new
+        return w
+
+
+class MLP(nn.Module):
+    @property
+    def device(self):
+        return self._dummy.device
+
+    def __init__(self, units_list, act_fn):
+        super().__init__()
+        assert act_fn == 'silu'
+        self._dummy = nn.Parameter(torch.empty(0), requires_grad=False)
+        self.units_list = units_list
+        self.depth = len(units_list) - 1
+        self.lins = nn.ModuleList([nn.Linear(units_list[i], units_list[i + 1]) for i in range(self.depth)])
+
+    def forward(self, x):
+        for i, lin in enumerate(self.lins):
+            x = lin(x)
+            x = F.silu(x) if i < self.depth - 1 else torch.sigmoid(x)
+        return x
+
+
+class ParNet(MLP):
+    def __init__(self, depth=3, units=UNITS, preds=1, act_fn='silu'):
+        self.units, self.preds = units, preds
+        super().__init__([units] * depth + [preds], act_fn)
+
+    def forward(self, x):
+        return super().forward(x).squeeze(dim=-1)
+
+
+class Net(nn.Module):
+    """feats: node-feature width (2 = coordinates in tsp/, 1 in tsp_nls/ and cvrp/);
+    with_phe: also create the unused par_net_phe head that tsp/ checkpoints contain."""
+
+    def __init__(self, feats=2, with_phe=True):
+        super().__init__()
+        self.emb_net = EmbNet(feats=feats)
+        if with_phe:
+            self.par_net_phe = ParNet()
+        self.par_net_heu = ParNet()
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, pyg):
+        x, edge_index, edge_attr = pyg.x, pyg.edge_index, pyg.edge_attr
+        needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.training or needs_graph or not x.is_cuda:
+            if not x.is_cuda:
+                raise _lib.DacoError("deepaco_amd.Net runs on a HIP device only (got CPU tensors)")
+            emb = self.emb_net(x, edge_index, edge_attr)
+            return self.par_net_heu(emb)
+        return self.forward_hip(pyg)
+
+    def freeze_gnn(self):
+        for param in self.emb_net.parameters():
+            param.requires_grad = False
+
+    @staticmethod
+    def reshape(pyg, vector):
+        '''Turn phe/heu vector into matrix with zero padding (tsp/net.py:94-102)'''
+        n_nodes = pyg.x.shape[0]
+        matrix = torch.zeros(size=(n_nodes, n_nodes), device=pyg.x.device, dtype=vector.dtype)
+        matrix[pyg.edge_index[0], pyg.edge_index[1]] = vector
+        return matrix
+
+    # ------------------------------------------------------------------ HIP inference path
+    def pack_params(self):
+        """Flat f32 parameter block in the layout csrc/daco_gnn.hip documents (BatchNorm folded)."""
+        key = tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + (next(self.parameters()).device,)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        e = self.emb_net
+        with torch.no_grad():
+            parts = [e.v_lin0.weight.reshape(-1), e.v_lin0.bias, e.e_lin0.weight.reshape(-1), e.e_lin0.bias]
+            for i in range(DEPTH):
+                Wv = torch.cat([m[i].weight for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)   # [128, 32]
+                bv = torch.cat([m[i].bias for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)
+                parts += [Wv.t().contiguous().reshape(-1), bv, e.e_lins0[i].weight.reshape(-1), e.e_lins0[i].bias]
+                for bn in (e.v_bns[i].module, e.e_bns[i].module):
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    parts += [scale, bn.bias - bn.running_mean * scale]
+            h = self.par_net_heu.lins
+            parts += [h[0].weight.reshape(-1), h[0].bias, h[1].weight.reshape(-1), h[1].bias, h[2].weight.reshape(-1),
+                      h[2].bias]
+            flat = torch.cat([p.float().reshape(-1) for p in parts]).contiguous()
+        assert flat.numel() == _lib.lib().daco_gnn_param_floats(e.feats)
+        self._packed, self._packed_key = flat, key
+        return flat
+
+    @torch.no_grad()
+    def forward_hip(self, pyg, return_embedding=False):
+        x = pyg.x.float().contiguous()
+        n, feats = x.shape
+        graph = getattr(pyg, "_daco_graph", None)
+        if graph is None:
+            ei = pyg.edge_index
+            src64 = ei[0]
+            sorted_already = bool((src64[1:] >= src64[:-1]).all()) if src64.numel() > 1 else True
+            perm = None if sorted_already else torch.argsort(src64, stable=True).to(torch.int32).contiguous()
+            rowptr = torch.zeros(n + 1, dtype=torch.int32, device=x.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(src64, minlength=n), 0).to(torch.int32)
+            graph = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous(), rowptr, perm)
+            try:
+                pyg._daco_graph = graph
+            except Exception:
+                pass
+        src, dst, rowptr, perm = graph
+        E = src.numel()
+        attr = pyg.edge_attr.float().contiguous().view(-1)
+        params = self.pack_params()
+        L = _lib.lib()
+        dev = x.device
+        with torch.cuda.device(dev):
+            heu = torch.empty(E, dtype=torch.float32, device=dev)
+            emb = torch.empty((E, UNITS), dtype=torch.float32, device=dev) if return_embedding else None
+            nbytes = L.daco_gnn_workspace_bytes(n, E)
+            ws = engine._workspace(dev, nbytes, "gnn")
+            rc = L.daco_gnn_forward(engine._stream(dev), n, E, feats, x.data_ptr(), src.data_ptr(), dst.data_ptr(),
+                                    rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, attr.data_ptr(),
+                                    params.data_ptr(), heu.data_ptr(), emb.data_ptr() if emb is not None else None,
+                                    ws.data_ptr(), ws.numel())
+        _lib.check(rc, "daco_gnn_forward")
+        return (heu, emb) if return_embedding else heu

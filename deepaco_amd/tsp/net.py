@@ -1,0 +1,15 @@
+"""Net for tsp/ (node features = 2-D coordinates; checkpoints carry the unused par_net_phe head).
+Same import surface as the reference's tsp/net.py: `from net import Net`."""
+import os
+import sys
+
+try:
+    from deepaco_amd.net import Net as _Net, EmbNet, MLP, ParNet  # noqa: F401
+except ImportError:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd.net import Net as _Net, EmbNet, MLP, ParNet  # noqa: F401
+
+
+class Net(_Net):
+    def __init__(self):
+        super().__init__(feats=2, with_phe=True)

@@ -195,6 +195,24 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
 int daco_two_opt(void *stream, int B, int T, int n, const float *dist, long dist_bstride,
                  uint16_t *tours, long max_iterations, int32_t *sweeps);
 
+/* ---------------------------------------------------------------------------------------------
+ * daco_gnn_forward -- replaces Net.forward in eval mode
+ *   EmbNet.forward tsp/net.py:27-45, MLP/ParNet.forward :59-66,74-75, Net.forward :84-88
+ * One graph: n nodes with `feats` input features, E directed edges with one attribute each.
+ *   x [n][feats], edge_attr [E], src/dst [E] int32 (edge_index rows), rowptr [n+1] int32 = CSR
+ *   offsets of the edges grouped by src, perm [E] int32 = edge ids in that grouped order or NULL
+ *   if the edge list is already sorted by src (the reference's kNN graphs are).
+ *   params: daco_gnn_param_floats(feats) floats, layout documented in csrc/daco_gnn.hip
+ *           (BatchNorm folded to scale/shift from the running statistics -> eval mode only).
+ *   heu out [E] f32 in (0,1);  emb out [E][32] or NULL (the edge embedding before the head).
+ */
+size_t daco_gnn_param_floats(int feats);
+size_t daco_gnn_workspace_bytes(int n, int E);
+int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, const int32_t *src,
+                     const int32_t *dst, const int32_t *rowptr, const int32_t *perm,
+                     const float *edge_attr, const float *params, float *heu, float *emb,
+                     void *workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

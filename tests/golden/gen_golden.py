@@ -365,6 +365,43 @@ def gen_grads(tsp_aco, cvrp_aco):
          loss=loss.detach(), grad=heu.grad)
 
 
+def gen_net():
+    """G5: Net.forward (tsp/net.py:27-45,59-66,84-88) with the shipped checkpoints, eval and train mode.
+    Checkpoints are converted to plain float arrays (data, not code)."""
+    cases = [("tsp", "tsp100", "tsp", 100, 20), ("tsp", "tsp20", "tsp", 20, 10),
+             ("tsp_nls", "tsp100", "tsp_nls", 100, 10), ("cvrp", "cvrp20", "cvrp", 20, None)]
+    for sub, ck, kind, n, k in cases:
+        net_mod = load_ref(sub, "net", f"ref_net_{sub}")
+        utils = load_ref(sub, "utils", f"ref_utils_{sub}")
+        sd = torch.load(os.path.join(REF, "pretrained", sub, ck + ".pt"), map_location="cpu")
+        model = net_mod.Net()
+        model.load_state_dict(sd)
+        torch.manual_seed(7)
+        if kind == "cvrp":
+            demands, distances = utils.gen_instance(n, "cpu")
+            pyg = utils.gen_pyg_data(demands, distances, "cpu")
+            extra = dict(demand=demands, distances=distances)
+        elif kind == "tsp_nls":
+            coords = torch.rand(n, 2)
+            pyg, distances = utils.gen_pyg_data(coords, k_sparse=k, start_node=0)
+            extra = dict(coords=coords, distances=distances)
+        else:
+            coords = torch.rand(n, 2)
+            pyg, distances = utils.gen_pyg_data(coords, k_sparse=k)
+            extra = dict(coords=coords, distances=distances)
+        model.eval()
+        with torch.no_grad():
+            heu_eval = model(pyg)
+            emb_eval = model.emb_net(pyg.x, pyg.edge_index, pyg.edge_attr)
+            mat = net_mod.Net.reshape(pyg, heu_eval) if kind != "cvrp" else heu_eval.reshape(n + 1, n + 1)
+        model.train()
+        with torch.no_grad():
+            heu_train = model(pyg)
+        weights = {"w__" + kk: v.float().numpy() for kk, v in sd.items() if v.numel() > 0 and v.dtype.is_floating_point}
+        save(f"g5_net_{sub}_{ck}", x=pyg.x, edge_index=pyg.edge_index, edge_attr=pyg.edge_attr, heu_eval=heu_eval,
+             emb_eval=emb_eval, heu_train=heu_train, heu_mat=mat, k_sparse=np.int32(k or 0), **extra, **weights)
+
+
 def main():
     torch.set_num_threads(1)
     print("reference:", REF)
@@ -378,6 +415,7 @@ def main():
     cvrp_aco = load_ref("cvrp", "aco", "ref_cvrp_aco")
     print("CVRP (G1/G2)"); gen_cvrp(cvrp_aco)
     print("gradients (G3)"); gen_grads(tsp_aco, cvrp_aco)
+    print("Net forward (G5)"); gen_net()
 
 
 if __name__ == "__main__":

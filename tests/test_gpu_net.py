@@ -1,0 +1,113 @@
+"""GPU tests of the heuristic network: HIP inference path vs the reference's outputs with its shipped
+checkpoints (fixtures g5_net_*), the torch-op training path, and an end-to-end training step."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import gnn as ognn
+from test_net_host import make_net, load_weights, names
+
+pytestmark = pytest.mark.gpu
+
+ATOL_HEU = 1e-5        # heu[E] eval-mode, abs tol 1e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def graph(g):
+    from deepaco_amd.net import GraphData
+    return GraphData(x=torch.from_numpy(g["x"]), edge_index=torch.from_numpy(g["edge_index"]),
+                     edge_attr=torch.from_numpy(g["edge_attr"])).to(dev())
+
+
+@pytest.mark.parametrize("name", names("g5_net"))
+def test_net_eval_hip_matches_reference(name):
+    g = load_golden(name)
+    net = make_net(name)
+    load_weights(net, g)
+    net = net.to(dev()).eval()
+    pyg = graph(g)
+    with torch.no_grad():
+        heu = net(pyg)                                   # HIP path (eval, no grad)
+    np.testing.assert_allclose(heu.cpu().numpy(), g["heu_eval"], atol=ATOL_HEU, rtol=1e-4)
+    heu2, emb = net.forward_hip(pyg, return_embedding=True)
+    assert torch.equal(heu, heu2)
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb_eval"], atol=3e-4, rtol=3e-4)
+    # torch-op path (what training uses) agrees with the HIP path
+    emb_t = net.emb_net(pyg.x, pyg.edge_index, pyg.edge_attr)
+    heu_t = net.par_net_heu(emb_t)
+    np.testing.assert_allclose(heu_t.detach().cpu().numpy(), heu.cpu().numpy(), atol=ATOL_HEU, rtol=1e-4)
+    if "cvrp" not in name:
+        mat = net.reshape(pyg, heu)
+        np.testing.assert_allclose(mat.cpu().numpy(), g["heu_mat"], atol=ATOL_HEU, rtol=1e-4)
+        assert (mat.cpu().numpy() == 0).sum() == (g["heu_mat"] == 0).sum()
+
+
+@pytest.mark.parametrize("name", names("g5_net"))
+def test_net_train_mode_matches_reference(name):
+    g = load_golden(name)
+    net = make_net(name)
+    load_weights(net, g)
+    net = net.to(dev()).train()
+    with torch.no_grad():
+        heu = net(graph(g))
+    np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=2e-5, rtol=2e-4)
+
+
+def test_random_graph_vs_oracle():
+    """Random weights, unsorted edge list with uneven degrees (exercises perm / CSR path and tile tails)."""
+    from deepaco_amd.cvrp.net import Net
+    from deepaco_amd.net import GraphData
+    torch.manual_seed(0)
+    net = Net().to(dev())
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    n, E = 37, 333
+    gen = torch.Generator().manual_seed(1)
+    src = torch.randint(0, n - 3, (E,), generator=gen)        # nodes n-3.. have no out-edges
+    dst = torch.randint(0, n, (E,), generator=gen)
+    pyg = GraphData(x=torch.rand(n, 1, generator=gen), edge_index=torch.stack([src, dst]),
+                    edge_attr=torch.rand(E, 1, generator=gen)).to(dev())
+    heu = net(pyg)
+    w = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if v.dtype.is_floating_point and v.numel()}
+    ref = ognn.net_forward(w, pyg.x.cpu().numpy(), pyg.edge_index.cpu().numpy(), pyg.edge_attr.cpu().numpy())
+    np.testing.assert_allclose(heu.cpu().numpy(), ref, atol=ATOL_HEU, rtol=1e-4)
+
+
+def test_training_step_end_to_end():
+    """tsp_nls/train.py:15-44 train_instance on a small instance: Net (torch ops, autograd) -> heuristic ->
+    ACO.sample (HIP forward + HIP backward) -> sample_2opt (HIP) -> REINFORCE loss -> AdamW step."""
+    from deepaco_amd.tsp_nls.net import Net
+    from deepaco_amd.tsp_nls.aco import ACO
+    from deepaco_amd.tsp_nls.utils import gen_pyg_data
+    torch.manual_seed(1234)
+    net = Net().to(dev())
+    opt = torch.optim.AdamW(net.parameters(), lr=3e-4)
+    coords = torch.rand(40, 2, device=dev())
+    pyg, distances = gen_pyg_data(coords, k_sparse=8, start_node=0)
+    before = [p.detach().clone() for p in net.parameters()]
+    net.train()
+    heu_vec = net(pyg)
+    heu_mat = net.reshape(pyg, heu_vec) + 1e-10
+    aco = ACO(n_ants=12, heuristic=heu_mat, distances=distances, device="cuda:0", local_search='nls')
+    costs, log_probs, paths = aco.sample()
+    costs_2opt, _ = aco.sample_2opt(paths)
+    cost = (costs_2opt - costs_2opt.mean()) * 0.95 + (costs - costs.mean()) * 0.05
+    loss = torch.sum(cost.detach() * log_probs.sum(dim=0)) / aco.n_ants
+    opt.zero_grad()
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=3.0, norm_type=2)
+    assert torch.isfinite(gn) and float(gn) > 0
+    opt.step()
+    changed = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, net.parameters()))
+    assert changed > 200
+    assert bool((costs_2opt <= costs + 1e-4).all())

@@ -1,0 +1,79 @@
+"""CPU-side checks of the Net drop-in: module tree / state_dict keys equal the reference checkpoints',
+graph construction (H1) equals the reference's utils on captured instances."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+
+def names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def make_net(name):
+    if "tsp_nls" in name:
+        from deepaco_amd.tsp_nls.net import Net
+    elif "cvrp" in name:
+        from deepaco_amd.cvrp.net import Net
+    else:
+        from deepaco_amd.tsp.net import Net
+    return Net()
+
+
+def load_weights(net, g):
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    return missing, unexpected
+
+
+@pytest.mark.parametrize("name", names("g5_net"))
+def test_checkpoint_keys_load_unchanged(name):
+    g = load_golden(name)
+    net = make_net(name)
+    missing, unexpected = load_weights(net, g)
+    assert unexpected == []
+    # the fixture drops only integer counters and the empty _dummy parameters
+    assert all(k.endswith("num_batches_tracked") or k.endswith("_dummy") for k in missing), missing
+    n_keys = len(net.state_dict())
+    assert n_keys == (258 if name.startswith("g5_net_tsp_tsp") else 251)
+    n_ckpt = sum(v.size for k, v in g.items() if k.startswith("w__") and "running_" not in k)
+    assert sum(p.numel() for p in net.parameters()) == n_ckpt
+
+
+@pytest.mark.parametrize("name", ["g5_net_tsp_tsp100", "g5_net_tsp_tsp20", "g5_net_tsp_nls_tsp100"])
+def test_tsp_graph_construction(name):
+    from deepaco_amd.tsp.utils import gen_pyg_data
+    g = load_golden(name)
+    start = 0 if "nls" in name else None
+    pyg, dist = gen_pyg_data(torch.from_numpy(g["coords"]), int(g["k_sparse"]), start_node=start)
+    assert np.array_equal(pyg.edge_index.numpy(), g["edge_index"])
+    assert np.array_equal(pyg.edge_attr.numpy(), g["edge_attr"])
+    assert np.array_equal(pyg.x.numpy(), g["x"])
+    assert np.array_equal(dist.numpy(), g["distances"])
+
+
+def test_cvrp_graph_construction():
+    from deepaco_amd.cvrp.utils import gen_pyg_data, gen_instance
+    g = load_golden("g5_net_cvrp_cvrp20")
+    pyg = gen_pyg_data(torch.from_numpy(g["demand"]), torch.from_numpy(g["distances"]), "cpu")
+    assert np.array_equal(pyg.edge_index.numpy(), g["edge_index"])
+    assert np.array_equal(pyg.edge_attr.numpy(), g["edge_attr"])
+    assert np.array_equal(pyg.x.numpy(), g["x"])
+    torch.manual_seed(7)
+    dem, dist = gen_instance(20, "cpu")
+    assert np.array_equal(dem.numpy(), g["demand"]) and np.array_equal(dist.numpy(), g["distances"])
+
+
+def test_net_refuses_cpu():
+    from deepaco_amd import _lib
+    g = load_golden("g5_net_tsp_tsp20")
+    net = make_net("g5_net_tsp_tsp20").eval()
+    from deepaco_amd.net import GraphData
+    pyg = GraphData(x=torch.from_numpy(g["x"]), edge_index=torch.from_numpy(g["edge_index"]),
+                    edge_attr=torch.from_numpy(g["edge_attr"]))
+    with pytest.raises(_lib.DacoError):
+        net(pyg)

@@ -157,3 +157,20 @@ def test_grad_closed_form_cvrp():
     out = ograd.cvrp_grad(g["pheromone"], g["heuristic"], 1, 1, g["demand"], float(g["capacity"]), g["paths"], G)
     scale = np.abs(g["grad"]).max()
     np.testing.assert_allclose(out, g["grad"], rtol=2e-4, atol=2e-6 * scale)
+
+
+@pytest.mark.parametrize("name", names("g5_net"))
+def test_gnn_restatement(name):
+    """oracle/gnn.py against Net.forward of the reference with its shipped checkpoints (eval + train BN)."""
+    from oracle import gnn
+    g = load_golden(name)
+    w = gnn.weights_from_fixture(g)
+    emb = gnn.emb_forward(w, g["x"], g["edge_index"], g["edge_attr"])
+    np.testing.assert_allclose(emb, g["emb_eval"], rtol=2e-4, atol=2e-4)
+    heu = gnn.net_forward(w, g["x"], g["edge_index"], g["edge_attr"])
+    np.testing.assert_allclose(heu, g["heu_eval"], atol=1e-5, rtol=1e-4)
+    heu_t = gnn.net_forward(w, g["x"], g["edge_index"], g["edge_attr"], train=True)
+    np.testing.assert_allclose(heu_t, g["heu_train"], atol=1e-5, rtol=1e-4)
+    n = g["x"].shape[0]
+    if "cvrp" not in name:
+        assert np.array_equal(gnn.reshape(n, g["edge_index"], g["heu_eval"]), g["heu_mat"])
