@@ -33,8 +33,8 @@ __host__ __device__ inline size_t off_layer(int feats, int l) { return (size_t)3
 __host__ __device__ inline size_t off_head(int feats) { return off_layer(feats, 12); }
 constexpr int HEAD_FLOATS = 2 * (32 * 32 + 32) + 32 + 1;
 
-__device__ inline float silu(float x) { return x / (1.0f + __expf(-x)); }
-__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ inline float silu(float x) { return x / (1.0f + expf(-x)); }
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // x = silu(v_lin0(x)); X1234(0) = layer-0 node linears.  8 nodes per 256-thread workgroup.
 __global__ void __launch_bounds__(256)
