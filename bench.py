@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--k-sparse", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
+    ap.add_argument("--force-device", type=int, default=None,
+                    help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,10 +121,15 @@ def main():
     if distributed:
         import torch.distributed as dist_pkg
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_pkg.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.force_device is None else args.force_device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if distributed:
+        if args.dist_backend == "nccl":
+            dist_pkg.init_process_group("nccl", device_id=dev)
+        else:
+            dist_pkg.init_process_group("gloo")
 
     from deepaco_amd import engine
     from deepaco_amd.parallel import barrier_max_time

@@ -101,6 +101,19 @@ struct Visited {
   __device__ inline void set(int bit) {       // bit is wave-uniform
     if (bit < 32) lo |= 1u << bit; else hi |= 1u << (bit - 32);
   }
+  // 0xFFFFFFFF if the candidate is closed, else 0 (v_bfe_i32); `x & ~mask` zeroes closed ones
+  template <int BIT> __device__ inline uint32_t closed_mask() const {
+    return (uint32_t)__builtin_amdgcn_sbfe((int)(BIT < 32 ? lo : hi), BIT & 31, 1);
+  }
+  // x if candidate BIT is open, +0.0f if closed -- two VALU ops (v_bfe_i32 + v_bfi_b32); written as
+  // asm because the optimiser otherwise rewrites it into and + cmp + cndmask
+  template <int BIT> __device__ inline float open_only(float x) const {
+    int m;
+    float r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(BIT < 32 ? lo : hi), "n"(BIT & 31));
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(r) : "v"(m), "v"(x));
+    return r;
+  }
   template <int BIT> __device__ inline void set_if(bool c) {
     if constexpr (BIT < 32) lo |= (c ? 1u : 0u) << BIT; else hi |= (c ? 1u : 0u) << (BIT - 32);
   }
@@ -126,7 +139,8 @@ tsp_sample_kernel(const SampleParams p) {
   float *logp_out = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
   const float *dist_b = (!CVRP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
-  uint16_t *nbr_a = (!CVRP && p.nbr) ? reinterpret_cast<uint16_t *>(p.nbr + ((size_t)b * A + a) * n) : nullptr;
+  uint32_t *nbr_a = (!CVRP && p.nbr) ? p.nbr + ((size_t)b * A + a) * n : nullptr;
+  int pprev = 0, second = 0;                            // neighbour-table bookkeeping
   const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
 
   // ---- start node
@@ -142,11 +156,12 @@ tsp_sample_kernel(const SampleParams p) {
   const int first = prev;
 
   Visited vis;
-  auto mark = [&](int k) {                              // k wave-uniform
-    const int vi = k / VEC;
-    const int bit = (vi >> 6) * VEC + (k % VEC);
-    if (lane == (vi & 63)) vis.set(bit);
+  auto mark = [&](int k) {                              // k wave-uniform, >= 0
+    const unsigned vi = (unsigned)k / VEC;
+    const unsigned bit = (vi >> 6) * VEC + ((unsigned)k % VEC);
+    if ((unsigned)lane == (vi & 63u)) vis.set((int)bit);
   };
+  int own_lane = -1, own_bit = 0;                       // SCAN: owner of the last choice, known without division
   if constexpr (!CVRP) mark(prev);
   if (lane == 0) path_out[0] = prev;
 
@@ -183,7 +198,7 @@ tsp_sample_kernel(const SampleParams p) {
     }
     // ---- stream the row of `prev`
     float row[CH][VEC];
-    const float *rp = (MODE == DACO_RACE_PHILOX ? Rb : Pb) + (size_t)prev * ld;
+    const float *rp = (MODE == DACO_RACE_PHILOX ? Rb : Pb) + (unsigned)prev * (unsigned)ld;
 #pragma unroll
     for (int c = 0; c < CH; ++c) load_vec<VEC>(rp + c * 64 * VEC, row[c]);
 
@@ -199,10 +214,12 @@ tsp_sample_kernel(const SampleParams p) {
       const uint32_t ux = (uint32_t)readlane_i((int)ucur, t & 63);
       // masked candidates become +0.0f, so every later add is a no-op for them
       float part = 0.0f;
+      float pre[NJ];                                      // running sums inside the lane (non-decreasing)
       static_for<NJ>([&](auto J) {
         constexpr int j = J, c = j / VEC, v = j % VEC;
-        row[c][v] = blk.template test<j>() ? 0.0f : row[c][v];
-        part = part + row[c][v];
+        row[c][v] = blk.template open_only<j>(row[c][v]);
+        part = j == 0 ? row[c][v] : part + row[c][v];     // (+0.0f + x == x: masked values are +0.0f, never -0.0f)
+        pre[j] = part;
       });
       const float incl = wave_scan_add(part);
       S = readlane_f(incl, 63);
@@ -213,22 +230,15 @@ tsp_sample_kernel(const SampleParams p) {
       else {
         const int L = __builtin_ctzll(m);
         const float excl = L ? readlane_f(incl, L - 1) : 0.0f;
-        // running sums inside the lane are non-decreasing, so the first index whose running
-        // sum reaches r is the count of those still below r (branch-free)
-        float run = excl;
+        // what is left to cover inside lane L; the lane's running sums are non-decreasing, so the
+        // first index reaching it is the count of those still below it (branch-free)
+        const float thr = r - excl;
         int cnt = 0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            run = run + row[c][v];
-            cnt += run < r ? 1 : 0;
-          }
-        }
+        static_for<NJ>([&](auto J) { cnt += pre[J] < thr ? 1 : 0; });
         int jsel = readlane_i(cnt, L);
         if (jsel >= NJ) {
-          // rounding: the in-lane running sum fell short of the scan's value -> last candidate
-          // of the lane with p > 0 (rare; wave-uniform branch)
+          // rounding: the lane's own sum fell short of r - excl although incl >= r -> last
+          // candidate of the lane with p > 0 (rare; wave-uniform branch)
           int last = 0;
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
@@ -237,7 +247,8 @@ tsp_sample_kernel(const SampleParams p) {
           }
           jsel = readlane_i(last, L);
         }
-        choice = ((jsel / VEC) * 64 + L) * VEC + (jsel % VEC);
+        choice = (int)((((unsigned)jsel / VEC) * 64u + (unsigned)L) * VEC + ((unsigned)jsel % VEC));
+        own_lane = L; own_bit = jsel;
         if constexpr (LOGP) pchoice = p.P[((size_t)b * n + prev) * ld + choice];
       }
     } else if constexpr (MODE == DACO_RACE_PHILOX) {
@@ -274,8 +285,8 @@ tsp_sample_kernel(const SampleParams p) {
       float part = 0.0f;
       static_for<NJ>([&](auto J) {
         constexpr int j = J, c = j / VEC, v = j % VEC;
-        row[c][v] = blk.template test<j>() ? 0.0f : row[c][v];
-        part = part + row[c][v];
+        row[c][v] = blk.template open_only<j>(row[c][v]);
+        part = j == 0 ? row[c][v] : part + row[c][v];     // (+0.0f + x == x: masked values are +0.0f, never -0.0f)
       });
       float S0 = 0.0f;                                    // un-normalised row sum (for backward)
       if (LOGP && p.norm_passes > 0) S0 = wave_sum(part);
@@ -328,15 +339,19 @@ tsp_sample_kernel(const SampleParams p) {
       else used = 0.0f;
       used = used + demand_b[choice];                  // scalar load
     } else {
-      mark(choice);
+      if (MODE == DACO_SCAN && own_lane >= 0) { if (lane == own_lane) vis.set(own_bit); }
+      else mark(choice);
     }
     if (lane == 0) path_out[(size_t)t * A] = choice;
     if (dist_b) {                                        // fused gen_path_costs (wave-uniform)
       cost = cost + dpend;
-      dpend = dist_b[(size_t)choice * n + prev];         // d[u_t][u_{t-1}], scalar load
+      dpend = dist_b[(unsigned)choice * (unsigned)n + (unsigned)prev];   // d[u_t][u_{t-1}], scalar load
     }
-    if (nbr_a && lane < 2)                               // lane 0: next(prev)=choice, lane 1: prev(choice)=prev
-      nbr_a[lane == 0 ? 2 * prev + 1 : 2 * choice] = (uint16_t)(lane == 0 ? choice : prev);
+    if (nbr_a) {                                         // node `prev` now knows both neighbours
+      if (lane == 0) nbr_a[(unsigned)prev] = (uint32_t)pprev | ((uint32_t)choice << 16);
+      if (t == 1) second = choice;
+      pprev = prev;
+    }
     prev = choice;
   }
   if constexpr (CVRP) {
@@ -355,10 +370,13 @@ tsp_sample_kernel(const SampleParams p) {
   }
   if (dist_b) {
     cost = cost + dpend;
-    cost = cost + dist_b[(size_t)first * n + prev];      // closing edge d[u_0][u_{n-1}] last
+    cost = cost + dist_b[(unsigned)first * (unsigned)n + (unsigned)prev];   // closing edge d[u_0][u_{n-1}] last
     if (lane == 0) p.costs[(size_t)b * A + a] = cost;
   }
-  if (nbr_a && lane < 2) nbr_a[lane == 0 ? 2 * prev + 1 : 2 * first] = (uint16_t)(lane == 0 ? first : prev);
+  if (nbr_a && lane == 0) {                             // close the cycle: last -> first -> second
+    if (n == 2) { nbr_a[first] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[prev] = (uint32_t)first | ((uint32_t)first << 16); }
+    else { nbr_a[prev] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[first] = (uint32_t)prev | ((uint32_t)second << 16); }
+  }
   if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
 }
 

@@ -41,7 +41,9 @@ def barrier_max_time(fn, device, distributed):
         torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        # gloo reduces host tensors, nccl (= RCCL) device tensors
+        tdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         dist.barrier()

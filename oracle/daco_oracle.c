@@ -194,8 +194,9 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  *   S = incl[63];  r = max(u * S, denorm_min),  u = component ((t>>6)&3) of
  *       Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))   [256 uniforms per refill]
  *   L = first lane with incl[L] >= r and part[L] > 0
- *   inside lane L: run = incl[L-1] (0 for L=0); walk its candidates in (c,v) order adding
- *   unblocked p>0; pick the first with run >= r, else the last unblocked p>0 of the lane. */
+ *   inside lane L: thr = r - incl[L-1] (incl[-1] = 0); walk its candidates in (c,v) order with
+ *   the lane's own running sum (from +0.0f, closed candidates add +0.0f); pick the first whose
+ *   running sum >= thr, else the last open candidate with p > 0 of the lane. */
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
                      uint64_t iter, uint32_t gid, int t, float *pr) {
   int vec = orc_vec_for_n(n), ld = orc_ld_for_n(n), ch = ld / (64 * vec);
@@ -218,7 +219,8 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   int L = -1;
   for (int l = 0; l < 64; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
   if (L < 0) return -1;
-  float run = L ? incl[L - 1] : 0.0f;
+  float thr = r - (L ? incl[L - 1] : 0.0f);
+  float run = 0.0f;
   int best = -1, last = -1;
   for (int c = 0; c < ch && best < 0; ++c)
     for (int v = 0; v < vec; ++v) {
@@ -226,7 +228,7 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
       if (k >= n || blocked[k] || !(row[k] > 0.0f)) continue;
       run = run + row[k];
       last = k;
-      if (run >= r) { best = k; break; }
+      if (run >= thr) { best = k; break; }
     }
   if (best < 0) best = last;
   if (best >= 0 && pr) *pr = row[best] / S;
