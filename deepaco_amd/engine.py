@@ -231,6 +231,31 @@ def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False):
     return (tours, sweeps) if want_sweeps else tours
 
 
+@torch.no_grad()
+def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20):
+    """Batched NLS driver (tsp_nls/aco.py:241-258) fully on the device.
+    dist, heuristic_dist [B,n,n]; tours [B,T,n] int16 (one row per tour).  Returns improved tours."""
+    B, T, n = tours.shape
+
+    def lengths(t):
+        return tour_costs(dist, t.permute(0, 2, 1).to(torch.int64).contiguous())
+
+    best = tours.clone().contiguous()
+    two_opt_(dist, best, maxt)
+    best_costs = lengths(best)
+    new = best
+    for _ in range(T_nls):
+        pert = new.clone()
+        two_opt_(heuristic_dist, pert, T_p)
+        two_opt_(dist, pert, maxt)
+        new = pert
+        new_costs = lengths(new)
+        improved = new_costs < best_costs
+        best = torch.where(improved.unsqueeze(2), new, best)
+        best_costs = torch.where(improved, new_costs, best_costs)
+    return best
+
+
 class BatchedTSP:
     """B independent TSP colonies advanced in lock-step on one GPU (the throughput path).
 
@@ -239,7 +264,7 @@ class BatchedTSP:
 
     def __init__(self, distances, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
                  pheromone=None, heuristic=None, min=None, sampler="scan", seed=None, ant_gid0=0,
-                 fixed_start=-1):
+                 fixed_start=-1, local_search=None):
         _require_gpu(distances)
         assert distances.dim() == 3
         self.distances = _f32c(distances)
@@ -262,6 +287,15 @@ class BatchedTSP:
         self.iteration = 0
         self.ant_gid0 = ant_gid0
         self.fixed_start = fixed_start
+        assert local_search in (None, "2opt", "nls")
+        self.local_search = local_search          # tsp_nls/aco.py: applied to the tours before costing
+        self._hdist = None
+
+    def _heuristic_dist(self):
+        if self._hdist is None:
+            h = self.heuristic.detach().float()
+            self._hdist = (1 / (h / h.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+        return self._hdist
 
     @torch.no_grad()
     def sparsify(self, k_sparse):
@@ -278,6 +312,15 @@ class BatchedTSP:
                                                 ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
                                                 batch=self.B, events=events, dist=self.distances, want_nbr=True)
         self.iteration += 1
+        if self.local_search is not None:
+            tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+            maxt = self.n // 4
+            if self.local_search == "2opt":
+                two_opt_(self.distances, tours, maxt)
+            else:
+                tours = nls_(self.distances, self._heuristic_dist(), tours, maxt)
+            paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
+            costs, nbr = tour_costs(self.distances, paths), None
         best_cost, best_idx = costs.min(dim=1)
         improved = best_cost < self.lowest_cost
         best_path = torch.gather(paths, 2, best_idx.view(self.B, 1, 1).expand(self.B, self.n, 1)).squeeze(2)
@@ -292,6 +335,56 @@ class BatchedTSP:
             cmin = torch.full_like(new_max, self.min)
             cmax = new_max.contiguous()
         pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
+        return paths, costs
+
+    @torch.no_grad()
+    def run(self, n_iterations):
+        for _ in range(n_iterations):
+            self.step()
+        return self.lowest_cost
+
+
+class BatchedCVRP:
+    """B independent CVRP colonies in lock-step (cvrp/aco.py ACO.run semantics per instance, AS /
+    elitist / MMAS); one host sync per iteration for the common route-table length L."""
+
+    def __init__(self, distances, demand, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
+                 pheromone=None, heuristic=None, min=None, capacity=50, sampler="scan", seed=None, ant_gid0=0):
+        _require_gpu(distances, demand)
+        self.distances = _f32c(distances)
+        self.demand = _f32c(demand)
+        self.B, self.n = distances.shape[0], distances.shape[1]
+        self.n_ants, self.decay, self.alpha, self.beta, self.capacity = n_ants, decay, alpha, beta, capacity
+        self.elitist, self.min_max = elitist, min_max
+        if min_max:
+            self.min = 0.1 if min is None else min
+            self.max = None
+        self.pheromone = torch.ones_like(self.distances) if pheromone is None else _f32c(pheromone).clone()
+        if min_max and pheromone is None:
+            self.pheromone = self.pheromone * self.min
+        self.heuristic = (1 / self.distances) if heuristic is None else heuristic
+        self.lowest_cost = torch.full((self.B,), float("inf"), device=distances.device)
+        self.sampler, self.iteration, self.ant_gid0 = sampler, 0, ant_gid0
+        self.seed = torch.initial_seed() if seed is None else seed
+
+    @torch.no_grad()
+    def step(self, Lmax=None):
+        paths, _, _, lens, flags = cvrp_sample(self.pheromone, self.heuristic, self.demand, self.capacity, self.n_ants,
+                                               self.alpha, self.beta, mode=self.sampler, seed=self.seed,
+                                               it=self.iteration, ant_gid0=self.ant_gid0, Lmax=Lmax, batch=self.B)
+        self.iteration += 1
+        L = int(lens.max())
+        paths = paths[:, :L].contiguous()
+        costs = tour_costs(self.distances, paths, closed=False)
+        self.lowest_cost = torch.minimum(self.lowest_cost, costs.min(dim=1).values)
+        cmin = cmax = None
+        if self.min_max:
+            new_max = self.lowest_cost.reciprocal() * self.n
+            if self.max is None:
+                self.pheromone *= (new_max / self.pheromone.amax(dim=(1, 2))).view(self.B, 1, 1)
+            self.max = new_max
+            cmin, cmax = torch.full_like(new_max, self.min), new_max.contiguous()
+        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, False, cmin, cmax, floor=1e-10)
         return paths, costs
 
     @torch.no_grad()
