@@ -27,7 +27,10 @@ SIGNATURES = {
                              _u32, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tour_costs": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp]),
     "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "daco_pheromone_update": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _f, _vp, _vp, _sz]),
+    "daco_pheromone_update": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp,
+                                   _sz]),
+    "daco_prob_matrix": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _vp, _sz]),
+    "daco_pick_move": (_i, [_vp, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp]),
     "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _u32, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp]),

@@ -87,8 +87,8 @@ __global__ void __launch_bounds__(64) argmin_cost_kernel(int A, const float *cos
 }
 
 __global__ void __launch_bounds__(256)
-deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, float decay,
-                   const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, const float *weights,
+                   float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
   const int bpi = (n + R - 1) / R;
   const int b = blockIdx.x / bpi;
@@ -109,7 +109,7 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
     for (int a = alo; a < ahi; ++a) {
       const uint32_t v = nb[(size_t)a * n];
       const int col = role ? (int)(v >> 16) : (int)(v & 0xFFFFu);
-      const float w = 1.0f / cs[a];
+      const float w = weights ? weights[(size_t)b * A + a] : 1.0f / cs[a];
       row[col] = row[col] + w;
     }
   }
@@ -124,7 +124,7 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
   }
 }
 
-// ------------------------------------------------------------------ CVRP (directed) deposit
+// ------------------------------------------------------------------ directed deposit (CVRP and siblings)
 // cvrp/aco.py:107-130: tau[path[:-1], path[1:]] += 1/cost per ant, duplicates of an index pair
 // within one ant (the padding edge (0,0)) collapse to ONE add.  Row i >= 1 (a customer) is
 // left exactly once per ant -> one lane per row walks the ants in order.  Row 0 (the depot) is
@@ -132,7 +132,7 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
 // follow the depot; the depot workgroup applies each ant's list (distinct columns -> parallel
 // lanes) in ant order, and the (0,0) edge once per ant if it occurs.
 __global__ void __launch_bounds__(256)
-build_next_kernel(int B, int n, int len, int A, const int64_t *paths, uint32_t *nbr, uint16_t *dlist, int *dcnt) {
+build_next_kernel(int B, int n, int len, int A, int hub, const int64_t *paths, uint32_t *nbr, uint16_t *dlist, int *dcnt) {
   const long total = (long)B * (len - 1) * A;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int a = (int)(i % A);
@@ -140,7 +140,7 @@ build_next_kernel(int B, int n, int len, int A, const int64_t *paths, uint32_t *
     const int k = (int)(r % (len - 1)), b = (int)(r / (len - 1));
     const int64_t *p = paths + (size_t)b * len * A + a;
     const uint32_t u = (uint32_t)p[(size_t)k * A], v = (uint32_t)p[(size_t)(k + 1) * A];
-    if (u != 0) nbr[((size_t)b * A + a) * n + u] = v << 16;
+    if ((int)u != hub) nbr[((size_t)b * A + a) * n + u] = v << 16;
     else {
       const int pos = atomicAdd(dcnt + (size_t)b * A + a, 1);
       dlist[((size_t)b * A + a) * len + pos] = (uint16_t)v;
@@ -148,36 +148,43 @@ build_next_kernel(int B, int n, int len, int A, const int64_t *paths, uint32_t *
   }
 }
 
+__device__ inline float ant_weight(const float *weights, const float *costs, size_t idx) {
+  return weights ? weights[idx] : 1.0f / costs[idx];
+}
+
+// rows other than the hub: at most one outgoing edge per ant (0xFFFF in the table = none)
 __global__ void __launch_bounds__(256)
-deposit_directed_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, float decay,
-                        const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+deposit_directed_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nbr, const float *costs,
+                        const float *weights, float decay, const int *best, const float *clamp_min,
+                        const float *clamp_max, float floor_val) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
-  const int bpi = (n - 1 + R - 1) / R;                 // rows 1..n-1
+  const int bpi = (n + R - 1) / R;
   const int b = blockIdx.x / bpi;
-  const int i0 = 1 + (blockIdx.x - b * bpi) * R;
+  const int i0 = (blockIdx.x - b * bpi) * R;
   const int Rv = min(R, n - i0);
   float *g = tau + ((size_t)b * n + i0) * n;
   const int cnt = Rv * n;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) rows[i] = g[i] * decay;
+  const int hub_lo = (hub - i0) * n, hub_hi = hub_lo + n;      // the hub row belongs to the hub kernel
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+    if (i < hub_lo || i >= hub_hi) rows[i] = g[i] * decay;
   __syncthreads();
   const int r = threadIdx.x;
-  if (r < Rv) {
+  if (r < Rv && i0 + r != hub) {
     const uint32_t *nb = nbr + (size_t)b * A * n + i0 + r;
-    const float *cs = costs + (size_t)b * A;
     float *row = rows + r * n;
     int alo = 0, ahi = A;
     if (best) { alo = best[b]; ahi = alo + 1; }
 #pragma unroll 4
     for (int a = alo; a < ahi; ++a) {
-      const int col = (int)(nb[(size_t)a * n] >> 16);
-      const float w = 1.0f / cs[a];
-      row[col] = row[col] + w;
+      const uint32_t col = nb[(size_t)a * n] >> 16;
+      if (col != 0xFFFFu) row[col] = row[col] + ant_weight(weights, costs, (size_t)b * A + a);
     }
   }
   __syncthreads();
   const bool clamp = clamp_max != nullptr;
   const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    if (i >= hub_lo && i < hub_hi) continue;
     float x = rows[i];
     if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
     if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
@@ -185,28 +192,30 @@ deposit_directed_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, co
   }
 }
 
+// the hub row (depot / dummy node): one add per route start, (hub,hub) at most once per ant
 __global__ void __launch_bounds__(64)
-deposit_depot_kernel(int n, int len, int A, float *tau, const uint16_t *dlist, const int *dcnt, const float *costs,
-                     float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+deposit_hub_kernel(int n, int len, int A, int hub, float *tau, const uint16_t *dlist, const int *dcnt, const float *costs,
+                   const float *weights, float decay, const int *best, const float *clamp_min, const float *clamp_max,
+                   float floor_val) {
   extern __shared__ __attribute__((aligned(16))) float row[];
   const int b = blockIdx.x, lane = threadIdx.x;
-  float *g = tau + (size_t)b * n * n;                   // row 0 of instance b
+  float *g = tau + ((size_t)b * n + hub) * n;
   for (int i = lane; i < n; i += 64) row[i] = g[i] * decay;
   __syncthreads();
   int alo = 0, ahi = A;
   if (best) { alo = best[b]; ahi = alo + 1; }
   for (int a = alo; a < ahi; ++a) {
     const int c = dcnt[(size_t)b * A + a];
-    const float w = 1.0f / costs[(size_t)b * A + a];
+    const float w = ant_weight(weights, costs, (size_t)b * A + a);
     const uint16_t *lst = dlist + ((size_t)b * A + a) * len;
     bool self = false;
     for (int j0 = 0; j0 < c; j0 += 64) {
       const int j = j0 + lane;
       const int v = j < c ? (int)lst[j] : -1;
-      if (v > 0) row[v] = row[v] + w;                   // distinct customers: no conflicts
-      self = self || v == 0;
+      if (v >= 0 && v != hub) row[v] = row[v] + w;      // distinct successors: no conflicts
+      self = self || v == hub;
     }
-    if (__ballot(self) != 0 && lane == 0) row[0] = row[0] + w;   // (0,0) collapses to one add
+    if (__ballot(self) != 0 && lane == 0) row[hub] = row[hub] + w;   // (hub,hub) collapses to one add
     __syncthreads();
   }
   const bool clamp = clamp_max != nullptr;
@@ -255,8 +264,8 @@ static int rows_per_block(int n) {
 extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
                                      const int64_t *paths, const float *costs, float decay, int elitist,
                                      int symmetric, const float *clamp_min, const float *clamp_max,
-                                     float floor_val, const uint32_t *nbr_in, void *workspace,
-                                     size_t workspace_bytes) {
+                                     float floor_val, const uint32_t *nbr_in, const float *weights, int hub,
+                                     void *workspace, size_t workspace_bytes) {
   if (B <= 0 || n < 3 || A <= 0 || !tau || !paths || !costs || !workspace) {
     set_error("daco_pheromone_update: bad argument (B=%d n=%d A=%d)", B, n, A);
     return DACO_E_BADARG;
@@ -264,6 +273,7 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   if ((clamp_min == nullptr) != (clamp_max == nullptr)) { set_error("daco_pheromone_update: clamp_min/clamp_max must both be given"); return DACO_E_BADARG; }
   if (n > DACO_MAX_NODES) { set_error("daco_pheromone_update: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
   if (symmetric && len != n) { set_error("daco_pheromone_update: symmetric deposit needs len == n"); return DACO_E_BADARG; }
+  if (hub >= n) { set_error("daco_pheromone_update: hub %d >= n %d", hub, n); return DACO_E_BADARG; }
   if (!symmetric && len < 2) { set_error("daco_pheromone_update: directed deposit needs len >= 2"); return DACO_E_BADARG; }
   if (!symmetric && nbr_in) { set_error("daco_pheromone_update: nbr input is for the symmetric deposit only"); return DACO_E_BADARG; }
   const size_t need = daco_pheromone_update_workspace_bytes(B, n, len, A);
@@ -275,18 +285,21 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
     uint16_t *dlist = (uint16_t *)((char *)best + align256((size_t)B * sizeof(int)));
     int *dcnt = (int *)((char *)dlist + align256((size_t)B * A * len * sizeof(uint16_t)));
     if (hipMemsetAsync(dcnt, 0, (size_t)B * A * sizeof(int), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+    if (hipMemsetAsync(workspace, 0xFF, (size_t)B * A * n * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
     const long total = (long)B * (len - 1) * A;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, paths, (uint32_t *)workspace, dlist, dcnt);
+    hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, hub, paths, (uint32_t *)workspace, dlist, dcnt);
     if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
     int R = (64 * 1024) / (4 * n);
     if (R > 256) R = 256;
-    const int bpi = (n - 1 + R - 1) / R;
-    hipLaunchKernelGGL(deposit_directed_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, tau,
-                       (const uint32_t *)workspace, costs, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
-    hipLaunchKernelGGL(deposit_depot_kernel, dim3(B), dim3(64), (size_t)n * sizeof(float), s, n, len, A, tau, dlist, dcnt,
-                       costs, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+    const int bpi = (n + R - 1) / R;
+    if (hub >= 0)
+      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(64), (size_t)n * sizeof(float), s, n, len, A, hub, tau, dlist, dcnt,
+                         costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+    hipLaunchKernelGGL(deposit_directed_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, hub, tau,
+                       (const uint32_t *)workspace, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max,
+                       floor_val);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) { set_error("directed pheromone update launch: %s", hipGetErrorString(e2)); return DACO_E_HIP; }
     return DACO_OK;
@@ -301,7 +314,7 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   const int R = rows_per_block(n);
   const int bpi = (n + R - 1) / R;
   hipLaunchKernelGGL(deposit_tsp_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, tau,
-                     nbr, costs, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+                     nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("pheromone update launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;

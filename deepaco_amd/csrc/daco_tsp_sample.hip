@@ -38,6 +38,8 @@ struct SampleParams {
   float *costs;          // [B][A] or null
   uint32_t *nbr;         // [B][A][n] prev | next << 16 (for the pheromone update) or null
   // CVRP (cvrp/aco.py:138-205): node 0 = depot, variable-length routes
+  const float *mask;     // PROB_STEP: [B][A][n] f32, 0 = closed
+  int step;              // PROB_STEP: step index (RNG counter word)
   const float *demand;   // [B][n]
   float capacity;
   int Lmax;              // rows of paths (and Lmax-1 rows of logp)
@@ -119,9 +121,15 @@ struct Visited {
   }
 };
 
-template <int VEC, int CH, int MODE, bool LOGP, bool CVRP>
+enum { PROB_TSP = 0, PROB_CVRP = 1, PROB_STEP = 2 };
+
+// PROB_TSP: whole closed tour; PROB_CVRP: whole capacity-constrained route sequence;
+// PROB_STEP: ONE draw per ant from an externally maintained mask (ACO.pick_move for the sibling
+// problems, whose feasibility logic stays with the caller).
+template <int VEC, int CH, int MODE, bool LOGP, int PROB>
 __global__ void __launch_bounds__(256)
 tsp_sample_kernel(const SampleParams p) {
+  constexpr bool CVRP = PROB == PROB_CVRP, STEP = PROB == PROB_STEP;
   constexpr int NJ = CH * VEC;                          // candidates per lane
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -134,12 +142,12 @@ tsp_sample_kernel(const SampleParams p) {
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
   const float *Pb = p.P + (size_t)b * n * ld + lane * VEC;
   const float *Rb = (MODE == DACO_RACE_PHILOX) ? p.R + (size_t)b * n * ld + lane * VEC : nullptr;
-  const int rows = CVRP ? p.Lmax : n;                    // rows of paths for one instance
-  int64_t *path_out = p.paths + (size_t)b * rows * A + a;
+  const int rows = CVRP ? p.Lmax : (STEP ? 2 : n);       // rows of paths for one instance (STEP: logp has 1 row)
+  int64_t *path_out = p.paths + (STEP ? (size_t)b * A : (size_t)b * rows * A) + a;
   float *logp_out = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
-  const float *dist_b = (!CVRP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
-  uint32_t *nbr_a = (!CVRP && p.nbr) ? p.nbr + ((size_t)b * A + a) * n : nullptr;
+  const float *dist_b = (PROB == PROB_TSP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
+  uint32_t *nbr_a = (PROB == PROB_TSP && p.nbr) ? p.nbr + ((size_t)b * A + a) * n : nullptr;
   int pprev = 0, second = 0;                            // neighbour-table bookkeeping
   const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
 
@@ -162,8 +170,8 @@ tsp_sample_kernel(const SampleParams p) {
     if ((unsigned)lane == (vi & 63u)) vis.set((int)bit);
   };
   int own_lane = -1, own_bit = 0;                       // SCAN: owner of the last choice, known without division
-  if constexpr (!CVRP) mark(prev);
-  if (lane == 0) path_out[0] = prev;
+  if constexpr (PROB == PROB_TSP) mark(prev);
+  if (lane == 0 && !STEP) path_out[0] = prev;
 
   // CVRP state: this lane's candidates' demands, customers left, load on the current route
   float dem[CH][VEC];
@@ -183,10 +191,19 @@ tsp_sample_kernel(const SampleParams p) {
   bool infeasible = false, overflow = false;
   float cost = 0.0f, dpend = 0.0f;                      // fused tour length (edge added one step late)
 
-  int t = 1;
-  for (; CVRP ? (t < p.Lmax && !(remaining == 0 && prev == 0)) : (t < n); ++t) {
+  const int t0 = STEP ? p.step : 1;                     // STEP: the caller's step index keys the RNG
+  int t = t0;
+  for (; CVRP ? (t < p.Lmax && !(remaining == 0 && prev == 0)) : (STEP ? t == t0 : t < n); ++t) {
     // ---- candidates closed at this step: visited, plus (CVRP) over capacity / depot rule
     Visited blk = vis;
+    if constexpr (STEP) {                                // closed = the caller's mask is 0
+      const float *mrow = p.mask + ((size_t)b * A + a) * n;
+      static_for<NJ>([&](auto J) {
+        constexpr int j = J, c = j / VEC, v = j % VEC;
+        const int k = (c * 64 + lane) * VEC + v;
+        blk.template set_if<j>(k < n ? mrow[k] == 0.0f : true);
+      });
+    }
     if constexpr (CVRP) {
       if (MODE == DACO_RACE_NOISE && t - 1 >= p.noise_steps) { overflow = true; break; }
       const float rem = p.capacity - used;
@@ -207,8 +224,8 @@ tsp_sample_kernel(const SampleParams p) {
 
     if constexpr (MODE == DACO_SCAN) {
       // uniform for step t: lane (t&63), component (t>>6)&3 of the Philox block (t>>8)*64 + lane
-      if ((t & 63) == 0 || t == 1) {
-        if ((t & 255) == 0 || t == 1) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 8) << 6) + lane));
+      if ((t & 63) == 0 || t == t0) {
+        if ((t & 255) == 0 || t == t0) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 8) << 6) + lane));
         ucur = comp(ublk, (t >> 6) & 3);
       }
       const uint32_t ux = (uint32_t)readlane_i((int)ucur, t & 63);
@@ -281,7 +298,7 @@ tsp_sample_kernel(const SampleParams p) {
         pchoice = p.P[((size_t)b * n + prev) * ld + choice];
       }
     } else {  // DACO_RACE_NOISE: the arithmetic of torch.multinomial's one-sample path
-      const float *q = p.noise + (((size_t)b * (CVRP ? p.noise_steps : n - 1) + (t - 1)) * A + a) * n;
+      const float *q = p.noise + (((size_t)b * (CVRP ? p.noise_steps : (STEP ? 1 : n - 1)) + (t - t0)) * A + a) * n;
       float part = 0.0f;
       static_for<NJ>([&](auto J) {
         constexpr int j = J, c = j / VEC, v = j % VEC;
@@ -330,19 +347,19 @@ tsp_sample_kernel(const SampleParams p) {
       if (lane == 0) {
         // (noise mode with normalisation passes: pchoice is already the normalised probability)
         const float pr = (MODE == DACO_RACE_NOISE && p.norm_passes > 0) ? pchoice : pchoice / S;
-        logp_out[(size_t)(t - 1) * A] = clamp_log(pr);
-        if (rs_out) rs_out[(size_t)(t - 1) * A] = S;
+        logp_out[(size_t)(t - t0) * A] = clamp_log(pr);
+        if (rs_out) rs_out[(size_t)(t - t0) * A] = S;
       }
     }
     if constexpr (CVRP) {
       if (choice != 0) { mark(choice); --remaining; }
       else used = 0.0f;
       used = used + demand_b[choice];                  // scalar load
-    } else {
+    } else if constexpr (PROB == PROB_TSP) {
       if (MODE == DACO_SCAN && own_lane >= 0) { if (lane == own_lane) vis.set(own_bit); }
       else mark(choice);
     }
-    if (lane == 0) path_out[(size_t)t * A] = choice;
+    if (lane == 0) path_out[STEP ? 0 : (size_t)t * A] = choice;
     if (dist_b) {                                        // fused gen_path_costs (wave-uniform)
       cost = cost + dpend;
       dpend = dist_b[(unsigned)choice * (unsigned)n + (unsigned)prev];   // d[u_t][u_{t-1}], scalar load
@@ -381,7 +398,7 @@ tsp_sample_kernel(const SampleParams p) {
 }
 
 // ------------------------------------------------------------------ host dispatch
-template <int VEC, int CH, bool CVRP>
+template <int VEC, int CH, int CVRP>
 static hipError_t launch_sample(const SampleParams &sp, int mode, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 3) / 4;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
@@ -393,7 +410,7 @@ static hipError_t launch_sample(const SampleParams &sp, int mode, bool logp, hip
   return hipGetLastError();
 }
 
-template <bool CVRP>
+template <int CVRP>
 static hipError_t dispatch_sample(const SampleParams &sp, int vec, int CH, int mode, bool lp, hipStream_t s) {
   if (vec == 1) return launch_sample<1, 1, CVRP>(sp, mode, lp, s);
   if (vec == 2) return launch_sample<2, 1, CVRP>(sp, mode, lp, s);
@@ -473,10 +490,11 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
   sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 0; sp.lens = nullptr;
+  sp.mask = nullptr; sp.step = 0;
   const bool lp = logp != nullptr;
   hipError_t e;
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
-  e = dispatch_sample<false>(sp, vec, CH, mode, lp, s);
+  e = dispatch_sample<PROB_TSP>(sp, vec, CH, mode, lp, s);
   if (e != hipSuccess) { set_error("tsp_sample_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
   return DACO_OK;
@@ -515,7 +533,57 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
-  hipError_t e = dispatch_sample<true>(sp, vec, CH, mode, logp != nullptr, s);
+  sp.mask = nullptr; sp.step = 0;
+  hipError_t e = dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
   if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+// ------------------------------------------------------------------ step-wise API (sibling problems)
+extern "C" int daco_prob_matrix(void *stream, int B, int n, const float *tau, long tau_bstride, const float *eta,
+                                long eta_bstride, float alpha, float beta, int mode, void *workspace,
+                                size_t workspace_bytes) {
+  if (B <= 0 || n < 2 || !tau || !eta || !workspace) { set_error("daco_prob_matrix: bad argument"); return DACO_E_BADARG; }
+  if (n > DACO_MAX_NODES) { set_error("daco_prob_matrix: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
+  const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
+  if (workspace_bytes < need) { set_error("daco_prob_matrix: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  const int ld = ld_alloc(n);
+  float *P = (float *)workspace;
+  float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
+  const long total = (long)B * n * ld;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, n, ld, tau, tau_bstride, eta,
+                     eta_bstride, alpha, beta, P, R);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("prob_matrix_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+extern "C" int daco_pick_move(void *stream, int B, int n, int A, const void *prob_workspace, size_t workspace_bytes,
+                              int mode, const int64_t *prev, const float *mask, const float *noise, uint64_t seed,
+                              uint64_t iter, uint32_t ant_gid0, int step, int64_t *actions, float *logp,
+                              float *rowsum, int32_t *flags) {
+  if (B <= 0 || n < 2 || A <= 0 || !prob_workspace || !prev || !mask || !actions || step < 0) {
+    set_error("daco_pick_move: bad argument (B=%d n=%d A=%d step=%d)", B, n, A, step);
+    return DACO_E_BADARG;
+  }
+  if (n > DACO_MAX_NODES) { set_error("daco_pick_move: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
+  if (mode < 0 || mode > 2) { set_error("daco_pick_move: bad mode %d", mode); return DACO_E_BADARG; }
+  if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_pick_move: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
+  const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
+  if (workspace_bytes < need) { set_error("daco_pick_move: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  const int vec = vec_for_n(n), CH = inst_chunks(n), ld = ld_alloc(n);
+  SampleParams sp;
+  sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
+  sp.P = (const float *)prob_workspace;
+  sp.R = mode == DACO_RACE_PHILOX ? (const float *)((const char *)prob_workspace + need / 2) : nullptr;
+  sp.norm_passes = 1; sp.start = prev; sp.fixed_start = -1; sp.noise = noise; sp.seed = seed; sp.iter = iter;
+  sp.ant_gid0 = ant_gid0; sp.paths = actions; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
+  sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
+  sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 1; sp.lens = nullptr;
+  sp.mask = mask; sp.step = step;
+  hipError_t e = dispatch_sample<PROB_STEP>(sp, vec, CH, mode, logp != nullptr, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("pick_move kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }

@@ -171,6 +171,53 @@ def sample_backward(tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, 
     return grad
 
 
+class PickService:
+    """ACO.pick_move as a service for the sibling problems (op, pctsp, sop, smtwtp, bpp, mkp):
+    build the fused transition matrix once per construction, then draw one action per ant per call
+    from a caller-maintained mask (include/deepaco_hip.h: daco_prob_matrix + daco_pick_move)."""
+
+    def __init__(self, tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", seed=0, it=0, ant_gid0=0):
+        _require_gpu(tau, eta)
+        self.n = tau.shape[-1]
+        self.B = tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1)
+        self.A, self.mode = n_ants, (MODES[mode] if isinstance(mode, str) else int(mode))
+        self.seed, self.it, self.gid0, self.dev = int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0), tau.device
+        tau, tbs = _bstride(tau, self.n)
+        eta, ebs = _bstride(eta, self.n)
+        L = _lib.lib()
+        with torch.cuda.device(self.dev):
+            nbytes = L.daco_tsp_sample_workspace_bytes(self.B, self.n, self.mode)
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)     # owned: lives across steps
+            rc = L.daco_prob_matrix(_stream(self.dev), self.B, self.n, tau.data_ptr(), tbs, eta.data_ptr(), ebs,
+                                    float(alpha), float(beta), self.mode, self.ws.data_ptr(), self.ws.numel())
+        _lib.check(rc, "daco_prob_matrix")
+        self.flags = torch.zeros((self.B,), dtype=torch.int32, device=self.dev)
+
+    def pick(self, prev, mask, step, require_prob=False, noise=None):
+        """prev [B,A] (or [A]) int64, mask [B,A,n] (or [A,n]) float -> (actions, log_probs|None, rowsum|None)
+        with the leading batch dimension of the inputs."""
+        squeeze = prev.dim() == 1
+        prev = prev.reshape(self.B, self.A).to(torch.int64).contiguous()
+        mask = _f32c(mask).reshape(self.B, self.A, self.n)
+        m = RACE_NOISE if noise is not None else self.mode
+        if noise is not None:
+            noise = _f32c(noise).reshape(self.B, self.A, self.n)
+        with torch.cuda.device(self.dev):
+            actions = torch.empty((self.B, self.A), dtype=torch.int64, device=self.dev)
+            logp = torch.empty((self.B, self.A), dtype=torch.float32, device=self.dev) if require_prob else None
+            rowsum = torch.empty((self.B, self.A), dtype=torch.float32, device=self.dev) if require_prob else None
+            rc = _lib.lib().daco_pick_move(_stream(self.dev), self.B, self.n, self.A, self.ws.data_ptr(), self.ws.numel(),
+                                           m, prev.data_ptr(), mask.data_ptr(),
+                                           noise.data_ptr() if noise is not None else None, self.seed, self.it,
+                                           self.gid0, int(step), actions.data_ptr(),
+                                           logp.data_ptr() if require_prob else None,
+                                           rowsum.data_ptr() if require_prob else None, self.flags.data_ptr())
+        _lib.check(rc, "daco_pick_move")
+        if squeeze:
+            return actions[0], (logp[0] if require_prob else None), (rowsum[0] if require_prob else None)
+        return actions, logp, rowsum
+
+
 def tour_costs(dist, paths, closed=True):
     """ACO.gen_path_costs for a batch (tsp/aco.py:121-132; closed=False: cvrp/aco.py:133-136)."""
     _require_gpu(dist, paths)
@@ -188,16 +235,19 @@ def tour_costs(dist, paths, closed=True):
 
 
 def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, clamp_min=None,
-                      clamp_max=None, floor=0.0, nbr=None):
+                      clamp_max=None, floor=0.0, nbr=None, weights=None, hub=0):
     """In-place ACO.update_pheronome for a batch (tsp/aco.py:95-118, cvrp/aco.py:107-130).
 
-    tau [B,n,n] f32 contiguous (modified in place); clamp_min/clamp_max: [B] f32 tensors or None."""
+    tau [B,n,n] f32 contiguous (modified in place); clamp_min/clamp_max: [B] f32 tensors or None.
+    weights [B,A]: explicit deposit per ant (default 1/cost); hub: see include/deepaco_hip.h."""
     _require_gpu(tau, paths, costs, clamp_min, clamp_max)
     assert tau.dim() == 3 and tau.dtype == torch.float32 and tau.is_contiguous()
     B, n, _ = tau.shape
     _, length, A = paths.shape
     paths = paths.contiguous()
     costs = _f32c(costs)
+    if weights is not None:
+        weights = _f32c(weights)
     dev = tau.device
     L = _lib.lib()
     with torch.cuda.device(dev):
@@ -208,6 +258,7 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
                                      clamp_min.data_ptr() if clamp_min is not None else None,
                                      clamp_max.data_ptr() if clamp_max is not None else None,
                                      float(floor), nbr.data_ptr() if nbr is not None else None,
+                                     weights.data_ptr() if weights is not None else None, int(hub),
                                      ws.data_ptr(), ws.numel())
     _lib.check(rc, "daco_pheromone_update")
     return tau

@@ -127,6 +127,26 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      int32_t *lens, int32_t *flags, void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
+ * daco_prob_matrix + daco_pick_move -- ACO.pick_move as a step-wise service
+ *   tsp/aco.py:165-177 and its copies in op/aco.py:186-193, pctsp/aco.py:157-164,
+ *   sop/aco.py:156-169, smtwtp/aco.py:139-151, bpp/aco.py:157-164, mkp/aco.py:147-154
+ * The sibling problems keep their feasibility rules on the caller's side and only need the
+ * draw: dist = tau[prev]^alpha * eta[prev]^beta * mask -> Categorical(dist).sample()/log_prob.
+ * daco_prob_matrix builds the fused transition matrix once per solution construction into
+ * `workspace` (daco_tsp_sample_workspace_bytes(B, n, mode) bytes); daco_pick_move then performs
+ * ONE draw per ant: prev [B][A] int64, mask [B][A][n] f32 (0 = closed), actions out [B][A] int64,
+ * logp / rowsum out [B][A] or NULL, noise [B][A][n] for DACO_RACE_NOISE.  `step` keys the Philox
+ * counter (use the step index of the construction loop).
+ */
+int daco_prob_matrix(void *stream, int B, int n, const float *tau, long tau_bstride,
+                     const float *eta, long eta_bstride, float alpha, float beta, int mode,
+                     void *workspace, size_t workspace_bytes);
+int daco_pick_move(void *stream, int B, int n, int A, const void *prob_workspace,
+                   size_t workspace_bytes, int mode, const int64_t *prev, const float *mask,
+                   const float *noise, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int step,
+                   int64_t *actions, float *logp, float *rowsum, int32_t *flags);
+
+/* ---------------------------------------------------------------------------------------------
  * daco_sample_backward -- replaces autograd through ACO.gen_path(require_prob=True)
  *   (tsp/aco.py:154-176, cvrp/aco.py:153-173; consumed by the REINFORCE losses in
  *    tsp/train.ipynb:45-49, tsp_nls/train.py:31-44, cvrp/train.ipynb:45-51)
@@ -170,14 +190,20 @@ int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dis
  *   clamp_min/clamp_max: [B] f32 device arrays or NULL (per-instance MMAS bounds)
  *   nbr   optional [B][A][n] uint32 as written by daco_tsp_sample (symmetric only); if NULL it
  *         is rebuilt from `paths` in the workspace
+ *   weights optional [B][A] f32: the amount each ant deposits, for the siblings whose rule is
+ *         not 1/cost (op/aco.py:134-139 Q*obj, bpp/aco.py:113-118 fit/n_ants, smtwtp/aco.py:90-95
+ *         1/(cost+1)); NULL = 1/cost.  `costs` still selects the elitist ant (first minimum).
+ *   hub   directed only: the one node a solution may leave several times (depot 0 in cvrp/
+ *         pctsp/bpp, the dummy end node in op/mkp); every other node is left at most once;
+ *         -1 if there is none (sop, smtwtp).  Edges (hub,hub) of one ant collapse to one add.
  *   workspace: daco_pheromone_update_workspace_bytes(B, n, len, A)
  */
 size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A);
 int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
                           const int64_t *paths, const float *costs, float decay, int elitist,
                           int symmetric, const float *clamp_min, const float *clamp_max,
-                          float floor_val, const uint32_t *nbr, void *workspace,
-                          size_t workspace_bytes);
+                          float floor_val, const uint32_t *nbr, const float *weights, int hub,
+                          void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_two_opt -- replaces batched_two_opt_python / _two_opt_python / two_opt_once

@@ -190,3 +190,29 @@ def cvrp_sample_rng(P, demand, capacity, A, mode, seed, it=0, ant_gid0=0, Lmax=N
     if L < 0:
         return None, None, L
     return paths[:L], (logp[:L - 1] if require_prob else None), L
+
+
+def pheromone_update_directed(tau, paths, costs, decay, weights=None, elitist=False, clamp_min=0.0, clamp_max=0.0,
+                              floor=0.0):
+    tau = _f32(tau).copy()
+    paths, costs = _i64(paths), _f32(costs)
+    n = tau.shape[0]
+    length, A = paths.shape
+    w = _f32(weights) if weights is not None else None
+    lib().orc_pheromone_update_directed(n, length, A, _p(tau), _p(paths), _p(costs), _p(w) if w is not None else None,
+                                        C.c_float(decay), int(elitist), C.c_float(clamp_min), C.c_float(clamp_max),
+                                        C.c_float(floor))
+    return tau
+
+
+def pick_move(P, prev, mask, mode="scan", noise=None, seed=0, it=0, ant_gid0=0, step=1, require_prob=True):
+    P, mask, prev = _f32(P), _f32(mask), _i64(prev)
+    n, A = P.shape[0], prev.shape[0]
+    actions = np.zeros(A, dtype=np.int64)
+    logp = np.zeros(A, dtype=np.float32) if require_prob else None
+    m = 0 if noise is not None else {"race": 1, "scan": 2}[mode]
+    nz = _f32(noise) if noise is not None else None
+    rc = lib().orc_pick_move(m, n, A, _p(P), _p(prev), _p(mask), _p(nz) if nz is not None else None, C.c_uint64(seed),
+                             C.c_uint64(it), C.c_uint32(ant_gid0), int(step), _p(actions),
+                             _p(logp) if require_prob else None)
+    return actions, logp, rc

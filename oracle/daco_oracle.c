@@ -355,9 +355,21 @@ void orc_pheromone_update_tsp(int n, int A, float *tau, const int64_t *paths, co
 /* ------------------------------------------------------------------ C5: pheromone update, CVRP
  * cvrp/aco.py:107-130.  Directed: tau[path[:-1], path[1:]] += w, duplicates of an index pair
  * (the padding edge (0,0)) collapse to one add; floor tau < 1e-10 -> 1e-10. */
+void orc_pheromone_update_directed(int n, int len, int A, float *tau, const int64_t *paths,
+                                   const float *costs, const float *weights, float decay, int elitist,
+                                   float clamp_min, float clamp_max, float floor_val);
 void orc_pheromone_update_cvrp(int n, int len, int A, float *tau, const int64_t *paths,
                                const float *costs, float decay, int elitist, float clamp_min,
                                float clamp_max) {
+  orc_pheromone_update_directed(n, len, A, tau, paths, costs, NULL, decay, elitist, clamp_min, clamp_max, 1e-10f);
+}
+/* The same directed deposit with an explicit amount per ant (weights != NULL) for the siblings
+ * whose rule is not 1/cost: op/aco.py:128-143, pctsp/aco.py:87-102, sop/aco.py:77-98,
+ * smtwtp/aco.py:77-97, bpp/aco.py:100-118, mkp/aco.py:88-103.  `costs` picks the elitist ant
+ * (first minimum); floor_val > 0 applies tau < floor -> floor at the end. */
+void orc_pheromone_update_directed(int n, int len, int A, float *tau, const int64_t *paths,
+                                   const float *costs, const float *weights, float decay, int elitist,
+                                   float clamp_min, float clamp_max, float floor_val) {
   float *buf = (float *)malloc(sizeof(float) * (len > 0 ? len : 1));
   for (long i = 0; i < (long)n * n; ++i) tau[i] = tau[i] * decay;
   int lo = 0, hi = A;
@@ -367,7 +379,7 @@ void orc_pheromone_update_cvrp(int n, int len, int A, float *tau, const int64_t 
     lo = b; hi = b + 1;
   }
   for (int a = lo; a < hi; ++a) {
-    float w = 1.0f / costs[a];
+    float w = weights ? weights[a] : 1.0f / costs[a];
     for (int k = 0; k + 1 < len; ++k)
       buf[k] = tau[paths[(long)k * A + a] * n + paths[(long)(k + 1) * A + a]] + w;
     for (int k = 0; k + 1 < len; ++k)
@@ -378,8 +390,35 @@ void orc_pheromone_update_cvrp(int n, int len, int A, float *tau, const int64_t 
       if (tau[i] < clamp_min) tau[i] = clamp_min;
       if (tau[i] > clamp_max) tau[i] = clamp_max;
     }
-  for (long i = 0; i < (long)n * n; ++i) if (tau[i] < 1e-10f) tau[i] = 1e-10f;
+  if (floor_val > 0.0f)
+    for (long i = 0; i < (long)n * n; ++i) if (tau[i] < floor_val) tau[i] = floor_val;
   free(buf);
+}
+
+/* ------------------------------------------------------------------ T2 as a service: one draw per ant
+ * ACO.pick_move (tsp/aco.py:165-177 and its copies in the sibling problems) on a caller-supplied
+ * mask [A][n] (0 = closed).  prev [A]; noise [A][n] for the recorded-noise mode; `step` keys the
+ * Philox counters exactly as the step index t does in the fused samplers. */
+int orc_pick_move(int mode, int n, int A, const float *P, const int64_t *prev, const float *mask,
+                  const float *noise, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int step,
+                  int64_t *actions, float *logp) {
+  int rc = ORC_OK;
+  float *p = (float *)malloc(sizeof(float) * n);
+  unsigned char *blocked = (unsigned char *)malloc(n);
+  for (int a = 0; a < A; ++a) {
+    const float *row = P + (long)prev[a] * n;
+    for (int k = 0; k < n; ++k) blocked[k] = mask[(long)a * n + k] == 0.0f;
+    float pr = 0.0f;
+    int best;
+    if (mode == MODE_NOISE) best = draw_noise(n, row, blocked, noise + (long)a * n, 1, p, &pr);
+    else if (mode == MODE_RACE) best = draw_race(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, p, logp ? &pr : NULL);
+    else best = draw_scan(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, &pr);
+    if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
+    actions[a] = best;
+    if (logp) logp[a] = clamp_log(pr);
+  }
+  free(p); free(blocked);
+  return rc;
 }
 
 /* ------------------------------------------------------------------ O1/O2: 2-opt
