@@ -402,6 +402,116 @@ def gen_net():
              emb_eval=emb_eval, heu_train=heu_train, heu_mat=mat, k_sparse=np.int32(k or 0), **extra, **weights)
 
 
+def load_ref_dir(subdir, alias):
+    """Import <subdir>/aco.py with <subdir> on sys.path (smtwtp/aco.py does `import utils`)."""
+    d = os.path.join(REF, subdir)
+    sys.path.insert(0, d)
+    for m in ("utils",):
+        sys.modules.pop(m, None)
+    try:
+        aco = load_ref(subdir, "aco", alias)
+        utils = load_ref(subdir, "utils", alias + "_utils")
+    finally:
+        sys.path.remove(d)
+        sys.modules.pop("utils", None)
+    return aco, utils
+
+
+def tapped(fn, *a, **k):
+    with NoiseTap() as tap:
+        out = fn(*a, **k)
+    return out, torch.stack(tap.q)
+
+
+def gen_siblings():
+    """S1-S6: one construction (recorded noise) + objective + pheromone update per sibling problem."""
+    A = 8
+    # ---- S4 SMTWTP (smtwtp/aco.py)
+    aco_m, utils = load_ref_dir("smtwtp", "ref_smtwtp")
+    torch.manual_seed(101)
+    _, due, wts, proc = utils.instance_gen(20, "cpu")
+    aco = aco_m.ACO(due, wts, proc, n_ants=A)
+    aco.pheromone = torch.rand(21, 21) + 0.2
+    tau0, heu = aco.pheromone.clone(), aco.heuristic.clone()
+    (paths, logp), q = tapped(aco.gen_path, True)
+    costs = aco.gen_path_costs(paths)
+    aco.update_pheronome(paths, costs)
+    el = aco_m.ACO(due, wts, proc, n_ants=A, elitist=True, pheromone=tau0.clone())
+    el.update_pheronome(paths, costs)
+    save("s4_smtwtp_n20", due_time=due, weights=wts, processing_time=proc, pheromone=tau0, heuristic=heu, noise=q,
+         paths=paths, log_probs=logp, costs=costs, decay=np.float32(aco.decay), pheromone_as=aco.pheromone,
+         pheromone_elitist=el.pheromone)
+    # ---- S3 SOP (sop/aco.py)
+    aco_m, utils = load_ref_dir("sop", "ref_sop")
+    torch.manual_seed(102)
+    dist, adj, prec = utils.training_instance_gen(20, "cpu")
+    aco = aco_m.ACO(dist, prec, n_ants=A, pheromone=torch.rand(20, 20) + 0.2)
+    tau0 = aco.pheromone.clone()
+    (paths, logp), q = tapped(aco.gen_path, True)
+    costs = aco.gen_path_costs(paths)
+    aco.update_pheronome(paths, costs)
+    save("s3_sop_n20", distances=dist, prec_cons=prec, pheromone=tau0, heuristic=aco.heuristic, noise=q, paths=paths,
+         log_probs=logp, costs=costs, decay=np.float32(aco.decay), pheromone_as=aco.pheromone)
+    # ---- S2 PCTSP (pctsp/aco.py)
+    aco_m, utils = load_ref_dir("pctsp", "ref_pctsp")
+    torch.manual_seed(103)
+    dist, prizes, pen = utils.gen_inst(20, "cpu")
+    aco = aco_m.ACO(dist, prizes, pen, n_ants=A)
+    aco.pheromone = torch.rand(21, 21) + 0.2
+    tau0 = aco.pheromone.clone()
+    (out, q) = tapped(aco.gen_sol, True)
+    sols, logp = out
+    objs = aco.gen_sol_obj(sols)
+    best_obj, best_idx = objs.max(dim=0)          # as run() does (pctsp/aco.py:73)
+    aco.update_pheronome(sols.T, objs, best_obj, best_idx)
+    save("s2_pctsp_n20", distances=dist, prizes=prizes, penalties=pen, pheromone=tau0, heuristic=aco.heuristic,
+         noise=q, sols=sols, log_probs=logp, objs=objs, decay=np.float32(aco.decay), pheromone_as=aco.pheromone)
+    # ---- S1 OP (op/aco.py)
+    aco_m, utils = load_ref_dir("op", "ref_op")
+    torch.manual_seed(104)
+    coor = torch.rand(30, 2)
+    _, dist, prizes = utils.gen_pyg_data(coor, k_sparse=8)
+    aco = aco_m.ACO(dist.clone(), prizes.clone(), 3.0, n_ants=A, k_sparse=8)
+    tau0 = aco.pheromone.clone()
+    (out, q) = tapped(aco.gen_sol, True)
+    sols, logp = out
+    objs = aco.gen_sol_obj(sols)
+    best_obj, best_idx = objs.max(dim=0)
+    aco.update_pheronome(sols.T, objs, best_obj, best_idx)
+    save("s1_op_n30", distances_in=dist, prizes_in=prizes, max_len=np.float32(3.0), k_sparse=np.int32(8),
+         distances=aco.distances, prizes=aco.prizes, pheromone=tau0, heuristic=aco.heuristic, Q=aco.Q, noise=q,
+         sols=sols, log_probs=logp, objs=objs, decay=np.float32(aco.decay), pheromone_as=aco.pheromone)
+    # ---- S5 BPP (bpp/aco.py)
+    aco_m, utils = load_ref_dir("bpp", "ref_bpp")
+    torch.manual_seed(105)
+    demand = utils.gen_instance(24, "cpu")
+    aco = aco_m.ACO(demand, n_ants=A)
+    aco.pheromone = torch.rand(25, 25) + 0.2
+    tau0 = aco.pheromone.clone()
+    (out, q) = tapped(aco.gen_path, True)
+    paths, logp = out
+    costs = aco.gen_path_costs(paths)
+    aco.update_pheronome(paths, -costs)           # as run() does (bpp/aco.py:96)
+    save("s5_bpp_n24", demand=demand, capacity=np.float32(aco.capacity), pheromone=tau0, heuristic=aco.heuristic,
+         noise=q, paths=paths, log_probs=logp, costs=costs, decay=np.float32(aco.decay), pheromone_as=aco.pheromone)
+    # ---- S6 MKP (mkp/aco.py)
+    aco_m, utils = load_ref_dir("mkp", "ref_mkp")
+    torch.manual_seed(106)
+    np.random.seed(106)
+    prize, weight = utils.gen_instance(20, 3, "cpu")
+    aco = aco_m.ACO(prize.clone(), weight.clone(), n_ants=A)
+    aco.pheromone = torch.rand(21, 21) + 0.2
+    tau0 = aco.pheromone.clone()
+    (out, q) = tapped(aco.gen_sol, True)
+    sols, logp = out
+    objs = aco.gen_sol_obj(sols)
+    best_obj, best_idx = objs.max(dim=0)
+    aco.update_pheronome(sols.T, objs, best_obj.item(), best_idx.item())
+    save("s6_mkp_n20", prize_in=prize, weight_in=weight, prize=aco.prize, weight=aco.weight, pheromone=tau0,
+         heuristic=aco.heuristic, Q=aco.Q, noise=q, start=sols[0], sols=sols, log_probs=logp, objs=objs,
+         decay=np.float32(aco.decay), pheromone_as=aco.pheromone)
+
+
 def main():
     torch.set_num_threads(1)
     print("reference:", REF)
@@ -416,6 +526,7 @@ def main():
     print("CVRP (G1/G2)"); gen_cvrp(cvrp_aco)
     print("gradients (G3)"); gen_grads(tsp_aco, cvrp_aco)
     print("Net forward (G5)"); gen_net()
+    print("siblings (S1-S6)"); gen_siblings()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,173 @@
+"""GPU parity tests for the sibling problems (S1-S6): with the reference's recorded noise every class
+rebuilds the reference's solutions exactly; objectives and the pheromone update match."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def noise_list(g):
+    return [T(q) for q in g["noise"]]
+
+
+def check_update(aco, fn, sols, g, key="pheromone_as"):
+    fn()
+    np.testing.assert_allclose(aco.pheromone.cpu().numpy(), g[key], rtol=2e-6, atol=1e-12)
+
+
+def test_smtwtp():
+    from deepaco_amd.smtwtp.aco import ACO
+    g = load_golden("s4_smtwtp_n20")
+    A = g["paths"].shape[1]
+    aco = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=A, pheromone=T(g["pheromone"]),
+              device="cuda:0")
+    np.testing.assert_array_equal(aco.heuristic.cpu().numpy(), g["heuristic"])
+    paths, logp = aco.gen_path(True, _noise=noise_list(g))
+    assert np.array_equal(paths.cpu().numpy(), g["paths"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(aco.gen_path_costs(paths).cpu().numpy(), g["costs"], rtol=1e-5)
+    aco.update_pheronome(paths, T(g["costs"]))
+    assert np.array_equal(aco.pheromone.cpu().numpy().view(np.uint32), g["pheromone_as"].view(np.uint32))
+    el = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=A, pheromone=T(g["pheromone"]),
+             elitist=True, device="cuda:0")
+    el.update_pheronome(paths, T(g["costs"]))
+    assert np.array_equal(el.pheromone.cpu().numpy().view(np.uint32), g["pheromone_elitist"].view(np.uint32))
+    low = aco.run(3)
+    assert float(low) <= float(g["costs"].max())
+
+
+def test_sop():
+    from deepaco_amd.sop.aco import ACO
+    g = load_golden("s3_sop_n20")
+    A = g["paths"].shape[1]
+    aco = ACO(T(g["distances"]), T(g["prec_cons"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
+    paths, logp = aco.gen_path(True, _noise=noise_list(g))
+    assert np.array_equal(paths.cpu().numpy(), g["paths"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(aco.gen_path_costs(paths).cpu().numpy(), g["costs"], rtol=1e-5)
+    aco.update_pheronome(paths, T(g["costs"]))
+    assert np.array_equal(aco.pheromone.cpu().numpy().view(np.uint32), g["pheromone_as"].view(np.uint32))
+    # precedence holds for freshly sampled paths in both samplers
+    for sampler in ("scan", "race"):
+        a2 = ACO(T(g["distances"]), T(g["prec_cons"]), n_ants=64, device="cuda:0", sampler=sampler, seed=4)
+        p = a2.gen_path().cpu().numpy()
+        pos = np.argsort(p, axis=0)                       # pos[node, ant]
+        jj, kk = np.nonzero(g["prec_cons"])
+        assert (pos[kk] < pos[jj]).all() and (np.sort(p, axis=0) == np.arange(20)[:, None]).all()
+
+
+def test_pctsp():
+    from deepaco_amd.pctsp.aco import ACO
+    g = load_golden("s2_pctsp_n20")
+    A = g["sols"].shape[1]
+    aco = ACO(T(g["distances"]), T(g["prizes"]), T(g["penalties"]), n_ants=A, device="cuda:0")
+    np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
+    aco.heuristic, aco.pheromone = T(g["heuristic"]), T(g["pheromone"])
+    sols, logp = aco.gen_sol(True, _noise=noise_list(g))
+    assert np.array_equal(sols.cpu().numpy(), g["sols"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(aco.gen_sol_obj(sols).cpu().numpy(), g["objs"], rtol=1e-5)
+    objs = T(g["objs"])
+    best_obj, best_idx = objs.max(dim=0)
+    aco.update_pheronome(sols.T, objs, best_obj, best_idx)
+    assert np.array_equal(aco.pheromone.cpu().numpy().view(np.uint32), g["pheromone_as"].view(np.uint32))
+    best, sol = aco.run(2)
+    assert sol[0] == 0 and float(best) > 0
+
+
+def test_op():
+    from deepaco_amd.op.aco import ACO
+    g = load_golden("s1_op_n30")
+    A = g["sols"].shape[1]
+    aco = ACO(T(g["distances_in"]), T(g["prizes_in"]), float(g["max_len"]), n_ants=A, k_sparse=int(g["k_sparse"]),
+              device="cuda:0")
+    np.testing.assert_array_equal(aco.distances.cpu().numpy(), g["distances"])
+    np.testing.assert_array_equal(aco.prizes.cpu().numpy(), g["prizes"])
+    np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
+    aco.heuristic = T(g["heuristic"])
+    sols, logp = aco.gen_sol(True, _noise=noise_list(g))
+    assert np.array_equal(sols.cpu().numpy(), g["sols"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(aco.gen_sol_obj(sols).cpu().numpy(), g["objs"], rtol=1e-6)
+    objs = T(g["objs"])
+    best_obj, best_idx = objs.max(dim=0)
+    aco.update_pheronome(sols.T, objs, best_obj, best_idx)
+    assert np.array_equal(aco.pheromone.cpu().numpy().view(np.uint32), g["pheromone_as"].view(np.uint32))
+    # fresh solutions respect the length budget (route + way back to the depot)
+    a2 = ACO(T(g["distances_in"]), T(g["prizes_in"]), float(g["max_len"]), n_ants=64, k_sparse=int(g["k_sparse"]),
+             device="cuda:0", seed=3)
+    s = a2.gen_sol()
+    d = a2.distances
+    real = s.clone()
+    length = torch.zeros(64, device=dev())
+    last = torch.zeros(64, dtype=torch.long, device=dev())
+    for k in range(1, s.shape[0]):
+        step = real[k]
+        move = step != a2.n
+        length = length + torch.where(move, d[last, step], torch.zeros_like(length))
+        last = torch.where(move, step, last)
+    back = torch.where(last != 0, d[last, torch.zeros_like(last)], torch.zeros_like(length))
+    assert float((length + back).max()) <= float(g["max_len"]) + 1e-4
+
+
+def test_bpp():
+    from deepaco_amd.bpp.aco import ACO
+    g = load_golden("s5_bpp_n24")
+    A = g["paths"].shape[1]
+    aco = ACO(T(g["demand"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
+    np.testing.assert_array_equal(aco.heuristic.cpu().numpy(), g["heuristic"])
+    paths, logp = aco.gen_path(True, _noise=noise_list(g))
+    assert np.array_equal(paths.cpu().numpy(), g["paths"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    costs = aco.gen_path_costs(paths)
+    np.testing.assert_allclose(costs.cpu().numpy(), g["costs"], rtol=1e-12)
+    aco.update_pheronome(paths, -T(g["costs"]))
+    np.testing.assert_allclose(aco.pheromone.cpu().numpy(), g["pheromone_as"], rtol=1e-6)
+    fit = aco.run(3)
+    assert 0 < float(fit) <= 1
+
+
+def test_mkp():
+    from deepaco_amd.mkp.aco import ACO
+    g = load_golden("s6_mkp_n20")
+    A = g["sols"].shape[1]
+    aco = ACO(T(g["prize_in"]), T(g["weight_in"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
+    np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
+    aco.heuristic = T(g["heuristic"])
+    sols, logp = aco.gen_sol(True, _noise=noise_list(g), _start=T(g["start"]))
+    assert np.array_equal(sols.cpu().numpy(), g["sols"])
+    np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(aco.gen_sol_obj(sols).cpu().numpy(), g["objs"], rtol=1e-6)
+    objs = T(g["objs"])
+    best_obj, best_idx = objs.max(dim=0)
+    aco.update_pheronome(sols.T, objs, best_obj.item(), best_idx.item())
+    assert np.array_equal(aco.pheromone.cpu().numpy().view(np.uint32), g["pheromone_as"].view(np.uint32))
+    # fresh solutions are feasible in every knapsack dimension
+    a2 = ACO(T(g["prize_in"]), T(g["weight_in"]), n_ants=64, device="cuda:0", seed=8)
+    s = a2.gen_sol().T
+    used = a2.weight[s].sum(dim=1)
+    assert float(used.max()) <= a2.n // 2 + 1e-5
+    best, _ = a2.run(2)
+    assert float(best) > 0
+
+
+def test_sibling_gradients_flow():
+    from deepaco_amd.smtwtp.aco import ACO
+    g = load_golden("s4_smtwtp_n20")
+    heu = T(g["heuristic"]).requires_grad_(True)
+    aco = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=8, heuristic=heu, device="cuda:0")
+    costs, logp = aco.sample()
+    loss = torch.sum((costs - costs.mean()) * logp.sum(dim=0)) / 8
+    loss.backward()
+    assert heu.grad is not None and bool(torch.isfinite(heu.grad).all()) and float(heu.grad.abs().sum()) > 0
