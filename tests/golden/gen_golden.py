@@ -486,6 +486,9 @@ def gen_siblings():
     torch.manual_seed(105)
     demand = utils.gen_instance(24, "cpu")
     aco = aco_m.ACO(demand, n_ants=A)
+    # numba types the fitness accumulators as float64 (int64 + float32 -> float64); under the identity
+    # shim numpy-2 scalars would stay float32, so hand the jitted functions a float64 demand array
+    aco.__dict__["demand_numpy"] = demand.numpy().astype(np.float64)
     aco.pheromone = torch.rand(25, 25) + 0.2
     tau0 = aco.pheromone.clone()
     (out, q) = tapped(aco.gen_path, True)

@@ -96,6 +96,8 @@ def test_op():
     np.testing.assert_array_equal(aco.prizes.cpu().numpy(), g["prizes"])
     np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
     aco.heuristic = T(g["heuristic"])
+    np.testing.assert_allclose(float(aco.Q), float(g["Q"]), rtol=1e-6)
+    aco.Q = T(g["Q"])                                     # (a GPU sum may round differently by one ulp)
     sols, logp = aco.gen_sol(True, _noise=noise_list(g))
     assert np.array_equal(sols.cpu().numpy(), g["sols"])
     np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
@@ -145,6 +147,7 @@ def test_mkp():
     aco = ACO(T(g["prize_in"]), T(g["weight_in"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
     np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
     aco.heuristic = T(g["heuristic"])
+    aco.Q = T(g["Q"])
     sols, logp = aco.gen_sol(True, _noise=noise_list(g), _start=T(g["start"]))
     assert np.array_equal(sols.cpu().numpy(), g["sols"])
     np.testing.assert_allclose(logp.cpu().numpy(), g["log_probs"], atol=2e-6, rtol=1e-5)
