@@ -239,3 +239,36 @@ def test_infeasible_row_sets_flag():
     for mode in ("scan", "race"):
         _, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=1)
         assert int(flags[0]) == 1
+
+
+# ------------------------------------------------------------------ 4. H3: inference schedule, statistical
+def test_inference_schedule_matches_cpu_port_statistically():
+    """tsp/test.ipynb infer_instance/test: incremental aco.run(t_diff) over t_aco = [1, 10, 20]; mean best
+    cost over instances must agree with the reference's CPU op sequence (oracle/torch_port.py) within
+    sampling noise, for both samplers (identical categorical distribution, different RNG streams)."""
+    from deepaco_amd.tsp.aco import ACO
+    from oracle import torch_port
+    n, A, inst = 60, 20, 10
+    t_aco = [1, 10, 20]
+    diffs = [t_aco[0]] + [t_aco[i + 1] - t_aco[i] for i in range(len(t_aco) - 1)]
+    dist, _, _ = make_instance(n, 777, inst)
+    torch.manual_seed(12345)
+    cpu = np.zeros(len(t_aco))
+    for b in range(inst):
+        d = dist[b]
+        tau, low = torch.ones_like(d), float("inf")
+        for i, td in enumerate(diffs):
+            for _ in range(td):
+                paths = torch_port.rollout(tau, 1 / d, A)
+                costs = torch_port.tour_lengths(d, paths)
+                low = min(low, float(costs.min()))
+                tau = torch_port.deposit(tau, paths, costs, 0.9)
+            cpu[i] += low / inst
+    for sampler in ("scan", "race"):
+        gpu = np.zeros(len(t_aco))
+        for b in range(inst):
+            aco = ACO(dist[b].to(dev()), n_ants=A, device="cuda:0", sampler=sampler, seed=1000 + b)
+            for i, td in enumerate(diffs):
+                gpu[i] += float(aco.run(td)) / inst
+        assert np.all(np.diff(gpu) <= 1e-6)                      # best-so-far never gets worse
+        np.testing.assert_allclose(gpu, cpu, rtol=0.05), (sampler, gpu, cpu)
