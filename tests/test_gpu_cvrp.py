@@ -133,3 +133,27 @@ def test_cvrp_class_run():
     assert float(low) <= first * 1.2 and aco.shortest_path[0] == 0
     with pytest.raises(NotImplementedError):
         ACO(d[0].to(dev()), demand[0].to(dev()), adaptive=True)
+
+
+def test_cvrp_nls_surface_float64_data():
+    """cvrp_nls instances are float64 with capacity 1.0 (cvrp_nls/utils.py:19-30); same sampler."""
+    from deepaco_amd.cvrp_nls.aco import ACO
+    d, demand, _, _ = cvrp_instance(40, 31)
+    cap = 1.0
+    dem = (demand[0] / 50.0).double()
+    aco = ACO(d[0].double().to(dev()), dem.to(dev()), n_ants=16, device="cuda:0", capacity=cap, seed=2)
+    costs, logp, paths = aco.sample()
+    assert costs.shape == (16,) and paths.shape[1] == 16 and logp.shape[0] == paths.shape[0] - 1
+    p = paths.cpu().numpy()
+    for a in range(16):
+        load, seen = 0.0, set()
+        for v in p[:, a]:
+            load = 0.0 if v == 0 else load + float(dem[v])
+            assert load <= cap + 1e-6
+            if v:
+                assert v not in seen
+                seen.add(int(v))
+        assert len(seen) == 40
+    with pytest.raises(NotImplementedError):
+        ACO(d[0].to(dev()), dem.to(dev()), swapstar=True, positions=torch.zeros(41, 2))
+    assert float(aco.run(3)) <= float(costs.max())
