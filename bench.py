@@ -110,6 +110,10 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
+    ap.add_argument("--shard", default="instances", choices=["instances", "ants"],
+                    help="instances: B colonies per GPU, no collective (weak scaling, default); "
+                         "ants: the same B colonies on every GPU, A/N ants each, one all-reduce of the "
+                         "pheromone deposits per iteration (strong scaling)")
     ap.add_argument("--force-device", type=int, default=None,
                     help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
     args = ap.parse_args()
@@ -136,11 +140,22 @@ def main():
 
     n, A, B = args.nodes, args.ants, args.batch
     k_sparse = args.k_sparse or max(5, n // 10)
-    dist_cpu = make_instances(B, n, 1234 + rank)
-    colony = engine.BatchedTSP(dist_cpu.to(dev), n_ants=A, sampler=args.sampler, seed=1234,
-                               ant_gid0=rank * B * A)
-    colony.sparsify(k_sparse)
-    colony.heuristic = colony.heuristic.contiguous()
+    ant_sharded = args.shard == "ants"
+    dist_cpu = make_instances(B, n, 1234 + (0 if ant_sharded else rank))
+    if ant_sharded:
+        d_dev = dist_cpu.to(dev)
+        _, idx = torch.topk(d_dev, k=k_sparse, dim=2, largest=False)
+        sparse = torch.full_like(d_dev, 1e10)
+        sparse.scatter_(2, idx, torch.gather(d_dev, 2, idx))
+        colony = engine.ant_sharded_tsp(d_dev, A, rank, world, heuristic=(1 / sparse).contiguous(),
+                                        sampler=args.sampler, seed=1234)
+        _step = colony.step
+        colony.step = lambda events=None: _step()
+    else:
+        colony = engine.BatchedTSP(dist_cpu.to(dev), n_ants=A, sampler=args.sampler, seed=1234,
+                                   ant_gid0=rank * B * A)
+        colony.sparsify(k_sparse)
+        colony.heuristic = colony.heuristic.contiguous()
 
     log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler}")
     for _ in range(args.warmup):
@@ -158,8 +173,8 @@ def main():
 
     elapsed = barrier_max_time(timed, dev, distributed)
     log(f"timed region: {elapsed*1e3:.1f} ms for {args.steps} steps")
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    tours = world * B * A * args.steps
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps if not ant_sharded else float("nan")
+    tours = (B * A if ant_sharded else world * B * A) * args.steps
     value = tours / elapsed
     bpt = bytes_per_tour(n, A)
     achieved = (B * A * bpt) / (kern_ms * 1e-3) / 1e9          # GB/s, dominant kernel, this rank
@@ -176,12 +191,12 @@ def main():
         line = {
             "metric": "ant-tours/sec, TSP-500 n_ants=512", "value": value, "unit": "ant-tours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if ant_sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TSP-{n} random-Euclidean, n_ants={A}, {B} instances per GPU, "
                                    f"AS update, heuristic 1/d sparsified k={k_sparse}, sampler={args.sampler}",
                        "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": args.sampler,
-                       "parallelism": f"instance-sharded x{world}"},
+                       "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
                          "kernel": "tsp_sample_kernel", "kernel_ms": kern_ms,

@@ -443,3 +443,30 @@ class BatchedCVRP:
         for _ in range(n_iterations):
             self.step()
         return self.lowest_cost
+
+
+def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1.0, heuristic=None, sampler="scan",
+                    seed=0):
+    """Ant-sharded TSP colony on this rank's GPU: A/world ants of every instance here, pheromone
+    replicated, ONE all-reduce (RCCL over xGMI when the process group is nccl) of the deposits per iteration.
+    Returns a parallel.AntShardedColony whose kernels are the HIP ones."""
+    from .parallel import AntShardedColony
+    _require_gpu(distances)
+    dist_ = _f32c(distances)
+    B, n, _ = dist_.shape
+    eta = (1 / dist_) if heuristic is None else heuristic
+    state = {}
+
+    def sample_fn(tau, lo, n_local, it):
+        paths, _, _, _, costs, nbr = tsp_sample(tau, eta, n_local, alpha, beta, mode=sampler, seed=seed, it=it,
+                                                ant_gid0=rank * B * n_local, batch=B, dist=dist_, want_nbr=True)
+        state["costs"], state["nbr"] = costs, nbr
+        return paths
+
+    def cost_fn(paths):
+        return state["costs"]                     # fused into the sampler
+
+    def deposit_fn(zero, paths, costs):
+        return pheromone_update_(zero, paths, costs, 1.0, nbr=state["nbr"])
+
+    return AntShardedColony(torch.ones_like(dist_), n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn)

@@ -272,3 +272,19 @@ def test_inference_schedule_matches_cpu_port_statistically():
                 gpu[i] += float(aco.run(td)) / inst
         assert np.all(np.diff(gpu) <= 1e-6)                      # best-so-far never gets worse
         np.testing.assert_allclose(gpu, cpu, rtol=0.05), (sampler, gpu, cpu)
+
+
+def test_ant_sharded_colony_world1_matches_batched():
+    """The ant-sharded colony (deposit on zeros + tau*decay + delta) with one rank draws the same tours as
+    BatchedTSP and keeps the same pheromone up to summation order."""
+    from deepaco_amd import engine
+    B, n, A, iters = 3, 40, 16, 4
+    dist, _, _ = make_instance(n, 9, B)
+    col = engine.ant_sharded_tsp(dist.to(dev()), A, 0, 1, seed=5)
+    ref = engine.BatchedTSP(dist.to(dev()), n_ants=A, seed=5)
+    for _ in range(iters):
+        p1, c1 = col.step()
+        p2, c2 = ref.step()
+        assert torch.equal(p1, p2) and torch.equal(c1, c2)
+    torch.testing.assert_close(col.tau, ref.pheromone, rtol=2e-6, atol=0)
+    torch.testing.assert_close(col.lowest_cost, ref.lowest_cost, rtol=0, atol=0)
