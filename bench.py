@@ -173,11 +173,12 @@ def main():
 
     elapsed = barrier_max_time(timed, dev, distributed)
     log(f"timed region: {elapsed*1e3:.1f} ms for {args.steps} steps")
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps if not ant_sharded else float("nan")
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps if not ant_sharded else None
     tours = (B * A if ant_sharded else world * B * A) * args.steps
     value = tours / elapsed
     bpt = bytes_per_tour(n, A)
-    achieved = (B * A * bpt) / (kern_ms * 1e-3) / 1e9          # GB/s, dominant kernel, this rank
+    per_launch = (B * (colony.hi - colony.lo) if ant_sharded else B * A) * bpt
+    achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms else None      # GB/s, dominant kernel, this rank
     gpu_best = colony.lowest_cost.detach().cpu()
 
     if rank == 0:
@@ -198,9 +199,11 @@ def main():
                        "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": args.sampler,
                        "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS, "traffic": traffic,
+                         "frac": achieved / PEAK_HBM_GBS if achieved else None, "traffic": traffic,
                          "kernel": "tsp_sample_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": B * A * bpt},
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "note": "rows are L2-resident and tau^a*eta^b is fused, so achieved algorithmic GB/s exceeds "
+                                 "the HBM peak; the kernel is instruction-issue bound (DESIGN.md 3.1, profiles/)"},
             "gpu_mean_best_cost": float(gpu_best.mean()),
         }
         if world == 1 and not args.no_cpu:
