@@ -105,8 +105,23 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
     float *row = rows + r * n;
     int alo = 0, ahi = A;
     if (best) { alo = best[b]; ahi = alo + 1; }
-#pragma unroll 4
-    for (int a = alo; a < ahi; ++a) {
+    // the neighbour-table loads are independent of the LDS chain: fetch 16 ants ahead, then apply in order
+    int a = alo;
+    for (; a + 16 <= ahi; a += 16) {
+      uint32_t v[16];
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        v[u] = nb[(size_t)(a + u) * n];
+        w[u] = weights ? weights[(size_t)b * A + a + u] : 1.0f / cs[a + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int col = role ? (int)(v[u] >> 16) : (int)(v[u] & 0xFFFFu);
+        row[col] = row[col] + w[u];
+      }
+    }
+    for (; a < ahi; ++a) {
       const uint32_t v = nb[(size_t)a * n];
       const int col = role ? (int)(v >> 16) : (int)(v & 0xFFFFu);
       const float w = weights ? weights[(size_t)b * A + a] : 1.0f / cs[a];
