@@ -156,21 +156,39 @@ class SMTWTP(_Base):
         late = (finish - self.due_time[jobs]).clamp(min=0)
         return (self.weights[jobs] * late).sum(dim=1)
 
-    def gen_path(self, require_prob=False, *, _noise=None):
-        self._begin()
-        A, dev = self.n_ants, self.device
-        rows = torch.arange(A, device=dev)
-        prev = torch.zeros(A, dtype=torch.long, device=dev)
-        mask = torch.ones(A, self.n + 1, device=dev)
-        mask[:, 0] = 0
-        seq, lps = [], []
-        for t in range(1, self.n + 1):
-            act, lp = self._pick(prev, mask, t, require_prob, _noise)
-            seq.append(act)
-            lps.append(lp)
-            mask[rows, act] = 0
-            prev = act
-        return (torch.stack(seq), torch.stack(lps)) if require_prob else torch.stack(seq)
+    def gen_path(self, require_prob=False, *, _noise=None, _stepwise=False):
+        """A permutation of the jobs drawn after the dummy start node: exactly the fused TSP kernel with
+        every ant starting at node 0 (one launch); `_stepwise=True` keeps the draw-by-draw service path
+        (same Philox counters, hence the same sequences) for cross-checking."""
+        if _stepwise:
+            self._begin()
+            A, dev = self.n_ants, self.device
+            rows = torch.arange(A, device=dev)
+            prev = torch.zeros(A, dtype=torch.long, device=dev)
+            mask = torch.ones(A, self.n + 1, device=dev)
+            mask[:, 0] = 0
+            seq, lps = [], []
+            for t in range(1, self.n + 1):
+                act, lp = self._pick(prev, mask, t, require_prob, _noise)
+                seq.append(act)
+                lps.append(lp)
+                mask[rows, act] = 0
+                prev = act
+            return (torch.stack(seq), torch.stack(lps)) if require_prob else torch.stack(seq)
+        it = self._calls
+        self._calls += 1
+        mode = "race_noise" if _noise is not None else self.sampler
+        noise = None if _noise is None else torch.stack(list(_noise)).unsqueeze(0)
+        tau = self.pheromone.detach().float()
+        if require_prob and torch.is_grad_enabled() and self.heuristic.requires_grad:
+            from .autograd import TspSampleFn
+            paths, logp, _ = TspSampleFn.apply(self.heuristic, tau, self.n_ants, self.alpha, self.beta, mode, 1, None, 0,
+                                               noise, self.seed, it)
+            return paths[1:], logp
+        paths, logp, _, _ = engine.tsp_sample(tau, self.heuristic.detach().float(), self.n_ants, self.alpha, self.beta,
+                                              mode=mode, norm_passes=1, fixed_start=0, noise=noise, seed=self.seed,
+                                              it=it, require_prob=require_prob, batch=1)
+        return (paths[0, 1:], logp[0]) if require_prob else paths[0, 1:]
 
 
 # =============================================================================== S3 SOP

@@ -45,6 +45,18 @@ def test_smtwtp():
     assert np.array_equal(el.pheromone.cpu().numpy().view(np.uint32), g["pheromone_elitist"].view(np.uint32))
     low = aco.run(3)
     assert float(low) <= float(g["costs"].max())
+    # fused (one launch) and draw-by-draw paths share the Philox counters: identical sequences
+    for sampler in ("scan", "race"):
+        a1 = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=32, device="cuda:0",
+                 sampler=sampler, seed=11)
+        a2 = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=32, device="cuda:0",
+                 sampler=sampler, seed=11)
+        p1, l1 = a1.gen_path(True)
+        p2, l2 = a2.gen_path(True, _stepwise=True)
+        assert torch.equal(p1, p2)
+        torch.testing.assert_close(l1, l2, rtol=1e-5, atol=2e-6)
+    pn, _ = aco.gen_path(True, _noise=noise_list(g), _stepwise=True)
+    assert np.array_equal(pn.cpu().numpy(), g["paths"])
 
 
 def test_sop():
