@@ -55,7 +55,9 @@ def test_smtwtp():
         p2, l2 = a2.gen_path(True, _stepwise=True)
         assert torch.equal(p1, p2)
         torch.testing.assert_close(l1, l2, rtol=1e-5, atol=2e-6)
-    pn, _ = aco.gen_path(True, _noise=noise_list(g), _stepwise=True)
+    fresh = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=A, pheromone=T(g["pheromone"]),
+                device="cuda:0")
+    pn, _ = fresh.gen_path(True, _noise=noise_list(g), _stepwise=True)
     assert np.array_equal(pn.cpu().numpy(), g["paths"])
 
 
