@@ -37,6 +37,9 @@ SIGNATURES = {
     "daco_gnn_param_floats": (_sz, [_i]),
     "daco_gnn_workspace_bytes": (_sz, [_i, _i]),
     "daco_gnn_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "daco_sibling_workspace_bytes": (_sz, [_i, _i, _i]),
+    "daco_sibling_sample": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _l, _f, _vp, _i, _i, _vp, _vp,
+                                 _i, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
 }
 

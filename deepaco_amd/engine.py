@@ -171,6 +171,69 @@ def sample_backward(tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, 
     return grad
 
 
+SIB_KINDS = {"sop": 3, "pctsp": 4, "op": 5, "mkp": 6}
+
+
+def sibling_sample(kind, tau, eta, n_ants, alpha=1.0, beta=1.0, aux_vec=None, aux_mat=None, scalar0=0.0,
+                   item_weights=None, mode="scan", start=None, noise=None, seed=0, it=0, ant_gid0=0,
+                   require_prob=False, Lmax=None):
+    """Fused solution construction for sop / pctsp / op / mkp, one instance batch B = leading dim of tau
+    (or 1).  See include/deepaco_hip.h daco_sibling_sample for the meaning of aux_vec / aux_mat / scalar0.
+    Returns (paths [B,rows,A], log_probs|None, rowsum|None, lens [B,A]|None, flags [B])."""
+    _require_gpu(tau, eta, aux_vec, aux_mat, item_weights, start, noise)
+    n = tau.shape[-1]
+    B = tau.shape[0] if tau.dim() == 3 else 1
+    dev = tau.device
+    tau, tbs = _bstride(tau, n)
+    eta, ebs = _bstride(eta, n)
+    k = SIB_KINDS[kind]
+    varlen = kind != "sop"
+    rows = (Lmax or 2 * n + 1) if varlen else n
+    m = MODES[mode] if isinstance(mode, str) else int(mode)
+    if aux_vec is not None:
+        aux_vec = _f32c(aux_vec).reshape(-1, n)
+        if aux_vec.shape[0] != B:
+            aux_vec = aux_vec.expand(B, n).contiguous()
+    abs_ = 0
+    if aux_mat is not None:
+        aux_mat, abs_ = _bstride(aux_mat, n)
+    mdim = 0
+    if item_weights is not None:
+        item_weights = _f32c(item_weights)
+        mdim = item_weights.shape[-1]
+        if item_weights.dim() == 2:
+            item_weights = item_weights.unsqueeze(0).expand(B, n, mdim).contiguous()
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        paths = torch.empty((B, rows, n_ants), dtype=torch.int64, device=dev)
+        logp = torch.empty((B, rows - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
+        rowsum = torch.ones((B, rows - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
+        lens = torch.empty((B, n_ants), dtype=torch.int32, device=dev) if varlen else None
+        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        steps = 0
+        if noise is not None:
+            noise = _f32c(noise)
+            steps = noise.shape[-3]
+            noise = noise.view(B, steps, n_ants, n)
+        if start is not None:
+            start = start.to(torch.int64).contiguous().view(B, n_ants)
+        nbytes = L.daco_sibling_workspace_bytes(B, n, m)
+        ws = _workspace(dev, nbytes, "sibling")
+        rc = L.daco_sibling_sample(_stream(dev), k, B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+                                   float(beta), aux_vec.data_ptr() if aux_vec is not None else None,
+                                   aux_mat.data_ptr() if aux_mat is not None else None, abs_, float(scalar0),
+                                   item_weights.data_ptr() if item_weights is not None else None, mdim, m,
+                                   start.data_ptr() if start is not None else None,
+                                   noise.data_ptr() if noise is not None else None, steps,
+                                   int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF, rows,
+                                   paths.data_ptr(), logp.data_ptr() if require_prob else None,
+                                   rowsum.data_ptr() if require_prob else None,
+                                   lens.data_ptr() if lens is not None else None, flags.data_ptr(), ws.data_ptr(),
+                                   ws.numel())
+    _lib.check(rc, "daco_sibling_sample")
+    return paths, logp, rowsum, lens, flags
+
+
 class PickService:
     """ACO.pick_move as a service for the sibling problems (op, pctsp, sop, smtwtp, bpp, mkp):
     build the fused transition matrix once per construction, then draw one action per ant per call

@@ -89,6 +89,29 @@ class _Base:
         act, logp, _ = self._svc.pick(prev, mask, step, require_prob=require_prob, noise=q)
         return act, logp
 
+    def _fused(self, kind, require_prob, noise, **kw):
+        """One-launch construction (daco_sibling_sample).  Gradients are not wired through the fused kernels
+        yet: callers fall back to the draw-by-draw path when the heuristic requires grad."""
+        it = self._calls
+        self._calls += 1
+        mode = "race_noise" if noise is not None else self.sampler
+        nz = None if noise is None else torch.stack(list(noise)).unsqueeze(0)
+        paths, logp, _, lens, flags = engine.sibling_sample(
+            kind, self.pheromone.detach().float(), self.heuristic.detach().float(), self.n_ants, self.alpha, self.beta,
+            mode=mode, noise=nz, seed=self.seed, it=it, require_prob=require_prob, **kw)
+        fl = int(flags[0])
+        if fl & 1:
+            raise ValueError("a transition row had no feasible candidate")
+        if fl & 2:
+            raise RuntimeError("solution buffer / noise tensor too short")
+        L = int(lens.max()) if lens is not None else paths.shape[1]
+        if require_prob:
+            return paths[0, :L], logp[0, :L - 1]
+        return paths[0, :L]
+
+    def _wants_grad(self, require_prob):
+        return require_prob and torch.is_grad_enabled() and self.heuristic.requires_grad
+
     def check_feasible(self):
         if bool(self._svc.flags.any()):
             raise ValueError("a transition row had no feasible candidate")
@@ -240,7 +263,10 @@ class SOP(_Base):
         assert paths.shape == (self.problem_size, self.n_ants)
         return engine.tour_costs(self.distances, paths.contiguous().unsqueeze(0), closed=False)[0]
 
-    def gen_path(self, require_prob=False, *, _noise=None):
+    def gen_path(self, require_prob=False, *, _noise=None, _stepwise=False):
+        if not _stepwise and not self._wants_grad(require_prob):
+            prec = self.prec_cons.float()
+            return self._fused("sop", require_prob, _noise, aux_vec=prec.sum(dim=1), aux_mat=prec.T.contiguous())
         self._begin()
         A, n, dev = self.n_ants, self.problem_size, self.device
         rows = torch.arange(A, device=dev)
@@ -319,7 +345,9 @@ class PCTSP(_Base):
         seen = torch.zeros(self.n_ants, self.n, device=self.device).scatter_(1, solutions.T, 1.0)
         return length + ((1 - seen) * self.penalties).sum(dim=1)
 
-    def gen_sol(self, require_prob=False, *, _noise=None):
+    def gen_sol(self, require_prob=False, *, _noise=None, _stepwise=False):
+        if not _stepwise and not self._wants_grad(require_prob):
+            return self._fused("pctsp", require_prob, _noise, aux_vec=self.prizes.float(), scalar0=self.min_prizes)
         self._begin()
         A, n, dev = self.n_ants, self.n, self.device
         rows = torch.arange(A, device=dev)
@@ -424,7 +452,11 @@ class OP(_Base):
         mask[(mask[:, :-1] == 0).all(dim=1), -1] = 1
         return mask
 
-    def gen_sol(self, require_prob=False, *, _noise=None):
+    def gen_sol(self, require_prob=False, *, _noise=None, _stepwise=False):
+        if not _stepwise and not self._wants_grad(require_prob):
+            d = self.distances.float().contiguous()
+            return self._fused("op", require_prob, _noise, aux_vec=d[:, 0].contiguous(), aux_mat=d,
+                               scalar0=float(self.max_len))
         self._begin()
         A, n, dev = self.n_ants, self.n, self.device
         cur = torch.zeros(A, dtype=torch.long, device=dev)
@@ -579,7 +611,10 @@ class MKP(_Base):
         mask[:, -1] = 1
         return mask, knapsack
 
-    def gen_sol(self, require_prob=False, *, _noise=None, _start=None):
+    def gen_sol(self, require_prob=False, *, _noise=None, _start=None, _stepwise=False):
+        if not _stepwise and not self._wants_grad(require_prob):
+            return self._fused("mkp", require_prob, _noise, item_weights=self.weight.float(), scalar0=float(self.n // 2),
+                               start=None if _start is None else _start.view(1, -1))
         self._begin()
         A, n, dev = self.n_ants, self.n, self.device
         if _start is not None:

@@ -147,6 +147,37 @@ int daco_pick_move(void *stream, int B, int n, int A, const void *prob_workspace
                    int64_t *actions, float *logp, float *rowsum, int32_t *flags);
 
 /* ---------------------------------------------------------------------------------------------
+ * daco_sibling_sample -- fused solution construction for sop / pctsp / op / mkp (one launch)
+ *   DACO_SIB_SOP   sop/aco.py:114-180    aux_vec[k] = number of predecessors of k (row sums of
+ *                  prec_cons), aux_mat[k][j] = prec_cons[j][k] ("who waits for k"); n-1 draws
+ *                  from node 0; paths [B][n][A]; Lmax/lens unused
+ *   DACO_SIB_PCTSP pctsp/aco.py:131-188  aux_vec = prizes, scalar0 = min prize; the depot opens
+ *                  when the collected prize exceeds scalar0 or nothing is left; ends at the depot
+ *   DACO_SIB_OP    op/aco.py:156-224     n counts the dummy end node n-1; aux_mat = distances
+ *                  (with the dummy row/column), aux_vec[k] = distances[k][0], scalar0 = max_len;
+ *                  a candidate closes for good once route + leg + way home exceeds scalar0
+ *   DACO_SIB_MKP   mkp/aco.py:113-183    n counts the dummy item n-1; item_weights [B][n][m],
+ *                  scalar0 = capacity (n_items // 2); start [B][A] or NULL (Philox)
+ * Variable-length kinds write paths [B][Lmax][A] padded with the resting node (depot 0 / dummy
+ * n-1) and lens [B][A]; logp/rowsum [B][rows-1][A] optional; flags as daco_cvrp_sample.  aux_mat
+ * is dense [B][n][n] (aux_mat_bstride between instances, 0 = shared).  Draws, modes, noise layout
+ * ([B][noise_steps][A][n]) and Philox counters are those of daco_tsp_sample / daco_pick_move.
+ */
+#define DACO_SIB_SOP 3
+#define DACO_SIB_PCTSP 4
+#define DACO_SIB_OP 5
+#define DACO_SIB_MKP 6
+size_t daco_sibling_workspace_bytes(int B, int n, int mode);
+int daco_sibling_sample(void *stream, int kind, int B, int n, int A,
+                        const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                        float alpha, float beta, const float *aux_vec, const float *aux_mat,
+                        long aux_mat_bstride, float scalar0, const float *item_weights, int m,
+                        int mode, const int64_t *start, const float *noise, int noise_steps,
+                        uint64_t seed, uint64_t iter, uint32_t ant_gid0, int Lmax,
+                        int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
+                        void *workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
  * daco_sample_backward -- replaces autograd through ACO.gen_path(require_prob=True)
  *   (tsp/aco.py:154-176, cvrp/aco.py:153-173; consumed by the REINFORCE losses in
  *    tsp/train.ipynb:45-49, tsp_nls/train.py:31-44, cvrp/train.ipynb:45-51)

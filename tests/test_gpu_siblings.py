@@ -188,3 +188,99 @@ def test_sibling_gradients_flow():
     loss = torch.sum((costs - costs.mean()) * logp.sum(dim=0)) / 8
     loss.backward()
     assert heu.grad is not None and bool(torch.isfinite(heu.grad).all()) and float(heu.grad.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------ fused one-launch constructions
+def _both_paths(make, gen_name, A, **kw):
+    """The fused kernel and the draw-by-draw service share Philox counters -> identical solutions."""
+    for sampler in ("scan", "race"):
+        a1, a2 = make(sampler), make(sampler)
+        s1, l1 = getattr(a1, gen_name)(True, **kw)
+        s2, l2 = getattr(a2, gen_name)(True, _stepwise=True, **kw)
+        assert s1.shape == s2.shape, (sampler, s1.shape, s2.shape)
+        assert torch.equal(s1, s2), sampler
+        torch.testing.assert_close(l1, l2, rtol=1e-5, atol=2e-6)
+
+
+def test_stepwise_service_still_matches_reference():
+    """The draw-by-draw path (daco_pick_move) against the fixtures, now that the default is fused."""
+    from deepaco_amd.sop.aco import ACO as SOP
+    from deepaco_amd.pctsp.aco import ACO as PCTSP
+    from deepaco_amd.op.aco import ACO as OP
+    from deepaco_amd.mkp.aco import ACO as MKP
+    g = load_golden("s3_sop_n20")
+    a = SOP(T(g["distances"]), T(g["prec_cons"]), n_ants=8, pheromone=T(g["pheromone"]), device="cuda:0")
+    assert np.array_equal(a.gen_path(True, _noise=noise_list(g), _stepwise=True)[0].cpu().numpy(), g["paths"])
+    g = load_golden("s2_pctsp_n20")
+    a = PCTSP(T(g["distances"]), T(g["prizes"]), T(g["penalties"]), n_ants=8, device="cuda:0")
+    a.heuristic, a.pheromone = T(g["heuristic"]), T(g["pheromone"])
+    assert np.array_equal(a.gen_sol(True, _noise=noise_list(g), _stepwise=True)[0].cpu().numpy(), g["sols"])
+    g = load_golden("s1_op_n30")
+    a = OP(T(g["distances_in"]), T(g["prizes_in"]), float(g["max_len"]), n_ants=8, k_sparse=int(g["k_sparse"]),
+           device="cuda:0")
+    a.heuristic = T(g["heuristic"])
+    assert np.array_equal(a.gen_sol(True, _noise=noise_list(g), _stepwise=True)[0].cpu().numpy(), g["sols"])
+    g = load_golden("s6_mkp_n20")
+    a = MKP(T(g["prize_in"]), T(g["weight_in"]), n_ants=8, pheromone=T(g["pheromone"]), device="cuda:0")
+    a.heuristic = T(g["heuristic"])
+    assert np.array_equal(a.gen_sol(True, _noise=noise_list(g), _start=T(g["start"]), _stepwise=True)[0].cpu().numpy(),
+                          g["sols"])
+
+
+@pytest.mark.parametrize("n", [20, 70, 150])
+def test_fused_sop_equals_stepwise(n):
+    from deepaco_amd.sop.aco import ACO
+    gen = torch.Generator().manual_seed(n)
+    dist = torch.rand(n, n, generator=gen) + 0.05
+    prec = torch.zeros(n, n)
+    order = torch.randperm(n - 1, generator=gen) + 1                 # a hidden feasible order
+    for _ in range(2 * n):
+        i, j = sorted(torch.randint(0, n - 1, (2,), generator=gen).tolist())
+        if i != j:
+            prec[order[j], order[i]] = 1                              # order[i] precedes order[j]
+    prec[1:, 0] = 1
+    _both_paths(lambda s: ACO(dist.to(dev()), prec.to(dev()), n_ants=48, device="cuda:0", sampler=s, seed=3),
+                "gen_path", 48)
+
+
+@pytest.mark.parametrize("n", [21, 101])
+def test_fused_pctsp_equals_stepwise(n):
+    from deepaco_amd.pctsp.aco import ACO
+    gen = torch.Generator().manual_seed(n)
+    coor = torch.rand(n, 2, generator=gen)
+    dist = torch.cdist(coor, coor)
+    prizes = torch.cat((torch.zeros(1), torch.rand(n - 1, generator=gen)))
+    pen = torch.cat((torch.zeros(1), torch.rand(n - 1, generator=gen) * 0.3))
+    _both_paths(lambda s: ACO(dist.to(dev()), prizes.to(dev()), pen.to(dev()), n_ants=40, device="cuda:0", sampler=s,
+                              seed=5), "gen_sol", 40)
+
+
+@pytest.mark.parametrize("n,max_len", [(30, 3.0), (100, 4.0)])
+def test_fused_op_equals_stepwise(n, max_len):
+    from deepaco_amd.op.aco import ACO
+    from deepaco_amd.tsp.utils import gen_distance_matrix
+    gen = torch.Generator().manual_seed(n)
+    coor = torch.rand(n, 2, generator=gen)
+    dist = gen_distance_matrix(coor)
+    dd = (coor - coor[0]).norm(dim=-1)
+    prizes = 1 + torch.floor(99 * dd / dd.max())
+    prizes = prizes / prizes.max()
+    _both_paths(lambda s: ACO(dist.to(dev()), prizes.to(dev()), max_len, n_ants=40, k_sparse=max(5, n // 5),
+                              device="cuda:0", sampler=s, seed=6), "gen_sol", 40)
+
+
+@pytest.mark.parametrize("n,m", [(20, 3), (50, 5)])
+def test_fused_mkp_equals_stepwise(n, m):
+    from deepaco_amd.mkp.aco import ACO
+    gen = torch.Generator().manual_seed(n)
+    prize = torch.rand(n, generator=gen)
+    w = torch.rand(n, m, generator=gen)
+    cons = w.max(0).values + torch.rand(m, generator=gen) * (w.sum(0) - w.max(0).values)
+    w = w * (n // 2) / cons.unsqueeze(0)
+    start = torch.randint(0, n, (40,), generator=gen).to(dev())
+    _both_paths(lambda s: ACO(prize.to(dev()), w.to(dev()), n_ants=40, device="cuda:0", sampler=s, seed=7), "gen_sol",
+                40, _start=start)
+    # Philox start nodes inside the kernel are valid items
+    a = ACO(prize.to(dev()), w.to(dev()), n_ants=256, device="cuda:0", seed=1)
+    s = a.gen_sol()
+    assert int(s[0].min()) >= 0 and int(s[0].max()) < n and len(set(s[0].tolist())) > 5
