@@ -221,9 +221,6 @@ tsp_sample_kernel(const SampleParams p) {
   for (; VARLEN ? (t < p.Lmax && !finished) : (STEP ? t == t0 : t < n); ++t) {
     // ---- candidates closed at this step: visited, plus the problem's own feasibility rules
     Visited blk = vis;
-    if constexpr (VARLEN && !CVRP) {
-      if (MODE == DACO_RACE_NOISE && t - 1 >= p.noise_steps) { overflow = true; break; }
-    }
     if constexpr (SOP) {                                 // a node opens when its last predecessor is visited
       static_for<NJ>([&](auto J) {
         constexpr int j = J;
@@ -262,6 +259,9 @@ tsp_sample_kernel(const SampleParams p) {
       blk.hi |= sticky.hi | ~regular.hi;
       // nothing left to add: the ant moves to the dummy node and stays (padding below)
       if (__ballot(((~blk.lo) | (~blk.hi)) != 0u) == 0) { finished = true; break; }
+    }
+    if constexpr (VARLEN && !CVRP) {
+      if (MODE == DACO_RACE_NOISE && t - 1 >= p.noise_steps) { overflow = true; break; }
     }
     if constexpr (STEP) {                                // closed = the caller's mask is 0
       const float *mrow = p.mask + ((size_t)b * A + a) * n;
