@@ -288,3 +288,38 @@ def test_ant_sharded_colony_world1_matches_batched():
         assert torch.equal(p1, p2) and torch.equal(c1, c2)
     torch.testing.assert_close(col.tau, ref.pheromone, rtol=2e-6, atol=0)
     torch.testing.assert_close(col.lowest_cost, ref.lowest_cost, rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------ 5. limits and odd shapes
+def test_maximum_size_and_limit():
+    from deepaco_amd import engine
+    n, A = 4096, 2
+    dist, tau, eta = make_instance(n, 4096)
+    paths, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", seed=3, it=0)
+    assert int(flags.sum()) == 0
+    rp, _, rc = oracle.tsp_sample_scan(oracle.prob_matrix(tau[0].numpy(), eta[0].numpy()), A, 3, 0, 0)
+    assert rc == 0 and np.array_equal(paths[0].cpu().numpy(), rp)
+    big = torch.ones(1, 4097, 4097, device=dev())
+    with pytest.raises(ValueError):
+        engine.tsp_sample(big, big, 2)
+
+
+@pytest.mark.parametrize("B,A", [(1, 1), (3, 5), (9, 3), (17, 6), (5, 130)])
+def test_odd_batch_and_ant_counts(B, A):
+    """Workgroup remap (XCD-aware, bijective for any grid) and partial last workgroups (A % 4 != 0)."""
+    from deepaco_amd import engine
+    n = 90
+    dist, tau, eta = make_instance(n, B * 100 + A, B)
+    paths, _, _, flags, costs, nbr = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", seed=8, it=1,
+                                                       dist=dist.to(dev()), want_nbr=True)
+    assert int(flags.sum()) == 0
+    for b in range(B):
+        rp, _, _ = oracle.tsp_sample_scan(oracle.prob_matrix(tau[b].numpy(), eta[b].numpy()), A, 8, 1, b * A)
+        assert np.array_equal(paths[b].cpu().numpy(), rp), (B, A, b)
+        assert np.array_equal(costs[b].cpu().numpy(), oracle.tour_costs(dist[b].numpy(), rp))
+    # the fused neighbour table equals the one rebuilt from the paths (same deposit either way)
+    t1 = tau.to(dev()).clone().contiguous()
+    t2 = t1.clone()
+    engine.pheromone_update_(t1, paths, costs, 0.9, nbr=nbr)
+    engine.pheromone_update_(t2, paths, costs, 0.9)
+    assert torch.equal(t1, t2)
