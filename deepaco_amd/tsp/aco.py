@@ -106,6 +106,46 @@ class ACO():
     # ------------------------------------------------------------------ tsp/aco.py:75-92
     @torch.no_grad()
     def run(self, n_iterations):
+        """The reference's loop (tsp/aco.py:75-92) without its per-iteration host sync: the
+        `if best_cost < self.lowest_cost` bookkeeping is done with device-side selects, and tour costs and
+        the neighbour table of the deposit come fused out of the construction kernel.  `lowest_cost` /
+        `shortest_path` are tensors from the first iteration on.  (If `gen_path` has been replaced on the
+        instance -- noise injection in the parity tests -- the plain call sequence is used instead.)"""
+        if "gen_path" in self.__dict__ or type(self).gen_path_costs is not ACO.gen_path_costs \
+                or getattr(self, "local_search_type", None) is not None:
+            return self._run_plain(n_iterations)
+        dev = self.distances.device
+        dist = self.distances.detach().float().contiguous()
+        lowest = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(())
+        shortest = self.shortest_path if self.shortest_path is not None else \
+            torch.zeros(self.problem_size, dtype=torch.int64, device=dev)
+        for _ in range(n_iterations):
+            paths, _, _, flags, costs, nbr = engine.tsp_sample(
+                self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha, self.beta, mode=self.sampler,
+                norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
+                dist=dist, want_nbr=True)
+            self._calls += 1
+            self._last_flags = flags
+            best_cost, best_idx = costs[0].min(dim=0)
+            improved = best_cost < lowest
+            shortest = torch.where(improved, paths[0].index_select(1, best_idx.view(1)).squeeze(1), shortest)
+            lowest = torch.where(improved, best_cost, lowest)
+            cmin = cmax = None
+            if self.min_max:
+                new_max = lowest.reciprocal() * self.problem_size          # n / lowest_cost (rtruediv)
+                if self.max is None:
+                    self.pheromone *= new_max / self.pheromone.max()
+                self.max = new_max
+                cmin = torch.full((1,), float(self.min), device=dev)
+                cmax = new_max.reshape(1).contiguous()
+            tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+            engine.pheromone_update_(tau, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
+            self.pheromone = tau[0]
+        self.lowest_cost, self.shortest_path = lowest, shortest
+        return self.lowest_cost
+
+    @torch.no_grad()
+    def _run_plain(self, n_iterations):
         for _ in range(n_iterations):
             paths = self.gen_path(require_prob=False)
             costs = self.gen_path_costs(paths)
