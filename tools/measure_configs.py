@@ -43,10 +43,10 @@ def run(cfg):
         dt = timeit(col.step, 10)
         return dict(config=cfg, desc=f"TSP-{n}, {A} ants, {B} instances, AS iteration", ms_per_iteration=dt * 1e3,
                     ant_tours_per_s=B * A / dt)
-    if cfg == "c3":
-        n, A, B = 500, 256, 64
+    if cfg.startswith("c3"):
+        n, A, B = (int(cfg.split(":")[1]) if ":" in cfg else 500), 256, 64
         col = engine.BatchedTSP(tsp_instances(B, n, 2), n_ants=A, seed=1, local_search="nls", fixed_start=0)
-        col.sparsify(50)
+        col.sparsify(max(5, n // 10))
         dt = timeit(col.step, 2, warm=1)
         return dict(config=cfg, desc=f"TSP-{n} + NLS (2-opt kernel, T_nls=10, T_p=20, maxt={n//4}), {A} ants, {B} instances",
                     ms_per_iteration=dt * 1e3, ant_tours_per_s=B * A / dt)
