@@ -118,3 +118,32 @@ def test_nls_class_surface_and_recorded_noise():
     assert isinstance(low, float) and low <= float(costs.mean())
     low_inf = aco.run(1, inference=True)
     assert low_inf <= low
+
+
+def test_incremental_equals_full_sweep_kernels():
+    """The default incremental kernel and the full-sweep kernels (staged / unstaged) choose the same moves:
+    identical tours and sweep counts on ACO-sampled tours, symmetric and perturbation (asymmetric) matrices."""
+    from deepaco_amd import engine
+    B, n, A = 2, 300, 48
+    d = tsp_instance(n, 99, B).to(dev())
+    eta = 1 / d
+    paths, _, _, _ = engine.tsp_sample(torch.ones_like(d), eta, A, mode="scan", seed=4, fixed_start=0)
+    tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+    hd = (1 / (eta / eta.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+    results = {}
+    try:
+        for variant in ("17", "18", "9", "8", "2"):
+            os.environ["DACO_TWO_OPT_VARIANT"] = variant
+            t1, s1 = engine.two_opt_(d, tours.clone(), n // 4, want_sweeps=True)
+            t2, s2 = engine.two_opt_(hd, t1.clone(), 20, want_sweeps=True)
+            t3, s3 = engine.two_opt_(d, t2.clone(), 10000, want_sweeps=True)
+            results[variant] = (t1, s1, t2, s2, t3, s3)
+    finally:
+        os.environ.pop("DACO_TWO_OPT_VARIANT", None)
+    ref = results["9"]
+    for variant, res in results.items():
+        for x, y in zip(res, ref):
+            assert torch.equal(x, y), variant
+    # and the oracle agrees on the first instance
+    o1, os1 = oracle.two_opt_batch(d[0].cpu().numpy(), tours[0].cpu().numpy().astype(np.uint16), n // 4)
+    assert np.array_equal(ref[0][0].cpu().numpy().astype(np.uint16), o1) and np.array_equal(ref[1][0].cpu().numpy(), os1)
