@@ -281,6 +281,34 @@ class PickService:
         return actions, logp, rowsum
 
 
+def tsp_knn_graph(coords, k_sparse, diag=1e9, want_dist=True):
+    """Batched gen_pyg_data (tsp/utils.py:16-36): coords [B,n,2] -> (dist [B,n,n] | None, edge_index [B,2,n*k],
+    edge_attr [B,n*k,1]) in one launch."""
+    _require_gpu(coords)
+    coords = _f32c(coords)
+    B, n, _ = coords.shape
+    dev = coords.device
+    with torch.cuda.device(dev):
+        dist = torch.empty((B, n, n), dtype=torch.float32, device=dev) if want_dist else None
+        ei = torch.empty((B, 2, n * k_sparse), dtype=torch.int64, device=dev)
+        ea = torch.empty((B, n * k_sparse, 1), dtype=torch.float32, device=dev)
+        # src / dst rows of one instance are the two halves of its [2, E] block
+        src = ei[:, 0]
+        dst = ei[:, 1]
+        if B > 1:                       # the kernel writes [B][E] arrays: use separate contiguous buffers
+            src_c = torch.empty((B, n * k_sparse), dtype=torch.int64, device=dev)
+            dst_c = torch.empty((B, n * k_sparse), dtype=torch.int64, device=dev)
+        else:
+            src_c, dst_c = src, dst
+        rc = _lib.lib().daco_tsp_knn_graph(_stream(dev), B, n, int(k_sparse), coords.data_ptr(), float(diag),
+                                           dist.data_ptr() if want_dist else None, src_c.data_ptr(), dst_c.data_ptr(),
+                                           ea.data_ptr())
+        if B > 1:
+            ei[:, 0], ei[:, 1] = src_c, dst_c
+    _lib.check(rc, "daco_tsp_knn_graph")
+    return dist, ei, ea
+
+
 def tour_costs(dist, paths, closed=True):
     """ACO.gen_path_costs for a batch (tsp/aco.py:121-132; closed=False: cvrp/aco.py:133-136)."""
     _require_gpu(dist, paths)

@@ -38,6 +38,22 @@ def gen_pyg_data(tsp_coordinates, k_sparse, start_node=None):
     return Data(x=x, edge_index=edge_index, edge_attr=edge_attr), distances
 
 
+def gen_pyg_data_batch(coords, k_sparse, start_node=None):
+    '''B instances at once on the device (one kernel launch): coords [B, n, 2] ->
+    list of (Data, distances) exactly as gen_pyg_data returns them per instance.'''
+    from deepaco_amd import engine
+    dist, ei, ea = engine.tsp_knn_graph(coords, k_sparse)
+    out = []
+    for b in range(coords.shape[0]):
+        if start_node is None:
+            x = coords[b]
+        else:
+            x = torch.zeros((coords.shape[1], 1), device=coords.device, dtype=coords.dtype)
+            x[start_node, 0] = 1.0
+        out.append((Data(x=x, edge_index=ei[b], edge_attr=ea[b]), dist[b]))
+    return out
+
+
 def _load(path, k_sparse, device, start_node=None):
     out = []
     for instance in torch.load(path):

@@ -270,6 +270,16 @@ int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, cons
                      const float *edge_attr, const float *params, float *heu, float *emb,
                      void *workspace, size_t workspace_bytes);
 
+/* ---------------------------------------------------------------------------------------------
+ * daco_tsp_knn_graph -- replaces gen_distance_matrix + gen_pyg_data for a batch of instances
+ *   tsp/utils.py:4-36, tsp_nls/utils.py:5-45
+ * coords [B][n][2] f32 -> dist [B][n][n] (diagonal = diag, 1e9 in the reference; may be NULL),
+ * edge_src / edge_dst [B][n*k] int64 (instance-local node ids; sources sorted, k per node,
+ * neighbours by ascending distance, ties -> smaller index) and edge_attr [B][n*k] f32.
+ */
+int daco_tsp_knn_graph(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
+                       int64_t *edge_src, int64_t *edge_dst, float *edge_attr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,26 @@ def test_training_step_end_to_end():
     changed = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, net.parameters()))
     assert changed > 100
     assert bool((costs_2opt <= costs + 1e-4).all())
+
+
+@pytest.mark.parametrize("name", ["g5_net_tsp_tsp100", "g5_net_tsp_tsp20", "g5_net_tsp_nls_tsp100"])
+def test_batched_graph_construction_matches_reference(name):
+    """daco_tsp_knn_graph (one launch for a batch) == the reference's gen_pyg_data on captured instances."""
+    from deepaco_amd.tsp.utils import gen_pyg_data_batch
+    g = load_golden(name)
+    k = int(g["k_sparse"])
+    coords = torch.from_numpy(g["coords"]).to(dev())
+    extra = torch.rand(3, coords.shape[0], 2, generator=torch.Generator().manual_seed(1)).to(dev())
+    batch = torch.cat((coords[None], extra), 0)
+    out = gen_pyg_data_batch(batch, k, start_node=0 if "nls" in name else None)
+    pyg, dist = out[0]
+    assert np.array_equal(pyg.edge_index.cpu().numpy(), g["edge_index"])
+    np.testing.assert_allclose(pyg.edge_attr.cpu().numpy(), g["edge_attr"], rtol=1e-6)
+    np.testing.assert_allclose(dist.cpu().numpy(), g["distances"], rtol=1e-6)
+    assert np.array_equal(pyg.x.cpu().numpy(), g["x"])
+    # the other instances agree with the per-instance torch construction
+    from deepaco_amd.tsp.utils import gen_pyg_data
+    for b in range(1, 4):
+        ref, rd = gen_pyg_data(batch[b], k)
+        assert torch.equal(out[b][0].edge_index, ref.edge_index)
+        torch.testing.assert_close(out[b][0].edge_attr, ref.edge_attr, rtol=1e-6, atol=0)
