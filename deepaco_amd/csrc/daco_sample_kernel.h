@@ -52,11 +52,6 @@ __device__ inline void static_for_impl(F &&f, std::integer_sequence<int, I...>) 
 template <int N, class F>
 __device__ inline void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int VEC> struct Vec;
-template <> struct Vec<1> { float v[1]; };
-template <> struct Vec<2> { float v[2]; };
-template <> struct Vec<4> { float v[4]; };
-
 template <int VEC>
 __device__ inline void load_vec(const float *p, float (&out)[VEC]) {
   if constexpr (VEC == 4) {
@@ -84,10 +79,6 @@ struct Visited {
   }
   __device__ inline void set(int bit) {       // bit is wave-uniform
     if (bit < 32) lo |= 1u << bit; else hi |= 1u << (bit - 32);
-  }
-  // 0xFFFFFFFF if the candidate is closed, else 0 (v_bfe_i32); `x & ~mask` zeroes closed ones
-  template <int BIT> __device__ inline uint32_t closed_mask() const {
-    return (uint32_t)__builtin_amdgcn_sbfe((int)(BIT < 32 ? lo : hi), BIT & 31, 1);
   }
   // x if candidate BIT is open, +0.0f if closed -- two VALU ops (v_bfe_i32 + v_bfi_b32); written as
   // asm because the optimiser otherwise rewrites it into and + cmp + cndmask
