@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- must be loaded first: libdeepaco_hip.so then bind
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdeepaco_hip.so")
 
-RACE_NOISE, RACE_PHILOX, SCAN = 0, 1, 2
+RACE_NOISE, RACE_PHILOX, SCAN, SCAN_WAVE = 0, 1, 2, 3
 MAX_NODES = 4096
 
 _lib = None

@@ -51,6 +51,7 @@ extern "C" int daco_sibling_sample(void *stream, int kind, int B, int n, int A, 
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_sibling_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
+  if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_sibling_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_sibling_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   const bool varlen = kind != DACO_SIB_SOP;

@@ -62,7 +62,9 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_tsp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
-  if (mode < 0 || mode > 2 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
+  if (mode < 0 || mode > 3 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
+  const bool two_per_wave = mode == DACO_SCAN && n > 128 && n <= 1024;
+  if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
   if (costs && !dist) { set_error("daco_tsp_sample: fused costs need the distance matrix"); return DACO_E_BADARG; }
@@ -93,7 +95,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   const bool lp = logp != nullptr;
   hipError_t e;
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
-  e = dispatch_sample<PROB_TSP>(sp, vec, CH, mode, lp, s);
+  e = two_per_wave ? launch_tsp_scan32(sp, lp, s) : dispatch_sample<PROB_TSP>(sp, vec, CH, mode, lp, s);
   if (e != hipSuccess) { set_error("tsp_sample_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
   return DACO_OK;
@@ -110,6 +112,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
+  if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
@@ -169,6 +172,7 @@ extern "C" int daco_pick_move(void *stream, int B, int n, int A, const void *pro
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_pick_move: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
+  if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_pick_move: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_pick_move: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);

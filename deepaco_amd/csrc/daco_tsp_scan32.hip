@@ -1,0 +1,233 @@
+// daco_tsp_scan32.hip -- TSP tour construction, prefix-scan draw, TWO ants per wavefront.
+//
+// Same reference behaviour as daco_tsp_sample.hip in DACO_SCAN mode (tsp/aco.py:134-177 with the
+// roulette draw of tsp_nls/aco.py:260-275), for 128 < n <= 1024.  The one-ant-per-wave kernel is
+// instruction-issue bound and two thirds of its instructions are per-STEP overhead (DPP scan,
+// ballot, lane picks, stores, loop) rather than per-candidate work.  Here each 32-lane half of a
+// wave builds one tour, so that overhead is paid once for two ants:
+//   * candidate k of an ant sits in lane s = (k/4) % 32 of its half, chunk c = k/128
+//     (16-byte loads, 512 contiguous bytes per half-wave load);
+//   * the inclusive scan needs only the in-row DPP steps plus row_bcast:15 (halves never mix);
+//   * per-ant values travel over the LDS crossbar (ds_swizzle / ds_bpermute, no VALU slot) or as
+//     two 16-bit fields of one scalar register picked per half with a single v_bfe;
+//   * picking the candidate inside the chosen lane reuses the scan: that lane deals its masked
+//     values to the 32 lanes of its half through LDS and the same scan + first-lane pick runs
+//     across candidates (instead of a compare-and-count chain every lane would have to execute).
+// Draw semantics are the 32-lane variant of the scan specification; the GPU
+// tests hold it bit-exact against the CPU restatement of that specification.
+#include "daco_sample_kernel.h"
+#include <cstdlib>
+
+namespace daco {
+
+// LLVM floating-point compare predicates for __builtin_amdgcn_fcmpf (wave-wide result mask)
+constexpr int FCMP_OGT = 2, FCMP_OGE = 3;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// inclusive add-scan inside each 32-lane half: Kogge-Stone in rows of 16, then (ROWS2) the second
+// row of each half adds the first row's total (lanes 16..31 += lane 15, lanes 48..63 += lane 47)
+template <bool ROWS2>
+__device__ inline float half_scan_add(float x) {
+  x = x + dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x);
+  x = x + dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x);
+  x = x + dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x);
+  x = x + dpp_f<DPP_ROW_SHR(8), 0xF, true>(0.0f, x);
+  // rows 1 and 3 only (row_mask 0xa): x += lane 15 of the row before; one instruction, rows 0 / 2 keep x.
+  // s_nop 1: two wait states between the VALU write of x and its DPP read.
+  if constexpr (ROWS2) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x));
+  return x;
+}
+// lane 31 of each half to all of its lanes (LDS crossbar, no memory, no VALU slot)
+__device__ inline float half_bcast_last(float x) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x3E0));   // BROADCAST,32,31
+}
+__device__ inline uint32_t lowest_bit(uint32_t x) { return x & (0u - x); }
+
+// FUSED: tour lengths and the neighbour table are both produced (the colony iteration's call)
+template <int CH2, bool LOGP, bool FUSED>
+__global__ void __launch_bounds__(256)
+tsp_scan32_kernel(const SampleParams p) {
+  constexpr int NJ = CH2 * 4;                           // candidates per lane (<= 32)
+  constexpr int ROWF = CH2 * 128;                       // padded row length of this layout
+  // open[h][k] = 1.0f while node k is unvisited by ant h of the workgroup, else 0.0f
+  __shared__ __attribute__((aligned(16))) float open_flags[8][ROWF];
+  // per ant: [0..31] candidate slots of the chosen lane, [32] threshold, [33] chosen lane, [34] choice
+  __shared__ __attribute__((aligned(16))) float pick[8][40];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int up = lane >> 5, s = lane & 31;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bpi = (p.A + 7) >> 3;                       // workgroups per instance (8 ants each)
+  const int b = w / bpi;
+  const int a0 = ((w - b * bpi) * 4 + wave) * 2;        // ants a0 (lower half), a0+1 (upper half)
+  if (a0 >= p.A) return;
+  const int n = p.n, A = p.A, ld = p.ld;
+  // odd A: the last upper half builds ant A-1 a second time (same counters, same tour, same stores)
+  const int a = a0 + up < A ? a0 + up : A - 1;
+  const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);   // lane 0 of each half
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
+  const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
+  char *path_t = (char *)(p.paths + (size_t)b * n * A);                // row t of this instance's [n][A] block
+  const uint32_t a8 = (uint32_t)a * 8u, a4 = (uint32_t)a * 4u;
+  char *logp_t = LOGP ? (char *)(p.logp + (size_t)b * (n - 1) * A) : nullptr;
+  char *rs_t = (LOGP && p.rowsum) ? (char *)(p.rowsum + (size_t)b * (n - 1) * A) : nullptr;
+  const bool want_cost = FUSED || p.costs != nullptr, want_nbr = FUSED || p.nbr != nullptr;
+  const char *dist_b = want_cost ? (const char *)(p.dist + (size_t)b * p.dist_bs) : nullptr;
+  char *nbr_b = want_nbr ? (char *)(p.nbr + (size_t)b * A * n) : nullptr;
+  const uint32_t an4 = (uint32_t)a * (uint32_t)n * 4u;
+  float *fl = open_flags[wave * 2 + up], *pk = pick[wave * 2 + up];
+#pragma unroll
+  for (int c = 0; c < CH2; ++c) *(float4 *)(fl + (c * 32 + s) * 4) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+  pk[s] = 0.0f;                                         // slots >= NJ stay zero for the whole kernel
+  if (s < 8) pk[32 + s] = 0.0f;
+  const int ubase = (lane & 32) << 2;                   // ds_bpermute byte address of this half's lane 0
+  // slot j = s of the chosen lane L is candidate (j/4)*128 + L*4 + j%4; lanes beyond NJ hold no slot
+  const int cbase = s < NJ ? ((s >> 2) << 7) | (s & 3) : 0;
+
+  int prev;
+  if (p.start) prev = (int)p.start[(size_t)b * A + a];
+  else if (p.fixed_start >= 0) prev = p.fixed_start;
+  else {
+    const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0);
+    prev = (int)__umulhi(r.x, (uint32_t)n);
+  }
+  const int first = prev;
+  __builtin_amdgcn_wave_barrier();
+  if (lead) {
+    fl[prev] = 0.0f;
+    *(int64_t *)(path_t + a8) = prev;
+  }
+  __builtin_amdgcn_wave_barrier();
+  int pprev = 0;
+  float cost = 0.0f, dpend = 0.0f;
+  u32x4 ublk = {0, 0, 0, 0};                            // 128 cached uniforms per ant (lane s: block base+s)
+  uint64_t feasible = ~0ull;
+
+  for (int tb = 0; tb < n; tb += 32) {
+    // uniform of step t: lane (t&31), component (t>>5)&3 of Philox block ((t>>7)<<5) + lane
+    if ((tb & 127) == 0) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((tb >> 7) << 5) + s));
+    const float ucur = u01(comp(ublk, (tb >> 5) & 3));
+    const int i1 = n - tb < 32 ? n - tb : 32;
+    for (int i = tb == 0 ? 1 : 0; i < i1; ++i) {
+      path_t += (size_t)A * 8;
+      const uint32_t voff = __umul24((uint32_t)prev, ldb) + lane_off;
+      float4 row[CH2], fo[CH2];
+#pragma unroll
+      for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
+      const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | (i << 2), __float_as_int(ucur)));
+#pragma unroll
+      for (int c = 0; c < CH2; ++c) fo[c] = *(const float4 *)(fl + (c * 32 + s) * 4);
+
+      // ---- level 1: which lane.  Closed candidates contribute p*0 = +0.0f; even and odd slots
+      // accumulate separately (packed fma: the products are exact, so each fma is one rounding)
+      f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+      for (int c = 0; c < CH2; ++c) {
+        acc = __builtin_elementwise_fma((f32x2){row[c].x, row[c].y}, (f32x2){fo[c].x, fo[c].y}, acc);
+        acc = __builtin_elementwise_fma((f32x2){row[c].z, row[c].w}, (f32x2){fo[c].z, fo[c].w}, acc);
+      }
+      const float part = acc.x + acc.y;
+      const float incl = half_scan_add<true>(part);
+      const float S = half_bcast_last(incl);
+      const float r = fmaxf(u * S, 1.401298464e-45f);   // keep r > 0 if u*S underflows
+      const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT);
+      feasible &= __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT);          // S > 0 <=> some open candidate has p > 0
+      // what is left to cover inside the chosen lane: r - incl[L-1]; lane L forms its own
+      float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
+      excl = s == 0 ? 0.0f : excl;
+      const float thr = r - excl;
+      // ---- level 2: which candidate of lane L.  Lane L deals its NJ values to the lanes of its
+      // half through LDS; the same scan + first-lane pick then runs across candidates.
+      const bool mine = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit((uint32_t)m) |
+                                                            ((uint64_t)lowest_bit((uint32_t)(m >> 32)) << 32));
+      if (mine) {
+#pragma unroll
+        for (int c = 0; c < CH2; ++c) *(float4 *)(pk + 4 * c) = row[c];
+        *(float2 *)(pk + 32) = make_float2(thr, __int_as_float(s));
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float cvraw = pk[s];
+      const float2 tl = *(const float2 *)(pk + 32);
+      const int mychoice = cbase + (__float_as_int(tl.y) << 2);
+      const float cv = cvraw * fl[mychoice];
+      const float sc = half_scan_add<(NJ > 16)>(cv);
+      const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP_OGT);
+      const uint64_t k = __builtin_amdgcn_fcmpf(sc, tl.x, FCMP_OGE) & pos;
+      uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
+      if (__builtin_expect(k0 == 0 || k1 == 0, 0)) {
+        // rounding: no candidate reached thr -> the lane's last open candidate with p > 0
+        const uint32_t q0 = (uint32_t)pos, q1 = (uint32_t)(pos >> 32);
+        if (k0 == 0 && q0) k0 = 0x80000000u >> __builtin_clz(q0);
+        if (k1 == 0 && q1) k1 = 0x80000000u >> __builtin_clz(q1);
+      }
+      const bool win = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit(k0) | ((uint64_t)lowest_bit(k1) << 32));
+      if (win) {
+        pk[34] = __int_as_float(mychoice);
+        fl[mychoice] = 0.0f;                            // visited
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int choice = __float_as_int(pk[34]);
+      __builtin_amdgcn_wave_barrier();
+
+      if (lead) {
+        *(int64_t *)(path_t + a8) = choice;
+        if constexpr (LOGP) {
+          const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);
+          *(float *)(logp_t + a4) = clamp_log(pc / S);
+          logp_t += (size_t)A * 4;
+          if (rs_t) { *(float *)(rs_t + a4) = S; rs_t += (size_t)A * 4; }
+        }
+        if (want_cost) {                                 // fused tour length, edge added one step late
+          cost = cost + dpend;
+          dpend = *(const float *)(dist_b + ((__umul24((uint32_t)choice, (uint32_t)n) + (uint32_t)prev) << 2));
+        }
+        if (want_nbr) *(uint32_t *)(nbr_b + an4 + ((uint32_t)prev << 2)) = (uint32_t)pprev | ((uint32_t)choice << 16);
+      }
+      pprev = prev;
+      prev = choice;
+    }
+  }
+  if (lead) {
+    if (want_cost) {
+      cost = cost + dpend;
+      cost = cost + *(const float *)(dist_b + ((__umul24((uint32_t)first, (uint32_t)n) + (uint32_t)prev) << 2));
+      p.costs[(size_t)b * A + a] = cost;
+    }
+    if (want_nbr) {                                     // close the cycle: last -> first -> second
+      uint32_t *nbr_a = (uint32_t *)(nbr_b + an4);
+      const int second = (int)p.paths[((size_t)b * n + 1) * A + a];
+      if (n == 2) { nbr_a[first] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[prev] = (uint32_t)first | ((uint32_t)first << 16); }
+      else { nbr_a[prev] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[first] = (uint32_t)prev | ((uint32_t)second << 16); }
+    }
+  }
+  if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+}
+
+template <int CH2>
+static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
+  const int bpi = (sp.A + 7) / 8;
+  dim3 grid((unsigned)(sp.B * bpi)), block(256);
+  const bool fused = sp.costs && sp.nbr;
+  static const int pad = getenv("DACO_SCAN32_LDS_PAD") ? atoi(getenv("DACO_SCAN32_LDS_PAD")) : 0;
+#define DACO_L32(L, F) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, L, F>), grid, block, pad, s, sp)
+  if (logp) { if (fused) DACO_L32(true, true); else DACO_L32(true, false); }
+  else { if (fused) DACO_L32(false, true); else DACO_L32(false, false); }
+#undef DACO_L32
+  return hipGetLastError();
+}
+
+// entry used by daco_tsp_sample (daco_tsp_sample.hip) when the two-ants-per-wave layout applies
+hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
+  switch ((sp.n + 127) / 128) {
+    case 2: return launch32<2>(sp, logp, s);
+    case 3: return launch32<3>(sp, logp, s);
+    case 4: return launch32<4>(sp, logp, s);
+    case 5: return launch32<5>(sp, logp, s);
+    case 6: return launch32<6>(sp, logp, s);
+    case 7: return launch32<7>(sp, logp, s);
+    default: return launch32<8>(sp, logp, s);
+  }
+}
+
+}  // namespace daco

@@ -8,9 +8,11 @@ paths [B, n, A] int64, log_probs [B, n-1, A] f32, costs [B, A] f32.
 import torch
 
 from . import _lib
-from ._lib import RACE_NOISE, RACE_PHILOX, SCAN  # noqa: F401
+from ._lib import RACE_NOISE, RACE_PHILOX, SCAN, SCAN_WAVE  # noqa: F401
 
-MODES = {"race_noise": RACE_NOISE, "race": RACE_PHILOX, "scan": SCAN}
+# "scan": daco_tsp_sample packs two ants per wavefront for 128 < n <= 1024; "scan_wave" keeps the
+# one-ant-per-wavefront draw for every n (what the step-wise service, CVRP and the siblings use)
+MODES = {"race_noise": RACE_NOISE, "race": RACE_PHILOX, "scan": SCAN, "scan_wave": SCAN_WAVE}
 
 _workspaces = {}
 

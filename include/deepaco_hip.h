@@ -40,7 +40,13 @@ extern "C" {
 /* sampler modes */
 #define DACO_RACE_NOISE 0  /* exponential race, noise read from memory (bit-exact parity mode) */
 #define DACO_RACE_PHILOX 1 /* exponential race, Philox4x32-10 noise generated in-kernel */
-#define DACO_SCAN 2        /* roulette / inverse-CDF by wavefront prefix scan, one uniform per step */
+#define DACO_SCAN 2        /* roulette / inverse-CDF by wavefront prefix scan, one uniform per step.
+                            * daco_tsp_sample packs two ants per wavefront for 128 < n <= 1024 (the
+                            * 32-lane variant of the scan); everything else uses
+                            * one ant per wavefront. */
+#define DACO_SCAN_WAVE 3   /* DACO_SCAN with the one-ant-per-wavefront layout for every n: the draw
+                            * daco_pick_move / daco_cvrp_sample / daco_sibling_sample make (there it
+                            * is a synonym of DACO_SCAN) */
 
 /* limits */
 #define DACO_MAX_NODES 4096

@@ -106,8 +106,10 @@ def tsp_sample_race(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=F
     return _sample_rng(lib().orc_tsp_sample_race, P, A, seed, it, ant_gid0, fixed_start, require_prob)
 
 
-def tsp_sample_scan(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=False):
-    return _sample_rng(lib().orc_tsp_sample_scan, P, A, seed, it, ant_gid0, fixed_start, require_prob)
+def tsp_sample_scan(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=False, wave=False):
+    """DACO_SCAN (two ants per wavefront for 128 < n <= 1024) or, with wave=True, DACO_SCAN_WAVE."""
+    fn = lib().orc_tsp_sample_scan_wave if wave else lib().orc_tsp_sample_scan
+    return _sample_rng(fn, P, A, seed, it, ant_gid0, fixed_start, require_prob)
 
 
 def tour_costs(dist, paths, closed=True):

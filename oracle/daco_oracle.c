@@ -189,42 +189,89 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
   return best;
 }
 
-/* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274:
- *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane_scan(part)
- *   S = incl[63];  r = max(u * S, denorm_min),  u = component ((t>>6)&3) of
- *       Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))   [256 uniforms per refill]
+/* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274.
+ * `lanes` = 64 (one ant per wavefront) or 32 (two ants per wavefront, TSP with 128 < n <= 1024):
+ *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
+ *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
+ *              (lanes = 32: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
+ *               end; the scan is Kogge-Stone in rows of 16, then lanes 16..31 add lane 15)
+ *   S = incl[lanes-1];  r = max(u * S, denorm_min)
+ *     lanes = 64: u = component ((t>>6)&3) of Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))
+ *     lanes = 32: u = component ((t>>5)&3) of Philox(ctr=(((t>>7)<<5) + (t&31), gid, iter, STREAM_SCAN))
  *   L = first lane with incl[L] >= r and part[L] > 0
- *   inside lane L: thr = r - incl[L-1] (incl[-1] = 0); walk its candidates in (c,v) order with
- *   the lane's own running sum (from +0.0f, closed candidates add +0.0f); pick the first whose
- *   running sum >= thr, else the last open candidate with p > 0 of the lane. */
+ *   inside lane L: thr = r - incl[L-1] (incl[-1] = 0);
+ *     lanes = 64: walk its candidates in (c,v) order with the lane's own running sum (from +0.0f,
+ *       closed candidates add +0.0f); pick the first whose running sum >= thr, else the last open
+ *       candidate with p > 0 of the lane;
+ *     lanes = 32: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
+ *       first j with scan[j] >= thr and p_j > 0, else the last j with p_j > 0. */
+int orc_scan_lanes(int n, int mode) { return (mode == 2 && n > 128 && n <= 1024) ? 32 : 64; }
+
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
-                     uint64_t iter, uint32_t gid, int t, float *pr) {
-  int vec = orc_vec_for_n(n), ld = orc_ld_for_n(n), ch = ld / (64 * vec);
+                     uint64_t iter, uint32_t gid, int t, float *pr, int lanes) {
+  int vec = orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
   float part[64], incl[64];
   uint32_t r4[4];
-  for (int l = 0; l < 64; ++l) {
+  for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
+  for (int l = 0; l < lanes; ++l) {
     float s = 0.0f;
-    for (int c = 0; c < ch; ++c)
-      for (int v = 0; v < vec; ++v) {
-        int k = (c * 64 + l) * vec + v;
-        s = s + ((k < n && !blocked[k]) ? row[k] : 0.0f);
-      }
+    if (lanes == 32) {
+      /* packed accumulation: slots v = 0,2 and v = 1,3 are summed separately (c ascending), then added */
+      float ev = 0.0f, od = 0.0f;
+      for (int c = 0; c < ch; ++c)
+        for (int v = 0; v < vec; ++v) {
+          int k = (c * lanes + l) * vec + v;
+          float x = (k < n && !blocked[k]) ? row[k] : 0.0f;
+          if (v & 1) od = od + x; else ev = ev + x;
+        }
+      s = ev + od;
+    } else {
+      for (int c = 0; c < ch; ++c)
+        for (int v = 0; v < vec; ++v) {
+          int k = (c * lanes + l) * vec + v;
+          s = s + ((k < n && !blocked[k]) ? row[k] : 0.0f);
+        }
+    }
     part[l] = s; incl[l] = s;
   }
-  lane_scan(incl);
-  float S = incl[63];
-  rng_block(seed, iter, STREAM_SCAN, gid, (((uint32_t)t >> 8) << 6) + ((uint32_t)t & 63u), r4);
-  float r = u01(r4[(t >> 6) & 3]) * S;
+  lane_scan(incl);                /* lanes = 32: lanes 0..31 of the 64-lane scan are exactly the half-wave scan */
+  float S = incl[lanes - 1];
+  uint32_t ut = (uint32_t)t;
+  if (lanes == 64) rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> 8) << 6) + (ut & 63u), r4);
+  else rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> 7) << 5) + (ut & 31u), r4);
+  float r = u01(r4[lanes == 64 ? (t >> 6) & 3 : (t >> 5) & 3]) * S;
   if (!(r > 0.0f)) r = 1.401298464e-45f;               /* keep r > 0 if u*S underflows */
   int L = -1;
-  for (int l = 0; l < 64; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
+  for (int l = 0; l < lanes; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
   if (L < 0) return -1;
   float thr = r - (L ? incl[L - 1] : 0.0f);
+  if (lanes == 32) {
+    /* level 2 of the two-ants-per-wave kernel: lane L's ch*vec candidate slots (closed ones
+     * +0.0f) are dealt to the 32 lanes and the same scan + first-lane pick runs across them */
+    float cv[64], sc[64];
+    int key[64], nj = ch * vec;
+    for (int j = 0; j < 64; ++j) { cv[j] = sc[j] = 0.0f; key[j] = -1; }
+    for (int j = 0; j < nj; ++j) {
+      int k = ((j / vec) * lanes + L) * vec + (j % vec);
+      key[j] = k;
+      cv[j] = sc[j] = (k < n && !blocked[k]) ? row[k] : 0.0f;
+    }
+    lane_scan(sc);
+    int best = -1, last = -1;
+    for (int j = 0; j < 32; ++j) {
+      if (!(cv[j] > 0.0f)) continue;
+      last = key[j];
+      if (sc[j] >= thr) { best = key[j]; break; }
+    }
+    if (best < 0) best = last;
+    if (best >= 0 && pr) *pr = row[best] / S;
+    return best;
+  }
   float run = 0.0f;
   int best = -1, last = -1;
   for (int c = 0; c < ch && best < 0; ++c)
     for (int v = 0; v < vec; ++v) {
-      int k = (c * 64 + L) * vec + v;
+      int k = (c * lanes + L) * vec + v;
       if (k >= n || blocked[k] || !(row[k] > 0.0f)) continue;
       run = run + row[k];
       last = k;
@@ -235,7 +282,7 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   return best;
 }
 
-enum { MODE_NOISE = 0, MODE_RACE = 1, MODE_SCAN = 2 };
+enum { MODE_NOISE = 0, MODE_RACE = 1, MODE_SCAN = 2, MODE_SCAN_WAVE = 3 };
 
 /* ------------------------------------------------------------------ T1/T2/T3: TSP tour construction
  * tsp/aco.py:134-177 and tsp_nls/aco.py:184-220.  start: given array (noise mode), else
@@ -265,7 +312,7 @@ static int tsp_sample(int mode, int n, int A, const float *P, const int64_t *sta
       int best;
       if (mode == MODE_NOISE) best = draw_noise(n, row, vis, noise + ((long)(t - 1) * A + a) * n, norm_passes, p, &pr);
       else if (mode == MODE_RACE) best = draw_race(n, row, vis, seed, iter, gid, t, p, logp ? &pr : NULL);
-      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr);
+      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr, orc_scan_lanes(n, mode));
       if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
       if (logp) logp[(long)(t - 1) * A + a] = clamp_log(pr);
       vis[best] = 1;
@@ -287,6 +334,11 @@ int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t it
 int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t iter,
                         uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
   return tsp_sample(MODE_SCAN, n, A, P, NULL, NULL, 0, seed, iter, ant_gid0, fixed_start, paths, logp);
+}
+/* DACO_SCAN_WAVE: the one-ant-per-wavefront layout for every n */
+int orc_tsp_sample_scan_wave(int n, int A, const float *P, uint64_t seed, uint64_t iter,
+                             uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
+  return tsp_sample(MODE_SCAN_WAVE, n, A, P, NULL, NULL, 0, seed, iter, ant_gid0, fixed_start, paths, logp);
 }
 
 /* ------------------------------------------------------------------ T4 / C5: tour costs
@@ -412,7 +464,7 @@ int orc_pick_move(int mode, int n, int A, const float *P, const int64_t *prev, c
     int best;
     if (mode == MODE_NOISE) best = draw_noise(n, row, blocked, noise + (long)a * n, 1, p, &pr);
     else if (mode == MODE_RACE) best = draw_race(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, p, logp ? &pr : NULL);
-    else best = draw_scan(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, &pr);
+    else best = draw_scan(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, &pr, 64);
     if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
     actions[a] = best;
     if (logp) logp[a] = clamp_log(pr);
@@ -541,7 +593,7 @@ int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand
       int best;
       if (mode == MODE_NOISE) best = draw_noise(n1, row, blocked, noise + ((long)(len - 1) * A + a) * n1, 1, p, &pr);
       else if (mode == MODE_RACE) best = draw_race(n1, row, blocked, seed, iter, gid, len, p, logp ? &pr : NULL);
-      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr);
+      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr, 64);
       if (best < 0) { fail = 1; break; }
       if (logp) logp[(long)(len - 1) * A + a] = clamp_log(pr);
       if (best != 0) { vis[best] = 1; --remaining; }

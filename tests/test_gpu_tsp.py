@@ -107,7 +107,9 @@ def test_aco_class_run_trace(name):
 # ------------------------------------------------------------------ 2. oracle, Philox modes
 SHAPES = [(2, 1, 1), (3, 2, 1), (5, 4, 1), (20, 7, 2), (63, 5, 1), (64, 9, 1), (65, 5, 2), (100, 33, 1),
           (128, 6, 1), (129, 6, 1), (200, 17, 2), (256, 4, 1), (257, 4, 1), (500, 12, 1), (777, 5, 1),
-          (1000, 6, 1), (1025, 3, 1)]
+          (1000, 6, 1), (1025, 3, 1),
+          # two ants per wavefront (128 < n <= 1024): every chunk count 2..8, odd ant counts
+          (130, 3, 1), (384, 7, 1), (385, 5, 2), (512, 9, 1), (640, 3, 1), (700, 4, 1), (896, 3, 1), (1024, 5, 1)]
 
 
 @pytest.mark.parametrize("mode", ["scan", "race"])
@@ -139,6 +141,33 @@ def test_fixed_start_and_no_logp(mode):
     fn = oracle.tsp_sample_scan if mode == "scan" else oracle.tsp_sample_race
     rp, _, _ = fn(oracle.prob_matrix(tau[0].numpy(), eta[0].numpy()), A, 9, 0, 0, fixed_start=0)
     assert np.array_equal(paths[0].cpu().numpy(), rp)
+
+
+@pytest.mark.parametrize("B,A", [(1, 1), (2, 7), (3, 16), (2, 33)])
+def test_two_ants_per_wave_fused_outputs(B, A):
+    """128 < n <= 1024 in scan mode: fused costs and neighbour table of the two-ants-per-wave kernel, any ant
+    count; 'scan_wave' keeps the one-ant-per-wave draw (a different but equally valid stream)."""
+    from deepaco_amd import engine
+    n = 300
+    dist, tau, eta = make_instance(n, 7 * B + A, B)
+    out = {}
+    for mode in ("scan", "scan_wave"):
+        paths, logp, _, flags, costs, nbr = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=21, it=2,
+                                                              dist=dist.to(dev()), want_nbr=True, require_prob=True)
+        assert int(flags.sum()) == 0
+        for b in range(B):
+            rp, rl, _ = oracle.tsp_sample_scan(oracle.prob_matrix(tau[b].numpy(), eta[b].numpy()), A, 21, 2, b * A,
+                                               require_prob=True, wave=(mode == "scan_wave"))
+            assert np.array_equal(paths[b].cpu().numpy(), rp), (mode, b)
+            np.testing.assert_allclose(logp[b].cpu().numpy(), rl, atol=ATOL_LOGP, rtol=1e-5)
+            assert np.array_equal(costs[b].cpu().numpy(), oracle.tour_costs(dist[b].numpy(), rp))
+        t1 = tau.to(dev()).clone().contiguous()
+        t2 = t1.clone()
+        engine.pheromone_update_(t1, paths, costs, 0.9, nbr=nbr)
+        engine.pheromone_update_(t2, paths, costs, 0.9)
+        assert torch.equal(t1, t2)
+        out[mode] = paths
+    assert not torch.equal(out["scan"], out["scan_wave"])
 
 
 @pytest.mark.parametrize("elitist,mmas", [(False, False), (True, False), (False, True)])
