@@ -8,7 +8,7 @@ costs -> best-so-far tracking -> fused evaporate+deposit pheromone update.  Inpu
 in HBM before the timed region.  value = N_gpus * B * A * steps / wall.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (tsp_sample_kernel) timed live with HIP events on the launch
+  roofline     dominant kernel (tsp_scan32_kernel for the default workload) timed live with HIP events on the launch
                stream; achieved = algorithmic bytes per launch / average launch duration.
                Algorithmic bytes per ant-tour follow SURVEY.md 8(d):
                (n-1)*8n + 8n + 8n^2/A + 8n  (two f32 rows per step, i64 path writes, amortised
@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+L2_ROW_STREAM_GBS = 18800.0    # measured L2->L1 ceiling for 2 KB row reads (tools/l2_row_stream_bench.hip)
 
 
 def make_instances(B, n, seed):
@@ -104,7 +105,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=500)
     ap.add_argument("--ants", type=int, default=512)
     ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
-    ap.add_argument("--sampler", default="scan", choices=["scan", "race"])
+    ap.add_argument("--sampler", default="scan", choices=["scan", "scan_wave", "race"])
     ap.add_argument("--k-sparse", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -180,6 +181,9 @@ def main():
     per_launch = (B * (colony.hi - colony.lo) if ant_sharded else B * A) * bpt
     achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms else None      # GB/s, dominant kernel, this rank
     gpu_best = colony.lowest_cost.detach().cpu()
+    two_per_wave = args.sampler == "scan" and 64 < n <= 1024       # daco_tsp_sample's layout rule
+    kernel_name = "tsp_scan32_kernel" if two_per_wave else "tsp_sample_kernel"
+    row_floats = (n + 127) // 128 * 128 if two_per_wave else ((n + 255) // 256 * 256 if n > 128 else n)
 
     if rank == 0:
         traffic = None
@@ -200,16 +204,22 @@ def main():
                        "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": achieved / PEAK_HBM_GBS if achieved else None, "traffic": traffic,
-                         "kernel": "tsp_sample_kernel", "kernel_ms": kern_ms,
+                         "kernel": kernel_name, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": per_launch,
-                         "note": "rows are L2-resident and tau^a*eta^b is fused, so achieved algorithmic GB/s exceeds "
-                                 "the HBM peak; the kernel is instruction-issue bound (DESIGN.md 3.1, profiles/)"},
-            # the bytes the kernel really moves per launch: one padded fused row (4*ld B) per ant-step out of L2
+                         "note": "the transition rows (tau^a*eta^b fused, one row per ant-step) are served by L2, "
+                                 "not HBM, so the algorithmic GB/s of SURVEY 8(d) exceeds the HBM peak and `traffic` "
+                                 "(measured HBM bytes) is far below the algorithmic bytes; the binding resource is "
+                                 "L2->L1 row streaming, see roofline_l2 (DESIGN.md 3.1, profiles/)"},
+            # the bytes the kernel really moves per launch: one padded fused row per ant-step out of L2
             "roofline_l2": None if not kern_ms else {
-                "bound": "l2", "unit": "GB/s", "peak": 34500.0,
-                "achieved": (B * A * (n - 1) * 4.0 * ((n + 255) // 256 * 256 if n > 128 else n)) / (kern_ms * 1e-3) / 1e9,
-                "note": "row bytes streamed per launch / kernel time vs the 34.5 TB/s aggregate L2 figure of "
-                        "MI355X_MICROARCH.md; L2 hit rate 0.93 (profiles/)"},
+                "bound": "l2", "unit": "GB/s", "peak": L2_ROW_STREAM_GBS,
+                "achieved": B * A * (n - 1) * 4.0 * row_floats / (kern_ms * 1e-3) / 1e9,
+                "frac": B * A * (n - 1) * 4.0 * row_floats / (kern_ms * 1e-3) / 1e9 / L2_ROW_STREAM_GBS,
+                "peak_spec": 34500.0,
+                "note": "row bytes streamed per launch / kernel time; peak = 18.8 TB/s, what a bare kernel that only "
+                        "streams the same 2 KB rows out of L2 reaches on MI355X at any occupancy "
+                        "(tools/l2_row_stream_bench.hip, profiles/r01_g_l2_row_stream.txt); peak_spec = the 34.5 TB/s "
+                        "aggregate L2 figure of MI355X_MICROARCH.md"},
             "gpu_mean_best_cost": float(gpu_best.mean()),
         }
         if world == 1 and not args.no_cpu:

@@ -57,7 +57,7 @@ tour_costs_kernel(int B, int n, int len, int A, const float *dist, long dist_bs,
   costs[idx] = s;
 }
 
-// nbr[b][a][node] = prev(node) | next(node) << 16 along ant a's closed tour
+// nbr[b][node][a] = prev(node) | next(node) << 16 along ant a's closed tour
 __global__ void __launch_bounds__(256)
 build_nbr_kernel(int B, int n, int A, const int64_t *paths, uint32_t *nbr) {
   const long total = (long)B * n * A;
@@ -69,7 +69,7 @@ build_nbr_kernel(int B, int n, int A, const int64_t *paths, uint32_t *nbr) {
     const uint32_t u = (uint32_t)p[(size_t)k * A];
     const uint32_t up = (uint32_t)p[(size_t)(k ? k - 1 : n - 1) * A];
     const uint32_t un = (uint32_t)p[(size_t)(k + 1 < n ? k + 1 : 0) * A];
-    nbr[((size_t)b * A + a) * n + u] = up | (un << 16);
+    nbr[((size_t)b * n + u) * A + a] = up | (un << 16);
   }
 }
 
@@ -86,49 +86,68 @@ __global__ void __launch_bounds__(64) argmin_cost_kernel(int A, const float *cos
   if (lane == 0) best[b] = r.idx == 0x7fffffff ? 0 : r.idx;
 }
 
+// Row owners: a workgroup keeps R rows of tau in LDS.  Row i receives, per ant and in ant order,
+// +w at column prev_a(i) and +w at column next_a(i) (tsp/aco.py:95-118: each ant's forward and
+// backward edges).  Adds to one element must stay in ant order, so each row is a chain of
+// dependent LDS read-modify-writes: two lanes per row (prev side / next side; they never meet on
+// a column within one ant) walk the ants in lock step.  The chain is LDS-latency bound, so the
+// rest is kept off it: the [node][ant] table arrives in coalesced chunks of DEP_CHUNK ants,
+// double-buffered in LDS by all four waves, and the chain reads it four ants at a time.
+constexpr int DEP_CHUNK = 64, DEP_ROWS = 32;
+
 __global__ void __launch_bounds__(256)
 deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, const float *weights,
                    float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[2][DEP_ROWS][DEP_CHUNK];
+  __shared__ __attribute__((aligned(16))) float wts[2][DEP_CHUNK];
   const int bpi = (n + R - 1) / R;
   const int b = blockIdx.x / bpi;
   const int i0 = (blockIdx.x - b * bpi) * R;
   const int Rv = min(R, n - i0);
   float *g = tau + ((size_t)b * n + i0) * n;
   const int cnt = Rv * n;
+  int alo = 0, ahi = A;
+  if (best) { alo = best[b]; ahi = alo + 1; }
+  const uint32_t *tab = nbr + ((size_t)b * n + i0) * A;            // rows i0.. of this instance's [n][A] table
+  const float *cs = costs + (size_t)b * A, *wt = weights ? weights + (size_t)b * A : nullptr;
+  // chunk loader: consecutive threads on consecutive ants of one row (256-byte segments)
+  auto load_chunk = [&](int c0, int buf) {
+    const int m = min(DEP_CHUNK, ahi - c0);
+    for (int i = threadIdx.x; i < Rv * DEP_CHUNK; i += blockDim.x) {
+      const int r = i / DEP_CHUNK, j = i - r * DEP_CHUNK;
+      stage[buf][r][j] = j < m ? tab[(size_t)r * A + c0 + j] : 0u;
+    }
+    if (threadIdx.x < DEP_CHUNK)
+      wts[buf][threadIdx.x] = threadIdx.x < m ? (wt ? wt[c0 + threadIdx.x] : 1.0f / cs[c0 + threadIdx.x]) : 0.0f;
+  };
+  load_chunk(alo, 0);
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) rows[i] = g[i] * decay;
   __syncthreads();
-  const int r = threadIdx.x >> 1, role = threadIdx.x & 1;
-  if (r < Rv) {
-    const uint32_t *nb = nbr + (size_t)b * A * n + i0 + r;
-    const float *cs = costs + (size_t)b * A;
-    float *row = rows + r * n;
-    int alo = 0, ahi = A;
-    if (best) { alo = best[b]; ahi = alo + 1; }
-    // the neighbour-table loads are independent of the LDS chain: fetch 16 ants ahead, then apply in order
-    int a = alo;
-    for (; a + 16 <= ahi; a += 16) {
-      uint32_t v[16];
-      float w[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        v[u] = nb[(size_t)(a + u) * n];
-        w[u] = weights ? weights[(size_t)b * A + a + u] : 1.0f / cs[a + u];
+  const int r = threadIdx.x >> 1, sh = (threadIdx.x & 1) << 4;     // prev side: low half-word, next side: high
+  float *row = rows + (r < Rv ? r : 0) * n;
+  int buf = 0;
+  for (int c0 = alo; c0 < ahi; c0 += DEP_CHUNK, buf ^= 1) {
+    if (c0 + DEP_CHUNK < ahi) load_chunk(c0 + DEP_CHUNK, buf ^ 1);  // next chunk lands while this one is applied
+    if (r < Rv) {
+      const int m = min(DEP_CHUNK, ahi - c0);
+      int j = 0;
+      for (; j + 4 <= m; j += 4) {
+        const uint4 v = *(const uint4 *)&stage[buf][r][j];
+        const float4 w = *(const float4 *)&wts[buf][j];
+        const int c0_ = (v.x >> sh) & 0xFFFFu, c1_ = (v.y >> sh) & 0xFFFFu, c2_ = (v.z >> sh) & 0xFFFFu, c3_ = (v.w >> sh) & 0xFFFFu;
+        row[c0_] = row[c0_] + w.x;
+        row[c1_] = row[c1_] + w.y;
+        row[c2_] = row[c2_] + w.z;
+        row[c3_] = row[c3_] + w.w;
       }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int col = role ? (int)(v[u] >> 16) : (int)(v[u] & 0xFFFFu);
-        row[col] = row[col] + w[u];
+      for (; j < m; ++j) {
+        const int col = (stage[buf][r][j] >> sh) & 0xFFFFu;
+        row[col] = row[col] + wts[buf][j];
       }
     }
-    for (; a < ahi; ++a) {
-      const uint32_t v = nb[(size_t)a * n];
-      const int col = role ? (int)(v >> 16) : (int)(v & 0xFFFFu);
-      const float w = weights ? weights[(size_t)b * A + a] : 1.0f / cs[a];
-      row[col] = row[col] + w;
-    }
+    __syncthreads();
   }
-  __syncthreads();
   const bool clamp = clamp_max != nullptr;
   const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
@@ -271,8 +290,9 @@ extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, i
 }
 
 static int rows_per_block(int n) {
-  int R = (64 * 1024) / (4 * n);      // keep the LDS image <= 64 KiB: two workgroups per CU
-  if (R > 32) R = 32;                  // 2 lanes per row, chain runs in one wave
+  // two workgroups per CU: 160 KiB of LDS less the two static staging images (2 x 16.5 KiB)
+  int R = (63 * 1024) / (4 * n);
+  if (R > DEP_ROWS) R = DEP_ROWS;     // two lanes per row, the chains of a workgroup run in one wave
   return R;
 }
 

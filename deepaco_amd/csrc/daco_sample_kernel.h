@@ -27,7 +27,7 @@ struct SampleParams {
   const float *dist;     // [B][n][n] (fused costs) or null
   long dist_bs;
   float *costs;          // [B][A] or null
-  uint32_t *nbr;         // [B][A][n] prev | next << 16 (for the pheromone update) or null
+  uint32_t *nbr;         // [B][n][A] prev | next << 16 per (node, ant), for the pheromone update; or null
   // CVRP (cvrp/aco.py:138-205): node 0 = depot, variable-length routes
   // fused sibling constructions (daco_sib_sample.hip)
   const float *aux_vec;  // [B][n]: SOP predecessor counts, PCTSP prizes, OP distance to the depot d[k][0]
@@ -123,7 +123,7 @@ tsp_sample_kernel(const SampleParams p) {
   float *logp_out = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
   const float *dist_b = (PROB == PROB_TSP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
-  uint32_t *nbr_a = (PROB == PROB_TSP && p.nbr) ? p.nbr + ((size_t)b * A + a) * n : nullptr;
+  uint32_t *nbr_a = (PROB == PROB_TSP && p.nbr) ? p.nbr + (size_t)b * n * A + a : nullptr;   // + node * A
   int pprev = 0, second = 0;                            // neighbour-table bookkeeping
   const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
 
@@ -441,7 +441,7 @@ tsp_sample_kernel(const SampleParams p) {
       dpend = dist_b[(unsigned)choice * (unsigned)n + (unsigned)prev];   // d[u_t][u_{t-1}], scalar load
     }
     if (nbr_a) {                                         // node `prev` now knows both neighbours
-      if (lane == 0) nbr_a[(unsigned)prev] = (uint32_t)pprev | ((uint32_t)choice << 16);
+      if (lane == 0) nbr_a[(size_t)prev * A] = (uint32_t)pprev | ((uint32_t)choice << 16);
       if (t == 1) second = choice;
       pprev = prev;
     }
@@ -468,8 +468,8 @@ tsp_sample_kernel(const SampleParams p) {
     if (lane == 0) p.costs[(size_t)b * A + a] = cost;
   }
   if (nbr_a && lane == 0) {                             // close the cycle: last -> first -> second
-    if (n == 2) { nbr_a[first] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[prev] = (uint32_t)first | ((uint32_t)first << 16); }
-    else { nbr_a[prev] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[first] = (uint32_t)prev | ((uint32_t)second << 16); }
+    if (n == 2) { nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[(size_t)prev * A] = (uint32_t)first | ((uint32_t)first << 16); }
+    else { nbr_a[(size_t)prev * A] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)second << 16); }
   }
   if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
 }
@@ -514,7 +514,7 @@ inline int inst_chunks(int n) {
 inline int ld_alloc(int n) { return inst_chunks(n) * 64 * vec_for_n(n); }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// daco_tsp_scan32.hip: TSP scan draw with two ants per wavefront (128 < n <= 1024)
+// daco_tsp_scan32.hip: TSP scan draw with two ants per wavefront (64 < n <= 1024)
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
 
 }  // namespace daco

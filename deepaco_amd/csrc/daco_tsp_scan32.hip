@@ -1,7 +1,7 @@
 // daco_tsp_scan32.hip -- TSP tour construction, prefix-scan draw, TWO ants per wavefront.
 //
 // Same reference behaviour as daco_tsp_sample.hip in DACO_SCAN mode (tsp/aco.py:134-177 with the
-// roulette draw of tsp_nls/aco.py:260-275), for 128 < n <= 1024.  The one-ant-per-wave kernel is
+// roulette draw of tsp_nls/aco.py:260-275), for 64 < n <= 1024.  The one-ant-per-wave kernel is
 // instruction-issue bound and two thirds of its instructions are per-STEP overhead (DPP scan,
 // ballot, lane picks, stores, loop) rather than per-candidate work.  Here each 32-lane half of a
 // wave builds one tour, so that overhead is paid once for two ants:
@@ -74,8 +74,8 @@ tsp_scan32_kernel(const SampleParams p) {
   char *rs_t = (LOGP && p.rowsum) ? (char *)(p.rowsum + (size_t)b * (n - 1) * A) : nullptr;
   const bool want_cost = FUSED || p.costs != nullptr, want_nbr = FUSED || p.nbr != nullptr;
   const char *dist_b = want_cost ? (const char *)(p.dist + (size_t)b * p.dist_bs) : nullptr;
-  char *nbr_b = want_nbr ? (char *)(p.nbr + (size_t)b * A * n) : nullptr;
-  const uint32_t an4 = (uint32_t)a * (uint32_t)n * 4u;
+  char *nbr_b = want_nbr ? (char *)(p.nbr + (size_t)b * n * A) : nullptr;        // [n][A] table of this instance
+  const uint32_t A4 = (uint32_t)A * 4u;
   float *fl = open_flags[wave * 2 + up], *pk = pick[wave * 2 + up];
 #pragma unroll
   for (int c = 0; c < CH2; ++c) *(float4 *)(fl + (c * 32 + s) * 4) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -182,7 +182,7 @@ tsp_scan32_kernel(const SampleParams p) {
           cost = cost + dpend;
           dpend = *(const float *)(dist_b + ((__umul24((uint32_t)choice, (uint32_t)n) + (uint32_t)prev) << 2));
         }
-        if (want_nbr) *(uint32_t *)(nbr_b + an4 + ((uint32_t)prev << 2)) = (uint32_t)pprev | ((uint32_t)choice << 16);
+        if (want_nbr) *(uint32_t *)(nbr_b + __umul24((uint32_t)prev, A4) + a4) = (uint32_t)pprev | ((uint32_t)choice << 16);
       }
       pprev = prev;
       prev = choice;
@@ -195,10 +195,10 @@ tsp_scan32_kernel(const SampleParams p) {
       p.costs[(size_t)b * A + a] = cost;
     }
     if (want_nbr) {                                     // close the cycle: last -> first -> second
-      uint32_t *nbr_a = (uint32_t *)(nbr_b + an4);
+      uint32_t *nbr_a = (uint32_t *)(nbr_b + a4);        // + node * A
       const int second = (int)p.paths[((size_t)b * n + 1) * A + a];
-      if (n == 2) { nbr_a[first] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[prev] = (uint32_t)first | ((uint32_t)first << 16); }
-      else { nbr_a[prev] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[first] = (uint32_t)prev | ((uint32_t)second << 16); }
+      if (n == 2) { nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[(size_t)prev * A] = (uint32_t)first | ((uint32_t)first << 16); }
+      else { nbr_a[(size_t)prev * A] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)second << 16); }
     }
   }
   if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
@@ -220,6 +220,7 @@ static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
 // entry used by daco_tsp_sample (daco_tsp_sample.hip) when the two-ants-per-wave layout applies
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
   switch ((sp.n + 127) / 128) {
+    case 1: return launch32<1>(sp, logp, s);
     case 2: return launch32<2>(sp, logp, s);
     case 3: return launch32<3>(sp, logp, s);
     case 4: return launch32<4>(sp, logp, s);

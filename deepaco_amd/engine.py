@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import RACE_NOISE, RACE_PHILOX, SCAN, SCAN_WAVE  # noqa: F401
 
-# "scan": daco_tsp_sample packs two ants per wavefront for 128 < n <= 1024; "scan_wave" keeps the
+# "scan": daco_tsp_sample packs two ants per wavefront for 64 < n <= 1024; "scan_wave" keeps the
 # one-ant-per-wavefront draw for every n (what the step-wise service, CVRP and the siblings use)
 MODES = {"race_noise": RACE_NOISE, "race": RACE_PHILOX, "scan": SCAN, "scan_wave": SCAN_WAVE}
 
@@ -83,7 +83,7 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
             dist, dbs = _bstride(dist, n)
             costs = torch.empty((B, n_ants), dtype=torch.float32, device=dev)
         if want_nbr:
-            nbr = torch.empty((B, n_ants, n), dtype=torch.int32, device=dev)
+            nbr = torch.empty((B, n, n_ants), dtype=torch.int32, device=dev)
         nbytes = L.daco_tsp_sample_workspace_bytes(B, n, m)
         ws = _workspace(dev, nbytes, "sample")
         rc = L.daco_tsp_sample(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs,

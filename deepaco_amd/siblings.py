@@ -201,6 +201,8 @@ class SMTWTP(_Base):
         it = self._calls
         self._calls += 1
         mode = "race_noise" if _noise is not None else self.sampler
+        if mode == "scan":
+            mode = "scan_wave"          # the draw of the step-wise service: fused == step-wise for every n
         noise = None if _noise is None else torch.stack(list(_noise)).unsqueeze(0)
         tau = self.pheromone.detach().float()
         if require_prob and torch.is_grad_enabled() and self.heuristic.requires_grad:

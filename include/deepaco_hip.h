@@ -41,7 +41,7 @@ extern "C" {
 #define DACO_RACE_NOISE 0  /* exponential race, noise read from memory (bit-exact parity mode) */
 #define DACO_RACE_PHILOX 1 /* exponential race, Philox4x32-10 noise generated in-kernel */
 #define DACO_SCAN 2        /* roulette / inverse-CDF by wavefront prefix scan, one uniform per step.
-                            * daco_tsp_sample packs two ants per wavefront for 128 < n <= 1024 (the
+                            * daco_tsp_sample packs two ants per wavefront for 64 < n <= 1024 (the
                             * 32-lane variant of the scan); everything else uses
                             * one ant per wavefront. */
 #define DACO_SCAN_WAVE 3   /* DACO_SCAN with the one-ant-per-wavefront layout for every n: the draw
@@ -87,7 +87,7 @@ int daco_ld_for_n(int n);
  *   dist, costs   optional fusion of ACO.gen_path_costs: if costs != NULL, dist [B][n][n]
  *              (dist_bstride as for tau) is read once per step and costs [B][A] receives the
  *              closed-tour length in daco_tour_costs' summation order.
- *   nbr        optional out [B][A][n] uint32: prev(node) | next(node) << 16 along each tour, the
+ *   nbr        optional out [B][n][A] uint32: prev(node) | next(node) << 16 per (node, ant), the
  *              form daco_pheromone_update consumes (saves its own pass over `paths`).
  *   workspace  daco_tsp_sample_workspace_bytes(B, n, mode) bytes of device scratch.
  *   ev_begin, ev_end   optional hipEvent_t pair (NULL to skip) recorded on `stream` immediately
@@ -225,7 +225,7 @@ int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dis
  *   tau   in/out [B][n][n] f32 (dense, stride n*n)
  *   paths [B][len][A] int64, costs [B][A] f32
  *   clamp_min/clamp_max: [B] f32 device arrays or NULL (per-instance MMAS bounds)
- *   nbr   optional [B][A][n] uint32 as written by daco_tsp_sample (symmetric only); if NULL it
+ *   nbr   optional [B][n][A] uint32 as written by daco_tsp_sample (symmetric only); if NULL it
  *         is rebuilt from `paths` in the workspace
  *   weights optional [B][A] f32: the amount each ant deposits, for the siblings whose rule is
  *         not 1/cost (op/aco.py:134-139 Q*obj, bpp/aco.py:113-118 fit/n_ants, smtwtp/aco.py:90-95

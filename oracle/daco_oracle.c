@@ -190,7 +190,7 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
 }
 
 /* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274.
- * `lanes` = 64 (one ant per wavefront) or 32 (two ants per wavefront, TSP with 128 < n <= 1024):
+ * `lanes` = 64 (one ant per wavefront) or 32 (two ants per wavefront, TSP with 64 < n <= 1024; vec = 4):
  *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
  *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
  *              (lanes = 32: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
@@ -205,11 +205,11 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  *       candidate with p > 0 of the lane;
  *     lanes = 32: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
  *       first j with scan[j] >= thr and p_j > 0, else the last j with p_j > 0. */
-int orc_scan_lanes(int n, int mode) { return (mode == 2 && n > 128 && n <= 1024) ? 32 : 64; }
+int orc_scan_lanes(int n, int mode) { return (mode == 2 && n > 64 && n <= 1024) ? 32 : 64; }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
                      uint64_t iter, uint32_t gid, int t, float *pr, int lanes) {
-  int vec = orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
+  int vec = lanes == 32 ? 4 : orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
   float part[64], incl[64];
   uint32_t r4[4];
   for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;

@@ -108,7 +108,7 @@ def test_aco_class_run_trace(name):
 SHAPES = [(2, 1, 1), (3, 2, 1), (5, 4, 1), (20, 7, 2), (63, 5, 1), (64, 9, 1), (65, 5, 2), (100, 33, 1),
           (128, 6, 1), (129, 6, 1), (200, 17, 2), (256, 4, 1), (257, 4, 1), (500, 12, 1), (777, 5, 1),
           (1000, 6, 1), (1025, 3, 1),
-          # two ants per wavefront (128 < n <= 1024): every chunk count 2..8, odd ant counts
+          # two ants per wavefront (64 < n <= 1024): every chunk count 1..8, odd ant counts
           (130, 3, 1), (384, 7, 1), (385, 5, 2), (512, 9, 1), (640, 3, 1), (700, 4, 1), (896, 3, 1), (1024, 5, 1)]
 
 
@@ -145,10 +145,10 @@ def test_fixed_start_and_no_logp(mode):
 
 @pytest.mark.parametrize("B,A", [(1, 1), (2, 7), (3, 16), (2, 33)])
 def test_two_ants_per_wave_fused_outputs(B, A):
-    """128 < n <= 1024 in scan mode: fused costs and neighbour table of the two-ants-per-wave kernel, any ant
+    """64 < n <= 1024 in scan mode: fused costs and neighbour table of the two-ants-per-wave kernel, any ant
     count; 'scan_wave' keeps the one-ant-per-wave draw (a different but equally valid stream)."""
     from deepaco_amd import engine
-    n = 300
+    n = 300 if A != 7 else 90
     dist, tau, eta = make_instance(n, 7 * B + A, B)
     out = {}
     for mode in ("scan", "scan_wave"):
