@@ -112,6 +112,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
+  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024;
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
@@ -137,7 +138,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
-  hipError_t e = dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
+  hipError_t e = two_per_wave ? launch_cvrp_scan32(sp, logp != nullptr, s) : dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
   if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }

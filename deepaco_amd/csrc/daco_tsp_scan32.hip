@@ -217,6 +217,176 @@ static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ CVRP (cvrp/aco.py:138-205)
+// Same draw, the closed set now also holds the customers whose demand exceeds the remaining
+// capacity (strict, cvrp/aco.py:200) and the depot while the ant stands on it with customers left
+// (:179).  Lanes multiply the row by the combined 0/1 factor, the chosen lane deals those masked
+// values.  The two ants of a wave finish at different steps: a finished half keeps stepping with
+// its stores and state updates switched off until its neighbour is done.
+template <int CH2, bool LOGP>
+__global__ void __launch_bounds__(256)
+cvrp_scan32_kernel(const SampleParams p) {
+  constexpr int NJ = CH2 * 4, ROWF = CH2 * 128;
+  __shared__ __attribute__((aligned(16))) float open_flags[8][ROWF];
+  __shared__ __attribute__((aligned(16))) float pick[8][40];
+  __shared__ __attribute__((aligned(16))) float dem_s[ROWF];          // demand of this instance, +inf padding
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int up = lane >> 5, s = lane & 31;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bpi = (p.A + 7) >> 3;
+  const int b = w / bpi;
+  const int a0 = ((w - b * bpi) * 4 + wave) * 2;
+  const int n = p.n, A = p.A, ld = p.ld, Lmax = p.Lmax;
+  for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
+  __syncthreads();
+  if (a0 >= A) return;
+  const int a = a0 + up < A ? a0 + up : A - 1;          // odd A: the last upper half repeats ant A-1
+  const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
+  const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
+  int64_t *path_a = p.paths + (size_t)b * Lmax * A + a;
+  float *logp_a = LOGP ? p.logp + (size_t)b * (Lmax - 1) * A + a : nullptr;
+  float *rs_a = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (Lmax - 1) * A + a : nullptr;
+  float *fl = open_flags[wave * 2 + up], *pk = pick[wave * 2 + up];
+  float4 dm[CH2];
+#pragma unroll
+  for (int c = 0; c < CH2; ++c) {
+    *(float4 *)(fl + (c * 32 + s) * 4) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    dm[c] = *(const float4 *)(dem_s + (c * 32 + s) * 4);
+  }
+  pk[s] = 0.0f;
+  if (s < 8) pk[32 + s] = 0.0f;
+  const int ubase = (lane & 32) << 2;
+  const int cbase = s < NJ ? ((s >> 2) << 7) | (s & 3) : 0;
+  __builtin_amdgcn_wave_barrier();
+  if (lead) path_a[0] = 0;
+
+  int prev = 0, remaining = n - 1, len = 1;
+  float used = 0.0f + dem_s[0];
+  bool finished = remaining == 0;
+  u32x4 ublk = {0, 0, 0, 0};
+  float ucur = 0.0f;
+  uint64_t feasible = ~0ull;
+  uint64_t act = __builtin_amdgcn_ballot_w64(!finished);               // lanes of the halves still building
+
+  for (int t = 1; t < Lmax && act != 0; ++t) {
+    const uint32_t voff = __umul24((uint32_t)prev, ldb) + lane_off;
+    float4 row[CH2], fo[CH2];
+#pragma unroll
+    for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
+    if ((t & 31) == 0 || t == 1) {
+      if ((t & 127) == 0 || t == 1) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 7) << 5) + s));
+      ucur = u01(comp(ublk, (t >> 5) & 3));
+    }
+    const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | ((t & 31) << 2), __float_as_int(ucur)));
+#pragma unroll
+    for (int c = 0; c < CH2; ++c) fo[c] = *(const float4 *)(fl + (c * 32 + s) * 4);
+    const float rem = p.capacity - used;
+    f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < CH2; ++c) {
+      float4 f = fo[c];
+      f.x = dm[c].x > rem ? 0.0f : f.x;  f.y = dm[c].y > rem ? 0.0f : f.y;
+      f.z = dm[c].z > rem ? 0.0f : f.z;  f.w = dm[c].w > rem ? 0.0f : f.w;
+      if (c == 0) f.x = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f.x;       // the depot, cvrp/aco.py:179
+      const f32x2 lo = (f32x2){row[c].x, row[c].y} * (f32x2){f.x, f.y}, hi = (f32x2){row[c].z, row[c].w} * (f32x2){f.z, f.w};
+      row[c] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      acc = acc + lo;
+      acc = acc + hi;
+    }
+    const float part = acc.x + acc.y;
+    const float incl = half_scan_add<true>(part);
+    const float S = half_bcast_last(incl);
+    const float r = fmaxf(u * S, 1.401298464e-45f);
+    const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT) & act;
+    feasible &= __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT) | ~act;
+    float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
+    excl = s == 0 ? 0.0f : excl;
+    const float thr = r - excl;
+    const bool mine = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit((uint32_t)m) |
+                                                          ((uint64_t)lowest_bit((uint32_t)(m >> 32)) << 32));
+    if (mine) {
+#pragma unroll
+      for (int c = 0; c < CH2; ++c) *(float4 *)(pk + 4 * c) = row[c];
+      *(float2 *)(pk + 32) = make_float2(thr, __int_as_float(s));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float cv = pk[s];
+    const float2 tl = *(const float2 *)(pk + 32);
+    const int mychoice = cbase + (__float_as_int(tl.y) << 2);
+    const float sc = half_scan_add<(NJ > 16)>(cv);
+    const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP_OGT) & act;
+    const uint64_t k = __builtin_amdgcn_fcmpf(sc, tl.x, FCMP_OGE) & pos;
+    uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
+    if (__builtin_expect(k0 == 0 || k1 == 0, 0)) {
+      const uint32_t q0 = (uint32_t)pos, q1 = (uint32_t)(pos >> 32);
+      if (k0 == 0 && q0) k0 = 0x80000000u >> __builtin_clz(q0);
+      if (k1 == 0 && q1) k1 = 0x80000000u >> __builtin_clz(q1);
+    }
+    const bool win = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit(k0) | ((uint64_t)lowest_bit(k1) << 32));
+    if (win) {
+      pk[34] = __int_as_float(mychoice);
+      if (mychoice != 0) fl[mychoice] = 0.0f;            // customers are visited once, the depot stays open
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int choice = __float_as_int(pk[34]);
+    __builtin_amdgcn_wave_barrier();
+
+    if (!finished) {
+      if (s == 0) {
+        path_a[(size_t)t * A] = choice;
+        if constexpr (LOGP) {
+          const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);
+          logp_a[(size_t)(t - 1) * A] = clamp_log(pc / S);
+          if (rs_a) rs_a[(size_t)(t - 1) * A] = S;
+        }
+      }
+      if (choice != 0) --remaining; else used = 0.0f;
+      used = used + dem_s[choice];
+      finished = remaining == 0 && choice == 0;
+      len = t + 1;
+      prev = finished ? 0 : choice;
+    }
+    act = __builtin_amdgcn_ballot_w64(!finished);
+  }
+  // the reference steps every ant until the slowest one is done: a done ant keeps drawing the
+  // depot (probability 1), so its column is padded with 0 / log(1-eps)
+  if (s == 0) {
+    if (p.lens) p.lens[(size_t)b * A + a] = len;
+    const float lp1 = clamp_log(1.0f);
+    for (int tt = len; tt < Lmax; ++tt) {
+      path_a[(size_t)tt * A] = 0;
+      if constexpr (LOGP) logp_a[(size_t)(tt - 1) * A] = lp1;
+    }
+    if (!finished && p.flags) atomicOr(p.flags + b, 2);
+  }
+  if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+}
+
+template <int CH2>
+static hipError_t launch_cvrp32(const SampleParams &sp, bool logp, hipStream_t s) {
+  const int bpi = (sp.A + 7) / 8;
+  dim3 grid((unsigned)(sp.B * bpi)), block(256);
+  if (logp) hipLaunchKernelGGL((cvrp_scan32_kernel<CH2, true>), grid, block, 0, s, sp);
+  else hipLaunchKernelGGL((cvrp_scan32_kernel<CH2, false>), grid, block, 0, s, sp);
+  return hipGetLastError();
+}
+
+// entry used by daco_cvrp_sample when the two-ants-per-wave layout applies
+hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
+  switch ((sp.n + 127) / 128) {
+    case 1: return launch_cvrp32<1>(sp, logp, s);
+    case 2: return launch_cvrp32<2>(sp, logp, s);
+    case 3: return launch_cvrp32<3>(sp, logp, s);
+    case 4: return launch_cvrp32<4>(sp, logp, s);
+    case 5: return launch_cvrp32<5>(sp, logp, s);
+    case 6: return launch_cvrp32<6>(sp, logp, s);
+    case 7: return launch_cvrp32<7>(sp, logp, s);
+    default: return launch_cvrp32<8>(sp, logp, s);
+  }
+}
+
 // entry used by daco_tsp_sample (daco_tsp_sample.hip) when the two-ants-per-wave layout applies
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
   switch ((sp.n + 127) / 128) {

@@ -185,7 +185,7 @@ def cvrp_sample_rng(P, demand, capacity, A, mode, seed, it=0, ant_gid0=0, Lmax=N
     Lmax = Lmax or 2 * n1 + 1
     paths = np.zeros((Lmax, A), dtype=np.int64)
     logp = np.zeros((Lmax - 1, A), dtype=np.float32) if require_prob else None
-    m = {"race": 1, "scan": 2}[mode]
+    m = {"race": 1, "scan": 2, "scan_wave": 3}[mode]
     L = lib().orc_cvrp_sample(m, n1, A, _p(P), _p(demand), C.c_float(capacity), None, 0, C.c_uint64(seed),
                               C.c_uint64(it), C.c_uint32(ant_gid0), Lmax, _p(paths),
                               _p(logp) if require_prob else None)

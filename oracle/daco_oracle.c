@@ -593,7 +593,7 @@ int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand
       int best;
       if (mode == MODE_NOISE) best = draw_noise(n1, row, blocked, noise + ((long)(len - 1) * A + a) * n1, 1, p, &pr);
       else if (mode == MODE_RACE) best = draw_race(n1, row, blocked, seed, iter, gid, len, p, logp ? &pr : NULL);
-      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr, 64);
+      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr, orc_scan_lanes(n1, mode));
       if (best < 0) { fail = 1; break; }
       if (logp) logp[(long)(len - 1) * A + a] = clamp_log(pr);
       if (best != 0) { vis[best] = 1; --remaining; }

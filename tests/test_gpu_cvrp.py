@@ -63,7 +63,7 @@ def test_cvrp_golden(name):
 
 @pytest.mark.parametrize("mode", ["scan", "race"])
 @pytest.mark.parametrize("n,A,B,cap", [(5, 3, 1, 50), (20, 9, 2, 50), (63, 5, 1, 30), (64, 5, 1, 50), (100, 17, 2, 50),
-                                        (128, 4, 1, 50), (200, 6, 1, 40), (300, 4, 1, 50)])
+                                        (128, 4, 1, 50), (200, 6, 1, 40), (300, 4, 1, 50), (500, 3, 1, 60)])
 def test_cvrp_philox_bit_exact_vs_oracle(mode, n, A, B, cap):
     from deepaco_amd import engine
     d, demand, tau, eta = cvrp_instance(n, 50 + n, B)
