@@ -93,20 +93,25 @@ __global__ void __launch_bounds__(64) argmin_cost_kernel(int A, const float *cos
 // a column within one ant) walk the ants in lock step.  The chain is LDS-latency bound, so the
 // rest is kept off it: the [node][ant] table arrives in coalesced chunks of DEP_CHUNK ants,
 // double-buffered in LDS by all four waves, and the chain reads it four ants at a time.
-constexpr int DEP_CHUNK = 64, DEP_ROWS = 32;
+constexpr int DEP_CHUNK = 64;
 
+// SYM: symmetric deposit, two lanes per row (prev / next side).  !SYM: directed deposit, one lane
+// per row adds at next_a(i) (0xFFFF = ant a does not leave node i); the hub row is skipped (it
+// belongs to deposit_hub_kernel).  LDS: rows[R][n] | stage[2][R][DEP_CHUNK] | wts[2][DEP_CHUNK].
+template <bool SYM>
 __global__ void __launch_bounds__(256)
-deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const float *costs, const float *weights,
-                   float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nbr, const float *costs, const float *weights,
+                    float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
-  __shared__ __attribute__((aligned(16))) uint32_t stage[2][DEP_ROWS][DEP_CHUNK];
-  __shared__ __attribute__((aligned(16))) float wts[2][DEP_CHUNK];
+  uint32_t *stage = (uint32_t *)(rows + (((size_t)R * n + 3) & ~(size_t)3));
+  float *wts = (float *)(stage + 2 * R * DEP_CHUNK);
   const int bpi = (n + R - 1) / R;
   const int b = blockIdx.x / bpi;
   const int i0 = (blockIdx.x - b * bpi) * R;
   const int Rv = min(R, n - i0);
   float *g = tau + ((size_t)b * n + i0) * n;
   const int cnt = Rv * n;
+  const int hub_lo = SYM ? -1 : (hub - i0) * n, hub_hi = SYM ? -1 : hub_lo + n;
   int alo = 0, ahi = A;
   if (best) { alo = best[b]; ahi = alo + 1; }
   const uint32_t *tab = nbr + ((size_t)b * n + i0) * A;            // rows i0.. of this instance's [n][A] table
@@ -116,34 +121,39 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
     const int m = min(DEP_CHUNK, ahi - c0);
     for (int i = threadIdx.x; i < Rv * DEP_CHUNK; i += blockDim.x) {
       const int r = i / DEP_CHUNK, j = i - r * DEP_CHUNK;
-      stage[buf][r][j] = j < m ? tab[(size_t)r * A + c0 + j] : 0u;
+      stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[(size_t)r * A + c0 + j] : 0xFFFFFFFFu;
     }
     if (threadIdx.x < DEP_CHUNK)
-      wts[buf][threadIdx.x] = threadIdx.x < m ? (wt ? wt[c0 + threadIdx.x] : 1.0f / cs[c0 + threadIdx.x]) : 0.0f;
+      wts[buf * DEP_CHUNK + threadIdx.x] = threadIdx.x < m ? (wt ? wt[c0 + threadIdx.x] : 1.0f / cs[c0 + threadIdx.x]) : 0.0f;
   };
   load_chunk(alo, 0);
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) rows[i] = g[i] * decay;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+    if (SYM || i < hub_lo || i >= hub_hi) rows[i] = g[i] * decay;
   __syncthreads();
-  const int r = threadIdx.x >> 1, sh = (threadIdx.x & 1) << 4;     // prev side: low half-word, next side: high
-  float *row = rows + (r < Rv ? r : 0) * n;
+  const int r = SYM ? threadIdx.x >> 1 : threadIdx.x;
+  const int sh = SYM ? (threadIdx.x & 1) << 4 : 16;                // prev side: low half-word, next side: high
+  const bool chain = r < Rv && (SYM || i0 + r != hub);
+  float *row = rows + (chain ? r : 0) * n;
   int buf = 0;
   for (int c0 = alo; c0 < ahi; c0 += DEP_CHUNK, buf ^= 1) {
     if (c0 + DEP_CHUNK < ahi) load_chunk(c0 + DEP_CHUNK, buf ^ 1);  // next chunk lands while this one is applied
-    if (r < Rv) {
+    if (chain) {
       const int m = min(DEP_CHUNK, ahi - c0);
+      const uint32_t *st = stage + (buf * R + r) * DEP_CHUNK;
+      const float *w = wts + buf * DEP_CHUNK;
       int j = 0;
       for (; j + 4 <= m; j += 4) {
-        const uint4 v = *(const uint4 *)&stage[buf][r][j];
-        const float4 w = *(const float4 *)&wts[buf][j];
-        const int c0_ = (v.x >> sh) & 0xFFFFu, c1_ = (v.y >> sh) & 0xFFFFu, c2_ = (v.z >> sh) & 0xFFFFu, c3_ = (v.w >> sh) & 0xFFFFu;
-        row[c0_] = row[c0_] + w.x;
-        row[c1_] = row[c1_] + w.y;
-        row[c2_] = row[c2_] + w.z;
-        row[c3_] = row[c3_] + w.w;
+        const uint4 v = *(const uint4 *)(st + j);
+        const float4 w4 = *(const float4 *)(w + j);
+        const uint32_t c0_ = (v.x >> sh) & 0xFFFFu, c1_ = (v.y >> sh) & 0xFFFFu, c2_ = (v.z >> sh) & 0xFFFFu, c3_ = (v.w >> sh) & 0xFFFFu;
+        if (SYM || c0_ != 0xFFFFu) row[c0_] = row[c0_] + w4.x;
+        if (SYM || c1_ != 0xFFFFu) row[c1_] = row[c1_] + w4.y;
+        if (SYM || c2_ != 0xFFFFu) row[c2_] = row[c2_] + w4.z;
+        if (SYM || c3_ != 0xFFFFu) row[c3_] = row[c3_] + w4.w;
       }
       for (; j < m; ++j) {
-        const int col = (stage[buf][r][j] >> sh) & 0xFFFFu;
-        row[col] = row[col] + wts[buf][j];
+        const uint32_t col = (st[j] >> sh) & 0xFFFFu;
+        if (SYM || col != 0xFFFFu) row[col] = row[col] + w[j];
       }
     }
     __syncthreads();
@@ -151,6 +161,7 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
   const bool clamp = clamp_max != nullptr;
   const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    if (!SYM && i >= hub_lo && i < hub_hi) continue;
     float x = rows[i];
     if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
     if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
@@ -162,11 +173,11 @@ deposit_tsp_kernel(int n, int A, int R, float *tau, const uint32_t *nbr, const f
 // cvrp/aco.py:107-130: tau[path[:-1], path[1:]] += 1/cost per ant, duplicates of an index pair
 // within one ant (the padding edge (0,0)) collapse to ONE add.  Row i >= 1 (a customer) is
 // left exactly once per ant -> one lane per row walks the ants in order.  Row 0 (the depot) is
-// left once per route: build_next_kernel also collects, per ant, the list of nodes that
-// follow the depot; the depot workgroup applies each ant's list (distinct columns -> parallel
-// lanes) in ant order, and the (0,0) edge once per ant if it occurs.
+// left once per route: build_next_kernel also collects, per ant, the SET of nodes that follow
+// the depot as a bitmap (W words per ant; a set, so the (0,0) padding edge counts once); the depot
+// kernel gives every column one thread that walks the ants in order with its sum in a register.
 __global__ void __launch_bounds__(256)
-build_next_kernel(int B, int n, int len, int A, int hub, const int64_t *paths, uint32_t *nbr, uint16_t *dlist, int *dcnt) {
+build_next_kernel(int B, int n, int len, int A, int hub, int W, const int64_t *paths, uint32_t *nbr, uint32_t *hubmask) {
   const long total = (long)B * (len - 1) * A;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int a = (int)(i % A);
@@ -174,11 +185,8 @@ build_next_kernel(int B, int n, int len, int A, int hub, const int64_t *paths, u
     const int k = (int)(r % (len - 1)), b = (int)(r / (len - 1));
     const int64_t *p = paths + (size_t)b * len * A + a;
     const uint32_t u = (uint32_t)p[(size_t)k * A], v = (uint32_t)p[(size_t)(k + 1) * A];
-    if ((int)u != hub) nbr[((size_t)b * A + a) * n + u] = v << 16;
-    else {
-      const int pos = atomicAdd(dcnt + (size_t)b * A + a, 1);
-      dlist[((size_t)b * A + a) * len + pos] = (uint16_t)v;
-    }
+    if ((int)u != hub) nbr[((size_t)b * n + u) * A + a] = v << 16;
+    else atomicOr(hubmask + ((size_t)b * A + a) * W + (v >> 5), 1u << (v & 31));
   }
 }
 
@@ -186,79 +194,30 @@ __device__ inline float ant_weight(const float *weights, const float *costs, siz
   return weights ? weights[idx] : 1.0f / costs[idx];
 }
 
-// rows other than the hub: at most one outgoing edge per ant (0xFFFF in the table = none)
+// the hub row (depot / dummy node): thread per column, ants in order, the running value stays in a
+// register; the bitmap words and weights do not depend on it, so their loads run ahead of the adds
 __global__ void __launch_bounds__(256)
-deposit_directed_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nbr, const float *costs,
-                        const float *weights, float decay, const int *best, const float *clamp_min,
-                        const float *clamp_max, float floor_val) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];
-  const int bpi = (n + R - 1) / R;
-  const int b = blockIdx.x / bpi;
-  const int i0 = (blockIdx.x - b * bpi) * R;
-  const int Rv = min(R, n - i0);
-  float *g = tau + ((size_t)b * n + i0) * n;
-  const int cnt = Rv * n;
-  const int hub_lo = (hub - i0) * n, hub_hi = hub_lo + n;      // the hub row belongs to the hub kernel
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
-    if (i < hub_lo || i >= hub_hi) rows[i] = g[i] * decay;
-  __syncthreads();
-  const int r = threadIdx.x;
-  if (r < Rv && i0 + r != hub) {
-    const uint32_t *nb = nbr + (size_t)b * A * n + i0 + r;
-    float *row = rows + r * n;
-    int alo = 0, ahi = A;
-    if (best) { alo = best[b]; ahi = alo + 1; }
-#pragma unroll 4
-    for (int a = alo; a < ahi; ++a) {
-      const uint32_t col = nb[(size_t)a * n] >> 16;
-      if (col != 0xFFFFu) row[col] = row[col] + ant_weight(weights, costs, (size_t)b * A + a);
-    }
-  }
-  __syncthreads();
-  const bool clamp = clamp_max != nullptr;
-  const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-    if (i >= hub_lo && i < hub_hi) continue;
-    float x = rows[i];
-    if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
-    if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
-    g[i] = x;
-  }
-}
-
-// the hub row (depot / dummy node): one add per route start, (hub,hub) at most once per ant
-__global__ void __launch_bounds__(64)
-deposit_hub_kernel(int n, int len, int A, int hub, float *tau, const uint16_t *dlist, const int *dcnt, const float *costs,
+deposit_hub_kernel(int n, int A, int W, int hub, float *tau, const uint32_t *hubmask, const float *costs,
                    const float *weights, float decay, const int *best, const float *clamp_min, const float *clamp_max,
                    float floor_val) {
-  extern __shared__ __attribute__((aligned(16))) float row[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x;
   float *g = tau + ((size_t)b * n + hub) * n;
-  for (int i = lane; i < n; i += 64) row[i] = g[i] * decay;
-  __syncthreads();
   int alo = 0, ahi = A;
   if (best) { alo = best[b]; ahi = alo + 1; }
-  for (int a = alo; a < ahi; ++a) {
-    const int c = dcnt[(size_t)b * A + a];
-    const float w = ant_weight(weights, costs, (size_t)b * A + a);
-    const uint16_t *lst = dlist + ((size_t)b * A + a) * len;
-    bool self = false;
-    for (int j0 = 0; j0 < c; j0 += 64) {
-      const int j = j0 + lane;
-      const int v = j < c ? (int)lst[j] : -1;
-      if (v >= 0 && v != hub) row[v] = row[v] + w;      // distinct successors: no conflicts
-      self = self || v == hub;
-    }
-    if (__ballot(self) != 0 && lane == 0) row[hub] = row[hub] + w;   // (hub,hub) collapses to one add
-    __syncthreads();
-  }
   const bool clamp = clamp_max != nullptr;
   const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
-  for (int i = lane; i < n; i += 64) {
-    float x = row[i];
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    float x = g[c] * decay;
+    const uint32_t *mw = hubmask + (size_t)b * A * W + (c >> 5);
+    const uint32_t bit = 1u << (c & 31);
+#pragma unroll 8
+    for (int a = alo; a < ahi; ++a) {
+      const float w = ant_weight(weights, costs, (size_t)b * A + a);
+      if (mw[(size_t)a * W] & bit) x = x + w;
+    }
     if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
     if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
-    g[i] = x;
+    g[c] = x;
   }
 }
 
@@ -284,16 +243,22 @@ extern "C" int daco_tour_costs(void *stream, int B, int n, int len, int A, const
 
 extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A) {
   if (B <= 0 || n <= 0 || A <= 0 || len <= 0) return 0;
-  // nbr table | best-ant index | (directed) depot successor lists + their counters
+  // nbr table | best-ant index | (directed) per-ant bitmap of the nodes that follow the hub
   return align256((size_t)B * A * n * sizeof(uint32_t)) + align256((size_t)B * sizeof(int)) +
-         align256((size_t)B * A * len * sizeof(uint16_t)) + align256((size_t)B * A * sizeof(int));
+         align256((size_t)B * A * ((n + 31) / 32) * sizeof(uint32_t));
 }
 
-static int rows_per_block(int n) {
-  // two workgroups per CU: 160 KiB of LDS less the two static staging images (2 x 16.5 KiB)
-  int R = (63 * 1024) / (4 * n);
-  if (R > DEP_ROWS) R = DEP_ROWS;     // two lanes per row, the chains of a workgroup run in one wave
+// rows per workgroup: two workgroups per CU (80 KiB of LDS each: the rows plus the two staging
+// images), chains of one workgroup inside one wave
+static int rows_per_block(int n, bool symmetric) {
+  int R = (80 * 1024 - 2 * DEP_CHUNK * 4 - 16) / (4 * n + 2 * DEP_CHUNK * 4);
+  const int cap = symmetric ? 32 : 64;
+  if (R > cap) R = cap;
+  if (R < 1) R = 1;
   return R;
+}
+static size_t deposit_lds_bytes(int R, int n) {
+  return (((size_t)R * n + 3) & ~(size_t)3) * sizeof(float) + (size_t)2 * R * DEP_CHUNK * sizeof(uint32_t) + 2 * DEP_CHUNK * sizeof(float);
 }
 
 extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
@@ -317,22 +282,21 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   const uint32_t *nbr = nbr_in ? nbr_in : (const uint32_t *)workspace;
   int *best = (int *)((char *)workspace + align256((size_t)B * A * n * sizeof(uint32_t)));
   if (!symmetric) {
-    uint16_t *dlist = (uint16_t *)((char *)best + align256((size_t)B * sizeof(int)));
-    int *dcnt = (int *)((char *)dlist + align256((size_t)B * A * len * sizeof(uint16_t)));
-    if (hipMemsetAsync(dcnt, 0, (size_t)B * A * sizeof(int), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+    const int W = (n + 31) / 32;
+    uint32_t *hubmask = (uint32_t *)((char *)best + align256((size_t)B * sizeof(int)));
+    if (hipMemsetAsync(hubmask, 0, (size_t)B * A * W * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
     if (hipMemsetAsync(workspace, 0xFF, (size_t)B * A * n * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
     const long total = (long)B * (len - 1) * A;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, hub, paths, (uint32_t *)workspace, dlist, dcnt);
+    hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, hub, W, paths, (uint32_t *)workspace, hubmask);
     if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
-    int R = (64 * 1024) / (4 * n);
-    if (R > 256) R = 256;
+    const int R = rows_per_block(n, false);
     const int bpi = (n + R - 1) / R;
     if (hub >= 0)
-      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(64), (size_t)n * sizeof(float), s, n, len, A, hub, tau, dlist, dcnt,
+      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), 0, s, n, A, W, hub, tau, hubmask,
                          costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
-    hipLaunchKernelGGL(deposit_directed_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, hub, tau,
+    hipLaunchKernelGGL(deposit_rows_kernel<false>, dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, hub, tau,
                        (const uint32_t *)workspace, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max,
                        floor_val);
     hipError_t e2 = hipGetLastError();
@@ -346,9 +310,9 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
     hipLaunchKernelGGL(build_nbr_kernel, dim3(blocks), dim3(256), 0, s, B, n, A, paths, (uint32_t *)workspace);
   }
   if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
-  const int R = rows_per_block(n);
+  const int R = rows_per_block(n, true);
   const int bpi = (n + R - 1) / R;
-  hipLaunchKernelGGL(deposit_tsp_kernel, dim3(B * bpi), dim3(256), (size_t)R * n * sizeof(float), s, n, A, R, tau,
+  hipLaunchKernelGGL(deposit_rows_kernel<true>, dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, 0, tau,
                      nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("pheromone update launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
