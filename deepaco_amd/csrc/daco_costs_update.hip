@@ -197,10 +197,14 @@ __device__ inline float ant_weight(const float *weights, const float *costs, siz
 // the hub row (depot / dummy node): thread per column, ants in order, the running value stays in a
 // register; the bitmap words and weights do not depend on it, so their loads run ahead of the adds
 __global__ void __launch_bounds__(256)
-deposit_hub_kernel(int n, int A, int W, int hub, float *tau, const uint32_t *hubmask, const float *costs,
-                   const float *weights, float decay, const int *best, const float *clamp_min, const float *clamp_max,
-                   float floor_val) {
+deposit_hub_kernel(int n, int A, int W, int hub, float *tau, const uint32_t *hubmask, const int32_t *tab_lens,
+                   const float *costs, const float *weights, float decay, const int *best, const float *clamp_min,
+                   const float *clamp_max, float floor_val) {
   const int b = blockIdx.x;
+  // a table written by the sampler holds each ant's own route only; the reference pads the shorter routes
+  // with the depot up to the longest one of the colony, i.e. one (hub,hub) edge for every shorter ant
+  int longest = 0;
+  if (tab_lens) for (int a = 0; a < A; ++a) longest = max(longest, tab_lens[(size_t)b * A + a]);
   float *g = tau + ((size_t)b * n + hub) * n;
   int alo = 0, ahi = A;
   if (best) { alo = best[b]; ahi = alo + 1; }
@@ -213,7 +217,8 @@ deposit_hub_kernel(int n, int A, int W, int hub, float *tau, const uint32_t *hub
 #pragma unroll 8
     for (int a = alo; a < ahi; ++a) {
       const float w = ant_weight(weights, costs, (size_t)b * A + a);
-      if (mw[(size_t)a * W] & bit) x = x + w;
+      const bool padded = tab_lens && c == hub && tab_lens[(size_t)b * A + a] < longest;
+      if ((mw[(size_t)a * W] & bit) || padded) x = x + w;
     }
     if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
     if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
@@ -239,6 +244,13 @@ extern "C" int daco_tour_costs(void *stream, int B, int n, int len, int A, const
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("tour_costs_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
+}
+
+extern "C" size_t daco_directed_table_bytes(int B, int n, int A) {
+  if (B <= 0 || n <= 0 || A <= 0) return 0;
+  // successor per (node, ant) | per-ant set of depot successors | per-ant route length
+  return align256((size_t)B * n * A * sizeof(uint32_t)) + align256((size_t)B * A * ((n + 31) / 32) * sizeof(uint32_t)) +
+         align256((size_t)B * A * sizeof(int32_t));
 }
 
 extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, int A) {
@@ -275,7 +287,7 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   if (symmetric && len != n) { set_error("daco_pheromone_update: symmetric deposit needs len == n"); return DACO_E_BADARG; }
   if (hub >= n) { set_error("daco_pheromone_update: hub %d >= n %d", hub, n); return DACO_E_BADARG; }
   if (!symmetric && len < 2) { set_error("daco_pheromone_update: directed deposit needs len >= 2"); return DACO_E_BADARG; }
-  if (!symmetric && nbr_in) { set_error("daco_pheromone_update: nbr input is for the symmetric deposit only"); return DACO_E_BADARG; }
+  if (!symmetric && nbr_in && hub != 0) { set_error("daco_pheromone_update: a directed next_table implies hub = 0"); return DACO_E_BADARG; }
   const size_t need = daco_pheromone_update_workspace_bytes(B, n, len, A);
   if (workspace_bytes < need) { set_error("daco_pheromone_update: workspace %zu < %zu", workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
@@ -283,21 +295,27 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   int *best = (int *)((char *)workspace + align256((size_t)B * A * n * sizeof(uint32_t)));
   if (!symmetric) {
     const int W = (n + 31) / 32;
-    uint32_t *hubmask = (uint32_t *)((char *)best + align256((size_t)B * sizeof(int)));
-    if (hipMemsetAsync(hubmask, 0, (size_t)B * A * W * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
-    if (hipMemsetAsync(workspace, 0xFF, (size_t)B * A * n * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
-    const long total = (long)B * (len - 1) * A;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, hub, W, paths, (uint32_t *)workspace, hubmask);
+    const uint32_t *hubmask = (const uint32_t *)((char *)best + align256((size_t)B * sizeof(int)));
+    const int32_t *tab_lens = nullptr;
+    if (nbr_in) {
+      hubmask = (const uint32_t *)((const char *)nbr_in + align256((size_t)B * n * A * sizeof(uint32_t)));
+      tab_lens = (const int32_t *)((const char *)hubmask + align256((size_t)B * A * W * sizeof(uint32_t)));
+    } else {
+      if (hipMemsetAsync((void *)hubmask, 0, (size_t)B * A * W * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+      if (hipMemsetAsync(workspace, 0xFF, (size_t)B * A * n * sizeof(uint32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+      const long total = (long)B * (len - 1) * A;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 16384) blocks = 16384;
+      hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, hub, W, paths, (uint32_t *)workspace, (uint32_t *)hubmask);
+    }
     if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
     const int R = rows_per_block(n, false);
     const int bpi = (n + R - 1) / R;
     if (hub >= 0)
-      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), 0, s, n, A, W, hub, tau, hubmask,
+      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), 0, s, n, A, W, hub, tau, hubmask, tab_lens,
                          costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
     hipLaunchKernelGGL(deposit_rows_kernel<false>, dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, hub, tau,
-                       (const uint32_t *)workspace, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max,
+                       nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max,
                        floor_val);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) { set_error("directed pheromone update launch: %s", hipGetErrorString(e2)); return DACO_E_HIP; }

@@ -28,6 +28,8 @@ struct SampleParams {
   long dist_bs;
   float *costs;          // [B][A] or null
   uint32_t *nbr;         // [B][n][A] prev | next << 16 per (node, ant), for the pheromone update; or null
+  uint32_t *hubmask;     // CVRP: [B][A][ceil(n/32)] set of nodes that follow the depot (with nbr); or null
+  int32_t *tab_lens;     // CVRP: [B][A] copy of lens inside the successor table (with nbr); or null
   // CVRP (cvrp/aco.py:138-205): node 0 = depot, variable-length routes
   // fused sibling constructions (daco_sib_sample.hip)
   const float *aux_vec;  // [B][n]: SOP predecessor counts, PCTSP prizes, OP distance to the depot d[k][0]
@@ -122,7 +124,7 @@ tsp_sample_kernel(const SampleParams p) {
   int64_t *path_out = p.paths + (STEP ? (size_t)b * A : (size_t)b * rows * A) + a;
   float *logp_out = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
-  const float *dist_b = (PROB == PROB_TSP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
+  const float *dist_b = ((PROB == PROB_TSP || CVRP) && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
   uint32_t *nbr_a = (PROB == PROB_TSP && p.nbr) ? p.nbr + (size_t)b * n * A + a : nullptr;   // + node * A
   int pprev = 0, second = 0;                            // neighbour-table bookkeeping
   const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
@@ -438,7 +440,14 @@ tsp_sample_kernel(const SampleParams p) {
     if (lane == 0) path_out[STEP ? 0 : (size_t)t * A] = choice;
     if (dist_b) {                                        // fused gen_path_costs (wave-uniform)
       cost = cost + dpend;
-      dpend = dist_b[(unsigned)choice * (unsigned)n + (unsigned)prev];   // d[u_t][u_{t-1}], scalar load
+      // TSP: d[u_t][u_{t-1}] (tsp/aco.py:127); CVRP: d[u_{t-1}][u_t] (cvrp/aco.py:135); scalar load
+      dpend = CVRP ? dist_b[(unsigned)prev * (unsigned)n + (unsigned)choice] : dist_b[(unsigned)choice * (unsigned)n + (unsigned)prev];
+    }
+    if constexpr (CVRP) {
+      if (p.nbr && lane == 0) {                          // who follows `prev` (depot: a set, one bit per successor)
+        if (prev != 0) p.nbr[((size_t)b * n + prev) * A + a] = (uint32_t)choice << 16;
+        else p.hubmask[((size_t)b * A + a) * ((n + 31) >> 5) + (choice >> 5)] |= 1u << (choice & 31);
+      }
     }
     if (nbr_a) {                                         // node `prev` now knows both neighbours
       if (lane == 0) nbr_a[(size_t)prev * A] = (uint32_t)pprev | ((uint32_t)choice << 16);
@@ -453,6 +462,7 @@ tsp_sample_kernel(const SampleParams p) {
     if (!finished) overflow = true;
     if (lane == 0) {
       if (p.lens) p.lens[(size_t)b * A + a] = t;
+      if constexpr (CVRP) { if (p.tab_lens) p.tab_lens[(size_t)b * A + a] = t; }
       const float lp1 = clamp_log(1.0f);
       const int64_t rest = DUMMY ? n - 1 : 0;
       for (int tt = t; tt < p.Lmax; ++tt) {
@@ -464,7 +474,7 @@ tsp_sample_kernel(const SampleParams p) {
   }
   if (dist_b) {
     cost = cost + dpend;
-    cost = cost + dist_b[(unsigned)first * (unsigned)n + (unsigned)prev];   // closing edge d[u_0][u_{n-1}] last
+    if constexpr (!CVRP) cost = cost + dist_b[(unsigned)first * (unsigned)n + (unsigned)prev];   // closing edge d[u_0][u_{n-1}] last
     if (lane == 0) p.costs[(size_t)b * A + a] = cost;
   }
   if (nbr_a && lane == 0) {                             // close the cycle: last -> first -> second

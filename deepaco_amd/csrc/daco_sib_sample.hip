@@ -79,7 +79,7 @@ extern "C" int daco_sibling_sample(void *stream, int kind, int B, int n, int A, 
   sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = start; sp.fixed_start = 0;
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
-  sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
+  sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr; sp.hubmask = nullptr; sp.tab_lens = nullptr;
   sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = aux_vec; sp.aux_mat = auxp; sp.scalar0 = scalar0; sp.wts = item_weights; sp.m = m;

@@ -63,7 +63,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   }
   if (n > DACO_MAX_NODES) { set_error("daco_tsp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
   if (mode < 0 || mode > 3 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
-  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);
+  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);   // 32-bit offsets
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
@@ -88,7 +88,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   sp.P = P; sp.R = R; sp.norm_passes = norm_passes; sp.start = start; sp.fixed_start = fixed_start;
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
-  sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
+  sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr; sp.hubmask = nullptr; sp.tab_lens = nullptr;
   sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 0; sp.lens = nullptr;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
@@ -106,19 +106,34 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
                                 const float *demand, float capacity, int mode, const float *noise,
                                 int noise_steps, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int Lmax,
                                 int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
+                                const float *dist, long dist_bstride, float *costs, void *next_table,
                                 void *workspace, size_t workspace_bytes) {
   if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !demand || !paths || !workspace || Lmax < 2) {
     set_error("daco_cvrp_sample: bad argument (B=%d n=%d A=%d Lmax=%d)", B, n, A, Lmax);
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
-  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024;
+  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
+  if (costs && !dist) { set_error("daco_cvrp_sample: fused costs need the distance matrix"); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
   if (workspace_bytes < need) { set_error("daco_cvrp_sample: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
+  uint32_t *hubmask = nullptr;
+  int32_t *tab_lens = nullptr;
+  if (next_table) {
+    // "no successor" everywhere, empty depot sets; the kernel fills in what each ant really does
+    const size_t tab = ((size_t)B * n * A * sizeof(uint32_t) + 255) & ~(size_t)255;
+    hubmask = (uint32_t *)((char *)next_table + tab);
+    tab_lens = (int32_t *)((char *)hubmask + (((size_t)B * A * ((n + 31) / 32) * sizeof(uint32_t) + 255) & ~(size_t)255));
+    if (hipMemsetAsync(next_table, 0xFF, (size_t)B * n * A * sizeof(uint32_t), s) != hipSuccess ||
+        hipMemsetAsync(hubmask, 0, (size_t)B * A * ((n + 31) / 32) * sizeof(uint32_t), s) != hipSuccess) {
+      set_error("daco_cvrp_sample: hipMemsetAsync failed");
+      return DACO_E_HIP;
+    }
+  }
   const int vec = vec_for_n(n), CH = inst_chunks(n), ld = ld_alloc(n);
   float *P = (float *)workspace;
   float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
@@ -134,7 +149,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = nullptr; sp.fixed_start = 0;
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.ant_gid0 = ant_gid0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
-  sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
+  sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = (uint32_t *)next_table; sp.hubmask = hubmask; sp.tab_lens = tab_lens;
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;

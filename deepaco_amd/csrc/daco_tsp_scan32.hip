@@ -223,13 +223,14 @@ static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
 // (:179).  Lanes multiply the row by the combined 0/1 factor, the chosen lane deals those masked
 // values.  The two ants of a wave finish at different steps: a finished half keeps stepping with
 // its stores and state updates switched off until its neighbour is done.
-template <int CH2, bool LOGP>
+template <int CH2, bool LOGP, bool FUSED>
 __global__ void __launch_bounds__(256)
 cvrp_scan32_kernel(const SampleParams p) {
   constexpr int NJ = CH2 * 4, ROWF = CH2 * 128;
   __shared__ __attribute__((aligned(16))) float open_flags[8][ROWF];
   __shared__ __attribute__((aligned(16))) float pick[8][40];
   __shared__ __attribute__((aligned(16))) float dem_s[ROWF];          // demand of this instance, +inf padding
+  __shared__ uint32_t hub_s[8][CH2 * 4];                               // per ant: set of nodes that follow the depot
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int up = lane >> 5, s = lane & 31;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -249,6 +250,12 @@ cvrp_scan32_kernel(const SampleParams p) {
   float *logp_a = LOGP ? p.logp + (size_t)b * (Lmax - 1) * A + a : nullptr;
   float *rs_a = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (Lmax - 1) * A + a : nullptr;
   float *fl = open_flags[wave * 2 + up], *pk = pick[wave * 2 + up];
+  const char *dist_b = (FUSED || p.costs) ? (const char *)(p.dist + (size_t)b * p.dist_bs) : nullptr;
+  char *next_b = (FUSED || p.nbr) ? (char *)(p.nbr + (size_t)b * n * A) : nullptr;           // [n][A] table of this instance
+  const uint32_t A4 = (uint32_t)A * 4u, a4 = (uint32_t)a * 4u;
+  uint32_t *hub_l = hub_s[wave * 2 + up];
+  if (s < CH2 * 4) hub_l[s] = 0u;
+  float cost = 0.0f, dpend = 0.0f;
   float4 dm[CH2];
 #pragma unroll
   for (int c = 0; c < CH2; ++c) {
@@ -333,33 +340,54 @@ cvrp_scan32_kernel(const SampleParams p) {
     const int choice = __float_as_int(pk[34]);
     __builtin_amdgcn_wave_barrier();
 
-    if (!finished) {
-      if (s == 0) {
-        path_a[(size_t)t * A] = choice;
-        if constexpr (LOGP) {
-          const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);
-          logp_a[(size_t)(t - 1) * A] = clamp_log(pc / S);
-          if (rs_a) rs_a[(size_t)(t - 1) * A] = S;
-        }
+    // ---- outputs: lane 0 of every half that is still building (one EXEC mask, no nesting)
+    const bool writer = __builtin_amdgcn_inverse_ballot_w64(act & 0x0000000100000001ull);
+    if (writer) {
+      path_a[(size_t)t * A] = choice;
+      if constexpr (LOGP) {
+        const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);
+        logp_a[(size_t)(t - 1) * A] = clamp_log(pc / S);
+        if (rs_a) rs_a[(size_t)(t - 1) * A] = S;
       }
-      if (choice != 0) --remaining; else used = 0.0f;
-      used = used + dem_s[choice];
-      finished = remaining == 0 && choice == 0;
-      len = t + 1;
-      prev = finished ? 0 : choice;
+      if (FUSED || dist_b) {                             // fused route length, edge added one step late
+        cost = cost + dpend;
+        dpend = *(const float *)(dist_b + ((__umul24((uint32_t)prev, (uint32_t)n) + (uint32_t)choice) << 2));
+      }
+      if (FUSED || next_b) {
+        // who follows `prev`.  Row 0 of the table is never read (the depot's successors are a set,
+        // kept as a bitmap), so the store needs no branch on prev
+        *(uint32_t *)(next_b + __umul24((uint32_t)prev, A4) + a4) = (uint32_t)choice << 16;
+        __hip_atomic_fetch_or(hub_l + (choice >> 5), prev == 0 ? 1u << (choice & 31) : 0u, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
+    // ---- state of each half, as selects (a finished half keeps its values)
+    const bool live = !finished;
+    const bool moved = live && choice != 0;
+    remaining -= moved ? 1 : 0;
+    const float load = moved ? used : 0.0f;              // back at the depot the load restarts from 0
+    used = live ? load + dem_s[choice] : used;
+    finished = finished || (remaining == 0 && choice == 0);
+    len = live ? t + 1 : len;
+    prev = finished ? 0 : choice;
     act = __builtin_amdgcn_ballot_w64(!finished);
   }
   // the reference steps every ant until the slowest one is done: a done ant keeps drawing the
   // depot (probability 1), so its column is padded with 0 / log(1-eps)
   if (s == 0) {
     if (p.lens) p.lens[(size_t)b * A + a] = len;
+    if (p.tab_lens) p.tab_lens[(size_t)b * A + a] = len;
     const float lp1 = clamp_log(1.0f);
     for (int tt = len; tt < Lmax; ++tt) {
       path_a[(size_t)tt * A] = 0;
       if constexpr (LOGP) logp_a[(size_t)(tt - 1) * A] = lp1;
     }
     if (!finished && p.flags) atomicOr(p.flags + b, 2);
+    if (dist_b) p.costs[(size_t)b * A + a] = cost + dpend;
+    if (next_b) {
+      uint32_t *hub_a = p.hubmask + ((size_t)b * A + a) * ((n + 31) >> 5);
+      for (int i = 0; i < ((n + 31) >> 5); ++i) hub_a[i] = hub_l[i];
+    }
   }
   if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
 }
@@ -368,8 +396,11 @@ template <int CH2>
 static hipError_t launch_cvrp32(const SampleParams &sp, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 7) / 8;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
-  if (logp) hipLaunchKernelGGL((cvrp_scan32_kernel<CH2, true>), grid, block, 0, s, sp);
-  else hipLaunchKernelGGL((cvrp_scan32_kernel<CH2, false>), grid, block, 0, s, sp);
+  const bool fused = sp.costs && sp.nbr;
+#define DACO_C32(L, F) hipLaunchKernelGGL((cvrp_scan32_kernel<CH2, L, F>), grid, block, 0, s, sp)
+  if (logp) { if (fused) DACO_C32(true, true); else DACO_C32(true, false); }
+  else { if (fused) DACO_C32(false, true); else DACO_C32(false, false); }
+#undef DACO_C32
   return hipGetLastError();
 }
 

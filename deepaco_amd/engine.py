@@ -106,10 +106,12 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
 
 
 def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
-                it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None):
+                it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False):
     """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
-    or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, lens [B,A], flags [B]); the
-    reference's result is paths[:, :lens.max()].  Returns (paths, log_probs|None, rowsum|None, lens, flags)."""
+    or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, rowsum|None, lens [B,A], flags [B]);
+    the reference's result is paths[:, :lens.max()].
+    dist: if given, route costs are fused into the kernel; want_table: also return the successor table
+    the directed pheromone update consumes.  With either, (..., costs|None, table|None) is appended."""
     _require_gpu(tau, eta, demand, noise)
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
@@ -133,6 +135,14 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
             noise = _f32c(noise)
             steps = noise.shape[-3]
             noise = noise.view(B, steps, n_ants, n)
+        costs = table = None
+        dbs = 0
+        if dist is not None:
+            _require_gpu(dist)
+            dist, dbs = _bstride(dist, n)
+            costs = torch.empty((B, n_ants), dtype=torch.float32, device=dev)
+        if want_table:
+            table = torch.empty((L.daco_directed_table_bytes(B, n, n_ants),), dtype=torch.uint8, device=dev)
         nbytes = L.daco_tsp_sample_workspace_bytes(B, n, m)
         ws = _workspace(dev, nbytes, "sample")
         rc = L.daco_cvrp_sample(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
@@ -141,8 +151,12 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
                                 int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF, Lmax,
                                 paths.data_ptr(), logp.data_ptr() if require_prob else None,
                                 rowsum.data_ptr() if require_prob else None, lens.data_ptr(),
-                                flags.data_ptr(), ws.data_ptr(), ws.numel())
+                                flags.data_ptr(), dist.data_ptr() if dist is not None else None, dbs,
+                                costs.data_ptr() if costs is not None else None,
+                                table.data_ptr() if table is not None else None, ws.data_ptr(), ws.numel())
     _lib.check(rc, "daco_cvrp_sample")
+    if dist is not None or want_table:
+        return paths, logp, rowsum, lens, flags, costs, table
     return paths, logp, rowsum, lens, flags
 
 
@@ -490,7 +504,7 @@ class BatchedTSP:
 
 class BatchedCVRP:
     """B independent CVRP colonies in lock-step (cvrp/aco.py ACO.run semantics per instance, AS /
-    elitist / MMAS); one host sync per iteration for the common route-table length L."""
+    elitist / MMAS); an iteration is sampler (+ fused costs and successor table) -> deposit, no host sync."""
 
     def __init__(self, distances, demand, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
                  pheromone=None, heuristic=None, min=None, capacity=50, sampler="scan", seed=None, ant_gid0=0):
@@ -512,14 +526,16 @@ class BatchedCVRP:
         self.seed = torch.initial_seed() if seed is None else seed
 
     @torch.no_grad()
-    def step(self, Lmax=None):
-        paths, _, _, lens, flags = cvrp_sample(self.pheromone, self.heuristic, self.demand, self.capacity, self.n_ants,
-                                               self.alpha, self.beta, mode=self.sampler, seed=self.seed,
-                                               it=self.iteration, ant_gid0=self.ant_gid0, Lmax=Lmax, batch=self.B)
+    def step(self, Lmax=None, trim=False):
+        """One colony iteration without a host round trip: the sampler also produces the route costs and the
+        successor table the directed deposit consumes.  Returns (paths [B, Lmax, A], costs [B, A]); rows past
+        an ant's route are 0 (self.last_lens holds the used rows; trim=True cuts to their maximum, which syncs)."""
+        paths, _, _, lens, flags, costs, table = cvrp_sample(
+            self.pheromone, self.heuristic, self.demand, self.capacity, self.n_ants, self.alpha, self.beta,
+            mode=self.sampler, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0, Lmax=Lmax, batch=self.B,
+            dist=self.distances, want_table=True)
         self.iteration += 1
-        L = int(lens.max())
-        paths = paths[:, :L].contiguous()
-        costs = tour_costs(self.distances, paths, closed=False)
+        self.last_lens, self.last_flags = lens, flags
         self.lowest_cost = torch.minimum(self.lowest_cost, costs.min(dim=1).values)
         cmin = cmax = None
         if self.min_max:
@@ -528,8 +544,19 @@ class BatchedCVRP:
                 self.pheromone *= (new_max / self.pheromone.amax(dim=(1, 2))).view(self.B, 1, 1)
             self.max = new_max
             cmin, cmax = torch.full_like(new_max, self.min), new_max.contiguous()
-        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, False, cmin, cmax, floor=1e-10)
+        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, False, cmin, cmax, floor=1e-10,
+                          nbr=table)
+        if trim:
+            paths = paths[:, :int(lens.max())].contiguous()
         return paths, costs
+
+    def check_feasible(self):
+        """Raise like the reference's Categorical if any draw of the last step had no feasible candidate (syncs)."""
+        fl = int(self.last_flags.max())
+        if fl & 1:
+            raise ValueError("BatchedCVRP: a transition row had no feasible candidate")
+        if fl & 2:
+            raise RuntimeError("BatchedCVRP: route buffer too short")
 
     @torch.no_grad()
     def run(self, n_iterations):

@@ -41,12 +41,12 @@ extern "C" {
 #define DACO_RACE_NOISE 0  /* exponential race, noise read from memory (bit-exact parity mode) */
 #define DACO_RACE_PHILOX 1 /* exponential race, Philox4x32-10 noise generated in-kernel */
 #define DACO_SCAN 2        /* roulette / inverse-CDF by wavefront prefix scan, one uniform per step.
-                            * daco_tsp_sample packs two ants per wavefront for 64 < n <= 1024 (the
-                            * 32-lane variant of the scan); everything else uses
-                            * one ant per wavefront. */
+                            * daco_tsp_sample and daco_cvrp_sample pack two ants per wavefront for
+                            * 64 < n <= 1024 (the 32-lane variant of the scan);
+                            * everything else uses one ant per wavefront. */
 #define DACO_SCAN_WAVE 3   /* DACO_SCAN with the one-ant-per-wavefront layout for every n: the draw
-                            * daco_pick_move / daco_cvrp_sample / daco_sibling_sample make (there it
-                            * is a synonym of DACO_SCAN) */
+                            * daco_pick_move / daco_sibling_sample make (there it is a synonym of
+                            * DACO_SCAN) */
 
 /* limits */
 #define DACO_MAX_NODES 4096
@@ -123,14 +123,24 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *   lens     out [B][A] int32 or NULL: rows used by each ant; the reference's L = max(lens)
  *   flags    out [B] int32 or NULL: bit 0 = a draw had no feasible candidate, bit 1 = Lmax or
  *            the noise tensor was too short; caller zeroes it.
+ *   dist, costs   optional fusion of gen_path_costs (cvrp/aco.py:133-136): if costs != NULL,
+ *            costs [B][A] receives sum_k dist[u_k][u_k+1] over the ant's own route (k ascending).
+ *            The reference also adds the (0,0) padding edges of the shorter routes, dist[0][0] =
+ *            1e-10 each (cvrp/utils.py): no-ops in f32 for any route longer than 2e-3.
+ *   next_table  optional out, daco_directed_table_bytes(B, n, A) bytes: per (node, ant) the node that
+ *            follows it plus, per ant, the set of nodes that follow the depot -- the form
+ *            daco_pheromone_update(symmetric = 0, nbr = next_table, hub = 0) consumes.
  *   workspace daco_tsp_sample_workspace_bytes(B, n, mode)
  */
+size_t daco_directed_table_bytes(int B, int n, int A);
 int daco_cvrp_sample(void *stream, int B, int n, int A,
                      const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                      float alpha, float beta, const float *demand, float capacity, int mode,
                      const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
                      uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
-                     int32_t *lens, int32_t *flags, void *workspace, size_t workspace_bytes);
+                     int32_t *lens, int32_t *flags,
+                     const float *dist, long dist_bstride, float *costs, void *next_table,
+                     void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_prob_matrix + daco_pick_move -- ACO.pick_move as a step-wise service
@@ -225,8 +235,9 @@ int daco_tour_costs(void *stream, int B, int n, int len, int A, const float *dis
  *   tau   in/out [B][n][n] f32 (dense, stride n*n)
  *   paths [B][len][A] int64, costs [B][A] f32
  *   clamp_min/clamp_max: [B] f32 device arrays or NULL (per-instance MMAS bounds)
- *   nbr   optional [B][n][A] uint32 as written by daco_tsp_sample (symmetric only); if NULL it
- *         is rebuilt from `paths` in the workspace
+ *   nbr   optional: symmetric: [B][n][A] uint32 as written by daco_tsp_sample; directed: the
+ *         next_table written by daco_cvrp_sample (hub must be 0); if NULL it is rebuilt from
+ *         `paths` in the workspace
  *   weights optional [B][A] f32: the amount each ant deposits, for the siblings whose rule is
  *         not 1/cost (op/aco.py:134-139 Q*obj, bpp/aco.py:113-118 fit/n_ants, smtwtp/aco.py:90-95
  *         1/(cost+1)); NULL = 1/cost.  `costs` still selects the elitist ant (first minimum).

@@ -122,6 +122,35 @@ def test_cvrp_full_size_properties(mode):
     assert np.array_equal(paths[b, :Lb, :64].cpu().numpy(), rp)
 
 
+@pytest.mark.parametrize("n,A,mode,elitist", [(100, 33, "scan", False), (100, 16, "scan", True), (40, 9, "scan", False),
+                                              (100, 12, "race", False), (300, 7, "scan_wave", False)])
+def test_cvrp_fused_costs_and_table_equal_separate_passes(n, A, mode, elitist):
+    """The sampler's fused route costs and successor table give the same costs and the same pheromone as
+    daco_tour_costs + the table rebuilt from the paths (both kernel layouts, any ant count)."""
+    from deepaco_amd import engine
+    B = 3
+    d, demand, tau, eta = cvrp_instance(n, 9 * n + A, B)
+    D, DM, TA, ET = d.to(dev()), demand.to(dev()), tau.to(dev()), eta.to(dev())
+    paths, _, _, lens, flags, costs, table = engine.cvrp_sample(TA, ET, DM, 50.0, A, mode=mode, seed=5, it=3, dist=D,
+                                                                want_table=True)
+    assert int(flags.sum()) == 0
+    p2, _, _, lens2, _ = engine.cvrp_sample(TA, ET, DM, 50.0, A, mode=mode, seed=5, it=3)
+    assert torch.equal(paths, p2) and torch.equal(lens, lens2)
+    pt = paths[:, :int(lens.max())].contiguous()
+    assert torch.equal(costs, engine.tour_costs(D, pt, closed=False))
+    t1 = TA.clone().contiguous()
+    engine.pheromone_update_(t1, paths, costs, 0.9, elitist, False, floor=1e-10, nbr=table)
+    for b in range(B):       # the reference pads each colony's routes to that colony's longest one
+        t2 = TA[b:b + 1].clone().contiguous()
+        pb = paths[b:b + 1, :int(lens[b].max())].contiguous()
+        engine.pheromone_update_(t2, pb, costs[b:b + 1], 0.9, elitist, False, floor=1e-10)
+        assert torch.equal(t1[b], t2[0]), b
+    col = engine.BatchedCVRP(D, DM, n_ants=A, capacity=50, seed=11, sampler=mode, elitist=elitist)
+    col.run(3)
+    col.check_feasible()
+    assert bool((col.lowest_cost > 0).all())
+
+
 def test_cvrp_class_run():
     from deepaco_amd.cvrp.aco import ACO
     d, demand, _, _ = cvrp_instance(50, 9)
