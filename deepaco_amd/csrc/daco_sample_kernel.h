@@ -527,5 +527,8 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // daco_tsp_scan32.hip: TSP scan draw with two ants per wavefront (64 < n <= 1024)
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
 hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
+// daco_scan16.hip: four ants per wavefront (n <= 128)
+hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s);
+hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s);
 
 }  // namespace daco

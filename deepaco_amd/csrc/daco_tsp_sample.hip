@@ -63,7 +63,8 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   }
   if (n > DACO_MAX_NODES) { set_error("daco_tsp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
   if (mode < 0 || mode > 3 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
-  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);   // 32-bit offsets
+  const bool packed = mode == DACO_SCAN && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);   // several ants per wave, 32-bit offsets
+  const bool four_per_wave = packed && n <= 128, two_per_wave = packed && n > 128;
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
@@ -95,7 +96,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   const bool lp = logp != nullptr;
   hipError_t e;
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
-  e = two_per_wave ? launch_tsp_scan32(sp, lp, s) : dispatch_sample<PROB_TSP>(sp, vec, CH, mode, lp, s);
+  e = four_per_wave ? launch_tsp_scan16(sp, lp, s) : two_per_wave ? launch_tsp_scan32(sp, lp, s) : dispatch_sample<PROB_TSP>(sp, vec, CH, mode, lp, s);
   if (e != hipSuccess) { set_error("tsp_sample_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
   return DACO_OK;
@@ -113,7 +114,8 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
-  const bool two_per_wave = mode == DACO_SCAN && n > 64 && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);
+  const bool packed = mode == DACO_SCAN && n <= 1024 && (size_t)n * A * 8 < ((size_t)1 << 32);
+  const bool four_per_wave = packed && n <= 128, two_per_wave = packed && n > 128;
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
@@ -153,7 +155,9 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
-  hipError_t e = two_per_wave ? launch_cvrp_scan32(sp, logp != nullptr, s) : dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
+  hipError_t e = four_per_wave ? launch_cvrp_scan16(sp, logp != nullptr, s)
+               : two_per_wave ? launch_cvrp_scan32(sp, logp != nullptr, s)
+                              : dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
   if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }

@@ -190,14 +190,15 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
 }
 
 /* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274.
- * `lanes` = 64 (one ant per wavefront) or 32 (two ants per wavefront, TSP with 64 < n <= 1024; vec = 4):
+ * `lanes` = 64 (one ant per wavefront), 32 (two ants per wavefront, 128 < n <= 1024) or 16 (four ants
+ * per wavefront, n <= 128); vec = 4 below 64 lanes:
  *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
  *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
  *              (lanes = 32: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
  *               end; the scan is Kogge-Stone in rows of 16, then lanes 16..31 add lane 15)
  *   S = incl[lanes-1];  r = max(u * S, denorm_min)
- *     lanes = 64: u = component ((t>>6)&3) of Philox(ctr=(((t>>8)<<6) + (t&63), gid, iter, STREAM_SCAN))
- *     lanes = 32: u = component ((t>>5)&3) of Philox(ctr=(((t>>7)<<5) + (t&31), gid, iter, STREAM_SCAN))
+ *     u = component ((t>>lg)&3) of Philox(ctr=(((t>>(lg+2))<<lg) + (t&(lanes-1)), gid, iter, STREAM_SCAN)),
+ *     lg = log2(lanes)
  *   L = first lane with incl[L] >= r and part[L] > 0
  *   inside lane L: thr = r - incl[L-1] (incl[-1] = 0);
  *     lanes = 64: walk its candidates in (c,v) order with the lane's own running sum (from +0.0f,
@@ -205,17 +206,18 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  *       candidate with p > 0 of the lane;
  *     lanes = 32: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
  *       first j with scan[j] >= thr and p_j > 0, else the last j with p_j > 0. */
-int orc_scan_lanes(int n, int mode) { return (mode == 2 && n > 64 && n <= 1024) ? 32 : 64; }
+int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 128 ? 16 : (n <= 1024 ? 32 : 64)); }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
                      uint64_t iter, uint32_t gid, int t, float *pr, int lanes) {
-  int vec = lanes == 32 ? 4 : orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
+  int vec = lanes < 64 ? 4 : orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
+  int lg = lanes == 64 ? 6 : (lanes == 32 ? 5 : 4);
   float part[64], incl[64];
   uint32_t r4[4];
   for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
   for (int l = 0; l < lanes; ++l) {
     float s = 0.0f;
-    if (lanes == 32) {
+    if (lanes < 64) {
       /* packed accumulation: slots v = 0,2 and v = 1,3 are summed separately (c ascending), then added */
       float ev = 0.0f, od = 0.0f;
       for (int c = 0; c < ch; ++c)
@@ -234,19 +236,18 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
     }
     part[l] = s; incl[l] = s;
   }
-  lane_scan(incl);                /* lanes = 32: lanes 0..31 of the 64-lane scan are exactly the half-wave scan */
+  lane_scan(incl);                /* lanes 0..31 (0..15) of the 64-lane scan are exactly the half-wave (row) scan */
   float S = incl[lanes - 1];
   uint32_t ut = (uint32_t)t;
-  if (lanes == 64) rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> 8) << 6) + (ut & 63u), r4);
-  else rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> 7) << 5) + (ut & 31u), r4);
-  float r = u01(r4[lanes == 64 ? (t >> 6) & 3 : (t >> 5) & 3]) * S;
+  rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> (lg + 2)) << lg) + (ut & (uint32_t)(lanes - 1)), r4);
+  float r = u01(r4[(ut >> lg) & 3u]) * S;
   if (!(r > 0.0f)) r = 1.401298464e-45f;               /* keep r > 0 if u*S underflows */
   int L = -1;
   for (int l = 0; l < lanes; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
   if (L < 0) return -1;
   float thr = r - (L ? incl[L - 1] : 0.0f);
-  if (lanes == 32) {
-    /* level 2 of the two-ants-per-wave kernel: lane L's ch*vec candidate slots (closed ones
+  if (lanes < 64) {
+    /* level 2 of the several-ants-per-wave kernels: lane L's ch*vec candidate slots (closed ones
      * +0.0f) are dealt to the 32 lanes and the same scan + first-lane pick runs across them */
     float cv[64], sc[64];
     int key[64], nj = ch * vec;
@@ -258,7 +259,7 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
     }
     lane_scan(sc);
     int best = -1, last = -1;
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < lanes; ++j) {
       if (!(cv[j] > 0.0f)) continue;
       last = key[j];
       if (sc[j] >= thr) { best = key[j]; break; }
