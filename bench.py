@@ -181,9 +181,10 @@ def main():
     per_launch = (B * (colony.hi - colony.lo) if ant_sharded else B * A) * bpt
     achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms else None      # GB/s, dominant kernel, this rank
     gpu_best = colony.lowest_cost.detach().cpu()
-    two_per_wave = args.sampler == "scan" and 64 < n <= 1024       # daco_tsp_sample's layout rule
-    kernel_name = "tsp_scan32_kernel" if two_per_wave else "tsp_sample_kernel"
-    row_floats = (n + 127) // 128 * 128 if two_per_wave else ((n + 255) // 256 * 256 if n > 128 else n)
+    # daco_tsp_sample's layout rule: 4 / 2 / 1 ants per wavefront
+    lanes = 64 if args.sampler != "scan" or n > 1024 else (16 if n <= 128 else 32)
+    kernel_name = {16: "scan16_kernel", 32: "tsp_scan32_kernel", 64: "tsp_sample_kernel"}[lanes]
+    row_floats = (n + 4 * lanes - 1) // (4 * lanes) * (4 * lanes) if lanes < 64 else ((n + 255) // 256 * 256 if n > 128 else n)
 
     if rank == 0:
         traffic = None

@@ -108,7 +108,7 @@ def test_aco_class_run_trace(name):
 SHAPES = [(2, 1, 1), (3, 2, 1), (5, 4, 1), (20, 7, 2), (63, 5, 1), (64, 9, 1), (65, 5, 2), (100, 33, 1),
           (128, 6, 1), (129, 6, 1), (200, 17, 2), (256, 4, 1), (257, 4, 1), (500, 12, 1), (777, 5, 1),
           (1000, 6, 1), (1025, 3, 1),
-          # two ants per wavefront (64 < n <= 1024): every chunk count 1..8, odd ant counts
+          # four / two ants per wavefront (n <= 128 / <= 1024): every chunk count, odd ant counts
           (130, 3, 1), (384, 7, 1), (385, 5, 2), (512, 9, 1), (640, 3, 1), (700, 4, 1), (896, 3, 1), (1024, 5, 1)]
 
 
@@ -145,7 +145,7 @@ def test_fixed_start_and_no_logp(mode):
 
 @pytest.mark.parametrize("B,A", [(1, 1), (2, 7), (3, 16), (2, 33)])
 def test_two_ants_per_wave_fused_outputs(B, A):
-    """64 < n <= 1024 in scan mode: fused costs and neighbour table of the two-ants-per-wave kernel, any ant
+    """n <= 1024 in scan mode: fused costs and neighbour table of the several-ants-per-wave kernels, any ant
     count; 'scan_wave' keeps the one-ant-per-wave draw (a different but equally valid stream)."""
     from deepaco_amd import engine
     n = 300 if A != 7 else 90
