@@ -116,6 +116,34 @@ def test_two_opt_bit_exact(name):
     assert np.array_equal(cap, g["after_cap5"])
 
 
+@pytest.mark.parametrize("n,wave", [(12, False), (150, False), (150, True)])
+def test_scan_draw_layouts_are_the_same_categorical(n, wave):
+    """The three lane layouts of the scan draw (16 / 32 / 64 lanes per ant: n <= 128, <= 1024, one ant per wave)
+    consume different uniforms but draw from the same distribution: first move ~ P[start][k]."""
+    rng = np.random.default_rng(n)
+    P = (rng.random((n, n)) ** 3 + 1e-4).astype(np.float32)
+    A = 6000
+    paths, _, rc = oracle.tsp_sample_scan(P, A, seed=17, it=3, fixed_start=0, wave=wave)
+    assert rc == 0
+    assert np.array_equal(np.sort(paths, axis=0), np.tile(np.arange(n)[:, None], (1, A)))
+    p = P[0].astype(np.float64).copy()
+    p[0] = 0
+    p /= p.sum()
+    order = np.argsort(-p)                      # pool the tail so every bin expects >= 8 draws
+    bins, cur = [], []
+    for k in order:
+        cur.append(k)
+        if p[cur].sum() * A >= 8:
+            bins.append(cur)
+            cur = []
+    if cur:
+        bins[-1] += cur
+    obs = np.bincount(paths[1], minlength=n).astype(np.float64)
+    chi2 = sum((obs[b].sum() - A * p[b].sum()) ** 2 / (A * p[b].sum()) for b in bins)
+    dof = len(bins) - 1
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
 def test_roulette_literal():
     g = load_golden("g6_roulette_n30")
     for u, route in zip(g["uniforms"], g["routes"]):
