@@ -176,6 +176,30 @@ class Net(nn.Module):
         return flat
 
     @torch.no_grad()
+    def forward_batch(self, x, edge_index, edge_attr):
+        """Eval-mode forward for B graphs of equal size in ONE pass of the HIP kernels: the graphs are laid side
+        by side as one block-diagonal graph (eval-mode BatchNorm is a per-feature affine map, so instances do not
+        interact).  x [B,n,feats], edge_index [B,2,E] (node ids local to each graph, e.g. engine.tsp_knn_graph),
+        edge_attr [B,E,1] or [B,E] -> heu [B,E], row b equal to forward() on graph b alone."""
+        if self.training:
+            raise _lib.DacoError("Net.forward_batch is an inference path (BatchNorm running statistics): call .eval()")
+        B, n, feats = x.shape
+        E = edge_index.shape[2]
+        off = (torch.arange(B, device=x.device, dtype=edge_index.dtype) * n).view(B, 1, 1)
+        merged = GraphData(x=x.reshape(B * n, feats), edge_index=(edge_index + off).permute(1, 0, 2).reshape(2, B * E),
+                           edge_attr=edge_attr.reshape(B * E, 1))
+        return self.forward_hip(merged).view(B, E)
+
+    @staticmethod
+    def reshape_batch(n_nodes, edge_index, heu):
+        """Batched Net.reshape (tsp/net.py:94-102): heu [B,E] -> [B,n,n] with zeros off the graph."""
+        B, E = heu.shape
+        out = torch.zeros((B, n_nodes, n_nodes), dtype=heu.dtype, device=heu.device)
+        bidx = torch.arange(B, device=heu.device).view(B, 1).expand(B, E)
+        out[bidx, edge_index[:, 0], edge_index[:, 1]] = heu
+        return out
+
+    @torch.no_grad()
     def forward_hip(self, pyg, return_embedding=False):
         x = pyg.x.float().contiguous()
         n, feats = x.shape

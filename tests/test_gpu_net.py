@@ -135,3 +135,28 @@ def test_batched_graph_construction_matches_reference(name):
         ref, rd = gen_pyg_data(batch[b], k)
         assert torch.equal(out[b][0].edge_index, ref.edge_index)
         torch.testing.assert_close(out[b][0].edge_attr, ref.edge_attr, rtol=1e-6, atol=0)
+
+
+def test_batched_forward_equals_per_graph():
+    """B graphs side by side in one pass == B separate forwards (eval mode), and the batched reshape."""
+    from deepaco_amd import engine
+    from deepaco_amd.net import GraphData
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    net = Net().to(dev).eval()
+    for m in net.modules():                     # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    B, n, k = 5, 60, 12
+    coords = torch.rand(B, n, 2, device=dev)
+    _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
+    heu = net.forward_batch(coords, ei, ea)
+    assert heu.shape == (B, n * k)
+    for b in range(B):
+        one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
+        torch.testing.assert_close(heu[b], one.view(-1), rtol=1e-6, atol=2e-7)     # (tile position moves the last bit)
+    mats = Net.reshape_batch(n, ei, heu)
+    one = Net.reshape(GraphData(x=coords[2], edge_index=ei[2], edge_attr=ea[2]), heu[2])
+    assert torch.equal(mats[2], one)      # same heu values scattered the same way

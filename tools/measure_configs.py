@@ -73,7 +73,13 @@ def run(cfg):
             with torch.no_grad():
                 t_hip = timeit(lambda: net(pyg), 20)
                 t_torch = timeit(lambda: net.par_net_heu(net.emb_net(pyg.x, pyg.edge_index, pyg.edge_attr)), 5)
-            out.append(dict(n=n, k=k, E=n * k, hip_ms=t_hip * 1e3, torch_ops_ms=t_torch * 1e3))
+            B = 64
+            coords = torch.rand(B, n, 2, device=dev)
+            _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
+            with torch.no_grad():
+                t_batch = timeit(lambda: net.forward_batch(coords, ei, ea), 5)
+            out.append(dict(n=n, k=k, E=n * k, hip_ms=t_hip * 1e3, torch_ops_ms=t_torch * 1e3,
+                            hip_batch64_ms=t_batch * 1e3, hip_batch64_ms_per_graph=t_batch * 1e3 / B))
         return dict(config=cfg, desc="Net.forward eval, one instance (HIP kernels vs torch ops on the same GPU)", sizes=out)
     raise SystemExit(f"unknown config {cfg}")
 
