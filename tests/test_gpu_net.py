@@ -160,3 +160,25 @@ def test_batched_forward_equals_per_graph():
     mats = Net.reshape_batch(n, ei, heu)
     one = Net.reshape(GraphData(x=coords[2], edge_index=ei[2], edge_attr=ea[2]), heu[2])
     assert torch.equal(mats[2], one)      # same heu values scattered the same way
+
+
+def test_batched_inference_pipeline():
+    """coords -> kNN graph -> GNN (batched) -> colonies: equals building each colony from per-graph pieces."""
+    from deepaco_amd import engine
+    from deepaco_amd.net import GraphData
+    from deepaco_amd.pipeline import infer_tsp_batch, EPS
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(5)
+    dev = torch.device("cuda:0")
+    net = Net().to(dev).eval()
+    B, n, k, A = 3, 40, 8, 16
+    coords = torch.rand(B, n, 2, device=dev)
+    best, colony = infer_tsp_batch(coords, A, [1, 4], k, net=net, seed=9)
+    assert best.shape == (2, B) and bool((best[1] <= best[0]).all())
+    dist, ei, ea = engine.tsp_knn_graph(coords, k)
+    heu = torch.stack([Net.reshape(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]),
+                                   net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b])).view(-1)) for b in range(B)])
+    ref = engine.BatchedTSP(dist, n_ants=A, heuristic=heu + EPS, seed=9)
+    torch.testing.assert_close(colony.heuristic, ref.heuristic, rtol=1e-6, atol=1e-12)
+    vb, _ = infer_tsp_batch(coords, A, [3], k, net=None, seed=9)          # vanilla heuristic
+    assert bool((vb > 0).all())
