@@ -116,19 +116,32 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
   if (best) { alo = best[b]; ahi = alo + 1; }
   const uint32_t *tab = nbr + ((size_t)b * n + i0) * A;            // rows i0.. of this instance's [n][A] table
   const float *cs = costs + (size_t)b * A, *wt = weights ? weights + (size_t)b * A : nullptr;
-  // chunk loader: consecutive threads on consecutive ants of one row (256-byte segments)
-  auto load_chunk = [&](int c0, int buf) {
+  // chunk loader: consecutive threads on consecutive ants of one row (256-byte segments).  Wave 0 runs
+  // the chains, so after the first chunk only waves 1..3 fetch: a chain never waits for a prefetch.
+  auto load_chunk = [&](int c0, int buf, int t0, int nt) {
     const int m = min(DEP_CHUNK, ahi - c0);
-    for (int i = threadIdx.x; i < Rv * DEP_CHUNK; i += blockDim.x) {
+    for (int i = t0; i < Rv * DEP_CHUNK; i += nt) {
       const int r = i / DEP_CHUNK, j = i - r * DEP_CHUNK;
       stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[(size_t)r * A + c0 + j] : 0xFFFFFFFFu;
     }
-    if (threadIdx.x < DEP_CHUNK)
-      wts[buf * DEP_CHUNK + threadIdx.x] = threadIdx.x < m ? (wt ? wt[c0 + threadIdx.x] : 1.0f / cs[c0 + threadIdx.x]) : 0.0f;
+    if (t0 < DEP_CHUNK)
+      wts[buf * DEP_CHUNK + t0] = t0 < m ? (wt ? wt[c0 + t0] : 1.0f / cs[c0 + t0]) : 0.0f;
   };
-  load_chunk(alo, 0);
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x)
-    if (SYM || i < hub_lo || i >= hub_hi) rows[i] = g[i] * decay;
+  load_chunk(alo, 0, threadIdx.x, 256);
+  // the rows themselves: 16-byte vectors when the slab is aligned (n % 4 == 0), else element-wise
+  const bool vec_ok = SYM && (n & 3) == 0 && ((uintptr_t)g & 15) == 0;
+  if (vec_ok) {
+    const float4 *g4 = (const float4 *)g;
+    float4 *r4 = (float4 *)rows;
+    for (int i = threadIdx.x; i < cnt / 4; i += blockDim.x) {
+      float4 x = g4[i];
+      x.x *= decay; x.y *= decay; x.z *= decay; x.w *= decay;
+      r4[i] = x;
+    }
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x)
+      if (SYM || i < hub_lo || i >= hub_hi) rows[i] = g[i] * decay;
+  }
   __syncthreads();
   const int r = SYM ? threadIdx.x >> 1 : threadIdx.x;
   const int sh = SYM ? (threadIdx.x & 1) << 4 : 16;                // prev side: low half-word, next side: high
@@ -136,20 +149,28 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
   float *row = rows + (chain ? r : 0) * n;
   int buf = 0;
   for (int c0 = alo; c0 < ahi; c0 += DEP_CHUNK, buf ^= 1) {
-    if (c0 + DEP_CHUNK < ahi) load_chunk(c0 + DEP_CHUNK, buf ^ 1);  // next chunk lands while this one is applied
+    if (c0 + DEP_CHUNK < ahi && threadIdx.x >= 64)                  // next chunk lands while this one is applied
+      load_chunk(c0 + DEP_CHUNK, buf ^ 1, threadIdx.x - 64, 192);
     if (chain) {
       const int m = min(DEP_CHUNK, ahi - c0);
       const uint32_t *st = stage + (buf * R + r) * DEP_CHUNK;
       const float *w = wts + buf * DEP_CHUNK;
       int j = 0;
+      // the next four ants' columns and weights are fetched before this group's adds: only the
+      // read-modify-writes themselves stay on the dependent chain
+      uint4 v = *(const uint4 *)st;
+      float4 w4 = *(const float4 *)w;
       for (; j + 4 <= m; j += 4) {
-        const uint4 v = *(const uint4 *)(st + j);
-        const float4 w4 = *(const float4 *)(w + j);
+        const int jn = j + 8 <= m ? j + 4 : j;            // (the staging rows hold DEP_CHUNK entries: in bounds)
+        const uint4 vn = *(const uint4 *)(st + jn);
+        const float4 wn = *(const float4 *)(w + jn);
         const uint32_t c0_ = (v.x >> sh) & 0xFFFFu, c1_ = (v.y >> sh) & 0xFFFFu, c2_ = (v.z >> sh) & 0xFFFFu, c3_ = (v.w >> sh) & 0xFFFFu;
         if (SYM || c0_ != 0xFFFFu) row[c0_] = row[c0_] + w4.x;
         if (SYM || c1_ != 0xFFFFu) row[c1_] = row[c1_] + w4.y;
         if (SYM || c2_ != 0xFFFFu) row[c2_] = row[c2_] + w4.z;
         if (SYM || c3_ != 0xFFFFu) row[c3_] = row[c3_] + w4.w;
+        v = vn;
+        w4 = wn;
       }
       for (; j < m; ++j) {
         const uint32_t col = (st[j] >> sh) & 0xFFFFu;
@@ -160,12 +181,24 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
   }
   const bool clamp = clamp_max != nullptr;
   const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-    if (!SYM && i >= hub_lo && i < hub_hi) continue;
-    float x = rows[i];
+  auto finish = [&](float x) {
     if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
     if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
-    g[i] = x;
+    return x;
+  };
+  if (vec_ok) {
+    float4 *g4 = (float4 *)g;
+    const float4 *r4 = (const float4 *)rows;
+    for (int i = threadIdx.x; i < cnt / 4; i += blockDim.x) {
+      float4 x = r4[i];
+      x.x = finish(x.x); x.y = finish(x.y); x.z = finish(x.z); x.w = finish(x.w);
+      g4[i] = x;
+    }
+  } else {
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      if (!SYM && i >= hub_lo && i < hub_hi) continue;
+      g[i] = finish(rows[i]);
+    }
   }
 }
 
@@ -195,34 +228,75 @@ __device__ inline float ant_weight(const float *weights, const float *costs, siz
 }
 
 // the hub row (depot / dummy node): thread per column, ants in order, the running value stays in a
-// register; the bitmap words and weights do not depend on it, so their loads run ahead of the adds
+// register.  The per-ant bitmap words and weights are staged through LDS in chunks of HUB_CHUNK
+// ants (coalesced loads, 1/cost computed once per ant), so the ant loop itself touches no memory
+// but LDS and has no dependent loads.
+constexpr int HUB_CHUNK = 256;
+
 __global__ void __launch_bounds__(256)
 deposit_hub_kernel(int n, int A, int W, int hub, float *tau, const uint32_t *hubmask, const int32_t *tab_lens,
                    const float *costs, const float *weights, float decay, const int *best, const float *clamp_min,
                    const float *clamp_max, float floor_val) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hub_lds[];   // [HUB_CHUNK][W] bitmap words | [HUB_CHUNK] weights | [HUB_CHUNK] padded?
+  uint32_t *mw = hub_lds;
+  float *wl = (float *)(hub_lds + (size_t)HUB_CHUNK * W);
+  uint32_t *padl = (uint32_t *)(wl + HUB_CHUNK);
+  __shared__ int longest_s;
   const int b = blockIdx.x;
-  // a table written by the sampler holds each ant's own route only; the reference pads the shorter routes
-  // with the depot up to the longest one of the colony, i.e. one (hub,hub) edge for every shorter ant
-  int longest = 0;
-  if (tab_lens) for (int a = 0; a < A; ++a) longest = max(longest, tab_lens[(size_t)b * A + a]);
   float *g = tau + ((size_t)b * n + hub) * n;
   int alo = 0, ahi = A;
   if (best) { alo = best[b]; ahi = alo + 1; }
+  // a table written by the sampler holds each ant's own route only; the reference pads the shorter routes
+  // with the depot up to the longest one of the colony, i.e. one (hub,hub) edge for every shorter ant
+  if (threadIdx.x == 0) longest_s = 0;
+  __syncthreads();
+  if (tab_lens) {
+    int mx = 0;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) mx = max(mx, tab_lens[(size_t)b * A + a]);
+    atomicMax(&longest_s, mx);
+  }
+  __syncthreads();
+  const int longest = longest_s;
   const bool clamp = clamp_max != nullptr;
   const float cmin = clamp ? clamp_min[b] : 0.0f, cmax = clamp ? clamp_max[b] : 0.0f;
-  for (int c = threadIdx.x; c < n; c += blockDim.x) {
-    float x = g[c] * decay;
-    const uint32_t *mw = hubmask + (size_t)b * A * W + (c >> 5);
+  // 256 columns per pass (one pass up to n = 256); the chunks are staged again for every pass
+  for (int cb = 0; cb < n; cb += blockDim.x) {
+    const int c = cb + threadIdx.x;
+    const uint32_t *mc = mw + (c >> 5);
     const uint32_t bit = 1u << (c & 31);
-#pragma unroll 8
-    for (int a = alo; a < ahi; ++a) {
-      const float w = ant_weight(weights, costs, (size_t)b * A + a);
-      const bool padded = tab_lens && c == hub && tab_lens[(size_t)b * A + a] < longest;
-      if ((mw[(size_t)a * W] & bit) || padded) x = x + w;
+    const bool is_hub = c == hub;
+    float v = c < n ? g[c] * decay : 0.0f;
+    for (int c0 = alo; c0 < ahi; c0 += HUB_CHUNK) {
+      const int m = min(HUB_CHUNK, ahi - c0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < m * W; i += blockDim.x) mw[i] = hubmask[((size_t)b * A + c0) * W + i];
+      for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        wl[j] = ant_weight(weights, costs, (size_t)b * A + c0 + j);
+        padl[j] = (tab_lens && tab_lens[(size_t)b * A + c0 + j] < longest) ? 1u : 0u;
+      }
+      __syncthreads();
+      if (c < n) {
+        int j = 0;
+        for (; j + 8 <= m; j += 8) {                      // the eight ants' words and weights are read up front
+          uint32_t hit[8];
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            hit[u] = (mc[(size_t)(j + u) * W] & bit) | (is_hub ? padl[j + u] : 0u);
+            wv[u] = wl[j + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v = hit[u] ? v + wv[u] : v;
+        }
+        for (; j < m; ++j)
+          if ((mc[(size_t)j * W] & bit) || (is_hub && padl[j])) v = v + wl[j];
+      }
     }
-    if (clamp) { x = x < cmin ? cmin : x; x = x > cmax ? cmax : x; }
-    if (floor_val > 0.0f) x = x < floor_val ? floor_val : x;
-    g[c] = x;
+    if (c < n) {
+      if (clamp) { v = v < cmin ? cmin : v; v = v > cmax ? cmax : v; }
+      if (floor_val > 0.0f) v = v < floor_val ? floor_val : v;
+      g[c] = v;
+    }
   }
 }
 
@@ -312,7 +386,7 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
     const int R = rows_per_block(n, false);
     const int bpi = (n + R - 1) / R;
     if (hub >= 0)
-      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), 0, s, n, A, W, hub, tau, hubmask, tab_lens,
+      hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), (size_t)HUB_CHUNK * (W + 2) * sizeof(uint32_t), s, n, A, W, hub, tau, hubmask, tab_lens,
                          costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
     hipLaunchKernelGGL(deposit_rows_kernel<false>, dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, hub, tau,
                        nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max,
