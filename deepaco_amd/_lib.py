@@ -23,7 +23,7 @@ SIGNATURES = {
     "daco_vec_for_n": (_i, [_i]),
     "daco_ld_for_n": (_i, [_i]),
     "daco_tsp_sample_workspace_bytes": (_sz, [_i, _i, _i]),
-    "daco_tsp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _i, _vp, _i, _vp, _u64, _u64,
+    "daco_tsp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _i, _vp, _i, _vp, _u64, _u64, _vp,
                              _u32, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tour_costs": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp]),
     "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -32,7 +32,7 @@ SIGNATURES = {
     "daco_prob_matrix": (_i, [_vp, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _vp, _sz]),
     "daco_pick_move": (_i, [_vp, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp]),
     "daco_directed_table_bytes": (_sz, [_i, _i, _i]),
-    "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _u32, _i,
+    "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _vp, _u32, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz]),
     "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
     "daco_gnn_param_floats": (_sz, [_i]),

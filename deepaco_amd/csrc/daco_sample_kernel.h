@@ -19,6 +19,7 @@ struct SampleParams {
   int fixed_start;
   const float *noise;    // [B][n-1][A][n] RACE_NOISE
   uint64_t seed, iter;
+  const uint64_t *iter_dev;  // optional device-side addend to iter (lets a captured HIP graph advance the RNG); or null
   uint32_t ant_gid0;
   int64_t *paths;        // [B][n][A]
   float *logp;           // [B][n-1][A] or null
@@ -117,6 +118,7 @@ tsp_sample_kernel(const SampleParams p) {
   const int a = (w - b * bpi) * 4 + wave;
   if (a >= p.A) return;                                 // no barriers below: safe
   const int n = p.n, A = p.A, ld = p.ld;
+  const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
   const float *Pb = p.P + (size_t)b * n * ld + lane * VEC;
   const float *Rb = (MODE == DACO_RACE_PHILOX) ? p.R + (size_t)b * n * ld + lane * VEC : nullptr;
@@ -134,12 +136,12 @@ tsp_sample_kernel(const SampleParams p) {
   if constexpr (CVRP || SOP || PCTSP || OP) prev = 0;
   else if constexpr (MKP) {
     if (p.start) prev = (int)p.start[(size_t)b * A + a];
-    else { const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0); prev = (int)__umulhi(r.x, (uint32_t)(n - 1)); }
+    else { const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0); prev = (int)__umulhi(r.x, (uint32_t)(n - 1)); }
   }
   else if (p.start) prev = (int)p.start[(size_t)b * A + a];
   else if (p.fixed_start >= 0) prev = p.fixed_start;
   else {
-    const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0);
+    const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0);
     prev = (int)__umulhi(r.x, (uint32_t)n);
   }
   prev = __builtin_amdgcn_readfirstlane(prev);
@@ -285,7 +287,7 @@ tsp_sample_kernel(const SampleParams p) {
     if constexpr (MODE == DACO_SCAN) {
       // uniform for step t: lane (t&63), component (t>>6)&3 of the Philox block (t>>8)*64 + lane
       if ((t & 63) == 0 || t == t0) {
-        if ((t & 255) == 0 || t == t0) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 8) << 6) + lane));
+        if ((t & 255) == 0 || t == t0) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 8) << 6) + lane));
         ucur = comp(ublk, (t >> 6) & 3);
       }
       const uint32_t ux = (uint32_t)readlane_i((int)ucur, t & 63);
@@ -336,7 +338,7 @@ tsp_sample_kernel(const SampleParams p) {
         constexpr int j = J, c = j / VEC, v = j % VEC;
         const int k = (c * 64 + lane) * VEC + v;
         // one Philox block serves candidates 4g..4g+3; a lane's VEC candidates share a block
-        if (v == 0) r4 = rng_block(p.seed, p.iter, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
+        if (v == 0) r4 = rng_block(p.seed, iter_now, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
         const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
         const float key = blk.template test<j>() ? __builtin_inff() : Lk * row[c][v];
         if (key < bk) { bk = key; bi = k; }

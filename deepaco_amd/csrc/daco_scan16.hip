@@ -62,6 +62,7 @@ scan16_kernel(const SampleParams p) {
   const int b = w / bpi;
   const int a0 = ((w - b * bpi) * 4 + wave) * 4;        // ants a0 .. a0+3, one per row
   const int n = p.n, A = p.A, ld = p.ld;
+  const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   if constexpr (CVRP) {
     for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
     __syncthreads();
@@ -101,7 +102,7 @@ scan16_kernel(const SampleParams p) {
   else if (p.start) prev = (int)p.start[(size_t)b * A + a];
   else if (p.fixed_start >= 0) prev = p.fixed_start;
   else {
-    const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0);
+    const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0);
     prev = (int)__umulhi(r.x, (uint32_t)n);
   }
   const int first = prev;
@@ -128,7 +129,7 @@ scan16_kernel(const SampleParams p) {
     for (int c = 0; c < CH; ++c) row[c] = *(const float4 *)(Pb + voff + c * 256);
     // uniform of step t: lane (t&15), component (t>>4)&3 of Philox block ((t>>6)<<4) + lane
     if ((t & 15) == 0 || t == 1) {
-      if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 6) << 4) + s));
+      if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 6) << 4) + s));
       ucur = u01(comp(ublk, (t >> 4) & 3));
     }
     const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | ((t & 15) << 2), __float_as_int(ucur)));

@@ -62,6 +62,7 @@ tsp_scan32_kernel(const SampleParams p) {
   const int a0 = ((w - b * bpi) * 4 + wave) * 2;        // ants a0 (lower half), a0+1 (upper half)
   if (a0 >= p.A) return;
   const int n = p.n, A = p.A, ld = p.ld;
+  const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   // odd A: the last upper half builds ant A-1 a second time (same counters, same tour, same stores)
   const int a = a0 + up < A ? a0 + up : A - 1;
   const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);   // lane 0 of each half
@@ -89,7 +90,7 @@ tsp_scan32_kernel(const SampleParams p) {
   if (p.start) prev = (int)p.start[(size_t)b * A + a];
   else if (p.fixed_start >= 0) prev = p.fixed_start;
   else {
-    const u32x4 r = rng_block(p.seed, p.iter, STREAM_START, gid, 0);
+    const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0);
     prev = (int)__umulhi(r.x, (uint32_t)n);
   }
   const int first = prev;
@@ -106,7 +107,7 @@ tsp_scan32_kernel(const SampleParams p) {
 
   for (int tb = 0; tb < n; tb += 32) {
     // uniform of step t: lane (t&31), component (t>>5)&3 of Philox block ((t>>7)<<5) + lane
-    if ((tb & 127) == 0) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((tb >> 7) << 5) + s));
+    if ((tb & 127) == 0) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((tb >> 7) << 5) + s));
     const float ucur = u01(comp(ublk, (tb >> 5) & 3));
     const int i1 = n - tb < 32 ? n - tb : 32;
     for (int i = tb == 0 ? 1 : 0; i < i1; ++i) {
@@ -238,6 +239,7 @@ cvrp_scan32_kernel(const SampleParams p) {
   const int b = w / bpi;
   const int a0 = ((w - b * bpi) * 4 + wave) * 2;
   const int n = p.n, A = p.A, ld = p.ld, Lmax = p.Lmax;
+  const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);
   for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
   __syncthreads();
   if (a0 >= A) return;
@@ -283,7 +285,7 @@ cvrp_scan32_kernel(const SampleParams p) {
 #pragma unroll
     for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
     if ((t & 31) == 0 || t == 1) {
-      if ((t & 127) == 0 || t == 1) ublk = rng_block(p.seed, p.iter, STREAM_SCAN, gid, (uint32_t)(((t >> 7) << 5) + s));
+      if ((t & 127) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 7) << 5) + s));
       ucur = u01(comp(ublk, (t >> 5) & 3));
     }
     const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | ((t & 31) << 2), __float_as_int(ucur)));

@@ -51,7 +51,7 @@ def _bstride(t, n):
 
 def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1, start=None,
                fixed_start=-1, noise=None, seed=0, it=0, ant_gid0=0, require_prob=False, batch=None,
-               events=None, dist=None, want_nbr=False):
+               events=None, dist=None, want_nbr=False, iter_dev=None):
     """ACO.gen_path for a batch (tsp/aco.py:134-177, tsp_nls/aco.py:184-220).
 
     tau, eta: [B,n,n] or [n,n] (shared).  Returns (paths, log_probs|None, rowsum|None, flags).
@@ -91,7 +91,8 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
                                float(alpha), float(beta), m, int(norm_passes),
                                start.data_ptr() if start is not None else None, int(fixed_start),
                                noise.data_ptr() if noise is not None else None,
-                               int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF,
+                               int(seed) & (2 ** 64 - 1), int(it), iter_dev.data_ptr() if iter_dev is not None else None,
+                               int(ant_gid0) & 0xFFFFFFFF,
                                paths.data_ptr(), logp.data_ptr() if require_prob else None,
                                rowsum.data_ptr() if require_prob else None, flags.data_ptr(),
                                dist.data_ptr() if dist is not None else None, dbs,
@@ -107,7 +108,8 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
 
 
 def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
-                it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False):
+                it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False,
+                iter_dev=None):
     """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
     or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, rowsum|None, lens [B,A], flags [B]);
     the reference's result is paths[:, :lens.max()].
@@ -149,7 +151,8 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
         rc = L.daco_cvrp_sample(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
                                 float(beta), demand.data_ptr(), float(capacity), m,
                                 noise.data_ptr() if noise is not None else None, steps,
-                                int(seed) & (2 ** 64 - 1), int(it), int(ant_gid0) & 0xFFFFFFFF, Lmax,
+                                int(seed) & (2 ** 64 - 1), int(it), iter_dev.data_ptr() if iter_dev is not None else None,
+                                int(ant_gid0) & 0xFFFFFFFF, Lmax,
                                 paths.data_ptr(), logp.data_ptr() if require_prob else None,
                                 rowsum.data_ptr() if require_prob else None, lens.data_ptr(),
                                 flags.data_ptr(), dist.data_ptr() if dist is not None else None, dbs,
@@ -465,12 +468,15 @@ class BatchedTSP:
         self.heuristic = 1 / sparse
 
     @torch.no_grad()
-    def step(self, events=None):
+    def step(self, events=None, _iter_dev=None):
+        # (_iter_dev: device-side iteration counter of a captured graph; self.iteration then stays frozen)
         paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
                                                 self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,
                                                 ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
-                                                batch=self.B, events=events, dist=self.distances, want_nbr=True)
-        self.iteration += 1
+                                                batch=self.B, events=events, dist=self.distances, want_nbr=True,
+                                                iter_dev=_iter_dev)
+        if _iter_dev is None:
+            self.iteration += 1
         if self.local_search is not None:
             tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
             maxt = self.n // 4
@@ -483,8 +489,9 @@ class BatchedTSP:
         best_cost, best_idx = costs.min(dim=1)
         improved = best_cost < self.lowest_cost
         best_path = torch.gather(paths, 2, best_idx.view(self.B, 1, 1).expand(self.B, self.n, 1)).squeeze(2)
-        self.shortest_path = torch.where(improved.unsqueeze(1), best_path, self.shortest_path)
-        self.lowest_cost = torch.where(improved, best_cost, self.lowest_cost)
+        # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)
+        self.shortest_path.copy_(torch.where(improved.unsqueeze(1), best_path, self.shortest_path))
+        self.lowest_cost.copy_(torch.where(improved, best_cost, self.lowest_cost))
         cmin = cmax = None
         if self.min_max:
             new_max = self.lowest_cost.reciprocal() * self.n          # n / lowest_cost (rtruediv)
@@ -497,9 +504,33 @@ class BatchedTSP:
         return paths, costs
 
     @torch.no_grad()
-    def run(self, n_iterations):
-        for _ in range(n_iterations):
-            self.step()
+    def run(self, n_iterations, graph=False):
+        """graph=True: the iteration is captured once into a HIP graph and replayed (small colonies are bound by
+        launch latency: ~10 launches of a few microseconds of work each).  Same tours and pheromone as the eager
+        loop: the Philox iteration counter of the captured sampler lives in device memory and is advanced inside
+        the graph."""
+        if not graph or n_iterations < 3:
+            for _ in range(n_iterations):
+                self.step()
+            return self.lowest_cost
+        self.step()                                        # eager: workspaces, first-iteration MMAS rescale
+        dev = self.distances.device
+        it_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # one un-captured pass on the capture stream (allocator warm-up)
+            self.step(_iter_dev=it_dev)
+            it_dev += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            self.step(_iter_dev=it_dev)
+            it_dev += 1
+        for _ in range(n_iterations - 2):
+            g.replay()
+        self.iteration += n_iterations - 1
+        self._graph = g                                    # keeps the captured buffers alive with the colony
         return self.lowest_cost
 
 

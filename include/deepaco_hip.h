@@ -79,6 +79,9 @@ int daco_ld_for_n(int n);
  *   noise      DACO_RACE_NOISE only: [B][n-1][A][n] f32 (the reference's q tensors, step-major).
  *   seed, iter, ant_gid0   Philox key and counter words: ant (b,a) uses global ant id
  *              ant_gid0 + b*A + a; `iter` must differ between calls that should be independent.
+ *   iter_offset  optional device pointer to a uint64 that the kernel adds to `iter` when it starts:
+ *              a caller that captures its iteration into a HIP graph keeps the counter in device
+ *              memory and bumps it inside the graph (arguments are frozen at capture).  NULL = 0.
  *   paths      out [B][n][A] int64  (reference layout: paths[:, i] is ant i's tour)
  *   logp       out [B][n-1][A] f32 or NULL: log(clamp(p_chosen/S, eps, 1-eps)), eps = 2^-23
  *   rowsum     out [B][n-1][A] f32 or NULL: S at each step (saved for daco_tsp_sample_backward)
@@ -99,7 +102,7 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
                     const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                     float alpha, float beta, int mode, int norm_passes,
                     const int64_t *start, int fixed_start, const float *noise,
-                    uint64_t seed, uint64_t iter, uint32_t ant_gid0,
+                    uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
                     int64_t *paths, float *logp, float *rowsum, int32_t *flags,
                     const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                     void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
@@ -137,7 +140,7 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                      float alpha, float beta, const float *demand, float capacity, int mode,
                      const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
-                     uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
+                     const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
                      int32_t *lens, int32_t *flags,
                      const float *dist, long dist_bstride, float *costs, void *next_table,
                      void *workspace, size_t workspace_bytes);

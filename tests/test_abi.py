@@ -46,11 +46,11 @@ def test_bad_arguments_return_error_codes():
     assert L.daco_tour_costs(None, 0, 0, 0, 0, None, 0, None, 0, None) == -1
     assert b"bad argument" in L.daco_last_error()
     # n above the register plan of the sampler -> DACO_E_TOOLARGE before anything is launched
-    rc = L.daco_tsp_sample(None, 1, 5000, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, 0, 1, None, None,
+    rc = L.daco_tsp_sample(None, 1, 5000, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, None, 0, 1, None, None,
                            None, None, 0, None, None, 1, 1 << 40, None, None)
     assert rc == -2 and b"DACO_MAX_NODES" in L.daco_last_error()
     # workspace too small
-    rc = L.daco_tsp_sample(None, 1, 100, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, 0, 1, None, None,
+    rc = L.daco_tsp_sample(None, 1, 100, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, None, 0, 1, None, None,
                            None, None, 0, None, None, 1, 16, None, None)
     assert rc == -4
     assert L.daco_tsp_sample_workspace_bytes(64, 500, _lib.SCAN) == 64 * 500 * 512 * 4

@@ -355,6 +355,25 @@ def test_odd_batch_and_ant_counts(B, A):
 
 
 @pytest.mark.parametrize("kw", [{}, {"elitist": True}, {"min_max": True}])
+@pytest.mark.parametrize("n,A,B", [(60, 20, 2), (150, 9, 1)])
+def test_graph_replay_equals_eager_loop(kw, n, A, B):
+    """BatchedTSP.run(graph=True): the iteration captured into a HIP graph (device-side Philox iteration counter)
+    gives the same colony, bit for bit, as the eager loop."""
+    from deepaco_amd import engine
+    dist, _, _ = make_instance(n, 17 + n, B)
+    c1 = engine.BatchedTSP(dist.to(dev()), n_ants=A, seed=4, **kw)
+    c2 = engine.BatchedTSP(dist.to(dev()), n_ants=A, seed=4, **kw)
+    r1 = c1.run(7)
+    r2 = c2.run(7, graph=True)
+    torch.cuda.synchronize()
+    assert c1.iteration == c2.iteration == 7
+    assert torch.equal(c1.pheromone, c2.pheromone)
+    assert torch.equal(r1, r2) and torch.equal(c1.shortest_path, c2.shortest_path)
+    r1, r2 = c1.run(2), c2.run(4, graph=True)      # the colonies stay usable either way
+    assert bool((r2 <= r1).all())
+
+
+@pytest.mark.parametrize("kw", [{}, {"elitist": True}, {"min_max": True}])
 def test_sync_free_run_equals_plain_sequence(kw):
     """ACO.run's device-side bookkeeping (no host sync, fused costs / neighbour table) gives the same colony as the
     reference's call sequence gen_path -> gen_path_costs -> update_pheronome."""
