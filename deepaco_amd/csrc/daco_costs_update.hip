@@ -86,6 +86,43 @@ __global__ void __launch_bounds__(64) argmin_cost_kernel(int A, const float *cos
   if (lane == 0) best[b] = r.idx == 0x7fffffff ? 0 : r.idx;
 }
 
+// best-so-far bookkeeping of ACO.run (tsp/aco.py:78-88): first minimum of the costs, and if it
+// beats the colony's record, the record and its tour are replaced (device-side: no host branch)
+__global__ void __launch_bounds__(256)
+track_best_kernel(int len, int A, const float *costs, const int64_t *paths, float *lowest, int64_t *shortest,
+                  int32_t *best_idx, float *mmas_max, float mmas_scale) {
+  __shared__ float rk[4];
+  __shared__ int ri[4];
+  __shared__ int take;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float bk = __builtin_inff();
+  int bi = 0x7fffffff;
+  for (int a = tid; a < A; a += 256) {
+    const float c = costs[(size_t)b * A + a];
+    if (c < bk) { bk = c; bi = a; }
+  }
+  const KeyIdx r = wave_arg<false>(bk, bi);
+  if (lane == 0) { rk[wave] = r.key; ri[wave] = r.idx; }
+  __syncthreads();
+  if (tid == 0) {
+    float k = rk[0];
+    int i = ri[0];
+    for (int w = 1; w < 4; ++w)
+      if (rk[w] < k || (rk[w] == k && ri[w] < i)) { k = rk[w]; i = ri[w]; }
+    if (i == 0x7fffffff) i = 0;
+    if (best_idx) best_idx[b] = i;
+    float low = lowest[b];
+    const bool improved = k < low;                      // `if best_cost < self.lowest_cost`
+    if (improved) { low = k; lowest[b] = k; }
+    if (mmas_max) mmas_max[b] = (1.0f / low) * mmas_scale;   // n / lowest_cost as rtruediv computes it: reciprocal, then * n
+    take = improved ? i : -1;
+  }
+  __syncthreads();
+  const int t = take;
+  if (t >= 0 && shortest)
+    for (int k = tid; k < len; k += 256) shortest[(size_t)b * len + k] = paths[((size_t)b * len + k) * A + t];
+}
+
 // Row owners: a workgroup keeps R rows of tau in LDS.  Row i receives, per ant and in ant order,
 // +w at column prev_a(i) and +w at column next_a(i) (tsp/aco.py:95-118: each ant's forward and
 // backward edges).  Adds to one element must stay in ant order, so each row is a chain of
@@ -317,6 +354,19 @@ extern "C" int daco_tour_costs(void *stream, int B, int n, int len, int A, const
                      len, A, dist, dist_bstride, paths, closed, costs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("tour_costs_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+extern "C" int daco_track_best(void *stream, int B, int len, int A, const float *costs, const int64_t *paths,
+                               float *lowest, int64_t *shortest, int32_t *best_idx, float *mmas_max, float mmas_scale) {
+  if (B <= 0 || len <= 0 || A <= 0 || !costs || !lowest || (shortest && !paths)) {
+    set_error("daco_track_best: bad argument (B=%d len=%d A=%d)", B, len, A);
+    return DACO_E_BADARG;
+  }
+  hipLaunchKernelGGL(track_best_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, len, A, costs, paths, lowest, shortest,
+                     best_idx, mmas_max, mmas_scale);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("track_best_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }
 

@@ -345,6 +345,25 @@ def tour_costs(dist, paths, closed=True):
     return costs
 
 
+def track_best_(costs, paths, lowest, shortest=None, mmas_scale=None):
+    """Best-so-far bookkeeping of ACO.run on the device (tsp/aco.py:78-88): updates lowest [B] and shortest
+    [B,len] in place where this iteration's first-minimum cost beats the record.  mmas_scale (= problem size):
+    also returns the MMAS upper bound n / lowest_cost [B] (computed like the reference's rtruediv)."""
+    _require_gpu(costs, paths, lowest, shortest)
+    B, length, A = paths.shape
+    assert costs.dtype == torch.float32 and costs.is_contiguous() and paths.is_contiguous()
+    assert lowest.dtype == torch.float32 and lowest.is_contiguous() and lowest.numel() == B
+    dev = costs.device
+    with torch.cuda.device(dev):
+        mx = torch.empty((B,), dtype=torch.float32, device=dev) if mmas_scale is not None else None
+        rc = _lib.lib().daco_track_best(_stream(dev), B, length, A, costs.data_ptr(), paths.data_ptr(), lowest.data_ptr(),
+                                        shortest.data_ptr() if shortest is not None else None, None,
+                                        mx.data_ptr() if mx is not None else None,
+                                        float(mmas_scale) if mmas_scale is not None else 0.0)
+    _lib.check(rc, "daco_track_best")
+    return mx
+
+
 def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, clamp_min=None,
                       clamp_max=None, floor=0.0, nbr=None, weights=None, hub=0):
     """In-place ACO.update_pheronome for a batch (tsp/aco.py:95-118, cvrp/aco.py:107-130).
@@ -452,6 +471,7 @@ class BatchedTSP:
         assert local_search in (None, "2opt", "nls")
         self.local_search = local_search          # tsp_nls/aco.py: applied to the tours before costing
         self._hdist = None
+        self._cmin = None
 
     def _heuristic_dist(self):
         if self._hdist is None:
@@ -486,20 +506,17 @@ class BatchedTSP:
                 tours = nls_(self.distances, self._heuristic_dist(), tours, maxt)
             paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
             costs, nbr = tour_costs(self.distances, paths), None
-        best_cost, best_idx = costs.min(dim=1)
-        improved = best_cost < self.lowest_cost
-        best_path = torch.gather(paths, 2, best_idx.view(self.B, 1, 1).expand(self.B, self.n, 1)).squeeze(2)
         # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)
-        self.shortest_path.copy_(torch.where(improved.unsqueeze(1), best_path, self.shortest_path))
-        self.lowest_cost.copy_(torch.where(improved, best_cost, self.lowest_cost))
+        new_max = track_best_(costs, paths, self.lowest_cost, self.shortest_path,
+                              mmas_scale=self.n if self.min_max else None)
         cmin = cmax = None
         if self.min_max:
-            new_max = self.lowest_cost.reciprocal() * self.n          # n / lowest_cost (rtruediv)
             if self.max is None:
                 self.pheromone *= (new_max / self.pheromone.amax(dim=(1, 2))).view(self.B, 1, 1)
             self.max = new_max
-            cmin = torch.full_like(new_max, self.min)
-            cmax = new_max.contiguous()
+            if self._cmin is None:
+                self._cmin = torch.full_like(new_max, self.min)
+            cmin, cmax = self._cmin, new_max
         pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
         return paths, costs
 
@@ -568,10 +585,9 @@ class BatchedCVRP:
             dist=self.distances, want_table=True)
         self.iteration += 1
         self.last_lens, self.last_flags = lens, flags
-        self.lowest_cost = torch.minimum(self.lowest_cost, costs.min(dim=1).values)
+        new_max = track_best_(costs, paths, self.lowest_cost, None, mmas_scale=self.n if self.min_max else None)
         cmin = cmax = None
         if self.min_max:
-            new_max = self.lowest_cost.reciprocal() * self.n
             if self.max is None:
                 self.pheromone *= (new_max / self.pheromone.amax(dim=(1, 2))).view(self.B, 1, 1)
             self.max = new_max

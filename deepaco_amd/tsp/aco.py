@@ -116,9 +116,9 @@ class ACO():
             return self._run_plain(n_iterations)
         dev = self.distances.device
         dist = self.distances.detach().float().contiguous()
-        lowest = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(())
-        shortest = self.shortest_path if self.shortest_path is not None else \
-            torch.zeros(self.problem_size, dtype=torch.int64, device=dev)
+        lowest = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(1).clone()
+        shortest = (self.shortest_path.clone() if self.shortest_path is not None else
+                    torch.zeros(self.problem_size, dtype=torch.int64, device=dev)).reshape(1, -1).contiguous()
         for _ in range(n_iterations):
             paths, _, _, flags, costs, nbr = engine.tsp_sample(
                 self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha, self.beta, mode=self.sampler,
@@ -126,22 +126,20 @@ class ACO():
                 dist=dist, want_nbr=True)
             self._calls += 1
             self._last_flags = flags
-            best_cost, best_idx = costs[0].min(dim=0)
-            improved = best_cost < lowest
-            shortest = torch.where(improved, paths[0].index_select(1, best_idx.view(1)).squeeze(1), shortest)
-            lowest = torch.where(improved, best_cost, lowest)
+            # `if best_cost < self.lowest_cost: ...` (tsp/aco.py:78-88) on the device
+            new_max = engine.track_best_(costs, paths, lowest, shortest,
+                                         mmas_scale=self.problem_size if self.min_max else None)
             cmin = cmax = None
             if self.min_max:
-                new_max = lowest.reciprocal() * self.problem_size          # n / lowest_cost (rtruediv)
                 if self.max is None:
-                    self.pheromone *= new_max / self.pheromone.max()
-                self.max = new_max
+                    self.pheromone *= new_max[0] / self.pheromone.max()
+                self.max = new_max[0]
                 cmin = torch.full((1,), float(self.min), device=dev)
-                cmax = new_max.reshape(1).contiguous()
+                cmax = new_max
             tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
             engine.pheromone_update_(tau, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
             self.pheromone = tau[0]
-        self.lowest_cost, self.shortest_path = lowest, shortest
+        self.lowest_cost, self.shortest_path = lowest[0], shortest[0]
         return self.lowest_cost
 
     @torch.no_grad()

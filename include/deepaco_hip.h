@@ -146,6 +146,19 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
+ * daco_track_best -- replaces the best-so-far bookkeeping inside ACO.run
+ *   tsp/aco.py:78-88, cvrp/aco.py:78-100: best_cost, best_idx = costs.min(dim=0);
+ *   if best_cost < self.lowest_cost: shortest_path = paths[:, best_idx]; lowest_cost = best_cost
+ *   (MMAS: max = n / lowest_cost).  Done on the device, so the loop needs no host branch.
+ *   costs [B][A]; paths [B][len][A] int64; lowest [B] f32 in/out (start at +inf); shortest [B][len]
+ *   int64 in/out or NULL; best_idx [B] int32 out or NULL (first minimum, torch.min semantics);
+ *   mmas_max [B] f32 out or NULL = (1 / lowest) * mmas_scale, the two roundings of the reference's
+ *   `problem_size / lowest_cost` on a tensor (reciprocal, then multiply).
+ */
+int daco_track_best(void *stream, int B, int len, int A, const float *costs, const int64_t *paths,
+                    float *lowest, int64_t *shortest, int32_t *best_idx, float *mmas_max, float mmas_scale);
+
+/* ---------------------------------------------------------------------------------------------
  * daco_prob_matrix + daco_pick_move -- ACO.pick_move as a step-wise service
  *   tsp/aco.py:165-177 and its copies in op/aco.py:186-193, pctsp/aco.py:157-164,
  *   sop/aco.py:156-169, smtwtp/aco.py:139-151, bpp/aco.py:157-164, mkp/aco.py:147-154
