@@ -34,8 +34,10 @@ __device__ inline float half_scan_add(float x) {
   x = x + dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x);
   x = x + dpp_f<DPP_ROW_SHR(8), 0xF, true>(0.0f, x);
   // rows 1 and 3 only (row_mask 0xa): x += lane 15 of the row before; one instruction, rows 0 / 2 keep x.
-  // s_nop 1: two wait states between the VALU write of x and its DPP read.
-  if constexpr (ROWS2) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(x));
+  // s_nop 1 on both sides: two wait states between a VALU write of x and a DPP read of it -- the
+  // compiler's hazard recogniser does not look inside the asm, nor does it know what follows it.
+  if constexpr (ROWS2)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1" : "+v"(x));
   return x;
 }
 // lane 31 of each half to all of its lanes (LDS crossbar, no memory, no VALU slot)
