@@ -182,7 +182,7 @@ def main():
     achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms else None      # GB/s, dominant kernel, this rank
     gpu_best = colony.lowest_cost.detach().cpu()
     # daco_tsp_sample's layout rule: 4 / 2 / 1 ants per wavefront
-    lanes = 64 if args.sampler != "scan" or n > 1024 else (16 if n <= 128 else 32)
+    lanes = 64 if args.sampler != "scan" or n > 512 else (16 if n <= 256 else 32)
     kernel_name = {16: "scan16_kernel", 32: "tsp_scan32_kernel", 64: "tsp_sample_kernel"}[lanes]
     row_floats = (n + 4 * lanes - 1) // (4 * lanes) * (4 * lanes) if lanes < 64 else ((n + 255) // 256 * 256 if n > 128 else n)
 

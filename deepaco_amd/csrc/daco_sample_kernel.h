@@ -526,7 +526,10 @@ inline int inst_chunks(int n) {
 inline int ld_alloc(int n) { return inst_chunks(n) * 64 * vec_for_n(n); }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// daco_tsp_scan32.hip: TSP scan draw with two ants per wavefront (128 < n <= 1024)
+// layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to
+// DACO_SCAN16_MAX_N nodes, two up to DACO_SCAN32_MAX_N, one above (the oracle restates the rule)
+constexpr int DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
+// daco_tsp_scan32.hip: TSP / CVRP scan draw with two ants per wavefront
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
 hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
 // daco_scan16.hip: four ants per wavefront (n <= 128)

@@ -1,14 +1,14 @@
-// daco_scan16.hip -- tour construction for small instances (n <= 128), prefix-scan draw, FOUR ants
+// daco_scan16.hip -- tour construction for small instances (n <= 256), prefix-scan draw, FOUR ants
 // per wavefront: TSP (tsp/aco.py:134-177, tsp_nls/aco.py:184-220) and CVRP (cvrp/aco.py:138-205).
 //
-// At n <= 128 a row is at most 512 bytes: the step is bound by instruction issue and by the
+// At n <= 256 a row is at most 1 KiB: the step is bound by instruction issue and by the
 // latency of its dependent chain, not by bytes, so the per-step overhead is shared by four ants.
 // Each 16-lane DPP row of a wave builds one tour:
-//   * candidate k of an ant sits in lane s = (k/4) % 16 of its row, chunk c = k/64 (c < CH <= 2);
+//   * candidate k of an ant sits in lane s = (k/4) % 16 of its row, chunk c = k/64 (c < CH <= 4);
 //   * visited flags are f32 0/1 in LDS, the lane's masked values p*open feed packed adds;
 //   * level 1: DPP row scan of the 16 lane sums (no cross-row step at all), S by ds_swizzle, the
 //     first lane with incl >= u*S per row from v_mbcnt (bits below me == bits below my row);
-//   * level 2: that lane deals its <= 8 masked values to the lanes of its row through LDS and
+//   * level 2: that lane deals its <= 16 masked values to the lanes of its row through LDS and
 //     the same scan + first-lane pick runs across candidates; the winner publishes the choice.
 // Draw semantics: the 16-lane variant of the scan specification; the GPU
 // tests hold it bit-exact against the CPU restatement of that specification.
@@ -43,18 +43,18 @@ __device__ inline bool some_row_empty(uint64_t x) {
   return ((x - 0x0001000100010001ull) & ~x & 0x8000800080008000ull) != 0;
 }
 
-// CH: chunks of 64 candidates (1: n <= 64, 2: n <= 128).  FUSED: costs and the update's table too.
+// CH: chunks of 64 candidates (n <= 64 * CH, CH <= 4).  FUSED: costs and the update's table too.
 template <int CH, bool LOGP, bool FUSED, bool CVRP>
 __global__ void __launch_bounds__(256)
 scan16_kernel(const SampleParams p) {
   constexpr int NJ = CH * 4;                            // candidates per lane
   constexpr int ROWF = CH * 64;                         // padded row length of this layout
-  constexpr int S2 = CH == 1 ? 2 : 3;                   // scan steps that cover NJ slots
+  constexpr int S2 = CH == 1 ? 2 : (CH == 2 ? 3 : 4);   // scan steps that cover NJ slots
   __shared__ __attribute__((aligned(16))) float open_flags[16][ROWF];
   // per ant: [0..15] candidate slots of the chosen lane (NJ used), [16] threshold, [17] chosen lane, [18] choice
   __shared__ __attribute__((aligned(16))) float pick[16][24];
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
-  __shared__ uint32_t hub_s[16][4];                     // CVRP: per ant, set of nodes that follow the depot
+  __shared__ uint32_t hub_s[16][8];                     // CVRP: per ant, set of nodes that follow the depot (n <= 256)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, s = lane & 15;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -92,7 +92,7 @@ scan16_kernel(const SampleParams p) {
   }
   pk[s] = 0.0f;                                         // slots >= NJ stay zero for the whole kernel
   if (s < 8) pk[16 + s] = 0.0f;
-  if (s < 4) hub_l[s] = 0u;
+  if (s < 8) hub_l[s] = 0u;
   const int ubase = (lane & 48) << 2;                   // ds_bpermute byte address of this row's lane 0
   // slot j = s of the chosen lane L is candidate (j/4)*64 + L*4 + j%4; lanes beyond NJ hold no slot
   const int cbase = s < NJ ? ((s >> 2) << 6) | (s & 3) : 0;
@@ -282,12 +282,22 @@ static hipError_t launch16(const SampleParams &sp, bool logp, hipStream_t s) {
   return hipGetLastError();
 }
 
-// entries used by daco_tsp_sample / daco_cvrp_sample for n <= 128 in DACO_SCAN mode
+// entries used by daco_tsp_sample / daco_cvrp_sample for n <= DACO_SCAN16_MAX_N in DACO_SCAN mode
 hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
-  return sp.n <= 64 ? launch16<1, false>(sp, logp, s) : launch16<2, false>(sp, logp, s);
+  switch ((sp.n + 63) / 64) {
+    case 1: return launch16<1, false>(sp, logp, s);
+    case 2: return launch16<2, false>(sp, logp, s);
+    case 3: return launch16<3, false>(sp, logp, s);
+    default: return launch16<4, false>(sp, logp, s);
+  }
 }
 hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
-  return sp.n <= 64 ? launch16<1, true>(sp, logp, s) : launch16<2, true>(sp, logp, s);
+  switch ((sp.n + 63) / 64) {
+    case 1: return launch16<1, true>(sp, logp, s);
+    case 2: return launch16<2, true>(sp, logp, s);
+    case 3: return launch16<3, true>(sp, logp, s);
+    default: return launch16<4, true>(sp, logp, s);
+  }
 }
 
 }  // namespace daco

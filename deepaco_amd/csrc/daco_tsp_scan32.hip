@@ -1,7 +1,7 @@
 // daco_tsp_scan32.hip -- TSP tour construction, prefix-scan draw, TWO ants per wavefront.
 //
 // Same reference behaviour as daco_tsp_sample.hip in DACO_SCAN mode (tsp/aco.py:134-177 with the
-// roulette draw of tsp_nls/aco.py:260-275), for 128 < n <= 1024.  The one-ant-per-wave kernel is
+// roulette draw of tsp_nls/aco.py:260-275), for 256 < n <= 512.  The one-ant-per-wave kernel is
 // instruction-issue bound and two thirds of its instructions are per-STEP overhead (DPP scan,
 // ballot, lane picks, stores, loop) rather than per-candidate work.  Here each 32-lane half of a
 // wave builds one tour, so that overhead is paid once for two ants:

@@ -42,7 +42,7 @@ extern "C" {
 #define DACO_RACE_PHILOX 1 /* exponential race, Philox4x32-10 noise generated in-kernel */
 #define DACO_SCAN 2        /* roulette / inverse-CDF by wavefront prefix scan, one uniform per step.
                             * daco_tsp_sample and daco_cvrp_sample pack four ants per wavefront for
-                            * n <= 128 and two for 128 < n <= 1024 (the 16- and 32-lane variants of the
+                            * n <= 256 and two for 256 < n <= 512 (the 16- and 32-lane variants of the
                             * scan); everything else uses one ant per wavefront. */
 #define DACO_SCAN_WAVE 3   /* DACO_SCAN with the one-ant-per-wavefront layout for every n: the draw
                             * daco_pick_move / daco_sibling_sample make (there it is a synonym of

@@ -190,8 +190,8 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
 }
 
 /* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274.
- * `lanes` = 64 (one ant per wavefront), 32 (two ants per wavefront, 128 < n <= 1024) or 16 (four ants
- * per wavefront, n <= 128); vec = 4 below 64 lanes:
+ * `lanes` = 64 (one ant per wavefront), 32 (two ants per wavefront, 256 < n <= 512) or 16 (four ants
+ * per wavefront, n <= 256); vec = 4 below 64 lanes:
  *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
  *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
  *              (lanes = 32: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
@@ -206,7 +206,7 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  *       candidate with p > 0 of the lane;
  *     lanes = 32: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
  *       first j with scan[j] >= thr and p_j > 0, else the last j with p_j > 0. */
-int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 128 ? 16 : (n <= 1024 ? 32 : 64)); }
+int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? 16 : (n <= 512 ? 32 : 64)); }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
                      uint64_t iter, uint32_t gid, int t, float *pr, int lanes) {
