@@ -17,6 +17,8 @@
 #include "daco_device.h"
 #include "../../include/deepaco_hip.h"
 
+#include <cstdlib>
+
 namespace daco {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,9 +34,12 @@ constexpr int LAYER_FLOATS = 32 * 128 + 128 + 32 * 32 + 32 + 4 * 32;
 __host__ __device__ inline size_t off_layer(int feats, int l) { return (size_t)32 * feats + 32 + 64 + (size_t)l * LAYER_FLOATS; }
 __host__ __device__ inline size_t off_head(int feats) { return off_layer(feats, 12); }
 constexpr int HEAD_FLOATS = 2 * (32 * 32 + 32) + 32 + 1;
+constexpr int GNN_SPLIT_MIN_EDGES = 200000;   // above this a layer is two launches (edge | node), below it one
 
-__device__ inline float silu(float x) { return x / (1.0f + expf(-x)); }
-__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1/(1+e^-x) with the hardware reciprocal (1 ulp) instead of the IEEE division sequence: the two
+// activations are evaluated 2*E*32 times per layer and were a quarter of the layer's VALU work
+__device__ inline float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+__device__ inline float silu(float x) { return x * sigmoidf(x); }
 
 // x = silu(v_lin0(x)); X1234(0) = layer-0 node linears.  8 nodes per 256-thread workgroup.
 __global__ void __launch_bounds__(256)
@@ -62,14 +67,20 @@ gnn_node_init_kernel(int n, int feats, const float *xin, const float *params, fl
   }
 }
 
-// w = silu(e_lin0(edge_attr))
+// w = silu(e_lin0(edge_attr)); four channels per thread (16-byte stores)
 __global__ void __launch_bounds__(256)
 gnn_edge_init_kernel(int E, int feats, const float *attr, const float *params, float *w) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)E * U) return;
-  const int e = (int)(idx >> 5), o = (int)(idx & 31);
+  if (idx >= (long)E * 8) return;
+  const int e = (int)(idx >> 3), c0 = (int)(idx & 7) * 4;
   const float *W = params + 32 * feats + 32, *b = W + 32;
-  w[idx] = silu(fmaf(attr[e], W[o], b[o]));
+  const float a = attr[e];
+  float4 out;
+  out.x = silu(fmaf(a, W[c0 + 0], b[c0 + 0]));
+  out.y = silu(fmaf(a, W[c0 + 1], b[c0 + 1]));
+  out.z = silu(fmaf(a, W[c0 + 2], b[c0 + 2]));
+  out.w = silu(fmaf(a, W[c0 + 3], b[c0 + 3]));
+  *reinterpret_cast<float4 *>(w + (size_t)e * U + c0) = out;
 }
 
 // one 32-edge x 32-channel tile: acc = Wm * a-rows, with the K split (0..15 | 16..31) over the two
@@ -92,47 +103,101 @@ __device__ inline f32x16 tile_gemm(const float *row, const float *Wm, int lane) 
 // MFMA 32x32 output layout: register r of lane l holds D[row][col], col = l & 31,
 __device__ inline int drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-__global__ void __launch_bounds__(256)
-gnn_layer_kernel(int n, int E, int feats, int layer, int edge_blocks, const int *src, const int *dst, const int *rowptr,
-                 const int *perm, const float *params, const float *x0, const float *X, const float *w0,
-                 float *x1out, float *Xnext, float *w1out) {
-  const float *lp = params + off_layer(feats, layer);
-  const float *We = lp + 32 * 128 + 128, *be = We + 32 * 32;
-  const float *sv = be + 32, *tv = sv + 32, *se = tv + 32, *te = se + 32;
-  if ((int)blockIdx.x < edge_blocks) {
-    // ---------------- edge update: 4 waves, one 32-edge tile each
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e0 = (blockIdx.x * 4 + wave) * 32;
-    if (e0 >= E) return;
-    const int o = lane & 31;
-    const int er = min(e0 + o, E - 1);
-    const f32x16 acc = tile_gemm(w0 + (size_t)er * U, We, lane);
-    const int s_l = src[er], d_l = dst[er];              // lane (l&31) holds its edge's endpoints
-    const float bo = be[o], sc = se[o], sh = te[o];
+// ---------------- edge update: 4 waves, one 32-edge tile each.
+// The MFMA result (lane = channel, 16 edge rows per lane) is turned through a wave-private LDS tile
+// so that the epilogue runs edge-major with 16-byte accesses: the residual, the two node terms
+// and the store are four accesses per array and lane instead of sixteen 4-byte ones.
+__device__ inline void edge_update(int E, int wg, const int *src, const int *dst, const float *We, const float *be,
+                                   const float *se, const float *te, const float *X, const float *w0, float *w1out,
+                                   float (*tile)[36]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int e0 = (wg * 4 + wave) * 32;
+  if (e0 >= E) return;
+  const int o = lane & 31;
+  // eight lanes per edge (4 channels each), eight edges per pass: every 16-byte access of a pass is
+  // one contiguous 1 KiB run for the edge arrays and whole 128-byte node rows for the gathers
+  const int c0 = (lane & 7) * 4;
+  float4 res[4];                                         // this lane's part of the old edge state (tile + residual)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = drow(r, lane), e = e0 + row;
-      const int s = __shfl(s_l, row), d = __shfl(d_l, row);
-      if (e < E) {
-        const float z = acc[r] + bo + X[(size_t)s * 128 + 64 + o] + X[(size_t)d * 128 + 96 + o];
-        const float y = fmaf(z, sc, sh);
-        w1out[(size_t)e * U + o] = w0[(size_t)e * U + o] + silu(y);
-      }
-    }
-    return;
+  for (int q = 0; q < 4; ++q) {
+    const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
+    res[q] = *reinterpret_cast<const float4 *>(w0 + (size_t)e * U + c0);
+    *reinterpret_cast<float4 *>(&tile[el][c0]) = res[q];
   }
-  // ---------------- node update (+ next layer's node linears): 8 nodes per workgroup
-  __shared__ float xs[8][U];
+  __builtin_amdgcn_wave_barrier();
+  const f32x16 acc = tile_gemm(&tile[o][0], We, lane);   // A rows out of LDS: the global read above was coalesced
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[drow(r, lane)][o] = acc[r];
+  __builtin_amdgcn_wave_barrier();
+  const float4 bb = *reinterpret_cast<const float4 *>(be + c0);
+  const float4 sc = *reinterpret_cast<const float4 *>(se + c0), sh = *reinterpret_cast<const float4 *>(te + c0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int el = q * 8 + (lane >> 3), e = e0 + el;
+    if (e < E) {
+      const int s = src[e], d = dst[e];
+      const float4 g = *reinterpret_cast<const float4 *>(&tile[el][c0]);
+      const float4 a3 = *reinterpret_cast<const float4 *>(X + (size_t)s * 128 + 64 + c0);
+      const float4 a4 = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 96 + c0);
+      float4 out;
+      out.x = res[q].x + silu(fmaf(g.x + bb.x + a3.x + a4.x, sc.x, sh.x));
+      out.y = res[q].y + silu(fmaf(g.y + bb.y + a3.y + a4.y, sc.y, sh.y));
+      out.z = res[q].z + silu(fmaf(g.z + bb.z + a3.z + a4.z, sc.z, sh.z));
+      out.w = res[q].w + silu(fmaf(g.w + bb.w + a3.w + a4.w, sc.w, sh.w));
+      *reinterpret_cast<float4 *>(w1out + (size_t)e * U + c0) = out;
+    }
+  }
+}
+
+// ---------------- node update (+ next layer's node linears): 8 nodes per workgroup, 32 lanes per node.
+// The neighbour ids of a node are fetched 32 at a time by its lanes (one coalesced load), so the
+// feature gathers X[dst] depend on a lane exchange, not on a second trip to memory, and the
+// compiler can keep several of them in flight.
+__device__ inline void node_update(int n, int wg, int feats, int layer, const int *dst, const int *rowptr, const int *perm,
+                                   const float *params, const float *sv, const float *tv, const float *x0, const float *X,
+                                   const float *w0, float *x1out, float *Xnext, float (*xs)[U]) {
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
-  const int i = ((int)blockIdx.x - edge_blocks) * 8 + il;
+  const int i = wg * 8 + il;
   float xn = 0.0f;
   if (i < n) {
     const int lo = rowptr[i], hi = rowptr[i + 1];
-    float agg = 0.0f;
-    for (int q = lo; q < hi; ++q) {
-      const int e = perm ? perm[q] : q;
-      agg = fmaf(sigmoidf(w0[(size_t)e * U + o]), X[(size_t)dst[e] * 128 + 32 + o], agg);
+    // eight lanes per incident edge (4 channels each), four edges per pass: 16-byte loads of whole
+    // 128-byte rows.  Edge j of the list goes to lane group j % 4; the four partial sums are added
+    // at the end (a fixed order, independent of the graph's size).
+    const int grp = o >> 3, c0 = (o & 7) * 4;
+    float4 part = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int q0 = lo; q0 < hi; q0 += 32) {
+      const int m = min(32, hi - q0);
+      int ev = 0, dv = 0;
+      if (o < m) {
+        ev = perm ? perm[q0 + o] : q0 + o;
+        dv = dst[ev];
+      }
+#pragma unroll 2
+      for (int j = 0; j < m; j += 4) {
+        const int jj = j + grp;
+        const int e = __shfl(ev, jj, 32), d = __shfl(dv, jj, 32);
+        if (jj < m) {
+          const float4 wv = *reinterpret_cast<const float4 *>(w0 + (size_t)e * U + c0);
+          const float4 xv = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 32 + c0);
+          part.x = fmaf(sigmoidf(wv.x), xv.x, part.x);
+          part.y = fmaf(sigmoidf(wv.y), xv.y, part.y);
+          part.z = fmaf(sigmoidf(wv.z), xv.z, part.z);
+          part.w = fmaf(sigmoidf(wv.w), xv.w, part.w);
+        }
+      }
     }
+    part.x += __shfl_xor(part.x, 8, 32);  part.y += __shfl_xor(part.y, 8, 32);
+    part.z += __shfl_xor(part.z, 8, 32);  part.w += __shfl_xor(part.w, 8, 32);
+    part.x += __shfl_xor(part.x, 16, 32); part.y += __shfl_xor(part.y, 16, 32);
+    part.z += __shfl_xor(part.z, 16, 32); part.w += __shfl_xor(part.w, 16, 32);
+    // back to one channel per lane: channel o is component o%4 of the lanes holding channels (o/4)*4..
+    const int from = o >> 2;
+    const float p0 = __shfl(part.x, from, 32), p1 = __shfl(part.y, from, 32), p2 = __shfl(part.z, from, 32),
+                p3 = __shfl(part.w, from, 32);
+    float agg = (o & 2) ? ((o & 1) ? p3 : p2) : ((o & 1) ? p1 : p0);
     agg = agg / (float)max(hi - lo, 1);
     const float y = fmaf(X[(size_t)i * 128 + o] + agg, sv[o], tv[o]);
     xn = x0[(size_t)i * U + o] + silu(y);
@@ -151,6 +216,39 @@ gnn_layer_kernel(int n, int E, int feats, int layer, int edge_blocks, const int 
   }
 }
 
+// one launch per layer (small graphs are launch-bound): edge workgroups first, then node workgroups
+__global__ void __launch_bounds__(256)
+gnn_layer_kernel(int n, int E, int feats, int layer, int edge_blocks, const int *src, const int *dst, const int *rowptr,
+                 const int *perm, const float *params, const float *x0, const float *X, const float *w0,
+                 float *x1out, float *Xnext, float *w1out) {
+  const float *lp = params + off_layer(feats, layer);
+  const float *We = lp + 32 * 128 + 128, *be = We + 32 * 32;
+  const float *sv = be + 32, *tv = sv + 32, *se = tv + 32, *te = se + 32;
+  __shared__ float xs[8][U];
+  __shared__ __attribute__((aligned(16))) float tile[4][32][36];
+  if ((int)blockIdx.x < edge_blocks) { edge_update(E, blockIdx.x, src, dst, We, be, se, te, X, w0, w1out, tile[threadIdx.x >> 6]); return; }
+  node_update(n, (int)blockIdx.x - edge_blocks, feats, layer, dst, rowptr, perm, params, sv, tv, x0, X, w0, x1out, Xnext, xs);
+}
+
+// large (batched) graphs: the two halves as separate launches, so the node half -- latency-bound
+// gathers -- runs at its own, much smaller register budget and full occupancy
+__global__ void __launch_bounds__(256)
+gnn_edge_kernel(int E, int feats, int layer, const int *src, const int *dst, const float *params, const float *X,
+                const float *w0, float *w1out) {
+  const float *lp = params + off_layer(feats, layer);
+  const float *We = lp + 32 * 128 + 128, *be = We + 32 * 32, *se = be + 32 + 64, *te = se + 32;
+  __shared__ __attribute__((aligned(16))) float tile[4][32][36];
+  edge_update(E, blockIdx.x, src, dst, We, be, se, te, X, w0, w1out, tile[threadIdx.x >> 6]);
+}
+__global__ void __launch_bounds__(256)
+gnn_node_kernel(int n, int feats, int layer, const int *dst, const int *rowptr, const int *perm, const float *params,
+                const float *x0, const float *X, const float *w0, float *x1out, float *Xnext) {
+  const float *lp = params + off_layer(feats, layer);
+  const float *sv = lp + 32 * 128 + 128 + 32 * 32 + 32, *tv = sv + 32;
+  __shared__ float xs[8][U];
+  node_update(n, blockIdx.x, feats, layer, dst, rowptr, perm, params, sv, tv, x0, X, w0, x1out, Xnext, xs);
+}
+
 // head: heu = sigmoid(W3 silu(W2 silu(W1 w + b1) + b2) + b3), three chained tile GEMMs
 __global__ void __launch_bounds__(256)
 gnn_head_kernel(int E, int feats, const float *params, const float *w, float *heu) {
@@ -161,9 +259,19 @@ gnn_head_kernel(int E, int feats, const float *params, const float *w, float *he
   const int e0 = (blockIdx.x * 4 + wave) * 32;
   if (e0 >= E) return;
   const int o = lane & 31;
-  const int er = min(e0 + o, E - 1);
-  f32x16 acc = tile_gemm(w + (size_t)er * U, W1, lane);
   float (*t)[36] = tile[wave];
+  {                                                       // the 32 x 32 input tile: coalesced 1 KiB runs into LDS
+    const int c0 = (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
+      *reinterpret_cast<float4 *>(&t[el][c0]) = *reinterpret_cast<const float4 *>(w + (size_t)e * U + c0);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  f32x16 acc = tile_gemm(&t[o][0], W1, lane);
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int r = 0; r < 16; ++r) t[drow(r, lane)][o] = silu(acc[r] + b1[o]);
   __builtin_amdgcn_wave_barrier();
@@ -215,12 +323,20 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
   for (int k = 0; k < 2; ++k) { wb[k] = (float *)p; p += align256((size_t)E * 32 * 4); }
   const int node_blocks = (n + 7) / 8, edge_blocks = (E + 127) / 128;
   hipLaunchKernelGGL(gnn_node_init_kernel, dim3(node_blocks), dim3(256), 0, s, n, feats, x, params, xb[0], Xb[0]);
-  hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 32 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
+  hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 8 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
   int cur = 0;
   for (int l = 0; l < 12; ++l) {
     float *wout = (l == 11 && emb) ? emb : wb[cur ^ 1];
-    hipLaunchKernelGGL(gnn_layer_kernel, dim3(edge_blocks + node_blocks), dim3(256), 0, s, n, E, feats, l, edge_blocks, src,
-                       dst, rowptr, perm, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
+    static const int split_min = getenv("DACO_GNN_SPLIT_MIN_EDGES") ? atoi(getenv("DACO_GNN_SPLIT_MIN_EDGES")) : GNN_SPLIT_MIN_EDGES;
+    if (E < split_min) {
+      hipLaunchKernelGGL(gnn_layer_kernel, dim3(edge_blocks + node_blocks), dim3(256), 0, s, n, E, feats, l, edge_blocks, src,
+                         dst, rowptr, perm, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
+    } else {
+      hipLaunchKernelGGL(gnn_node_kernel, dim3(node_blocks), dim3(256), 0, s, n, feats, l, dst, rowptr, perm, params, xb[cur],
+                         Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1]);
+      hipLaunchKernelGGL(gnn_edge_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, l, src, dst, params, Xb[cur], wb[cur],
+                         wout);
+    }
     if (l == 11 && emb) { wb[cur ^ 1] = emb; }
     cur ^= 1;
   }
