@@ -47,6 +47,9 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 110          # include/deepaco_hip.h DACO_VERSION this table was written against
+
+
 class DacoError(RuntimeError):
     pass
 
@@ -63,6 +66,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
+        if h.daco_version() != ABI_VERSION:     # a stale .so would be called with the wrong argument lists
+            raise DacoError(f"{LIB_PATH} has ABI version {h.daco_version()}, this package binds {ABI_VERSION}: "
+                            "rebuild it (make -C deepaco_amd/csrc)")
         _lib = h
     return _lib
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 100 /* 0.1.0 */
+#define DACO_VERSION 110 /* 0.1.10: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
