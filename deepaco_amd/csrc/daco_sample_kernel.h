@@ -305,7 +305,7 @@ tsp_sample_kernel(const SampleParams p) {
       float r = u01(ux) * S;
       r = r > 0.0f ? r : 1.401298464e-45f;               // keep r > 0 if u*S underflows
       const uint64_t m = __ballot(incl >= r && part > 0.0f);
-      if (m == 0) { infeasible = true; choice = 0; }
+      if (m == 0) { infeasible = true; choice = 0; own_lane = -1; }   // (node 0 is marked by index below)
       else {
         const int L = __builtin_ctzll(m);
         const float excl = L ? readlane_f(incl, L - 1) : 0.0f;

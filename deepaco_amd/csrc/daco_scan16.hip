@@ -158,7 +158,8 @@ scan16_kernel(const SampleParams p) {
     const float S = row_bcast_last(incl);
     const float r = fmaxf(u * S, 1.401298464e-45f);     // keep r > 0 if u*S underflows
     const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP16_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP16_OGT) & act;
-    feasible &= __builtin_amdgcn_fcmpf(S, 0.0f, FCMP16_OGT) | ~act;    // S > 0 <=> some open candidate has p > 0
+    const uint64_t alive = __builtin_amdgcn_fcmpf(S, 0.0f, FCMP16_OGT);   // S > 0 <=> some open candidate has p > 0
+    feasible &= alive | ~act;
     // what is left to cover inside the chosen lane: r - incl[L-1]; lane L forms its own
     float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
     const float thr = r - excl;
@@ -174,7 +175,7 @@ scan16_kernel(const SampleParams p) {
     const float2 tl = *(const float2 *)(pk + 16);
     const int mychoice = cbase + (__float_as_int(tl.y) << 2);
     const float sc = row_scan_add<S2>(cv);
-    const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP16_OGT) & act;
+    const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP16_OGT) & act & alive;   // (a dead row holds stale slots)
     uint64_t k = __builtin_amdgcn_fcmpf(sc, tl.x, FCMP16_OGE) & pos;
     if (__builtin_expect(some_row_empty(k), 0)) {
       // rounding: no candidate of a row reached thr -> that lane's last open candidate with p > 0
@@ -191,8 +192,10 @@ scan16_kernel(const SampleParams p) {
       if (!CVRP || mychoice != 0) fl[mychoice] = 0.0f;  // visited (the CVRP depot stays open)
     }
     __builtin_amdgcn_wave_barrier();
-    const int choice = __float_as_int(pk[18]);
+    // no feasible candidate (flagged; the reference raises): move to node 0 like the one-ant kernel and the oracle
+    const int choice = S > 0.0f ? __float_as_int(pk[18]) : 0;
     __builtin_amdgcn_wave_barrier();
+    if constexpr (!CVRP) { if (s == 0 && !(S > 0.0f)) fl[0] = 0.0f; }
 
     // ---- outputs: lane 0 of every row that is still building
     const bool writer = __builtin_amdgcn_inverse_ballot_w64(act & LEAD);

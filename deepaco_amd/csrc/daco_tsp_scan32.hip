@@ -135,7 +135,8 @@ tsp_scan32_kernel(const SampleParams p) {
       const float S = half_bcast_last(incl);
       const float r = fmaxf(u * S, 1.401298464e-45f);   // keep r > 0 if u*S underflows
       const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT);
-      feasible &= __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT);          // S > 0 <=> some open candidate has p > 0
+      const uint64_t alive = __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT);    // S > 0 <=> some open candidate has p > 0
+      feasible &= alive;
       // what is left to cover inside the chosen lane: r - incl[L-1]; lane L forms its own
       float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
       excl = s == 0 ? 0.0f : excl;
@@ -155,7 +156,7 @@ tsp_scan32_kernel(const SampleParams p) {
       const int mychoice = cbase + (__float_as_int(tl.y) << 2);
       const float cv = cvraw * fl[mychoice];
       const float sc = half_scan_add<(NJ > 16)>(cv);
-      const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP_OGT);
+      const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP_OGT) & alive;   // (a dead row holds stale slots)
       const uint64_t k = __builtin_amdgcn_fcmpf(sc, tl.x, FCMP_OGE) & pos;
       uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
       if (__builtin_expect(k0 == 0 || k1 == 0, 0)) {
@@ -170,10 +171,12 @@ tsp_scan32_kernel(const SampleParams p) {
         fl[mychoice] = 0.0f;                            // visited
       }
       __builtin_amdgcn_wave_barrier();
-      const int choice = __float_as_int(pk[34]);
+      // no feasible candidate (flagged; the reference raises): move to node 0 like the one-ant kernel and the oracle
+      const int choice = S > 0.0f ? __float_as_int(pk[34]) : 0;
       __builtin_amdgcn_wave_barrier();
 
       if (lead) {
+        if (!(S > 0.0f)) fl[0] = 0.0f;
         *(int64_t *)(path_t + a8) = choice;
         if constexpr (LOGP) {
           const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);

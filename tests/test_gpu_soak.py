@@ -1,0 +1,17 @@
+"""Randomised parity soak through the C ABI (tests/soak_parity.py): random sizes across the three lane layouts,
+ant counts, seeds and value distributions (uniform, heavy-tailed, sparse with exact zeros, denormal-scale), TSP
+and CVRP, infeasible draws included -- every tour must equal the oracle's."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [3, 20240917])
+def test_random_cases_match_the_oracle(seed):
+    import soak_parity
+    assert soak_parity.run(250, seed, save_failures=False) == 0

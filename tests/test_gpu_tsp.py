@@ -150,12 +150,10 @@ def test_scan_draw_extreme_rows_bit_exact(n, A, wave):
     paths, logp, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode=mode, seed=77, it=1, require_prob=True)
     rp, rl, rc = oracle.tsp_sample_scan(P, A, 77, 1, require_prob=True, wave=wave)
     assert int(flags[0]) == (1 if rc else 0)
+    # (a draw without feasible candidate is flagged -- the reference raises -- and moves to node 0 in every kernel)
+    assert np.array_equal(paths[0].cpu().numpy(), rp)
     if rc == 0:
-        assert np.array_equal(paths[0].cpu().numpy(), rp)
         np.testing.assert_allclose(logp[0].cpu().numpy(), rl, atol=ATOL_LOGP, rtol=1e-5)
-    else:                                                  # ants that stayed feasible still match in full
-        ok = np.array([len(set(rp[:, a])) == n for a in range(A)])
-        assert ok.any() and np.array_equal(paths[0].cpu().numpy()[:, ok], rp[:, ok])
 
 
 @pytest.mark.parametrize("mode", ["scan", "race"])
