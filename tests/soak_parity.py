@@ -73,9 +73,80 @@ def one_case(c, rng, dev, save_failures):
     return ok
 
 
+def random_routes(rng, n, A, demand=None, cap=None):
+    """[L, A] int64: random permutations (TSP) or random feasible CVRP routes padded with the depot."""
+    if demand is None:
+        return np.stack([rng.permutation(n) for _ in range(A)], axis=1).astype(np.int64)
+    cols = []
+    for _ in range(A):
+        order, route, load = rng.permutation(np.arange(1, n)), [0], 0.0
+        for c in order:
+            if load + demand[c] > cap:
+                route.append(0)
+                load = 0.0
+            route.append(int(c))
+            load += demand[c]
+        route.append(0)
+        cols.append(route)
+    L = max(len(c) for c in cols)
+    return np.stack([np.array(c + [0] * (L - len(c))) for c in cols], axis=1).astype(np.int64)
+
+
+def update_case(c, rng, dev):
+    """pheromone update (symmetric / directed, AS / elitist / MMAS clamp) and 2-opt against the oracle."""
+    n = int(rng.choice([rng.integers(4, 40), rng.integers(40, 130), rng.integers(130, 520)]))
+    A = int(rng.integers(1, 150))
+    tau = (rng.random((n, n)) + 0.05).astype(np.float32)
+    elitist = bool(rng.integers(0, 3) == 0)
+    clamp = bool(rng.integers(0, 3) == 0)
+    cmin, cmax = (0.2, 0.9) if clamp else (0.0, 0.0)
+    decay = float(rng.choice([0.9, 0.5, 0.99]))
+    directed = n >= 6 and bool(rng.integers(0, 2))
+    if directed:
+        demand = np.concatenate(([0.0], rng.integers(1, 10, n - 1))).astype(np.float32)
+        paths = random_routes(rng, n, A, demand, float(rng.integers(10, 40)))
+    else:
+        paths = random_routes(rng, n, A)
+    costs = (rng.random(A) * 10 + 1).astype(np.float32)
+    t = torch.from_numpy(tau)[None].clone().contiguous().to(dev)
+    kw = {}
+    if clamp:
+        kw = dict(clamp_min=torch.full((1,), cmin, device=dev), clamp_max=torch.full((1,), cmax, device=dev))
+    engine.pheromone_update_(t, torch.from_numpy(paths)[None].contiguous().to(dev), torch.from_numpy(costs)[None].to(dev),
+                             decay, elitist, not directed, floor=1e-10 if directed else 0.0, **kw)
+    if directed:
+        ref = oracle.pheromone_update_directed(tau, paths, costs, decay, None, elitist, cmin, cmax, 1e-10)
+    else:
+        ref = oracle.pheromone_update_tsp(tau, paths, costs, decay, elitist, cmin, cmax)
+    ok = np.array_equal(t[0].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    if ok and not directed and n <= 200:                   # 2-opt on a few of the tours, random (asymmetric) matrix
+        d = (rng.random((n, n)) + 0.01).astype(np.float32)
+        if rng.integers(0, 2):
+            d = ((d + d.T) / 2).astype(np.float32)
+        tours = paths[:, :min(A, 6)].T.astype(np.uint16).copy()
+        cap = int(rng.choice([1, 5, 1000]))
+        out, sweeps = engine.two_opt_(torch.from_numpy(d).to(dev), torch.from_numpy(tours.astype(np.int16)).to(dev), cap,
+                                      want_sweeps=True)
+        rt, rs = oracle.two_opt_batch(d, tours, cap)
+        ok = np.array_equal(out.cpu().numpy().astype(np.uint16), rt) and np.array_equal(sweeps[0].cpu().numpy(), rs)
+    if not ok:
+        print(f"MISMATCH update case {c}: n={n} A={A} elitist={elitist} clamp={clamp} directed={directed}", flush=True)
+    return ok
+
+
+def run_updates(cases, seed):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    return sum(0 if update_case(c, rng, dev) else 1 for c in range(cases))
+
+
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     t0 = time.time()
     n_bad = run(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    print(f"{n_cases} cases, {n_bad} mismatches, {time.time() - t0:.1f} s")
+    print(f"{n_cases} sampler cases, {n_bad} mismatches, {time.time() - t0:.1f} s")
+    t0 = time.time()
+    u_bad = run_updates(n_cases // 4, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n_cases // 4} update / 2-opt cases, {u_bad} mismatches, {time.time() - t0:.1f} s")
+    n_bad += u_bad
     sys.exit(1 if n_bad else 0)

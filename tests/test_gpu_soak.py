@@ -15,3 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def test_random_cases_match_the_oracle(seed):
     import soak_parity
     assert soak_parity.run(250, seed, save_failures=False) == 0
+
+
+def test_random_updates_and_two_opt_match_the_oracle():
+    import soak_parity
+    assert soak_parity.run_updates(60, 11) == 0
