@@ -43,22 +43,24 @@ def one_case(c, rng, dev, save_failures):
     P = P.astype(np.float32)
     seed, it = int(rng.integers(1, 2 ** 40)), int(rng.integers(0, 1000))
     wave = bool(rng.integers(0, 4) == 0)
+    race = bool(rng.integers(0, 5) == 0)
+    mode = "race" if race else ("scan_wave" if wave else "scan")
     tau = torch.from_numpy(P)[None].contiguous().to(dev)
     eta = torch.ones(1, n, n, device=dev)
     cvrp = n >= 4 and rng.integers(0, 3) == 0
     if cvrp:
         demand = np.concatenate(([0.0], rng.integers(1, 10, n - 1))).astype(np.float32)
         cap = float(rng.integers(10, 60))
-        paths, _, _, lens, flags = engine.cvrp_sample(tau, eta, torch.from_numpy(demand).to(dev), cap, A,
-                                                      mode="scan_wave" if wave else "scan", seed=seed, it=it)
-        rp, _, L = oracle.cvrp_sample_rng(P, demand, cap, A, "scan_wave" if wave else "scan", seed, it)
+        paths, _, _, lens, flags = engine.cvrp_sample(tau, eta, torch.from_numpy(demand).to(dev), cap, A, mode=mode,
+                                                      seed=seed, it=it)
+        rp, _, L = oracle.cvrp_sample_rng(P, demand, cap, A, mode, seed, it)
         if L < 0:
             ok = int(flags[0]) != 0
         else:
             ok = int(flags[0]) == 0 and L == int(lens.max()) and np.array_equal(paths[0, :L].cpu().numpy(), rp)
     else:
-        paths, _, _, flags = engine.tsp_sample(tau, eta, A, mode="scan_wave" if wave else "scan", seed=seed, it=it)
-        rp, _, rc = oracle.tsp_sample_scan(P, A, seed, it, wave=wave)
+        paths, _, _, flags = engine.tsp_sample(tau, eta, A, mode=mode, seed=seed, it=it)
+        rp, _, rc = oracle.tsp_sample_race(P, A, seed, it) if race else oracle.tsp_sample_scan(P, A, seed, it, wave=wave)
         if rc:                         # a draw without feasible candidate: flagged, and both move to node 0
             ok = int(flags[0]) == 1 and np.array_equal(paths[0].cpu().numpy(), rp)
         else:
@@ -69,7 +71,7 @@ def one_case(c, rng, dev, save_failures):
             np.savez(os.path.join(ROOT, "gpurun_out", f"soak_fail_{c}.npz"), P=P, A=A, seed=seed, it=it, wave=wave,
                      cvrp=cvrp, gpu_paths=paths[0].cpu().numpy(), flags=flags.cpu().numpy(),
                      ref_paths=rp if rp is not None else np.zeros(1))
-        print(f"MISMATCH case {c}: n={n} A={A} kind={kind} wave={wave} cvrp={cvrp} seed={seed} it={it}", flush=True)
+        print(f"MISMATCH case {c}: n={n} A={A} kind={kind} mode={mode} cvrp={cvrp} seed={seed} it={it}", flush=True)
     return ok
 
 
