@@ -58,6 +58,17 @@ def one_case(c, rng, dev, save_failures):
             ok = int(flags[0]) != 0
         else:
             ok = int(flags[0]) == 0 and L == int(lens.max()) and np.array_equal(paths[0, :L].cpu().numpy(), rp)
+            if ok:                                          # the fused outputs: route costs and the deposit's table
+                d = (rng.random((n, n)) + 0.01).astype(np.float32)
+                d[0, 0] = 1e-10
+                D = torch.from_numpy(d)[None].to(dev)
+                p2, _, _, _, _, costs, table = engine.cvrp_sample(tau, eta, torch.from_numpy(demand).to(dev), cap, A,
+                                                                  mode=mode, seed=seed, it=it, dist=D, want_table=True)
+                t1, t2 = tau.clone(), tau.clone()
+                engine.pheromone_update_(t1, p2, costs, 0.9, False, False, floor=1e-10, nbr=table)
+                engine.pheromone_update_(t2, p2[:, :L].contiguous(), costs, 0.9, False, False, floor=1e-10)
+                ok = torch.equal(p2, paths) and torch.equal(t1, t2) and \
+                    np.array_equal(costs[0].cpu().numpy(), oracle.tour_costs(d, rp, closed=False))
     else:
         paths, _, _, flags = engine.tsp_sample(tau, eta, A, mode=mode, seed=seed, it=it)
         rp, _, rc = oracle.tsp_sample_race(P, A, seed, it) if race else oracle.tsp_sample_scan(P, A, seed, it, wave=wave)
@@ -65,6 +76,15 @@ def one_case(c, rng, dev, save_failures):
             ok = int(flags[0]) == 1 and np.array_equal(paths[0].cpu().numpy(), rp)
         else:
             ok = int(flags[0]) == 0 and np.array_equal(paths[0].cpu().numpy(), rp)
+            if ok and n >= 3:                               # the fused outputs: tour costs and the neighbour table
+                d = (rng.random((n, n)) + 0.01).astype(np.float32)
+                D = torch.from_numpy(d)[None].to(dev)
+                p2, _, _, _, costs, nbr = engine.tsp_sample(tau, eta, A, mode=mode, seed=seed, it=it, dist=D, want_nbr=True)
+                t1, t2 = tau.clone(), tau.clone()
+                engine.pheromone_update_(t1, p2, costs, 0.9, nbr=nbr)
+                engine.pheromone_update_(t2, p2, costs, 0.9)
+                ok = torch.equal(p2, paths) and torch.equal(t1, t2) and \
+                    np.array_equal(costs[0].cpu().numpy(), oracle.tour_costs(d, rp))
     if not ok:
         if save_failures:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
