@@ -571,6 +571,7 @@ class BatchedCVRP:
             self.pheromone = self.pheromone * self.min
         self.heuristic = (1 / self.distances) if heuristic is None else heuristic
         self.lowest_cost = torch.full((self.B,), float("inf"), device=distances.device)
+        self.shortest_path = None               # [B, Lmax] int64 once a step has run (zero-padded routes)
         self.sampler, self.iteration, self.ant_gid0 = sampler, 0, ant_gid0
         self.seed = torch.initial_seed() if seed is None else seed
 
@@ -585,7 +586,10 @@ class BatchedCVRP:
             dist=self.distances, want_table=True)
         self.iteration += 1
         self.last_lens, self.last_flags = lens, flags
-        new_max = track_best_(costs, paths, self.lowest_cost, None, mmas_scale=self.n if self.min_max else None)
+        if self.shortest_path is None or self.shortest_path.shape[1] != paths.shape[1]:
+            self.shortest_path = torch.zeros((self.B, paths.shape[1]), dtype=torch.int64, device=paths.device)
+        new_max = track_best_(costs, paths, self.lowest_cost, self.shortest_path,
+                              mmas_scale=self.n if self.min_max else None)
         cmin = cmax = None
         if self.min_max:
             if self.max is None:

@@ -149,6 +149,9 @@ def test_cvrp_fused_costs_and_table_equal_separate_passes(n, A, mode, elitist):
     col.run(3)
     col.check_feasible()
     assert bool((col.lowest_cost > 0).all())
+    # the recorded best route really has the recorded cost
+    best = engine.tour_costs(D, col.shortest_path.unsqueeze(2).contiguous(), closed=False)[:, 0]
+    torch.testing.assert_close(best, col.lowest_cost, rtol=1e-6, atol=0)
 
 
 def test_cvrp_class_run():
