@@ -95,6 +95,52 @@ class ACO():
     # ------------------------------------------------------------------ cvrp/aco.py:72-104
     @torch.no_grad()
     def run(self, n_iterations):
+        """The reference's loop (cvrp/aco.py:72-104) without its per-iteration host round trips: route costs and
+        the deposit's successor table come fused out of the construction kernel and the `if best_cost <
+        self.lowest_cost` bookkeeping is daco_track_best.  One sync at the end trims `shortest_path` to its route.
+        (If `gen_path` / `gen_path_costs` were replaced on the instance, the plain call sequence runs instead.)"""
+        if "gen_path" in self.__dict__ or "gen_path_costs" in self.__dict__ or type(self).gen_path is not ACO.gen_path \
+                or type(self).gen_path_costs is not ACO.gen_path_costs:
+            return self._run_plain(n_iterations)
+        dev = self.distances.device
+        dist = self.distances.detach().float().contiguous()
+        n = self.problem_size
+        lowest = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(1).clone()
+        shortest = torch.zeros((1, 2 * n + 1), dtype=torch.int64, device=dev)
+        if self.shortest_path is not None:
+            shortest[0, :self.shortest_path.numel()] = self.shortest_path
+        flags_seen = torch.zeros(1, dtype=torch.int32, device=dev)
+        for _ in range(n_iterations):
+            paths, _, _, lens, flags, costs, table = engine.cvrp_sample(
+                self.pheromone.detach(), self.heuristic.detach(), self.demand, self.capacity, self.n_ants, self.alpha,
+                self.beta, mode=self.sampler, seed=self.seed, it=self._calls, batch=1, dist=dist, want_table=True)
+            self._calls += 1
+            flags_seen |= flags
+            new_max = engine.track_best_(costs, paths, lowest, shortest,
+                                         mmas_scale=self.problem_size if self.min_max else None)
+            cmin = cmax = None
+            if self.min_max:
+                if self.max is None:
+                    self.pheromone *= new_max[0] / self.pheromone.max()
+                self.max = new_max[0]
+                cmin = torch.full((1,), float(self.min), device=dev)
+                cmax = new_max
+            tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+            engine.pheromone_update_(tau, paths, costs, self.decay, self.elitist, False, cmin, cmax, floor=1e-10,
+                                     nbr=table)
+            self.pheromone = tau[0]
+        fl = int(flags_seen[0])                      # the only host sync of the loop
+        if fl & 1:
+            raise ValueError("ACO.run: a transition row had no feasible candidate")
+        if fl & 2:
+            raise RuntimeError("ACO.run: route buffer too short")
+        route = shortest[0]
+        last = int(torch.nonzero(route).max()) if bool((route != 0).any()) else 0
+        self.lowest_cost, self.shortest_path = lowest[0], route[:last + 2].clone()
+        return self.lowest_cost
+
+    @torch.no_grad()
+    def _run_plain(self, n_iterations):
         for _ in range(n_iterations):
             paths = self.gen_path(require_prob=False)
             costs = self.gen_path_costs(paths)

@@ -167,6 +167,24 @@ def test_cvrp_class_run():
         ACO(d[0].to(dev()), demand[0].to(dev()), adaptive=True)
 
 
+@pytest.mark.parametrize("kw", [{}, {"elitist": True}, {"min_max": True}])
+@pytest.mark.parametrize("n", [30, 100])
+def test_cvrp_sync_free_run_equals_plain_sequence(kw, n):
+    """ACO.run (fused costs / successor table, device-side bookkeeping) == the reference's call sequence
+    gen_path -> gen_path_costs -> update_pheronome, pheromone bit for bit."""
+    from deepaco_amd.cvrp.aco import ACO
+    d, demand, _, _ = cvrp_instance(n, 5 * n)
+    a1 = ACO(d[0].to(dev()), demand[0].to(dev()), n_ants=24, device="cuda:0", seed=8, **kw)
+    a2 = ACO(d[0].to(dev()), demand[0].to(dev()), n_ants=24, device="cuda:0", seed=8, **kw)
+    r1, r2 = a1.run(6), a2._run_plain(6)
+    assert float(r1) == float(r2)
+    assert torch.equal(a1.pheromone, a2.pheromone)
+    s1, s2 = a1.shortest_path.tolist(), a2.shortest_path.tolist()
+    while len(s2) > 1 and s2[-1] == 0 and s2[-2] == 0:      # the reference keeps the iteration's padding
+        s2.pop()
+    assert s1 == s2
+
+
 def test_cvrp_nls_surface_float64_data():
     """cvrp_nls instances are float64 with capacity 1.0 (cvrp_nls/utils.py:19-30); same sampler."""
     from deepaco_amd.cvrp_nls.aco import ACO
