@@ -115,6 +115,8 @@ def main():
                     help="instances: B colonies per GPU, no collective (weak scaling, default); "
                          "ants: the same B colonies on every GPU, A/N ants each, one all-reduce of the "
                          "pheromone deposits per iteration (strong scaling)")
+    ap.add_argument("--exchange", default="tours", choices=["tours", "delta"],
+                    help="--shard ants: all-gather of the tours (int16; exact, default) or all-reduce of delta-tau")
     ap.add_argument("--force-device", type=int, default=None,
                     help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
     args = ap.parse_args()
@@ -149,7 +151,7 @@ def main():
         sparse = torch.full_like(d_dev, 1e10)
         sparse.scatter_(2, idx, torch.gather(d_dev, 2, idx))
         colony = engine.ant_sharded_tsp(d_dev, A, rank, world, heuristic=(1 / sparse).contiguous(),
-                                        sampler=args.sampler, seed=1234)
+                                        sampler=args.sampler, seed=1234, exchange=args.exchange)
         _step = colony.step
         colony.step = lambda events=None: _step()
     else:

@@ -19,6 +19,7 @@ struct SampleParams {
   int fixed_start;
   const float *noise;    // [B][n-1][A][n] RACE_NOISE
   uint64_t seed, iter;
+  int gid_bstride;           // ant-id stride between instances (0 = A): a rank that builds a slice of a colony's ants keeps the colony's ids
   const uint64_t *iter_dev;  // optional device-side addend to iter (lets a captured HIP graph advance the RNG); or null
   uint32_t ant_gid0;
   int64_t *paths;        // [B][n][A]
@@ -119,7 +120,7 @@ tsp_sample_kernel(const SampleParams p) {
   if (a >= p.A) return;                                 // no barriers below: safe
   const int n = p.n, A = p.A, ld = p.ld;
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
-  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const float *Pb = p.P + (size_t)b * n * ld + lane * VEC;
   const float *Rb = (MODE == DACO_RACE_PHILOX) ? p.R + (size_t)b * n * ld + lane * VEC : nullptr;
   const int rows = VARLEN ? p.Lmax : (STEP ? 2 : n);     // rows of paths for one instance (STEP: logp has 1 row)

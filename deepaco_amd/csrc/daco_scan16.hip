@@ -71,7 +71,7 @@ scan16_kernel(const SampleParams p) {
   // A not a multiple of 4: the spare rows build ant A-1 again (same counters, same tour, same stores)
   const int a = a0 + q < A ? a0 + q : A - 1;
   const uint64_t LEAD = 0x0001000100010001ull;          // lane 0 of each row
-  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
   const int rows = CVRP ? p.Lmax : n;                   // rows of paths for one instance

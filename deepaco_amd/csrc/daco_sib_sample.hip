@@ -77,7 +77,7 @@ extern "C" int daco_sibling_sample(void *stream, int kind, int B, int n, int A, 
   SampleParams sp;
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
   sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = start; sp.fixed_start = 0;
-  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = nullptr; sp.ant_gid0 = ant_gid0;
+  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = nullptr; sp.ant_gid0 = ant_gid0; sp.gid_bstride = 0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr; sp.hubmask = nullptr; sp.tab_lens = nullptr;
   sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;

@@ -53,6 +53,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
                                const float *eta, long eta_bstride, float alpha, float beta, int mode,
                                int norm_passes, const int64_t *start, int fixed_start,
                                const float *noise, uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
+                               int ant_gid_bstride,
                                int64_t *paths, float *logp, float *rowsum, int32_t *flags,
                                const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                                void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end) {
@@ -68,6 +69,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
+  if (ant_gid_bstride < 0 || (ant_gid_bstride > 0 && ant_gid_bstride < A)) { set_error("daco_tsp_sample: ant_gid_bstride %d < A %d", ant_gid_bstride, A); return DACO_E_BADARG; }
   if (costs && !dist) { set_error("daco_tsp_sample: fused costs need the distance matrix"); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sample_workspace_bytes(B, n, mode);
   if (workspace_bytes < need) { set_error("daco_tsp_sample: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
@@ -87,7 +89,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   SampleParams sp;
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
   sp.P = P; sp.R = R; sp.norm_passes = norm_passes; sp.start = start; sp.fixed_start = fixed_start;
-  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0;
+  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr; sp.hubmask = nullptr; sp.tab_lens = nullptr;
   sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 0; sp.lens = nullptr;
@@ -149,7 +151,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   SampleParams sp;
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
   sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = nullptr; sp.fixed_start = 0;
-  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0;
+  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = 0;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = (uint32_t *)next_table; sp.hubmask = hubmask; sp.tab_lens = tab_lens;
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
@@ -202,7 +204,7 @@ extern "C" int daco_pick_move(void *stream, int B, int n, int A, const void *pro
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
   sp.P = (const float *)prob_workspace;
   sp.R = mode == DACO_RACE_PHILOX ? (const float *)((const char *)prob_workspace + need / 2) : nullptr;
-  sp.norm_passes = 1; sp.start = prev; sp.fixed_start = -1; sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = nullptr;
+  sp.norm_passes = 1; sp.start = prev; sp.fixed_start = -1; sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = nullptr; sp.gid_bstride = 0;
   sp.ant_gid0 = ant_gid0; sp.paths = actions; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
   sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 1; sp.lens = nullptr;

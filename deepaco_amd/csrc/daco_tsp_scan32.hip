@@ -68,7 +68,7 @@ tsp_scan32_kernel(const SampleParams p) {
   // odd A: the last upper half builds ant A-1 a second time (same counters, same tour, same stores)
   const int a = a0 + up < A ? a0 + up : A - 1;
   const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);   // lane 0 of each half
-  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
   char *path_t = (char *)(p.paths + (size_t)b * n * A);                // row t of this instance's [n][A] block
@@ -250,7 +250,7 @@ cvrp_scan32_kernel(const SampleParams p) {
   if (a0 >= A) return;
   const int a = a0 + up < A ? a0 + up : A - 1;          // odd A: the last upper half repeats ant A-1
   const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);
-  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * A + a);
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
   int64_t *path_a = p.paths + (size_t)b * Lmax * A + a;

@@ -51,7 +51,7 @@ def _bstride(t, n):
 
 def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1, start=None,
                fixed_start=-1, noise=None, seed=0, it=0, ant_gid0=0, require_prob=False, batch=None,
-               events=None, dist=None, want_nbr=False, iter_dev=None):
+               events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0):
     """ACO.gen_path for a batch (tsp/aco.py:134-177, tsp_nls/aco.py:184-220).
 
     tau, eta: [B,n,n] or [n,n] (shared).  Returns (paths, log_probs|None, rowsum|None, flags).
@@ -92,7 +92,7 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
                                start.data_ptr() if start is not None else None, int(fixed_start),
                                noise.data_ptr() if noise is not None else None,
                                int(seed) & (2 ** 64 - 1), int(it), iter_dev.data_ptr() if iter_dev is not None else None,
-                               int(ant_gid0) & 0xFFFFFFFF,
+                               int(ant_gid0) & 0xFFFFFFFF, int(ant_gid_bstride),
                                paths.data_ptr(), logp.data_ptr() if require_prob else None,
                                rowsum.data_ptr() if require_prob else None, flags.data_ptr(),
                                dist.data_ptr() if dist is not None else None, dbs,
@@ -618,9 +618,11 @@ class BatchedCVRP:
 
 
 def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1.0, heuristic=None, sampler="scan",
-                    seed=0):
+                    seed=0, exchange="delta"):
     """Ant-sharded TSP colony on this rank's GPU: A/world ants of every instance here, pheromone
-    replicated, ONE all-reduce (RCCL over xGMI when the process group is nccl) of the deposits per iteration.
+    replicated, one collective per iteration (RCCL over xGMI when the process group is nccl):
+    exchange="delta": all-reduce of the deposits [B,n,n]; exchange="tours": all-gather of the tours (int16) and
+    costs, every rank applies the full deposit in ant order -- bit-identical to BatchedTSP with the same seed.
     Returns a parallel.AntShardedColony whose kernels are the HIP ones."""
     from .parallel import AntShardedColony
     _require_gpu(distances)
@@ -628,10 +630,14 @@ def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1
     B, n, _ = dist_.shape
     eta = (1 / dist_) if heuristic is None else heuristic
     state = {}
+    exact = exchange == "tours"
 
     def sample_fn(tau, lo, n_local, it):
+        # exact: colony-wide ant ids (ant lo + a of instance b is ant b*A + lo + a of the single-GPU colony)
         paths, _, _, _, costs, nbr = tsp_sample(tau, eta, n_local, alpha, beta, mode=sampler, seed=seed, it=it,
-                                                ant_gid0=rank * B * n_local, batch=B, dist=dist_, want_nbr=True)
+                                                ant_gid0=lo if exact else rank * B * n_local,
+                                                ant_gid_bstride=n_ants if exact else 0, batch=B, dist=dist_,
+                                                want_nbr=not exact)
         state["costs"], state["nbr"] = costs, nbr
         return paths
 
@@ -641,4 +647,8 @@ def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1
     def deposit_fn(zero, paths, costs):
         return pheromone_update_(zero, paths, costs, 1.0, nbr=state["nbr"])
 
-    return AntShardedColony(torch.ones_like(dist_), n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn)
+    def update_fn(tau, paths, costs):
+        return pheromone_update_(tau, paths.contiguous(), costs.contiguous(), decay)
+
+    return AntShardedColony(torch.ones_like(dist_), n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn,
+                            exchange=exchange, update_fn=update_fn)

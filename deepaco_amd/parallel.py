@@ -4,10 +4,13 @@ The rollout path shards two ways:
 
 * instance-sharded (primary): colonies are independent, each rank owns B/N instances and its own
   pheromone; there is NO data-path collective -- only a final gather of the [B] best costs.
-* ant-sharded: every rank runs A/N ants of the SAME instances with a replicated pheromone; each
-  iteration the ranks' deposits (delta-tau, [B, n, n] f32) are summed with ONE all-reduce and
-  every rank applies tau <- decay*tau + delta.  The sum order across ranks differs from the
-  single-GPU ant order, so pheromone agrees to ~1e-6 relative, not bitwise.
+* ant-sharded: every rank runs A/N ants of the SAME instances with a replicated pheromone.  Two exchanges:
+  - "delta": the ranks' deposits (delta-tau, [B, n, n] f32) are summed with ONE all-reduce and every rank
+    applies tau <- decay*tau + delta.  The sum order across ranks differs from the single-GPU ant order,
+    so pheromone agrees to ~1e-6 relative, not bitwise.
+  - "tours" (exact): the ranks all-gather their tours (as int16: n*A_local*2 bytes per instance instead of
+    4*n*n) and costs, and every rank applies the full deposit in ant order -- with the colony-wide ant ids
+    (ant_gid_bstride) the N-GPU colony is bit-identical to the single-GPU one.
 
 Everything here is host logic over torch.distributed and is exercised on CPU with the gloo
 backend (tests/test_parallel_gloo.py); the kernels are injected as callables.
@@ -74,18 +77,52 @@ class AntShardedColony:
     deposit_fn(zeros_like_tau, paths, costs) -> delta (deposit with decay = 1 onto zeros, in place)
     The callables are the engine's kernels on a GPU and plain torch on CPU in the gloo tests."""
 
-    def __init__(self, tau, n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn):
+    def __init__(self, tau, n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn, exchange="delta",
+                 update_fn=None):
+        """exchange="tours" needs update_fn(tau, paths [B,n,A], costs [B,A]) -> tau updated in place (the full
+        evaporate + deposit of the single-GPU colony) instead of deposit_fn."""
+        assert exchange in ("delta", "tours")
+        assert exchange == "delta" or update_fn is not None
         self.tau = tau
         self.n_ants, self.decay, self.rank, self.world = n_ants, decay, rank, world
         self.lo, self.hi = shard_range(n_ants, rank, world)
         self.sample_fn, self.cost_fn, self.deposit_fn = sample_fn, cost_fn, deposit_fn
+        self.exchange, self.update_fn = exchange, update_fn
         self.lowest_cost = torch.full((tau.shape[0],), float("inf"), device=tau.device)
         self.iteration = 0
+
+    def _gather_ants(self, x, dim):
+        """all-gather along the ant dimension (ranks may own one ant more or less: padded, then trimmed)."""
+        if self.world == 1:
+            return x
+        q = -(-self.n_ants // self.world)
+        shape = list(x.shape)
+        shape[dim] = q
+        pad = torch.zeros(shape, dtype=x.dtype, device=x.device)
+        pad.narrow(dim, 0, x.shape[dim]).copy_(x)
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        if pad.dtype == torch.int16:          # neither gloo nor RCCL moves int16: ship the same bytes as uint8
+            dist.all_gather([o.view(torch.uint8) for o in out], pad.view(torch.uint8))
+        else:
+            dist.all_gather(out, pad)
+        parts = []
+        for r in range(self.world):
+            lo, hi = shard_range(self.n_ants, r, self.world)
+            parts.append(out[r].narrow(dim, 0, hi - lo))
+        return torch.cat(parts, dim=dim)
 
     @torch.no_grad()
     def step(self):
         paths = self.sample_fn(self.tau, self.lo, self.hi - self.lo, self.iteration)
         costs = self.cost_fn(paths)
+        if self.exchange == "tours":
+            narrow = torch.int16 if paths.shape[1] <= 32767 else torch.int32
+            all_paths = self._gather_ants(paths.to(narrow), 2).to(torch.int64)       # the one data-path collective
+            all_costs = self._gather_ants(costs, 1)
+            self.update_fn(self.tau, all_paths, all_costs)
+            self.lowest_cost = torch.minimum(self.lowest_cost, all_costs.min(dim=1).values)
+            self.iteration += 1
+            return paths, costs
         delta = self.deposit_fn(torch.zeros_like(self.tau), paths, costs)
         best = costs.min(dim=1).values
         if self.world > 1:

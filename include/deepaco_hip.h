@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 110 /* 0.1.10: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 111 /* 0.1.11: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -79,6 +79,10 @@ int daco_ld_for_n(int n);
  *   noise      DACO_RACE_NOISE only: [B][n-1][A][n] f32 (the reference's q tensors, step-major).
  *   seed, iter, ant_gid0   Philox key and counter words: ant (b,a) uses global ant id
  *              ant_gid0 + b*A + a; `iter` must differ between calls that should be independent.
+ *   ant_gid_bstride  0, or the ant-id stride between instances when this call builds only a slice of a
+ *              colony's ants: ant (b,a) then uses id ant_gid0 + b*ant_gid_bstride + a.  A rank that owns ants
+ *              [lo, hi) of colonies with A_total ants passes ant_gid0 = lo, ant_gid_bstride = A_total and draws
+ *              exactly the tours a single call with all A_total ants would draw for those ants.
  *   iter_offset  optional device pointer to a uint64 that the kernel adds to `iter` when it starts:
  *              a caller that captures its iteration into a HIP graph keeps the counter in device
  *              memory and bumps it inside the graph (arguments are frozen at capture).  NULL = 0.
@@ -103,6 +107,7 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
                     float alpha, float beta, int mode, int norm_passes,
                     const int64_t *start, int fixed_start, const float *noise,
                     uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
+                    int ant_gid_bstride,
                     int64_t *paths, float *logp, float *rowsum, int32_t *flags,
                     const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                     void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);

@@ -34,7 +34,7 @@ def test_ctypes_table_matches_header():
 
 def test_version_and_layout_helpers_agree_with_oracle():
     L = _lib.lib()
-    assert L.daco_version() >= 110
+    assert L.daco_version() >= 111
     for n in (2, 5, 63, 64, 65, 100, 128, 129, 255, 256, 257, 500, 1000, 4096):
         assert L.daco_vec_for_n(n) == oracle.vec_for_n(n)
         assert L.daco_ld_for_n(n) == oracle.ld_for_n(n)
@@ -46,11 +46,11 @@ def test_bad_arguments_return_error_codes():
     assert L.daco_tour_costs(None, 0, 0, 0, 0, None, 0, None, 0, None) == -1
     assert b"bad argument" in L.daco_last_error()
     # n above the register plan of the sampler -> DACO_E_TOOLARGE before anything is launched
-    rc = L.daco_tsp_sample(None, 1, 5000, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, None, 0, 1, None, None,
+    rc = L.daco_tsp_sample(None, 1, 5000, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, None, 0, 0, 1, None, None,
                            None, None, 0, None, None, 1, 1 << 40, None, None)
     assert rc == -2 and b"DACO_MAX_NODES" in L.daco_last_error()
     # workspace too small
-    rc = L.daco_tsp_sample(None, 1, 100, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, None, 0, 1, None, None,
+    rc = L.daco_tsp_sample(None, 1, 100, 4, 1, 0, 1, 0, 1.0, 1.0, 2, 1, None, -1, None, 0, 0, None, 0, 0, 1, None, None,
                            None, None, 0, None, None, 1, 16, None, None)
     assert rc == -4
     assert L.daco_tsp_sample_workspace_bytes(64, 500, _lib.SCAN) == 64 * 500 * 512 * 4

@@ -2,7 +2,7 @@
 
 The kernels are replaced by the CPU oracle here (tests may use it as the checker); what is
 under test is sharding, the barrier/max timing helper, the final gather of the instance-sharded
-mode and the delta-tau all-reduce of the ant-sharded mode."""
+mode and both exchanges of the ant-sharded mode (delta-tau all-reduce; all-gather of the tours, exact)."""
 import os
 import socket
 
@@ -83,6 +83,24 @@ def _worker(rank, world, port, q):
         col.step()
     out["tau"] = col.tau.numpy()
     out["low"] = col.lowest_cost.tolist()
+    # --- ant-sharded, exact: all-gather of the tours (int16), full deposit on every rank; 13 ants -> 7 + 6
+    A3 = 13
+
+    def sample3(tau, gid0, n_local, it):
+        ps = [oracle.tsp_sample_scan(oracle.prob_matrix(tau[b].numpy(), eta[b]), n_local, seed, it, b * A3 + gid0)[0]
+              for b in range(Bs)]
+        return torch.from_numpy(np.stack(ps))
+
+    def update_fn(tau, paths, costs):
+        for b in range(Bs):
+            tau[b] = torch.from_numpy(oracle.pheromone_update_tsp(tau[b].numpy(), paths[b].numpy(), costs[b].numpy(), 0.9))
+
+    col3 = parallel.AntShardedColony(torch.ones(Bs, n, n), A3, 0.9, rank, world, sample3, cost_fn, None,
+                                     exchange="tours", update_fn=update_fn)
+    for _ in range(3):
+        col3.step()
+    out["tau3"] = col3.tau.numpy()
+    out["low3"] = col3.lowest_cost.tolist()
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -125,6 +143,19 @@ def test_world2_gloo():
             tau = oracle.pheromone_update_tsp(tau, paths, costs, 0.9)
         np.testing.assert_allclose(res[0]["tau"][b], tau, rtol=2e-6)
         assert res[0]["low"][b] == pytest.approx(low, rel=1e-6)
+    # tour exchange: bit-identical to the single-process colony with all 13 ants, on both ranks
+    assert np.array_equal(res[0]["tau3"], res[1]["tau3"]) and res[0]["low3"] == res[1]["low3"]
+    for b in range(Bs):
+        tau = np.ones((n, n), np.float32)
+        eta = (1.0 / Ds[b]).numpy()
+        low = np.inf
+        for it in range(3):
+            paths, _, _ = oracle.tsp_sample_scan(oracle.prob_matrix(tau, eta), 13, seed, it, b * 13)
+            costs = oracle.tour_costs(Ds[b].numpy(), paths)
+            low = min(low, float(costs.min()))
+            tau = oracle.pheromone_update_tsp(tau, paths, costs, 0.9)
+        assert np.array_equal(res[0]["tau3"][b].view(np.uint32), tau.view(np.uint32))
+        assert res[0]["low3"][b] == low
 
 
 def test_shard_range_covers_everything():
