@@ -11,6 +11,7 @@
 // (probe-verified bit-identical).  Evaporation is fused into the
 // LDS fill and the MMAS clamp / floor into the write-back, so tau makes one round trip.
 #include "daco_device.h"
+#include <cstdlib>
 #include "../../include/deepaco_hip.h"
 
 namespace daco {
@@ -384,10 +385,13 @@ extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, i
          align256((size_t)B * A * ((n + 31) / 32) * sizeof(uint32_t));
 }
 
-// rows per workgroup: two workgroups per CU (80 KiB of LDS each: the rows plus the two staging
-// images), chains of one workgroup inside one wave
+// rows per workgroup from an LDS budget: smaller slabs mean more workgroups per CU moving tau while others run
+// their add chains.  Measured (DACO_DEPOSIT_LDS_KB sweep, TSP-500 x 512 x 64 / CVRP-100 x 512 x 256): symmetric
+// 80 / 53 / 40 / 32 KiB -> 119 / 91 / 84 / 105 us; directed 80 / 40 / 26 / 20 KiB -> 92 / 70 / 54 / 53 us.
 static int rows_per_block(int n, bool symmetric) {
-  int R = (80 * 1024 - 2 * DEP_CHUNK * 4 - 16) / (4 * n + 2 * DEP_CHUNK * 4);
+  static const int override_kb = getenv("DACO_DEPOSIT_LDS_KB") ? atoi(getenv("DACO_DEPOSIT_LDS_KB")) : 0;
+  const int budget_kb = override_kb ? override_kb : (symmetric ? 40 : 24);
+  int R = (budget_kb * 1024 - 2 * DEP_CHUNK * 4 - 16) / (4 * n + 2 * DEP_CHUNK * 4);
   const int cap = symmetric ? 32 : 64;
   if (R > cap) R = cap;
   if (R < 1) R = 1;
