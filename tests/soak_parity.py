@@ -156,6 +156,39 @@ def update_case(c, rng, dev):
     return ok
 
 
+def batch_case(c, rng, dev):
+    """several instances per launch (workgroup remap, batch strides, per-instance ant ids): every instance must
+    equal its own single-instance oracle run."""
+    n = int(rng.choice([rng.integers(2, 65), rng.integers(65, 257), rng.integers(257, 513), rng.integers(513, 600)]))
+    A, B = int(rng.integers(1, 30)), int(rng.integers(2, 12))
+    P = (rng.random((B, n, n)) ** 2 + 1e-3).astype(np.float32)
+    seed, it, gid0 = int(rng.integers(1, 2 ** 40)), int(rng.integers(0, 1000)), int(rng.integers(0, 10 ** 6))
+    mode = str(rng.choice(["scan", "scan_wave", "race"]))
+    d = (rng.random((B, n, n)) + 0.01).astype(np.float32)
+    tau = torch.from_numpy(P).to(dev)
+    share_eta = bool(rng.integers(0, 2))                       # a shared (stride-0) matrix next to a batched one
+    eta = torch.ones(n, n, device=dev) if share_eta else torch.ones(B, n, n, device=dev)
+    paths, _, _, flags, costs, _ = engine.tsp_sample(tau, eta, A, mode=mode, seed=seed, it=it, ant_gid0=gid0,
+                                                     dist=torch.from_numpy(d).to(dev), want_nbr=True, batch=B)
+    ok = int(flags.sum()) == 0
+    for b in range(B):
+        fn = oracle.tsp_sample_race if mode == "race" else oracle.tsp_sample_scan
+        kw = {} if mode == "race" else {"wave": mode == "scan_wave"}
+        rp, _, rc = fn(P[b], A, seed, it, gid0 + b * A, **kw)
+        ok = ok and rc == 0 and np.array_equal(paths[b].cpu().numpy(), rp)
+        if n >= 3:
+            ok = ok and np.array_equal(costs[b].cpu().numpy(), oracle.tour_costs(d[b], rp))
+    if not ok:
+        print(f"MISMATCH batch case {c}: n={n} A={A} B={B} mode={mode} seed={seed} it={it} gid0={gid0}", flush=True)
+    return ok
+
+
+def run_batches(cases, seed):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    return sum(0 if batch_case(c, rng, dev) else 1 for c in range(cases))
+
+
 def run_updates(cases, seed):
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
@@ -171,4 +204,8 @@ if __name__ == "__main__":
     u_bad = run_updates(n_cases // 4, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"{n_cases // 4} update / 2-opt cases, {u_bad} mismatches, {time.time() - t0:.1f} s")
     n_bad += u_bad
+    t0 = time.time()
+    b_bad = run_batches(n_cases // 4, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n_cases // 4} multi-instance cases, {b_bad} mismatches, {time.time() - t0:.1f} s")
+    n_bad += b_bad
     sys.exit(1 if n_bad else 0)

@@ -20,3 +20,8 @@ def test_random_cases_match_the_oracle(seed):
 def test_random_updates_and_two_opt_match_the_oracle():
     import soak_parity
     assert soak_parity.run_updates(60, 11) == 0
+
+
+def test_random_multi_instance_launches_match_the_oracle():
+    import soak_parity
+    assert soak_parity.run_batches(60, 5) == 0
