@@ -189,6 +189,74 @@ def run_batches(cases, seed):
     return sum(0 if batch_case(c, rng, dev) else 1 for c in range(cases))
 
 
+def sibling_case(c, rng, dev):
+    """fused sibling constructions (one launch) against their draw-by-draw service path: same Philox counters,
+    identical solutions (SOP precedences, PCTSP prize threshold, OP length budget, MKP knapsacks)."""
+    kind = int(rng.integers(0, 4))
+    n = int(rng.choice([rng.integers(6, 40), rng.integers(40, 140), rng.integers(140, 260)]))
+    A = int(rng.integers(2, 48))
+    sampler = str(rng.choice(["scan", "race"]))
+    seed = int(rng.integers(1, 2 ** 31))
+    g = torch.Generator().manual_seed(int(rng.integers(1, 2 ** 31)))
+    kw = {}
+    if kind == 0:
+        from deepaco_amd.sop.aco import ACO
+        dist = torch.rand(n, n, generator=g) + 0.05
+        prec = torch.zeros(n, n)
+        order = torch.randperm(n - 1, generator=g) + 1
+        for _ in range(int(rng.integers(0, 3 * n))):
+            i, j = sorted(torch.randint(0, n - 1, (2,), generator=g).tolist())
+            if i != j:
+                prec[order[j], order[i]] = 1
+        prec[1:, 0] = 1
+        make = lambda: ACO(dist.to(dev), prec.to(dev), n_ants=A, device="cuda:0", sampler=sampler, seed=seed)
+        name = "gen_path"
+    elif kind == 1:
+        from deepaco_amd.pctsp.aco import ACO
+        coor = torch.rand(n, 2, generator=g)
+        dist = torch.cdist(coor, coor)
+        prizes = torch.cat((torch.zeros(1), torch.rand(n - 1, generator=g)))
+        pen = torch.cat((torch.zeros(1), torch.rand(n - 1, generator=g) * 0.3))
+        make = lambda: ACO(dist.to(dev), prizes.to(dev), pen.to(dev), n_ants=A, device="cuda:0", sampler=sampler, seed=seed)
+        name = "gen_sol"
+    elif kind == 2:
+        from deepaco_amd.op.aco import ACO
+        from deepaco_amd.tsp.utils import gen_distance_matrix
+        coor = torch.rand(n, 2, generator=g)
+        dist = gen_distance_matrix(coor)
+        dd = (coor - coor[0]).norm(dim=-1)
+        prizes = 1 + torch.floor(99 * dd / dd.max())
+        prizes = prizes / prizes.max()
+        max_len = float(rng.uniform(1.5, 5.0))
+        make = lambda: ACO(dist.to(dev), prizes.to(dev), max_len, n_ants=A, k_sparse=max(5, n // 5), device="cuda:0",
+                           sampler=sampler, seed=seed)
+        name = "gen_sol"
+    else:
+        from deepaco_amd.mkp.aco import ACO
+        m = int(rng.integers(1, 7))
+        n = min(n, 120)
+        prize = torch.rand(n, generator=g)
+        w = torch.rand(n, m, generator=g)
+        cons = w.max(0).values + torch.rand(m, generator=g) * (w.sum(0) - w.max(0).values)
+        w = w * (n // 2) / cons.unsqueeze(0)
+        kw = {"_start": torch.randint(0, n, (A,), generator=g).to(dev)}
+        make = lambda: ACO(prize.to(dev), w.to(dev), n_ants=A, device="cuda:0", sampler=sampler, seed=seed)
+        name = "gen_sol"
+    a1, a2 = make(), make()
+    s1, l1 = getattr(a1, name)(True, **kw)
+    s2, l2 = getattr(a2, name)(True, _stepwise=True, **kw)
+    ok = s1.shape == s2.shape and torch.equal(s1, s2) and torch.allclose(l1, l2, rtol=1e-5, atol=2e-6)
+    if not ok:
+        print(f"MISMATCH sibling case {c}: kind={kind} n={n} A={A} sampler={sampler} seed={seed}", flush=True)
+    return ok
+
+
+def run_siblings(cases, seed):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    return sum(0 if sibling_case(c, rng, dev) else 1 for c in range(cases))
+
+
 def run_updates(cases, seed):
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
@@ -208,4 +276,8 @@ if __name__ == "__main__":
     b_bad = run_batches(n_cases // 4, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"{n_cases // 4} multi-instance cases, {b_bad} mismatches, {time.time() - t0:.1f} s")
     n_bad += b_bad
+    t0 = time.time()
+    s_bad = run_siblings(n_cases // 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n_cases // 20} sibling cases (fused vs draw-by-draw), {s_bad} mismatches, {time.time() - t0:.1f} s")
+    n_bad += s_bad
     sys.exit(1 if n_bad else 0)

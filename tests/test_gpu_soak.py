@@ -25,3 +25,8 @@ def test_random_updates_and_two_opt_match_the_oracle():
 def test_random_multi_instance_launches_match_the_oracle():
     import soak_parity
     assert soak_parity.run_batches(60, 5) == 0
+
+
+def test_random_fused_siblings_equal_their_stepwise_paths():
+    import soak_parity
+    assert soak_parity.run_siblings(40, 9) == 0
