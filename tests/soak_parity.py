@@ -257,6 +257,44 @@ def run_siblings(cases, seed):
     return sum(0 if sibling_case(c, rng, dev) else 1 for c in range(cases))
 
 
+def grad_case(c, rng, dev):
+    """gradient of the log-probabilities w.r.t. the heuristic (sampler forward with log-probs + replay backward)
+    against the closed form on the drawn tours, all lane layouts."""
+    from oracle import grad as ograd
+    from deepaco_amd.tsp.aco import ACO
+    n = int(rng.choice([rng.integers(4, 65), rng.integers(65, 257), rng.integers(257, 400)]))
+    A = int(rng.integers(1, 12))
+    beta = int(rng.integers(1, 3))
+    mode = str(rng.choice(["scan", "scan_wave", "race"]))
+    seed = int(rng.integers(1, 2 ** 31))
+    g = torch.Generator().manual_seed(seed)
+    cds = torch.rand(n, 2, generator=g)
+    d = torch.cdist(cds, cds)
+    d[torch.arange(n), torch.arange(n)] = 1e9
+    tau = torch.rand(n, n, generator=g) + 0.2
+    eta = torch.rand(n, n, generator=g) + 1e-2
+    heu = eta.to(dev).requires_grad_(True)
+    aco = ACO(d.to(dev), n_ants=A, heuristic=heu, pheromone=tau.to(dev), beta=beta, device="cuda:0", sampler=mode, seed=seed)
+    costs, logp = aco.sample()
+    w = torch.linspace(-1, 1, A, device=dev) if A > 1 else torch.ones(1, device=dev)
+    (logp.sum(0) * w).sum().backward()
+    paths = ACO(d.to(dev), n_ants=A, heuristic=eta.to(dev), pheromone=tau.to(dev), beta=beta, device="cuda:0", sampler=mode,
+                seed=seed).gen_path()
+    G = np.tile(w.cpu().numpy()[None, :], (n - 1, 1))
+    ref = ograd.tsp_grad(tau.numpy(), eta.numpy(), 1, beta, paths.cpu().numpy(), G)
+    scale = np.abs(ref).max()
+    ok = np.allclose(heu.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * scale)
+    if not ok:
+        print(f"MISMATCH grad case {c}: n={n} A={A} beta={beta} mode={mode} seed={seed}", flush=True)
+    return ok
+
+
+def run_grads(cases, seed):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    return sum(0 if grad_case(c, rng, dev) else 1 for c in range(cases))
+
+
 def run_updates(cases, seed):
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
@@ -280,4 +318,8 @@ if __name__ == "__main__":
     s_bad = run_siblings(n_cases // 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"{n_cases // 20} sibling cases (fused vs draw-by-draw), {s_bad} mismatches, {time.time() - t0:.1f} s")
     n_bad += s_bad
+    t0 = time.time()
+    g_bad = run_grads(n_cases // 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n_cases // 20} gradient cases, {g_bad} mismatches, {time.time() - t0:.1f} s")
+    n_bad += g_bad
     sys.exit(1 if n_bad else 0)

@@ -30,3 +30,8 @@ def test_random_multi_instance_launches_match_the_oracle():
 def test_random_fused_siblings_equal_their_stepwise_paths():
     import soak_parity
     assert soak_parity.run_siblings(40, 9) == 0
+
+
+def test_random_gradients_match_the_closed_form():
+    import soak_parity
+    assert soak_parity.run_grads(30, 4) == 0
