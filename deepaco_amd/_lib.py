@@ -42,12 +42,14 @@ SIGNATURES = {
     "daco_sibling_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_sibling_sample": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _l, _f, _vp, _i, _i, _vp, _vp,
                                  _i, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "daco_sibling_backward": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _l, _f, _vp, _i, _vp, _vp,
+                                   _vp, _vp, _vp]),
     "daco_tsp_knn_graph": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
     "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
 }
 
 
-ABI_VERSION = 111          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 112          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

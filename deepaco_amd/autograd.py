@@ -52,3 +52,30 @@ class CvrpSampleFn(torch.autograd.Function):
         grad = engine.sample_backward(tau, eta, a, b, paths, rowsum, glogp.contiguous().unsqueeze(0), lens=lens,
                                       demand=demand, capacity=cap)
         return (grad[0],) + (None,) * 10
+
+
+class SiblingSampleFn(torch.autograd.Function):
+    """Fused sop / pctsp / op / mkp construction whose log-probabilities carry gradient to the heuristic
+    (daco_sibling_sample forward, daco_sibling_backward = route replay with the problem's own feasibility rules)."""
+
+    @staticmethod
+    def forward(ctx, heuristic, pheromone, kind, n_ants, alpha, beta, mode, noise, seed, it, kw):
+        eta = heuristic.detach().float()
+        tau = pheromone.detach().float()
+        paths, logp, rowsum, lens, flags = engine.sibling_sample(kind, tau, eta, n_ants, alpha, beta, mode=mode,
+                                                                 noise=noise, seed=seed, it=it, require_prob=True, **kw)
+        ctx.save_for_backward(tau, eta, paths, rowsum, lens if lens is not None else torch.empty(0))
+        ctx.meta = (kind, alpha, beta, {k: v for k, v in kw.items() if k in ("aux_vec", "aux_mat", "scalar0", "item_weights")})
+        ctx.mark_non_differentiable(paths, flags)
+        out_lens = lens if lens is not None else torch.empty(0, dtype=torch.int32, device=paths.device)
+        ctx.mark_non_differentiable(out_lens)
+        return paths, logp, out_lens, flags
+
+    @staticmethod
+    def backward(ctx, _gp, glogp, _gl, _gf):
+        tau, eta, paths, rowsum, lens = ctx.saved_tensors
+        kind, alpha, beta, kw = ctx.meta
+        grad = engine.sibling_backward(kind, tau, eta, alpha, beta, paths, rowsum, glogp.contiguous(),
+                                       lens=lens if lens.numel() else None, **kw)
+        grad = grad[0] if ctx.needs_input_grad[0] and grad.shape[0] == 1 and eta.dim() == 2 else grad
+        return (grad,) + (None,) * 10

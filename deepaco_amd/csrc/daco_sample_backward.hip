@@ -98,9 +98,173 @@ sample_backward_kernel(const BackwardParams p) {
   }
 }
 
+// ------------------------------------------------------------------ sibling constructions
+// The same gradient for the fused sop / pctsp / op / mkp constructions (daco_sibling_sample): the
+// wave replays the route with the problem's own feasibility bookkeeping -- the rules of
+// daco_sample_kernel.h, restated on the one-candidate-per-lane-and-chunk layout of this file
+// (sop/aco.py:128-180, pctsp/aco.py:166-188, op/aco.py:195-224, mkp/aco.py:163-183).
+struct SibBackwardParams {
+  BackwardParams b;
+  const float *aux_vec;          // [B][n]
+  const float *aux_mat;          // [B][n][n] (stride aux_bs)
+  long aux_bs;
+  float scalar0;
+  const float *wts;              // MKP [B][n][m]
+  int m;
+};
+
+constexpr int SIBB_CHUNKS = 16;  // n <= 1024 (larger instances take the draw-by-draw gradient path)
+
+template <int KIND>
+__global__ void __launch_bounds__(256)
+sibling_backward_kernel(const SibBackwardParams q) {
+  constexpr bool SOP = KIND == DACO_SIB_SOP, PCTSP = KIND == DACO_SIB_PCTSP, OP = KIND == DACO_SIB_OP, MKP = KIND == DACO_SIB_MKP;
+  constexpr bool DUMMY = OP || MKP;
+  const BackwardParams &p = q.b;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bpi = (p.A + 3) >> 2;
+  const int b = blockIdx.x / bpi;
+  const int a = (blockIdx.x - b * bpi) * 4 + wave;
+  if (a >= p.A) return;
+  const int n = p.n, A = p.A;
+  const float *tau = p.tau + (size_t)b * p.tau_bs, *eta = p.eta + (size_t)b * p.eta_bs;
+  const int64_t *path = p.paths + (size_t)b * p.rows * A + a;
+  const float *rs = p.rowsum + (size_t)b * (p.rows - 1) * A + a;
+  const float *gl = p.grad_logp + (size_t)b * (p.rows - 1) * A + a;
+  float *grad = p.grad_eta + (size_t)b * n * n;
+  const float *avec = (SOP || PCTSP || OP) ? q.aux_vec + (size_t)b * n : nullptr;
+  const float *amat = (SOP || OP) ? q.aux_mat + (size_t)b * q.aux_bs : nullptr;
+  const float *wts = MKP ? q.wts + (size_t)b * n * q.m : nullptr;
+  const int len = SOP ? n : p.lens[(size_t)b * A + a];
+  const int chunks = (n + 63) / 64;
+
+  uint32_t vis = 0, sticky = 0;                        // bit c: candidate lane + 64c
+  int prev = (int)path[0];
+  float cnt[SIBB_CHUNKS];                              // SOP: unvisited predecessors; OP: way home
+  float used = 0.0f, knap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int remaining = n - 1;
+  if (!PCTSP && (prev & 63) == lane) vis |= 1u << (prev >> 6);
+#pragma unroll
+  for (int c = 0; c < SIBB_CHUNKS; ++c) {
+    const int k = lane + 64 * c;
+    cnt[c] = 0.0f;
+    if (c < chunks && k < n) {
+      if (SOP) cnt[c] = avec[k] - amat[k];               // node 0 is visited first: row 0 of "who waits"
+      if (OP) cnt[c] = avec[k];
+    }
+  }
+  if (MKP) for (int dd = 0; dd < 8; ++dd) if (dd < q.m) knap[dd] = wts[(size_t)prev * q.m + dd];
+
+  for (int t = 1; t < len; ++t) {
+    const int j = (int)path[(size_t)t * A];
+    const float g = gl[(size_t)(t - 1) * A];
+    const float S = rs[(size_t)(t - 1) * A];
+    const float *trow = tau + (size_t)prev * n, *erow = eta + (size_t)prev * n;
+    // ---- candidates open at this step
+    uint32_t open = 0;
+    const bool depot_open = PCTSP ? (prev != 0 && (used > q.scalar0 || remaining == 0)) : true;
+#pragma unroll
+    for (int c = 0; c < SIBB_CHUNKS; ++c) {
+      const int k = lane + 64 * c;
+      if (c < chunks && k < n) {
+        bool o = !((vis >> c) & 1u);
+        if (SOP) o = o && cnt[c] == 0.0f;
+        if (PCTSP && k == 0) o = depot_open;
+        if (OP) {
+          if (used + amat[(size_t)prev * n + k] + cnt[c] > q.scalar0) sticky |= 1u << c;
+          o = o && !((sticky >> c) & 1u) && k < n - 1;
+        }
+        if (MKP) {
+          bool over = false;
+          if (k < n - 1)
+            for (int dd = 0; dd < 8; ++dd)
+              if (dd < q.m) over = over || (knap[dd] + wts[(size_t)k * q.m + dd] > q.scalar0);
+          if (over) sticky |= 1u << c;
+          o = o && !((sticky >> c) & 1u) && k < n - 1;
+        }
+        if (o) open |= 1u << c;
+      }
+    }
+    if (g != 0.0f) {
+      const float pj = pw(trow[j], p.alpha) * pw(erow[j], p.beta);
+      const float pr = pj / S;
+      if (pr > DACO_EPS_F32 && pr < 1.0f - DACO_EPS_F32) {      // inside the clamp: gradient flows
+        const float cg = g / S;
+        float *grow = grad + (size_t)prev * n;
+#pragma unroll
+        for (int c = 0; c < SIBB_CHUNKS; ++c) {
+          const int k = lane + 64 * c;
+          if (c < chunks && ((open >> c) & 1u)) {
+            const float e = erow[k];
+            const float pk = pw(trow[k], p.alpha) * pw(e, p.beta);
+            float val = -cg * p.beta * (pk / e);
+            if (k == j) val += g * p.beta / e;
+            unsafeAtomicAdd(grow + k, val);
+          }
+        }
+      }
+    }
+    // ---- the move
+    if (SOP) {
+      if ((j & 63) == lane) vis |= 1u << (j >> 6);
+#pragma unroll
+      for (int c = 0; c < SIBB_CHUNKS; ++c) {
+        const int k = lane + 64 * c;
+        if (c < chunks && k < n) cnt[c] = cnt[c] - amat[(size_t)j * n + k];
+      }
+    } else if (PCTSP) {
+      used = used + avec[j];
+      if (j != 0) { if ((j & 63) == lane) vis |= 1u << (j >> 6); --remaining; }
+    } else if (OP) {
+      used = used + amat[(size_t)prev * n + j];
+      if ((j & 63) == lane) vis |= 1u << (j >> 6);
+    } else {
+      if ((j & 63) == lane) vis |= 1u << (j >> 6);
+      for (int dd = 0; dd < 8; ++dd) if (dd < q.m) knap[dd] = knap[dd] + wts[(size_t)j * q.m + dd];
+    }
+    prev = j;
+  }
+  (void)DUMMY;
+}
+
 }  // namespace daco
 
 using namespace daco;
+
+extern "C" int daco_sibling_backward(void *stream, int kind, int B, int n, int A, int rows, const float *tau,
+                                     long tau_bstride, const float *eta, long eta_bstride, float alpha, float beta,
+                                     const float *aux_vec, const float *aux_mat, long aux_mat_bstride, float scalar0,
+                                     const float *item_weights, int m, const int64_t *paths, const float *rowsum,
+                                     const float *grad_logp, const int32_t *lens, float *grad_eta) {
+  if (B <= 0 || n < 2 || A <= 0 || rows < 2 || !tau || !eta || !paths || !rowsum || !grad_logp || !grad_eta) {
+    set_error("daco_sibling_backward: bad argument (B=%d n=%d A=%d rows=%d)", B, n, A, rows);
+    return DACO_E_BADARG;
+  }
+  if (n > 64 * SIBB_CHUNKS) { set_error("daco_sibling_backward: n=%d exceeds %d", n, 64 * SIBB_CHUNKS); return DACO_E_TOOLARGE; }
+  if (kind != DACO_SIB_SOP && !lens) { set_error("daco_sibling_backward: variable-length kinds need lens"); return DACO_E_BADARG; }
+  if (kind == DACO_SIB_MKP && (m < 1 || m > 8 || !item_weights)) { set_error("daco_sibling_backward: mkp needs 1..8 weight columns"); return DACO_E_BADARG; }
+  if ((kind == DACO_SIB_SOP || kind == DACO_SIB_OP) && (!aux_vec || !aux_mat)) { set_error("daco_sibling_backward: aux_vec / aux_mat missing"); return DACO_E_BADARG; }
+  if (kind == DACO_SIB_PCTSP && !aux_vec) { set_error("daco_sibling_backward: aux_vec missing"); return DACO_E_BADARG; }
+  SibBackwardParams sp;
+  BackwardParams &bp = sp.b;
+  bp.B = B; bp.n = n; bp.A = A; bp.rows = rows; bp.tau = tau; bp.eta = eta; bp.tau_bs = tau_bstride;
+  bp.eta_bs = eta_bstride; bp.alpha = alpha; bp.beta = beta; bp.paths = paths; bp.rowsum = rowsum;
+  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = nullptr; bp.capacity = 0.0f; bp.grad_eta = grad_eta;
+  sp.aux_vec = aux_vec; sp.aux_mat = aux_mat; sp.aux_bs = aux_mat_bstride; sp.scalar0 = scalar0; sp.wts = item_weights; sp.m = m;
+  dim3 grid((unsigned)(B * ((A + 3) / 4))), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (kind) {
+    case DACO_SIB_SOP: hipLaunchKernelGGL(sibling_backward_kernel<DACO_SIB_SOP>, grid, block, 0, s, sp); break;
+    case DACO_SIB_PCTSP: hipLaunchKernelGGL(sibling_backward_kernel<DACO_SIB_PCTSP>, grid, block, 0, s, sp); break;
+    case DACO_SIB_OP: hipLaunchKernelGGL(sibling_backward_kernel<DACO_SIB_OP>, grid, block, 0, s, sp); break;
+    case DACO_SIB_MKP: hipLaunchKernelGGL(sibling_backward_kernel<DACO_SIB_MKP>, grid, block, 0, s, sp); break;
+    default: set_error("daco_sibling_backward: unknown kind %d", kind); return DACO_E_BADARG;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("sibling_backward_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
 
 extern "C" int daco_sample_backward(void *stream, int B, int n, int A, int rows, const float *tau,
                                     long tau_bstride, const float *eta, long eta_bstride, float alpha,

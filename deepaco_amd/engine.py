@@ -254,6 +254,42 @@ def sibling_sample(kind, tau, eta, n_ants, alpha=1.0, beta=1.0, aux_vec=None, au
     return paths, logp, rowsum, lens, flags
 
 
+def sibling_backward(kind, tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, aux_vec=None, aux_mat=None,
+                     scalar0=0.0, item_weights=None):
+    """Gradient of sum(grad_logp * log_probs) w.r.t. eta for a fused sibling construction -> [B,n,n]."""
+    _require_gpu(tau, eta, paths, rowsum, grad_logp, aux_vec, aux_mat, item_weights)
+    n = tau.shape[-1]
+    B, rows, A = paths.shape
+    tau, tbs = _bstride(tau, n)
+    eta, ebs = _bstride(eta, n)
+    paths = paths.contiguous()
+    rowsum, grad_logp = _f32c(rowsum), _f32c(grad_logp)
+    if aux_vec is not None:
+        aux_vec = _f32c(aux_vec).reshape(-1, n)
+        if aux_vec.shape[0] != B:
+            aux_vec = aux_vec.expand(B, n).contiguous()
+    abs_ = 0
+    if aux_mat is not None:
+        aux_mat, abs_ = _bstride(aux_mat, n)
+    mdim = 0
+    if item_weights is not None:
+        item_weights = _f32c(item_weights)
+        mdim = item_weights.shape[-1]
+        if item_weights.dim() == 2:
+            item_weights = item_weights.unsqueeze(0).expand(B, n, mdim).contiguous()
+    dev = paths.device
+    with torch.cuda.device(dev):
+        grad = torch.zeros((B, n, n), dtype=torch.float32, device=dev)
+        rc = _lib.lib().daco_sibling_backward(
+            _stream(dev), SIB_KINDS[kind], B, n, A, rows, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+            float(beta), aux_vec.data_ptr() if aux_vec is not None else None,
+            aux_mat.data_ptr() if aux_mat is not None else None, abs_, float(scalar0),
+            item_weights.data_ptr() if item_weights is not None else None, mdim, paths.data_ptr(), rowsum.data_ptr(),
+            grad_logp.data_ptr(), lens.contiguous().data_ptr() if lens is not None else None, grad.data_ptr())
+    _lib.check(rc, "daco_sibling_backward")
+    return grad
+
+
 class PickService:
     """ACO.pick_move as a service for the sibling problems (op, pctsp, sop, smtwtp, bpp, mkp):
     build the fused transition matrix once per construction, then draw one action per ant per call

@@ -14,7 +14,8 @@ Each class keeps the constructor, method names and return layouts of the referen
 The feasibility rules themselves stay on the caller's side of that boundary, as in the
 reference, but vectorised over ants as torch ops on the device (the reference loops over ants
 in Python for OP and MKP, op/aco.py:208-215, mkp/aco.py:174-181).  `sample()` returns
-log-probabilities that carry gradient to the heuristic (autograd.Function around each draw).
+log-probabilities that carry gradient to the heuristic (one autograd.Function around the fused
+construction; around each draw on the step-wise path).
 Pass `_noise=[q_1, q_2, ...]` (the reference's recorded Exp(1) tensors) to reproduce the
 reference's solutions bit for bit.
 """
@@ -90,15 +91,21 @@ class _Base:
         return act, logp
 
     def _fused(self, kind, require_prob, noise, **kw):
-        """One-launch construction (daco_sibling_sample).  Gradients are not wired through the fused kernels
-        yet: callers fall back to the draw-by-draw path when the heuristic requires grad."""
+        """One-launch construction (daco_sibling_sample).  With a heuristic that requires grad the log-probs come
+        from autograd.SiblingSampleFn (backward = daco_sibling_backward, a replay of the routes; n <= 1024)."""
         it = self._calls
         self._calls += 1
         mode = "race_noise" if noise is not None else self.sampler
         nz = None if noise is None else torch.stack(list(noise)).unsqueeze(0)
-        paths, logp, _, lens, flags = engine.sibling_sample(
-            kind, self.pheromone.detach().float(), self.heuristic.detach().float(), self.n_ants, self.alpha, self.beta,
-            mode=mode, noise=nz, seed=self.seed, it=it, require_prob=require_prob, **kw)
+        if self._wants_grad(require_prob):
+            from .autograd import SiblingSampleFn
+            paths, logp, lens, flags = SiblingSampleFn.apply(self.heuristic, self.pheromone, kind, self.n_ants, self.alpha,
+                                                             self.beta, mode, nz, self.seed, it, kw)
+            lens = lens if lens.numel() else None
+        else:
+            paths, logp, _, lens, flags = engine.sibling_sample(
+                kind, self.pheromone.detach().float(), self.heuristic.detach().float(), self.n_ants, self.alpha, self.beta,
+                mode=mode, noise=nz, seed=self.seed, it=it, require_prob=require_prob, **kw)
         fl = int(flags[0])
         if fl & 1:
             raise ValueError("a transition row had no feasible candidate")
@@ -266,7 +273,7 @@ class SOP(_Base):
         return engine.tour_costs(self.distances, paths.contiguous().unsqueeze(0), closed=False)[0]
 
     def gen_path(self, require_prob=False, *, _noise=None, _stepwise=False):
-        if not _stepwise and not self._wants_grad(require_prob):
+        if not _stepwise and not (self._wants_grad(require_prob) and self.heuristic.shape[-1] > 1024):
             prec = self.prec_cons.float()
             return self._fused("sop", require_prob, _noise, aux_vec=prec.sum(dim=1), aux_mat=prec.T.contiguous())
         self._begin()
@@ -348,7 +355,7 @@ class PCTSP(_Base):
         return length + ((1 - seen) * self.penalties).sum(dim=1)
 
     def gen_sol(self, require_prob=False, *, _noise=None, _stepwise=False):
-        if not _stepwise and not self._wants_grad(require_prob):
+        if not _stepwise and not (self._wants_grad(require_prob) and self.heuristic.shape[-1] > 1024):
             return self._fused("pctsp", require_prob, _noise, aux_vec=self.prizes.float(), scalar0=self.min_prizes)
         self._begin()
         A, n, dev = self.n_ants, self.n, self.device
@@ -455,7 +462,7 @@ class OP(_Base):
         return mask
 
     def gen_sol(self, require_prob=False, *, _noise=None, _stepwise=False):
-        if not _stepwise and not self._wants_grad(require_prob):
+        if not _stepwise and not (self._wants_grad(require_prob) and self.heuristic.shape[-1] > 1024):
             d = self.distances.float().contiguous()
             return self._fused("op", require_prob, _noise, aux_vec=d[:, 0].contiguous(), aux_mat=d,
                                scalar0=float(self.max_len))
@@ -614,7 +621,7 @@ class MKP(_Base):
         return mask, knapsack
 
     def gen_sol(self, require_prob=False, *, _noise=None, _start=None, _stepwise=False):
-        if not _stepwise and not self._wants_grad(require_prob):
+        if not _stepwise and not (self._wants_grad(require_prob) and self.heuristic.shape[-1] > 1024):
             return self._fused("mkp", require_prob, _noise, item_weights=self.weight.float(), scalar0=float(self.n // 2),
                                start=None if _start is None else _start.view(1, -1))
         self._begin()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 111 /* 0.1.11: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 112 /* 0.1.11: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -213,6 +213,19 @@ int daco_sibling_sample(void *stream, int kind, int B, int n, int A,
                         uint64_t seed, uint64_t iter, uint32_t ant_gid0, int Lmax,
                         int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
                         void *workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_sibling_backward -- daco_sample_backward for the fused sibling constructions: the gradient of
+ * sum(grad_logp * log_probs) w.r.t. eta for solutions drawn by daco_sibling_sample (same kind, aux_vec,
+ * aux_mat, scalar0, item_weights; paths / rowsum / lens as that call returned them).  aux_mat is the
+ * caller's dense [B][n][n] matrix.  n <= 1024.  grad_eta [B][n][n] is accumulated into (caller zeroes).
+ */
+int daco_sibling_backward(void *stream, int kind, int B, int n, int A, int rows,
+                          const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                          float alpha, float beta, const float *aux_vec, const float *aux_mat,
+                          long aux_mat_bstride, float scalar0, const float *item_weights, int m,
+                          const int64_t *paths, const float *rowsum, const float *grad_logp,
+                          const int32_t *lens, float *grad_eta);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_sample_backward -- replaces autograd through ACO.gen_path(require_prob=True)

@@ -189,7 +189,7 @@ def run_batches(cases, seed):
     return sum(0 if batch_case(c, rng, dev) else 1 for c in range(cases))
 
 
-def sibling_case(c, rng, dev):
+def sibling_case(c, rng, dev, grad=False):
     """fused sibling constructions (one launch) against their draw-by-draw service path: same Philox counters,
     identical solutions (SOP precedences, PCTSP prize threshold, OP length budget, MKP knapsacks)."""
     kind = int(rng.integers(0, 4))
@@ -243,18 +243,28 @@ def sibling_case(c, rng, dev):
         make = lambda: ACO(prize.to(dev), w.to(dev), n_ants=A, device="cuda:0", sampler=sampler, seed=seed)
         name = "gen_sol"
     a1, a2 = make(), make()
+    if grad:                                                # gradient to the heuristic: fused replay vs per-draw autograd
+        h = (torch.rand(a1.heuristic.shape, generator=g) + 0.05).to(dev)
+        a1.heuristic, a2.heuristic = h.clone().requires_grad_(True), h.clone().requires_grad_(True)
     s1, l1 = getattr(a1, name)(True, **kw)
     s2, l2 = getattr(a2, name)(True, _stepwise=True, **kw)
     ok = s1.shape == s2.shape and torch.equal(s1, s2) and torch.allclose(l1, l2, rtol=1e-5, atol=2e-6)
+    if grad and ok:
+        w = torch.linspace(-1, 1, l1.shape[1], device=dev) if l1.shape[1] > 1 else torch.ones(1, device=dev)
+        (l1.sum(0) * w).sum().backward()
+        (l2.sum(0) * w).sum().backward()
+        g1, g2 = a1.heuristic.grad, a2.heuristic.grad
+        scale = float(g2.abs().max()) + 1e-30
+        ok = torch.allclose(g1, g2, rtol=3e-4, atol=3e-6 * scale)
     if not ok:
-        print(f"MISMATCH sibling case {c}: kind={kind} n={n} A={A} sampler={sampler} seed={seed}", flush=True)
+        print(f"MISMATCH sibling case {c}: kind={kind} n={n} A={A} sampler={sampler} seed={seed} grad={grad}", flush=True)
     return ok
 
 
-def run_siblings(cases, seed):
+def run_siblings(cases, seed, grad=False):
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
-    return sum(0 if sibling_case(c, rng, dev) else 1 for c in range(cases))
+    return sum(0 if sibling_case(c, rng, dev, grad) else 1 for c in range(cases))
 
 
 def grad_case(c, rng, dev):

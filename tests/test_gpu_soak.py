@@ -35,3 +35,8 @@ def test_random_fused_siblings_equal_their_stepwise_paths():
 def test_random_gradients_match_the_closed_form():
     import soak_parity
     assert soak_parity.run_grads(30, 4) == 0
+
+
+def test_random_fused_sibling_gradients_equal_the_stepwise_autograd():
+    import soak_parity
+    assert soak_parity.run_siblings(30, 17, grad=True) == 0
