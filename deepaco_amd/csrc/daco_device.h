@@ -156,4 +156,13 @@ __device__ inline float pw(float x, float a) {
   return powf(x, a);
 }
 
+// d(tau^a * eta^b)/d eta = b * tau^a * eta^(b-1), written as b * pk / eta wherever eta != 0 (the expression the
+// gradient fixtures pin); at eta == 0 that would be 0/0, while the reference's autograd (tsp/aco.py:171-172)
+// gives tau^a for b = 1, 0 for b > 1 and inf for b < 1.
+__device__ inline float dprob_deta(float pk, float t, float e, float alpha, float beta) {
+  if (e != 0.0f) return beta * (pk / e);
+  if (beta == 1.0f) return pw(t, alpha);
+  return beta > 1.0f ? 0.0f : __builtin_inff();
+}
+
 }  // namespace daco

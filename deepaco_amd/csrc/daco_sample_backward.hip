@@ -80,8 +80,9 @@ sample_backward_kernel(const BackwardParams p) {
           }
           if (!open) continue;
           const float e = erow[k];
-          const float pk = pw(trow[k], p.alpha) * pw(e, p.beta);
-          float val = -c * p.beta * (pk / e);
+          const float tk = trow[k];
+          const float pk = pw(tk, p.alpha) * pw(e, p.beta);
+          float val = -c * dprob_deta(pk, tk, e, p.alpha, p.beta);
           if (k == j) val += g * p.beta / e;
           unsafeAtomicAdd(grow + k, val);
         }
@@ -196,8 +197,9 @@ sibling_backward_kernel(const SibBackwardParams q) {
           const int k = lane + 64 * c;
           if (c < chunks && ((open >> c) & 1u)) {
             const float e = erow[k];
-            const float pk = pw(trow[k], p.alpha) * pw(e, p.beta);
-            float val = -cg * p.beta * (pk / e);
+            const float tk = trow[k];
+            const float pk = pw(tk, p.alpha) * pw(e, p.beta);
+            float val = -cg * dprob_deta(pk, tk, e, p.alpha, p.beta);
             if (k == j) val += g * p.beta / e;
             unsafeAtomicAdd(grow + k, val);
           }

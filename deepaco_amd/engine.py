@@ -481,7 +481,7 @@ class BatchedTSP:
 
     def __init__(self, distances, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
                  pheromone=None, heuristic=None, min=None, sampler="scan", seed=None, ant_gid0=0,
-                 fixed_start=-1, local_search=None):
+                 fixed_start=-1, local_search=None, inference=False):
         _require_gpu(distances)
         assert distances.dim() == 3
         self.distances = _f32c(distances)
@@ -506,6 +506,7 @@ class BatchedTSP:
         self.fixed_start = fixed_start
         assert local_search in (None, "2opt", "nls")
         self.local_search = local_search          # tsp_nls/aco.py: applied to the tours before costing
+        self.inference = inference                # tsp_nls/aco.py:235,242: 2-opt sweeps n//4 (training) or 10000 (inference)
         self._hdist = None
         self._cmin = None
 
@@ -535,7 +536,7 @@ class BatchedTSP:
             self.iteration += 1
         if self.local_search is not None:
             tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
-            maxt = self.n // 4
+            maxt = 10000 if self.inference else self.n // 4
             if self.local_search == "2opt":
                 two_opt_(self.distances, tours, maxt)
             else:
@@ -669,10 +670,10 @@ def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1
     exact = exchange == "tours"
 
     def sample_fn(tau, lo, n_local, it):
-        # exact: colony-wide ant ids (ant lo + a of instance b is ant b*A + lo + a of the single-GPU colony)
+        # colony-wide ant ids in both modes (ant lo + a of instance b is ant b*A + lo + a of the single-GPU colony):
+        # rank-local ids would overlap when n_ants % world != 0 (shard_range gives the first ranks one ant more)
         paths, _, _, _, costs, nbr = tsp_sample(tau, eta, n_local, alpha, beta, mode=sampler, seed=seed, it=it,
-                                                ant_gid0=lo if exact else rank * B * n_local,
-                                                ant_gid_bstride=n_ants if exact else 0, batch=B, dist=dist_,
+                                                ant_gid0=lo, ant_gid_bstride=n_ants, batch=B, dist=dist_,
                                                 want_nbr=not exact)
         state["costs"], state["nbr"] = costs, nbr
         return paths

@@ -31,7 +31,9 @@ def infer_tsp_batch(coords, n_ants, t_aco, k_sparse, net=None, node_feature="coo
         heu = net.forward_batch(x, ei, ea)
         heuristic = net.reshape_batch(n, ei, heu) + EPS
     colony = engine.BatchedTSP(dist, n_ants=n_ants, heuristic=heuristic, sampler=sampler, seed=seed,
-                               local_search=local_search, fixed_start=0 if local_search else -1, **aco_kw)
+                               local_search=local_search, fixed_start=0 if local_search else -1,
+                               inference=True,      # tsp_nls/test.py:30 aco.run(t, inference=True): 2-opt to convergence
+                               **aco_kw)
     if net is None:
         colony.sparsify(k_sparse)
     out, done = [], 0

@@ -46,7 +46,12 @@ class _PickFn(torch.autograd.Function):
         inside = (logp > torch.log(torch.tensor(eps, device=logp.device))) & \
                  (logp < torch.log(torch.tensor(1 - eps, device=logp.device)))
         g = (glogp * inside).unsqueeze(1)
-        contrib = -g * b * p / (e_rows * S.unsqueeze(1))
+        # d p_k / d eta_k = b tau^a eta^(b-1): b p/eta where eta != 0; at eta == 0 the reference's autograd gives
+        # tau^a (b = 1) or 0 (b > 1), not 0/0
+        zero = e_rows == 0
+        dp = torch.where(zero, (tau[prev] ** a) * mask if b == 1 else torch.zeros_like(p),
+                         b * p / torch.where(zero, torch.ones_like(e_rows), e_rows))
+        contrib = -g * dp / S.unsqueeze(1)
         contrib[torch.arange(A, device=prev.device), act] += (g.squeeze(1) * b) / e_rows[torch.arange(A), act]
         grad = torch.zeros_like(eta).index_add_(0, prev, contrib)
         return (grad,) + (None,) * 8

@@ -2,7 +2,7 @@
 """Randomised soak: scan-draw tours (all lane layouts, TSP and CVRP) against the CPU oracle on random sizes,
 ant counts, seeds and value distributions (uniform, heavy-tailed, sparse with exact zeros, tiny).
 usage: python tests/soak_parity.py [cases] [seed]   -- prints one line per mismatch and a summary
-(test infrastructure: tests/test_gpu_soak.py runs a short soak in the GPU suite)."""
+(test infrastructure: tests/test_gpu_08_soak.py runs a short soak in the GPU suite)."""
 import os
 import sys
 import time

