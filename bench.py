@@ -7,32 +7,96 @@ one colony iteration over the whole batch: tour construction (the dominant kerne
 costs -> best-so-far tracking -> fused evaporate+deposit pheromone update.  Inputs are resident
 in HBM before the timed region.  value = N_gpus * B * A * steps / wall.
 
-Extra objects on the JSON line:
-  roofline     dominant kernel (tsp_scan32_kernel for the default workload) timed live with HIP events on the launch
-               stream; achieved = algorithmic bytes per launch / average launch duration.
-               Algorithmic bytes per ant-tour follow SURVEY.md 8(d):
-               (n-1)*8n + 8n + 8n^2/A + 8n  (two f32 rows per step, i64 path writes, amortised
-               update) -- the kernel itself streams ONE fused row per step, see DESIGN.md.
-  cpu_baseline torch-CPU port of the reference's op sequence (oracle/torch_port.py), timed on
-               this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+Launching: `python bench.py --gpus N` starts N ranks itself (one process per GPU, RCCL process group);
+under torchrun (RANK / WORLD_SIZE in the environment) it is one of the ranks.
+
+Objects on the JSON line besides the contract's keys:
+  roofline      dominant kernel (tsp_scan32_kernel for the default workload) timed live with HIP events on the
+                launch stream.  The fused transition rows live in L2/MALL, so the bound is the L2 -> CU row
+                stream: achieved = row bytes per launch / kernel time against the guide's aggregate L2 figure
+                (MI355X_MICROARCH.md: 34.5 TB/s).  `algorithmic` holds SURVEY.md 8(d)'s figure
+                ((n-1)*8n + 8n + 8n^2/A + 8n bytes per ant-tour) over the same time and its ratio to the HBM peak;
+                `hbm` the counter-measured HBM-side bytes per launch (from profiles/, source named) next to the
+                compulsory floor.
+  sustained     the same step loop run for >= --min-seconds after the timed region (so that samplers outside
+                this process can see the GPU busy); not the metric.
+  cpu_baseline  torch-CPU port of the reference's op sequence (oracle/torch_port.py) on this host's cores,
+                16 instances x 20 iterations of the same workload run as 16 parallel processes
+                (rank 0, N = 1 only), and the best-cost gap against the GPU path on the same instances.
+  extras        BASELINE.json's other single-GPU configurations (2, 3, 4, the per-GPU share of 5), the 2-opt
+                kernel and the GNN forward, each with its own roofline object (N = 1 only; --no-extras skips).
+  rccl          N > 1: ranks, backend and the measured all-reduce bus bandwidth of a [B, n, n] f32 buffer.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
-L2_ROW_STREAM_GBS = 18800.0    # measured L2->L1 ceiling for 2 KB row reads (tools/l2_row_stream_bench.hip)
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md, HBM section)
+PEAK_L2_GBS = 34500.0          # aggregate L2 bandwidth (MI355X_MICROARCH.md, L2 section)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=500)
+    ap.add_argument("--ants", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
+    ap.add_argument("--sampler", default="scan", choices=["scan", "scan_wave", "race"])
+    ap.add_argument("--k-sparse", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configurations")
+    ap.add_argument("--cpu-instances", type=int, default=16)
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="length of the sustained (untimed-by-metric) loop")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
+    ap.add_argument("--shard", default="instances", choices=["instances", "ants"],
+                    help="instances: B colonies per GPU, no collective (weak scaling, default); "
+                         "ants: the same B colonies on every GPU, A/N ants each, one collective per iteration "
+                         "(strong scaling)")
+    ap.add_argument("--exchange", default="tours", choices=["tours", "delta"],
+                    help="--shard ants: all-gather of the tours (int16; exact, default) or all-reduce of delta-tau")
+    ap.add_argument("--force-device", type=int, default=None,
+                    help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start N copies of this script, one per GPU, wired up through
+    the torch.distributed environment variables.  Rank 0's stdout (the JSON line) passes through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------- inputs
 def make_instances(B, n, seed):
     """coords ~ U[0,1)^2 (tsp/train.ipynb:84), distances with diag 1e9 (tsp/utils.py:4-14)."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     coords = torch.rand(B, n, 2, generator=g)
     dist = torch.cdist(coords, coords)
@@ -41,42 +105,69 @@ def make_instances(B, n, seed):
     return dist
 
 
-def bytes_per_tour(n, A):
-    return (n - 1) * 8 * n + 8 * n + 8 * n * n / A + 8 * n
+def bytes_per_tour(n, A, steps=None):
+    """two f32 rows per step, i64 path writes, the update's tau round trip shared by A ants and its
+    re-read of the paths."""
+    steps = n - 1 if steps is None else steps
+    return steps * 8 * n + 8 * n + 8 * n * n / A + 8 * n
 
 
-def log(msg):
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+def sampler_layout(n, sampler):
+    """daco_tsp_sample's layout rule -> (kernel name, floats per fused row as the kernel streams it)."""
+    lanes = 64 if sampler != "scan" or n > 512 else (16 if n <= 256 else 32)
+    name = {16: "scan16_kernel", 32: "tsp_scan32_kernel", 64: "tsp_sample_kernel"}[lanes]
+    if lanes < 64:
+        row = (n + 4 * lanes - 1) // (4 * lanes) * (4 * lanes)
+    else:
+        row = (n + 255) // 256 * 256 if n > 128 else n
+    return name, row
 
 
-def cpu_baseline(d, k_sparse, n_ants, iters, budget_s=25.0):
-    """Reference CPU path (torch port) on ONE instance of the same workload, `iters` colony
-    iterations (bounded: stops early once budget_s is exceeded).  The intra-op thread count is
-    calibrated on a few rollout steps (torch's default of one thread per logical CPU is far from
-    optimal for [512 x 500] tensors on a many-core host) and reported as `cores`."""
+def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, traffic_source=None):
+    """Roofline object of a tour-construction launch: L2 row stream as the bound, SURVEY 8(d)'s algorithmic bytes and
+    the HBM-side picture next to it."""
+    name, row = sampler_layout(n, sampler)
+    steps = n - 1 if steps_per_tour is None else steps_per_tour
+    row_bytes = B * A * steps * 4.0 * row
+    alg_bytes = B * A * bytes_per_tour(n, A, steps)
+    ach = row_bytes / (kern_ms * 1e-3) / 1e9
+    compulsory = B * (8.0 * n * n + 8.0 * A * n)
+    return {"bound": "l2", "achieved": ach, "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": ach / PEAK_L2_GBS,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": name, "kernel_ms": kern_ms, "row_bytes_per_launch": row_bytes,
+            "algorithmic": {"bytes_per_launch": alg_bytes, "GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                            "over_hbm_peak": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                            "note": "SURVEY 8(d) bytes / kernel time; above the HBM peak because the rows are "
+                                    "L2/MALL-resident and tau^a*eta^b is fused into one row -- not a roofline fraction"},
+            "hbm": {"counter_bytes": traffic, "compulsory_bytes": compulsory,
+                    "ratio": traffic / compulsory if traffic else None,
+                    "GBps": traffic / (kern_ms * 1e-3) / 1e9 if traffic else None, "peak": PEAK_HBM_GBS}}
+
+
+def time_launches(fn, steps, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+# ---------------------------------------------------------------------------------------------- CPU leg
+def _cpu_colony(job):
+    """One instance of the workload on the reference's CPU op sequence (a worker process of cpu_baseline)."""
+    import torch
     from oracle import torch_port
+    d, k_sparse, n_ants, iters, threads, seed, budget_s = job
+    torch.set_num_threads(threads)
+    torch.manual_seed(seed)
     _, idx = torch.topk(d, k=k_sparse, dim=1, largest=False)
     sparse = torch.full_like(d, 1e10)
     sparse.scatter_(1, idx, torch.gather(d, 1, idx))
     heu = 1 / sparse
-    n = d.shape[0]
-    ncpu = os.cpu_count() or 1
-    best_t, best_threads = None, 1
-    for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
-        torch.set_num_threads(th)
-        tau = torch.ones_like(d)
-        cur = torch.randint(0, n, (n_ants,))
-        mask = torch.ones(n_ants, n)
-        t0 = time.perf_counter()
-        for _ in range(12):                      # 12 steps of tsp/aco.py pick_move's op stream
-            w = (tau[cur] ** 1) * (heu[cur] ** 1) * mask
-            cur = torch.distributions.Categorical(w + 1e-30).sample()
-        dt = time.perf_counter() - t0
-        log(f"cpu calibration: {th} threads -> {dt/12*1e3:.2f} ms/step")
-        if best_t is None or dt < best_t:
-            best_t, best_threads = dt, th
-    torch.set_num_threads(best_threads)
-    torch.manual_seed(1234)
     tau = torch.ones_like(d)
     lowest, done = float("inf"), 0
     t0 = time.perf_counter()
@@ -88,48 +179,169 @@ def cpu_baseline(d, k_sparse, n_ants, iters, budget_s=25.0):
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    log(f"cpu port: {done} iterations in {dt:.1f}s")
-    out = {"value": n_ants * done / dt, "unit": "ant-tours/s", "cores": best_threads, "kind": "port",
-           "sample": f"1 instance x {n_ants} ants x {done} colony iterations of the same TSP-{n} workload "
-                     f"(oracle/torch_port.py: the reference's aten op sequence, torch {torch.__version__} CPU, "
-                     f"{best_threads} intra-op threads calibrated on a {ncpu}-CPU host)"}
-    return out, lowest, done
+    return lowest, done, time.perf_counter() - t0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nodes", type=int, default=500)
-    ap.add_argument("--ants", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
-    ap.add_argument("--sampler", default="scan", choices=["scan", "scan_wave", "race"])
-    ap.add_argument("--k-sparse", type=int, default=None)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
-    ap.add_argument("--shard", default="instances", choices=["instances", "ants"],
-                    help="instances: B colonies per GPU, no collective (weak scaling, default); "
-                         "ants: the same B colonies on every GPU, A/N ants each, one all-reduce of the "
-                         "pheromone deposits per iteration (strong scaling)")
-    ap.add_argument("--exchange", default="tours", choices=["tours", "delta"],
-                    help="--shard ants: all-gather of the tours (int16; exact, default) or all-reduce of delta-tau")
-    ap.add_argument("--force-device", type=int, default=None,
-                    help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
-    args = ap.parse_args()
+def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=100.0):
+    """Reference CPU path (torch port): `instances` colonies of the same workload, `iters` iterations each, as
+    parallel processes with `threads` intra-op threads each (calibrated on a few rollout steps: torch's default of
+    one thread per logical CPU is far from optimal for [512 x 500] tensors on a many-core host).
+    Returns (cpu_baseline object, per-instance best costs, iterations done)."""
+    import multiprocessing as mp
+    import torch
+    n = dist_cpu.shape[1]
+    ncpu = os.cpu_count() or 1
+    d = dist_cpu[0]
+    heu = 1 / d
+    best_t, threads = None, 1
+    for th in sorted({t for t in (2, 4, 8, 16) if t <= ncpu}):
+        torch.set_num_threads(th)
+        tau = torch.ones_like(d)
+        cur = torch.randint(0, n, (n_ants,))
+        mask = torch.ones(n_ants, n)
+        t0 = time.perf_counter()
+        for _ in range(12):                      # 12 steps of tsp/aco.py pick_move's op stream
+            w = (tau[cur] ** 1) * (heu[cur] ** 1) * mask
+            cur = torch.distributions.Categorical(w + 1e-30).sample()
+        dt = time.perf_counter() - t0
+        log(f"cpu calibration: {th} threads -> {dt/12*1e3:.2f} ms/step")
+        if best_t is None or dt < best_t * 0.9:          # more threads only if they buy >= 10 %
+            best_t, threads = dt, th
+    instances = min(instances, dist_cpu.shape[0])
+    procs = max(1, min(instances, ncpu // threads))
+    jobs = [(dist_cpu[b].clone(), k_sparse, n_ants, iters, threads, 4321 + b, budget_s) for b in range(instances)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = pool.map(_cpu_colony, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    done = min(r[1] for r in res)
+    busy = max(r[2] for r in res)
+    tours = sum(r[1] for r in res) * n_ants
+    log(f"cpu port: {instances} instances x {done} iterations on {procs} processes x {threads} threads: "
+        f"{busy:.1f}s of colony time ({wall:.1f}s with process start-up)")
+    out = {"value": tours / busy, "unit": "ant-tours/s", "cores": procs * threads, "kind": "port",
+           "sample": f"{instances} instances x {n_ants} ants x {done} colony iterations of the same TSP-{n} workload "
+                     f"(oracle/torch_port.py: the reference's aten op sequence, torch {torch.__version__} CPU), "
+                     f"{procs} processes x {threads} intra-op threads on a {ncpu}-CPU host, {busy:.1f} s",
+           "one_process_value": n_ants * res[0][1] / res[0][2]}
+    return out, [r[0] for r in res], done
 
+
+# ---------------------------------------------------------------------------------------------- extras
+def extra_configs(dev, headline_colony):
+    """BASELINE.json's other single-GPU configurations, each one timed end to end (all kernels of an iteration) with
+    a roofline object for its dominant kernel (timed by HIP events inside the library where the entry offers it)."""
+    import torch
+    from deepaco_amd import engine
+    out = {}
+
+    def tsp(tag, n, A, B, k, steps):
+        col = engine.BatchedTSP(make_instances(B, n, 77).to(dev), n_ants=A, seed=5)
+        col.sparsify(k)
+        col.heuristic = col.heuristic.contiguous()
+        col.step(); col.step()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record(); b.record()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            col.step(events=ev[s])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        out[tag] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, AS iteration", "value": B * A / dt,
+                    "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "roofline": roofline_rows(n, A, B, "scan", kms)}
+        del col
+
+    tsp("c2_tsp100_a512_b256", 100, 512, 256, 20, 10)
+    tsp("c5_share_tsp1000_a2048_b64", 1000, 2048, 64, 100, 2)
+
+    # config 4: CVRP-100, capacity mask in the sampling kernel
+    n, A, B = 100, 512, 256
+    g = torch.Generator().manual_seed(3)
+    loc = torch.cat((torch.full((B, 1, 2), 0.5), torch.rand(B, n, 2, generator=g)), 1)
+    dem = torch.cat((torch.zeros(B, 1), torch.randint(1, 10, (B, n), generator=g).float()), 1)
+    d = torch.cdist(loc, loc)
+    i = torch.arange(n + 1)
+    d[:, i, i] = 1e-10
+    col = engine.BatchedCVRP(d.to(dev), dem.to(dev), n_ants=A, capacity=50, seed=1)
+    dt = time_launches(col.step, 10)
+    L = float(col.last_lens.float().mean())
+    # kernel time ~ iteration minus the deposit (no event hook on this entry): the whole iteration is charged
+    rf = roofline_rows(n + 1, A, B, "scan", dt * 1e3, steps_per_tour=L)
+    rf["kernel"] = "scan16_kernel<CVRP> (whole iteration charged: sampler + deposit)"
+    out["c4_cvrp100_a512_b256"] = {"workload": f"CVRP-{n} (capacity mask), n_ants={A}, {B} instances, AS iteration",
+                                   "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3,
+                                   "mean_route_len": L, "roofline": rf}
+    del col
+
+    # config 3: TSP-500 + NLS; the 2-opt kernel is 99 % of it
+    n, A, B = 500, 256, 64
+    col = engine.BatchedTSP(make_instances(B, n, 2).to(dev), n_ants=A, seed=1, local_search="nls", fixed_start=0)
+    col.sparsify(50)
+    dt = time_launches(col.step, 1, warm=1)
+    paths, _, _, _ = engine.tsp_sample(col.pheromone, col.heuristic, A, seed=3, batch=B, fixed_start=0)
+    tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, sweeps = engine.two_opt_(col.distances, tours, n // 4, want_sweeps=True)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter() - t0
+    nsw = float(sweeps.sum())
+    pair_bytes = 8.0 * (n - 1) * (n - 2) + 4 * n          # SURVEY 8(d): 4 f32 gathers per pair of a full sweep + the tour
+    ach = nsw * pair_bytes / t2 / 1e9
+    out["c3_tsp500_nls_a256_b64"] = {
+        "workload": f"TSP-{n} + NLS (2-opt kernel; T_nls=10, T_p=20, maxt={n // 4}), n_ants={A}, {B} instances",
+        "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3,
+        "two_opt": {"tours": B * A, "sweeps": nsw, "seconds": t2, "sweeps_per_s": nsw / t2,
+                    "pair_evaluations_per_s_full_sweep_equivalent": nsw * (n - 1) * (n - 2) / 2 / t2},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                     "traffic": None, "kernel": "two_opt_incr_kernel",
+                     "note": "SURVEY 8(d): (8(n-1)(n-2) + 4n) gathered bytes per best-improvement sweep x sweeps "
+                             "applied / kernel time; the distance matrix is L2-resident and the incremental kernel "
+                             "re-evaluates only the pairs a move touched, so this is a sweep-equivalent rate"}}
+    del col
+
+    # GNN forward (eval), 64 graphs of TSP-500 k=50 side by side
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(0)
+    net = Net().to(dev).eval()
+    n, k, B = 500, 50, 64
+    coords = torch.rand(B, n, 2, device=dev)
+    _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
+    with torch.no_grad():
+        dt = time_launches(lambda: net.forward_batch(coords, ei, ea), 5)
+    E = n * k
+    per_layer = 2.0 * E * 32 * 4 + 6.0 * n * 32 * 4 + 20e3          # SURVEY 8(d)
+    alg = B * 12 * per_layer
+    flops = B * 12 * 2.0 * 32 * 32 * (4 * n + E)
+    out["gnn_tsp500_k50_b64"] = {"workload": f"Net.forward eval, {B} graphs of TSP-{n} (k={k}) in one pass",
+                                 "value": B / dt, "unit": "graphs/s", "ms_per_step": dt * 1e3,
+                                 "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": PEAK_HBM_GBS,
+                                              "unit": "GB/s", "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                              "kernel": "gnn_edge_kernel + gnn_node_kernel x 12 layers (whole forward)",
+                                              "mfma_tflops": flops / dt / 1e12}}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- one rank
+def worker(args):
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"rank {rank}: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs "
+            f"(n_gpus = {world})")
     distributed = world > 1
     if distributed:
         import torch.distributed as dist_pkg
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev_index = local_rank if args.force_device is None else args.force_device
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: needs GPU {dev_index}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if distributed:
@@ -164,7 +376,6 @@ def main():
     for _ in range(args.warmup):
         colony.step()
     torch.cuda.synchronize()
-    log("warm-up done")
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for a, b in ev:      # create the handles; the library re-records them around the kernel
         a.record(); b.record()
@@ -177,71 +388,111 @@ def main():
     elapsed = barrier_max_time(timed, dev, distributed)
     log(f"timed region: {elapsed*1e3:.1f} ms for {args.steps} steps")
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps if not ant_sharded else None
-    tours = (B * A if ant_sharded else world * B * A) * args.steps
-    value = tours / elapsed
-    bpt = bytes_per_tour(n, A)
-    per_launch = (B * (colony.hi - colony.lo) if ant_sharded else B * A) * bpt
-    achieved = per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms else None      # GB/s, dominant kernel, this rank
+    tours_per_step = B * A if ant_sharded else world * B * A
+    value = tours_per_step * args.steps / elapsed
     gpu_best = colony.lowest_cost.detach().cpu()
-    # daco_tsp_sample's layout rule: 4 / 2 / 1 ants per wavefront
-    lanes = 64 if args.sampler != "scan" or n > 512 else (16 if n <= 256 else 32)
-    kernel_name = {16: "scan16_kernel", 32: "tsp_scan32_kernel", 64: "tsp_sample_kernel"}[lanes]
-    row_floats = (n + 4 * lanes - 1) // (4 * lanes) * (4 * lanes) if lanes < 64 else ((n + 255) // 256 * 256 if n > 128 else n)
+
+    # sustained loop (not the metric): the same steps for >= min-seconds
+    sustained = None
+    if args.min_seconds > 0:
+        chunk = max(1, int(0.25 / max(elapsed / args.steps, 1e-5)))
+        state = {"steps": 0}
+
+        def sustain():
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < args.min_seconds:
+                for _ in range(chunk):
+                    colony.step()
+                torch.cuda.synchronize()
+                state["steps"] += chunk
+                if distributed:          # every rank must run the same number of chunks (ant-sharded steps communicate)
+                    flag = torch.tensor([time.perf_counter() - t0 < args.min_seconds], dtype=torch.int32,
+                                        device=dev if args.dist_backend == "nccl" else "cpu")
+                    dist_pkg.broadcast(flag, 0)
+                    if not int(flag.item()):
+                        break
+        s_el = barrier_max_time(sustain, dev, distributed)
+        sustained = {"seconds": s_el, "steps": state["steps"], "value": tours_per_step * state["steps"] / s_el,
+                     "unit": "ant-tours/s"}
+        log(f"sustained: {state['steps']} steps in {s_el:.2f} s")
+
+    rccl = None
+    if distributed:
+        rccl = {"ranks": world, "backend": args.dist_backend,
+                "data_path_collective": "none (instance-sharded)" if not ant_sharded else
+                ("all-gather of int16 tours + f32 costs per iteration" if args.exchange == "tours"
+                 else "all-reduce of delta-tau [B,n,n] f32 per iteration")}
+        if args.dist_backend == "nccl":
+            buf = torch.ones((B, n, n), device=dev)
+            for _ in range(2):
+                dist_pkg.all_reduce(buf)
+            reps = 5
+            t_ar = barrier_max_time(lambda: [dist_pkg.all_reduce(buf) for _ in range(reps)], dev, True) / reps
+            nbytes = buf.numel() * 4
+            rccl["allreduce_bytes"] = nbytes
+            rccl["allreduce_ms"] = t_ar * 1e3
+            rccl["allreduce_busbw_GBps"] = 2 * (world - 1) / world * nbytes / t_ar / 1e9
 
     if rank == 0:
-        traffic = None
+        traffic = tsrc = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f"tsp{n}_a{A}_b{B}_{args.sampler}")
+                tj = json.load(open(tfile))
+                traffic = tj.get(f"tsp{n}_a{A}_b{B}_{args.sampler}")
+                tsrc = "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this workload, not collected in this run)" \
+                    if traffic else None
             except Exception:
                 traffic = None
         line = {
             "metric": "ant-tours/sec, TSP-500 n_ants=512", "value": value, "unit": "ant-tours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if ant_sharded else "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if ant_sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TSP-{n} random-Euclidean, n_ants={A}, {B} instances per GPU, "
                                    f"AS update, heuristic 1/d sparsified k={k_sparse}, sampler={args.sampler}",
                        "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": args.sampler,
                        "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": achieved / PEAK_HBM_GBS if achieved else None, "traffic": traffic,
-                         "kernel": kernel_name, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": per_launch,
-                         "note": "the transition rows (tau^a*eta^b fused, one row per ant-step) are served by L2, "
-                                 "not HBM, so the algorithmic GB/s of SURVEY 8(d) exceeds the HBM peak and `traffic` "
-                                 "(measured HBM bytes) is far below the algorithmic bytes; the binding resource is "
-                                 "L2->L1 row streaming, see roofline_l2 (DESIGN.md 3.1, profiles/)"},
-            # the bytes the kernel really moves per launch: one padded fused row per ant-step out of L2
-            "roofline_l2": None if not kern_ms else {
-                "bound": "l2", "unit": "GB/s", "peak": L2_ROW_STREAM_GBS,
-                "achieved": B * A * (n - 1) * 4.0 * row_floats / (kern_ms * 1e-3) / 1e9,
-                "frac": B * A * (n - 1) * 4.0 * row_floats / (kern_ms * 1e-3) / 1e9 / L2_ROW_STREAM_GBS,
-                "peak_spec": 34500.0,
-                "note": "row bytes streamed per launch / kernel time; peak = 18.8 TB/s, what a bare kernel that only "
-                        "streams the same 2 KB rows out of L2 reaches on MI355X at any occupancy "
-                        "(tools/l2_row_stream_bench.hip, profiles/r01_g_l2_row_stream.txt); peak_spec = the 34.5 TB/s "
-                        "aggregate L2 figure of MI355X_MICROARCH.md"},
+            "roofline": roofline_rows(n, A, B, args.sampler, kern_ms, traffic=traffic, traffic_source=tsrc)
+            if kern_ms else None,
+            "sustained": sustained,
             "gpu_mean_best_cost": float(gpu_best.mean()),
         }
-        if world == 1 and not args.no_cpu:
-            cb, cpu_best, done = cpu_baseline(dist_cpu[0], k_sparse, A, args.cpu_iters)
+        if rccl:
+            line["rccl"] = rccl
+        if world == 1 and not args.no_extras and not ant_sharded:
+            try:
+                line["extras"] = extra_configs(dev, colony)
+            except Exception as e:          # the headline must still be reported
+                log(f"extras failed: {e!r}")
+                line["extras"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu and not ant_sharded:
+            cb, cpu_best, done = cpu_baseline(dist_cpu, k_sparse, A, args.cpu_instances, args.cpu_iters)
             line["cpu_baseline"] = cb
-            # best-cost gap at equal iterations on the same instance (fresh GPU colonies, 16 seeds)
-            reps = 16
-            gcol = engine.BatchedTSP(dist_cpu[:1].repeat(reps, 1, 1).to(dev), n_ants=A, sampler=args.sampler, seed=99)
+            # best-cost gap: the same instances, equal iterations, fresh GPU colonies
+            ni = len(cpu_best)
+            gcol = engine.BatchedTSP(dist_cpu[:ni].to(dev), n_ants=A, sampler=args.sampler, seed=99)
             gcol.sparsify(k_sparse)
             gcol.run(done)
-            gb = float(gcol.lowest_cost.mean())
-            line["best_cost_gap"] = {"gpu_mean_best": gb, "cpu_best": cpu_best, "gap": (gb - cpu_best) / cpu_best,
-                                     "instances": 1, "iterations": done,
-                                     "note": "same instance, equal iterations; GPU value is the mean over 16 seeds"}
+            gb = gcol.lowest_cost.cpu()
+            cm = sum(cpu_best) / ni
+            line["best_cost_gap"] = {"gpu_mean_best": float(gb.mean()), "cpu_mean_best": cm,
+                                     "gap": (float(gb.mean()) - cm) / cm, "instances": ni, "iterations": done,
+                                     "gpu_better_or_equal_on": int(sum(float(gb[i]) <= cpu_best[i] for i in range(ni))),
+                                     "note": "same instances, equal iterations, independent RNG streams"}
             line["speedup_vs_cpu"] = value / cb["value"]
         print(json.dumps(line), flush=True)
     if distributed:
         dist_pkg.barrier()
         dist_pkg.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    worker(args)
 
 
 if __name__ == "__main__":

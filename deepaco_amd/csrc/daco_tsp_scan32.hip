@@ -17,6 +17,7 @@
 // tests hold it bit-exact against the CPU restatement of that specification.
 #include "daco_sample_kernel.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace daco {
 
@@ -46,180 +47,252 @@ __device__ inline float half_bcast_last(float x) {
 }
 __device__ inline uint32_t lowest_bit(uint32_t x) { return x & (0u - x); }
 
-// FUSED: tour lengths and the neighbour table are both produced (the colony iteration's call)
-template <int CH2, bool LOGP, bool FUSED>
+// number of j in 0..NJ-1 with run[j] < t for a nondecreasing run[] (binary search written as selects: 5 compares,
+// 11 v_cndmask, no dynamic register index); entries past NJ are +inf and fold away at compile time
+template <int NJ>
+__device__ inline int count_below(const float (&run)[16], float t) {
+  auto R = [&](int j) { return j < NJ ? run[j] : __builtin_inff(); };
+  const bool b3 = R(7) < t;
+  const bool b2 = (b3 ? R(11) : R(3)) < t;
+  const float lo = b2 ? R(5) : R(1), hi = b2 ? R(13) : R(9);
+  const bool b1 = (b3 ? hi : lo) < t;
+  const float e0 = b1 ? R(2) : R(0), e1 = b1 ? R(6) : R(4), e2 = b1 ? R(10) : R(8), e3 = b1 ? R(14) : R(12);
+  const float f0 = b2 ? e1 : e0, f1 = b2 ? e3 : e2;
+  const bool b0 = (b3 ? f1 : f0) < t;
+  // (the four probes leave element 15 untested: it is below t only if all sixteen are)
+  return ((b3 ? 8 : 0) | (b2 ? 4 : 0) | (b1 ? 2 : 0) | (b0 ? 1 : 0)) + ((NJ == 16 && run[15] < t) ? 1 : 0);
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// What a step costs was measured piece by piece (tools/scan32_ablate.hip, profiles/r02_scan32_ablation.txt): the
+// row stream itself runs at the L2 ceiling, and everything that made the first version 1.9x slower than that was
+// per-step small traffic -- an i64 path store, a 4-byte distance gather and a 4-byte neighbour-table store per ant
+// and step (2 active lanes per instruction), plus the LDS hand-over of the chosen lane's candidates.  So:
+//   * level 2 runs INSIDE the chosen lane: every lane keeps the running sums of its own NJ masked candidates
+//     (sequential f32 in slot order: the lane sum is the last of them), and after level 1 the chosen lane finds its
+//     candidate by a binary search over those sums.  Per-ant values (row sum, chosen lane, choice) are SGPRs
+//     (v_readlane / s_ff1), selected per half with one v_cndmask -- nothing is handed through LDS;
+//   * the visited flags are f16 0/1 in LDS (v_fma_mix_f32 multiplies the f32 weight by the f16 flag: still exact,
+//     one rounding), laid out so a lane reads its 16 flags with two 16-byte loads;
+//   * the tour stays in LDS (u16) while it is built.  When the workgroup's 8 tours are complete it writes them out
+//     together: paths as 64-byte runs (8 ants x i64) per step row, the neighbour table as 32-byte runs per node row
+//     through an inverse-permutation table in LDS, and the tour lengths from 64-edge gathers with all lanes active
+//     (summed in step order by one lane per ant, as the reference's sum).
+// The step loop touches memory only for the row.
+template <int CH2, bool LOGP>
 __global__ void __launch_bounds__(256)
 tsp_scan32_kernel(const SampleParams p) {
-  constexpr int NJ = CH2 * 4;                           // candidates per lane (<= 32)
-  constexpr int ROWF = CH2 * 128;                       // padded row length of this layout
-  // open[h][k] = 1.0f while node k is unvisited by ant h of the workgroup, else 0.0f
-  __shared__ __attribute__((aligned(16))) float open_flags[8][ROWF];
-  // per ant: [0..31] candidate slots of the chosen lane, [32] threshold, [33] chosen lane, [34] choice
-  __shared__ __attribute__((aligned(16))) float pick[8][40];
+  constexpr int NJ = CH2 * 4;                           // candidates per lane (<= 16)
+  constexpr int NG = (NJ + 7) / 8;                      // 16-byte flag groups per lane
+  static_assert(CH2 >= 1 && CH2 <= 4, "two ants per wavefront: n <= 512");
+  // open[h][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited by ant h, else 0.0.
+  // Slot j = c*4 + v of lane s is node c*128 + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
+  __shared__ __attribute__((aligned(16))) _Float16 open_flags[8][512];
+  __shared__ __attribute__((aligned(16))) uint16_t tour_s[8][512];   // tour_s[h][t] = node visited at step t
+  __shared__ __attribute__((aligned(16))) float dstage[4][2][64];    // epilogue: edge lengths of one 64-step chunk
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int up = lane >> 5, s = lane & 31;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
   const int bpi = (p.A + 7) >> 3;                       // workgroups per instance (8 ants each)
   const int b = w / bpi;
-  const int a0 = ((w - b * bpi) * 4 + wave) * 2;        // ants a0 (lower half), a0+1 (upper half)
-  if (a0 >= p.A) return;
+  const int abase = (w - b * bpi) * 8;                  // first ant of the workgroup
+  const int a0 = abase + wave * 2;                      // ants a0 (lower half), a0+1 (upper half)
   const int n = p.n, A = p.A, ld = p.ld;
+  const bool active = a0 < A;                           // (a wave without ants still joins the epilogue's barriers)
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
-  // odd A: the last upper half builds ant A-1 a second time (same counters, same tour, same stores)
+  // odd A: the last upper half builds ant A-1 a second time (same counters, same tour; its copy is not written)
   const int a = a0 + up < A ? a0 + up : A - 1;
   const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);   // lane 0 of each half
+  const bool upper = __builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFF00000000ull);  // per-half select mask
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
-  char *path_t = (char *)(p.paths + (size_t)b * n * A);                // row t of this instance's [n][A] block
-  const uint32_t a8 = (uint32_t)a * 8u, a4 = (uint32_t)a * 4u;
+  const uint32_t a4 = (uint32_t)a * 4u;
   char *logp_t = LOGP ? (char *)(p.logp + (size_t)b * (n - 1) * A) : nullptr;
   char *rs_t = (LOGP && p.rowsum) ? (char *)(p.rowsum + (size_t)b * (n - 1) * A) : nullptr;
-  const bool want_cost = FUSED || p.costs != nullptr, want_nbr = FUSED || p.nbr != nullptr;
-  const char *dist_b = want_cost ? (const char *)(p.dist + (size_t)b * p.dist_bs) : nullptr;
-  char *nbr_b = want_nbr ? (char *)(p.nbr + (size_t)b * n * A) : nullptr;        // [n][A] table of this instance
-  const uint32_t A4 = (uint32_t)A * 4u;
-  float *fl = open_flags[wave * 2 + up], *pk = pick[wave * 2 + up];
-#pragma unroll
-  for (int c = 0; c < CH2; ++c) *(float4 *)(fl + (c * 32 + s) * 4) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-  pk[s] = 0.0f;                                         // slots >= NJ stay zero for the whole kernel
-  if (s < 8) pk[32 + s] = 0.0f;
-  const int ubase = (lane & 32) << 2;                   // ds_bpermute byte address of this half's lane 0
-  // slot j = s of the chosen lane L is candidate (j/4)*128 + L*4 + j%4; lanes beyond NJ hold no slot
-  const int cbase = s < NJ ? ((s >> 2) << 7) | (s & 3) : 0;
+  _Float16 *fl = open_flags[wave * 2 + up];
+  uint16_t *tour = tour_s[wave * 2 + up];
+  // flag index of node k: group (k>>8), lane (k>>2)&31, element ((k>>7)&1)*4 + (k&3)
+  auto flag_index = [](int k) { return ((k >> 8) << 8) | (((k >> 2) & 31) << 3) | (((k >> 7) & 1) << 2) | (k & 3); };
+  bool feasible = true;
 
-  int prev;
-  if (p.start) prev = (int)p.start[(size_t)b * A + a];
-  else if (p.fixed_start >= 0) prev = p.fixed_start;
-  else {
-    const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0);
-    prev = (int)__umulhi(r.x, (uint32_t)n);
-  }
-  const int first = prev;
-  __builtin_amdgcn_wave_barrier();
-  if (lead) {
-    fl[prev] = 0.0f;
-    *(int64_t *)(path_t + a8) = prev;
-  }
-  __builtin_amdgcn_wave_barrier();
-  int pprev = 0;
-  float cost = 0.0f, dpend = 0.0f;
-  u32x4 ublk = {0, 0, 0, 0};                            // 128 cached uniforms per ant (lane s: block base+s)
-  uint64_t feasible = ~0ull;
+  if (active) {
+    const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) *(f16x8 *)(fl + g * 256 + s * 8) = ones;
+    int prev;
+    if (p.start) prev = (int)p.start[(size_t)b * A + a];
+    else if (p.fixed_start >= 0) prev = p.fixed_start;
+    else {
+      const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0);
+      prev = (int)__umulhi(r.x, (uint32_t)n);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lead) {
+      fl[flag_index(prev)] = (_Float16)0.0f;
+      tour[0] = (uint16_t)prev;
+    }
+    __builtin_amdgcn_wave_barrier();
+    u32x4 ublk = {0, 0, 0, 0};                          // 128 cached uniforms per ant (lane s: block base+s)
 
-  for (int tb = 0; tb < n; tb += 32) {
-    // uniform of step t: lane (t&31), component (t>>5)&3 of Philox block ((t>>7)<<5) + lane
-    if ((tb & 127) == 0) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((tb >> 7) << 5) + s));
-    const float ucur = u01(comp(ublk, (tb >> 5) & 3));
-    const int i1 = n - tb < 32 ? n - tb : 32;
-    for (int i = tb == 0 ? 1 : 0; i < i1; ++i) {
-      path_t += (size_t)A * 8;
-      const uint32_t voff = __umul24((uint32_t)prev, ldb) + lane_off;
-      float4 row[CH2], fo[CH2];
+    for (int tb = 0; tb < n; tb += 32) {
+      // uniform of step t: lane (t&31), component (t>>5)&3 of Philox block ((t>>7)<<5) + lane
+      if ((tb & 127) == 0) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((tb >> 7) << 5) + s));
+      const int ucur = __float_as_int(u01(comp(ublk, (tb >> 5) & 3)));
+      const int i1 = n - tb < 32 ? n - tb : 32;
+      for (int i = tb == 0 ? 1 : 0; i < i1; ++i) {
+        const uint32_t rowoff = __umul24((uint32_t)prev, ldb);
+        const uint32_t voff = rowoff + lane_off;
+        float4 row[CH2];
+        f16x8 fo[NG];
 #pragma unroll
-      for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
-      const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | (i << 2), __float_as_int(ucur)));
+        for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
+        const int u_lo = __builtin_amdgcn_readlane(ucur, i), u_hi = __builtin_amdgcn_readlane(ucur, i + 32);
+        const float u = __int_as_float(upper ? u_hi : u_lo);
 #pragma unroll
-      for (int c = 0; c < CH2; ++c) fo[c] = *(const float4 *)(fl + (c * 32 + s) * 4);
+        for (int g = 0; g < NG; ++g) fo[g] = *(const f16x8 *)(fl + g * 256 + s * 8);
 
-      // ---- level 1: which lane.  Closed candidates contribute p*0 = +0.0f; even and odd slots
-      // accumulate separately (packed fma: the products are exact, so each fma is one rounding)
-      f32x2 acc = {0.0f, 0.0f};
+        // ---- the lane's running sums in slot order.  A closed slot adds p*0 = +0.0f; the product with the
+        // 0/1 flag is exact, so each fma rounds once like an add.
+        float run[16];
+        float acc = 0.0f;
 #pragma unroll
-      for (int c = 0; c < CH2; ++c) {
-        acc = __builtin_elementwise_fma((f32x2){row[c].x, row[c].y}, (f32x2){fo[c].x, fo[c].y}, acc);
-        acc = __builtin_elementwise_fma((f32x2){row[c].z, row[c].w}, (f32x2){fo[c].z, fo[c].w}, acc);
-      }
-      const float part = acc.x + acc.y;
-      const float incl = half_scan_add<true>(part);
-      const float S = half_bcast_last(incl);
-      const float r = fmaxf(u * S, 1.401298464e-45f);   // keep r > 0 if u*S underflows
-      const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT);
-      const uint64_t alive = __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT);    // S > 0 <=> some open candidate has p > 0
-      feasible &= alive;
-      // what is left to cover inside the chosen lane: r - incl[L-1]; lane L forms its own
-      float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
-      excl = s == 0 ? 0.0f : excl;
-      const float thr = r - excl;
-      // ---- level 2: which candidate of lane L.  Lane L deals its NJ values to the lanes of its
-      // half through LDS; the same scan + first-lane pick then runs across candidates.
-      const bool mine = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit((uint32_t)m) |
-                                                            ((uint64_t)lowest_bit((uint32_t)(m >> 32)) << 32));
-      if (mine) {
-#pragma unroll
-        for (int c = 0; c < CH2; ++c) *(float4 *)(pk + 4 * c) = row[c];
-        *(float2 *)(pk + 32) = make_float2(thr, __int_as_float(s));
-      }
-      __builtin_amdgcn_wave_barrier();
-      const float cvraw = pk[s];
-      const float2 tl = *(const float2 *)(pk + 32);
-      const int mychoice = cbase + (__float_as_int(tl.y) << 2);
-      const float cv = cvraw * fl[mychoice];
-      const float sc = half_scan_add<(NJ > 16)>(cv);
-      const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP_OGT) & alive;   // (a dead row holds stale slots)
-      const uint64_t k = __builtin_amdgcn_fcmpf(sc, tl.x, FCMP_OGE) & pos;
-      uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
-      if (__builtin_expect(k0 == 0 || k1 == 0, 0)) {
-        // rounding: no candidate reached thr -> the lane's last open candidate with p > 0
-        const uint32_t q0 = (uint32_t)pos, q1 = (uint32_t)(pos >> 32);
-        if (k0 == 0 && q0) k0 = 0x80000000u >> __builtin_clz(q0);
-        if (k1 == 0 && q1) k1 = 0x80000000u >> __builtin_clz(q1);
-      }
-      const bool win = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit(k0) | ((uint64_t)lowest_bit(k1) << 32));
-      if (win) {
-        pk[34] = __int_as_float(mychoice);
-        fl[mychoice] = 0.0f;                            // visited
-      }
-      __builtin_amdgcn_wave_barrier();
-      // no feasible candidate (flagged; the reference raises): move to node 0 like the one-ant kernel and the oracle
-      const int choice = S > 0.0f ? __float_as_int(pk[34]) : 0;
-      __builtin_amdgcn_wave_barrier();
-
-      if (lead) {
-        if (!(S > 0.0f)) fl[0] = 0.0f;
-        *(int64_t *)(path_t + a8) = choice;
-        if constexpr (LOGP) {
-          const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);
-          *(float *)(logp_t + a4) = clamp_log(pc / S);
-          logp_t += (size_t)A * 4;
-          if (rs_t) { *(float *)(rs_t + a4) = S; rs_t += (size_t)A * 4; }
+        for (int c = 0; c < CH2; ++c) {
+          const int e = (c & 1) * 4;
+          acc = __builtin_fmaf(row[c].x, (float)fo[c >> 1][e + 0], acc); run[4 * c + 0] = acc;
+          acc = __builtin_fmaf(row[c].y, (float)fo[c >> 1][e + 1], acc); run[4 * c + 1] = acc;
+          acc = __builtin_fmaf(row[c].z, (float)fo[c >> 1][e + 2], acc); run[4 * c + 2] = acc;
+          acc = __builtin_fmaf(row[c].w, (float)fo[c >> 1][e + 3], acc); run[4 * c + 3] = acc;
         }
-        if (want_cost) {                                 // fused tour length, edge added one step late
-          cost = cost + dpend;
-          dpend = *(const float *)(dist_b + ((__umul24((uint32_t)choice, (uint32_t)n) + (uint32_t)prev) << 2));
+        // ---- level 1: which lane
+        const float part = acc;
+        const float incl = half_scan_add<true>(part);
+        const int incl_i = __float_as_int(incl);
+        const float S0 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 31));
+        const float S1 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 63));
+        const float S = upper ? S1 : S0;
+        const float r = fmaxf(u * S, 1.401298464e-45f);   // keep r > 0 if u*S underflows
+        const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT);
+        const bool alive0 = S0 > 0.0f, alive1 = S1 > 0.0f;                 // S > 0 <=> some open candidate has p > 0
+        feasible = feasible && alive0 && alive1;
+        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+        const int L0 = m0 ? __builtin_ctz(m0) : 0, L1 = m1 ? __builtin_ctz(m1) : 0;     // chosen lane of each half
+        // ---- level 2, in every lane (only lane L's result is read): what is left to cover inside the lane is
+        // r - incl[L-1]; the candidate is the first slot whose running sum reaches it (such a slot is open with
+        // p > 0; the threshold is kept > 0 so that a slot is "reached" only by a positive term)
+        float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
+        excl = s == 0 ? 0.0f : excl;
+        const float thr = fmaxf(r - excl, 1.401298464e-45f);
+        const int cnt = count_below<NJ>(run, thr);
+        int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
+        if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
+          // rounding: no running sum reached thr -> the lane's last open candidate with p > 0, which is where the
+          // running sum reaches its final value
+          const int last = count_below<NJ>(run, part);
+          if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
+          if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 + 32);
         }
-        if (want_nbr) *(uint32_t *)(nbr_b + __umul24((uint32_t)prev, A4) + a4) = (uint32_t)pprev | ((uint32_t)choice << 16);
+        // slot j of lane L is node (j>>2)*128 + L*4 + (j&3), flag ((j>>3)<<8) | L<<3 | (j&7).
+        // No feasible candidate (flagged; the reference raises): move to node 0 like the one-ant kernel and the oracle
+        const int c0 = alive0 ? (((j0 >> 2) << 7) | (j0 & 3)) + (L0 << 2) : 0;
+        const int c1 = alive1 ? (((j1 >> 2) << 7) | (j1 & 3)) + (L1 << 2) : 0;
+        const int f0 = alive0 ? ((j0 >> 3) << 8) | (L0 << 3) | (j0 & 7) : 0;
+        const int f1 = alive1 ? ((j1 >> 3) << 8) | (L1 << 3) | (j1 & 7) : 0;
+        const int choice = upper ? c1 : c0;
+        if (lead) {
+          fl[upper ? f1 : f0] = (_Float16)0.0f;            // visited
+          tour[tb + i] = (uint16_t)choice;
+          if constexpr (LOGP) {
+            const float pc = *(const float *)(Pb + rowoff + (uint32_t)choice * 4u);
+            *(float *)(logp_t + a4) = clamp_log(pc / S);
+            logp_t += (size_t)A * 4;
+            if (rs_t) { *(float *)(rs_t + a4) = S; rs_t += (size_t)A * 4; }
+          }
+        }
+        // the next step's flag loads must follow this store (same wave: the LDS executes them in program order);
+        // the compiler barrier keeps the program order
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        prev = choice;
       }
-      pprev = prev;
-      prev = choice;
     }
   }
-  if (lead) {
-    if (want_cost) {
-      cost = cost + dpend;
-      cost = cost + *(const float *)(dist_b + ((__umul24((uint32_t)first, (uint32_t)n) + (uint32_t)prev) << 2));
-      p.costs[(size_t)b * A + a] = cost;
-    }
-    if (want_nbr) {                                     // close the cycle: last -> first -> second
-      uint32_t *nbr_a = (uint32_t *)(nbr_b + a4);        // + node * A
-      const int second = (int)p.paths[((size_t)b * n + 1) * A + a];
-      if (n == 2) { nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)prev << 16); nbr_a[(size_t)prev * A] = (uint32_t)first | ((uint32_t)first << 16); }
-      else { nbr_a[(size_t)prev * A] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)second << 16); }
+  if (!feasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+
+  // ------------------------------------------------------------------ epilogue: the workgroup's 8 tours leave LDS
+  __syncthreads();
+  const int nant = A - abase < 8 ? A - abase : 8;        // ants of this workgroup (the last one may hold fewer)
+  {
+    // paths[b][t][abase + k]: 8 lanes = one 64-byte run per step row
+    int64_t *pb = p.paths + (size_t)b * n * A + abase;
+    const int k = threadIdx.x & 7;
+    if (k < nant)
+      for (int t = threadIdx.x >> 3; t < n; t += 32) pb[(size_t)t * A + k] = (int64_t)tour_s[k][t];
+  }
+  if (p.costs) {
+    // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], k = 1..n-1, then the closing edge -- f32, that order.
+    // 64 edges of each of the wave's two ants are gathered with every lane active and staged in LDS; lanes 0 and 32
+    // add their ant's 64 values one after the other.
+    const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+    const uint16_t *t0 = tour_s[wave * 2], *t1 = tour_s[wave * 2 + 1];
+    const float *mine = dstage[wave][up];
+    float cost = 0.0f;
+    if (active) {
+      for (int base = 1; base < n; base += 64) {
+        const int t = base + lane;
+        float d0 = 0.0f, d1 = 0.0f;
+        if (t < n) {
+          d0 = dist_b[(uint32_t)t0[t] * (uint32_t)n + t0[t - 1]];
+          d1 = dist_b[(uint32_t)t1[t] * (uint32_t)n + t1[t - 1]];
+        }
+        dstage[wave][0][lane] = d0;
+        dstage[wave][1][lane] = d1;
+        __builtin_amdgcn_wave_barrier();
+        if (lead) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float4 v = *(const float4 *)(mine + 4 * q);      // (slots past the tour's end hold +0.0f)
+            cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lead && a0 + up < A) {
+        const uint16_t *tm = up ? t1 : t0;
+        cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+        p.costs[(size_t)b * A + a0 + up] = cost;
+      }
     }
   }
-  if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+  if (p.nbr) {
+    // neighbour table nbr[b][node][ant] = prev | next << 16 (what the pheromone update consumes): invert the tours in
+    // LDS (the flag array is free now), then 8 lanes write one 32-byte run per node row
+    __syncthreads();                                     // every wave is done with its flags
+    uint16_t (*inv)[512] = reinterpret_cast<uint16_t (*)[512]>(open_flags);
+    for (int e = threadIdx.x; e < 8 * 512 / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int k = threadIdx.x & 7;
+    if (k < nant)                                         // (the other slots hold no tour: their entries are not nodes)
+      for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k][tour_s[k][t]] = (uint16_t)t;
+    __syncthreads();
+    uint32_t *nb = p.nbr + (size_t)b * n * A + abase;
+    if (k < nant)
+      for (int node = threadIdx.x >> 3; node < n; node += 32) {
+        const int t = inv[k][node];
+        const uint32_t pv = tour_s[k][t == 0 ? n - 1 : t - 1], nx = tour_s[k][t == n - 1 ? 0 : t + 1];
+        nb[(size_t)node * A + k] = pv | (nx << 16);
+      }
+  }
 }
 
 template <int CH2>
 static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 7) / 8;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
-  const bool fused = sp.costs && sp.nbr;
   static const int pad = getenv("DACO_SCAN32_LDS_PAD") ? atoi(getenv("DACO_SCAN32_LDS_PAD")) : 0;
-#define DACO_L32(L, F) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, L, F>), grid, block, pad, s, sp)
-  if (logp) { if (fused) DACO_L32(true, true); else DACO_L32(true, false); }
-  else { if (fused) DACO_L32(false, true); else DACO_L32(false, false); }
-#undef DACO_L32
+  if (logp) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, true>), grid, block, pad, s, sp);
+  else hipLaunchKernelGGL((tsp_scan32_kernel<CH2, false>), grid, block, pad, s, sp);
   return hipGetLastError();
 }
 
@@ -234,7 +307,6 @@ __global__ void __launch_bounds__(256)
 cvrp_scan32_kernel(const SampleParams p) {
   constexpr int NJ = CH2 * 4, ROWF = CH2 * 128;
   __shared__ __attribute__((aligned(16))) float open_flags[8][ROWF];
-  __shared__ __attribute__((aligned(16))) float pick[8][40];
   __shared__ __attribute__((aligned(16))) float dem_s[ROWF];          // demand of this instance, +inf padding
   __shared__ uint32_t hub_s[8][CH2 * 4];                               // per ant: set of nodes that follow the depot
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -250,13 +322,14 @@ cvrp_scan32_kernel(const SampleParams p) {
   if (a0 >= A) return;
   const int a = a0 + up < A ? a0 + up : A - 1;          // odd A: the last upper half repeats ant A-1
   const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);
+  const bool upper = __builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFF00000000ull);
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
   int64_t *path_a = p.paths + (size_t)b * Lmax * A + a;
   float *logp_a = LOGP ? p.logp + (size_t)b * (Lmax - 1) * A + a : nullptr;
   float *rs_a = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (Lmax - 1) * A + a : nullptr;
-  float *fl = open_flags[wave * 2 + up], *pk = pick[wave * 2 + up];
+  float *fl = open_flags[wave * 2 + up];
   const char *dist_b = (FUSED || p.costs) ? (const char *)(p.dist + (size_t)b * p.dist_bs) : nullptr;
   char *next_b = (FUSED || p.nbr) ? (char *)(p.nbr + (size_t)b * n * A) : nullptr;           // [n][A] table of this instance
   const uint32_t A4 = (uint32_t)A * 4u, a4 = (uint32_t)a * 4u;
@@ -269,10 +342,6 @@ cvrp_scan32_kernel(const SampleParams p) {
     *(float4 *)(fl + (c * 32 + s) * 4) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     dm[c] = *(const float4 *)(dem_s + (c * 32 + s) * 4);
   }
-  pk[s] = 0.0f;
-  if (s < 8) pk[32 + s] = 0.0f;
-  const int ubase = (lane & 32) << 2;
-  const int cbase = s < NJ ? ((s >> 2) << 7) | (s & 3) : 0;
   __builtin_amdgcn_wave_barrier();
   if (lead) path_a[0] = 0;
 
@@ -293,58 +362,53 @@ cvrp_scan32_kernel(const SampleParams p) {
       if ((t & 127) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 7) << 5) + s));
       ucur = u01(comp(ublk, (t >> 5) & 3));
     }
-    const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | ((t & 31) << 2), __float_as_int(ucur)));
+    const int ucur_i = __float_as_int(ucur);
+    const int u_lo = __builtin_amdgcn_readlane(ucur_i, t & 31), u_hi = __builtin_amdgcn_readlane(ucur_i, (t & 31) + 32);
+    const float u = __int_as_float(upper ? u_hi : u_lo);
 #pragma unroll
     for (int c = 0; c < CH2; ++c) fo[c] = *(const float4 *)(fl + (c * 32 + s) * 4);
     const float rem = p.capacity - used;
-    f32x2 acc = {0.0f, 0.0f};
+    // the lane's running sums in slot order; a closed slot (visited, over capacity, or the depot while standing on
+    // it) adds p*0 = +0.0f
+    float run[16];
+    float acc = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH2; ++c) {
       float4 f = fo[c];
       f.x = dm[c].x > rem ? 0.0f : f.x;  f.y = dm[c].y > rem ? 0.0f : f.y;
       f.z = dm[c].z > rem ? 0.0f : f.z;  f.w = dm[c].w > rem ? 0.0f : f.w;
       if (c == 0) f.x = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f.x;       // the depot, cvrp/aco.py:179
-      const f32x2 lo = (f32x2){row[c].x, row[c].y} * (f32x2){f.x, f.y}, hi = (f32x2){row[c].z, row[c].w} * (f32x2){f.z, f.w};
-      row[c] = make_float4(lo.x, lo.y, hi.x, hi.y);
-      acc = acc + lo;
-      acc = acc + hi;
+      acc = __builtin_fmaf(row[c].x, f.x, acc); run[4 * c + 0] = acc;
+      acc = __builtin_fmaf(row[c].y, f.y, acc); run[4 * c + 1] = acc;
+      acc = __builtin_fmaf(row[c].z, f.z, acc); run[4 * c + 2] = acc;
+      acc = __builtin_fmaf(row[c].w, f.w, acc); run[4 * c + 3] = acc;
     }
-    const float part = acc.x + acc.y;
+    const float part = acc;
     const float incl = half_scan_add<true>(part);
-    const float S = half_bcast_last(incl);
+    const int incl_i = __float_as_int(incl);
+    const float S0 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 31)), S1 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 63));
+    const float S = upper ? S1 : S0;
     const float r = fmaxf(u * S, 1.401298464e-45f);
     const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT) & act;
     feasible &= __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT) | ~act;
     float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
     excl = s == 0 ? 0.0f : excl;
-    const float thr = r - excl;
-    const bool mine = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit((uint32_t)m) |
-                                                          ((uint64_t)lowest_bit((uint32_t)(m >> 32)) << 32));
-    if (mine) {
-#pragma unroll
-      for (int c = 0; c < CH2; ++c) *(float4 *)(pk + 4 * c) = row[c];
-      *(float2 *)(pk + 32) = make_float2(thr, __int_as_float(s));
+    const float thr = fmaxf(r - excl, 1.401298464e-45f);
+    const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+    const int L0 = m0 ? __builtin_ctz(m0) : 0, L1 = m1 ? __builtin_ctz(m1) : 0;         // chosen lane of each half
+    // level 2 inside the chosen lane: first slot whose running sum reaches thr (see tsp_scan32_kernel)
+    const int cnt = count_below<NJ>(run, thr);
+    int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
+    if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
+      const int last = count_below<NJ>(run, part);
+      if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
+      if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 + 32);
     }
-    __builtin_amdgcn_wave_barrier();
-    const float cv = pk[s];
-    const float2 tl = *(const float2 *)(pk + 32);
-    const int mychoice = cbase + (__float_as_int(tl.y) << 2);
-    const float sc = half_scan_add<(NJ > 16)>(cv);
-    const uint64_t pos = __builtin_amdgcn_fcmpf(cv, 0.0f, FCMP_OGT) & act;
-    const uint64_t k = __builtin_amdgcn_fcmpf(sc, tl.x, FCMP_OGE) & pos;
-    uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
-    if (__builtin_expect(k0 == 0 || k1 == 0, 0)) {
-      const uint32_t q0 = (uint32_t)pos, q1 = (uint32_t)(pos >> 32);
-      if (k0 == 0 && q0) k0 = 0x80000000u >> __builtin_clz(q0);
-      if (k1 == 0 && q1) k1 = 0x80000000u >> __builtin_clz(q1);
-    }
-    const bool win = __builtin_amdgcn_inverse_ballot_w64((uint64_t)lowest_bit(k0) | ((uint64_t)lowest_bit(k1) << 32));
-    if (win) {
-      pk[34] = __int_as_float(mychoice);
-      if (mychoice != 0) fl[mychoice] = 0.0f;            // customers are visited once, the depot stays open
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int choice = __float_as_int(pk[34]);
+    // a half without a feasible candidate (flagged) or already finished moves to the depot
+    const int c0 = m0 ? (((j0 >> 2) << 7) | (j0 & 3)) + (L0 << 2) : 0;
+    const int c1 = m1 ? (((j1 >> 2) << 7) | (j1 & 3)) + (L1 << 2) : 0;
+    const int choice = upper ? c1 : c0;
+    if (lead && choice != 0) fl[choice] = 0.0f;          // customers are visited once, the depot stays open
     __builtin_amdgcn_wave_barrier();
 
     // ---- outputs: lane 0 of every half that is still building (one EXEC mask, no nesting)
@@ -431,11 +495,7 @@ hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
     case 1: return launch32<1>(sp, logp, s);
     case 2: return launch32<2>(sp, logp, s);
     case 3: return launch32<3>(sp, logp, s);
-    case 4: return launch32<4>(sp, logp, s);
-    case 5: return launch32<5>(sp, logp, s);
-    case 6: return launch32<6>(sp, logp, s);
-    case 7: return launch32<7>(sp, logp, s);
-    default: return launch32<8>(sp, logp, s);
+    default: return launch32<4>(sp, logp, s);        // (the dispatch rule sends n <= 512 here)
   }
 }
 

@@ -194,17 +194,18 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  * per wavefront, n <= 256); vec = 4 below 64 lanes:
  *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
  *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
- *              (lanes = 32: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
- *               end; the scan is Kogge-Stone in rows of 16, then lanes 16..31 add lane 15)
+ *              (lanes = 16: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
+ *               end; lanes = 32: the scan is Kogge-Stone in rows of 16, then lanes 16..31 add lane 15)
  *   S = incl[lanes-1];  r = max(u * S, denorm_min)
  *     u = component ((t>>lg)&3) of Philox(ctr=(((t>>(lg+2))<<lg) + (t&(lanes-1)), gid, iter, STREAM_SCAN)),
  *     lg = log2(lanes)
  *   L = first lane with incl[L] >= r and part[L] > 0
  *   inside lane L: thr = r - incl[L-1] (incl[-1] = 0);
- *     lanes = 64: walk its candidates in (c,v) order with the lane's own running sum (from +0.0f,
+ *     lanes = 64, 32: walk its candidates in (c,v) order with the lane's own running sum (from +0.0f,
  *       closed candidates add +0.0f); pick the first whose running sum >= thr, else the last open
- *       candidate with p > 0 of the lane;
- *     lanes = 32: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
+ *       candidate with p > 0 of the lane (the 32-lane kernel finds it by binary search over the
+ *       running sums it keeps in registers);
+ *     lanes = 16: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
  *       first j with scan[j] >= thr and p_j > 0, else the last j with p_j > 0. */
 int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? 16 : (n <= 512 ? 32 : 64)); }
 
@@ -217,7 +218,7 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
   for (int l = 0; l < lanes; ++l) {
     float s = 0.0f;
-    if (lanes < 64) {
+    if (lanes == 16) {
       /* packed accumulation: slots v = 0,2 and v = 1,3 are summed separately (c ascending), then added */
       float ev = 0.0f, od = 0.0f;
       for (int c = 0; c < ch; ++c)
@@ -246,9 +247,9 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   for (int l = 0; l < lanes; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
   if (L < 0) return -1;
   float thr = r - (L ? incl[L - 1] : 0.0f);
-  if (lanes < 64) {
-    /* level 2 of the several-ants-per-wave kernels: lane L's ch*vec candidate slots (closed ones
-     * +0.0f) are dealt to the 32 lanes and the same scan + first-lane pick runs across them */
+  if (lanes == 16) {
+    /* level 2 of the four-ants-per-wave kernel: lane L's ch*vec candidate slots (closed ones
+     * +0.0f) are dealt to the lanes of its row and the same scan + first-lane pick runs across them */
     float cv[64], sc[64];
     int key[64], nj = ch * vec;
     for (int j = 0; j < 64; ++j) { cv[j] = sc[j] = 0.0f; key[j] = -1; }
