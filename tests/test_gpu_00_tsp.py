@@ -285,6 +285,31 @@ def test_full_size_properties_tsp500(mode):
     assert np.array_equal(t2[b].cpu().numpy().view(np.uint32), rt.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,A,B", [(500, 512, 4), (400, 256, 2), (1000, 256, 2), (100, 512, 8)])
+def test_every_ant_of_a_full_size_launch_vs_oracle(n, A, B):
+    """All B x A tours of a full-size launch against the oracle (heavy rows with random diagonals: the rare paths
+    of the draw -- no running sum reaching the threshold, lane sums that round differently from the scan -- show
+    up once in a few thousand tours; they did, in the first version of the in-lane search).  Covers the headline
+    shape, config 3's ant count, config 5's n and config 2's shape (per instance)."""
+    from deepaco_amd import engine
+    dist, tau, eta = make_instance(n, 2024 + n, B)
+    paths, _, _, flags, costs, nbr = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", seed=11, it=3,
+                                                      dist=dist.to(dev()), want_nbr=True)
+    assert int(flags.sum()) == 0
+    p = paths.cpu().numpy()
+    for b in range(B):
+        rp, _, rc = oracle.tsp_sample_scan(oracle.prob_matrix(tau[b].numpy(), eta[b].numpy()), A, 11, 3, b * A)
+        assert rc == 0
+        bad = [a for a in range(A) if not np.array_equal(rp[:, a], p[b, :, a])]
+        assert not bad, (b, bad[:8])
+        assert np.array_equal(costs[b].cpu().numpy(), oracle.tour_costs(dist[b].numpy(), rp))
+    t1 = tau.to(dev()).clone().contiguous()
+    t2 = t1.clone()
+    engine.pheromone_update_(t1, paths, costs, 0.9, nbr=nbr)       # the table written by the sampler's epilogue
+    engine.pheromone_update_(t2, paths, costs, 0.9)                # rebuilt from the paths
+    assert torch.equal(t1, t2)
+
+
 def test_infeasible_row_sets_flag():
     from deepaco_amd import engine
     n, A = 10, 4
