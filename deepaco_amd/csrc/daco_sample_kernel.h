@@ -2,6 +2,7 @@
 // step-wise draws) and daco_sib_sample.hip (fused sibling-problem constructions).  See daco_tsp_sample.hip
 // for the design notes.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -303,7 +304,9 @@ tsp_sample_kernel(const SampleParams p) {
       });
       const float incl = wave_scan_add(part);
       S = readlane_f(incl, 63);
-      float r = u01(ux) * S;
+      float uval = u01(ux);
+      if constexpr (PROB == PROB_TSP) { if (p.noise) uval = p.noise[((size_t)b * (p.n - 1) + (t - 1)) * p.A + a]; }   // injected uniforms (tests)
+      float r = uval * S;
       r = r > 0.0f ? r : 1.401298464e-45f;               // keep r > 0 if u*S underflows
       const uint64_t m = __ballot(incl >= r && part > 0.0f);
       if (m == 0) { infeasible = true; choice = 0; own_lane = -1; }   // (node 0 is marked by index below)
@@ -524,7 +527,12 @@ inline int inst_chunks(int n) {
   for (int c : avail) if (c >= need) return c;
   return -1;
 }
-inline int ld_alloc(int n) { return inst_chunks(n) * 64 * vec_for_n(n); }
+// DACO_LD_PAD (floats, multiple of 4; measurement knob): extra zero padding per row, to move the row stride off the
+// 2 KB period (tools/l2_bw_shapes.hip measures +7 % L2 row rate at 2304 B) at the price of a larger L2 footprint
+inline int ld_alloc(int n) {
+  static const int pad = getenv("DACO_LD_PAD") ? atoi(getenv("DACO_LD_PAD")) & ~3 : 0;
+  return inst_chunks(n) * 64 * vec_for_n(n) + pad;
+}
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to

@@ -121,6 +121,7 @@ scan16_kernel(const SampleParams p) {
   uint64_t feasible = ~0ull;
   uint64_t act = CVRP ? __builtin_amdgcn_ballot_w64(!finished) : ~0ull;     // lanes of the rows still building
   const int tend = CVRP ? p.Lmax : n;
+  const float *uin = (!CVRP && p.noise) ? p.noise + (size_t)b * (n - 1) * A + a : nullptr;
 
   for (int t = 1; t < tend && act != 0; ++t) {
     const uint32_t voff = __umul24((uint32_t)prev, ldb) + lane_off;
@@ -132,7 +133,8 @@ scan16_kernel(const SampleParams p) {
       if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 6) << 4) + s));
       ucur = u01(comp(ublk, (t >> 4) & 3));
     }
-    const float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | ((t & 15) << 2), __float_as_int(ucur)));
+    float u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase | ((t & 15) << 2), __float_as_int(ucur)));
+    if constexpr (!CVRP) { if (uin) u = uin[(size_t)(t - 1) * A]; }       // injected uniform stream (tests): [B][n-1][A]
 #pragma unroll
     for (int c = 0; c < CH; ++c) fo[c] = *(const float4 *)(fl + (c * 16 + s) * 4);
 

@@ -135,6 +135,7 @@ tsp_scan32_kernel(const SampleParams p) {
     }
     __builtin_amdgcn_wave_barrier();
     u32x4 ublk = {0, 0, 0, 0};                          // 128 cached uniforms per ant (lane s: block base+s)
+    const float *uin = p.noise ? p.noise + (size_t)b * (n - 1) * A + a : nullptr;
 
     for (int tb = 0; tb < n; tb += 32) {
       // uniform of step t: lane (t&31), component (t>>5)&3 of Philox block ((t>>7)<<5) + lane
@@ -149,7 +150,8 @@ tsp_scan32_kernel(const SampleParams p) {
 #pragma unroll
         for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
         const int u_lo = __builtin_amdgcn_readlane(ucur, i), u_hi = __builtin_amdgcn_readlane(ucur, i + 32);
-        const float u = __int_as_float(upper ? u_hi : u_lo);
+        float u = __int_as_float(upper ? u_hi : u_lo);
+        if (uin) u = uin[(size_t)(tb + i - 1) * A];         // injected uniform stream (tests): [B][n-1][A]
 #pragma unroll
         for (int g = 0; g < NG; ++g) fo[g] = *(const f16x8 *)(fl + g * 256 + s * 8);
 

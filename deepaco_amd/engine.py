@@ -75,8 +75,8 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
         flags = torch.zeros((B,), dtype=torch.int32, device=dev)
         if start is not None:
             start = start.to(torch.int64).contiguous().view(B, n_ants)
-        if noise is not None:
-            noise = _f32c(noise).view(B, n - 1, n_ants, n)
+        if noise is not None:      # race_noise: the reference's q tensors; scan modes: injected uniforms [B, n-1, A]
+            noise = _f32c(noise).view(B, n - 1, n_ants, n) if m == RACE_NOISE else _f32c(noise).view(B, n - 1, n_ants)
         costs = nbr = None
         dbs = 0
         if dist is not None:

@@ -21,6 +21,32 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(t):
+    """gloo moves host tensors: a device tensor goes through the host (tests and CPU-only rendezvous); nccl (= RCCL)
+    reduces device tensors in place over xGMI."""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
+def all_gather_(out, x):
+    if _host_staged(x):
+        host = [o.cpu() for o in out]
+        dist.all_gather(host, x.cpu())
+        for o, h in zip(out, host):
+            o.copy_(h)
+    else:
+        dist.all_gather(out, x)
+
+
+def all_reduce_(x, op=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(x):
+        h = x.cpu()
+        dist.all_reduce(h, op=op)
+        x.copy_(h)
+    else:
+        dist.all_reduce(x, op=op)
+
+
 def shard_range(total, rank, world):
     """Contiguous, balanced [lo, hi) slice of `total` items for `rank` (first ranks get the extra)."""
     q, r = divmod(total, world)
@@ -61,7 +87,7 @@ def gather_best(lowest_cost, total, rank, world):
     pad = torch.full((q,), float("inf"), dtype=lowest_cost.dtype, device=lowest_cost.device)
     pad[: lowest_cost.numel()] = lowest_cost
     out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
+    all_gather_(out, pad)
     parts = []
     for r in range(world):
         lo, hi = shard_range(total, r, world)
@@ -102,9 +128,9 @@ class AntShardedColony:
         pad.narrow(dim, 0, x.shape[dim]).copy_(x)
         out = [torch.empty_like(pad) for _ in range(self.world)]
         if pad.dtype == torch.int16:          # neither gloo nor RCCL moves int16: ship the same bytes as uint8
-            dist.all_gather([o.view(torch.uint8) for o in out], pad.view(torch.uint8))
+            all_gather_([o.view(torch.uint8) for o in out], pad.view(torch.uint8))
         else:
-            dist.all_gather(out, pad)
+            all_gather_(out, pad)
         parts = []
         for r in range(self.world):
             lo, hi = shard_range(self.n_ants, r, self.world)
@@ -126,8 +152,8 @@ class AntShardedColony:
         delta = self.deposit_fn(torch.zeros_like(self.tau), paths, costs)
         best = costs.min(dim=1).values
         if self.world > 1:
-            dist.all_reduce(delta, op=dist.ReduceOp.SUM)          # the one data-path collective
-            dist.all_reduce(best, op=dist.ReduceOp.MIN)
+            all_reduce_(delta, dist.ReduceOp.SUM)                 # the one data-path collective
+            all_reduce_(best, dist.ReduceOp.MIN)
         self.tau = self.tau * self.decay + delta
         self.lowest_cost = torch.minimum(self.lowest_cost, best)
         self.iteration += 1

@@ -76,7 +76,9 @@ int daco_ld_for_n(int n);
  *              DACO_SCAN: r = u*S, first candidate (lane-major order) whose running sum >= r.
  *   start      [B][A] int64 or NULL.  If NULL: fixed_start >= 0 -> every ant starts there,
  *              fixed_start < 0 -> start = floor(n * u32 / 2^32) from the Philox stream.
- *   noise      DACO_RACE_NOISE only: [B][n-1][A][n] f32 (the reference's q tensors, step-major).
+ *   noise      DACO_RACE_NOISE: [B][n-1][A][n] f32 (the reference's q tensors, step-major), required.
+ *              DACO_SCAN / DACO_SCAN_WAVE: NULL, or [B][n-1][A] f32 uniforms in (0,1) that replace the Philox
+ *              stream (the reference's roulette with an injected uniform stream, tsp_nls/aco.py:266-274).
  *   seed, iter, ant_gid0   Philox key and counter words: ant (b,a) uses global ant id
  *              ant_gid0 + b*A + a; `iter` must differ between calls that should be independent.
  *   ant_gid_bstride  0, or the ant-id stride between instances when this call builds only a slice of a

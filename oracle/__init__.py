@@ -112,6 +112,18 @@ def tsp_sample_scan(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=F
     return _sample_rng(fn, P, A, seed, it, ant_gid0, fixed_start, require_prob)
 
 
+def tsp_sample_scan_injected(P, uniforms, fixed_start=0, wave=False, require_prob=False):
+    """The scan draw with caller-supplied uniforms [n-1][A] (f32) instead of Philox."""
+    P, u = _f32(P), _f32(uniforms)
+    n, A = P.shape[0], u.shape[1]
+    assert u.shape == (n - 1, A)
+    paths = np.zeros((n, A), dtype=np.int64)
+    logp = np.zeros((n - 1, A), dtype=np.float32) if require_prob else None
+    rc = lib().orc_tsp_sample_scan_injected(n, A, _p(P), _p(u), int(wave), int(fixed_start), None, _p(paths),
+                                            _p(logp) if require_prob else None)
+    return paths, logp, rc
+
+
 def tour_costs(dist, paths, closed=True):
     dist, paths = _f32(dist), _i64(paths)
     n, (length, A) = dist.shape[0], paths.shape

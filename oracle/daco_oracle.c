@@ -210,7 +210,7 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
 int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? 16 : (n <= 512 ? 32 : 64)); }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
-                     uint64_t iter, uint32_t gid, int t, float *pr, int lanes) {
+                     uint64_t iter, uint32_t gid, int t, float *pr, int lanes, const float *u_inj) {
   int vec = lanes < 64 ? 4 : orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
   int lg = lanes == 64 ? 6 : (lanes == 32 ? 5 : 4);
   float part[64], incl[64];
@@ -241,7 +241,9 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   float S = incl[lanes - 1];
   uint32_t ut = (uint32_t)t;
   rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> (lg + 2)) << lg) + (ut & (uint32_t)(lanes - 1)), r4);
-  float r = u01(r4[(ut >> lg) & 3u]) * S;
+  /* u_inj: the uniform comes from the caller instead of Philox (the reference's roulette with an injected
+   * stream, tsp_nls/aco.py:266-274; how the GPU scan draw is tied to it, tests/test_gpu_00_tsp.py) */
+  float r = (u_inj ? *u_inj : u01(r4[(ut >> lg) & 3u])) * S;
   if (!(r > 0.0f)) r = 1.401298464e-45f;               /* keep r > 0 if u*S underflows */
   int L = -1;
   for (int l = 0; l < lanes; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
@@ -314,7 +316,8 @@ static int tsp_sample(int mode, int n, int A, const float *P, const int64_t *sta
       int best;
       if (mode == MODE_NOISE) best = draw_noise(n, row, vis, noise + ((long)(t - 1) * A + a) * n, norm_passes, p, &pr);
       else if (mode == MODE_RACE) best = draw_race(n, row, vis, seed, iter, gid, t, p, logp ? &pr : NULL);
-      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr, orc_scan_lanes(n, mode));
+      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr, orc_scan_lanes(n, mode),
+                            noise ? noise + ((long)(t - 1) * A + a) : NULL);     /* scan modes: noise = uniforms [n-1][A] */
       if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
       if (logp) logp[(long)(t - 1) * A + a] = clamp_log(pr);
       vis[best] = 1;
@@ -332,6 +335,11 @@ int orc_tsp_sample_noise(int n, int A, const float *P, const int64_t *start, con
 int orc_tsp_sample_race(int n, int A, const float *P, uint64_t seed, uint64_t iter,
                         uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
   return tsp_sample(MODE_RACE, n, A, P, NULL, NULL, 0, seed, iter, ant_gid0, fixed_start, paths, logp);
+}
+/* scan draw with the uniforms supplied by the caller: u [n-1][A] f32 in (0,1) */
+int orc_tsp_sample_scan_injected(int n, int A, const float *P, const float *u, int wave, int fixed_start,
+                                 const int64_t *start, int64_t *paths, float *logp) {
+  return tsp_sample(wave ? MODE_SCAN_WAVE : MODE_SCAN, n, A, P, start, u, 0, 0, 0, 0, fixed_start, paths, logp);
 }
 int orc_tsp_sample_scan(int n, int A, const float *P, uint64_t seed, uint64_t iter,
                         uint32_t ant_gid0, int fixed_start, int64_t *paths, float *logp) {
@@ -466,7 +474,7 @@ int orc_pick_move(int mode, int n, int A, const float *P, const int64_t *prev, c
     int best;
     if (mode == MODE_NOISE) best = draw_noise(n, row, blocked, noise + (long)a * n, 1, p, &pr);
     else if (mode == MODE_RACE) best = draw_race(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, p, logp ? &pr : NULL);
-    else best = draw_scan(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, &pr, 64);
+    else best = draw_scan(n, row, blocked, seed, iter, ant_gid0 + (uint32_t)a, step, &pr, 64, NULL);
     if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
     actions[a] = best;
     if (logp) logp[a] = clamp_log(pr);
@@ -595,7 +603,7 @@ int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand
       int best;
       if (mode == MODE_NOISE) best = draw_noise(n1, row, blocked, noise + ((long)(len - 1) * A + a) * n1, 1, p, &pr);
       else if (mode == MODE_RACE) best = draw_race(n1, row, blocked, seed, iter, gid, len, p, logp ? &pr : NULL);
-      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr, orc_scan_lanes(n1, mode));
+      else best = draw_scan(n1, row, blocked, seed, iter, gid, len, &pr, orc_scan_lanes(n1, mode), NULL);
       if (best < 0) { fail = 1; break; }
       if (logp) logp[(long)(len - 1) * A + a] = clamp_log(pr);
       if (best != 0) { vis[best] = 1; --remaining; }

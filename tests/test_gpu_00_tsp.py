@@ -320,6 +320,94 @@ def test_infeasible_row_sets_flag():
         assert int(flags[0]) == 1
 
 
+# ------------------------------------------------------------------ I1: the scan draw IS the reference's roulette
+@pytest.mark.parametrize("mode", ["scan", "scan_wave"])
+def test_scan_kernels_reproduce_reference_roulette_routes(mode):
+    """g6: routes the reference's `_inference_sample` (tsp_nls/aco.py:260-275) built from an injected uniform
+    stream.  The same uniforms fed to the HIP scan kernels (four ants per wavefront / one ant per wavefront)
+    give the same routes (n = 30: one chunk, the lanes walk the candidates in index order like the reference)."""
+    from deepaco_amd import engine
+    g = load_golden("g6_roulette_n30")
+    n, A = g["probmat"].shape[0], g["uniforms"].shape[0]
+    u = torch.from_numpy(g["uniforms"].astype(np.float32).T.copy()).to(dev())[None]       # [1][n-1][A]
+    paths, _, _, flags = engine.tsp_sample(T(g["probmat"])[None], torch.ones(1, n, n, device=dev()), A, mode=mode,
+                                           fixed_start=0, noise=u)
+    assert int(flags.sum()) == 0
+    assert np.array_equal(paths[0].cpu().numpy().T.astype(np.uint16), g["routes"])
+    rp, _, _ = oracle.tsp_sample_scan_injected(g["probmat"], u[0].cpu().numpy(), fixed_start=0, wave=(mode == "scan_wave"))
+    assert np.array_equal(paths[0].cpu().numpy(), rp)
+
+
+def _layout_order(n, lanes):
+    """position of candidate k in the order the lanes of a layout walk a row: (lane, chunk, slot)."""
+    vec = 4 if lanes < 64 else (4 if n > 128 else (2 if n > 64 else 1))
+    k = np.arange(n)
+    key = ((k // vec) % lanes) * 1_000_000 + (k // (lanes * vec)) * 100 + (k % vec)
+    return np.argsort(key, kind="stable")
+
+
+@pytest.mark.parametrize("n,lanes", [(200, 16), (500, 32), (640, 64)])
+def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
+    """The benchmarked sampler against the LITERAL arithmetic of the reference's roulette (tsp_nls/aco.py:266-274:
+    r = U * sum(prob_row * mask) in f64, subtract prob[k] one after the other until r <= 0), step by step along
+    the tours the kernel built from an injected uniform stream.  A categorical draw does not depend on the order
+    in which the candidates are walked; the kernels walk them lane by lane (coalesced 16-byte loads), so the
+    reference's loop is run over the same order.  The two can only differ where U*S falls within rounding of a
+    boundary between two neighbouring candidates (f32 tree sums vs f64 subtraction): every mismatch must be such
+    a boundary case, and they must be rare."""
+    from deepaco_amd import engine
+    A = 8
+    g = torch.Generator().manual_seed(n)
+    tau = torch.rand(1, n, n, generator=g) + 0.1
+    eta = torch.rand(1, n, n, generator=g) ** 2 + 1e-10
+    u = torch.rand(1, n - 1, A, generator=g).clamp_(1e-7, 1 - 1e-7)
+    paths, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", fixed_start=0, noise=u.to(dev()))
+    assert int(flags.sum()) == 0
+    assert {16: n <= 256, 32: 256 < n <= 512, 64: n > 512}[lanes]
+    P = oracle.prob_matrix(tau[0].numpy(), eta[0].numpy())
+    order = _layout_order(n, lanes)
+    p = paths[0].cpu().numpy()
+    un = u[0].numpy()
+    mismatches = 0
+    for a in range(A):
+        mask = np.ones(n, dtype=np.float32)
+        mask[p[0, a]] = 0
+        for t in range(1, n):
+            prob = (P[p[t - 1, a]] * mask)[order]                      # f32, the reference's prob_row * mask
+            rnd = np.float64(un[t - 1, a]) * np.float64(prob.sum(dtype=np.float32))
+            cum = np.cumsum(prob.astype(np.float64))
+            j = int(np.searchsorted(cum, rnd, side="left"))           # first j with rnd - cum[j] <= 0
+            j = min(j, n - 1)
+            k_ref, k_gpu = int(order[j]), int(p[t, a])
+            if k_ref != k_gpu:
+                mismatches += 1
+                jg = int(np.where(order == k_gpu)[0][0])
+                lo, hi = min(j, jg), max(j, jg)
+                assert prob[jg] > 0 and not (prob[lo + 1:hi] > 0).any(), "not a neighbouring open candidate"
+                assert abs(cum[lo] - rnd) <= 4e-6 * cum[-1], "not a rounding-boundary draw"
+            mask[k_gpu] = 0
+    assert mismatches <= 2, mismatches                                   # (expected: 0 of ~4000 draws)
+
+
+# ------------------------------------------------------------------ U3: sparsify (tsp/aco.py:52-67)
+def test_sparsify_matches_reference():
+    """ACO.sparsify(k) and the batched BatchedTSP.sparsify against the heuristic the reference built on the captured
+    instance (fixture g1_tsp_n50_a16_sparse: `heuristic` is the reference's aco.heuristic after sparsify(k))."""
+    from deepaco_amd import engine
+    from deepaco_amd.tsp.aco import ACO
+    g = load_golden("g1_tsp_n50_a16_sparse")
+    k = int(g["sparsify_k"])
+    aco = ACO(T(g["distances"]), n_ants=4, device="cuda:0")
+    aco.sparsify(k)
+    assert np.array_equal(aco.heuristic.cpu().numpy().view(np.uint32), g["heuristic"].view(np.uint32))
+    n = g["distances"].shape[0]
+    assert int((aco.heuristic.cpu() > 1e-9).sum()) == n * k            # k live edges per node, 1e-10 elsewhere
+    col = engine.BatchedTSP(T(g["distances"])[None].repeat(3, 1, 1), n_ants=4)
+    col.sparsify(k)
+    for b in range(3):
+        assert np.array_equal(col.heuristic[b].cpu().numpy().view(np.uint32), g["heuristic"].view(np.uint32))
+
+
 # ------------------------------------------------------------------ 4. H3: inference schedule, statistical
 def test_inference_schedule_matches_cpu_port_statistically():
     """tsp/test.ipynb infer_instance/test: incremental aco.run(t_diff) over t_aco = [1, 10, 20]; mean best

@@ -36,22 +36,6 @@ def _worker(rank, world, port, q, B, n, A, iters, exchange):
     from deepaco_amd import engine
     dev = torch.device("cuda:0")
     col = engine.ant_sharded_tsp(_instances(B, n, 5).to(dev), A, rank, world, seed=77, exchange=exchange)
-    # gloo reduces host tensors: route the collectives of this test through the CPU
-    import deepaco_amd.parallel as par
-    real_gather, real_reduce = dist.all_gather, dist.all_reduce
-
-    def gather(out, x, *a, **k):
-        host = [o.cpu() for o in out]
-        real_gather(host, x.cpu(), *a, **k)
-        for o, h in zip(out, host):
-            o.copy_(h)
-
-    def reduce(x, *a, **k):
-        h = x.cpu()
-        real_reduce(h, *a, **k)
-        x.copy_(h)
-
-    par.dist.all_gather, par.dist.all_reduce = gather, reduce
     for _ in range(iters):
         col.step()
     torch.cuda.synchronize()
@@ -85,4 +69,41 @@ def test_two_ranks_equal_single_process(exchange, n, A):
         assert (res[0][0].view("uint32") == ref_tau.view("uint32")).all()
         assert (res[0][1] == ref_low).all()
     else:
+        # colony-wide ant ids: the same tours as the single-GPU colony, deposits summed in a different order
         assert res[0][0].shape == ref_tau.shape and (res[0][0] > 0).all()
+        import numpy as np
+        np.testing.assert_allclose(res[0][0], ref_tau, rtol=2e-5)
+        np.testing.assert_allclose(res[0][1], ref_low, rtol=0, atol=0)
+
+
+def _bench_line(*args, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]               # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun) starts two ranks by itself; both on cuda:0 here, gloo rendezvous.
+    Instance-sharded: n_gpus = 2, twice the tours of the one-rank run per step, no data-path collective."""
+    common = ("--no-cpu", "--no-extras", "--min-seconds", "0", "--steps", "3", "--warmup", "1", "--nodes", "120",
+              "--ants", "64", "--batch", "4")
+    one = _bench_line(*common)
+    two = _bench_line("--gpus", "2", "--dist-backend", "gloo", "--force-device", "0", *common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["rccl"]["ranks"] == 2 and two["config"]["parallelism"] == "instance-sharded x2"
+    assert two["scaling"] == "weak" and two["value"] > 0 and one["value"] > 0
+    assert one["roofline"]["bound"] == "l2" and 0 < one["roofline"]["frac"] < 1.0
+    # ant-sharded, exact exchange: strong scaling, same colony on both ranks
+    ants = _bench_line("--gpus", "2", "--dist-backend", "gloo", "--force-device", "0", "--shard", "ants", *common)
+    assert ants["n_gpus"] == 2 and ants["scaling"] == "strong"

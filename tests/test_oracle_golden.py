@@ -150,6 +150,19 @@ def test_roulette_literal():
         assert np.array_equal(oracle.roulette_route(g["probmat"], u, 0), route)
 
 
+@pytest.mark.parametrize("wave", [False, True])
+def test_scan_draw_with_injected_uniforms_is_the_reference_roulette(wave):
+    """I1: the scan draw specification fed the g6 uniforms reproduces the routes the reference's
+    `_inference_sample` (tsp_nls/aco.py:260-275) built from the same uniforms.  At n = 30 every lane layout walks
+    the candidates in index order, as the reference does; the arithmetic differs (f32 scan vs f64 subtraction), so
+    a uniform within rounding of a boundary could pick the neighbour -- none of the 174 recorded draws is."""
+    g = load_golden("g6_roulette_n30")
+    u = g["uniforms"].astype(np.float32).T.copy()                 # [n-1][A]
+    paths, _, rc = oracle.tsp_sample_scan_injected(g["probmat"], u, fixed_start=0, wave=wave)
+    assert rc == 0
+    assert np.array_equal(paths.T.astype(np.uint16), g["routes"])
+
+
 @pytest.mark.parametrize("name", names("g1_cvrp"))
 def test_cvrp_sampler_and_update(name):
     g = load_golden(name)

@@ -13,6 +13,7 @@
 //   7 rows_lds   as 2 through global_load_lds_dwordx4 (LDS-DMA, no VGPR write-back)
 //   8 stream_lds as 0 through global_load_lds_dwordx4
 //   9 rows_dw    as 1 with dword loads (16 instructions of 128 B per half-wave)
+//  10 rows_c64   as 1 with 64 CONTIGUOUS bytes per lane (lane s owns bytes 64s..64s+63: candidates in index order)
 // build: hipcc -O3 --offload-arch=gfx950 tools/l2_bw_shapes.hip -o tools/l2_bw_shapes
 // run:   tools/l2_bw_shapes [instances=64] [lds_pad_bytes=0]
 #include <hip/hip_runtime.h>
@@ -78,6 +79,9 @@ __global__ void __launch_bounds__(256) shapes(const float *P, int B, int n, int 
         o[j] = ((h >> 8) % (unsigned)(inst_bytes / 128)) * 128u + within * 16u;
       }
       r0 = *(const v4 *)(Pb + o[0]); r1 = *(const v4 *)(Pb + o[1]); r2 = *(const v4 *)(Pb + o[2]); r3 = *(const v4 *)(Pb + o[3]);
+    } else if (MODE == 10) {
+      const unsigned o = prev * (unsigned)ldb + s * 64u;
+      r0 = *(const v4 *)(Pb + o); r1 = *(const v4 *)(Pb + o + 16); r2 = *(const v4 *)(Pb + o + 32); r3 = *(const v4 *)(Pb + o + 48);
     } else {   // 9: dword loads
       const unsigned o = prev * (unsigned)ldb + s * 4u;
       float f[16];
@@ -131,5 +135,6 @@ int main(int argc, char **argv) {
   run<7>("rows_lds", P, B, n, 2048, out, lds);
   run<8>("stream_lds", P, B, n, 2048, out, lds);
   run<9>("rows_dw", P, B, n, 2048, out, lds);
+  run<10>("rows_c64", P, B, n, 2048, out, lds);
   return 0;
 }
