@@ -1,0 +1,685 @@
+// daco_gnn_train.hip -- heuristic network, TRAINING mode: forward with per-graph batch statistics and the full
+// backward, both as HIP kernels (no library GEMM anywhere).
+//
+// Reference behaviour replaced: EmbNet.forward tsp/net.py:27-45 with BatchNorm in training mode (the statistics
+// of the ONE graph being trained on, :21,24,43-44), MLP/ParNet.forward :59-75, and what autograd derives from
+// them for tsp_nls/train.py:15-44 (loss.backward()).  G equal-sized graphs may be laid side by side (n = G*n_g
+// nodes, E = G*E_g edges, node ids offset per graph): every graph normalises with its own statistics, exactly as G
+// separate reference forwards would.
+//
+// Per layer (x [n,32], w [E,32]):
+//   X = x Wv^T + bv = (x1|x2|x3|x4)                     node_post of the previous layer (MFMA-free: n is small)
+//   ze = w We^T + be + x3[src] + x4[dst]                edge_pre   (MFMA 32x32x2 f32 tile GEMM) + sum, sum^2 per channel
+//   zv = x1 + mean_{e: src=i} sigmoid(w_e) * x2[dst_e]  node_pre   (CSR gather, no atomics)   + sum, sum^2 per channel
+//   w' = w + silu(bn_e(ze)),  x' = x + silu(bn_v(zv))   edge_post / node_post (batch statistics, biased variance)
+// The channel sums are accumulated in f64 (tile-wise partial sums, then one hardware f64 atomic per channel), so the
+// mean/variance do not depend on the summation order beyond f64 rounding.
+// Saved for the backward: x, X, w, ze, zv of every layer (n, E are training-sized: TSP-500, k = 50 is 3.2 MB per
+// edge tensor).  The backward walks the layers in reverse:
+//   edge_bwd_stats / node_bwd_stats   sum(g_y), sum(g_y * zhat) per channel (the two BatchNorm reductions)
+//   node_bwd_apply                    g_zv -> gX[:, x1 block], g_msg = g_zv / degree
+//   edge_bwd_main                     g_ze -> gw (in place: residual + g_ze We + gate path), scatter-adds into gX
+//                                     (x2, x3, x4 blocks; hardware f32 atomics), gWe += g_ze^T w (MFMA outer products
+//                                     accumulated over the tiles a wave walks), gbe
+//   node_lin_bwd                      gx (in place: residual + gX Wv), gWv += gX^T x (MFMA), gbv
+// Parameter gradients land in a flat block with the layout of the parameter block (see daco_gnn.hip), BatchNorm
+// slots holding d/dgamma, d/dbeta.
+#include "daco_device.h"
+#include "../../include/deepaco_hip.h"
+
+namespace daco {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TU = 32;
+constexpr int T_LAYER_FLOATS = 32 * 128 + 128 + 32 * 32 + 32 + 4 * 32;
+constexpr float BN_EPS = 1e-5f;
+__host__ __device__ inline size_t t_off_layer(int feats, int l) { return (size_t)32 * feats + 32 + 64 + (size_t)l * T_LAYER_FLOATS; }
+__host__ __device__ inline size_t t_off_head(int feats) { return t_off_layer(feats, 12); }
+
+__device__ inline float t_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+__device__ inline float t_silu(float x) { return x * t_sigmoid(x); }
+__device__ inline float t_dsilu(float x) { const float s = t_sigmoid(x); return s * (1.0f + x * (1.0f - s)); }
+__device__ inline int t_drow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// D[i][j] += sum_k A[i][k] * B[k][j] over k = 0..31 with v_mfma_f32_32x32x2_f32; lane l supplies A[l%32][k] and
+// B[k][l%32] for k = (l/32)*16 + kk.  a(kk) / b(kk) are functors returning those elements.
+template <class FA, class FB>
+__device__ inline f32x16 mfma32(f32x16 acc, FA a, FB b) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(kk), b(kk), acc, 0, 0, 0);
+  return acc;
+}
+constexpr f32x16 ZERO16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// per-channel batch statistics of graph g: mean and 1/sqrt(var + eps) from the f64 sums
+struct Stat { float mean, rstd; };
+__device__ inline Stat load_stat(const double *sums, int g, int c, int count) {
+  const double s = sums[((size_t)g * 32 + c) * 2], q = sums[((size_t)g * 32 + c) * 2 + 1];
+  const double m = s / count;
+  double v = q / count - m * m;
+  v = v < 0.0 ? 0.0 : v;
+  return Stat{(float)m, (float)(1.0 / sqrt(v + (double)BN_EPS))};
+}
+
+// ------------------------------------------------------------------ forward
+// ze = w We^T + be + x3[src] + x4[dst] for one 32-edge tile per wave; channel sums of the tile -> f64 atomics
+__global__ void __launch_bounds__(256)
+gnn_t_edge_pre(int E, int Eg, const int *src, const int *dst, const float *We, const float *be, const float *X,
+               const float *w0, float *ze, double *sums) {
+  __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float (*tile)[36] = tile_s[wave];
+  const int e0 = (blockIdx.x * 4 + wave) * 32;
+  if (e0 >= E) return;
+  const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
+    *reinterpret_cast<float4 *>(&tile[el][c0]) = *reinterpret_cast<const float4 *>(w0 + (size_t)e * TU + c0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const f32x16 acc = mfma32(ZERO16, [&](int kk) { return tile[o][h * 16 + kk]; },
+                            [&](int kk) { return We[o * TU + h * 16 + kk]; });
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[t_drow(r, lane)][o] = acc[r];
+  __builtin_amdgcn_wave_barrier();
+  const float4 bb = *reinterpret_cast<const float4 *>(be + c0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int el = q * 8 + (lane >> 3), e = e0 + el;
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < E) {
+      const int s = src[e], d = dst[e];
+      const float4 g = *reinterpret_cast<const float4 *>(&tile[el][c0]);
+      const float4 a3 = *reinterpret_cast<const float4 *>(X + (size_t)s * 128 + 64 + c0);
+      const float4 a4 = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 96 + c0);
+      z = make_float4(g.x + bb.x + a3.x + a4.x, g.y + bb.y + a3.y + a4.y, g.z + bb.z + a3.z + a4.z, g.w + bb.w + a3.w + a4.w);
+      *reinterpret_cast<float4 *>(ze + (size_t)e * TU + c0) = z;
+    }
+    *reinterpret_cast<float4 *>(&tile[el][c0]) = z;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // lanes 0..31: sum of channel o over the tile's edges, lanes 32..63: sum of squares; flushed per graph
+  double accd = 0.0;
+  int gcur = e0 / Eg;
+  for (int el = 0; el < 32 && e0 + el < E; ++el) {
+    const int g = (e0 + el) / Eg;
+    if (g != gcur) { unsafeAtomicAdd(sums + ((size_t)gcur * 32 + o) * 2 + h, accd); accd = 0.0; gcur = g; }
+    const float v = tile[el][o];
+    accd += h ? (double)v * (double)v : (double)v;
+  }
+  unsafeAtomicAdd(sums + ((size_t)gcur * 32 + o) * 2 + h, accd);
+}
+
+// zv = x1 + mean over out-edges of sigmoid(w) * x2[dst]; 8 nodes per workgroup, 32 lanes per node
+__global__ void __launch_bounds__(256)
+gnn_t_node_pre(int n, int ng, const int *dst, const int *rowptr, const int *perm, const float *X, const float *w0,
+               float *zv, double *sums) {
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  if (i >= n) return;
+  const int lo = rowptr[i], hi = rowptr[i + 1];
+  float agg = 0.0f;
+  for (int q = lo; q < hi; ++q) {
+    const int e = perm ? perm[q] : q;
+    agg = fmaf(t_sigmoid(w0[(size_t)e * TU + o]), X[(size_t)dst[e] * 128 + 32 + o], agg);
+  }
+  agg = agg / (float)max(hi - lo, 1);
+  const float z = X[(size_t)i * 128 + o] + agg;
+  zv[(size_t)i * TU + o] = z;
+  const int g = i / ng;
+  unsafeAtomicAdd(sums + ((size_t)g * 32 + o) * 2, (double)z);
+  unsafeAtomicAdd(sums + ((size_t)g * 32 + o) * 2 + 1, (double)z * (double)z);
+}
+
+// w' = w + silu(gamma * (ze - mean) * rstd + beta)
+__global__ void __launch_bounds__(256)
+gnn_t_edge_post(int E, int Eg, const float *gamma, const float *beta, const double *sums, const float *w0, const float *ze,
+                float *w1) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)E * TU) return;
+  const int e = (int)(idx >> 5), c = (int)(idx & 31);
+  const Stat st = load_stat(sums, e / Eg, c, Eg);
+  const float y = fmaf((ze[idx] - st.mean) * st.rstd, gamma[c], beta[c]);
+  w1[idx] = w0[idx] + t_silu(y);
+}
+
+// x' = x + silu(bn_v(zv)); then the NEXT layer's node linears X' = x' Wv^T + bv (WT/bv = next layer's, or null)
+__global__ void __launch_bounds__(256)
+gnn_t_node_post(int n, int ng, const float *gamma, const float *beta, const double *sums, const float *x0, const float *zv,
+                float *x1, const float *WTnext, const float *bvnext, float *Xnext) {
+  __shared__ float xs[8][TU];
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  float xn = 0.0f;
+  if (i < n) {
+    const Stat st = load_stat(sums, i / ng, o, ng);
+    const float y = fmaf((zv[(size_t)i * TU + o] - st.mean) * st.rstd, gamma[o], beta[o]);
+    xn = x0[(size_t)i * TU + o] + t_silu(y);
+    x1[(size_t)i * TU + o] = xn;
+  }
+  if (!WTnext) return;
+  xs[il][o] = xn;
+  __syncthreads();
+  if (i >= n) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float acc = bvnext[q * 32 + o];
+    for (int c = 0; c < TU; ++c) acc = fmaf(xs[il][c], WTnext[c * 128 + q * 32 + o], acc);
+    Xnext[(size_t)i * 128 + q * 32 + o] = acc;
+  }
+}
+
+// x0 = silu(v_lin0 xin), pre-activation a0 saved; X(0) = layer-0 node linears
+__global__ void __launch_bounds__(256)
+gnn_t_node_init(int n, int feats, const float *xin, const float *params, float *a0, float *x, float *X) {
+  __shared__ float xs[8][TU];
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  const float *W = params, *b = params + 32 * feats;
+  float v = 0.0f;
+  if (i < n) {
+    v = b[o];
+    for (int f = 0; f < feats; ++f) v = fmaf(xin[(size_t)i * feats + f], W[o * feats + f], v);
+    a0[(size_t)i * TU + o] = v;
+    v = t_silu(v);
+    x[(size_t)i * TU + o] = v;
+  }
+  xs[il][o] = v;
+  __syncthreads();
+  if (i >= n) return;
+  const float *WT = params + t_off_layer(feats, 0), *bv = WT + 32 * 128;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float acc = bv[q * 32 + o];
+    for (int c = 0; c < TU; ++c) acc = fmaf(xs[il][c], WT[c * 128 + q * 32 + o], acc);
+    X[(size_t)i * 128 + q * 32 + o] = acc;
+  }
+}
+__global__ void __launch_bounds__(256)
+gnn_t_edge_init(int E, int feats, const float *attr, const float *params, float *w) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)E * TU) return;
+  const int e = (int)(idx >> 5), c = (int)(idx & 31);
+  const float *W = params + 32 * feats + 32, *b = W + 32;
+  w[idx] = t_silu(fmaf(attr[e], W[c], b[c]));
+}
+
+// head forward (sigmoid(W3 silu(W2 silu(W1 w + b1) + b2) + b3)), one 32-edge tile per wave
+__global__ void __launch_bounds__(256)
+gnn_t_head_fwd(int E, const float *hp, const float *w, float *heu) {
+  __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];
+  const float *W1 = hp, *b1 = W1 + 1024, *W2 = b1 + 32, *b2 = W2 + 1024, *W3 = b2 + 32, *b3 = W3 + 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e0 = (blockIdx.x * 4 + wave) * 32;
+  if (e0 >= E) return;
+  const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
+  float (*t)[36] = tile_s[wave];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
+    *reinterpret_cast<float4 *>(&t[el][c0]) = *reinterpret_cast<const float4 *>(w + (size_t)e * TU + c0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  f32x16 acc = mfma32(ZERO16, [&](int kk) { return t[o][h * 16 + kk]; }, [&](int kk) { return W1[o * TU + h * 16 + kk]; });
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[t_drow(r, lane)][o] = t_silu(acc[r] + b1[o]);
+  __builtin_amdgcn_wave_barrier();
+  acc = mfma32(ZERO16, [&](int kk) { return t[o][h * 16 + kk]; }, [&](int kk) { return W2[o * TU + h * 16 + kk]; });
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[t_drow(r, lane)][o] = t_silu(acc[r] + b2[o]) * W3[o];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 32) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < TU; ++c) s = s + t[lane][c];
+    const int e = e0 + lane;
+    if (e < E) heu[e] = t_sigmoid(s + b3[0]);
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// flush a wave's 32x32 accumulator (MFMA output layout) and a per-channel vector into global memory
+__device__ inline void flush_acc(float *dstM, const f32x16 &acc, int lane) {
+  const int j = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dstM + t_drow(r, lane) * TU + j, acc[r]);
+}
+
+// head backward: waves walk tiles (grid-stride), recompute a1, a2, accumulate gW1/gW2/gW3/gb in registers
+__global__ void __launch_bounds__(256)
+gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const float *gheu, float *gw, float *ghp) {
+  __shared__ __attribute__((aligned(16))) float tin_s[4][32][36], ta_s[4][32][36], tg_s[4][32][36];
+  const float *W1 = hp, *b1 = W1 + 1024, *W2 = b1 + 32, *b2 = W2 + 1024, *W3 = b2 + 32;
+  float *gW1 = ghp, *gb1 = gW1 + 1024, *gW2 = gb1 + 32, *gb2 = gW2 + 1024, *gW3 = gb2 + 32, *gb3 = gW3 + 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
+  float (*tin)[36] = tin_s[wave], (*ta)[36] = ta_s[wave], (*tg)[36] = tg_s[wave];
+  f32x16 aW1 = ZERO16, aW2 = ZERO16;
+  float aW3 = 0.f, ab1 = 0.f, ab2 = 0.f, ab3 = 0.f;
+  const int ntiles = (E + 31) / 32;
+  for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
+    const int e0 = tix * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
+      *reinterpret_cast<float4 *>(&tin[el][c0]) = *reinterpret_cast<const float4 *>(w + (size_t)e * TU + c0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // a1 = w W1^T + b1 -> ta (pre-activation), h1 = silu(a1) -> tg (temporarily)
+    f32x16 acc = mfma32(ZERO16, [&](int kk) { return tin[o][h * 16 + kk]; }, [&](int kk) { return W1[o * TU + h * 16 + kk]; });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float a = acc[r] + b1[o]; ta[t_drow(r, lane)][o] = a; tg[t_drow(r, lane)][o] = t_silu(a); }
+    __builtin_amdgcn_wave_barrier();
+    // a2 = h1 W2^T + b2; h2 = silu(a2); gs = gheu * heu * (1 - heu) per edge
+    acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return W2[o * TU + h * 16 + kk]; });
+    // per-edge scalar gs for the 16 rows this lane holds
+    float a2r[16], gsr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = e0 + t_drow(r, lane);
+      float gs = 0.0f;
+      if (e < E) { const float hv = heu[e]; gs = gheu[e] * hv * (1.0f - hv); }
+      a2r[r] = acc[r] + b2[o]; gsr[r] = gs;
+    }
+    // gW3[o] += sum_e gs * h2[e][o]; gb3 += sum_e gs (lane o = 0 of half 0 only, below); g_a2 = gs * W3[o] * dsilu(a2)
+    float ga2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      aW3 += gsr[r] * t_silu(a2r[r]);
+      ga2[r] = gsr[r] * W3[o] * t_dsilu(a2r[r]);
+      ab2 += ga2[r];
+      if (o == 0) ab3 += gsr[r];
+    }
+    // gW2 += g_a2^T h1 (h1 is in tg); then g_h1 = g_a2 W2 -> needs g_a2 as a tile: reuse tin after saving nothing
+    // (w tile is still needed for gW1: keep tin, put g_a2 into a second use of tg AFTER the outer product)
+    // stage g_a2 in registers -> write to tin? no: use ta for a1 (needed), so write g_a2 over tg after reading h1.
+    // 1) outer product needs A = g_a2^T (from a tile) and B = h1 (tg): put g_a2 into tin's place temporarily is not
+    //    possible (w needed later), so spill w tile to registers first.
+    float4 wsave[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wsave[q] = *reinterpret_cast<const float4 *>(&tin[q * 8 + (lane >> 3)][c0]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tin[t_drow(r, lane)][o] = ga2[r];                 // tin := g_a2 [edge][ch]
+    __builtin_amdgcn_wave_barrier();
+    aW2 = mfma32(aW2, [&](int kk) { return tin[h * 16 + kk][o]; }, [&](int kk) { return tg[h * 16 + kk][o]; });
+    // g_h1 = g_a2 W2 : D[e][c] = sum_o g_a2[e][o] W2[o][c]
+    acc = mfma32(ZERO16, [&](int kk) { return tin[o][h * 16 + kk]; }, [&](int kk) { return W2[(h * 16 + kk) * TU + o]; });
+    __builtin_amdgcn_wave_barrier();
+    // g_a1 = g_h1 * dsilu(a1) -> tg
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float g = acc[r] * t_dsilu(ta[t_drow(r, lane)][o]); tg[t_drow(r, lane)][o] = g; ab1 += g; }
+    __builtin_amdgcn_wave_barrier();
+    // restore the w tile, gW1 += g_a1^T w, gw = g_a1 W1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&tin[q * 8 + (lane >> 3)][c0]) = wsave[q];
+    __builtin_amdgcn_wave_barrier();
+    aW1 = mfma32(aW1, [&](int kk) { return tg[h * 16 + kk][o]; }, [&](int kk) { return tin[h * 16 + kk][o]; });
+    acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return W1[(h * 16 + kk) * TU + o]; });
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ta[t_drow(r, lane)][o] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + (lane >> 3), e = e0 + el;
+      if (e < E) *reinterpret_cast<float4 *>(gw + (size_t)e * TU + c0) = *reinterpret_cast<const float4 *>(&ta[el][c0]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  flush_acc(gW1, aW1, lane);
+  flush_acc(gW2, aW2, lane);
+  // per-channel vectors: both halves hold partial sums for channel o
+  unsafeAtomicAdd(gW3 + o, aW3);
+  unsafeAtomicAdd(gb1 + o, ab1);
+  unsafeAtomicAdd(gb2 + o, ab2);
+  if (o == 0) unsafeAtomicAdd(gb3, ab3);
+}
+
+// sum(g_y), sum(g_y * zhat) per channel and graph for an [R,32] tensor (edges or nodes); g_y = gout * dsilu(y)
+__global__ void __launch_bounds__(256)
+gnn_t_bwd_stats(int R, int Rg, const float *gamma, const float *beta, const double *fsums, const float *z, const float *gout,
+                double *bsums) {
+  // 8 rows per pass and workgroup-pass; thread = (row slot, channel); rows of one workgroup: a contiguous chunk
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int rows_per_wg = 256;
+  const int r0 = blockIdx.x * rows_per_wg;
+  double s1 = 0.0, s2 = 0.0;
+  int gcur = -1;
+  for (int r = r0 + il; r < min(R, r0 + rows_per_wg); r += 8) {
+    const int g = r / Rg;
+    if (g != gcur) {
+      if (gcur >= 0) { unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2, s1); unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2 + 1, s2); }
+      s1 = s2 = 0.0; gcur = g;
+    }
+    const Stat st = load_stat(fsums, g, o, Rg);
+    const float zh = (z[(size_t)r * TU + o] - st.mean) * st.rstd;
+    const float gy = gout[(size_t)r * TU + o] * t_dsilu(fmaf(zh, gamma[o], beta[o]));
+    s1 += (double)gy; s2 += (double)gy * (double)zh;
+  }
+  if (gcur >= 0) { unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2, s1); unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2 + 1, s2); }
+}
+
+// g_z of a BatchNorm'd row element: (gamma * rstd) * (g_y - mean(g_y) - zhat * mean(g_y * zhat))
+__device__ inline float bn_bwd(float gout, float z, const Stat &st, float gamma, float beta, const double *bsums, int g, int c,
+                               int count) {
+  const float zh = (z - st.mean) * st.rstd;
+  const float gy = gout * t_dsilu(fmaf(zh, gamma, beta));
+  const float m1 = (float)(bsums[((size_t)g * 32 + c) * 2] / count), m2 = (float)(bsums[((size_t)g * 32 + c) * 2 + 1] / count);
+  return gamma * st.rstd * (gy - m1 - zh * m2);
+}
+
+// node side: g_zv -> gX[:, 0:32] (x1 block) and g_msg = g_zv / degree; BatchNorm parameter gradients
+__global__ void __launch_bounds__(256)
+gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const float *beta, const double *fsums,
+                     const double *bsums, const float *zv, const float *gx, float *gX, float *gmsg) {
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  if (i >= n) return;
+  const int g = i / ng;
+  const Stat st = load_stat(fsums, g, o, ng);
+  const float gz = bn_bwd(gx[(size_t)i * TU + o], zv[(size_t)i * TU + o], st, gamma[o], beta[o], bsums, g, o, ng);
+  gX[(size_t)i * 128 + o] = gz;
+  gmsg[(size_t)i * TU + o] = gz / (float)max(rowptr[i + 1] - rowptr[i], 1);
+}
+
+// edge side of a layer's backward, waves walk 32-edge tiles
+__global__ void __launch_bounds__(256)
+gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, const float *gamma, const float *beta,
+               const double *fsums, const double *bsums, const float *X, const float *w0, const float *ze, const float *gmsg,
+               float *gw /* in: grad wrt w', out: grad wrt w */, float *gX, float *gWe, float *gbe) {
+  __shared__ __attribute__((aligned(16))) float tw_s[4][32][36], tg_s[4][32][36];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
+  float (*tw)[36] = tw_s[wave], (*tg)[36] = tg_s[wave];
+  f32x16 aW = ZERO16;
+  float ab = 0.0f;
+  const int ntiles = (E + 31) / 32;
+  for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
+    const int e0 = tix * 32;
+    // edge-major pass: g_ze per element, scatter-adds, gate path; tiles tw = w, tg = g_ze
+    float4 gres[4], gate_term[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + (lane >> 3), e = e0 + el;
+      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), gz = wv;
+      gres[q] = wv; gate_term[q] = wv;
+      if (e < E) {
+        const int g = e / Eg, s = src[e], d = dst[e];
+        wv = *reinterpret_cast<const float4 *>(w0 + (size_t)e * TU + c0);
+        const float4 zz = *reinterpret_cast<const float4 *>(ze + (size_t)e * TU + c0);
+        const float4 go = *reinterpret_cast<const float4 *>(gw + (size_t)e * TU + c0);
+        gres[q] = go;
+        const float zc[4] = {zz.x, zz.y, zz.z, zz.w}, gc[4] = {go.x, go.y, go.z, go.w}, wc[4] = {wv.x, wv.y, wv.z, wv.w};
+        float gzc[4], gt[4];
+        const float4 gm = *reinterpret_cast<const float4 *>(gmsg + (size_t)s * TU + c0);
+        const float4 x2 = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 32 + c0);
+        const float gmc[4] = {gm.x, gm.y, gm.z, gm.w}, x2c[4] = {x2.x, x2.y, x2.z, x2.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const Stat st = load_stat(fsums, g, c0 + k, Eg);
+          gzc[k] = bn_bwd(gc[k], zc[k], st, gamma[c0 + k], beta[c0 + k], bsums, g, c0 + k, Eg);
+          const float gate = t_sigmoid(wc[k]);
+          gt[k] = gmc[k] * x2c[k] * gate * (1.0f - gate);                   // d msg / d w through the gate
+          unsafeAtomicAdd(gX + (size_t)d * 128 + 32 + c0 + k, gmc[k] * gate);   // d / d x2[dst]
+          unsafeAtomicAdd(gX + (size_t)s * 128 + 64 + c0 + k, gzc[k]);          // d / d x3[src]
+          unsafeAtomicAdd(gX + (size_t)d * 128 + 96 + c0 + k, gzc[k]);          // d / d x4[dst]
+        }
+        gz = make_float4(gzc[0], gzc[1], gzc[2], gzc[3]);
+        gate_term[q] = make_float4(gt[0], gt[1], gt[2], gt[3]);
+      }
+      *reinterpret_cast<float4 *>(&tw[el][c0]) = wv;
+      *reinterpret_cast<float4 *>(&tg[el][c0]) = gz;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // gWe[o][c] += sum_e g_ze[e][o] * w[e][c];  gbe[o] += sum_e g_ze[e][o]
+    aW = mfma32(aW, [&](int kk) { return tg[h * 16 + kk][o]; }, [&](int kk) { return tw[h * 16 + kk][o]; });
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) ab += tg[h * 16 + kk][o];
+    // g_w (through the edge linear) = g_ze We : D[e][c] = sum_o g_ze[e][o] We[o][c]
+    const f32x16 acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return We[(h * 16 + kk) * TU + o]; });
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tw[t_drow(r, lane)][o] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + (lane >> 3), e = e0 + el;
+      if (e < E) {
+        const float4 a = *reinterpret_cast<const float4 *>(&tw[el][c0]);
+        float4 out;
+        out.x = gres[q].x + a.x + gate_term[q].x; out.y = gres[q].y + a.y + gate_term[q].y;
+        out.z = gres[q].z + a.z + gate_term[q].z; out.w = gres[q].w + a.w + gate_term[q].w;
+        *reinterpret_cast<float4 *>(gw + (size_t)e * TU + c0) = out;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  flush_acc(gWe, aW, lane);
+  unsafeAtomicAdd(gbe + o, ab);
+}
+
+// node linears backward: gx (in: grad wrt x', out: grad wrt x) += gX Wv; gWvT[c][c'] += sum_i x[i][c] gX[i][c'];
+// gbv[c'] += sum_i gX[i][c'].  Waves walk 32-node tiles.
+__global__ void __launch_bounds__(256)
+gnn_t_node_lin_bwd(int n, const float *WT, const float *x0, const float *gX, float *gx, float *gWT, float *gbv) {
+  __shared__ __attribute__((aligned(16))) float tx_s[4][32][36], tG_s[4][32][132];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = lane & 31, h = lane >> 5;
+  float (*tx)[36] = tx_s[wave], (*tG)[132] = tG_s[wave];
+  f32x16 aW[4] = {ZERO16, ZERO16, ZERO16, ZERO16};
+  float ab[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (n + 31) / 32;
+  for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
+    const int i0 = tix * 32;
+    for (int k = lane; k < 32 * 32; k += 64) { const int r = k >> 5, c = k & 31; tx[r][c] = i0 + r < n ? x0[(size_t)(i0 + r) * TU + c] : 0.0f; }
+    for (int k = lane; k < 32 * 128; k += 64) { const int r = k >> 7, c = k & 127; tG[r][c] = i0 + r < n ? gX[(size_t)(i0 + r) * 128 + c] : 0.0f; }
+    __builtin_amdgcn_wave_barrier();
+    // gWT[c][32q + c'] : D_q[c][c'] = sum_i x[i][c] * gX[i][32q + c']
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      aW[q] = mfma32(aW[q], [&](int kk) { return tx[h * 16 + kk][o]; }, [&](int kk) { return tG[h * 16 + kk][q * 32 + o]; });
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) ab[q] += tG[h * 16 + kk][q * 32 + o];
+    }
+    // gx[i][c] += sum_{c'} gX[i][c'] * W[c'][c] = sum_{c'} gX[i][c'] * WT[c*128 + c']: four K = 32 blocks
+    f32x16 acc = ZERO16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      acc = mfma32(acc, [&](int kk) { return tG[o][q * 32 + h * 16 + kk]; }, [&](int kk) { return WT[o * 128 + q * 32 + h * 16 + kk]; });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + t_drow(r, lane);
+      if (i < n) gx[(size_t)i * TU + o] += acc[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(gWT + t_drow(r, lane) * 128 + q * 32 + j, aW[q][r]);
+    unsafeAtomicAdd(gbv + q * 32 + o, ab[q]);
+  }
+}
+
+// BatchNorm parameter gradients from the backward sums: d/dgamma = sum(g_y * zhat), d/dbeta = sum(g_y), over graphs
+__global__ void gnn_t_bn_param_grad(int G, const double *bsums, float *ggamma, float *gbeta) {
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  double a = 0.0, b = 0.0;
+  for (int g = 0; g < G; ++g) { b += bsums[((size_t)g * 32 + c) * 2]; a += bsums[((size_t)g * 32 + c) * 2 + 1]; }
+  ggamma[c] = (float)a; gbeta[c] = (float)b;
+}
+
+// first linears: x0 = silu(a0), a0 = xin W^T + b  /  w0 = silu(attr * W + b)
+__global__ void __launch_bounds__(256)
+gnn_t_node_init_bwd(int n, int feats, const float *xin, const float *a0, const float *gx, float *gW, float *gb) {
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  float accW[8] = {0, 0, 0, 0, 0, 0, 0, 0}, accb = 0.0f;
+  for (int i = blockIdx.x * 8 + il; i < n; i += gridDim.x * 8) {
+    const float g = gx[(size_t)i * TU + o] * t_dsilu(a0[(size_t)i * TU + o]);
+    accb += g;
+    for (int f = 0; f < feats; ++f) accW[f] = fmaf(g, xin[(size_t)i * feats + f], accW[f]);
+  }
+  unsafeAtomicAdd(gb + o, accb);
+  for (int f = 0; f < feats; ++f) unsafeAtomicAdd(gW + o * feats + f, accW[f]);
+}
+__global__ void __launch_bounds__(256)
+gnn_t_edge_init_bwd(int E, const float *attr, const float *W, const float *b, const float *gw, float *gW, float *gb) {
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  float accW = 0.0f, accb = 0.0f;
+  for (int e = blockIdx.x * 8 + il; e < E; e += gridDim.x * 8) {
+    const float a = attr[e];
+    const float g = gw[(size_t)e * TU + o] * t_dsilu(fmaf(a, W[o], b[o]));
+    accb += g; accW = fmaf(g, a, accW);
+  }
+  unsafeAtomicAdd(gb + o, accb);
+  unsafeAtomicAdd(gW + o, accW);
+}
+
+// mean / biased variance of every BatchNorm (for the running-statistics update on the host side)
+__global__ void gnn_t_export_stats(int G, int count_e, int count_v, const double *fsums_all, float *out) {
+  // fsums_all: [12][2 (e, v)][G][32][2]; out: [12][2][G][32][2] (mean, biased var)
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 12 * 2 * G * 32) return;
+  const int which = (idx / (G * 32)) & 1;
+  const int cnt = which == 0 ? count_e : count_v;
+  const double s = fsums_all[(size_t)idx * 2], q = fsums_all[(size_t)idx * 2 + 1];
+  const double m = s / cnt;
+  double v = q / cnt - m * m;
+  out[(size_t)idx * 2] = (float)m;
+  out[(size_t)idx * 2 + 1] = (float)(v < 0.0 ? 0.0 : v);
+}
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct TrainWs {
+  float *a0, *x[13], *X[12], *w[13], *ze[12], *zv[12];
+  double *fsums;   // [12][2][G][32][2]
+  // backward scratch
+  float *gx, *gw, *gX, *gmsg;
+  double *bsums;   // [2][G][32][2]
+  size_t total;
+};
+static TrainWs carve(void *base, int n, int E, int G) {
+  TrainWs t;
+  char *p = (char *)base;
+  auto take = [&](size_t bytes) { char *r = p; p += al256(bytes); return r; };
+  t.a0 = (float *)take((size_t)n * 32 * 4);
+  for (int l = 0; l <= 12; ++l) t.x[l] = (float *)take((size_t)n * 32 * 4);
+  for (int l = 0; l < 12; ++l) t.X[l] = (float *)take((size_t)n * 128 * 4);
+  for (int l = 0; l <= 12; ++l) t.w[l] = (float *)take((size_t)E * 32 * 4);
+  for (int l = 0; l < 12; ++l) t.ze[l] = (float *)take((size_t)E * 32 * 4);
+  for (int l = 0; l < 12; ++l) t.zv[l] = (float *)take((size_t)n * 32 * 4);
+  t.fsums = (double *)take((size_t)12 * 2 * G * 32 * 2 * 8);
+  t.gx = (float *)take((size_t)n * 32 * 4);
+  t.gw = (float *)take((size_t)E * 32 * 4);
+  t.gX = (float *)take((size_t)n * 128 * 4);
+  t.gmsg = (float *)take((size_t)n * 32 * 4);
+  t.bsums = (double *)take((size_t)2 * G * 32 * 2 * 8);
+  t.total = (size_t)(p - (char *)base);
+  return t;
+}
+
+}  // namespace daco
+
+using namespace daco;
+
+extern "C" size_t daco_gnn_train_workspace_bytes(int n, int E, int G) {
+  if (n <= 0 || E <= 0 || G <= 0) return 0;
+  return carve(nullptr, n, E, G).total;
+}
+
+static int check_train_args(const char *what, int n, int E, int feats, int G) {
+  if (n <= 0 || E <= 0 || feats < 1 || feats > 8 || G <= 0 || n % G || E % G) {
+    set_error("%s: bad argument (n=%d E=%d feats=%d G=%d; n and E must be multiples of G)", what, n, E, feats, G);
+    return DACO_E_BADARG;
+  }
+  return DACO_OK;
+}
+
+extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
+                                      const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const float *edge_attr,
+                                      const float *params, float *heu, float *stats_out, void *workspace,
+                                      size_t workspace_bytes) {
+  if (int rc = check_train_args("daco_gnn_train_forward", n, E, feats, G)) return rc;
+  if (!x || !src || !dst || !rowptr || !edge_attr || !params || !heu || !workspace) { set_error("daco_gnn_train_forward: null pointer"); return DACO_E_BADARG; }
+  if (workspace_bytes < daco_gnn_train_workspace_bytes(n, E, G)) { set_error("daco_gnn_train_forward: workspace too small"); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  TrainWs t = carve(workspace, n, E, G);
+  const int ng = n / G, Eg = E / G;
+  const int node_blocks = (n + 7) / 8, tile_blocks = (E + 127) / 128;
+  const unsigned ew_blocks = (unsigned)(((long)E * 32 + 255) / 256);
+  if (hipMemsetAsync(t.fsums, 0, (size_t)12 * 2 * G * 32 * 2 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+  hipLaunchKernelGGL(gnn_t_node_init, dim3(node_blocks), dim3(256), 0, s, n, feats, x, params, t.a0, t.x[0], t.X[0]);
+  hipLaunchKernelGGL(gnn_t_edge_init, dim3(ew_blocks), dim3(256), 0, s, E, feats, edge_attr, params, t.w[0]);
+  for (int l = 0; l < 12; ++l) {
+    const float *lp = params + t_off_layer(feats, l);
+    const float *We = lp + 32 * 128 + 128, *be = We + 1024, *gv = be + 32, *bv_ = gv + 32, *ge = bv_ + 32, *bee = ge + 32;
+    double *fe = t.fsums + ((size_t)l * 2 + 0) * G * 64, *fv = t.fsums + ((size_t)l * 2 + 1) * G * 64;
+    hipLaunchKernelGGL(gnn_t_edge_pre, dim3(tile_blocks), dim3(256), 0, s, E, Eg, src, dst, We, be, t.X[l], t.w[l], t.ze[l], fe);
+    hipLaunchKernelGGL(gnn_t_node_pre, dim3(node_blocks), dim3(256), 0, s, n, ng, dst, rowptr, perm, t.X[l], t.w[l], t.zv[l], fv);
+    hipLaunchKernelGGL(gnn_t_edge_post, dim3(ew_blocks), dim3(256), 0, s, E, Eg, ge, bee, fe, t.w[l], t.ze[l], t.w[l + 1]);
+    const float *WTn = l < 11 ? params + t_off_layer(feats, l + 1) : nullptr;
+    hipLaunchKernelGGL(gnn_t_node_post, dim3(node_blocks), dim3(256), 0, s, n, ng, gv, bv_, fv, t.x[l], t.zv[l], t.x[l + 1], WTn,
+                       WTn ? WTn + 32 * 128 : nullptr, l < 11 ? t.X[l + 1] : nullptr);
+  }
+  hipLaunchKernelGGL(gnn_t_head_fwd, dim3(tile_blocks), dim3(256), 0, s, E, params + t_off_head(feats), t.w[12], heu);
+  if (stats_out)
+    hipLaunchKernelGGL(gnn_t_export_stats, dim3((12 * 2 * G * 32 + 255) / 256), dim3(256), 0, s, G, Eg, ng, t.fsums, stats_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("gnn train forward launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
+                                       const int32_t *dst, const int32_t *rowptr, const float *edge_attr, const float *params,
+                                       const float *heu, const float *grad_heu, float *grad_params, void *workspace,
+                                       size_t workspace_bytes) {
+  if (int rc = check_train_args("daco_gnn_train_backward", n, E, feats, G)) return rc;
+  if (!x || !src || !dst || !rowptr || !edge_attr || !params || !heu || !grad_heu || !grad_params || !workspace) { set_error("daco_gnn_train_backward: null pointer"); return DACO_E_BADARG; }
+  if (workspace_bytes < daco_gnn_train_workspace_bytes(n, E, G)) { set_error("daco_gnn_train_backward: workspace too small"); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  TrainWs t = carve(workspace, n, E, G);
+  const int ng = n / G, Eg = E / G;
+  const int node_blocks = (n + 7) / 8;
+  const int etiles = (E + 31) / 32, ntiles = (n + 31) / 32;
+  const int egrid = etiles / 4 + 1 < 1024 ? etiles / 4 + 1 : 1024, ngrid = ntiles / 4 + 1 < 512 ? ntiles / 4 + 1 : 512;
+  const size_t pfloats = t_off_head(feats) + 2 * (1024 + 32) + 32 + 1;
+  if (hipMemsetAsync(grad_params, 0, pfloats * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+  if (hipMemsetAsync(t.gx, 0, (size_t)n * 32 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+  hipLaunchKernelGGL(gnn_t_head_bwd, dim3(egrid), dim3(256), 0, s, E, params + t_off_head(feats), t.w[12], heu, grad_heu, t.gw,
+                     grad_params + t_off_head(feats));
+  for (int l = 11; l >= 0; --l) {
+    const float *lp = params + t_off_layer(feats, l);
+    const float *WT = lp, *We = lp + 32 * 128 + 128, *gv = We + 1024 + 32, *bv_ = gv + 32, *ge = bv_ + 32, *bee = ge + 32;
+    float *glp = grad_params + t_off_layer(feats, l);
+    float *gWT = glp, *gbv = glp + 32 * 128, *gWe = gbv + 128, *gbe = gWe + 1024, *ggv = gbe + 32, *gbv_ = ggv + 32, *gge = gbv_ + 32, *gbee = gge + 32;
+    double *fe = t.fsums + ((size_t)l * 2 + 0) * G * 64, *fv = t.fsums + ((size_t)l * 2 + 1) * G * 64;
+    double *be_s = t.bsums, *bv_s = t.bsums + (size_t)G * 64;
+    if (hipMemsetAsync(t.bsums, 0, (size_t)2 * G * 64 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    if (hipMemsetAsync(t.gX, 0, (size_t)n * 128 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((E + 255) / 256), dim3(256), 0, s, E, Eg, ge, bee, fe, t.ze[l], t.gw, be_s);
+    hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((n + 255) / 256), dim3(256), 0, s, n, ng, gv, bv_, fv, t.zv[l], t.gx, bv_s);
+    hipLaunchKernelGGL(gnn_t_node_bwd_apply, dim3(node_blocks), dim3(256), 0, s, n, ng, rowptr, gv, bv_, fv, bv_s, t.zv[l], t.gx,
+                       t.gX, t.gmsg);
+    hipLaunchKernelGGL(gnn_t_edge_bwd, dim3(egrid), dim3(256), 0, s, E, Eg, src, dst, We, ge, bee, fe, be_s, t.X[l], t.w[l], t.ze[l],
+                       t.gmsg, t.gw, t.gX, gWe, gbe);
+    hipLaunchKernelGGL(gnn_t_node_lin_bwd, dim3(ngrid), dim3(256), 0, s, n, WT, t.x[l], t.gX, t.gx, gWT, gbv);
+    hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, be_s, gge, gbee);
+    hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, bv_s, ggv, gbv_);
+  }
+  hipLaunchKernelGGL(gnn_t_node_init_bwd, dim3(node_blocks < 256 ? node_blocks : 256), dim3(256), 0, s, n, feats, x, t.a0, t.gx,
+                     grad_params, grad_params + 32 * feats);
+  const float *W0e = params + 32 * feats + 32;
+  hipLaunchKernelGGL(gnn_t_edge_init_bwd, dim3(E / 8 + 1 < 1024 ? E / 8 + 1 : 1024), dim3(256), 0, s, E, edge_attr, W0e, W0e + 32, t.gw,
+                     grad_params + 32 * feats + 32, grad_params + 32 * feats + 64);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("gnn train backward launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}

@@ -7,9 +7,11 @@ e_bns.{i}.module.*}, par_net_heu.{_dummy, lins.{i}}, and the unused par_net_phe 
 forward(pyg):
   * inference (module in eval mode and no gradient required) -> one call into
     libdeepaco_hip.so (daco_gnn_forward: 14 kernel launches, MFMA edge linears, BatchNorm folded);
-  * training (train mode or autograd on) -> the same math as torch ops on the HIP device, so
-    autograd provides the backward.  Train-mode BatchNorm uses the statistics of the single
-    graph, as in the reference (tsp/net.py:21,24,43-44).
+  * training mode -> daco_gnn_train_forward / daco_gnn_train_backward behind a torch.autograd.Function
+    (csrc/daco_gnn_train.hip: BatchNorm on the statistics of the single graph, as in the reference
+    tsp/net.py:21,24,43-44; MFMA linears and weight gradients; no library GEMM).  The BatchNorm running
+    statistics are updated from the statistics the kernels report.  `Net.train_backend = "torch"` (or
+    eval mode with gradients required) runs the same math as torch ops with autograd instead.
 `pyg` only needs `.x`, `.edge_index`, `.edge_attr` (torch_geometric is not required).
 """
 import torch
@@ -115,9 +117,70 @@ class ParNet(MLP):
         return super().forward(x).squeeze(dim=-1)
 
 
+def _csr_graph(pyg, n, device):
+    """(src, dst, rowptr, perm) int32 for the kernels; cached on the graph object."""
+    graph = getattr(pyg, "_daco_graph", None)
+    if graph is None:
+        ei = pyg.edge_index
+        src64 = ei[0]
+        sorted_already = bool((src64[1:] >= src64[:-1]).all()) if src64.numel() > 1 else True
+        perm = None if sorted_already else torch.argsort(src64, stable=True).to(torch.int32).contiguous()
+        rowptr = torch.zeros(n + 1, dtype=torch.int32, device=device)
+        rowptr[1:] = torch.cumsum(torch.bincount(src64, minlength=n), 0).to(torch.int32)
+        graph = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous(), rowptr, perm)
+        try:
+            pyg._daco_graph = graph
+        except Exception:
+            pass
+    return graph
+
+
+class _GnnTrainFn(torch.autograd.Function):
+    """heu = Net(graph) in training mode; the backward returns d loss / d (flat parameter block)."""
+
+    @staticmethod
+    def forward(ctx, flat, x, attr, src, dst, rowptr, perm, feats, G):
+        n, E = x.shape[0], src.numel()
+        L = _lib.lib()
+        dev = x.device
+        with torch.cuda.device(dev):
+            heu = torch.empty(E, dtype=torch.float32, device=dev)
+            stats = torch.empty((DEPTH, 2, G, UNITS, 2), dtype=torch.float32, device=dev)
+            # the activations the backward reads stay in this block: one per forward call, kept by ctx
+            ws = torch.empty(L.daco_gnn_train_workspace_bytes(n, E, G), dtype=torch.uint8, device=dev)
+            flat = flat.detach().contiguous()
+            rc = L.daco_gnn_train_forward(engine._stream(dev), n, E, feats, G, x.data_ptr(), src.data_ptr(), dst.data_ptr(),
+                                          rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, attr.data_ptr(),
+                                          flat.data_ptr(), heu.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel())
+        _lib.check(rc, "daco_gnn_train_forward")
+        ctx.save_for_backward(flat, x, attr, src, dst, rowptr, heu)
+        ctx.ws, ctx.feats, ctx.G = ws, feats, G
+        ctx.mark_non_differentiable(stats)
+        return heu, stats
+
+    @staticmethod
+    def backward(ctx, gheu, _gstats):
+        flat, x, attr, src, dst, rowptr, heu = ctx.saved_tensors
+        n, E = x.shape[0], src.numel()
+        L = _lib.lib()
+        dev = x.device
+        with torch.cuda.device(dev):
+            gflat = torch.empty_like(flat)
+            gheu = gheu.float().contiguous()
+            rc = L.daco_gnn_train_backward(engine._stream(dev), n, E, ctx.feats, ctx.G, x.data_ptr(), src.data_ptr(),
+                                           dst.data_ptr(), rowptr.data_ptr(), attr.data_ptr(), flat.data_ptr(),
+                                           heu.data_ptr(), gheu.data_ptr(), gflat.data_ptr(), ctx.ws.data_ptr(),
+                                           ctx.ws.numel())
+        _lib.check(rc, "daco_gnn_train_backward")
+        ctx.ws = None
+        return (gflat,) + (None,) * 8
+
+
 class Net(nn.Module):
     """feats: node-feature width (2 = coordinates in tsp/, 1 in tsp_nls/ and cvrp/);
     with_phe: also create the unused par_net_phe head that tsp/ checkpoints contain."""
+
+    train_backend = "hip"          # "torch": training forward/backward as torch ops + autograd (cross-check)
 
     def __init__(self, feats=2, with_phe=True):
         super().__init__()
@@ -131,10 +194,12 @@ class Net(nn.Module):
     # ------------------------------------------------------------------ reference surface
     def forward(self, pyg):
         x, edge_index, edge_attr = pyg.x, pyg.edge_index, pyg.edge_attr
+        if not x.is_cuda:
+            raise _lib.DacoError("deepaco_amd.Net runs on a HIP device only (got CPU tensors)")
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self.training or needs_graph or not x.is_cuda:
-            if not x.is_cuda:
-                raise _lib.DacoError("deepaco_amd.Net runs on a HIP device only (got CPU tensors)")
+        if self.training and self.train_backend == "hip":
+            return self.forward_train_hip(pyg)
+        if self.training or needs_graph:
             emb = self.emb_net(x, edge_index, edge_attr)
             return self.par_net_heu(emb)
         return self.forward_hip(pyg)
@@ -150,6 +215,59 @@ class Net(nn.Module):
         matrix = torch.zeros(size=(n_nodes, n_nodes), device=pyg.x.device, dtype=vector.dtype)
         matrix[pyg.edge_index[0], pyg.edge_index[1]] = vector
         return matrix
+
+    # ------------------------------------------------------------------ HIP training path
+    def pack_params_train(self):
+        """Flat parameter block for the training kernels, built from the live parameters with differentiable ops
+        (views + one cat), so that autograd hands the flat gradient back to every nn.Parameter.  Layout of
+        csrc/daco_gnn.hip with gamma / beta in the BatchNorm slots."""
+        e = self.emb_net
+        parts = [e.v_lin0.weight.reshape(-1), e.v_lin0.bias, e.e_lin0.weight.reshape(-1), e.e_lin0.bias]
+        for i in range(DEPTH):
+            Wv = torch.cat([m[i].weight for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)   # [128, 32]
+            bv = torch.cat([m[i].bias for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)
+            parts += [Wv.t().reshape(-1), bv, e.e_lins0[i].weight.reshape(-1), e.e_lins0[i].bias,
+                      e.v_bns[i].module.weight, e.v_bns[i].module.bias, e.e_bns[i].module.weight, e.e_bns[i].module.bias]
+        h = self.par_net_heu.lins
+        parts += [h[0].weight.reshape(-1), h[0].bias, h[1].weight.reshape(-1), h[1].bias, h[2].weight.reshape(-1), h[2].bias]
+        return torch.cat([p.float().reshape(-1) for p in parts])
+
+    @torch.no_grad()
+    def _update_running_stats(self, stats, count_e, count_v):
+        """BatchNorm1d's training-mode side effect, from the statistics the kernels report: for each graph in turn
+        running = (1 - m) * running + m * batch (variance unbiased), as G successive reference forwards would do."""
+        G = stats.shape[2]
+        for i in range(DEPTH):
+            for which, bn, cnt in ((0, self.emb_net.e_bns[i].module, count_e), (1, self.emb_net.v_bns[i].module, count_v)):
+                m = bn.momentum if bn.momentum is not None else 0.1
+                decay = (1 - m) ** torch.arange(G - 1, -1, -1, device=stats.device, dtype=torch.float32)     # oldest graph first
+                mean, var = stats[i, which, :, :, 0], stats[i, which, :, :, 1] * (cnt / max(cnt - 1, 1))
+                bn.running_mean.mul_((1 - m) ** G).add_(m * (decay.view(G, 1) * mean).sum(0))
+                bn.running_var.mul_((1 - m) ** G).add_(m * (decay.view(G, 1) * var).sum(0))
+                bn.num_batches_tracked += G
+
+    def forward_train_hip(self, pyg, graphs=1):
+        """Training-mode forward through the HIP kernels (graphs > 1: that many equal-sized graphs side by side,
+        each normalised with its own statistics).  Differentiable w.r.t. the parameters."""
+        x = pyg.x.float().contiguous()
+        n, feats = x.shape
+        src, dst, rowptr, perm = _csr_graph(pyg, n, x.device)
+        attr = pyg.edge_attr.float().contiguous().view(-1)
+        flat = self.pack_params_train()
+        heu, stats = _GnnTrainFn.apply(flat, x, attr, src, dst, rowptr, perm, feats, graphs)
+        self._update_running_stats(stats, src.numel() // graphs, n // graphs)
+        return heu
+
+    def forward_batch_train(self, x, edge_index, edge_attr):
+        """Training forward for B equal-sized graphs in one pass (tsp_nls/train.py's batch of instances): x [B,n,feats],
+        edge_index [B,2,E] (ids local to each graph), edge_attr [B,E(,1)] -> heu [B,E]; graph b is normalised with its own
+        BatchNorm statistics, exactly as B separate training forwards."""
+        B, n, feats = x.shape
+        E = edge_index.shape[2]
+        off = (torch.arange(B, device=x.device, dtype=edge_index.dtype) * n).view(B, 1, 1)
+        merged = GraphData(x=x.reshape(B * n, feats), edge_index=(edge_index + off).permute(1, 0, 2).reshape(2, B * E),
+                           edge_attr=edge_attr.reshape(B * E, 1))
+        return self.forward_train_hip(merged, graphs=B).view(B, E)
 
     # ------------------------------------------------------------------ HIP inference path
     def pack_params(self):
@@ -203,19 +321,7 @@ class Net(nn.Module):
     def forward_hip(self, pyg, return_embedding=False):
         x = pyg.x.float().contiguous()
         n, feats = x.shape
-        graph = getattr(pyg, "_daco_graph", None)
-        if graph is None:
-            ei = pyg.edge_index
-            src64 = ei[0]
-            sorted_already = bool((src64[1:] >= src64[:-1]).all()) if src64.numel() > 1 else True
-            perm = None if sorted_already else torch.argsort(src64, stable=True).to(torch.int32).contiguous()
-            rowptr = torch.zeros(n + 1, dtype=torch.int32, device=x.device)
-            rowptr[1:] = torch.cumsum(torch.bincount(src64, minlength=n), 0).to(torch.int32)
-            graph = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous(), rowptr, perm)
-            try:
-                pyg._daco_graph = graph
-            except Exception:
-                pass
+        graph = _csr_graph(pyg, n, x.device)
         src, dst, rowptr, perm = graph
         E = src.numel()
         attr = pyg.edge_attr.float().contiguous().view(-1)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 112 /* 0.1.11: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 113 /* 0.1.12: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -322,6 +322,33 @@ int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, cons
                      const int32_t *dst, const int32_t *rowptr, const int32_t *perm,
                      const float *edge_attr, const float *params, float *heu, float *emb,
                      void *workspace, size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_gnn_train_forward / daco_gnn_train_backward -- replace Net.forward in TRAINING mode and the backward
+ * autograd derives from it
+ *   EmbNet.forward tsp/net.py:27-45 with BatchNorm on the statistics of the one graph (:21,24,43-44),
+ *   MLP/ParNet.forward :59-75; loss.backward() of tsp_nls/train.py:15-44 as far as the network goes.
+ * G equal-sized graphs side by side (n = G * n_g nodes, E = G * E_g edges, graph g owns nodes [g*n_g, (g+1)*n_g) and
+ * edges [g*E_g, (g+1)*E_g), node ids already offset): every graph is normalised with its own statistics.
+ *   x, src, dst, rowptr, perm, edge_attr   as daco_gnn_forward
+ *   params     daco_gnn_param_floats(feats) floats in the layout of csrc/daco_gnn.hip with the BatchNorm slots
+ *              holding weight (gamma) and bias (beta) instead of the folded scale / shift
+ *   heu        out [E]
+ *   stats_out  out [12][2][G][32][2] f32 or NULL: (mean, biased variance) of every BatchNorm (index 0 = edge BN,
+ *              1 = node BN of the layer), for the caller's running-statistics update
+ *   workspace  daco_gnn_train_workspace_bytes(n, E, G) bytes; the forward leaves the activations the backward needs
+ *              there: pass the SAME, untouched block to daco_gnn_train_backward
+ *   grad_heu   [E] d loss / d heu;   grad_params out: d loss / d params, same layout as params
+ * No library GEMM is called: the 32x32 linears and their weight gradients run on v_mfma_f32_32x32x2_f32.
+ */
+size_t daco_gnn_train_workspace_bytes(int n, int E, int G);
+int daco_gnn_train_forward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
+                           const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const float *edge_attr,
+                           const float *params, float *heu, float *stats_out, void *workspace, size_t workspace_bytes);
+int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
+                            const int32_t *dst, const int32_t *rowptr, const float *edge_attr, const float *params,
+                            const float *heu, const float *grad_heu, float *grad_params, void *workspace,
+                            size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_tsp_knn_graph -- replaces gen_distance_matrix + gen_pyg_data for a batch of instances

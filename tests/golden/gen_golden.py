@@ -402,6 +402,36 @@ def gen_net():
              emb_eval=emb_eval, heu_train=heu_train, heu_mat=mat, k_sparse=np.int32(k or 0), **extra, **weights)
 
 
+def gen_netgrad():
+    """G7: one training step of the heuristic network (tsp_nls/train.py:15-44 as far as the network goes): train-mode
+    forward (BatchNorm on the statistics of the one graph), a scalar loss sum(heu * coef) with a recorded coefficient
+    vector, loss.backward().  Stored: heu, every parameter's gradient, the BatchNorm running statistics after the
+    forward.  Inputs (graph, weights) are those of the matching g5 fixture (same seed, same checkpoint)."""
+    cases = [("tsp", "tsp20", "tsp", 20, 10), ("tsp_nls", "tsp100", "tsp_nls", 100, 10), ("cvrp", "cvrp20", "cvrp", 20, None)]
+    for sub, ck, kind, n, k in cases:
+        net_mod = load_ref(sub, "net", f"ref_net_{sub}")
+        utils = load_ref(sub, "utils", f"ref_utils_{sub}")
+        sd = torch.load(os.path.join(REF, "pretrained", sub, ck + ".pt"), map_location="cpu")
+        model = net_mod.Net()
+        model.load_state_dict(sd)
+        torch.manual_seed(7)
+        if kind == "cvrp":
+            demands, distances = utils.gen_instance(n, "cpu")
+            pyg = utils.gen_pyg_data(demands, distances, "cpu")
+        elif kind == "tsp_nls":
+            pyg, _ = utils.gen_pyg_data(torch.rand(n, 2), k_sparse=k, start_node=0)
+        else:
+            pyg, _ = utils.gen_pyg_data(torch.rand(n, 2), k_sparse=k)
+        model.train()
+        heu = model(pyg)
+        coef = torch.randn(heu.shape, generator=torch.Generator().manual_seed(99))
+        loss = torch.sum(heu * coef)
+        loss.backward()
+        grads = {"g__" + kk: v.grad.numpy() for kk, v in model.named_parameters() if v.grad is not None and v.numel() > 0}
+        stats = {"rs__" + kk: v.numpy() for kk, v in model.state_dict().items() if "running_" in kk}
+        save(f"g7_netgrad_{sub}_{ck}", heu_train=heu.detach(), coef=coef, loss=loss.detach(), **grads, **stats)
+
+
 def load_ref_dir(subdir, alias):
     """Import <subdir>/aco.py with <subdir> on sys.path (smtwtp/aco.py does `import utils`)."""
     d = os.path.join(REF, subdir)
@@ -529,6 +559,7 @@ def main():
     print("CVRP (G1/G2)"); gen_cvrp(cvrp_aco)
     print("gradients (G3)"); gen_grads(tsp_aco, cvrp_aco)
     print("Net forward (G5)"); gen_net()
+    print("Net training step (G7)"); gen_netgrad()
     print("siblings (S1-S6)"); gen_siblings()
 
 
