@@ -31,6 +31,29 @@ class TspSampleFn(torch.autograd.Function):
         return (grad[0],) + (None,) * 11
 
 
+class TspBatchSampleFn(torch.autograd.Function):
+    """B colonies at once: (heuristic [B,n,n]) -> (paths [B,n,A], log_probs [B,n-1,A], flags [B]); one sampler launch
+    forward, one daco_sample_backward launch backward (the batched tsp_nls/train.py step)."""
+
+    @staticmethod
+    def forward(ctx, heuristic, pheromone, n_ants, alpha, beta, mode, norm_passes, fixed_start, seed, it):
+        eta = heuristic.detach().contiguous()
+        B = eta.shape[0]
+        paths, logp, rowsum, flags = engine.tsp_sample(
+            pheromone, eta, n_ants, alpha, beta, mode=mode, norm_passes=norm_passes, fixed_start=fixed_start,
+            seed=seed, it=it, require_prob=True, batch=B)
+        ctx.save_for_backward(pheromone, eta, paths, rowsum)
+        ctx.ab = (alpha, beta)
+        ctx.mark_non_differentiable(paths, flags)
+        return paths, logp, flags
+
+    @staticmethod
+    def backward(ctx, _gp, glogp, _gf):
+        tau, eta, paths, rowsum = ctx.saved_tensors
+        grad = engine.sample_backward(tau, eta, ctx.ab[0], ctx.ab[1], paths, rowsum, glogp.contiguous())
+        return (grad,) + (None,) * 9
+
+
 class CvrpSampleFn(torch.autograd.Function):
     """(heuristic [n,n]) -> (paths [Lmax,A], log_probs [Lmax-1,A], lens [A], flags [1])."""
 

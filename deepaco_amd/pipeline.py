@@ -42,3 +42,44 @@ def infer_tsp_batch(coords, n_ants, t_aco, k_sparse, net=None, node_feature="coo
         done = t
         out.append(colony.lowest_cost.clone())
     return torch.stack(out), colony
+
+
+W_2OPT = 0.95      # tsp_nls/train.py:13: weight of the locally-searched costs in the REINFORCE signal
+
+
+def train_tsp_nls_batch(net, optimizer, coords, n_ants, k_sparse, seed=0, it=0, max_norm=3.0, local_search="nls"):
+    """One optimisation step of tsp_nls/train.py:15-44 (`train_instance`) for a batch of B instances, on the device end
+    to end: kNN graphs (one launch) -> Net in training mode (HIP kernels, per-graph BatchNorm statistics) -> heuristic
+    matrices -> B colonies sampled with log-probabilities (one launch) -> NLS / 2-opt costs -> REINFORCE loss with the
+    mixed baseline -> backward (sampler backward + GNN backward kernels) -> gradient clipping -> optimizer step.
+    coords [B,n,2].  Returns (loss, mean sampled cost, mean locally-searched cost) as tensors."""
+    from .autograd import TspBatchSampleFn
+    B, n, _ = coords.shape
+    dev = coords.device
+    net.train()
+    dist, ei, ea = engine.tsp_knn_graph(coords, k_sparse)
+    x = torch.zeros((B, n, 1), device=dev)
+    x[:, 0] = 1.0                                                     # tsp_nls/utils.py:38-44: one-hot of the start node
+    heu = net.forward_batch_train(x, ei, ea)
+    heu_mat = net.reshape_batch(n, ei, heu) + EPS
+    tau = torch.ones((B, n, n), device=dev)
+    paths, log_probs, flags = TspBatchSampleFn.apply(heu_mat, tau, n_ants, 1.0, 1.0, "scan", 2, 0, seed, it)
+    with torch.no_grad():
+        costs = engine.tour_costs(dist, paths)                        # [B, A]
+        tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+        maxt = n // 4                                                 # tsp_nls/aco.py:235,242 (training)
+        if local_search == "nls":
+            h = heu_mat.detach()
+            hdist = (1 / (h / h.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+            tours = engine.nls_(dist, hdist, tours, maxt)
+        else:
+            engine.two_opt_(dist, tours, maxt)
+        costs_ls = engine.tour_costs(dist, tours.permute(0, 2, 1).to(torch.int64).contiguous())
+        cost = (costs_ls - costs_ls.mean(dim=1, keepdim=True)) * W_2OPT + (costs - costs.mean(dim=1, keepdim=True)) * (1 - W_2OPT)
+    # sum over instances of sum_a cost_a * sum_t logp[t,a] / A, averaged over the batch (train.py:35-40)
+    loss = torch.sum(cost.unsqueeze(1) * log_probs) / n_ants / B
+    optimizer.zero_grad()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(parameters=net.parameters(), max_norm=max_norm, norm_type=2)
+    optimizer.step()
+    return loss.detach(), costs.mean(), costs_ls.mean()

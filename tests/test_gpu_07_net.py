@@ -246,6 +246,26 @@ def test_training_step_end_to_end():
     assert bool((costs_2opt <= costs + 1e-4).all())
 
 
+def test_batched_training_step_on_device():
+    """pipeline.train_tsp_nls_batch: tsp_nls/train.py's step for B instances at once; parameters move, the loss is
+    finite, local search only lowers costs.  A few steps at a fixed seed lower the mean sampled cost on held instances."""
+    from deepaco_amd.pipeline import train_tsp_nls_batch
+    from deepaco_amd.tsp_nls.net import Net
+    torch.manual_seed(11)
+    net = Net().to(dev())
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in net.parameters()]
+    coords = torch.rand(6, 30, 2, device=dev())
+    first = None
+    for step in range(12):
+        loss, c, c_ls = train_tsp_nls_batch(net, opt, coords, n_ants=16, k_sparse=8, seed=5, it=step)
+        assert torch.isfinite(loss) and float(c_ls) <= float(c) + 1e-5
+        first = float(c) if first is None else first
+    changed = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, net.parameters()))
+    assert changed > 100
+    assert float(c) < first               # the policy improved on the instances it trains on
+
+
 @pytest.mark.parametrize("name", ["g5_net_tsp_tsp100", "g5_net_tsp_tsp20", "g5_net_tsp_nls_tsp100"])
 def test_batched_graph_construction_matches_reference(name):
     """daco_tsp_knn_graph (one launch for a batch) == the reference's gen_pyg_data on captured instances."""
