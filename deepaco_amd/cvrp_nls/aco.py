@@ -1,12 +1,17 @@
-"""ACO for CVRP with the constructor and sampler surface of the reference's cvrp_nls/aco.py.
+"""ACO for CVRP with the constructor, sampler and local-search surface of the reference's cvrp_nls/aco.py.
 
 The tour construction, costing and pheromone update of cvrp_nls/aco.py:35-272 are the same code
 as cvrp/aco.py (float64 instance data, capacity normalised to 1.0) and run on the same HIP
 kernels here (instance data are cast to float32 on the device).  `sample()` returns
-`(costs, log_probs, paths)` as in cvrp_nls/aco.py:100-104.  The SWAP* local search
-(`swapstar=True`, cvrp_nls/aco.py:106-128,443-448 -> ctypes into the vendored HGS-CVRP C++ via
-/tmp files) is a CPU pointer-chasing solver outside this path's scope:
-requesting it raises NotImplementedError instead of silently skipping it.
+`(costs, log_probs, paths)` as in cvrp_nls/aco.py:100-104.
+
+Local search (`swapstar=True`; cvrp_nls/aco.py:106-128, 443-448).  The reference hands every ant's routes to the
+vendored HGS-CVRP C++ (one thread-pool task per ant, /tmp files, ctypes).  Here `multiple_swap_star` improves all
+selected ants in ONE launch of daco_cvrp_local_search (csrc/daco_cvrp_ls.hip: relocate / swap / intra-route 2-opt, best
+improvement) and keeps the reference's three-stage schedule `neural_swapstar`: search on the distances, `disturb` = 10
+moves on the heuristic-derived matrix, search on the distances again.  HGS's own LocalSearch (randomised neighbourhood
+order, SWAP* reinsertion) is third-party code and is not reproduced move for move; what is guaranteed -- and tested -- is
+a feasible solution that is never worse and a local optimum of the three neighbourhoods.
 """
 import os
 import sys
@@ -18,8 +23,31 @@ try:
 except ImportError:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from deepaco_amd.cvrp.aco import ACO as _CvrpACO
+from deepaco_amd import engine
 
 CAPACITY = 1.0
+
+
+def get_subroutes(route, end_with_zero=True):
+    """cvrp_nls/aco.py:12-20: the non-empty depot-to-depot pieces of a route sequence."""
+    x = torch.nonzero(route == 0).flatten()
+    subroutes = []
+    for i, j in zip(x, x[1:]):
+        if j - i > 1:
+            subroutes.append(route[i:j + 1] if end_with_zero else route[i:j])
+    return subroutes
+
+
+def merge_subroutes(subroutes, length, device):
+    """cvrp_nls/aco.py:22-33: back to one zero-padded sequence of `length` entries."""
+    route = torch.zeros(length, dtype=torch.long, device=device)
+    i = 0
+    for r in subroutes:
+        if len(r) > 2:
+            r = torch.as_tensor(r[:-1], device=device)
+            route[i: i + len(r)] = r
+            i += len(r)
+    return route
 
 
 class ACO(_CvrpACO):
@@ -27,20 +55,69 @@ class ACO(_CvrpACO):
     def __init__(self, distances, demand, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
                  pheromone=None, heuristic=None, min=None, device='cpu', adaptive=False, capacity=CAPACITY,
                  swapstar=False, positions=None, inference=False, *, sampler='scan', seed=None):
-        if swapstar:
-            raise NotImplementedError("SWAP* (HGS-CVRP C++ local search) is outside the rollout hot path; "
-                                      "use swapstar=False")
         super().__init__(distances.float(), demand.float(), n_ants, decay, alpha, beta, elitist, min_max,
                          None if pheromone is None else pheromone.float(),
                          None if heuristic is None else heuristic.float(), min, device, adaptive, float(capacity),
                          sampler=sampler, seed=seed)
-        self.swapstar, self.positions, self.inference = False, positions, inference
+        self.swapstar, self.positions, self.inference = swapstar, positions, inference
+        self._heuristic_dist = None
 
     def sample(self, inference=False):
         paths, log_probs = self.gen_path(require_prob=True)
         costs = self.gen_path_costs(paths)
         return costs, log_probs, paths
 
+    # ------------------------------------------------------------------ cvrp_nls/aco.py:106-112
+    def sample_nls(self):
+        paths, log_probs = self.gen_path(require_prob=True)
+        costs_raw = self.gen_path_costs(paths).detach()
+        paths = self.multiple_swap_star(paths)
+        costs = self.gen_path_costs(paths).detach()
+        return costs, log_probs, costs_raw
+
+    # ------------------------------------------------------------------ cvrp_nls/aco.py:128-132
+    @property
+    def heuristic_dist(self):
+        if self._heuristic_dist is None:
+            heu = self.heuristic.detach().float()
+            self._heuristic_dist = (1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)).contiguous()
+        return self._heuristic_dist
+
+    # ------------------------------------------------------------------ cvrp_nls/aco.py:114-126, 443-448
+    @torch.no_grad()
+    def multiple_swap_star(self, paths, indexes=None, disturb=10):
+        """Improve the ants' solutions (all, or the columns `indexes`) in place and return `paths`
+        ([L, A] int64; a longer buffer is returned if a column does not end with two depots to spare)."""
+        limit = 100000 if self.inference else max(self.problem_size, 50)
+        sel = paths if indexes is None else paths[:, indexes]
+        work = sel.contiguous().unsqueeze(0).clone()
+        dist = self.distances.detach().float().contiguous()
+        for matrix, count in ((dist, limit), (self.heuristic_dist, disturb), (dist, limit)):
+            engine.cvrp_local_search_(matrix, self.demand, self.capacity, work, count)
+        if indexes is None:
+            paths.copy_(work[0])
+        else:
+            paths[:, indexes] = work[0]
+        return paths
+
     @torch.no_grad()
     def run(self, n_iterations, inference=False):
-        return super().run(n_iterations)
+        if not self.swapstar:
+            return super().run(n_iterations)
+        for _ in range(n_iterations):                          # cvrp_nls/aco.py:135-171 (non-adaptive branch)
+            paths = self.gen_path(require_prob=False)
+            costs = self.gen_path_costs(paths)
+            indexes = costs.topk(min(8, self.n_ants), largest=False).indices
+            self.multiple_swap_star(paths, indexes=indexes)
+            costs = self.gen_path_costs(paths)
+            best_cost, best_idx = costs.min(dim=0)
+            if best_cost < self.lowest_cost:
+                self.shortest_path = paths[:, best_idx].clone()
+                self.lowest_cost = best_cost
+                if self.min_max:
+                    max_ = self.problem_size / self.lowest_cost
+                    if self.max is None:
+                        self.pheromone *= max_ / self.pheromone.max()
+                    self.max = max_
+            self.update_pheronome(paths, costs)
+        return self.lowest_cost

@@ -448,6 +448,32 @@ def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False):
     return (tours, sweeps) if want_sweeps else tours
 
 
+def cvrp_local_search_(dist, demand, capacity, paths, max_moves, want_stats=False):
+    """In-place local search on CVRP solutions (cvrp_nls/aco.py:114-126): dist [B,n,n] or [n,n], demand [B,n] or [n],
+    paths [B,Lmax,A] or [Lmax,A] int64 (route sequences as gen_path returns them).  Relocate / swap / intra-route
+    2-opt, best improvement, at most max_moves moves per solution.  Returns paths (and lens, moves [B,A])."""
+    _require_gpu(dist, demand, paths)
+    n = dist.shape[-1]
+    assert paths.dtype == torch.int64
+    p3 = paths if paths.dim() == 3 else paths.unsqueeze(0)
+    assert p3.is_contiguous()
+    B, Lmax, A = p3.shape
+    dist, dbs = _bstride(dist, n)
+    demand = _f32c(demand)
+    if demand.dim() == 1:
+        demand = demand.unsqueeze(0).expand(B, n).contiguous()
+    dev = paths.device
+    with torch.cuda.device(dev):
+        lens = torch.empty((B, A), dtype=torch.int32, device=dev) if want_stats else None
+        moves = torch.empty((B, A), dtype=torch.int32, device=dev) if want_stats else None
+        rc = _lib.lib().daco_cvrp_local_search(_stream(dev), B, n, A, Lmax, dist.data_ptr(), dbs, demand.data_ptr(),
+                                               float(capacity), p3.data_ptr(), int(max_moves),
+                                               lens.data_ptr() if want_stats else None,
+                                               moves.data_ptr() if want_stats else None)
+    _lib.check(rc, "daco_cvrp_local_search")
+    return (paths, lens, moves) if want_stats else paths
+
+
 @torch.no_grad()
 def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20):
     """Batched NLS driver (tsp_nls/aco.py:241-258) fully on the device.

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 113 /* 0.1.12: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 114 /* 0.1.13: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -349,6 +349,25 @@ int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const 
                             const int32_t *dst, const int32_t *rowptr, const float *edge_attr, const float *params,
                             const float *heu, const float *grad_heu, float *grad_params, void *workspace,
                             size_t workspace_bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_cvrp_local_search -- replaces ACO.multiple_swap_star's per-ant CPU tasks
+ *   cvrp_nls/aco.py:114-126 (one swapstar() call per ant through a thread pool), cvrp_nls/swapstar.py:240-271
+ *   (/tmp-file hand-over) and the entry it calls in the vendored HGS-CVRP (Program/C_Interface.cpp:128-172).
+ * A deterministic best-improvement search over relocate / swap / intra-route 2-opt moves (specified in
+ * csrc/daco_cvrp_ls.hip, restated in oracle/cvrp_ls.py); HGS's own LocalSearch (third-party, randomised neighbourhood
+ * order) is NOT reproduced move for move: results are feasible, never worse, and local optima of these neighbourhoods.
+ *   dist     [B][n][n] f32 (dist_bstride elements between instances, 0 = shared); need not be symmetric
+ *   demand   [B][n] f32, demand[.][0] = 0;  capacity: vehicle capacity in the same unit
+ *   paths    in/out [B][Lmax][A] int64: column (b, a) is ant a's route sequence 0 a b 0 c d 0 ... zero-padded
+ *            (the layout of ACO.gen_path, cvrp/aco.py:138-165); rewritten in place without empty routes
+ *   max_moves  moves applied at most per solution (the reference's `count`/`limit`)
+ *   lens     out [B][A] int32 or NULL: entries used by each solution (including the closing depot)
+ *   moves    out [B][A] int32 or NULL: moves applied
+ */
+int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lmax, const float *dist, long dist_bstride,
+                           const float *demand, float capacity, int64_t *paths, int max_moves, int32_t *lens,
+                           int32_t *moves);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_tsp_knn_graph -- replaces gen_distance_matrix + gen_pyg_data for a batch of instances
