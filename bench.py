@@ -285,7 +285,7 @@ def extra_configs(dev, headline_colony):
     tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _, sweeps = engine.two_opt_(col.distances, tours, n // 4, want_sweeps=True)
+    _, sweeps = engine.two_opt_(col.distances, tours, n // 4, want_sweeps=True, dist_t="symmetric")
     torch.cuda.synchronize()
     t2 = time.perf_counter() - t0
     nsw = float(sweeps.sum())

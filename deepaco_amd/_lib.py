@@ -49,11 +49,11 @@ SIGNATURES = {
     "daco_sibling_backward": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _l, _f, _vp, _i, _vp, _vp,
                                    _vp, _vp, _vp]),
     "daco_tsp_knn_graph": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
-    "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp]),
 }
 
 
-ABI_VERSION = 114          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 115          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

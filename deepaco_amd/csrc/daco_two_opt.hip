@@ -298,11 +298,239 @@ two_opt_incr_kernel(int n, int T, const float *dist, long dist_bs, uint16_t *tou
   if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = (int32_t)it;
 }
 
+// ------------------------------------------------------------------ incremental sweeps, row traffic made explicit
+// rocprofv3 counters of two_opt_incr_kernel on config 3 (profiles/r02_pmc_2opt_incr_v1.txt): 12 L2 line requests per
+// gather instruction, 23 TB/s out of L2 -- every 64-lane gather d[t[i-1]][t[j]] pulls most of a 2 KB matrix row
+// through the 32 KB L1 for 256 useful bytes, and the patch phase (rows i < p, columns j in [p-1, q]) touches a
+// different matrix row for every tour row.  Same algorithm and arithmetic as two_opt_incr_kernel, other data movement:
+//   * block rows i in [p, q+1] (contiguous): each wave owns a run of them and keeps d[t[i-1]][.] and d[t[i]][.] in LDS,
+//     one coalesced 2 KB copy per new row (the row gathered from as d[t[i]][.] is the d[t[i-1]][.] of the next i);
+//     both gathers of a pair are LDS reads;
+//   * scattered rows recomputed in full (cached minimiser inside the changed range): the same, two copies per row;
+//   * patch phase: ONE LANE PER TOUR ROW, lanes walk the changed columns j together and read
+//     d[t[i-1]][t[j]] as dT[t[j]][t[i-1]] (dT = the transposed matrix, or d itself when it is symmetric): all 64 lanes
+//     of a gather read the SAME matrix row t[j], and only the q-p+3 rows of the changed segment are touched per
+//     sweep instead of ~p different ones.  Every lane keeps its own running minimum (j ascends, strict <), so the
+//     phase needs no cross-lane reduction.
+template <int W>
+__global__ void __launch_bounds__(64 * W)
+two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long dist_bs, uint16_t *tours, long max_iterations,
+                     int32_t *sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int np4 = (n + 3) / 4 * 4;
+  int2 *pe = reinterpret_cast<int2 *>(smem);                       // tour records (see two_opt_kernel)
+  uint64_t *rb = reinterpret_cast<uint64_t *>(pe + np4);           // per-row minimum key, rows 1..n-2
+  int *full_list = reinterpret_cast<int *>(rb + np4);              // scattered rows to recompute
+  int *part_list = full_list + np4;                                // rows to patch in [p-1, q]
+  uint64_t *red = reinterpret_cast<uint64_t *>(part_list + np4);   // W reduction slots (+ row id)
+  int *cnt = reinterpret_cast<int *>(red + 2 * W);                 // [0] full count, [1] partial count
+  float *rows = reinterpret_cast<float *>(cnt + 8);                // W x 2 x np4 staged matrix rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * W;
+  const int b = blockIdx.x / T;
+  const float *d = dist + (size_t)b * dist_bs;
+  const float *dT = distT ? distT + (size_t)b * dist_bs : nullptr;
+  uint16_t *tour = tours + (size_t)blockIdx.x * n;
+  float *rowA = rows + (size_t)wave * 2 * np4, *rowB = rowA + np4;
+
+  for (int k = tid; k < n; k += NT) {
+    const int u = tour[k], v = tour[k + 1 < n ? k + 1 : 0];
+    pe[k] = make_int2(u | (v << 16), __float_as_int(d[(size_t)u * n + v]));
+  }
+  __syncthreads();
+  auto stage = [&](float *dst, int node) {                // coalesced copy of row d[node][0..n) into the wave's slot
+    const float *src = d + (size_t)node * n;
+    for (int k = lane; k < n; k += 64) dst[k] = src[k];
+  };
+  // minimum of row i over j in (i, n) with both distance rows in LDS; lanes stride j
+  auto row_min_staged = [&](int i, const float *gA, const float *gB) {
+    const int2 ri = pe[i - 1];
+    const int na = ri.x & 0xFFFF, nb = (unsigned)ri.x >> 16;
+    const float eab = __int_as_float(ri.y);
+    float bk = __builtin_inff();
+    int bj = 0x7fffffff;
+    for (int j = i + 1 + lane; j < n; j += 64) {
+      const int2 rec = pe[j];
+      const int nc = rec.x & 0xFFFF, nd = (unsigned)rec.x >> 16;
+      float change = gA[nc] + gB[nd];
+      change = change - eab;
+      change = change - __int_as_float(rec.y);
+      if (na == nc || nd == nb) change = __builtin_inff();
+      if (change < bk) { bk = change; bj = j; }
+    }
+    const KeyIdx w = wave_arg<false>(bk, bj);
+    if (lane == 0) rb[i] = w.idx == 0x7fffffff ? KEY_NONE : make_key(w.key, w.idx);
+  };
+
+  int p = 1, q = n - 1;                                   // "everything changed" for the first sweep
+  bool first = true;
+  long it = 0;
+  while (it < max_iterations) {
+    // ---- classify the rows below the block: recompute in full (minimiser inside the changed range) or patch
+    const int blo = first ? 1 : p, bhi = first ? n - 1 : min(q + 2, n - 1);       // block rows [blo, bhi)
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    if (!first)
+      for (int i = 1 + tid; i < p; i += NT) {
+        const uint64_t key = rb[i];
+        const int jb = (int)(uint32_t)key;
+        if (key != KEY_NONE && jb >= p - 1 && jb <= q) full_list[atomicAdd(&cnt[0], 1)] = i;
+        else part_list[atomicAdd(&cnt[1], 1)] = i;
+      }
+    __syncthreads();
+    const int nfull = cnt[0], npart = cnt[1];
+    // ---- block rows: each wave a contiguous run with (about) the same number of pairs; rolling rows in LDS
+    {
+      const int R = bhi - blo;
+      int lo = blo, hi = bhi;
+      if (W > 1 && R > 0) {
+        // pairs of row i = n-1-i; cumulative pairs from blo: S(i) = sum_{r=blo}^{i-1} (n-1-r); split S into W equal parts
+        const float tot = (float)R * (float)(n - 1 - blo) - 0.5f * (float)R * (float)(R - 1);
+        auto bound = [&](int k) {                          // first row whose cumulative pair count reaches k/W of the total
+          if (k <= 0) return blo;
+          if (k >= W) return bhi;
+          const float target = tot * (float)k / (float)W, a = (float)(n - 1 - blo) + 0.5f;
+          float x = a - sqrtf(fmaxf(a * a - 2.0f * target, 0.0f));          // solves x*a' - x^2/2 = target
+          int r = blo + (int)x;
+          return max(blo, min(r, bhi));
+        };
+        lo = bound(wave); hi = bound(wave + 1);
+      }
+      if (lo < hi) {
+        if (n <= 512) {
+          // the next row travels through registers while the current one is evaluated out of LDS (the chain of a
+          // sweep is a sequence of L2 round trips: overlap them with the LDS work instead of adding them up)
+          float nx[8];
+          auto fetch = [&](int node) {
+            const float *src = d + (size_t)node * n;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { const int k = lane + 64 * m; nx[m] = k < n ? src[k] : 0.0f; }
+          };
+          auto put = [&](float *dst) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { const int k = lane + 64 * m; if (k < n) dst[k] = nx[m]; }
+          };
+          fetch(pe[lo - 1].x & 0xFFFF);
+          put(rowB);
+          fetch((unsigned)pe[lo - 1].x >> 16);
+          for (int i = lo; i < hi; ++i) {
+            float *tmp = rowA; rowA = rowB; rowB = tmp;
+            put(rowB);                                      // d[t[i]][.]
+            if (i + 1 < hi) fetch((unsigned)pe[i].x >> 16); // d[t[i+1]][.], in flight during this row's pairs
+            row_min_staged(i, rowA, rowB);
+          }
+        } else {
+          stage(rowB, pe[lo - 1].x & 0xFFFF);             // becomes rowA of the first row
+          for (int i = lo; i < hi; ++i) {
+            float *tmp = rowA; rowA = rowB; rowB = tmp;
+            stage(rowB, (unsigned)pe[i - 1].x >> 16);
+            row_min_staged(i, rowA, rowB);
+          }
+        }
+      }
+    }
+    // ---- scattered full rows: one wave per row, both rows staged
+    for (int r = wave; r < nfull; r += W) {
+      const int i = full_list[r];
+      const int2 ri = pe[i - 1];
+      stage(rowA, ri.x & 0xFFFF);
+      stage(rowB, (unsigned)ri.x >> 16);
+      row_min_staged(i, rowA, rowB);
+    }
+    // ---- patch phase: one lane per row, all lanes walk j = p-1 .. q together; with the transposed matrix the two
+    // values of a pair are dT[t[j]][t[i-1]] and dT[t[j+1]][t[i]], i.e. all 64 lanes of a gather read one matrix row.
+    // (Copying the segment's rows into LDS first was tried: the extra barriers and the load -> barrier -> compute
+    // chain per chunk made the sweep 1.6x slower; a sweep is bound by its chain of L2 round trips, not by bytes.)
+    for (int r = tid; r < ((npart + NT - 1) / NT) * NT; r += NT) {
+      const bool act = r < npart;
+      const int i = act ? part_list[r] : 1;
+      const int2 ri = pe[i - 1];
+      const int na = ri.x & 0xFFFF, nb = (unsigned)ri.x >> 16;
+      const float eab = __int_as_float(ri.y);
+      float bk = __builtin_inff();
+      int bj = 0x7fffffff;
+      constexpr int UN = 8;                                // columns per batch: 2 * UN gathers in flight per lane
+      for (int j0 = p - 1; j0 <= q; j0 += UN) {
+        int2 rec[UN];
+        float A[UN], Bv[UN];
+#pragma unroll
+        for (int m = 0; m < UN; ++m) {
+          rec[m] = pe[min(j0 + m, q)];                     // (uniform address: one LDS broadcast)
+          const int nc = rec[m].x & 0xFFFF, nd = (unsigned)rec[m].x >> 16;
+          if (dT) { A[m] = dT[(size_t)nc * n + na]; Bv[m] = dT[(size_t)nd * n + nb]; }
+          else { A[m] = d[(size_t)na * n + nc]; Bv[m] = d[(size_t)nb * n + nd]; }
+        }
+#pragma unroll
+        for (int m = 0; m < UN; ++m) {
+          const int j = j0 + m;
+          const int nc = rec[m].x & 0xFFFF, nd = (unsigned)rec[m].x >> 16;
+          float change = A[m] + Bv[m];
+          change = change - eab;
+          change = change - __int_as_float(rec[m].y);
+          if (j > q || j <= i || na == nc || nd == nb) change = __builtin_inff();
+          if (change < bk) { bk = change; bj = j; }
+        }
+      }
+      if (act && bj != 0x7fffffff) {
+        const uint64_t k = make_key(bk, bj);
+        if (k < rb[i]) rb[i] = k;
+      }
+    }
+    __syncthreads();
+    // ---- global minimum over the rows: (key's change, row i) lexicographic, then j from the key
+    uint64_t best = KEY_NONE;
+    int bi = 0x7fffffff;
+    for (int i = 1 + tid; i < n - 1; i += NT) {
+      const uint64_t k = rb[i];
+      if (k != KEY_NONE && (k >> 32) < (best >> 32)) { best = k; bi = i; }   // rows ascend: first minimum kept
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      const uint64_t ok = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if ((ok >> 32) < (best >> 32) || ((ok >> 32) == (best >> 32) && oi < bi)) { best = ok; bi = oi; }
+    }
+    if (lane == 0) { red[2 * wave] = best; red[2 * wave + 1] = (uint64_t)(uint32_t)bi; }
+    __syncthreads();
+    best = red[0];
+    bi = (int)red[1];
+#pragma unroll
+    for (int w = 1; w < W; ++w) {
+      const uint64_t ok = red[2 * w];
+      const int oi = (int)red[2 * w + 1];
+      if ((ok >> 32) < (best >> 32) || ((ok >> 32) == (best >> 32) && oi < bi)) { best = ok; bi = oi; }
+    }
+    ++it;
+    const uint32_t o32 = (uint32_t)(best >> 32);
+    const float gk = best == KEY_NONE ? 0.0f : __uint_as_float((o32 >> 31) ? (o32 ^ 0x80000000u) : ~o32);
+    if (!(gk < 0.0f) || !((double)gk < -1e-6)) break;
+    p = bi;
+    q = (int)(uint32_t)best;
+    first = false;
+    __syncthreads();                                      // everyone has read red[] and the records
+    const int half = (q - p + 1) >> 1;
+    for (int k = tid; k < half; k += NT) {
+      const int x = pe[p + k].x, y = pe[q - k].x;
+      pe[p + k].x = (x & 0xFFFF0000) | (y & 0xFFFF);
+      pe[q - k].x = (y & 0xFFFF0000) | (x & 0xFFFF);
+    }
+    __syncthreads();
+    for (int k = p - 1 + tid; k <= q; k += NT) {
+      const int u = pe[k].x & 0xFFFF;
+      const int v = pe[k + 1 < n ? k + 1 : 0].x & 0xFFFF;
+      const float len = d[(size_t)u * n + v];
+      pe[k].y = __float_as_int(len);
+      reinterpret_cast<unsigned short *>(&pe[k].x)[1] = (unsigned short)v;
+    }
+    __syncthreads();
+  }
+  for (int k = tid; k < n; k += NT) tour[k] = (uint16_t)(pe[k].x & 0xFFFF);
+  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = (int32_t)it;
+}
+
 }  // namespace daco
 
 using namespace daco;
 
-extern "C" int daco_two_opt(void *stream, int B, int T, int n, const float *dist, long dist_bstride,
+extern "C" int daco_two_opt(void *stream, int B, int T, int n, const float *dist, const float *dist_T, long dist_bstride,
                             uint16_t *tours, long max_iterations, int32_t *sweeps) {
   if (B <= 0 || T <= 0 || n < 4 || !dist || !tours || max_iterations < 0) {
     set_error("daco_two_opt: bad argument (B=%d T=%d n=%d)", B, T, n);
@@ -317,11 +545,15 @@ extern "C" int daco_two_opt(void *stream, int B, int T, int n, const float *dist
   // default: the incremental kernel (16 + log2(waves per tour)); the full-sweep kernels (variant = waves per
   // tour * 2 + staged) stay selectable with DACO_TWO_OPT_VARIANT for tuning / cross-checks.  Measured on the
   // NLS workload (tools/measure_configs.py c3:n): n=100 25 vs 45 ms, n=200 62 vs 189 ms, n=500 507 vs 1985 ms.
-  int variant = n <= 128 ? 17 : 18;
+  // 32: two_opt_incr2_kernel (explicit row traffic; dist_T lets its patch phase read matrix rows of the changed segment)
+  int variant = n <= 128 ? 17 : 32;
   if (const char *ev = getenv("DACO_TWO_OPT_VARIANT")) variant = atoi(ev);
 #define DACO_2OPT(W, ST) hipLaunchKernelGGL((two_opt_kernel<W, ST>), dim3(B * T), dim3(64 * W), lds_bytes(W, ST), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps)
   auto lds_incr = [&](int W) { return (2 * np4 + 2 * np4 + np4 + np4 + 4 * W + 2 + 6) * sizeof(int); };
+  auto lds_incr2 = [&](int W) { return lds_incr(W) + 8 * sizeof(int) + (size_t)W * 2 * np4 * sizeof(float); };
   switch (variant) {
+    case 32: hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds_incr2(4), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps); break;
+    case 33: hipLaunchKernelGGL((two_opt_incr2_kernel<2>), dim3(B * T), dim3(128), lds_incr2(2), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps); break;
     case 16: hipLaunchKernelGGL((two_opt_incr_kernel<1>), dim3(B * T), dim3(64), lds_incr(1), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
     case 17: hipLaunchKernelGGL((two_opt_incr_kernel<2>), dim3(B * T), dim3(128), lds_incr(2), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
     case 18: hipLaunchKernelGGL((two_opt_incr_kernel<4>), dim3(B * T), dim3(256), lds_incr(4), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;

@@ -430,19 +430,29 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
     return tau
 
 
-def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False):
+def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None):
     """In-place batched 2-opt (tsp_nls/two_opt.py:41-49).  dist [B,n,n] or [n,n];
-    tours [B,T,n] or [T,n] int16/uint16 storage (values < 65536), one ROW per tour."""
+    tours [B,T,n] or [T,n] int16/uint16 storage (values < 65536), one ROW per tour.
+    dist_t: the transposed matrices (same shape as dist), "symmetric" if dist equals its transpose, or None: only
+    changes how the kernel reads the matrix (see include/deepaco_hip.h), never the result."""
     _require_gpu(dist, tours)
     n = dist.shape[-1]
+    if isinstance(dist_t, str):
+        assert dist_t == "symmetric"
+        dist_t = dist
     assert tours.dtype in (torch.int16, torch.uint16) and tours.is_contiguous()
     t3 = tours if tours.dim() == 3 else tours.unsqueeze(0)
     B, T, _ = t3.shape
+    same = dist_t is dist
     dist, dbs = _bstride(dist, n)
+    if dist_t is not None:
+        dist_t = dist if same else _bstride(dist_t, n)[0]
+        assert dist_t.shape == dist.shape
     dev = tours.device
     with torch.cuda.device(dev):
         sweeps = torch.empty((B, T), dtype=torch.int32, device=dev) if want_sweeps else None
-        rc = _lib.lib().daco_two_opt(_stream(dev), B, T, n, dist.data_ptr(), dbs, t3.data_ptr(),
+        rc = _lib.lib().daco_two_opt(_stream(dev), B, T, n, dist.data_ptr(),
+                                     dist_t.data_ptr() if dist_t is not None else None, dbs, t3.data_ptr(),
                                      int(max_iterations), sweeps.data_ptr() if want_sweeps else None)
     _lib.check(rc, "daco_two_opt")
     return (tours, sweeps) if want_sweeps else tours
@@ -475,22 +485,34 @@ def cvrp_local_search_(dist, demand, capacity, paths, max_moves, want_stats=Fals
 
 
 @torch.no_grad()
-def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20):
+def transposed_for_two_opt(m):
+    """What two_opt_'s dist_t wants for matrix m: "symmetric" if m equals its transpose (one device comparison),
+    else a transposed contiguous copy."""
+    mt = m.transpose(-1, -2)
+    return "symmetric" if bool(torch.equal(m, mt)) else mt.contiguous()
+
+
+def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuristic_dist_t=None):
     """Batched NLS driver (tsp_nls/aco.py:241-258) fully on the device.
-    dist, heuristic_dist [B,n,n]; tours [B,T,n] int16 (one row per tour).  Returns improved tours."""
+    dist, heuristic_dist [B,n,n]; tours [B,T,n] int16 (one row per tour).  Returns improved tours.
+    dist_t / heuristic_dist_t: see two_opt_ (callers that run many iterations pass them once)."""
     B, T, n = tours.shape
+    if dist_t is None:
+        dist_t = transposed_for_two_opt(dist)
+    if heuristic_dist_t is None:
+        heuristic_dist_t = transposed_for_two_opt(heuristic_dist)
 
     def lengths(t):
         return tour_costs(dist, t.permute(0, 2, 1).to(torch.int64).contiguous())
 
     best = tours.clone().contiguous()
-    two_opt_(dist, best, maxt)
+    two_opt_(dist, best, maxt, dist_t=dist_t)
     best_costs = lengths(best)
     new = best
     for _ in range(T_nls):
         pert = new.clone()
-        two_opt_(heuristic_dist, pert, T_p)
-        two_opt_(dist, pert, maxt)
+        two_opt_(heuristic_dist, pert, T_p, dist_t=heuristic_dist_t)
+        two_opt_(dist, pert, maxt, dist_t=dist_t)
         new = pert
         new_costs = lengths(new)
         improved = new_costs < best_costs
@@ -534,6 +556,8 @@ class BatchedTSP:
         self.local_search = local_search          # tsp_nls/aco.py: applied to the tours before costing
         self.inference = inference                # tsp_nls/aco.py:235,242: 2-opt sweeps n//4 (training) or 10000 (inference)
         self._hdist = None
+        self._hdist_t = None
+        self._dist_t = None
         self._cmin = None
 
     def _heuristic_dist(self):
@@ -563,10 +587,15 @@ class BatchedTSP:
         if self.local_search is not None:
             tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
             maxt = 10000 if self.inference else self.n // 4
+            if self._dist_t is None:
+                self._dist_t = transposed_for_two_opt(self.distances)
             if self.local_search == "2opt":
-                two_opt_(self.distances, tours, maxt)
+                two_opt_(self.distances, tours, maxt, dist_t=self._dist_t)
             else:
-                tours = nls_(self.distances, self._heuristic_dist(), tours, maxt)
+                hd = self._heuristic_dist()
+                if self._hdist_t is None:
+                    self._hdist_t = transposed_for_two_opt(hd)
+                tours = nls_(self.distances, hd, tours, maxt, dist_t=self._dist_t, heuristic_dist_t=self._hdist_t)
             paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
             costs, nbr = tour_costs(self.distances, paths), None
         # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)

@@ -71,9 +71,9 @@ def train_tsp_nls_batch(net, optimizer, coords, n_ants, k_sparse, seed=0, it=0, 
         if local_search == "nls":
             h = heu_mat.detach()
             hdist = (1 / (h / h.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
-            tours = engine.nls_(dist, hdist, tours, maxt)
+            tours = engine.nls_(dist, hdist, tours, maxt, dist_t="symmetric")
         else:
-            engine.two_opt_(dist, tours, maxt)
+            engine.two_opt_(dist, tours, maxt, dist_t="symmetric")
         costs_ls = engine.tour_costs(dist, tours.permute(0, 2, 1).to(torch.int64).contiguous())
         cost = (costs_ls - costs_ls.mean(dim=1, keepdim=True)) * W_2OPT + (costs - costs.mean(dim=1, keepdim=True)) * (1 - W_2OPT)
     # sum over instances of sum_a cost_a * sum_t logp[t,a] / A, averaged over the batch (train.py:35-40)

@@ -123,6 +123,16 @@ class ACO(_TspACO):
             self._heuristic_dist = (1 / (h / h.max(-1, keepdim=True).values + 1e-5)).contiguous()
         return self._heuristic_dist
 
+    def _transposed(self, name):
+        """engine.two_opt_'s dist_t for self.<name>, computed once per matrix object ("symmetric" or a transposed copy)."""
+        m = getattr(self, name).detach().to(torch.float32)
+        cache = self.__dict__.setdefault("_t_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] is not getattr(self, name):
+            hit = (getattr(self, name), engine.transposed_for_two_opt(m))
+            cache[name] = hit
+        return hit[1]
+
     def _tours(self, paths):
         return paths.T.contiguous().to(torch.int16)
 
@@ -135,20 +145,21 @@ class ACO(_TspACO):
     @torch.no_grad()
     def two_opt(self, paths, inference=False):
         maxt = 10000 if inference else self.problem_size // 4
-        best = two_opt_device(self.distances, self._tours(paths), maxt)
+        best = two_opt_device(self.distances, self._tours(paths), maxt, self._transposed("distances"))
         return self._paths(best)
 
     @torch.no_grad()
     def nls(self, paths, inference=False, T_nls=10, T_p=20):
         maxt = 10000 if inference else self.problem_size // 4
         dist = self.distances.to(torch.float32)
-        best_paths = two_opt_device(dist, self._tours(paths), maxt)
+        dist_t, hd_t = self._transposed("distances"), self._transposed("heuristic_dist")
+        best_paths = two_opt_device(dist, self._tours(paths), maxt, dist_t)
         best_costs = self._tour_costs(best_paths)
         new_paths = best_paths
 
         for _ in range(T_nls):
-            perturbed_paths = two_opt_device(self.heuristic_dist, new_paths, T_p)
-            new_paths = two_opt_device(dist, perturbed_paths, maxt)
+            perturbed_paths = two_opt_device(self.heuristic_dist, new_paths, T_p, hd_t)
+            new_paths = two_opt_device(dist, perturbed_paths, maxt, dist_t)
             new_costs = self._tour_costs(new_paths)
 
             improved = new_costs < best_costs
