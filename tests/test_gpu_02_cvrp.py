@@ -204,6 +204,9 @@ def test_cvrp_nls_surface_float64_data():
                 assert v not in seen
                 seen.add(int(v))
         assert len(seen) == 40
-    with pytest.raises(NotImplementedError):
-        ACO(d[0].to(dev()), dem.to(dev()), swapstar=True, positions=torch.zeros(41, 2))
     assert float(aco.run(3)) <= float(costs.max())
+    # swapstar=True: the local search runs on the device (tests/test_gpu_09_cvrp_ls.py); float64 instance data are cast
+    ls = ACO(d[0].double().to(dev()), dem.to(dev()), n_ants=16, device="cuda:0", capacity=cap, seed=2, swapstar=True,
+             positions=torch.zeros(41, 2))
+    c_ls, _, c_raw = ls.sample_nls()
+    assert bool((c_ls <= c_raw + 1e-5).all()) and bool((c_ls < c_raw - 1e-4).any())

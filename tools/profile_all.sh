@@ -1,23 +1,41 @@
 #!/bin/bash
-# Regenerates the round's evidence under gpurun_out/<tag>/ in one GPU session (copy what should be
-# judged into profiles/).  usage (on the GPU box, from the repo root):  bash tools/profile_all.sh r02
-#   bench line (+cpu leg), rocprofv3 kernel stats of the same command, PMC passes (HBM bytes, L2 hit rate,
-#   wave-time split), end-to-end configs, layout sweep, L2 row-stream ceiling, GNN batch profile.
+# Regenerates the round's evidence under gpurun_out/<tag>/ in one GPU session (copy what should be judged into
+# profiles/).  usage (on the GPU box, from the repo root):  bash tools/profile_all.sh r02
 set -u
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# 1. 2-opt counters first (bench.py's config-3 roofline reads profiles/two_opt_l2.json)
+(cd $R && bash tools/pmc_generic.sh gpurun_out/$TAG/pmc2opt 2opt -- python tools/run_two_opt_c3.py 16 > /dev/null)
+python $R/tools/pmc_summary.py $OUT/pmc2opt two_opt > $OUT/pmc_2opt_incr2.txt
+python $R/tools/run_two_opt_c3.py 16 2>/dev/null | grep "^{" > $OUT/two_opt_c3_b16.json
+python3 - <<EOF
+import json, re
+txt = open("$OUT/pmc_2opt_incr2.txt").read()
+m = re.search(r"TCP_TCC_READ_REQ_sum\s+([0-9.e+]+)", txt)
+run = json.load(open("$OUT/two_opt_c3_b16.json"))
+if m:
+    json.dump({"l2_read_bytes_per_sweep": float(m.group(1)) * 128.0 / run["sweeps"],
+               "source": "profiles/r02_pmc_2opt_incr2.txt: TCP_TCC_READ_REQ_sum x 128 B / sweeps of tools/run_two_opt_c3.py 16 "
+                         "(rocprofv3 --pmc, mean over the warm-up and the measured launch: both run the same sweeps)"},
+              open("$R/profiles/two_opt_l2.json", "w"), indent=1)
+EOF
+# 2. the bench line, its kernel trace, its counters
 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python $R/bench.py --no-cpu > $OUT/bench_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python $R/bench.py --no-cpu --no-extras --min-seconds 0 > $OUT/bench_profiled.log 2>&1
 cp $OUT/stats/p_kernel_stats.csv $OUT/kernel_stats_bench_default.csv
-(cd $R && bash tools/pmc_pass.sh gpurun_out/$TAG/pmc final -- > /dev/null && python tools/pmc_summary.py gpurun_out/$TAG/pmc daco > $OUT/pmc_summary.txt)
-python $R/bench.py --no-cpu --batch 1 --steps 50 --warmup 5 2>/dev/null | grep "^{" > $OUT/bench_b1.json
-python $R/tools/measure_configs.py headline c2 c3 c4 gnn 2>/dev/null | grep "^{" > $OUT/configs_end_to_end.jsonl
-python $R/tools/sweep_layouts.py 2>/dev/null | grep "^{" > $OUT/sweep_layouts.jsonl
-if [ ! -x $R/tools/l2_row_stream_bench ]; then /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $R/tools/l2_row_stream_bench.hip -o $R/tools/l2_row_stream_bench 2>/dev/null; fi
-for m in 0 1 4; do $R/tools/l2_row_stream_bench $m | tail -1; done > $OUT/l2_row_stream.txt
+(cd $R && bash tools/pmc_pass.sh gpurun_out/$TAG/pmc final -- --no-extras --min-seconds 0 > /dev/null && python tools/pmc_summary.py gpurun_out/$TAG/pmc daco > $OUT/pmc_summary.txt)
+python $R/bench.py --no-cpu --no-extras --min-seconds 0 --batch 1 --steps 50 --warmup 5 2>/dev/null | grep "^{" > $OUT/bench_b1.json
+# 3. multi-rank self-launch (two ranks on this one GPU, gloo rendezvous)
+python $R/bench.py --gpus 2 --dist-backend gloo --force-device 0 --no-cpu --no-extras --min-seconds 0 --batch 32 2>/dev/null | grep "^{" > $OUT/bench_2ranks_one_gpu.json
+# 4. training step: kernel list (no library GEMM) and timing
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o p -- python $R/tools/run_train_step.py 5 > $OUT/train_step.log 2>&1
+cp $OUT/train_stats/p_kernel_stats.csv $OUT/kernel_stats_train_step.csv
+# 5. GNN batch inference profile, shapes microbenchmarks
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gnn_stats -o p -- python $R/tools/run_gnn_batch.py > /dev/null 2>&1
 cp $OUT/gnn_stats/p_kernel_stats.csv $OUT/kernel_stats_gnn_batch64_n500.csv
-tail -1 $OUT/bench_default.json | cut -c1-240
+$R/tools/l2_bw_shapes 64 0 > $OUT/l2_bw_shapes.txt 2>&1
+$R/tools/scan32_ablate > $OUT/scan32_ablate.txt 2>&1
+tail -1 $OUT/bench_default.json | cut -c1-300
