@@ -535,6 +535,25 @@ inline int ld_alloc(int n) {
 }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- shared by the several-ants-per-wavefront kernels (daco_tsp_scan32.hip, daco_scan16.hip)
+// number of j in 0..NJ-1 with run[j] < t for a nondecreasing run[] (binary search written as selects: 5 compares,
+// 11 v_cndmask, no dynamic register index); entries past NJ are +inf and fold away at compile time
+template <int NJ>
+__device__ inline int count_below(const float (&run)[16], float t) {
+  auto R = [&](int j) { return j < NJ ? run[j] : __builtin_inff(); };
+  const bool b3 = R(7) < t;
+  const bool b2 = (b3 ? R(11) : R(3)) < t;
+  const float lo = b2 ? R(5) : R(1), hi = b2 ? R(13) : R(9);
+  const bool b1 = (b3 ? hi : lo) < t;
+  const float e0 = b1 ? R(2) : R(0), e1 = b1 ? R(6) : R(4), e2 = b1 ? R(10) : R(8), e3 = b1 ? R(14) : R(12);
+  const float f0 = b2 ? e1 : e0, f1 = b2 ? e3 : e2;
+  const bool b0 = (b3 ? f1 : f0) < t;
+  // (the four probes leave element 15 untested: it is below t only if all sixteen are)
+  return ((b3 ? 8 : 0) | (b2 ? 4 : 0) | (b1 ? 2 : 0) | (b0 ? 1 : 0)) + ((NJ == 16 && run[15] < t) ? 1 : 0);
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 // layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to
 // DACO_SCAN16_MAX_N nodes, two up to DACO_SCAN32_MAX_N, one above (the oracle restates the rule)
 constexpr int DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;

@@ -47,24 +47,6 @@ __device__ inline float half_bcast_last(float x) {
 }
 __device__ inline uint32_t lowest_bit(uint32_t x) { return x & (0u - x); }
 
-// number of j in 0..NJ-1 with run[j] < t for a nondecreasing run[] (binary search written as selects: 5 compares,
-// 11 v_cndmask, no dynamic register index); entries past NJ are +inf and fold away at compile time
-template <int NJ>
-__device__ inline int count_below(const float (&run)[16], float t) {
-  auto R = [&](int j) { return j < NJ ? run[j] : __builtin_inff(); };
-  const bool b3 = R(7) < t;
-  const bool b2 = (b3 ? R(11) : R(3)) < t;
-  const float lo = b2 ? R(5) : R(1), hi = b2 ? R(13) : R(9);
-  const bool b1 = (b3 ? hi : lo) < t;
-  const float e0 = b1 ? R(2) : R(0), e1 = b1 ? R(6) : R(4), e2 = b1 ? R(10) : R(8), e3 = b1 ? R(14) : R(12);
-  const float f0 = b2 ? e1 : e0, f1 = b2 ? e3 : e2;
-  const bool b0 = (b3 ? f1 : f0) < t;
-  // (the four probes leave element 15 untested: it is below t only if all sixteen are)
-  return ((b3 ? 8 : 0) | (b2 ? 4 : 0) | (b1 ? 2 : 0) | (b0 ? 1 : 0)) + ((NJ == 16 && run[15] < t) ? 1 : 0);
-}
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 // What a step costs was measured piece by piece (tools/scan32_ablate.hip, profiles/r02_scan32_ablation.txt): the
 // row stream itself runs at the L2 ceiling, and everything that made the first version 1.9x slower than that was
 // per-step small traffic -- an i64 path store, a 4-byte distance gather and a 4-byte neighbour-table store per ant

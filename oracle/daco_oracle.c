@@ -194,19 +194,17 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  * per wavefront, n <= 256); vec = 4 below 64 lanes:
  *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
  *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
- *              (lanes = 16: slots v = 0,2 and v = 1,3 accumulate separately and are added at the
- *               end; lanes = 32: the scan is Kogge-Stone in rows of 16, then lanes 16..31 add lane 15)
+ *              (Kogge-Stone in rows of 16; lanes = 32: lanes 16..31 then add lane 15; lanes = 64: rows 1, 3 add
+ *               the row before, then lanes 32..63 add lane 31)
  *   S = incl[lanes-1];  r = max(u * S, denorm_min)
  *     u = component ((t>>lg)&3) of Philox(ctr=(((t>>(lg+2))<<lg) + (t&(lanes-1)), gid, iter, STREAM_SCAN)),
  *     lg = log2(lanes)
  *   L = first lane with incl[L] >= r and part[L] > 0
  *   inside lane L: thr = r - incl[L-1] (incl[-1] = 0);
- *     lanes = 64, 32: walk its candidates in (c,v) order with the lane's own running sum (from +0.0f,
- *       closed candidates add +0.0f); pick the first whose running sum >= thr, else the last open
- *       candidate with p > 0 of the lane (the 32-lane kernel finds it by binary search over the
- *       running sums it keeps in registers);
- *     lanes = 16: the lane's candidate slots j = c*vec+v are scanned across lanes like level 1:
- *       first j with scan[j] >= thr and p_j > 0, else the last j with p_j > 0. */
+ *     walk its candidates in (c,v) order with the lane's own running sum (from +0.0f, closed
+ *       candidates add +0.0f); pick the first whose running sum >= thr, else the last open
+ *       candidate with p > 0 of the lane (the several-ants-per-wave kernels find it by binary
+ *       search over the running sums they keep in registers).  One rule for all three layouts. */
 int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? 16 : (n <= 512 ? 32 : 64)); }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
@@ -218,23 +216,11 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
   for (int l = 0; l < lanes; ++l) {
     float s = 0.0f;
-    if (lanes == 16) {
-      /* packed accumulation: slots v = 0,2 and v = 1,3 are summed separately (c ascending), then added */
-      float ev = 0.0f, od = 0.0f;
-      for (int c = 0; c < ch; ++c)
-        for (int v = 0; v < vec; ++v) {
-          int k = (c * lanes + l) * vec + v;
-          float x = (k < n && !blocked[k]) ? row[k] : 0.0f;
-          if (v & 1) od = od + x; else ev = ev + x;
-        }
-      s = ev + od;
-    } else {
-      for (int c = 0; c < ch; ++c)
-        for (int v = 0; v < vec; ++v) {
-          int k = (c * lanes + l) * vec + v;
-          s = s + ((k < n && !blocked[k]) ? row[k] : 0.0f);
-        }
-    }
+    for (int c = 0; c < ch; ++c)
+      for (int v = 0; v < vec; ++v) {
+        int k = (c * lanes + l) * vec + v;
+        s = s + ((k < n && !blocked[k]) ? row[k] : 0.0f);
+      }
     part[l] = s; incl[l] = s;
   }
   lane_scan(incl);                /* lanes 0..31 (0..15) of the 64-lane scan are exactly the half-wave (row) scan */
@@ -249,28 +235,6 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
   for (int l = 0; l < lanes; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
   if (L < 0) return -1;
   float thr = r - (L ? incl[L - 1] : 0.0f);
-  if (lanes == 16) {
-    /* level 2 of the four-ants-per-wave kernel: lane L's ch*vec candidate slots (closed ones
-     * +0.0f) are dealt to the lanes of its row and the same scan + first-lane pick runs across them */
-    float cv[64], sc[64];
-    int key[64], nj = ch * vec;
-    for (int j = 0; j < 64; ++j) { cv[j] = sc[j] = 0.0f; key[j] = -1; }
-    for (int j = 0; j < nj; ++j) {
-      int k = ((j / vec) * lanes + L) * vec + (j % vec);
-      key[j] = k;
-      cv[j] = sc[j] = (k < n && !blocked[k]) ? row[k] : 0.0f;
-    }
-    lane_scan(sc);
-    int best = -1, last = -1;
-    for (int j = 0; j < lanes; ++j) {
-      if (!(cv[j] > 0.0f)) continue;
-      last = key[j];
-      if (sc[j] >= thr) { best = key[j]; break; }
-    }
-    if (best < 0) best = last;
-    if (best >= 0 && pr) *pr = row[best] / S;
-    return best;
-  }
   float run = 0.0f;
   int best = -1, last = -1;
   for (int c = 0; c < ch && best < 0; ++c)
