@@ -117,8 +117,15 @@ tsp_sample_kernel(const SampleParams p) {
   const int w = xcd_remap(blockIdx.x, gridDim.x);
   const int bpi = (p.A + 3) >> 2;                       // workgroups per instance (4 ants each)
   const int b = w / bpi;
-  const int a = (w - b * bpi) * 4 + wave;
-  if (a >= p.A) return;                                 // no barriers below: safe
+  const int a_raw = (w - b * bpi) * 4 + wave;
+  // PROB_TSP ends with a workgroup epilogue (barriers): a wave without an ant builds ant A-1 again and writes nothing
+  constexpr bool EPI = PROB == PROB_TSP;                // tour kept in LDS, outputs written by the workgroup at the end
+  const bool dup = EPI && a_raw >= p.A;
+  if (a_raw >= p.A && !dup) return;                     // (the other problems have no barrier below: safe)
+  const int a = dup ? p.A - 1 : a_raw;
+  extern __shared__ __attribute__((aligned(16))) uint16_t epi_lds[];   // EPI: [4][TL] tours | [4][TL] inverse | [4][64] f32
+  const int TL = (p.n + 7) & ~7;
+  uint16_t *tour = epi_lds + (size_t)wave * TL;
   const int n = p.n, A = p.A, ld = p.ld;
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
@@ -128,8 +135,8 @@ tsp_sample_kernel(const SampleParams p) {
   int64_t *path_out = p.paths + (STEP ? (size_t)b * A : (size_t)b * rows * A) + a;
   float *logp_out = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_out = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
-  const float *dist_b = ((PROB == PROB_TSP || CVRP) && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;
-  uint32_t *nbr_a = (PROB == PROB_TSP && p.nbr) ? p.nbr + (size_t)b * n * A + a : nullptr;   // + node * A
+  const float *dist_b = (CVRP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;      // (TSP: in the epilogue)
+  uint32_t *nbr_a = nullptr;                            // (TSP: the neighbour table is written by the epilogue)
   int pprev = 0, second = 0;                            // neighbour-table bookkeeping
   const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
 
@@ -157,7 +164,7 @@ tsp_sample_kernel(const SampleParams p) {
   };
   int own_lane = -1, own_bit = 0;                       // SCAN: owner of the last choice, known without division
   if constexpr (PROB == PROB_TSP || SOP || OP || MKP) mark(prev);
-  if (lane == 0 && !STEP) path_out[0] = prev;
+  if (lane == 0 && !STEP) { if constexpr (EPI) tour[0] = (uint16_t)prev; else path_out[0] = prev; }
 
   // per-candidate constants / counters of the constrained problems (this lane's candidates):
   //   CVRP demand, SOP number of unvisited predecessors, OP distance back to the depot
@@ -443,7 +450,7 @@ tsp_sample_kernel(const SampleParams p) {
       if (MODE == DACO_SCAN && own_lane >= 0) { if (lane == own_lane) vis.set(own_bit); }
       else mark(choice);
     }
-    if (lane == 0) path_out[STEP ? 0 : (size_t)t * A] = choice;
+    if (lane == 0) { if constexpr (EPI) tour[t] = (uint16_t)choice; else path_out[STEP ? 0 : (size_t)t * A] = choice; }
     if (dist_b) {                                        // fused gen_path_costs (wave-uniform)
       cost = cost + dpend;
       // TSP: d[u_t][u_{t-1}] (tsp/aco.py:127); CVRP: d[u_{t-1}][u_t] (cvrp/aco.py:135); scalar load
@@ -488,6 +495,59 @@ tsp_sample_kernel(const SampleParams p) {
     else { nbr_a[(size_t)prev * A] = (uint32_t)pprev | ((uint32_t)first << 16); nbr_a[(size_t)first * A] = (uint32_t)prev | ((uint32_t)second << 16); }
   }
   if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+  if constexpr (EPI) {
+    // ---- the workgroup's (up to) 4 tours leave LDS together (see tsp_scan32_kernel): paths in 32-byte runs per step
+    // row, tour lengths from 64-edge gathers summed in step order by one lane, the neighbour table through an
+    // inverse-permutation table in LDS.  Per-step stores / gathers with one active lane cost more than the row stream.
+    __syncthreads();
+    const int abase = (w - b * bpi) * 4;
+    const int nant = A - abase < 4 ? A - abase : 4;
+    const int k4 = threadIdx.x & 3;
+    {
+      int64_t *pb = p.paths + (size_t)b * n * A + abase;
+      if (k4 < nant)
+        for (int tt = threadIdx.x >> 2; tt < n; tt += 64) pb[(size_t)tt * A + k4] = (int64_t)epi_lds[(size_t)k4 * TL + tt];
+    }
+    if (p.costs && !dup) {
+      const float *dist_e = p.dist + (size_t)b * p.dist_bs;
+      float *stage = reinterpret_cast<float *>(epi_lds + (size_t)8 * TL) + wave * 64;
+      float cost_e = 0.0f;
+      for (int base = 1; base < n; base += 64) {
+        const int tt = base + lane;
+        stage[lane] = tt < n ? dist_e[(unsigned)tour[tt] * (unsigned)n + (unsigned)tour[tt - 1]] : 0.0f;   // d[u_t][u_{t-1}], tsp/aco.py:127
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+#pragma unroll
+          for (int q4 = 0; q4 < 16; ++q4) {
+            const float4 v = *reinterpret_cast<const float4 *>(stage + 4 * q4);     // (slots past the tour's end hold +0.0f)
+            cost_e = cost_e + v.x; cost_e = cost_e + v.y; cost_e = cost_e + v.z; cost_e = cost_e + v.w;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) {
+        cost_e = cost_e + dist_e[(unsigned)tour[0] * (unsigned)n + (unsigned)tour[n - 1]];    // closing edge d[u_0][u_{n-1}] last
+        p.costs[(size_t)b * A + a] = cost_e;
+      }
+    }
+    if (p.nbr) {
+      uint16_t *inv = epi_lds + (size_t)4 * TL;
+      for (int e = threadIdx.x; e < 4 * TL; e += 256) inv[e] = 0;
+      __syncthreads();
+      if (k4 < nant)
+        for (int tt = threadIdx.x >> 2; tt < n; tt += 64) inv[(size_t)k4 * TL + epi_lds[(size_t)k4 * TL + tt]] = (uint16_t)tt;
+      __syncthreads();
+      uint32_t *nb = p.nbr + (size_t)b * n * A + abase;
+      if (k4 < nant) {
+        const uint16_t *tk = epi_lds + (size_t)k4 * TL;
+        for (int node = threadIdx.x >> 2; node < n; node += 64) {
+          const int tt = inv[(size_t)k4 * TL + node];
+          const uint32_t pv = tk[tt == 0 ? n - 1 : tt - 1], nx = tk[tt == n - 1 ? 0 : tt + 1];
+          nb[(size_t)node * A + k4] = pv | (nx << 16);
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ host dispatch
@@ -495,7 +555,11 @@ template <int VEC, int CH, int CVRP>
 static hipError_t launch_sample(const SampleParams &sp, int mode, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 3) / 4;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
-#define DACO_LAUNCH(M, L) hipLaunchKernelGGL((tsp_sample_kernel<VEC, CH, M, L, CVRP>), grid, block, 0, s, sp)
+  // PROB_TSP keeps the workgroup's tours (+ the inverse table and a staging row per wave) in LDS
+  const size_t dyn = CVRP == PROB_TSP ? (size_t)8 * ((sp.n + 7) & ~7) * sizeof(uint16_t) + 4 * 64 * sizeof(float) : 0;
+#define DACO_LAUNCH(M, L) do { \
+    if (dyn > 64 * 1024) (void)hipFuncSetAttribute((const void *)tsp_sample_kernel<VEC, CH, M, L, CVRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+    hipLaunchKernelGGL((tsp_sample_kernel<VEC, CH, M, L, CVRP>), grid, block, dyn, s, sp); } while (0)
   if (mode == DACO_SCAN) { if (logp) DACO_LAUNCH(DACO_SCAN, true); else DACO_LAUNCH(DACO_SCAN, false); }
   else if (mode == DACO_RACE_PHILOX) { if (logp) DACO_LAUNCH(DACO_RACE_PHILOX, true); else DACO_LAUNCH(DACO_RACE_PHILOX, false); }
   else { if (logp) DACO_LAUNCH(DACO_RACE_NOISE, true); else DACO_LAUNCH(DACO_RACE_NOISE, false); }
