@@ -616,11 +616,29 @@ __device__ inline int count_below(const float (&run)[16], float t) {
   return ((b3 ? 8 : 0) | (b2 ? 4 : 0) | (b1 ? 2 : 0) | (b0 ? 1 : 0)) + ((NJ == 16 && run[15] < t) ? 1 : 0);
 }
 
+// the same for up to 32 running sums: one compare picks the half, 16 selects build it, then the 16-entry search
+template <int NJ>
+__device__ inline int count_below32(const float (&run)[32], float t) {
+  if constexpr (NJ <= 16) {
+    float r16[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r16[j] = run[j];
+    return count_below<NJ>(r16, t);
+  } else {
+    const bool b4 = run[15] < t;
+    float sel[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sel[j] = b4 ? (16 + j < NJ ? run[16 + j] : __builtin_inff()) : run[j];
+    return count_below<16>(sel, t) + (b4 ? 16 : 0);
+  }
+}
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to
 // DACO_SCAN16_MAX_N nodes, two up to DACO_SCAN32_MAX_N, one above (the oracle restates the rule)
 constexpr int DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
+// DACO_SCAN_LAYOUT=16 (measurement knob): four ants per wavefront up to n = 512 (TSP)
+inline int scan16_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 16) ? 512 : DACO_SCAN16_MAX_N; return v; }
 // daco_tsp_scan32.hip: TSP / CVRP scan draw with two ants per wavefront
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
 hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s);

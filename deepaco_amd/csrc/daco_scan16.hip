@@ -37,16 +37,19 @@ __device__ inline uint64_t row_first(uint64_t m) {
   return m & ~((m | 0x8000800080008000ull) - 0x0001000100010001ull);
 }
 
-// CH: chunks of 64 candidates (n <= 64 * CH, CH <= 4).
+// CH: chunks of 64 candidates (n <= 64 * CH; CH <= 4 in production, TSP up to 8 = n <= 512 as a measured alternative
+// to the two-ants-per-wavefront kernel).
 template <int CH, bool LOGP, bool CVRP>
 __global__ void __launch_bounds__(256)
 scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) {
   constexpr int NJ = CH * 4;                            // candidates per lane
   constexpr int NG = (NJ + 7) / 8;                      // 16-byte flag groups per lane
   constexpr int ROWF = CH * 64;                         // padded row length of this layout
+  constexpr int FL = CH <= 4 ? 256 : 512;               // flag / inverse-table entries per ant
+  static_assert(!CVRP || CH <= 4, "CVRP: n <= 256 (hub bitmap, demand row)");
   // open[ant][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited, else 0.0; slot
   // j = c*4 + v of lane s is node c*64 + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
-  __shared__ __attribute__((aligned(16))) _Float16 open_flags[16][256];
+  __shared__ __attribute__((aligned(16))) _Float16 open_flags[16][FL];
   __shared__ __attribute__((aligned(16))) float dstage[4][4][64];    // epilogue: edge lengths of one 64-step chunk
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
   __shared__ uint32_t hub_s[16][8];                     // CVRP: per ant, set of nodes that follow the depot (n <= 256)
@@ -90,7 +93,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     {
       const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
-      for (int g = 0; g < 2; ++g) *(f16x8 *)(fl + g * 128 + s * 8) = ones;
+      for (int g = 0; g < FL / 128; ++g) *(f16x8 *)(fl + g * 128 + s * 8) = ones;
 #pragma unroll
       for (int c = 0; c < CH; ++c) { if constexpr (CVRP) dm[c] = *(const float4 *)(dem_s + (c * 16 + s) * 4); else dm[c] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
@@ -139,7 +142,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
 
       // ---- the lane's running sums in slot order (closed slots add p*0 = +0.0f; the product with a 0/1 factor is exact)
       const float rem = CVRP ? p.capacity - used : 0.0f;
-      float run[16];
+      float run[32];
       float acc = 0.0f;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
@@ -170,11 +173,11 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       // ---- level 2 in every lane (only the chosen lane's result is used)
       const float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
       const float thr = fmaxf(r - excl, 1.401298464e-45f);
-      int cnt = count_below<NJ>(run, thr);
+      int cnt = count_below32<NJ>(run, thr);
       const bool mine = __builtin_amdgcn_inverse_ballot_w64(row_first(m));
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && cnt >= NJ) != 0, 0)) {
         // rounding: no running sum reached thr -> the lane's last open candidate with p > 0
-        const int last = count_below<NJ>(run, part);
+        const int last = count_below32<NJ>(run, part);
         cnt = cnt >= NJ ? last : cnt;
       }
       const int node = ((cnt >> 2) << 6) | (s << 2) | (cnt & 3);
@@ -284,8 +287,8 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     // node row.  TSP: nbr[node][ant] = prev | next << 16.  CVRP: successor << 16 (customers are visited once; row 0 is
     // never read -- the depot's successors are a SET, kept as a bitmap per ant).
     __syncthreads();
-    uint16_t (*inv)[256] = reinterpret_cast<uint16_t (*)[256]>(open_flags);
-    for (int e = threadIdx.x; e < 16 * 256 / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(open_flags);
+    for (int e = threadIdx.x; e < 16 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (k16 < nant) {
       const int lk = CVRP ? len_s[k16] : n;
@@ -336,7 +339,11 @@ hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
     case 1: return launch16<1, false>(sp, logp, s);
     case 2: return launch16<2, false>(sp, logp, s);
     case 3: return launch16<3, false>(sp, logp, s);
-    default: return launch16<4, false>(sp, logp, s);
+    case 4: return launch16<4, false>(sp, logp, s);
+    case 5: return launch16<5, false>(sp, logp, s);
+    case 6: return launch16<6, false>(sp, logp, s);
+    case 7: return launch16<7, false>(sp, logp, s);
+    default: return launch16<8, false>(sp, logp, s);
   }
 }
 hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
