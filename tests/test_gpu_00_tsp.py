@@ -285,12 +285,12 @@ def test_full_size_properties_tsp500(mode):
     assert np.array_equal(t2[b].cpu().numpy().view(np.uint32), rt.view(np.uint32))
 
 
-@pytest.mark.parametrize("n,A,B", [(500, 512, 4), (400, 256, 2), (1000, 256, 2), (100, 512, 8)])
+@pytest.mark.parametrize("n,A,B", [(500, 512, 4), (400, 256, 2), (1000, 256, 2), (1000, 2048, 2), (100, 512, 8)])
 def test_every_ant_of_a_full_size_launch_vs_oracle(n, A, B):
     """All B x A tours of a full-size launch against the oracle (heavy rows with random diagonals: the rare paths
     of the draw -- no running sum reaching the threshold, lane sums that round differently from the scan -- show
     up once in a few thousand tours; they did, in the first version of the in-lane search).  Covers the headline
-    shape, config 3's ant count, config 5's n and config 2's shape (per instance)."""
+    shape, config 3's ant count, config 5's shape (TSP-1000 x 2048 ants, two instances) and config 2's shape."""
     from deepaco_amd import engine
     dist, tau, eta = make_instance(n, 2024 + n, B)
     paths, _, _, flags, costs, nbr = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", seed=11, it=3,

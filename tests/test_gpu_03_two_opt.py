@@ -147,3 +147,37 @@ def test_incremental_equals_full_sweep_kernels():
     # and the oracle agrees on the first instance
     o1, os1 = oracle.two_opt_batch(d[0].cpu().numpy(), tours[0].cpu().numpy().astype(np.uint16), n // 4)
     assert np.array_equal(ref[0][0].cpu().numpy().astype(np.uint16), o1) and np.array_equal(ref[1][0].cpu().numpy(), os1)
+
+
+def test_config3_full_size_nls_iteration():
+    """BASELINE config 3 at its own sizes (TSP-500, 256 ants, NLS with maxt = n//4, T_nls = 10, T_p = 20), two
+    instances: one colony iteration through BatchedTSP(local_search='nls').  Properties: every tour a permutation
+    starting at node 0, the NLS never makes a tour longer, costs equal an independent gather-sum; and for a few ants
+    the first 2-opt pass (the one deterministic piece: maxt sweeps on the sampled tour) equals the oracle bit for bit."""
+    from deepaco_amd import engine
+    import oracle
+    B, n, A = 2, 500, 256
+    g = torch.Generator().manual_seed(33)
+    c = torch.rand(B, n, 2, generator=g)
+    d = torch.cdist(c, c)
+    i = torch.arange(n)
+    d[:, i, i] = 1e9
+    dev = torch.device("cuda:0")
+    dd = d.to(dev)
+    col = engine.BatchedTSP(dd, n_ants=A, seed=4, local_search="nls", fixed_start=0)
+    col.sparsify(50)
+    raw, _, _, _ = engine.tsp_sample(col.pheromone, col.heuristic, A, seed=4, it=0, fixed_start=0, batch=B)
+    raw_costs = engine.tour_costs(dd, raw)
+    paths, costs = col.step()
+    assert bool((paths.sort(dim=1).values == torch.arange(n, device=dev).view(1, n, 1)).all())
+    assert bool((paths[:, 0] == 0).all())
+    assert bool((costs <= raw_costs + 1e-4).all()) and float(costs.mean()) < 0.75 * float(raw_costs.mean())
+    u = paths.transpose(1, 2)
+    ref = torch.stack([dd[b][u[b], torch.roll(u[b], 1, dims=1)].double().sum(1) for b in range(B)])
+    torch.testing.assert_close(costs.double(), ref, rtol=1e-5, atol=0)
+    assert torch.equal(col.lowest_cost, costs.min(dim=1).values)
+    # first pass of the local search on the sampled tours vs the oracle (4 ants of instance 1)
+    tours = raw[1, :, :4].T.contiguous().to(torch.int16)
+    out, sweeps = engine.two_opt_(dd[1], tours.clone(), n // 4, want_sweeps=True, dist_t="symmetric")
+    ref_t, ref_s = oracle.two_opt_batch(d[1].numpy(), tours.cpu().numpy().astype(np.uint16), n // 4)
+    assert np.array_equal(out.cpu().numpy().astype(np.uint16), ref_t) and np.array_equal(sweeps[0].cpu().numpy(), ref_s)
