@@ -15,6 +15,14 @@ def _pw(x, a):
     return x if a == 1 else (x * x if a == 2 else np.power(x, a))
 
 
+def _dp_deta(tau_row, eta_row, alpha, beta, p):
+    """d (tau^a eta^b) / d eta = b tau^a eta^(b-1): b p / eta where eta != 0; at eta == 0 autograd gives tau^a for
+    b = 1 and 0 for b > 1 (not 0/0)."""
+    safe = np.where(eta_row != 0, eta_row, 1.0)
+    at_zero = _pw(tau_row, alpha) * (p == p) if beta == 1 else np.zeros_like(p)
+    return np.where(eta_row != 0, beta * p / safe, at_zero)
+
+
 def tsp_grad(tau, eta, alpha, beta, paths, grad_logp):
     n, A = paths.shape
     tau64, eta64 = tau.astype(np.float64), eta.astype(np.float64)
@@ -30,7 +38,7 @@ def tsp_grad(tau, eta, alpha, beta, paths, grad_logp):
             pr = np.float32(p[j] / S)
             g = float(grad_logp[t - 1, a])
             if EPS < pr < np.float32(1) - EPS and g != 0.0:
-                out[prev] -= g * beta * p / (eta64[prev] * S)
+                out[prev] -= g * _dp_deta(tau64[prev], eta64[prev], alpha, beta, p) * open_ / S
                 out[prev, j] += g * beta / eta64[prev, j]
             open_[j] = False
             prev = j

@@ -78,6 +78,47 @@ def test_grad_vs_closed_form_philox(mode, n, A, beta):
     np.testing.assert_allclose(heu.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * scale)
 
 
+def test_grad_is_finite_where_the_heuristic_is_exactly_zero():
+    """a heuristic with exact zeros (Net.reshape output without the +EPS offset).  d(tau^a eta^b)/d eta at
+    eta = 0 is tau^a for b = 1 (what the reference's autograd gives), not the 0/0 of b*p/eta: the backward kernel must
+    return finite gradients equal to autograd's.  Tours are hand-made so that no step is infeasible."""
+    from deepaco_amd import engine
+    n, A = 40, 6
+    g = torch.Generator().manual_seed(8)
+    tau = (torch.rand(n, n, generator=g) + 0.2).to(dev())
+    eta = (torch.rand(n, n, generator=g) + 0.05)
+    paths = torch.stack([torch.randperm(n, generator=g) for _ in range(A)], 1)           # [n, A]
+    used = torch.zeros(n, n, dtype=torch.bool)
+    for a in range(A):
+        used[paths[:-1, a], paths[1:, a]] = True
+    zero = (torch.rand(n, n, generator=g) < 0.4) & ~used                                 # zeros only off the tours' edges
+    eta = torch.where(zero, torch.zeros_like(eta), eta).to(dev())
+    paths = paths.to(dev())
+    # reference: the reference's own op sequence (tsp/aco.py:165-177) in float64 with autograd
+    e64 = eta.double().requires_grad_(True)
+    t64 = tau.double()
+    w = torch.linspace(-1, 1, A, device=dev()).double()
+    mask = torch.ones(A, n, dtype=torch.float64, device=dev())
+    ar = torch.arange(A, device=dev())
+    mask[ar, paths[0]] = 0
+    total, rowsum = 0.0, []
+    for t in range(1, n):
+        prob = t64[paths[t - 1]] * e64[paths[t - 1]] * mask
+        S = prob.sum(1)
+        rowsum.append(S.detach().float())
+        eps = 1.1920928955078125e-07           # Categorical clamps the probabilities (tsp/aco.py:174-176): no gradient there
+        total = total + (torch.log(torch.clamp(prob[ar, paths[t]] / S, eps, 1 - eps)) * w).sum()
+        mask = mask.clone()
+        mask[ar, paths[t]] = 0
+    total.backward()
+    G = w.float().view(1, 1, A).expand(1, n - 1, A).contiguous()
+    grad = engine.sample_backward(tau[None], eta[None], 1.0, 1.0, paths[None].contiguous(), torch.stack(rowsum)[None], G)
+    assert bool(torch.isfinite(grad).all())
+    ref = e64.grad.float()
+    assert float((ref[zero.to(dev())]).abs().max()) > 0                                   # the zero entries do carry gradient
+    torch.testing.assert_close(grad[0], ref, rtol=2e-4, atol=2e-5 * float(ref.abs().max()))
+
+
 def test_no_grad_path_unchanged():
     """Without requires_grad (or under no_grad) sample() takes the plain path and returns the same tours."""
     from deepaco_amd.tsp.aco import ACO
