@@ -301,6 +301,50 @@ def extra_configs(dev, headline_colony):
                              "trips per sweep (DESIGN.md 3.4), not by this bandwidth"}}
     del col
 
+    # headline workload with the LEARNED heuristic: Net + the reference's pretrained tsp500 weights
+    # (tests/golden/w_tsp_tsp500.npz: the checkpoint as plain arrays), heu + 1e-10, next to the vanilla 1/d on the
+    # same instances and seeds
+    try:
+        import numpy as np
+        from deepaco_amd.tsp.net import Net as TspNet
+        wz = np.load(os.path.join(ROOT, "tests", "golden", "w_tsp_tsp500.npz"))
+        lnet = TspNet()
+        lnet.load_state_dict({k[3:]: torch.from_numpy(wz[k]) for k in wz.files}, strict=False)
+        lnet = lnet.to(dev).eval()
+        n, A, B, k = 500, 512, 64, 50
+        g = torch.Generator().manual_seed(4242)
+        coords = torch.rand(B, n, 2, generator=g).to(dev)
+        dist, ei, ea = engine.tsp_knn_graph(coords, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            heu = lnet.reshape_batch(n, ei, lnet.forward_batch(coords, ei, ea)) + 1e-10
+        torch.cuda.synchronize()
+        t_net = time.perf_counter() - t0
+        res = {}
+        for tag, kw in (("learned", dict(heuristic=heu)), ("vanilla_1_over_d_sparsified", {})):
+            col = engine.BatchedTSP(dist, n_ants=A, seed=7, **kw)
+            if not kw:
+                col.sparsify(k)
+            col.heuristic = col.heuristic.contiguous()
+            col.step(); col.step()
+            dtl = time_launches(col.step, 10, warm=0)
+            col2 = engine.BatchedTSP(dist, n_ants=A, seed=7, **kw)
+            if not kw:
+                col2.sparsify(k)
+            best = []
+            for T in (1, 10, 20):
+                col2.run(T - col2.iteration)
+                best.append(float(col2.lowest_cost.mean()))
+            res[tag] = {"value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3,
+                        "mean_best_cost_after_1_10_20_iterations": best}
+        out["headline_learned_heuristic"] = {
+            "workload": f"TSP-{n}, n_ants={A}, {B} instances, heuristic = Net(pretrained tsp500) + 1e-10 vs 1/d sparsified k={k}",
+            "gnn_forward_ms_for_the_batch": t_net * 1e3, **res}
+        del lnet
+    except Exception as e:
+        out["headline_learned_heuristic"] = {"error": repr(e)}
+
     # GNN forward (eval), 64 graphs of TSP-500 k=50 side by side
     from deepaco_amd.tsp.net import Net
     torch.manual_seed(0)

@@ -432,6 +432,13 @@ def gen_netgrad():
         save(f"g7_netgrad_{sub}_{ck}", heu_train=heu.detach(), coef=coef, loss=loss.detach(), **grads, **stats)
 
 
+def gen_bench_weights():
+    """The checkpoint the reference ships for the headline size (pretrained/tsp/tsp500.pt) as plain float arrays (data,
+    not code): bench.py's learned-heuristic variant loads them into deepaco_amd's Net."""
+    sd = torch.load(os.path.join(REF, "pretrained", "tsp", "tsp500.pt"), map_location="cpu")
+    save("w_tsp_tsp500", **{"w__" + k: v.float().numpy() for k, v in sd.items() if v.numel() > 0 and v.dtype.is_floating_point})
+
+
 def load_ref_dir(subdir, alias):
     """Import <subdir>/aco.py with <subdir> on sys.path (smtwtp/aco.py does `import utils`)."""
     d = os.path.join(REF, subdir)
@@ -560,6 +567,7 @@ def main():
     print("gradients (G3)"); gen_grads(tsp_aco, cvrp_aco)
     print("Net forward (G5)"); gen_net()
     print("Net training step (G7)"); gen_netgrad()
+    print("bench weights"); gen_bench_weights()
     print("siblings (S1-S6)"); gen_siblings()
 
 
