@@ -331,6 +331,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   const float *dT = distT ? distT + (size_t)b * dist_bs : nullptr;
   uint16_t *tour = tours + (size_t)blockIdx.x * n;
   float *rowA = rows + (size_t)wave * 2 * np4, *rowB = rowA + np4;
+  const bool symmetric = distT == dist;                  // (the caller passes the matrix itself as its transpose)
 
   for (int k = tid; k < n; k += NT) {
     const int u = tour[k], v = tour[k + 1 < n ? k + 1 : 0];
@@ -365,19 +366,9 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   bool first = true;
   long it = 0;
   while (it < max_iterations) {
-    // ---- classify the rows below the block: recompute in full (minimiser inside the changed range) or patch
     const int blo = first ? 1 : p, bhi = first ? n - 1 : min(q + 2, n - 1);       // block rows [blo, bhi)
-    if (tid < 2) cnt[tid] = 0;
-    __syncthreads();
-    if (!first)
-      for (int i = 1 + tid; i < p; i += NT) {
-        const uint64_t key = rb[i];
-        const int jb = (int)(uint32_t)key;
-        if (key != KEY_NONE && jb >= p - 1 && jb <= q) full_list[atomicAdd(&cnt[0], 1)] = i;
-        else part_list[atomicAdd(&cnt[1], 1)] = i;
-      }
-    __syncthreads();
-    const int nfull = cnt[0], npart = cnt[1];
+    // (the rows below the block were classified while the previous move was applied: lists and counts are ready)
+    const int nfull = first ? 0 : cnt[0], npart = first ? 0 : cnt[1];
     // ---- block rows: each wave a contiguous run with (about) the same number of pairs; rolling rows in LDS
     {
       const int R = bhi - blo;
@@ -428,7 +419,8 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
         }
       }
     }
-    // ---- scattered full rows: one wave per row, both rows staged
+    // ---- scattered full rows: one wave per row, both rows staged (prefetching the next pair through registers, as the
+    // block rows do, was measured 5 % slower here: these rows are few)
     for (int r = wave; r < nfull; r += W) {
       const int i = full_list[r];
       const int2 ri = pe[i - 1];
@@ -489,6 +481,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
       if ((ok >> 32) < (best >> 32) || ((ok >> 32) == (best >> 32) && oi < bi)) { best = ok; bi = oi; }
     }
     if (lane == 0) { red[2 * wave] = best; red[2 * wave + 1] = (uint64_t)(uint32_t)bi; }
+    if (tid < 2) cnt[tid] = 0;                            // (everyone read the counts before the barrier above)
     __syncthreads();
     best = red[0];
     bi = (int)red[1];
@@ -505,19 +498,34 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     p = bi;
     q = (int)(uint32_t)best;
     first = false;
-    __syncthreads();                                      // everyone has read red[] and the records
+    // ---- apply the move and, in the same phase, classify the rows below the block for the next sweep: recompute in
+    // full (cached minimiser inside the changed range) or patch.  (pe was last read before the previous barrier.)
     const int half = (q - p + 1) >> 1;
     for (int k = tid; k < half; k += NT) {
       const int x = pe[p + k].x, y = pe[q - k].x;
       pe[p + k].x = (x & 0xFFFF0000) | (y & 0xFFFF);
       pe[q - k].x = (y & 0xFFFF0000) | (x & 0xFFFF);
     }
+    if (symmetric) {
+      // the inner edges are the old ones walked backwards: same lengths, mirrored (e'[k] = e[p+q-1-k], k in [p, q-1])
+      const int ehalf = (q - p) >> 1;
+      for (int k = tid; k < ehalf; k += NT) {
+        const int x = pe[p + k].y, y = pe[q - 1 - k].y;
+        pe[p + k].y = y;
+        pe[q - 1 - k].y = x;
+      }
+    }
+    for (int i = 1 + tid; i < p; i += NT) {
+      const uint64_t key = rb[i];
+      const int jb = (int)(uint32_t)key;
+      if (key != KEY_NONE && jb >= p - 1 && jb <= q) full_list[atomicAdd(&cnt[0], 1)] = i;
+      else part_list[atomicAdd(&cnt[1], 1)] = i;
+    }
     __syncthreads();
-    for (int k = p - 1 + tid; k <= q; k += NT) {
+    for (int k = p - 1 + tid; k <= q; k += NT) {          // records p-1 .. q: successor (+ edge length where it is new)
       const int u = pe[k].x & 0xFFFF;
       const int v = pe[k + 1 < n ? k + 1 : 0].x & 0xFFFF;
-      const float len = d[(size_t)u * n + v];
-      pe[k].y = __float_as_int(len);
+      if (!symmetric || k == p - 1 || k == q) pe[k].y = __float_as_int(d[(size_t)u * n + v]);
       reinterpret_cast<unsigned short *>(&pe[k].x)[1] = (unsigned short)v;
     }
     __syncthreads();
