@@ -176,8 +176,26 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       int cnt = count_below32<NJ>(run, thr);
       const bool mine = __builtin_amdgcn_inverse_ballot_w64(row_first(m));
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && cnt >= NJ) != 0, 0)) {
-        // rounding: no running sum reached thr -> the lane's last open candidate with p > 0
-        const int last = count_below32<NJ>(run, part);
+        // rounding: no running sum reached thr -> the lane's last open candidate with p > 0 (rare: the row and the flags
+        // are read again; "where the running sum reaches its final value" is not the same -- a term can be absorbed)
+        int last = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float4 rw = *(const float4 *)(Pb + voff + c * 256);
+          const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * 128 + s * 8);
+          const int e = (c & 1) * 4;
+          const float rv[4] = {rw.x, rw.y, rw.z, rw.w};
+          const float dv[4] = {dm[c].x, dm[c].y, dm[c].z, dm[c].w};
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float f = (float)ff[e + v];
+            if constexpr (CVRP) {
+              f = dv[v] > rem ? 0.0f : f;
+              if (c == 0 && v == 0) f = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f;
+            }
+            last = rv[v] * f > 0.0f ? 4 * c + v : last;
+          }
+        }
         cnt = cnt >= NJ ? last : cnt;
       }
       const int node = ((cnt >> 2) << 6) | (s << 2) | (cnt & 3);

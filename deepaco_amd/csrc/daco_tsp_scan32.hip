@@ -171,9 +171,20 @@ tsp_scan32_kernel(const SampleParams p) {
         const int cnt = count_below<NJ>(run, thr);
         int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
         if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
-          // rounding: no running sum reached thr -> the lane's last open candidate with p > 0, which is where the
-          // running sum reaches its final value
-          const int last = count_below<NJ>(run, part);
+          // rounding: no running sum reached thr -> the lane's last open candidate with p > 0.  (Not "where the
+          // running sum reaches its final value": a positive term can be absorbed by the sum before it -- a randomised
+          // soak found that difference once in 6000 launches.)  Rare: the row and the flags are simply read again.
+          int last = 0;
+#pragma unroll
+          for (int c = 0; c < CH2; ++c) {
+            const float4 rw = *(const float4 *)(Pb + voff + c * 512);
+            const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * 256 + s * 8);
+            const int e = (c & 1) * 4;
+            last = rw.x * (float)ff[e + 0] > 0.0f ? 4 * c + 0 : last;
+            last = rw.y * (float)ff[e + 1] > 0.0f ? 4 * c + 1 : last;
+            last = rw.z * (float)ff[e + 2] > 0.0f ? 4 * c + 2 : last;
+            last = rw.w * (float)ff[e + 3] > 0.0f ? 4 * c + 3 : last;
+          }
           if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
           if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 + 32);
         }
@@ -384,7 +395,20 @@ cvrp_scan32_kernel(const SampleParams p) {
     const int cnt = count_below<NJ>(run, thr);
     int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
     if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
-      const int last = count_below<NJ>(run, part);
+      // rounding: no running sum reached thr -> the lane's last open candidate with p > 0 (row and flags read again)
+      int last = 0;
+#pragma unroll
+      for (int c = 0; c < CH2; ++c) {
+        const float4 rw = *(const float4 *)(Pb + voff + c * 512);
+        float4 f = *(const float4 *)(fl + (c * 32 + s) * 4);
+        f.x = dm[c].x > rem ? 0.0f : f.x;  f.y = dm[c].y > rem ? 0.0f : f.y;
+        f.z = dm[c].z > rem ? 0.0f : f.z;  f.w = dm[c].w > rem ? 0.0f : f.w;
+        if (c == 0) f.x = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f.x;
+        last = rw.x * f.x > 0.0f ? 4 * c + 0 : last;
+        last = rw.y * f.y > 0.0f ? 4 * c + 1 : last;
+        last = rw.z * f.z > 0.0f ? 4 * c + 2 : last;
+        last = rw.w * f.w > 0.0f ? 4 * c + 3 : last;
+      }
       if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
       if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 + 32);
     }
