@@ -46,8 +46,11 @@ class ACO():
                  ):
         if adaptive:
             raise NotImplementedError("the adaptive elitist baseline (cvrp/aco.py:207-383) is out of scope")
-        if not distances.is_cuda:
-            raise engine._lib.DacoError("deepaco_amd.cvrp.ACO needs tensors on a HIP device; there is no CPU path")
+        # device='cpu' + host tensors (cvrp/test.py): staged to the HIP device, see engine.stage_to_hip
+        distances = engine.stage_to_hip(distances)
+        demand = engine.stage_to_hip(demand, distances)
+        pheromone = engine.stage_to_hip(pheromone, distances)
+        heuristic = engine.stage_to_hip(heuristic, distances)
         self.problem_size = len(distances)
         self.distances = distances
         self.capacity = capacity

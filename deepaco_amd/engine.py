@@ -25,6 +25,19 @@ def _require_gpu(*tensors):
                 "deepaco_amd kernels run on a HIP device only (got a CPU tensor); there is no CPU fallback")
 
 
+def stage_to_hip(t, like=None):
+    """The reference's test scripts build the colony with device='cpu' and host tensors (tsp_nls/test.py:22-29,
+    cvrp/test.py:20-27).  There is no CPU compute path here: host tensors handed to a colony are copied to the HIP
+    device once (differentiably, so a heuristic keeps its autograd history) and everything runs -- and is returned --
+    there.  `like`: a tensor whose device to use; default: the current HIP device."""
+    if t is None or not torch.is_tensor(t) or t.is_cuda:
+        return t
+    if not torch.cuda.is_available():
+        raise _lib.DacoError("deepaco_amd has no CPU path: no HIP device is visible for the host tensors passed in")
+    dev = like.device if (like is not None and like.is_cuda) else torch.device("cuda", torch.cuda.current_device())
+    return t.to(dev)
+
+
 def _workspace(device, nbytes, tag):
     """Per (device, stream, tag) scratch buffer, grown on demand (owned by the caller side of the ABI)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)

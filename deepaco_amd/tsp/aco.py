@@ -49,10 +49,10 @@ class ACO():
                  sampler='scan',
                  seed=None,
                  ):
-        if not distances.is_cuda:
-            raise engine._lib.DacoError(
-                "deepaco_amd.ACO needs `distances` on a HIP device (e.g. device='cuda:0'); "
-                "there is no CPU path in this package")
+        # device='cpu' + host tensors (the reference's test scripts): staged to the HIP device, see engine.stage_to_hip
+        distances = engine.stage_to_hip(distances)
+        pheromone = engine.stage_to_hip(pheromone, distances)
+        heuristic = engine.stage_to_hip(heuristic, distances)
         self.problem_size = len(distances)
         self.distances = distances
         self.n_ants = n_ants

@@ -49,8 +49,6 @@ class ACO(_TspACO):
                  ):
         if not distances.is_cuda and str(device) != 'cpu':
             distances = distances.to(device)            # the reference moves them too (:29)
-        if pheromone is not None and not pheromone.is_cuda:
-            pheromone = pheromone.to(distances.device)
         super().__init__(distances, n_ants, decay, alpha, beta, elitist, min_max, pheromone, heuristic, min,
                          device, sampler=sampler, seed=seed)
         assert local_search in [None, "2opt", "nls"]

@@ -62,8 +62,11 @@ def test_product_has_no_cpu_path():
     from deepaco_amd import engine
     from deepaco_amd.tsp.aco import ACO
     d = torch.rand(5, 5)
-    with pytest.raises(_lib.DacoError):
-        ACO(d, n_ants=4)
+    if torch.cuda.is_available():          # host tensors are staged to the HIP device, never computed on the CPU
+        assert ACO(d, n_ants=4).distances.is_cuda
+    else:
+        with pytest.raises(_lib.DacoError):
+            ACO(d, n_ants=4)
     with pytest.raises(_lib.DacoError):
         engine.tsp_sample(d, d, 4)
 

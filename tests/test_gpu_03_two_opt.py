@@ -181,3 +181,24 @@ def test_config3_full_size_nls_iteration():
     out, sweeps = engine.two_opt_(dd[1], tours.clone(), n // 4, want_sweeps=True, dist_t="symmetric")
     ref_t, ref_s = oracle.two_opt_batch(d[1].numpy(), tours.cpu().numpy().astype(np.uint16), n // 4)
     assert np.array_equal(out.cpu().numpy().astype(np.uint16), ref_t) and np.array_equal(sweeps[0].cpu().numpy(), ref_s)
+
+
+def test_reference_test_script_call_pattern_with_host_tensors():
+    """tsp_nls/test.py:16-33 builds the colony from HOST tensors with device='cpu' (the reference's numba local search
+    runs there): ACO(n_ants, heuristic=heu_mat.cpu(), distances=distances.cpu(), device='cpu', local_search='nls'),
+    then sample(inference=True) and run(inference=True).  The same calls work unchanged: the inputs are staged to
+    the HIP device once and everything runs there (there is no CPU compute path)."""
+    from deepaco_amd.tsp_nls.aco import ACO
+    n = 60
+    g = torch.Generator().manual_seed(12)
+    c = torch.rand(n, 2, generator=g)
+    d = torch.cdist(c, c)
+    d[torch.arange(n), torch.arange(n)] = 1e9
+    heu = 1 / d + 1e-10
+    aco = ACO(n_ants=20, heuristic=heu.cpu(), distances=d.cpu(), device='cpu', local_search='nls', seed=3)
+    assert aco.distances.is_cuda and aco.heuristic.is_cuda
+    costs = aco.sample(inference=True)[0]
+    baseline, best_sample = costs.mean().item(), torch.min(costs).item()
+    best_1 = aco.run(n_iterations=1, inference=True)
+    best_T = aco.run(n_iterations=4, inference=True)
+    assert isinstance(best_1, float) and best_T <= best_1 <= baseline + 1e-6 and best_sample <= baseline
