@@ -637,6 +637,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to
 // DACO_SCAN16_MAX_N nodes, two up to DACO_SCAN32_MAX_N, one above (the oracle restates the rule)
 constexpr int DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
+// TSP: the two-ants-per-wavefront kernel serves n <= 1024 (DACO_SCAN_LAYOUT=64: measurement knob, one ant per wavefront above 512)
+inline int tsp_scan32_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 64) ? 512 : 1024; return v; }
 // DACO_SCAN_LAYOUT=16 (measurement knob): four ants per wavefront up to n = 512 (TSP)
 inline int scan16_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 16) ? 512 : DACO_SCAN16_MAX_N; return v; }
 // daco_tsp_scan32.hip: TSP / CVRP scan draw with two ants per wavefront

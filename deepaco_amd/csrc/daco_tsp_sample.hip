@@ -65,7 +65,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   if (n > DACO_MAX_NODES) { set_error("daco_tsp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
   if (mode < 0 || mode > 3 || norm_passes < 0 || norm_passes > 2) { set_error("daco_tsp_sample: bad mode %d / norm_passes %d", mode, norm_passes); return DACO_E_BADARG; }
   const bool packed = mode == DACO_SCAN && (size_t)n * A * 8 < ((size_t)1 << 32);   // several ants per wave, 32-bit offsets
-  const bool four_per_wave = packed && n <= scan16_max_n(), two_per_wave = packed && !four_per_wave && n <= DACO_SCAN32_MAX_N;
+  const bool four_per_wave = packed && n <= scan16_max_n(), two_per_wave = packed && !four_per_wave && n <= tsp_scan32_max_n();
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode == DACO_RACE_NOISE && !noise) { set_error("daco_tsp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
   if (fixed_start >= n) { set_error("daco_tsp_sample: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }

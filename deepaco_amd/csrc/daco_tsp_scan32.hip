@@ -65,13 +65,14 @@ __device__ inline uint32_t lowest_bit(uint32_t x) { return x & (0u - x); }
 template <int CH2, bool LOGP>
 __global__ void __launch_bounds__(256)
 tsp_scan32_kernel(const SampleParams p) {
-  constexpr int NJ = CH2 * 4;                           // candidates per lane (<= 16)
+  constexpr int NJ = CH2 * 4;                           // candidates per lane (<= 32)
   constexpr int NG = (NJ + 7) / 8;                      // 16-byte flag groups per lane
-  static_assert(CH2 >= 1 && CH2 <= 4, "two ants per wavefront: n <= 512");
+  constexpr int FL = CH2 <= 4 ? 512 : 1024;             // flag / tour / inverse-table entries per ant
+  static_assert(CH2 >= 1 && CH2 <= 8, "two ants per wavefront: n <= 1024");
   // open[h][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited by ant h, else 0.0.
   // Slot j = c*4 + v of lane s is node c*128 + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
-  __shared__ __attribute__((aligned(16))) _Float16 open_flags[8][512];
-  __shared__ __attribute__((aligned(16))) uint16_t tour_s[8][512];   // tour_s[h][t] = node visited at step t
+  __shared__ __attribute__((aligned(16))) _Float16 open_flags[8][FL];
+  __shared__ __attribute__((aligned(16))) uint16_t tour_s[8][FL];    // tour_s[h][t] = node visited at step t
   __shared__ __attribute__((aligned(16))) float dstage[4][2][64];    // epilogue: edge lengths of one 64-step chunk
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int up = lane >> 5, s = lane & 31;
@@ -102,7 +103,7 @@ tsp_scan32_kernel(const SampleParams p) {
   if (active) {
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
-    for (int g = 0; g < 2; ++g) *(f16x8 *)(fl + g * 256 + s * 8) = ones;
+    for (int g = 0; g < FL / 256; ++g) *(f16x8 *)(fl + g * 256 + s * 8) = ones;
     int prev;
     if (p.start) prev = (int)p.start[(size_t)b * A + a];
     else if (p.fixed_start >= 0) prev = p.fixed_start;
@@ -139,7 +140,7 @@ tsp_scan32_kernel(const SampleParams p) {
 
         // ---- the lane's running sums in slot order.  A closed slot adds p*0 = +0.0f; the product with the
         // 0/1 flag is exact, so each fma rounds once like an add.
-        float run[16];
+        float run[32];
         float acc = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH2; ++c) {
@@ -168,7 +169,7 @@ tsp_scan32_kernel(const SampleParams p) {
         float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
         excl = s == 0 ? 0.0f : excl;
         const float thr = fmaxf(r - excl, 1.401298464e-45f);
-        const int cnt = count_below<NJ>(run, thr);
+        const int cnt = count_below32<NJ>(run, thr);
         int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
         if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
           // rounding: no running sum reached thr -> the lane's last open candidate with p > 0.  (Not "where the
@@ -264,8 +265,8 @@ tsp_scan32_kernel(const SampleParams p) {
     // neighbour table nbr[b][node][ant] = prev | next << 16 (what the pheromone update consumes): invert the tours in
     // LDS (the flag array is free now), then 8 lanes write one 32-byte run per node row
     __syncthreads();                                     // every wave is done with its flags
-    uint16_t (*inv)[512] = reinterpret_cast<uint16_t (*)[512]>(open_flags);
-    for (int e = threadIdx.x; e < 8 * 512 / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(open_flags);
+    for (int e = threadIdx.x; e < 8 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int k = threadIdx.x & 7;
     if (k < nant)                                         // (the other slots hold no tour: their entries are not nodes)
@@ -503,7 +504,11 @@ hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
     case 1: return launch32<1>(sp, logp, s);
     case 2: return launch32<2>(sp, logp, s);
     case 3: return launch32<3>(sp, logp, s);
-    default: return launch32<4>(sp, logp, s);        // (the dispatch rule sends n <= 512 here)
+    case 4: return launch32<4>(sp, logp, s);
+    case 5: return launch32<5>(sp, logp, s);
+    case 6: return launch32<6>(sp, logp, s);
+    case 7: return launch32<7>(sp, logp, s);
+    default: return launch32<8>(sp, logp, s);        // (n <= 1024)
   }
 }
 

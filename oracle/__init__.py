@@ -107,7 +107,7 @@ def tsp_sample_race(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=F
 
 
 def tsp_sample_scan(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=False, wave=False):
-    """DACO_SCAN (four / two ants per wavefront for n <= 256 / <= 512) or, with wave=True, DACO_SCAN_WAVE."""
+    """DACO_SCAN (four / two ants per wavefront for n <= 256 / <= 1024) or, with wave=True, DACO_SCAN_WAVE."""
     fn = lib().orc_tsp_sample_scan_wave if wave else lib().orc_tsp_sample_scan
     return _sample_rng(fn, P, A, seed, it, ant_gid0, fixed_start, require_prob)
 

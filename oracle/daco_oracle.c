@@ -206,6 +206,8 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  *       candidate with p > 0 of the lane (the several-ants-per-wave kernels find it by binary
  *       search over the running sums they keep in registers).  One rule for all three layouts. */
 int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? 16 : (n <= 512 ? 32 : 64)); }
+/* TSP: the two-ants-per-wavefront kernel serves n <= 1024 (its LDS tour / flag buffers hold 1024 entries) */
+int orc_scan_lanes_tsp(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? 16 : (n <= 1024 ? 32 : 64)); }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
                      uint64_t iter, uint32_t gid, int t, float *pr, int lanes, const float *u_inj) {
@@ -280,7 +282,7 @@ static int tsp_sample(int mode, int n, int A, const float *P, const int64_t *sta
       int best;
       if (mode == MODE_NOISE) best = draw_noise(n, row, vis, noise + ((long)(t - 1) * A + a) * n, norm_passes, p, &pr);
       else if (mode == MODE_RACE) best = draw_race(n, row, vis, seed, iter, gid, t, p, logp ? &pr : NULL);
-      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr, orc_scan_lanes(n, mode),
+      else best = draw_scan(n, row, vis, seed, iter, gid, t, &pr, orc_scan_lanes_tsp(n, mode),
                             noise ? noise + ((long)(t - 1) * A + a) : NULL);     /* scan modes: noise = uniforms [n-1][A] */
       if (best < 0) { rc = ORC_INFEASIBLE; best = 0; pr = 0.0f; }
       if (logp) logp[(long)(t - 1) * A + a] = clamp_log(pr);

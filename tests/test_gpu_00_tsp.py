@@ -346,7 +346,7 @@ def _layout_order(n, lanes):
     return np.argsort(key, kind="stable")
 
 
-@pytest.mark.parametrize("n,lanes", [(200, 16), (500, 32), (640, 64)])
+@pytest.mark.parametrize("n,lanes", [(200, 16), (500, 32), (640, 32), (1100, 64)])
 def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
     """The benchmarked sampler against the LITERAL arithmetic of the reference's roulette (tsp_nls/aco.py:266-274:
     r = U * sum(prob_row * mask) in f64, subtract prob[k] one after the other until r <= 0), step by step along
@@ -363,7 +363,7 @@ def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
     u = torch.rand(1, n - 1, A, generator=g).clamp_(1e-7, 1 - 1e-7)
     paths, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", fixed_start=0, noise=u.to(dev()))
     assert int(flags.sum()) == 0
-    assert {16: n <= 256, 32: 256 < n <= 512, 64: n > 512}[lanes]
+    assert {16: n <= 256, 32: 256 < n <= 1024, 64: n > 1024}[lanes]
     P = oracle.prob_matrix(tau[0].numpy(), eta[0].numpy())
     order = _layout_order(n, lanes)
     p = paths[0].cpu().numpy()
