@@ -182,7 +182,7 @@ def _cpu_colony(job):
     return lowest, done, time.perf_counter() - t0
 
 
-def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=150.0):
+def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0):
     """Reference CPU path (torch port): `instances` colonies of the same workload, `iters` iterations each, as
     parallel processes with a few intra-op threads each (torch's default of one thread per logical CPU is far from
     optimal for [512 x 500] tensors on a many-core host).
@@ -192,9 +192,9 @@ def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=150.0):
     n = dist_cpu.shape[1]
     ncpu = os.cpu_count() or 1
     # intra-op threads per colony process: the [512 x 500] elementwise ops of a rollout step stop scaling beyond a few
-    # threads (measured on the 256-CPU box: 2 -> 3.75, 4 -> 3.53, 8 -> 3.48, 16 -> 4.03 ms per step), and 16 colonies
-    # run side by side; 4 threads each = 64 busy cores
-    threads = max(1, min(4, ncpu // max(1, min(instances, dist_cpu.shape[0]))))
+    # threads (one process alone on the 256-CPU box: 2 -> 3.75, 4 -> 3.53, 8 -> 3.48, 16 -> 4.03 ms per step), and with 16
+    # colonies side by side fewer threads each is faster still (20 iterations: 88 s at 2 threads, 150 s at 4, > 300 s at 8)
+    threads = max(1, min(2, ncpu // max(1, min(instances, dist_cpu.shape[0]))))
     instances = min(instances, dist_cpu.shape[0])
     procs = max(1, min(instances, ncpu // threads))
     jobs = [(dist_cpu[b].clone(), k_sparse, n_ants, iters, threads, 4321 + b, budget_s) for b in range(instances)]

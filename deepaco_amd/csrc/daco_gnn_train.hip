@@ -519,6 +519,7 @@ __global__ void gnn_t_bn_param_grad(int G, const double *bsums, float *ggamma, f
 // first linears: x0 = silu(a0), a0 = xin W^T + b  /  w0 = silu(attr * W + b)
 __global__ void __launch_bounds__(256)
 gnn_t_node_init_bwd(int n, int feats, const float *xin, const float *a0, const float *gx, float *gW, float *gb) {
+  __shared__ float red[8][TU][9];
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
   float accW[8] = {0, 0, 0, 0, 0, 0, 0, 0}, accb = 0.0f;
   for (int i = blockIdx.x * 8 + il; i < n; i += gridDim.x * 8) {
@@ -526,11 +527,22 @@ gnn_t_node_init_bwd(int n, int feats, const float *xin, const float *a0, const f
     accb += g;
     for (int f = 0; f < feats; ++f) accW[f] = fmaf(g, xin[(size_t)i * feats + f], accW[f]);
   }
-  unsafeAtomicAdd(gb + o, accb);
-  for (int f = 0; f < feats; ++f) unsafeAtomicAdd(gW + o * feats + f, accW[f]);
+  // one atomic per channel and workgroup (not per thread: 64 addresses would serialise a quarter million atomics)
+  for (int f = 0; f < 8; ++f) red[il][o][f] = accW[f];
+  red[il][o][8] = accb;
+  __syncthreads();
+  if (il == 0) {
+    for (int f = 0; f <= 8; ++f) {
+      float v = 0.0f;
+      for (int r = 0; r < 8; ++r) v += red[r][o][f];
+      if (f == 8) unsafeAtomicAdd(gb + o, v);
+      else if (f < feats) unsafeAtomicAdd(gW + o * feats + f, v);
+    }
+  }
 }
 __global__ void __launch_bounds__(256)
 gnn_t_edge_init_bwd(int E, const float *attr, const float *W, const float *b, const float *gw, float *gW, float *gb) {
+  __shared__ float red[8][TU][2];
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
   float accW = 0.0f, accb = 0.0f;
   for (int e = blockIdx.x * 8 + il; e < E; e += gridDim.x * 8) {
@@ -538,8 +550,14 @@ gnn_t_edge_init_bwd(int E, const float *attr, const float *W, const float *b, co
     const float g = gw[(size_t)e * TU + o] * t_dsilu(fmaf(a, W[o], b[o]));
     accb += g; accW = fmaf(g, a, accW);
   }
-  unsafeAtomicAdd(gb + o, accb);
-  unsafeAtomicAdd(gW + o, accW);
+  red[il][o][0] = accW; red[il][o][1] = accb;
+  __syncthreads();
+  if (il == 0) {
+    float vw = 0.0f, vb = 0.0f;
+    for (int r = 0; r < 8; ++r) { vw += red[r][o][0]; vb += red[r][o][1]; }
+    unsafeAtomicAdd(gW + o, vw);
+    unsafeAtomicAdd(gb + o, vb);
+  }
 }
 
 // mean / biased variance of every BatchNorm (for the running-statistics update on the host side)
@@ -674,10 +692,10 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, be_s, gge, gbee);
     hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, bv_s, ggv, gbv_);
   }
-  hipLaunchKernelGGL(gnn_t_node_init_bwd, dim3(node_blocks < 256 ? node_blocks : 256), dim3(256), 0, s, n, feats, x, t.a0, t.gx,
+  hipLaunchKernelGGL(gnn_t_node_init_bwd, dim3(node_blocks < 128 ? node_blocks : 128), dim3(256), 0, s, n, feats, x, t.a0, t.gx,
                      grad_params, grad_params + 32 * feats);
   const float *W0e = params + 32 * feats + 32;
-  hipLaunchKernelGGL(gnn_t_edge_init_bwd, dim3(E / 8 + 1 < 1024 ? E / 8 + 1 : 1024), dim3(256), 0, s, E, edge_attr, W0e, W0e + 32, t.gw,
+  hipLaunchKernelGGL(gnn_t_edge_init_bwd, dim3(E / 64 + 1 < 512 ? E / 64 + 1 : 512), dim3(256), 0, s, E, edge_attr, W0e, W0e + 32, t.gw,
                      grad_params + 32 * feats + 32, grad_params + 32 * feats + 64);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("gnn train backward launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
