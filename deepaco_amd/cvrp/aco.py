@@ -113,9 +113,13 @@ class ACO():
         if self.shortest_path is not None:
             shortest[0, :self.shortest_path.numel()] = self.shortest_path
         flags_seen = torch.zeros(1, dtype=torch.int32, device=dev)
+        # one private copy for the whole loop (see tsp/aco.py run): updated in place, rebound at the end
+        tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+        eta = self.heuristic.detach()
+        cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
         for _ in range(n_iterations):
             paths, _, _, lens, flags, costs, table = engine.cvrp_sample(
-                self.pheromone.detach(), self.heuristic.detach(), self.demand, self.capacity, self.n_ants, self.alpha,
+                tau, eta, self.demand, self.capacity, self.n_ants, self.alpha,
                 self.beta, mode=self.sampler, seed=self.seed, it=self._calls, batch=1, dist=dist, want_table=True)
             self._calls += 1
             flags_seen |= flags
@@ -124,14 +128,12 @@ class ACO():
             cmin = cmax = None
             if self.min_max:
                 if self.max is None:
-                    self.pheromone *= new_max[0] / self.pheromone.max()
+                    tau *= new_max[0] / tau.max()
                 self.max = new_max[0]
-                cmin = torch.full((1,), float(self.min), device=dev)
-                cmax = new_max
-            tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+                cmin, cmax = cmin_t, new_max
             engine.pheromone_update_(tau, paths, costs, self.decay, self.elitist, False, cmin, cmax, floor=1e-10,
                                      nbr=table)
-            self.pheromone = tau[0]
+        self.pheromone = tau[0]
         fl = int(flags_seen[0])                      # the only host sync of the loop
         if fl & 1:
             raise ValueError("ACO.run: a transition row had no feasible candidate")

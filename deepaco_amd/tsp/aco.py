@@ -119,9 +119,14 @@ class ACO():
         lowest = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(1).clone()
         shortest = (self.shortest_path.clone() if self.shortest_path is not None else
                     torch.zeros(self.problem_size, dtype=torch.int64, device=dev)).reshape(1, -1).contiguous()
+        # one private copy for the whole loop, updated in place and rebound at the end (the reference rebinds
+        # self.pheromone every iteration, tsp/aco.py:101: a tensor the caller still holds is never modified)
+        tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+        eta = self.heuristic.detach()
+        cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
         for _ in range(n_iterations):
             paths, _, _, flags, costs, nbr = engine.tsp_sample(
-                self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha, self.beta, mode=self.sampler,
+                tau, eta, self.n_ants, self.alpha, self.beta, mode=self.sampler,
                 norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
                 dist=dist, want_nbr=True)
             self._calls += 1
@@ -132,13 +137,11 @@ class ACO():
             cmin = cmax = None
             if self.min_max:
                 if self.max is None:
-                    self.pheromone *= new_max[0] / self.pheromone.max()
+                    tau *= new_max[0] / tau.max()
                 self.max = new_max[0]
-                cmin = torch.full((1,), float(self.min), device=dev)
-                cmax = new_max
-            tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+                cmin, cmax = cmin_t, new_max
             engine.pheromone_update_(tau, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
-            self.pheromone = tau[0]
+        self.pheromone = tau[0]
         self.lowest_cost, self.shortest_path = lowest[0], shortest[0]
         return self.lowest_cost
 
