@@ -36,10 +36,36 @@ __host__ __device__ inline size_t off_head(int feats) { return off_layer(feats, 
 constexpr int HEAD_FLOATS = 2 * (32 * 32 + 32) + 32 + 1;
 constexpr int GNN_SPLIT_MIN_EDGES = 200000;   // above this a layer is two launches (edge | node), below it one
 
-// 1/(1+e^-x) with the hardware reciprocal (1 ulp) instead of the IEEE division sequence: the two
-// activations are evaluated 2*E*32 times per layer and were a quarter of the layer's VALU work
-__device__ inline float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+// Activations.  e^-x in six full-rate instructions instead of libm's twelve (the two activations are evaluated 2*E*32 times
+// per layer and were most of a layer's VALU work): t = -x*log2(e) as the rounded product plus its exact residual (two fmas,
+// the second adds the low word of log2 e), 2^t on the hardware exponential (its range reduction is exact), first-order
+// correction for the residual: ~1 ulp, like libm.  1/(1+e^-x) with the hardware reciprocal (1 ulp).  The two-wide
+// versions are the same arithmetic on v_pk_* instructions.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299e-8f, LN2F = 0.693147182464599609375f;
+__device__ inline float exp_neg(float x) {
+  const float nx = fminf(-x, 87.0f);                      // beyond: e^-x > 1e37, sigmoid and silu are 0 to f32 either way
+  const float t = nx * L2E_HI;
+  const float lo = fmaf(nx, L2E_LO, fmaf(nx, L2E_HI, -t));
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, lo * LN2F, e);
+}
+__device__ inline float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_neg(x)); }
 __device__ inline float silu(float x) { return x * sigmoidf(x); }
+__device__ inline f32x2 sigmoid2(f32x2 x) {
+  f32x2 nx;
+  nx.x = fminf(-x.x, 87.0f); nx.y = fminf(-x.y, 87.0f);
+  const f32x2 hi = {L2E_HI, L2E_HI}, lw = {L2E_LO, L2E_LO}, ln2 = {LN2F, LN2F}, one = {1.0f, 1.0f};
+  const f32x2 t = nx * hi;
+  const f32x2 lo = __builtin_elementwise_fma(nx, lw, __builtin_elementwise_fma(nx, hi, -t));
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const f32x2 d = one + __builtin_elementwise_fma(e, lo * ln2, e);
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return r;
+}
+__device__ inline f32x2 silu2(f32x2 x) { return x * sigmoid2(x); }
 
 // x = silu(v_lin0(x)); X1234(0) = layer-0 node linears.  8 nodes per 256-thread workgroup.
 __global__ void __launch_bounds__(256)
@@ -249,6 +275,205 @@ gnn_node_kernel(int n, int feats, int layer, const int *dst, const int *rowptr, 
   node_update(n, blockIdx.x, feats, layer, dst, rowptr, perm, params, sv, tv, x0, X, w0, x1out, Xnext, xs);
 }
 
+// ---------------- fused layer for src-sorted edge lists (perm == nullptr; the reference's k-NN graphs are built that way,
+// tsp/utils.py:16-27): a wave owns NPW consecutive nodes AND their out-edges, so the old edge state is read once -- it feeds
+// the edge update (w') and, through gate = sigmoid(w0), the node aggregation -- instead of once per half.  Per 32-edge tile:
+// the MFMA tile GEMM and the edge-major epilogue of edge_update, plus gate * x2[dst] written channel-major into a second
+// wave-private LDS tile; lane = channel then adds the tile's edges in edge order, cutting at the nodes' CSR boundaries
+// (wave-uniform scalars).  The wave finishes its nodes itself: x' and the next layer's four node linears.
+// Sum order of the aggregation: the node's edges in list order (a fixed order; the split kernels add four interleaved
+// partial sums -- both are within the fixtures' tolerance of the reference's scatter-mean).
+constexpr int FUSED_MAX_NPW = 16;
+__global__ void __launch_bounds__(256, 3)
+gnn_fused_layer_kernel(int n, int E, int feats, int layer, int npw, const int *src, const int *dst, const int *rowptr,
+                       const float *params, const float *x0, const float *X, const float *w0, float *x1out, float *Xnext,
+                       float *w1out) {
+  __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];
+  __shared__ __attribute__((aligned(16))) float prod_s[4][32][36];            // [channel][edge of the tile]
+  __shared__ float agg_s[4][FUSED_MAX_NPW][U];
+  __shared__ __attribute__((aligned(16))) float we_s[32][36];                 // We, re-read per tile (16 registers less)
+  const float *lp = params + off_layer(feats, layer);
+  const float *We = lp + 32 * 128 + 128, *be = We + 32 * 32;
+  const float *sv = be + 32, *tv = sv + 32, *se = tv + 32, *te = se + 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  *reinterpret_cast<float4 *>(&we_s[threadIdx.x >> 3][(threadIdx.x & 7) * 4]) = *reinterpret_cast<const float4 *>(We + threadIdx.x * 4);
+  __syncthreads();                                                            // the only workgroup barrier
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.  All workgroups are resident at once, so
+  // with the natural numbering every XCD would gather node rows of every graph (64 x TSP-500: 16 MB).  Renumbered, XCD x
+  // owns one contiguous eighth of the nodes -- its gathers stay inside a few graphs' rows (2 MB).
+  const int per_xcd = (int)gridDim.x >> 3;                                    // the grid is a multiple of 8
+  const int block = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  const int i0 = (block * 4 + wave) * npw;
+  if (i0 >= n) return;
+  const int cnt = min(npw, n - i0);
+  // the wave's CSR boundaries live in lanes 0..cnt of one register (read back with v_readlane: the walk below must not
+  // touch memory, a vector load there would drain the prefetch queue)
+  const int rp = rowptr[i0 + min(lane, cnt)];
+  auto row_at = [&](int j) { return __builtin_amdgcn_readlane(rp, j); };
+  const int ebeg = row_at(0), eend = row_at(cnt);
+  float (*tile)[36] = tile_s[wave], (*prod)[36] = prod_s[wave];
+  const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
+#pragma unroll
+  for (int j = 0; j < FUSED_MAX_NPW; ++j) agg_s[wave][j][o] = 0.0f;           // nodes without out-edges aggregate 0
+  const float bias_h = be[o];                       // the accumulator starts from the bias (lane = output channel)
+  const float4 sc = *reinterpret_cast<const float4 *>(se + c0), sh = *reinterpret_cast<const float4 *>(te + c0);
+  // walk state of the aggregation: node i0 + cur collects edges up to seg_end
+  int cur = 0, seg_end = row_at(1);
+  while (cur < cnt && seg_end <= ebeg) { ++cur; seg_end = cur < cnt ? row_at(cur + 1) : 0x7fffffff; }
+  float run = 0.0f;
+  // Every load of the loop is unconditional (edge ids clamped to the wave's last edge; the stores and the products are
+  // masked instead), so one iteration's twelve gathers and the next tile's rows are all in flight together: eight lanes per
+  // edge (4 channels each), eight edges per pass, four passes per tile.
+  const int g8 = lane >> 3, elast = eend - 1;
+  float4 res[4];
+  int sn[4], dn[4];
+  if (ebeg < eend) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = min(ebeg + q * 8 + g8, elast);
+      res[q] = *reinterpret_cast<const float4 *>(w0 + (size_t)e * U + c0);
+      sn[q] = src[e]; dn[q] = dst[e];
+    }
+  }
+  for (int e0 = ebeg; e0 < eend; e0 += 32) {
+    float4 a3[4], a4[4], x2[4], old[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      old[q] = res[q];
+      *reinterpret_cast<float4 *>(&tile[q * 8 + g8][c0]) = old[q];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (values the compiler would otherwise keep across iterations -- a 16-register accumulator seed, the We operands --
+    // and then spill are made to look loop-variant)
+    f32x16 acc;
+    float seed = bias_h;
+    int opaque = 0;
+    asm volatile("" : "+v"(seed), "+s"(opaque));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = seed;
+    {
+      float a[16], bw[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4 *>(&tile[o][h * 16 + q * 4]);
+        a[q * 4 + 0] = t.x; a[q * 4 + 1] = t.y; a[q * 4 + 2] = t.z; a[q * 4 + 3] = t.w;
+        const float4 u = *reinterpret_cast<const float4 *>(&we_s[o][h * 16 + q * 4 + opaque * 4]);
+        bw[q * 4 + 0] = u.x; bw[q * 4 + 1] = u.y; bw[q * 4 + 2] = u.z; bw[q * 4 + 3] = u.w;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bw[kk], acc, 0, 0, 0);
+    }
+    // The gates sigmoid(w0) need nothing but the old rows: they are computed here, between the sixteen dependent MFMAs
+    // (64 cycles each, during which the wave would otherwise issue nothing) -- half of the tile's activation work.
+    f32x2 gate[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x2 w01 = {old[q].x, old[q].y}, w23 = {old[q].z, old[q].w};
+      gate[q][0] = sigmoid2(w01);
+      gate[q][1] = sigmoid2(w23);
+      asm volatile("" : "+v"(gate[q][0]), "+v"(gate[q][1]));                   // computed here, not sunk to their use
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA ...
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);                     // ... then ten VALU instructions of the gates
+    }
+    __builtin_amdgcn_sched_barrier(0);                                        // (nothing else moves into the chain)
+    // behind the matrix work: this tile's twelve gathers, then the next tile's rows and node ids
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a3[q] = *reinterpret_cast<const float4 *>(X + (size_t)sn[q] * 128 + 64 + c0);
+      a4[q] = *reinterpret_cast<const float4 *>(X + (size_t)dn[q] * 128 + 96 + c0);
+      x2[q] = *reinterpret_cast<const float4 *>(X + (size_t)dn[q] * 128 + 32 + c0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = min(e0 + 32 + q * 8 + g8, elast);
+      res[q] = *reinterpret_cast<const float4 *>(w0 + (size_t)e * U + c0);
+      sn[q] = src[e]; dn[q] = dst[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[drow(r, lane)][o] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + g8, e = e0 + el;
+      const bool live = e < eend;
+      const float4 g = *reinterpret_cast<const float4 *>(&tile[el][c0]);
+      const f32x2 y01 = {fmaf(g.x + a3[q].x + a4[q].x, sc.x, sh.x), fmaf(g.y + a3[q].y + a4[q].y, sc.y, sh.y)};
+      const f32x2 y23 = {fmaf(g.z + a3[q].z + a4[q].z, sc.z, sh.z), fmaf(g.w + a3[q].w + a4[q].w, sc.w, sh.w)};
+      const f32x2 s01 = silu2(y01), s23 = silu2(y23);
+      const f32x2 g01 = gate[q][0], g23 = gate[q][1];
+      if (live) {
+        float4 out;
+        out.x = old[q].x + s01.x; out.y = old[q].y + s01.y; out.z = old[q].z + s23.x; out.w = old[q].w + s23.y;
+        *reinterpret_cast<float4 *>(w1out + (size_t)e * U + c0) = out;
+      }
+      prod[c0 + 0][el] = live ? g01.x * x2[q].x : 0.0f;
+      prod[c0 + 1][el] = live ? g01.y * x2[q].y : 0.0f;
+      prod[c0 + 2][el] = live ? g23.x * x2[q].z : 0.0f;
+      prod[c0 + 3][el] = live ? g23.y * x2[q].w : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane = channel: the tile's 32 products in edge order, cut at the CSR boundaries
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      const float4 v4 = *reinterpret_cast<const float4 *>(&prod[o][j * 4]);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        run += v[k];
+        const int enext = e0 + j * 4 + k + 1;
+        if (enext == seg_end) {
+          agg_s[wave][cur][o] = run;
+          run = 0.0f;
+          do { ++cur; seg_end = cur < cnt ? row_at(cur + 1) : 0x7fffffff; } while (cur < cnt && seg_end <= enext);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the wave's nodes, four at a time: x' = x0 + silu(bn_v(x1 + mean)), then the next layer's node linears (lane -> outputs
+  // lane and lane + 64; the weights are read once per group of four nodes)
+  const float *WT = params + off_layer(feats, layer + 1), *bv = WT + 32 * 128;
+  for (int j0 = 0; j0 < cnt; j0 += 4) {
+    float xn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xn[j] = 0.0f;
+      if (j0 + j < cnt) {
+        const int i = i0 + j0 + j;
+        const int deg = row_at(j0 + j + 1) - row_at(j0 + j);
+        const float agg = agg_s[wave][j0 + j][o] / (float)max(deg, 1);
+        const float y = fmaf(X[(size_t)i * 128 + o] + agg, sv[o], tv[o]);
+        xn[j] = x0[(size_t)i * U + o] + silu(y);
+        if (h == 0) x1out[(size_t)i * U + o] = xn[j];
+      }
+    }
+    if (layer == 11) continue;
+    float y0[4], y1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { y0[j] = bv[lane]; y1[j] = bv[64 + lane]; }
+    for (int c = 0; c < U; ++c) {
+      const float wa = WT[c * 128 + lane], wb = WT[c * 128 + 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xc = __shfl(xn[j], c, 64);
+        y0[j] = fmaf(xc, wa, y0[j]);
+        y1[j] = fmaf(xc, wb, y1[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j0 + j < cnt) {
+        Xnext[(size_t)(i0 + j0 + j) * 128 + lane] = y0[j];
+        Xnext[(size_t)(i0 + j0 + j) * 128 + 64 + lane] = y1[j];
+      }
+  }
+}
+
 // head: heu = sigmoid(W3 silu(W2 silu(W1 w + b1) + b2) + b3), three chained tile GEMMs
 __global__ void __launch_bounds__(256)
 gnn_head_kernel(int E, int feats, const float *params, const float *w, float *heu) {
@@ -325,10 +550,31 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
   hipLaunchKernelGGL(gnn_node_init_kernel, dim3(node_blocks), dim3(256), 0, s, n, feats, x, params, xb[0], Xb[0]);
   hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 8 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
   int cur = 0;
+  // tuning / test knobs, read per call: the edge count from which a layer leaves the single-launch kernel, and the fused
+  // kernel's nodes per wave (0: the split edge | node kernels)
+  const int split_min = getenv("DACO_GNN_SPLIT_MIN_EDGES") ? atoi(getenv("DACO_GNN_SPLIT_MIN_EDGES")) : GNN_SPLIT_MIN_EDGES;
+  const int fused_npw = getenv("DACO_GNN_FUSED_NPW") ? atoi(getenv("DACO_GNN_FUSED_NPW")) : -1;
+  // nodes per wave of the fused kernel: the launch should fill the device's wave slots (3 per SIMD at its register
+  // budget) a whole number of times -- 1.3 rounds of workgroups cost as much as 2 -- with at most 16 nodes per wave
+  int npw = fused_npw;
+  if (npw < 0) {
+    static int slots = 0;
+    if (!slots) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      slots = cus * 12;
+    }
+    const int rounds = (n + FUSED_MAX_NPW * slots - 1) / (FUSED_MAX_NPW * slots);
+    npw = (n + rounds * slots - 1) / (rounds * slots);
+    if (npw < 4) npw = 4;
+  }
+  if (npw > FUSED_MAX_NPW) npw = FUSED_MAX_NPW;
   for (int l = 0; l < 12; ++l) {
     float *wout = (l == 11 && emb) ? emb : wb[cur ^ 1];
-    static const int split_min = getenv("DACO_GNN_SPLIT_MIN_EDGES") ? atoi(getenv("DACO_GNN_SPLIT_MIN_EDGES")) : GNN_SPLIT_MIN_EDGES;
-    if (E < split_min) {
+    if (E >= split_min && !perm && fused_npw != 0) {
+      hipLaunchKernelGGL(gnn_fused_layer_kernel, dim3((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8)), dim3(256), 0, s, n, E, feats, l,
+                         npw, src, dst, rowptr, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
+    } else if (E < split_min) {
       hipLaunchKernelGGL(gnn_layer_kernel, dim3(edge_blocks + node_blocks), dim3(256), 0, s, n, E, feats, l, edge_blocks, src,
                          dst, rowptr, perm, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
     } else {

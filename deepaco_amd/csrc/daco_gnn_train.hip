@@ -51,14 +51,23 @@ __device__ inline f32x16 mfma32(f32x16 acc, FA a, FB b) {
 }
 constexpr f32x16 ZERO16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-// per-channel batch statistics of graph g: mean and 1/sqrt(var + eps) from the f64 sums
+// per-channel batch statistics of graph g: (mean, 1/sqrt(var + eps)), tabulated once per BatchNorm from the f64 sums by
+// gnn_t_stat_table (the consumers read two floats per element instead of redoing an f64 divide and square root)
 struct Stat { float mean, rstd; };
-__device__ inline Stat load_stat(const double *sums, int g, int c, int count) {
-  const double s = sums[((size_t)g * 32 + c) * 2], q = sums[((size_t)g * 32 + c) * 2 + 1];
+__device__ inline Stat load_stat(const float2 *tab, int g, int c, int /*count*/) {
+  const float2 t = tab[(size_t)g * 32 + c];
+  return Stat{t.x, t.y};
+}
+// forward table: (mean, rstd); backward table: (sum(g_y) / count, sum(g_y * zhat) / count)
+__global__ void gnn_t_stat_table(int G, int count, const double *sums, float2 *tab, int backward) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * 32) return;
+  const double s = sums[(size_t)idx * 2], q = sums[(size_t)idx * 2 + 1];
+  if (backward) { tab[idx] = make_float2((float)(s / count), (float)(q / count)); return; }
   const double m = s / count;
   double v = q / count - m * m;
   v = v < 0.0 ? 0.0 : v;
-  return Stat{(float)m, (float)(1.0 / sqrt(v + (double)BN_EPS))};
+  tab[idx] = make_float2((float)m, (float)(1.0 / sqrt(v + (double)BN_EPS)));
 }
 
 // ------------------------------------------------------------------ forward
@@ -135,7 +144,7 @@ gnn_t_node_pre(int n, int ng, const int *dst, const int *rowptr, const int *perm
 
 // w' = w + silu(gamma * (ze - mean) * rstd + beta)
 __global__ void __launch_bounds__(256)
-gnn_t_edge_post(int E, int Eg, const float *gamma, const float *beta, const double *sums, const float *w0, const float *ze,
+gnn_t_edge_post(int E, int Eg, const float *gamma, const float *beta, const float2 *sums, const float *w0, const float *ze,
                 float *w1) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)E * TU) return;
@@ -147,7 +156,7 @@ gnn_t_edge_post(int E, int Eg, const float *gamma, const float *beta, const doub
 
 // x' = x + silu(bn_v(zv)); then the NEXT layer's node linears X' = x' Wv^T + bv (WT/bv = next layer's, or null)
 __global__ void __launch_bounds__(256)
-gnn_t_node_post(int n, int ng, const float *gamma, const float *beta, const double *sums, const float *x0, const float *zv,
+gnn_t_node_post(int n, int ng, const float *gamma, const float *beta, const float2 *sums, const float *x0, const float *zv,
                 float *x1, const float *WTnext, const float *bvnext, float *Xnext) {
   __shared__ float xs[8][TU];
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
@@ -342,7 +351,7 @@ gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const f
 
 // sum(g_y), sum(g_y * zhat) per channel and graph for an [R,32] tensor (edges or nodes); g_y = gout * dsilu(y)
 __global__ void __launch_bounds__(256)
-gnn_t_bwd_stats(int R, int Rg, const float *gamma, const float *beta, const double *fsums, const float *z, const float *gout,
+gnn_t_bwd_stats(int R, int Rg, const float *gamma, const float *beta, const float2 *fsums, const float *z, const float *gout,
                 double *bsums) {
   // 8 rows per pass and workgroup-pass; thread = (row slot, channel); rows of one workgroup: a contiguous chunk
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
@@ -365,18 +374,18 @@ gnn_t_bwd_stats(int R, int Rg, const float *gamma, const float *beta, const doub
 }
 
 // g_z of a BatchNorm'd row element: (gamma * rstd) * (g_y - mean(g_y) - zhat * mean(g_y * zhat))
-__device__ inline float bn_bwd(float gout, float z, const Stat &st, float gamma, float beta, const double *bsums, int g, int c,
-                               int count) {
+__device__ inline float bn_bwd(float gout, float z, const Stat &st, float gamma, float beta, const float2 *btab, int g, int c,
+                               int /*count*/) {
   const float zh = (z - st.mean) * st.rstd;
   const float gy = gout * t_dsilu(fmaf(zh, gamma, beta));
-  const float m1 = (float)(bsums[((size_t)g * 32 + c) * 2] / count), m2 = (float)(bsums[((size_t)g * 32 + c) * 2 + 1] / count);
-  return gamma * st.rstd * (gy - m1 - zh * m2);
+  const float2 m = btab[(size_t)g * 32 + c];
+  return gamma * st.rstd * (gy - m.x - zh * m.y);
 }
 
 // node side: g_zv -> gX[:, 0:32] (x1 block) and g_msg = g_zv / degree; BatchNorm parameter gradients
 __global__ void __launch_bounds__(256)
-gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const float *beta, const double *fsums,
-                     const double *bsums, const float *zv, const float *gx, float *gX, float *gmsg) {
+gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const float *beta, const float2 *fsums,
+                     const float2 *bsums, const float *zv, const float *gx, float *gX, float *gmsg) {
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
   const int i = blockIdx.x * 8 + il;
   if (i >= n) return;
@@ -390,7 +399,7 @@ gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const
 // edge side of a layer's backward, waves walk 32-edge tiles
 __global__ void __launch_bounds__(256)
 gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, const float *gamma, const float *beta,
-               const double *fsums, const double *bsums, const float *X, const float *w0, const float *ze, const float *gmsg,
+               const float2 *fsums, const float2 *bsums, const float *X, const float *w0, const float *ze, const float *gmsg,
                float *gw /* in: grad wrt w', out: grad wrt w */, float *gX, float *gWe, float *gbe) {
   __shared__ __attribute__((aligned(16))) float tw_s[4][32][36], tg_s[4][32][36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -579,6 +588,8 @@ static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct TrainWs {
   float *a0, *x[13], *X[12], *w[13], *ze[12], *zv[12];
   double *fsums;   // [12][2][G][32][2]
+  float2 *ftab;    // [12][2][G][32] (mean, rstd)
+  float2 *btab;    // [2][G][32] (mean g_y, mean g_y zhat) of the layer being differentiated
   // backward scratch
   float *gx, *gw, *gX, *gmsg;
   double *bsums;   // [2][G][32][2]
@@ -595,6 +606,8 @@ static TrainWs carve(void *base, int n, int E, int G) {
   for (int l = 0; l < 12; ++l) t.ze[l] = (float *)take((size_t)E * 32 * 4);
   for (int l = 0; l < 12; ++l) t.zv[l] = (float *)take((size_t)n * 32 * 4);
   t.fsums = (double *)take((size_t)12 * 2 * G * 32 * 2 * 8);
+  t.ftab = (float2 *)take((size_t)12 * 2 * G * 32 * 8);
+  t.btab = (float2 *)take((size_t)2 * G * 32 * 8);
   t.gx = (float *)take((size_t)n * 32 * 4);
   t.gw = (float *)take((size_t)E * 32 * 4);
   t.gX = (float *)take((size_t)n * 128 * 4);
@@ -640,11 +653,15 @@ extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int
     const float *lp = params + t_off_layer(feats, l);
     const float *We = lp + 32 * 128 + 128, *be = We + 1024, *gv = be + 32, *bv_ = gv + 32, *ge = bv_ + 32, *bee = ge + 32;
     double *fe = t.fsums + ((size_t)l * 2 + 0) * G * 64, *fv = t.fsums + ((size_t)l * 2 + 1) * G * 64;
+    float2 *fte = t.ftab + ((size_t)l * 2 + 0) * G * 32, *ftv = t.ftab + ((size_t)l * 2 + 1) * G * 32;
+    const unsigned tb = (unsigned)((G * 32 + 255) / 256);
     hipLaunchKernelGGL(gnn_t_edge_pre, dim3(tile_blocks), dim3(256), 0, s, E, Eg, src, dst, We, be, t.X[l], t.w[l], t.ze[l], fe);
     hipLaunchKernelGGL(gnn_t_node_pre, dim3(node_blocks), dim3(256), 0, s, n, ng, dst, rowptr, perm, t.X[l], t.w[l], t.zv[l], fv);
-    hipLaunchKernelGGL(gnn_t_edge_post, dim3(ew_blocks), dim3(256), 0, s, E, Eg, ge, bee, fe, t.w[l], t.ze[l], t.w[l + 1]);
+    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, fe, fte, 0);
+    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, fv, ftv, 0);
+    hipLaunchKernelGGL(gnn_t_edge_post, dim3(ew_blocks), dim3(256), 0, s, E, Eg, ge, bee, fte, t.w[l], t.ze[l], t.w[l + 1]);
     const float *WTn = l < 11 ? params + t_off_layer(feats, l + 1) : nullptr;
-    hipLaunchKernelGGL(gnn_t_node_post, dim3(node_blocks), dim3(256), 0, s, n, ng, gv, bv_, fv, t.x[l], t.zv[l], t.x[l + 1], WTn,
+    hipLaunchKernelGGL(gnn_t_node_post, dim3(node_blocks), dim3(256), 0, s, n, ng, gv, bv_, ftv, t.x[l], t.zv[l], t.x[l + 1], WTn,
                        WTn ? WTn + 32 * 128 : nullptr, l < 11 ? t.X[l + 1] : nullptr);
   }
   hipLaunchKernelGGL(gnn_t_head_fwd, dim3(tile_blocks), dim3(256), 0, s, E, params + t_off_head(feats), t.w[12], heu);
@@ -682,11 +699,16 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     double *be_s = t.bsums, *bv_s = t.bsums + (size_t)G * 64;
     if (hipMemsetAsync(t.bsums, 0, (size_t)2 * G * 64 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
     if (hipMemsetAsync(t.gX, 0, (size_t)n * 128 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
-    hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((E + 255) / 256), dim3(256), 0, s, E, Eg, ge, bee, fe, t.ze[l], t.gw, be_s);
-    hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((n + 255) / 256), dim3(256), 0, s, n, ng, gv, bv_, fv, t.zv[l], t.gx, bv_s);
-    hipLaunchKernelGGL(gnn_t_node_bwd_apply, dim3(node_blocks), dim3(256), 0, s, n, ng, rowptr, gv, bv_, fv, bv_s, t.zv[l], t.gx,
+    const float2 *fte = t.ftab + ((size_t)l * 2 + 0) * G * 32, *ftv = t.ftab + ((size_t)l * 2 + 1) * G * 32;
+    float2 *bte = t.btab, *btv = t.btab + (size_t)G * 32;
+    const unsigned tb = (unsigned)((G * 32 + 255) / 256);
+    hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((E + 255) / 256), dim3(256), 0, s, E, Eg, ge, bee, fte, t.ze[l], t.gw, be_s);
+    hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((n + 255) / 256), dim3(256), 0, s, n, ng, gv, bv_, ftv, t.zv[l], t.gx, bv_s);
+    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, be_s, bte, 1);
+    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, bv_s, btv, 1);
+    hipLaunchKernelGGL(gnn_t_node_bwd_apply, dim3(node_blocks), dim3(256), 0, s, n, ng, rowptr, gv, bv_, ftv, btv, t.zv[l], t.gx,
                        t.gX, t.gmsg);
-    hipLaunchKernelGGL(gnn_t_edge_bwd, dim3(egrid), dim3(256), 0, s, E, Eg, src, dst, We, ge, bee, fe, be_s, t.X[l], t.w[l], t.ze[l],
+    hipLaunchKernelGGL(gnn_t_edge_bwd, dim3(egrid), dim3(256), 0, s, E, Eg, src, dst, We, ge, bee, fte, bte, t.X[l], t.w[l], t.ze[l],
                        t.gmsg, t.gw, t.gX, gWe, gbe);
     hipLaunchKernelGGL(gnn_t_node_lin_bwd, dim3(ngrid), dim3(256), 0, s, n, WT, t.x[l], t.gX, t.gx, gWT, gbv);
     hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, be_s, gge, gbee);

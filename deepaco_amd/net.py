@@ -135,6 +135,23 @@ def _csr_graph(pyg, n, device):
     return graph
 
 
+def _merge_graphs(x, edge_index, edge_attr, k_sparse=None):
+    """B equal-sized graphs as one block-diagonal GraphData.  k_sparse: the caller's promise that every graph is the regular
+    k-nearest-neighbour layout engine.tsp_knn_graph / gen_pyg_data build (edge j*k + t leaves node j): the CSR arrays are then
+    written down directly instead of being derived (sortedness check, bincount, cumsum and a host sync per call)."""
+    B, n, feats = x.shape
+    E = edge_index.shape[2]
+    off = (torch.arange(B, device=x.device, dtype=edge_index.dtype) * n).view(B, 1, 1)
+    ei = (edge_index + off).permute(1, 0, 2).reshape(2, B * E)
+    merged = GraphData(x=x.reshape(B * n, feats), edge_index=ei, edge_attr=edge_attr.reshape(B * E, 1))
+    if k_sparse is not None:
+        if E != n * int(k_sparse):
+            raise _lib.DacoError(f"k_sparse = {k_sparse} does not describe graphs of {n} nodes and {E} edges")
+        rowptr = torch.arange(0, B * n + 1, device=x.device, dtype=torch.int32) * int(k_sparse)
+        merged._daco_graph = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous(), rowptr, None)
+    return merged
+
+
 class _GnnTrainFn(torch.autograd.Function):
     """heu = Net(graph) in training mode; the backward returns d loss / d (flat parameter block)."""
 
@@ -258,16 +275,12 @@ class Net(nn.Module):
         self._update_running_stats(stats, src.numel() // graphs, n // graphs)
         return heu
 
-    def forward_batch_train(self, x, edge_index, edge_attr):
+    def forward_batch_train(self, x, edge_index, edge_attr, k_sparse=None):
         """Training forward for B equal-sized graphs in one pass (tsp_nls/train.py's batch of instances): x [B,n,feats],
         edge_index [B,2,E] (ids local to each graph), edge_attr [B,E(,1)] -> heu [B,E]; graph b is normalised with its own
-        BatchNorm statistics, exactly as B separate training forwards."""
-        B, n, feats = x.shape
-        E = edge_index.shape[2]
-        off = (torch.arange(B, device=x.device, dtype=edge_index.dtype) * n).view(B, 1, 1)
-        merged = GraphData(x=x.reshape(B * n, feats), edge_index=(edge_index + off).permute(1, 0, 2).reshape(2, B * E),
-                           edge_attr=edge_attr.reshape(B * E, 1))
-        return self.forward_train_hip(merged, graphs=B).view(B, E)
+        BatchNorm statistics, exactly as B separate training forwards.  k_sparse: see _merge_graphs."""
+        B, E = x.shape[0], edge_index.shape[2]
+        return self.forward_train_hip(_merge_graphs(x, edge_index, edge_attr, k_sparse), graphs=B).view(B, E)
 
     # ------------------------------------------------------------------ HIP inference path
     def pack_params(self):
@@ -294,19 +307,15 @@ class Net(nn.Module):
         return flat
 
     @torch.no_grad()
-    def forward_batch(self, x, edge_index, edge_attr):
+    def forward_batch(self, x, edge_index, edge_attr, k_sparse=None):
         """Eval-mode forward for B graphs of equal size in ONE pass of the HIP kernels: the graphs are laid side
         by side as one block-diagonal graph (eval-mode BatchNorm is a per-feature affine map, so instances do not
         interact).  x [B,n,feats], edge_index [B,2,E] (node ids local to each graph, e.g. engine.tsp_knn_graph),
-        edge_attr [B,E,1] or [B,E] -> heu [B,E], row b equal to forward() on graph b alone."""
+        edge_attr [B,E,1] or [B,E] -> heu [B,E], row b equal to forward() on graph b alone.  k_sparse: see _merge_graphs."""
         if self.training:
             raise _lib.DacoError("Net.forward_batch is an inference path (BatchNorm running statistics): call .eval()")
-        B, n, feats = x.shape
-        E = edge_index.shape[2]
-        off = (torch.arange(B, device=x.device, dtype=edge_index.dtype) * n).view(B, 1, 1)
-        merged = GraphData(x=x.reshape(B * n, feats), edge_index=(edge_index + off).permute(1, 0, 2).reshape(2, B * E),
-                           edge_attr=edge_attr.reshape(B * E, 1))
-        return self.forward_hip(merged).view(B, E)
+        B, E = x.shape[0], edge_index.shape[2]
+        return self.forward_hip(_merge_graphs(x, edge_index, edge_attr, k_sparse)).view(B, E)
 
     @staticmethod
     def reshape_batch(n_nodes, edge_index, heu):

@@ -28,7 +28,7 @@ def infer_tsp_batch(coords, n_ants, t_aco, k_sparse, net=None, node_feature="coo
         else:
             x = torch.zeros((B, n, 1), device=coords.device)
             x[:, 0] = 1.0
-        heu = net.forward_batch(x, ei, ea)
+        heu = net.forward_batch(x, ei, ea, k_sparse=k_sparse)
         heuristic = net.reshape_batch(n, ei, heu) + EPS
     colony = engine.BatchedTSP(dist, n_ants=n_ants, heuristic=heuristic, sampler=sampler, seed=seed,
                                local_search=local_search, fixed_start=0 if local_search else -1,
@@ -60,7 +60,7 @@ def train_tsp_nls_batch(net, optimizer, coords, n_ants, k_sparse, seed=0, it=0, 
     dist, ei, ea = engine.tsp_knn_graph(coords, k_sparse)
     x = torch.zeros((B, n, 1), device=dev)
     x[:, 0] = 1.0                                                     # tsp_nls/utils.py:38-44: one-hot of the start node
-    heu = net.forward_batch_train(x, ei, ea)
+    heu = net.forward_batch_train(x, ei, ea, k_sparse=k_sparse)
     heu_mat = net.reshape_batch(n, ei, heu) + EPS
     tau = torch.ones((B, n, n), device=dev)
     paths, log_probs, flags = TspBatchSampleFn.apply(heu_mat, tau, n_ants, 1.0, 1.0, "scan", 2, 0, seed, it)

@@ -334,3 +334,58 @@ def test_batched_inference_pipeline():
     torch.testing.assert_close(colony.heuristic, ref.heuristic, rtol=1e-6, atol=1e-12)
     vb, _ = infer_tsp_batch(coords, A, [3], k, net=None, seed=9)          # vanilla heuristic
     assert bool((vb > 0).all())
+
+
+@pytest.mark.parametrize("npw", [4, 7, 11, 16])
+def test_fused_layer_kernel_vs_oracle_on_ragged_sorted_graph(npw, monkeypatch):
+    """The fused layer kernel (src-sorted edge lists; a wave owns nodes and their out-edges) on a graph with uneven
+    degrees, nodes without out-edges at the front, in the middle and at the end, and a node count that is not a multiple
+    of the nodes-per-wave: against the numpy restatement of the reference's forward (tsp/net.py:27-45)."""
+    from deepaco_amd.cvrp.net import Net
+    from deepaco_amd.net import GraphData
+    monkeypatch.setenv("DACO_GNN_SPLIT_MIN_EDGES", "1")
+    monkeypatch.setenv("DACO_GNN_FUSED_NPW", str(npw))
+    torch.manual_seed(2)
+    net = Net().to(dev())
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    net.eval()
+    n = 203
+    gen = torch.Generator().manual_seed(7)
+    deg = torch.randint(0, 90, (n,), generator=gen)
+    deg[:3] = 0; deg[70:75] = 0; deg[-2:] = 0; deg[100] = 200                 # empty runs and one node spanning several tiles
+    src = torch.repeat_interleave(torch.arange(n), deg)
+    E = int(src.numel())
+    dst = torch.randint(0, n, (E,), generator=gen)
+    pyg = GraphData(x=torch.rand(n, 1, generator=gen), edge_index=torch.stack([src, dst]),
+                    edge_attr=torch.rand(E, 1, generator=gen)).to(dev())
+    with torch.no_grad():
+        heu = net(pyg)
+    w = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items() if v.dtype.is_floating_point and v.numel()}
+    ref = ognn.net_forward(w, pyg.x.cpu().numpy(), pyg.edge_index.cpu().numpy(), pyg.edge_attr.cpu().numpy())
+    np.testing.assert_allclose(heu.cpu().numpy(), ref, atol=ATOL_HEU, rtol=1e-4)
+    monkeypatch.setenv("DACO_GNN_FUSED_NPW", "0")                              # the split kernels on the same graph
+    with torch.no_grad():
+        heu_split = net(pyg)
+    torch.testing.assert_close(heu, heu_split, rtol=1e-5, atol=2e-6)
+
+
+def test_fused_layer_kernel_at_bench_size_equals_per_graph():
+    """9 graphs of TSP-500 (k = 50) side by side take the fused layer kernel (E >= 200 000); each graph alone takes the
+    single-launch layer kernel: same heuristic up to the aggregation's summation order."""
+    from deepaco_amd import engine
+    from deepaco_amd.net import GraphData
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(4)
+    d = torch.device("cuda:0")
+    net = Net().to(d).eval()
+    B, n, k = 9, 500, 50
+    coords = torch.rand(B, n, 2, device=d)
+    _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
+    heu = net.forward_batch(coords, ei, ea, k_sparse=k)
+    assert torch.equal(heu, net.forward_batch(coords, ei, ea))          # the CSR shortcut describes the same graph
+    for b in (0, 4, 8):
+        one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
+        torch.testing.assert_close(heu[b], one.view(-1), rtol=1e-5, atol=2e-6)

@@ -77,7 +77,7 @@ def run(cfg):
             coords = torch.rand(B, n, 2, device=dev)
             _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
             with torch.no_grad():
-                t_batch = timeit(lambda: net.forward_batch(coords, ei, ea), 5)
+                t_batch = timeit(lambda: net.forward_batch(coords, ei, ea, k_sparse=k), 5)
             out.append(dict(n=n, k=k, E=n * k, hip_ms=t_hip * 1e3, torch_ops_ms=t_torch * 1e3,
                             hip_batch64_ms=t_batch * 1e3, hip_batch64_ms_per_graph=t_batch * 1e3 / B))
         return dict(config=cfg, desc="Net.forward eval, one instance (HIP kernels vs torch ops on the same GPU)", sizes=out)

@@ -17,6 +17,6 @@ net = Net().to(dev).eval()
 coords = torch.rand(B, n, 2, device=dev)
 _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
 for _ in range(reps):
-    heu = net.forward_batch(coords, ei, ea)
+    heu = net.forward_batch(coords, ei, ea, k_sparse=k)
 torch.cuda.synchronize()
 print("ok", tuple(heu.shape), float(heu.mean()))
