@@ -50,10 +50,14 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     "daco_tsp_knn_graph": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
     "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp]),
+    "daco_two_opt_tables_bytes": (_sz, [_i, _i]),
+    "daco_two_opt_prepare": (_i, [_vp, _i, _i, _vp, _l, _vp, _sz]),
+    "daco_two_opt_nbr": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _vp]),
+    "daco_two_opt_auto": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp, _vp, _vp, _l, _vp]),
 }
 
 
-ABI_VERSION = 115          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 116          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

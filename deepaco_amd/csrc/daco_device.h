@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #define DACO_WAVE 64
+// flag in daco_two_opt_auto's per-tour state word (sweeps done | flag): the search of that tour has ended
+constexpr int TWO_OPT_DONE = 0x40000000;
 
 namespace daco {
 

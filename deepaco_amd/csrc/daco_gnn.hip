@@ -561,7 +561,7 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
     static int slots = 0;
     if (!slots) {
       int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
       slots = cus * 12;
     }
     const int rounds = (n + FUSED_MAX_NPW * slots - 1) / (FUSED_MAX_NPW * slots);

@@ -695,7 +695,6 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     const float *WT = lp, *We = lp + 32 * 128 + 128, *gv = We + 1024 + 32, *bv_ = gv + 32, *ge = bv_ + 32, *bee = ge + 32;
     float *glp = grad_params + t_off_layer(feats, l);
     float *gWT = glp, *gbv = glp + 32 * 128, *gWe = gbv + 128, *gbe = gWe + 1024, *ggv = gbe + 32, *gbv_ = ggv + 32, *gge = gbv_ + 32, *gbee = gge + 32;
-    double *fe = t.fsums + ((size_t)l * 2 + 0) * G * 64, *fv = t.fsums + ((size_t)l * 2 + 1) * G * 64;
     double *be_s = t.bsums, *bv_s = t.bsums + (size_t)G * 64;
     if (hipMemsetAsync(t.bsums, 0, (size_t)2 * G * 64 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
     if (hipMemsetAsync(t.gX, 0, (size_t)n * 128 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }

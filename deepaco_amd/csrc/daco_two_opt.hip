@@ -315,7 +315,10 @@ two_opt_incr_kernel(int n, int T, const float *dist, long dist_bs, uint16_t *tou
 template <int W>
 __global__ void __launch_bounds__(64 * W)
 two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long dist_bs, uint16_t *tours, long max_iterations,
-                     int32_t *sweeps_out) {
+                     int32_t *sweeps_out, int32_t *state, int budget) {
+  // state (daco_two_opt_auto's hand-over between this kernel and the candidate-list kernel): sweeps done so far per tour,
+  // TWO_OPT_DONE set once the search ended; this launch resumes there and does at most `budget` sweeps
+  if (state && (state[blockIdx.x] & TWO_OPT_DONE)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int np4 = (n + 3) / 4 * 4;
   int2 *pe = reinterpret_cast<int2 *>(smem);                       // tour records (see two_opt_kernel)
@@ -364,8 +367,10 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
 
   int p = 1, q = n - 1;                                   // "everything changed" for the first sweep
   bool first = true;
-  long it = 0;
-  while (it < max_iterations) {
+  long it = state ? state[blockIdx.x] : 0;
+  const long stop_at = state ? min(max_iterations, it + (long)budget) : max_iterations;
+  bool ended = false;
+  while (it < stop_at) {
     const int blo = first ? 1 : p, bhi = first ? n - 1 : min(q + 2, n - 1);       // block rows [blo, bhi)
     // (the rows below the block were classified while the previous move was applied: lists and counts are ready)
     const int nfull = first ? 0 : cnt[0], npart = first ? 0 : cnt[1];
@@ -494,7 +499,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     ++it;
     const uint32_t o32 = (uint32_t)(best >> 32);
     const float gk = best == KEY_NONE ? 0.0f : __uint_as_float((o32 >> 31) ? (o32 ^ 0x80000000u) : ~o32);
-    if (!(gk < 0.0f) || !((double)gk < -1e-6)) break;
+    if (!(gk < 0.0f) || !((double)gk < -1e-6)) { ended = true; break; }
     p = bi;
     q = (int)(uint32_t)best;
     first = false;
@@ -532,6 +537,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   }
   for (int k = tid; k < n; k += NT) tour[k] = (uint16_t)(pe[k].x & 0xFFFF);
   if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = (int32_t)it;
+  if (state && tid == 0) state[blockIdx.x] = (int32_t)it | ((ended || it >= max_iterations) ? TWO_OPT_DONE : 0);
 }
 
 }  // namespace daco
@@ -560,8 +566,8 @@ extern "C" int daco_two_opt(void *stream, int B, int T, int n, const float *dist
   auto lds_incr = [&](int W) { return (2 * np4 + 2 * np4 + np4 + np4 + 4 * W + 2 + 6) * sizeof(int); };
   auto lds_incr2 = [&](int W) { return lds_incr(W) + 8 * sizeof(int) + (size_t)W * 2 * np4 * sizeof(float); };
   switch (variant) {
-    case 32: hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds_incr2(4), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps); break;
-    case 33: hipLaunchKernelGGL((two_opt_incr2_kernel<2>), dim3(B * T), dim3(128), lds_incr2(2), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps); break;
+    case 32: hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds_incr2(4), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps, (int32_t *)nullptr, 0); break;
+    case 33: hipLaunchKernelGGL((two_opt_incr2_kernel<2>), dim3(B * T), dim3(128), lds_incr2(2), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps, (int32_t *)nullptr, 0); break;
     case 16: hipLaunchKernelGGL((two_opt_incr_kernel<1>), dim3(B * T), dim3(64), lds_incr(1), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
     case 17: hipLaunchKernelGGL((two_opt_incr_kernel<2>), dim3(B * T), dim3(128), lds_incr(2), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
     case 18: hipLaunchKernelGGL((two_opt_incr_kernel<4>), dim3(B * T), dim3(256), lds_incr(4), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
@@ -575,5 +581,50 @@ extern "C" int daco_two_opt(void *stream, int B, int T, int n, const float *dist
 #undef DACO_2OPT
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("two_opt_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+namespace daco {
+int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
+                       const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps, int32_t *state,
+                       uint32_t w_switch, int final_pass);
+}
+
+// Both kernels on one call: the candidate-list kernel while a tour's candidate count W stays below w_switch, the dense
+// incremental kernel in slices of `slice` sweeps while it is above (tours fresh from sampling: every pair is a candidate),
+// alternating without a host round trip -- a per-tour state word carries the sweep count across launches, finished
+// tours leave at once.  Whatever is still unfinished after the last slice is completed by the candidate-list kernel.
+extern "C" int daco_two_opt_auto(void *stream, int B, int T, int n, const float *dist, const float *dist_T, long dist_bstride,
+                                 const void *tables, const void *tables_T, uint16_t *tours, long max_iterations,
+                                 int32_t *sweeps) {
+  if (B <= 0 || T <= 0 || n < 4 || !dist || !tours || !tables || !tables_T || !sweeps || max_iterations < 0) {
+    set_error("daco_two_opt_auto: bad argument (B=%d T=%d n=%d)", B, T, n);
+    return DACO_E_BADARG;
+  }
+  if (n > 1024) { set_error("daco_two_opt_auto: n=%d above 1024", n); return DACO_E_TOOLARGE; }
+  if (max_iterations >= TWO_OPT_DONE) max_iterations = TWO_OPT_DONE - 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sweeps, 0, (size_t)B * T * sizeof(int32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+  // measured crossovers at n = 500 (tools/bench_two_opt_nbr.py, profiles/r02_two_opt_nbr.txt): the dense kernel's cost grows
+  // with the length of the reversed segment, the candidate kernel's with the candidate count.  Repairing a perturbed tour
+  // on the distance matrix reverses long segments: candidates win up to ~50-60 k per sweep; the 20 perturbation sweeps on
+  // the heuristic-derived (asymmetric) matrix reverse short ones: the dense kernel wins from ~25 k.
+  uint32_t w_switch = (uint32_t)((double)n * n / (tables == tables_T ? 5.0 : 10.0));
+  if (const char *ev = getenv("DACO_TWO_OPT_SWITCH")) w_switch = (uint32_t)atol(ev);
+  int slice = n / 10 < 32 ? 32 : n / 10, slices = 5;
+  if (const char *ev = getenv("DACO_TWO_OPT_SLICE")) slice = atoi(ev);
+  if (const char *ev = getenv("DACO_TWO_OPT_SLICES")) slices = atoi(ev);
+  const size_t np4 = (size_t)(n + 3) / 4 * 4;
+  const size_t lds = (2 * np4 + 2 * np4 + np4 + np4 + 4 * 4 + 2 + 6) * sizeof(int) + 8 * sizeof(int) + (size_t)4 * 2 * np4 * sizeof(float);
+  for (int r = 0; r < slices; ++r) {
+    int rc = launch_two_opt_nbr(s, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, nullptr, sweeps, w_switch, 0);
+    if (rc != DACO_OK) return rc;
+    hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds, s, n, T, dist, dist_T, dist_bstride, tours,
+                       max_iterations, (int32_t *)nullptr, sweeps, slice);
+  }
+  int rc = launch_two_opt_nbr(s, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, nullptr, sweeps, 0xffffffffu, 1);
+  if (rc != DACO_OK) return rc;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("two_opt_auto launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }

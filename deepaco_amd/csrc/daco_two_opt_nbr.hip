@@ -1,0 +1,316 @@
+// daco_two_opt_nbr.hip -- best-improvement 2-opt with neighbour-list candidate pruning, one workgroup per tour.
+//
+// Reference behaviour replaced: tsp_nls/two_opt.py:6-49 (two_opt_once evaluates every pair 1 <= i < j <= n-1 per sweep).
+// This kernel applies exactly the reference's moves but evaluates only the pairs that can win.  With
+//   change(i,j) = ((a + b) - c) - e,  a = d[t[i-1]][t[j]], b = d[t[i]][t[j+1]], c = d[t[i-1]][t[i]], e = d[t[j]][t[j+1]]
+// a pair with a >= c + tol and b >= e + tol has a real-valued change >= 2 tol; the three f32 roundings of the
+// reference's expression move it by at most 2.5 ulp(2M) (M = largest off-diagonal |d|), so with tol = 4 ulp(2M) its
+// computed change is > 0 and it can never be the strict minimum below the reference's initial delta = 0.  Every other
+// pair is evaluated with the reference's own expression (same loads, same three roundings, no FMA) and the minimum is
+// taken with ties to the first (i,j) in row-major order -- so the chosen move, the tours and the sweep counts are
+// bit-identical to the dense kernels (daco_two_opt.hip) and to the reference; only the work differs.
+//
+// Candidates come from tables built once per distance matrix (daco_two_opt_prepare):
+//   nb[x][k]  = (d[x][v], v) for the k-th nearest v of x (ascending (d, v))        8 bytes per entry
+//   rk[x][y]  = #{v : d[x][v] < d[x][y] + tol}                                       uint16
+// For the tour edge at positions (m, m+1) = (x, y):
+//   side A (row i = m+1):  the rk[x][y] nearest v of x are the t[j] with a < c + tol          -> pairs (m+1, pos[v])
+//   side B (column j = m): the rkT[y][x] nearest u of y IN THE TRANSPOSED matrix are the t[i] with b < e + tol
+//                                                                                              -> pairs (pos[u], m)
+// (for a symmetric matrix the transposed tables are the same tables).  The value stored in the table is one of the
+// two loads of the pair; the other is a gather from the matrix.  A sweep is: prefix sum of the 2n candidate counts,
+// then per 2048 candidates an expansion of the lists into (list, k) records in LDS and a flat, balanced loop over the
+// records (two 8-byte LDS records, one table entry, one matrix gather per candidate), a workgroup arg-min on the packed
+// key (ordered change, i, j), the reversal, and the refresh of the records / ranks of the edges p-1 .. q.
+// W is a few thousand for tours near a local optimum (perturbation and repair sweeps of the NLS: ~3-6 k at n = 500
+// against 125 k pairs) and approaches 2 n^2 / 2 for tours with many long edges; callers choose (engine.two_opt_).
+#include <cstdlib>
+
+#include "daco_device.h"
+#include "../../include/deepaco_hip.h"
+
+namespace daco {
+
+struct NbrEntry { float d; uint32_t id; };
+
+constexpr size_t NBR_HEADER = 256;            // per-instance header: [0] bits of M = max off-diagonal |d|
+__host__ __device__ inline size_t nbr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t nbr_instance_bytes(int n) {
+  return NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)) + nbr_align((size_t)n * n * sizeof(uint16_t));
+}
+__device__ inline const NbrEntry *nbr_nb(const unsigned char *tab) { return reinterpret_cast<const NbrEntry *>(tab + NBR_HEADER); }
+__device__ inline const uint16_t *nbr_rk(const unsigned char *tab, int n) {
+  return reinterpret_cast<const uint16_t *>(tab + NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)));
+}
+
+// f32 -> u32 with the same order (negative values reversed, sign flipped)
+__device__ inline uint32_t ord_f32(float x) {
+  const uint32_t u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float unord_f32(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+// ------------------------------------------------------------------ tables
+__global__ void __launch_bounds__(256)
+nbr_maxabs_kernel(int n, const float *dist, long bstride, unsigned char *tabs, size_t tab_stride) {
+  const int b = blockIdx.y;
+  const float *d = dist + (size_t)b * bstride;
+  float m = 0.0f;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)n * n; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx / n), y = (int)(idx - (long)x * n);
+    if (x != y) m = fmaxf(m, fabsf(d[idx]));            // (NaN entries are ignored by fmaxf; inf is kept)
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(tabs + (size_t)b * tab_stride), __float_as_uint(m));
+}
+
+__device__ inline float nbr_tol(float M) {
+  const float v = 2.0f * M;
+  if (!(v < 3.0e38f)) return __uint_as_float(0x7f800000u);                   // inf / overflow: every pair is a candidate
+  return 4.0f * (__uint_as_float(__float_as_uint(v) & 0x7f800000u) * 1.1920928955078125e-07f);   // 4 ulp(2M)
+}
+
+// one workgroup per matrix row: bitonic sort of (ordered d, id) keys in LDS, then the tolerance ranks
+__global__ void __launch_bounds__(256)
+nbr_sort_rows_kernel(int n, int P2, const float *dist, long bstride, unsigned char *tabs, size_t tab_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t *key = reinterpret_cast<uint64_t *>(smem);                          // P2 keys
+  const int b = blockIdx.x / n, x = blockIdx.x - b * n, tid = threadIdx.x;
+  const float *row = dist + (size_t)b * bstride + (size_t)x * n;
+  unsigned char *tab = tabs + (size_t)b * tab_stride;
+  for (int y = tid; y < P2; y += 256)
+    key[y] = y < n ? ((uint64_t)ord_f32(row[y]) << 32) | (uint32_t)y : ~(uint64_t)0;
+  __syncthreads();
+  for (int k = 2; k <= P2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int idx = tid; idx < P2; idx += 256) {
+        const int ixj = idx ^ j;
+        if (ixj > idx) {
+          const uint64_t a = key[idx], c = key[ixj];
+          if ((a > c) == ((idx & k) == 0)) { key[idx] = c; key[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  NbrEntry *nb = const_cast<NbrEntry *>(nbr_nb(tab)) + (size_t)x * n;
+  for (int k = tid; k < n; k += 256) {
+    NbrEntry e;
+    e.d = unord_f32((uint32_t)(key[k] >> 32));
+    e.id = (uint32_t)key[k];
+    nb[k] = e;
+  }
+  const float tol = nbr_tol(__uint_as_float(*reinterpret_cast<const unsigned int *>(tab)));
+  uint16_t *rk = const_cast<uint16_t *>(nbr_rk(tab, n)) + (size_t)x * n;
+  for (int y = tid; y < n; y += 256) {
+    const uint32_t thr = ord_f32(row[y] + tol);
+    int lo = 0, hi = n;                                                         // first k with d_k >= thr
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((uint32_t)(key[mid] >> 32) < thr) lo = mid + 1; else hi = mid;
+    }
+    rk[y] = (uint16_t)lo;
+  }
+}
+
+// ------------------------------------------------------------------ the search
+// LDS: rec[n] {t[k] | t[k+1] << 16, e[k]} | t[n+1] u16 | pos[n] u16 | rA[n] u16 | rB[n] u16 | pre[2n+1] u32 |
+//      queue[NBR_QUEUE] u32 | red[4] u64 | wsum[4] u32
+constexpr int NBR_QUEUE = 2048;               // candidates expanded per pass, one u32 (item << 16 | k) each
+
+__device__ inline uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, s, 64), hi = __shfl_xor((uint32_t)(v >> 32), s, 64);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *tabs, const unsigned char *tabsT,
+                   size_t tab_stride, uint16_t *tours, long max_iterations, int32_t *sweeps_out, int32_t *state,
+                   uint32_t w_switch, int final_pass) {
+  // state / w_switch / final_pass: daco_two_opt_auto's hand-over with the dense kernel (see there).  A tour whose
+  // candidate count exceeds w_switch is left for the dense kernel with its sweep count in the state word.
+  if (state) {
+    const int st = state[blockIdx.x];
+    if (st & TWO_OPT_DONE) {
+      if (final_pass && threadIdx.x == 0) state[blockIdx.x] = st & ~TWO_OPT_DONE;
+      return;
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int np2 = (n + 2) & ~1;
+  int2 *rec = reinterpret_cast<int2 *>(smem);                 // position k: {t[k] | t[k+1] << 16, bits of e[k] = d[t[k]][t[k+1]]}
+  uint16_t *t = reinterpret_cast<uint16_t *>(rec + np2);      // n + 1 (t[n] = t[0])
+  uint16_t *pos = t + np2;
+  uint16_t *rA = pos + np2;
+  uint16_t *rB = rA + np2;
+  uint32_t *pre = reinterpret_cast<uint32_t *>(rB + np2);     // 2n + 1
+  uint32_t *queue = pre + 2 * np2 + 2;                        // NBR_QUEUE records: item << 16 | k
+  uint64_t *red = reinterpret_cast<uint64_t *>(queue + NBR_QUEUE);
+  uint32_t *wsum = reinterpret_cast<uint32_t *>(red + 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / T;
+  const float *d = dist + (size_t)b * dist_bs;
+  const NbrEntry *nb = nbr_nb(tabs + (size_t)b * tab_stride), *nbT = nbr_nb(tabsT + (size_t)b * tab_stride);
+  const uint16_t *rk = nbr_rk(tabs + (size_t)b * tab_stride, n), *rkT = nbr_rk(tabsT + (size_t)b * tab_stride, n);
+  uint16_t *tour = tours + (size_t)blockIdx.x * n;
+
+  for (int k = tid; k < n; k += 256) { const uint16_t v = tour[k]; t[k] = v; pos[v] = (uint16_t)k; }
+  __syncthreads();
+  if (tid == 0) t[n] = t[0];
+  __syncthreads();
+  // edge m = (t[m], t[m+1]): its record and the candidate counts of its two sides
+  auto refresh_edge = [&](int m) {
+    const int x = t[m], y = t[m + 1];
+    rec[m] = make_int2(x | (y << 16), __float_as_int(d[(size_t)x * n + y]));
+    rA[m] = rk[(size_t)x * n + y];
+    rB[m] = rkT[(size_t)y * n + x];
+  };
+  for (int m = tid; m < n; m += 256) refresh_edge(m);
+  __syncthreads();
+
+  const int items = 2 * n, ipt = (items + 255) / 256;         // candidate lists: item 2m = side A of edge m, 2m+1 = side B
+  auto count_of = [&](int item) -> uint32_t {
+    const int m = item >> 1;
+    return (item & 1) ? (m >= 2 ? rB[m] : 0) : (m <= n - 3 ? rA[m] : 0);
+  };
+  long it = state ? state[blockIdx.x] : 0;
+  bool handed_over = false;
+  while (it < max_iterations) {
+    // ---- prefix sum of the candidate counts (thread tid owns items tid*ipt ..)
+    {
+      const int i0 = tid * ipt;
+      uint32_t local = 0;
+      for (int q = 0; q < ipt; ++q)
+        if (i0 + q < items) local += count_of(i0 + q);
+      uint32_t inc = local;
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) { const uint32_t o = __shfl_up(inc, s, 64); if (lane >= s) inc += o; }
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      uint32_t base = inc - local;
+      for (int w = 0; w < wave; ++w) base += wsum[w];
+      for (int q = 0; q < ipt; ++q)
+        if (i0 + q < items) { pre[i0 + q] = base; base += count_of(i0 + q); }
+      if (tid == 255) pre[items] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      __syncthreads();
+    }
+    const uint32_t W = pre[items];
+    if (W > w_switch) { handed_over = true; break; }          // uniform
+    ++it;
+    uint64_t best = ~(uint64_t)0;
+    for (uint32_t c0 = 0; c0 < W; c0 += NBR_QUEUE) {
+      // ---- expand the items overlapping [c0, c0 + NBR_QUEUE) into (item, k) records
+      for (int item = tid; item < items; item += 256) {
+        const uint32_t lo = pre[item], hi = pre[item + 1];
+        if (hi > c0 && lo < c0 + NBR_QUEUE) {
+          const uint32_t from = lo > c0 ? lo : c0, to = hi < c0 + NBR_QUEUE ? hi : c0 + NBR_QUEUE;
+          for (uint32_t w = from; w < to; ++w) queue[w - c0] = ((uint32_t)item << 16) | (w - lo);
+        }
+      }
+      __syncthreads();
+      // ---- evaluate them: both sides read the record of their own edge m and the record at / before the candidate's position.
+      // (One candidate per thread and trip: the loop is bound by the L1's one tag lookup per clock -- the matrix gather
+      // touches 64 lines per wave -- not by latency; batching eight candidates per thread measured 10 % slower.)
+      const uint32_t cnt = W - c0 < (uint32_t)NBR_QUEUE ? W - c0 : (uint32_t)NBR_QUEUE;
+      for (uint32_t w = tid; w < cnt; w += 256) {
+        const uint32_t qr = queue[w];
+        const int item = (int)(qr >> 16), k = (int)(qr & 0xffff), m = item >> 1;
+        const bool sideB = item & 1;
+        const int2 r1 = rec[m];
+        const int centre = sideB ? (int)((uint32_t)r1.x >> 16) : (r1.x & 0xffff);          // t[m+1] | t[m]
+        const NbrEntry en = (sideB ? nbT : nb)[(size_t)centre * n + k];
+        const int pw = pos[en.id];
+        const bool ok = sideB ? (pw >= 1 && pw < m) : (pw > m + 1);
+        const int2 r2 = rec[sideB ? max(pw - 1, 0) : pw];
+        // side A: i = m + 1, j = pw: a = table, b = d[t[i]][t[j+1]]; side B: i = pw, j = m: b = table, a = d[t[i-1]][t[j]]
+        const int u1 = sideB ? (r2.x & 0xffff) : (int)((uint32_t)r1.x >> 16);
+        const int u2 = sideB ? (r1.x & 0xffff) : (int)((uint32_t)r2.x >> 16);
+        const float g = ok ? d[(size_t)u1 * n + u2] : 0.0f;
+        const float c = __int_as_float(sideB ? r2.y : r1.y), ej = __int_as_float(sideB ? r1.y : r2.y);
+        const float change = ((en.d + g) - c) - ej;                                          // a + b = b + a exactly
+        const uint32_t ij = sideB ? (((uint32_t)pw << 16) | (uint32_t)m) : (((uint32_t)(m + 1) << 16) | (uint32_t)pw);
+        const uint64_t key = ((uint64_t)ord_f32(change) << 32) | ij;
+        best = (ok && key < best) ? key : best;
+      }
+      __syncthreads();
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    uint64_t g = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) g = red[w] < g ? red[w] : g;
+    const float delta = g == ~(uint64_t)0 ? 0.0f : unord_f32((uint32_t)(g >> 32));
+    if (!((double)delta < -1e-6)) break;                      // `if delta < -1e-6` (two_opt.py:25); uniform
+    const int p = (int)((g >> 16) & 0xffff), q = (int)(g & 0xffff);
+    // ---- reverse t[p..q], refresh what depends on it
+    const int L = q - p + 1;
+    for (int k = tid; k < (L >> 1); k += 256) { const uint16_t u = t[p + k], v = t[q - k]; t[p + k] = v; t[q - k] = u; }
+    __syncthreads();
+    for (int k = tid; k < L; k += 256) pos[t[p + k]] = (uint16_t)(p + k);
+    for (int m = p - 1 + tid; m <= q; m += 256) refresh_edge(m);   // (q <= n-1: edge n-1 ends at t[n] = t[0], unchanged as p >= 1)
+    __syncthreads();
+  }
+  for (int k = tid; k < n; k += 256) tour[k] = t[k];
+  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = (int32_t)it;
+  if (state && tid == 0) state[blockIdx.x] = (int32_t)it | ((handed_over || final_pass) ? 0 : TWO_OPT_DONE);
+}
+
+}  // namespace daco
+
+using namespace daco;
+
+extern "C" size_t daco_two_opt_tables_bytes(int B, int n) {
+  if (B <= 0 || n < 4) return 0;
+  return (size_t)B * nbr_instance_bytes(n);
+}
+
+extern "C" int daco_two_opt_prepare(void *stream, int B, int n, const float *dist, long dist_bstride, void *tables,
+                                    size_t tables_bytes) {
+  if (B <= 0 || n < 4 || !dist || !tables) { set_error("daco_two_opt_prepare: bad argument (B=%d n=%d)", B, n); return DACO_E_BADARG; }
+  if (n > 1024) { set_error("daco_two_opt_prepare: n=%d above 1024 (row sort in LDS)", n); return DACO_E_TOOLARGE; }
+  if (tables_bytes < daco_two_opt_tables_bytes(B, n)) { set_error("daco_two_opt_prepare: tables too small"); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t stride = nbr_instance_bytes(n);
+  unsigned char *tabs = (unsigned char *)tables;
+  for (int b = 0; b < B; ++b)
+    if (hipMemsetAsync(tabs + (size_t)b * stride, 0, NBR_HEADER, s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+  int P2 = 4;
+  while (P2 < n) P2 <<= 1;
+  hipLaunchKernelGGL(nbr_maxabs_kernel, dim3(16, B), dim3(256), 0, s, n, dist, dist_bstride, tabs, stride);
+  hipLaunchKernelGGL(nbr_sort_rows_kernel, dim3((unsigned)B * n), dim3(256), (size_t)P2 * 8, s, n, P2, dist, dist_bstride, tabs, stride);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("two_opt table kernels launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
+namespace daco {
+int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
+                       const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps, int32_t *state,
+                       uint32_t w_switch, int final_pass) {
+  const int np2 = (n + 2) & ~1;
+  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)(2 * np2 + 2) * 4 + (size_t)NBR_QUEUE * 4 + 4 * 8 + 4 * 4 + 16;
+  hipLaunchKernelGGL(two_opt_nbr_kernel, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
+                     (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
+                     sweeps, state, w_switch, final_pass);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("two_opt_nbr_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+}  // namespace daco
+
+extern "C" int daco_two_opt_nbr(void *stream, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
+                                const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps) {
+  if (B <= 0 || T <= 0 || n < 4 || !dist || !tours || !tables || !tables_T || max_iterations < 0) {
+    set_error("daco_two_opt_nbr: bad argument (B=%d T=%d n=%d)", B, T, n);
+    return DACO_E_BADARG;
+  }
+  if (n > 1024) { set_error("daco_two_opt_nbr: n=%d above 1024", n); return DACO_E_TOOLARGE; }
+  return launch_two_opt_nbr((hipStream_t)stream, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, sweeps,
+                            nullptr, 0xffffffffu, 0);
+}

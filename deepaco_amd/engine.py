@@ -443,13 +443,74 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
     return tau
 
 
-def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None):
+class TwoOptTables:
+    """Sorted neighbour lists + tolerance ranks of a batch of matrices for the candidate-list 2-opt kernel
+    (daco_two_opt_prepare).  Built once per matrix; `tables_t` are the tables of the transposed matrices (the same
+    object for symmetric matrices)."""
+
+    def __init__(self, dist, dist_t=None):
+        _require_gpu(dist)
+        n = dist.shape[-1]
+        if n > 1024:
+            raise _lib.DacoError(f"two_opt tables: n = {n} above 1024")
+        if dist_t is None:
+            dist_t = transposed_for_two_opt(dist)
+        self.n = n
+        self.dist_t = dist_t                       # what two_opt_'s dense kernel wants as well
+        self.tables = self._build(dist)
+        self.tables_t = self.tables if isinstance(dist_t, str) or dist_t is dist else self._build(dist_t)
+
+    @staticmethod
+    def _build(m):
+        n = m.shape[-1]
+        m, dbs = _bstride(m, n)
+        B = 1 if m.dim() == 2 else m.shape[0]
+        L = _lib.lib()
+        dev = m.device
+        with torch.cuda.device(dev):
+            nbytes = L.daco_two_opt_tables_bytes(B, n)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = L.daco_two_opt_prepare(_stream(dev), B, n, m.data_ptr(), dbs, buf.data_ptr(), nbytes)
+        _lib.check(rc, "daco_two_opt_prepare")
+        return buf
+
+
+def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None, tables=None, kernel="auto"):
     """In-place batched 2-opt (tsp_nls/two_opt.py:41-49).  dist [B,n,n] or [n,n];
     tours [B,T,n] or [T,n] int16/uint16 storage (values < 65536), one ROW per tour.
     dist_t: the transposed matrices (same shape as dist), "symmetric" if dist equals its transpose, or None: only
-    changes how the kernel reads the matrix (see include/deepaco_hip.h), never the result."""
+    changes how the kernel reads the matrix (see include/deepaco_hip.h), never the result.
+    tables: a TwoOptTables of `dist` -> the candidate-list kernel takes over whenever a tour's candidate count is small
+    (same moves, same result; far less work per sweep on tours near a local optimum, more on tours with many long edges:
+    kernel="auto" switches per tour between it and the dense kernel, kernel="nbr" forces the candidate lists)."""
     _require_gpu(dist, tours)
     n = dist.shape[-1]
+    if tables is not None:
+        assert tours.dtype in (torch.int16, torch.uint16) and tours.is_contiguous() and tables.n == n
+        t3 = tours if tours.dim() == 3 else tours.unsqueeze(0)
+        shape = t3.shape[:2]
+        dist, dbs = _bstride(dist, n)
+        if dist.dim() == 2:                         # one matrix (and one table set) for every tour
+            t3 = t3.view(1, -1, n)
+        B, T, _ = t3.shape
+        dev = tours.device
+        with torch.cuda.device(dev):
+            if kernel == "nbr":
+                sweeps = torch.empty(tuple(shape), dtype=torch.int32, device=dev) if want_sweeps else None
+                rc = _lib.lib().daco_two_opt_nbr(_stream(dev), B, T, n, dist.data_ptr(), dbs, tables.tables.data_ptr(),
+                                                 tables.tables_t.data_ptr(), t3.data_ptr(), int(max_iterations),
+                                                 sweeps.data_ptr() if want_sweeps else None)
+            else:
+                assert kernel == "auto"
+                dt = tables.dist_t
+                dt = dist if isinstance(dt, str) else (None if dt is None else _bstride(dt, n)[0])
+                sweeps = torch.empty(tuple(shape), dtype=torch.int32, device=dev)
+                rc = _lib.lib().daco_two_opt_auto(_stream(dev), B, T, n, dist.data_ptr(),
+                                                  dt.data_ptr() if dt is not None else None, dbs,
+                                                  tables.tables.data_ptr(), tables.tables_t.data_ptr(), t3.data_ptr(),
+                                                  int(max_iterations), sweeps.data_ptr())
+        _lib.check(rc, "daco_two_opt_" + kernel)
+        return (tours, sweeps) if want_sweeps else tours
     if isinstance(dist_t, str):
         assert dist_t == "symmetric"
         dist_t = dist
@@ -505,27 +566,38 @@ def transposed_for_two_opt(m):
     return "symmetric" if bool(torch.equal(m, mt)) else mt.contiguous()
 
 
-def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuristic_dist_t=None):
+def two_opt_tables(dist, dist_t=None):
+    """TwoOptTables(dist) where the candidate-list kernel applies (n <= 1024), else None (two_opt_ then runs the dense kernel)."""
+    return TwoOptTables(dist, dist_t) if dist.shape[-1] <= 1024 else None
+
+
+def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuristic_dist_t=None, tables=None,
+         heuristic_tables=None):
     """Batched NLS driver (tsp_nls/aco.py:241-258) fully on the device.
     dist, heuristic_dist [B,n,n]; tours [B,T,n] int16 (one row per tour).  Returns improved tours.
-    dist_t / heuristic_dist_t: see two_opt_ (callers that run many iterations pass them once)."""
+    dist_t / heuristic_dist_t, tables / heuristic_tables: see two_opt_ (callers that run many iterations pass them once;
+    the tables are built here otherwise -- one sort of every matrix row -- since the 21 passes of one NLS amortise them)."""
     B, T, n = tours.shape
     if dist_t is None:
-        dist_t = transposed_for_two_opt(dist)
+        dist_t = transposed_for_two_opt(dist) if tables is None else tables.dist_t
     if heuristic_dist_t is None:
-        heuristic_dist_t = transposed_for_two_opt(heuristic_dist)
+        heuristic_dist_t = transposed_for_two_opt(heuristic_dist) if heuristic_tables is None else heuristic_tables.dist_t
+    if tables is None:
+        tables = two_opt_tables(dist, dist_t)
+    if heuristic_tables is None:
+        heuristic_tables = two_opt_tables(heuristic_dist, heuristic_dist_t)
 
     def lengths(t):
         return tour_costs(dist, t.permute(0, 2, 1).to(torch.int64).contiguous())
 
     best = tours.clone().contiguous()
-    two_opt_(dist, best, maxt, dist_t=dist_t)
+    two_opt_(dist, best, maxt, dist_t=dist_t, tables=tables)
     best_costs = lengths(best)
     new = best
     for _ in range(T_nls):
         pert = new.clone()
-        two_opt_(heuristic_dist, pert, T_p, dist_t=heuristic_dist_t)
-        two_opt_(dist, pert, maxt, dist_t=dist_t)
+        two_opt_(heuristic_dist, pert, T_p, dist_t=heuristic_dist_t, tables=heuristic_tables)
+        two_opt_(dist, pert, maxt, dist_t=dist_t, tables=tables)
         new = pert
         new_costs = lengths(new)
         improved = new_costs < best_costs
@@ -571,6 +643,7 @@ class BatchedTSP:
         self._hdist = None
         self._hdist_t = None
         self._dist_t = None
+        self._tables = self._htables = None
         self._cmin = None
 
     def _heuristic_dist(self):
@@ -602,13 +675,16 @@ class BatchedTSP:
             maxt = 10000 if self.inference else self.n // 4
             if self._dist_t is None:
                 self._dist_t = transposed_for_two_opt(self.distances)
+                self._tables = two_opt_tables(self.distances, self._dist_t)
             if self.local_search == "2opt":
-                two_opt_(self.distances, tours, maxt, dist_t=self._dist_t)
+                two_opt_(self.distances, tours, maxt, dist_t=self._dist_t, tables=self._tables)
             else:
                 hd = self._heuristic_dist()
                 if self._hdist_t is None:
                     self._hdist_t = transposed_for_two_opt(hd)
-                tours = nls_(self.distances, hd, tours, maxt, dist_t=self._dist_t, heuristic_dist_t=self._hdist_t)
+                    self._htables = two_opt_tables(hd, self._hdist_t)
+                tours = nls_(self.distances, hd, tours, maxt, dist_t=self._dist_t, heuristic_dist_t=self._hdist_t,
+                             tables=self._tables, heuristic_tables=self._htables)
             paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
             costs, nbr = tour_costs(self.distances, paths), None
         # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)

@@ -131,6 +131,16 @@ class ACO(_TspACO):
             cache[name] = hit
         return hit[1]
 
+    def _tables(self, name):
+        """engine.TwoOptTables of self.<name> (neighbour lists for the candidate-list 2-opt kernel), once per matrix object."""
+        cache = self.__dict__.setdefault("_tab_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] is not getattr(self, name):
+            m = getattr(self, name).detach().to(torch.float32)
+            hit = (getattr(self, name), engine.two_opt_tables(m, self._transposed(name)))
+            cache[name] = hit
+        return hit[1]
+
     def _tours(self, paths):
         return paths.T.contiguous().to(torch.int16)
 
@@ -143,7 +153,8 @@ class ACO(_TspACO):
     @torch.no_grad()
     def two_opt(self, paths, inference=False):
         maxt = 10000 if inference else self.problem_size // 4
-        best = two_opt_device(self.distances, self._tours(paths), maxt, self._transposed("distances"))
+        best = two_opt_device(self.distances, self._tours(paths), maxt, self._transposed("distances"),
+                              self._tables("distances"))
         return self._paths(best)
 
     @torch.no_grad()
@@ -151,13 +162,14 @@ class ACO(_TspACO):
         maxt = 10000 if inference else self.problem_size // 4
         dist = self.distances.to(torch.float32)
         dist_t, hd_t = self._transposed("distances"), self._transposed("heuristic_dist")
-        best_paths = two_opt_device(dist, self._tours(paths), maxt, dist_t)
+        tabs, hd_tabs = self._tables("distances"), self._tables("heuristic_dist")
+        best_paths = two_opt_device(dist, self._tours(paths), maxt, dist_t, tabs)
         best_costs = self._tour_costs(best_paths)
         new_paths = best_paths
 
         for _ in range(T_nls):
-            perturbed_paths = two_opt_device(self.heuristic_dist, new_paths, T_p, hd_t)
-            new_paths = two_opt_device(dist, perturbed_paths, maxt, dist_t)
+            perturbed_paths = two_opt_device(self.heuristic_dist, new_paths, T_p, hd_t, hd_tabs)
+            new_paths = two_opt_device(dist, perturbed_paths, maxt, dist_t, tabs)
             new_costs = self._tour_costs(new_paths)
 
             improved = new_costs < best_costs

@@ -20,10 +20,11 @@ except ImportError:
     from deepaco_amd import engine
 
 
-def two_opt_device(dist, tours_i16, max_iterations=1000, dist_t=None):
-    """dist [n,n] or [B,n,n] f32 on device, tours [T,n] or [B,T,n] int16 on device -> new tensor."""
+def two_opt_device(dist, tours_i16, max_iterations=1000, dist_t=None, tables=None):
+    """dist [n,n] or [B,n,n] f32 on device, tours [T,n] or [B,T,n] int16 on device -> new tensor.
+    dist_t / tables: engine.two_opt_'s (how the kernels read the matrix; never the result)."""
     out = tours_i16.clone().contiguous()
-    engine.two_opt_(dist, out, max_iterations, dist_t=dist_t)
+    engine.two_opt_(dist, out, max_iterations, dist_t=dist_t, tables=tables)
     return out
 
 

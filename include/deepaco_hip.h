@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 115 /* 0.1.14: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 116 /* 0.1.15: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -307,6 +307,31 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
  */
 int daco_two_opt(void *stream, int B, int T, int n, const float *dist, const float *dist_T, long dist_bstride,
                  uint16_t *tours, long max_iterations, int32_t *sweeps);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_two_opt_prepare / daco_two_opt_nbr -- the same search as daco_two_opt (tsp_nls/two_opt.py:6-49: same moves,
+ * same tours, same sweep counts, bit for bit), evaluating per sweep only the pairs that can be the reference's strict
+ * minimum: for the tour edge (x, y) the nodes v with d[x][v] < d[x][y] + tol and the nodes u with d[u][y] < d[x][y] + tol
+ * (tol = 4 ulp(2 max|d|) covers the three f32 roundings of the reference's expression; csrc/daco_two_opt_nbr.hip has
+ * the argument).  A few thousand evaluations per sweep instead of n^2/2 once tours are near a local optimum (the
+ * perturbation / repair passes of the NLS); more than n^2/2 for tours with many long edges -- callers choose per call.
+ *   daco_two_opt_prepare: builds, per instance, the sorted neighbour lists and tolerance ranks of `dist` [B][n][n]
+ *          (n <= 1024) into `tables` (daco_two_opt_tables_bytes(B, n) bytes).  Once per matrix.
+ *   daco_two_opt_nbr: tables = prepare(dist); tables_T = prepare(transposed dist), or the same pointer when dist is
+ *          symmetric.  tours / max_iterations / sweeps as daco_two_opt.
+ */
+size_t daco_two_opt_tables_bytes(int B, int n);
+int daco_two_opt_prepare(void *stream, int B, int n, const float *dist, long dist_bstride, void *tables, size_t tables_bytes);
+int daco_two_opt_nbr(void *stream, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
+                     const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps);
+/*   daco_two_opt_auto: both kernels on one call, chosen per tour and per phase of its search without a host round
+ *          trip: the candidate-list kernel while the tour's candidate count is below ~n^2/10, the dense incremental
+ *          kernel (daco_two_opt's; dist_T as there, may be NULL) in slices of sweeps while it is above -- tours fresh
+ *          from sampling start dense and finish on the candidate lists.  Same result as either kernel alone.
+ *          sweeps [B][T] int32 is REQUIRED here (it carries the per-tour state between the launches).
+ */
+int daco_two_opt_auto(void *stream, int B, int T, int n, const float *dist, const float *dist_T, long dist_bstride,
+                      const void *tables, const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_gnn_forward -- replaces Net.forward in eval mode

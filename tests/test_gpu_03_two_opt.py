@@ -202,3 +202,76 @@ def test_reference_test_script_call_pattern_with_host_tensors():
     best_1 = aco.run(n_iterations=1, inference=True)
     best_T = aco.run(n_iterations=4, inference=True)
     assert isinstance(best_1, float) and best_T <= best_1 <= baseline + 1e-6 and best_sample <= baseline
+
+
+@pytest.mark.parametrize("n,Tn,B,maxit", [(4, 3, 1, 50), (5, 4, 2, 50), (33, 6, 1, 1000), (129, 5, 2, 1000), (257, 4, 1, 30),
+                                           (500, 6, 1, 125), (1000, 2, 1, 40)])
+def test_candidate_list_kernel_vs_oracle(n, Tn, B, maxit):
+    """daco_two_opt_nbr (neighbour-list pruning) makes the reference's moves: tours and sweep counts equal the oracle's
+    full evaluation bit for bit, from random permutations (every pair is a candidate at first) to convergence."""
+    from deepaco_amd import engine
+    d = tsp_instance(n, 7 + n, B)
+    rng = np.random.default_rng(n)
+    tours = np.stack([[rng.permutation(n) for _ in range(Tn)] for _ in range(B)]).astype(np.int16)
+    dd = d.to(dev())
+    tabs = engine.TwoOptTables(dd)
+    for kernel in ("nbr", "auto"):
+        out, sweeps = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel=kernel)
+        for b in range(B):
+            ref, rs = oracle.two_opt_batch(d[b].numpy(), tours[b].astype(np.uint16), maxit)
+            assert np.array_equal(out[b].cpu().numpy().astype(np.uint16), ref), (n, b, kernel)
+            assert np.array_equal(sweeps[b].cpu().numpy(), rs), kernel
+
+
+def test_candidate_list_kernel_on_perturbation_and_asymmetric_matrices():
+    """The NLS schedule (2-opt on dist, 20 sweeps on the asymmetric heuristic-derived matrix, 2-opt on dist again) with
+    the candidate-list kernel equals the dense kernels at every stage; a random non-symmetric matrix with values of very
+    different magnitude (tolerance ranks from the largest entry) and a shared [n,n] matrix as well."""
+    from deepaco_amd import engine
+    B, n, A = 2, 300, 48
+    d = tsp_instance(n, 99, B).to(dev())
+    eta = 1 / d
+    paths, _, _, _ = engine.tsp_sample(torch.ones_like(d), eta, A, mode="scan", seed=4, fixed_start=0)
+    tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+    hd = (1 / (eta / eta.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+    td, th = engine.TwoOptTables(d), engine.TwoOptTables(hd)
+    assert th.tables_t is not th.tables
+    t1, s1 = engine.two_opt_(d, tours.clone(), n // 4, want_sweeps=True)
+    u1, r1 = engine.two_opt_(d, tours.clone(), n // 4, want_sweeps=True, tables=td, kernel="nbr")
+    assert torch.equal(t1, u1) and torch.equal(s1, r1)
+    v1, q1 = engine.two_opt_(d, tours.clone(), n // 4, want_sweeps=True, tables=td)          # auto: dense slices first
+    assert torch.equal(t1, v1) and torch.equal(s1, q1)
+    t2, s2 = engine.two_opt_(hd, t1.clone(), 20, want_sweeps=True)
+    u2, r2 = engine.two_opt_(hd, t1.clone(), 20, want_sweeps=True, tables=th, kernel="nbr")
+    assert torch.equal(t2, u2) and torch.equal(s2, r2)
+    v2, q2 = engine.two_opt_(hd, t1.clone(), 20, want_sweeps=True, tables=th)
+    assert torch.equal(t2, v2) and torch.equal(s2, q2)
+    t3, s3 = engine.two_opt_(d, t2.clone(), 10000, want_sweeps=True)
+    u3, r3 = engine.two_opt_(d, t2.clone(), 10000, want_sweeps=True, tables=td, kernel="nbr")
+    assert torch.equal(t3, u3) and torch.equal(s3, r3)
+    v3, q3 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True, tables=td)           # sampled tours to convergence
+    w3, p3 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True)
+    assert torch.equal(v3, w3) and torch.equal(q3, p3)
+    os.environ["DACO_TWO_OPT_SLICE"], os.environ["DACO_TWO_OPT_SLICES"] = "7", "3"   # hand-overs at odd places, unfinished heavy tours
+    try:
+        v4, q4 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True, tables=td)
+    finally:
+        os.environ.pop("DACO_TWO_OPT_SLICE"); os.environ.pop("DACO_TWO_OPT_SLICES")
+    assert torch.equal(v4, w3) and torch.equal(q4, p3)
+    # sparse learned-heuristic style matrix: a plateau of 1e5 off the k-NN graph
+    k = 20
+    _, idx = torch.topk(d, k=k, dim=2, largest=False)
+    h = torch.zeros_like(d).scatter_(2, idx, torch.rand(B, n, k, device=d.device) + 0.05)
+    hp = (1 / (h / h.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+    tp = engine.TwoOptTables(hp)
+    t4, s4 = engine.two_opt_(hp, t3.clone(), 20, want_sweeps=True)
+    u4, r4 = engine.two_opt_(hp, t3.clone(), 20, want_sweeps=True, tables=tp)
+    assert torch.equal(t4, u4) and torch.equal(s4, r4)
+    # random asymmetric matrix, one [n,n] matrix shared by a [B,T,n] batch of tours
+    g = torch.Generator().manual_seed(5)
+    m = (torch.rand(n, n, generator=g) * torch.logspace(-2, 2, n).view(n, 1) + 0.01).to(dev())
+    rng = np.random.default_rng(1)
+    rt = T(np.stack([[rng.permutation(n) for _ in range(8)] for _ in range(2)]).astype(np.int16))
+    t5, s5 = engine.two_opt_(m, rt.clone(), 60, want_sweeps=True)
+    u5, r5 = engine.two_opt_(m, rt.clone(), 60, want_sweeps=True, tables=engine.TwoOptTables(m))
+    assert torch.equal(t5, u5) and torch.equal(s5, r5)
