@@ -318,7 +318,8 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
                      int32_t *sweeps_out, int32_t *state, int budget) {
   // state (daco_two_opt_auto's hand-over between this kernel and the candidate-list kernel): sweeps done so far per tour,
   // TWO_OPT_DONE set once the search ended; this launch resumes there and does at most `budget` sweeps
-  if (state && (state[blockIdx.x] & TWO_OPT_DONE)) return;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);      // an XCD walks consecutive tours: few instances' rows in its L2 at a time
+  if (state && (state[blk] & TWO_OPT_DONE)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int np4 = (n + 3) / 4 * 4;
   int2 *pe = reinterpret_cast<int2 *>(smem);                       // tour records (see two_opt_kernel)
@@ -329,10 +330,10 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   int *cnt = reinterpret_cast<int *>(red + 2 * W);                 // [0] full count, [1] partial count
   float *rows = reinterpret_cast<float *>(cnt + 8);                // W x 2 x np4 staged matrix rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * W;
-  const int b = blockIdx.x / T;
+  const int b = blk / T;
   const float *d = dist + (size_t)b * dist_bs;
   const float *dT = distT ? distT + (size_t)b * dist_bs : nullptr;
-  uint16_t *tour = tours + (size_t)blockIdx.x * n;
+  uint16_t *tour = tours + (size_t)blk * n;
   float *rowA = rows + (size_t)wave * 2 * np4, *rowB = rowA + np4;
   const bool symmetric = distT == dist;                  // (the caller passes the matrix itself as its transpose)
 
@@ -367,7 +368,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
 
   int p = 1, q = n - 1;                                   // "everything changed" for the first sweep
   bool first = true;
-  long it = state ? state[blockIdx.x] : 0;
+  long it = state ? state[blk] : 0;
   const long stop_at = state ? min(max_iterations, it + (long)budget) : max_iterations;
   bool ended = false;
   while (it < stop_at) {
@@ -536,8 +537,8 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     __syncthreads();
   }
   for (int k = tid; k < n; k += NT) tour[k] = (uint16_t)(pe[k].x & 0xFFFF);
-  if (sweeps_out && tid == 0) sweeps_out[blockIdx.x] = (int32_t)it;
-  if (state && tid == 0) state[blockIdx.x] = (int32_t)it | ((ended || it >= max_iterations) ? TWO_OPT_DONE : 0);
+  if (sweeps_out && tid == 0) sweeps_out[blk] = (int32_t)it;
+  if (state && tid == 0) state[blk] = (int32_t)it | ((ended || it >= max_iterations) ? TWO_OPT_DONE : 0);
 }
 
 }  // namespace daco
