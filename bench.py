@@ -271,34 +271,35 @@ def extra_configs(dev, headline_colony):
     dt = time_launches(col.step, 1, warm=1)
     paths, _, _, _ = engine.tsp_sample(col.pheromone, col.heuristic, A, seed=3, batch=B, fixed_start=0)
     tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+    # the first 2-opt pass of the iteration alone (sampled tours, <= n // 4 sweeps), as the colony runs it: candidate-list
+    # kernel / dense incremental kernel chosen per tour (daco_two_opt_auto), tables built once per matrix
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    _, sweeps = engine.two_opt_(col.distances, tours, n // 4, want_sweeps=True, dist_t="symmetric")
+    _, sweeps = engine.two_opt_(col.distances, tours, n // 4, want_sweeps=True, dist_t=col._dist_t, tables=col._tables)
     torch.cuda.synchronize()
     t2 = time.perf_counter() - t0
     nsw = float(sweeps.sum())
-    # Bound of the 2-opt kernel: L2 line requests (rocprofv3 TCP_TCC_READ_REQ x 128 B; a sweep is a few hundred
-    # scattered gathers out of an L2-resident matrix).  The per-sweep figure comes from the counter passes committed
-    # under profiles/ (same workload); it is not collected in this run.
-    l2_per_sweep = l2_src = None
+    # Bound of the 2-opt kernels: L2 line requests (rocprofv3 TCP_TCC_READ_REQ x 128 B; a candidate is one table entry and
+    # one matrix gather out of an L2-resident instance).  The per-tour figure comes from the counter passes committed
+    # under profiles/ (same workload, 16 instances); it is not collected in this run.
+    l2_per_tour = l2_src = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "two_opt_l2.json")))
-        l2_per_sweep, l2_src = tj["l2_read_bytes_per_sweep"], tj["source"]
+        l2_per_tour, l2_src = tj["l2_read_bytes_per_tour_iteration"], tj["source"]
     except Exception:
         pass
-    ach = nsw * l2_per_sweep / t2 / 1e9 if l2_per_sweep else None
+    ach = B * A * l2_per_tour / dt / 1e9 if l2_per_tour else None
     out["c3_tsp500_nls_a256_b64"] = {
-        "workload": f"TSP-{n} + NLS (2-opt kernel; T_nls=10, T_p=20, maxt={n // 4}), n_ants={A}, {B} instances",
+        "workload": f"TSP-{n} + NLS (T_nls=10, T_p=20, maxt={n // 4}; 21 2-opt passes per iteration), n_ants={A}, {B} instances",
         "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3,
-        "two_opt": {"tours": B * A, "sweeps": nsw, "seconds": t2, "sweeps_per_s": nsw / t2,
-                    "full_sweep_pair_evaluations_per_s": nsw * (n - 1) * (n - 2) / 2 / t2,
-                    "survey_8d_gathered_GBps": nsw * (8.0 * (n - 1) * (n - 2) + 4 * n) / t2 / 1e9},
+        "two_opt_first_pass": {"tours": B * A, "sweeps": nsw, "seconds": t2, "sweeps_per_s": nsw / t2,
+                               "reference_pair_evaluations_per_s": nsw * (n - 1) * (n - 2) / 2 / t2},
         "roofline": {"bound": "l2", "achieved": ach, "peak": PEAK_L2_GBS, "unit": "GB/s",
                      "frac": ach / PEAK_L2_GBS if ach else None, "traffic": None, "traffic_source": l2_src,
-                     "kernel": "two_opt_incr2_kernel",
-                     "note": "L2 read requests x 128 B per best-improvement sweep (counter-measured on this workload) x "
-                             "sweeps / kernel time; the kernel is bound by the latency of its chain of dependent L2 round "
-                             "trips per sweep (DESIGN.md 3.4), not by this bandwidth"}}
+                     "kernel": "two_opt_nbr_kernel (+ two_opt_incr2_kernel for tours with long candidate lists)",
+                     "note": "L2 read requests x 128 B of the 2-opt kernels per tour and NLS iteration (counter-measured on "
+                             "this workload) x tours / iteration time; the kernels wait on dependent gathers (waves parked on "
+                             "memory most of the time, DESIGN.md 3.4), they are not bound by this bandwidth"}}
     del col
 
     # headline workload with the LEARNED heuristic: Net + the reference's pretrained tsp500 weights

@@ -612,7 +612,7 @@ extern "C" int daco_two_opt_auto(void *stream, int B, int T, int n, const float 
   // the heuristic-derived (asymmetric) matrix reverse short ones: the dense kernel wins from ~25 k.
   uint32_t w_switch = (uint32_t)((double)n * n / (tables == tables_T ? 5.0 : 10.0));
   if (const char *ev = getenv("DACO_TWO_OPT_SWITCH")) w_switch = (uint32_t)atol(ev);
-  int slice = n / 10 < 32 ? 32 : n / 10, slices = 5;
+  int slice = n / 6 < 48 ? 48 : n / 6, slices = 3;          // (every launch costs ~30 us even when all its tours are elsewhere)
   if (const char *ev = getenv("DACO_TWO_OPT_SLICE")) slice = atoi(ev);
   if (const char *ev = getenv("DACO_TWO_OPT_SLICES")) slices = atoi(ev);
   const size_t np4 = (size_t)(n + 3) / 4 * 4;
