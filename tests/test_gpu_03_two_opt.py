@@ -275,3 +275,41 @@ def test_candidate_list_kernel_on_perturbation_and_asymmetric_matrices():
     t5, s5 = engine.two_opt_(m, rt.clone(), 60, want_sweeps=True)
     u5, r5 = engine.two_opt_(m, rt.clone(), 60, want_sweeps=True, tables=engine.TwoOptTables(m))
     assert torch.equal(t5, u5) and torch.equal(s5, r5)
+
+
+def test_candidate_list_kernel_many_small_cases_with_ties():
+    """Sixty small searches, candidate-list kernel vs dense kernel vs (a third of them) the oracle: integer grid
+    coordinates (many equal distances: tie-breaking on (i, j), tolerance ranks with ties), duplicate points (zero
+    distances), row-scaled and random asymmetric matrices, sweep caps that stop the search midway."""
+    from deepaco_amd import engine
+    rng = np.random.default_rng(2026)
+    for case in range(60):
+        n = int(rng.integers(4, 160))
+        kind = case % 4
+        if kind == 0:                                            # integer grid: ties everywhere
+            c = rng.integers(0, 6, size=(n, 2)).astype(np.float32)
+            d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
+        elif kind == 1:                                          # uniform points, a few duplicated
+            c = rng.random((n, 2)).astype(np.float32)
+            c[rng.integers(0, n, size=max(1, n // 10))] = c[0]
+            d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
+        elif kind == 2:                                          # row-scaled distances (the NLS perturbation matrix's shape)
+            c = rng.random((n, 2)).astype(np.float32)
+            d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
+            d = (d * rng.uniform(1.0, 300.0, size=(n, 1))).astype(np.float32)
+        else:                                                    # random asymmetric
+            d = (rng.random((n, n)) * 10 ** rng.uniform(-2, 4)).astype(np.float32)
+        np.fill_diagonal(d, 1e9)
+        Tn = int(rng.integers(1, 9))
+        maxit = int(rng.choice([1, 3, 17, 10000]))
+        tours = np.stack([rng.permutation(n) for _ in range(Tn)]).astype(np.int16)
+        dd = T(d)
+        tabs = engine.TwoOptTables(dd)
+        a, sa = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True)
+        b, sb = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel="nbr")
+        c2, sc = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs)
+        assert torch.equal(a, b) and torch.equal(sa, sb), (case, n, kind, maxit)
+        assert torch.equal(a, c2) and torch.equal(sa, sc), (case, n, kind, maxit)
+        if case % 3 == 0:
+            ref, rs = oracle.two_opt_batch(d, tours.astype(np.uint16), maxit)
+            assert np.array_equal(a.cpu().numpy().astype(np.uint16), ref) and np.array_equal(sa[0].cpu().numpy(), rs), (case, n, kind)
