@@ -33,7 +33,7 @@ namespace daco {
 
 struct NbrEntry { float d; uint32_t id; };
 
-constexpr size_t NBR_HEADER = 256;            // per-instance header: [0] bits of M = max off-diagonal |d|
+constexpr size_t NBR_HEADER = 256;            // per-instance header: [0] bits of M = max off-diagonal |d|, [1] ~ordered(min off-diagonal d)
 __host__ __device__ inline size_t nbr_align(size_t x) { return (x + 255) & ~(size_t)255; }
 __host__ __device__ inline size_t nbr_instance_bytes(int n) {
   return NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)) + nbr_align((size_t)n * n * sizeof(uint16_t));
@@ -55,14 +55,18 @@ __global__ void __launch_bounds__(256)
 nbr_maxabs_kernel(int n, const float *dist, long bstride, unsigned char *tabs, size_t tab_stride) {
   const int b = blockIdx.y;
   const float *d = dist + (size_t)b * bstride;
-  float m = 0.0f;
+  float m = 0.0f, lo = __builtin_inff();
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)n * n; idx += (long)gridDim.x * 256) {
     const int x = (int)(idx / n), y = (int)(idx - (long)x * n);
-    if (x != y) m = fmaxf(m, fabsf(d[idx]));            // (NaN entries are ignored by fmaxf; inf is kept)
+    if (x != y) { m = fmaxf(m, fabsf(d[idx])); lo = fminf(lo, d[idx]); }   // (NaN entries are ignored; inf is kept)
   }
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int *>(tabs + (size_t)b * tab_stride), __float_as_uint(m));
+  for (int s = 32; s > 0; s >>= 1) { m = fmaxf(m, __shfl_xor(m, s, 64)); lo = fminf(lo, __shfl_xor(lo, s, 64)); }
+  if ((threadIdx.x & 63) == 0) {
+    unsigned int *hdr = reinterpret_cast<unsigned int *>(tabs + (size_t)b * tab_stride);
+    atomicMax(hdr, __float_as_uint(m));
+    atomicMax(hdr + 1, ~ord_f32(lo));                     // a maximum of the complement = the minimum (header starts zeroed)
+  }
 }
 
 __device__ inline float nbr_tol(float M) {
@@ -156,12 +160,15 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
   uint32_t *queue = pre + 2 * np2 + 2;                        // NBR_QUEUE records: item << 16 | k
   uint64_t *red = reinterpret_cast<uint64_t *>(queue + NBR_QUEUE);
   uint32_t *wsum = reinterpret_cast<uint32_t *>(red + 4);
+  uint32_t *incumbent = wsum + 4;                             // ordered image of the best change any thread has seen this sweep
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blk / T;
   const float *d = dist + (size_t)b * dist_bs;
   const NbrEntry *nb = nbr_nb(tabs + (size_t)b * tab_stride), *nbT = nbr_nb(tabsT + (size_t)b * tab_stride);
   const uint16_t *rk = nbr_rk(tabs + (size_t)b * tab_stride, n), *rkT = nbr_rk(tabsT + (size_t)b * tab_stride, n);
   uint16_t *tour = tours + (size_t)blk * n;
+  // smallest off-diagonal entry: the unknown load of a candidate is at least this
+  const float dmin = unord_f32(~reinterpret_cast<const unsigned int *>(tabs + (size_t)b * tab_stride)[1]);
 
   for (int k = tid; k < n; k += 256) { const uint16_t v = tour[k]; t[k] = v; pos[v] = (uint16_t)k; }
   __syncthreads();
@@ -177,10 +184,12 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
   for (int m = tid; m < n; m += 256) refresh_edge(m);
   __syncthreads();
 
-  const int items = 2 * n, ipt = (items + 255) / 256;         // candidate lists: item 2m = side A of edge m, 2m+1 = side B
+  // candidate lists: item m < n = side A of edge m, item n + m = side B of edge m (all A lists first: the lanes of a wave are
+  // then on the same side, except in the one wave that straddles the boundary, and each side's code runs unselected)
+  const int items = 2 * n, ipt = (items + 255) / 256;
   auto count_of = [&](int item) -> uint32_t {
-    const int m = item >> 1;
-    return (item & 1) ? (m >= 2 ? rB[m] : 0) : (m <= n - 3 ? rA[m] : 0);
+    const int m = item < n ? item : item - n;
+    return item >= n ? (m >= 2 ? rB[m] : 0) : (m <= n - 3 ? rA[m] : 0);
   };
   long it = state ? state[blk] : 0;
   bool handed_over = false;
@@ -201,6 +210,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
       for (int q = 0; q < ipt; ++q)
         if (i0 + q < items) { pre[i0 + q] = base; base += count_of(i0 + q); }
       if (tid == 255) pre[items] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (tid == 0) *incumbent = ord_f32(0.0f);               // the reference's `delta = 0`: only negative changes can win
       __syncthreads();
     }
     const uint32_t W = pre[items];
@@ -221,25 +231,50 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
       // (Tried and measured no faster: eight candidates per thread with all loads of a stage in flight -- half the
       // occupancy, 10 % slower; requesting the next candidate's table entry before the current gather is consumed -- equal.)
       const uint32_t cnt = W - c0 < (uint32_t)NBR_QUEUE ? W - c0 : (uint32_t)NBR_QUEUE;
+      // Incumbent filter: f32 addition and subtraction are monotone, so with the unknown load u >= dmin the computed change
+      // ((table + u) - c) - e is >= ((table + dmin) - c) - e =: lb, exactly.  If lb is strictly above a change some
+      // candidate has already achieved (or above the reference's initial delta = 0) this candidate can neither be nor tie
+      // the minimum, and its matrix gather -- the expensive access: one 128-byte L2 line for 4 bytes -- is skipped.  The
+      // incumbent is shared through one LDS word (atomic minimum of the ordered image); which candidates get skipped
+      // depends on timing, the minimum that is found does not.
+      const uint32_t un = (uint32_t)n;
       for (uint32_t w = tid; w < cnt; w += 256) {
         const uint32_t qr = queue[w];
-        const int item = (int)(qr >> 16), k = (int)(qr & 0xffff), m = item >> 1;
-        const bool sideB = item & 1;
-        const int2 r1 = rec[m];
-        const int centre = sideB ? (int)((uint32_t)r1.x >> 16) : (r1.x & 0xffff);          // t[m+1] | t[m]
-        const NbrEntry en = (sideB ? nbT : nb)[(size_t)centre * n + k];
-        const int pw = pos[en.id];
-        const bool ok = sideB ? (pw >= 1 && pw < m) : (pw > m + 1);
-        const int2 r2 = rec[sideB ? max(pw - 1, 0) : pw];
-        // side A: i = m + 1, j = pw: a = table, b = d[t[i]][t[j+1]]; side B: i = pw, j = m: b = table, a = d[t[i-1]][t[j]]
-        const int u1 = sideB ? (r2.x & 0xffff) : (int)((uint32_t)r1.x >> 16);
-        const int u2 = sideB ? (r1.x & 0xffff) : (int)((uint32_t)r2.x >> 16);
-        const float g = ok ? d[(size_t)u1 * n + u2] : 0.0f;
-        const float c = __int_as_float(sideB ? r2.y : r1.y), ej = __int_as_float(sideB ? r1.y : r2.y);
-        const float change = ((en.d + g) - c) - ej;                                          // a + b = b + a exactly
-        const uint32_t ij = sideB ? (((uint32_t)pw << 16) | (uint32_t)m) : (((uint32_t)(m + 1) << 16) | (uint32_t)pw);
-        const uint64_t key = ((uint64_t)ord_f32(change) << 32) | ij;
-        best = (ok && key < best) ? key : best;
+        const uint32_t item = qr >> 16, k = qr & 0xffff;
+        const uint32_t inc = *incumbent;
+        if (item < un) {
+          // side A: i = m + 1, j = pos[v]: a = d[t[m]][v] from the table, b = d[t[i]][t[j+1]] gathered
+          const uint32_t m = item;
+          const int2 r1 = rec[m];
+          const NbrEntry en = nb[(uint32_t)(r1.x & 0xffff) * un + k];
+          const uint32_t j = pos[en.id];
+          const int2 r2 = rec[j];
+          const float c = __int_as_float(r1.y), ej = __int_as_float(r2.y);
+          const float lb = ((en.d + dmin) - c) - ej;
+          if (j > m + 1 && !(ord_f32(lb) > inc)) {
+            const float g = d[((uint32_t)r1.x >> 16) * un + ((uint32_t)r2.x >> 16)];
+            const uint32_t oc = ord_f32(((en.d + g) - c) - ej);
+            const uint64_t key = ((uint64_t)oc << 32) | ((m + 1) << 16) | j;
+            best = key < best ? key : best;
+            if (oc < inc) atomicMin(incumbent, oc);
+          }
+        } else {
+          // side B: j = m, i = pos[u]: b = d[u][t[m+1]] from the (transposed) table, a = d[t[i-1]][t[j]] gathered
+          const uint32_t m = item - un;
+          const int2 r1 = rec[m];
+          const NbrEntry en = nbT[((uint32_t)r1.x >> 16) * un + k];
+          const uint32_t i = pos[en.id];
+          const int2 r2 = rec[i > 0 ? i - 1 : 0];
+          const float c = __int_as_float(r2.y), ej = __int_as_float(r1.y);
+          const float lb = ((en.d + dmin) - c) - ej;
+          if (i >= 1 && i < m && !(ord_f32(lb) > inc)) {
+            const float g = d[(uint32_t)(r2.x & 0xffff) * un + (uint32_t)(r1.x & 0xffff)];
+            const uint32_t oc = ord_f32(((g + en.d) - c) - ej);
+            const uint64_t key = ((uint64_t)oc << 32) | (i << 16) | m;
+            best = key < best ? key : best;
+            if (oc < inc) atomicMin(incumbent, oc);
+          }
+        }
       }
       __syncthreads();
     }
@@ -298,7 +333,7 @@ int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, lo
                        const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps, int32_t *state,
                        uint32_t w_switch, int final_pass) {
   const int np2 = (n + 2) & ~1;
-  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)(2 * np2 + 2) * 4 + (size_t)NBR_QUEUE * 4 + 4 * 8 + 4 * 4 + 16;
+  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)(2 * np2 + 2) * 4 + (size_t)NBR_QUEUE * 4 + 4 * 8 + 4 * 4 + 32;
   hipLaunchKernelGGL(two_opt_nbr_kernel, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
                      (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
                      sweeps, state, w_switch, final_pass);
