@@ -24,6 +24,7 @@
 // key (ordered change, i, j), the reversal, and the refresh of the records / ranks of the edges p-1 .. q.
 // W is a few thousand for tours near a local optimum (perturbation and repair sweeps of the NLS: ~3-6 k at n = 500
 // against 125 k pairs) and approaches 2 n^2 / 2 for tours with many long edges; callers choose (engine.two_opt_).
+#include <cstdio>
 #include <cstdlib>
 
 #include "daco_device.h"
@@ -122,20 +123,28 @@ nbr_sort_rows_kernel(int n, int P2, const float *dist, long bstride, unsigned ch
 //      queue[NBR_QUEUE] u32 | red[4] u64 | wsum[4] u32
 constexpr int NBR_QUEUE = 2048;               // candidates expanded per pass, one u32 (item << 16 | k) each
 
+// minimum of a 64-bit key over the wave on the DPP network of daco_device.h (no LDS traffic), broadcast from lane 63
+template <int CTRL, int ROW_MASK>
+__device__ inline void min_step_u64(uint32_t &hi, uint32_t &lo) {
+  const uint32_t ohi = (uint32_t)dpp_i<CTRL, ROW_MASK, false>((int)hi, (int)hi);     // lanes without a source read themselves
+  const uint32_t olo = (uint32_t)dpp_i<CTRL, ROW_MASK, false>((int)lo, (int)lo);
+  if (ohi < hi || (ohi == hi && olo < lo)) { hi = ohi; lo = olo; }
+}
 __device__ inline uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, s, 64), hi = __shfl_xor((uint32_t)(v >> 32), s, 64);
-    const uint64_t o = ((uint64_t)hi << 32) | lo;
-    v = o < v ? o : v;
-  }
-  return v;
+  uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+  min_step_u64<DPP_ROW_SHR(1), 0xF>(hi, lo);
+  min_step_u64<DPP_ROW_SHR(2), 0xF>(hi, lo);
+  min_step_u64<DPP_ROW_SHR(4), 0xF>(hi, lo);
+  min_step_u64<DPP_ROW_SHR(8), 0xF>(hi, lo);
+  min_step_u64<DPP_ROW_BCAST15, 0xA>(hi, lo);
+  min_step_u64<DPP_ROW_BCAST31, 0xC>(hi, lo);
+  return ((uint64_t)(uint32_t)readlane_i((int)hi, 63) << 32) | (uint32_t)readlane_i((int)lo, 63);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))   // 8 waves per SIMD (800 SGPRs per SIMD)
 two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *tabs, const unsigned char *tabsT,
                    size_t tab_stride, uint16_t *tours, long max_iterations, int32_t *sweeps_out, int32_t *state,
-                   uint32_t w_switch, int final_pass) {
+                   uint32_t w_switch, int final_pass, unsigned long long *prof) {
   // state / w_switch / final_pass: daco_two_opt_auto's hand-over with the dense kernel (see there).  A tour whose
   // candidate count exceeds w_switch is left for the dense kernel with its sweep count in the state word.
   // (tour index: XCD x walks a contiguous eighth of the tours, so the few instances it works on at a time -- matrix
@@ -162,6 +171,11 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
   uint32_t *wsum = reinterpret_cast<uint32_t *>(red + 4);
   uint32_t *incumbent = wsum + 4;                             // ordered image of the best change any thread has seen this sweep
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // prof (DACO_TWO_OPT_PROFILE=1, a debugging aid): shader-clock cycles per phase as thread 0 sees them, summed over tours
+  unsigned long long tmark = prof ? clock64() : 0;
+  auto lap = [&](int slot) {
+    if (prof && tid == 0) { const unsigned long long now = clock64(); atomicAdd(prof + slot, now - tmark); tmark = now; }
+  };
   const int b = blk / T;
   const float *d = dist + (size_t)b * dist_bs;
   const NbrEntry *nb = nbr_nb(tabs + (size_t)b * tab_stride), *nbT = nbr_nb(tabsT + (size_t)b * tab_stride);
@@ -186,6 +200,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
 
   // candidate lists: item m < n = side A of edge m, item n + m = side B of edge m (all A lists first: the lanes of a wave are
   // then on the same side, except in the one wave that straddles the boundary, and each side's code runs unselected)
+  lap(0);                                                     // set-up: tour, positions, all edges' records and ranks
   const int items = 2 * n, ipt = (items + 255) / 256;
   auto count_of = [&](int item) -> uint32_t {
     const int m = item < n ? item : item - n;
@@ -208,25 +223,36 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
       uint32_t base = inc - local;
       for (int w = 0; w < wave; ++w) base += wsum[w];
       for (int q = 0; q < ipt; ++q)
-        if (i0 + q < items) { pre[i0 + q] = base; base += count_of(i0 + q); }
+        if (i0 + q < items) {
+          const uint32_t cq = count_of(i0 + q);
+          pre[i0 + q] = base;
+          // the first NBR_QUEUE candidates are expanded right here (most sweeps near a local optimum have no more)
+          for (uint32_t w = base; w < base + cq && w < (uint32_t)NBR_QUEUE; ++w) queue[w] = ((uint32_t)(i0 + q) << 16) | (w - base);
+          base += cq;
+        }
       if (tid == 255) pre[items] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
       if (tid == 0) *incumbent = ord_f32(0.0f);               // the reference's `delta = 0`: only negative changes can win
       __syncthreads();
     }
     const uint32_t W = pre[items];
+    lap(1);                                                   // prefix sum (+ first chunk's expansion)
     if (W > w_switch) { handed_over = true; break; }          // uniform
     ++it;
+    if (prof && tid == 0) { atomicAdd(prof + 6, 1ull); atomicAdd(prof + 7, (unsigned long long)W); }
     uint64_t best = ~(uint64_t)0;
     for (uint32_t c0 = 0; c0 < W; c0 += NBR_QUEUE) {
-      // ---- expand the items overlapping [c0, c0 + NBR_QUEUE) into (item, k) records
-      for (int item = tid; item < items; item += 256) {
-        const uint32_t lo = pre[item], hi = pre[item + 1];
-        if (hi > c0 && lo < c0 + NBR_QUEUE) {
-          const uint32_t from = lo > c0 ? lo : c0, to = hi < c0 + NBR_QUEUE ? hi : c0 + NBR_QUEUE;
-          for (uint32_t w = from; w < to; ++w) queue[w - c0] = ((uint32_t)item << 16) | (w - lo);
+      // ---- expand the items overlapping [c0, c0 + NBR_QUEUE) into (item, k) records (the first chunk: done above)
+      if (c0 > 0) {
+        __syncthreads();                                      // the previous chunk's records have been consumed
+        for (int item = tid; item < items; item += 256) {
+          const uint32_t lo = pre[item], hi = pre[item + 1];
+          if (hi > c0 && lo < c0 + NBR_QUEUE) {
+            const uint32_t from = lo > c0 ? lo : c0, to = hi < c0 + NBR_QUEUE ? hi : c0 + NBR_QUEUE;
+            for (uint32_t w = from; w < to; ++w) queue[w - c0] = ((uint32_t)item << 16) | (w - lo);
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
       // ---- evaluate them: both sides read the record of their own edge m and the record at / before the candidate's position.
       // (Tried and measured no faster: eight candidates per thread with all loads of a stage in flight -- half the
       // occupancy, 10 % slower; requesting the next candidate's table entry before the current gather is consumed -- equal.)
@@ -276,11 +302,12 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
           }
         }
       }
-      __syncthreads();
     }
+    lap(2);                                                   // evaluation (this wave's share)
     best = wave_min_u64(best);
     if (lane == 0) red[wave] = best;
     __syncthreads();
+    lap(3);                                                   // waiting for the other waves + reduction
     uint64_t g = red[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) g = red[w] < g ? red[w] : g;
@@ -294,6 +321,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
     for (int k = tid; k < L; k += 256) pos[t[p + k]] = (uint16_t)(p + k);
     for (int m = p - 1 + tid; m <= q; m += 256) refresh_edge(m);   // (q <= n-1: edge n-1 ends at t[n] = t[0], unchanged as p >= 1)
     __syncthreads();
+    lap(4);                                                   // reversal, positions, records and ranks of edges p-1 .. q
   }
   for (int k = tid; k < n; k += 256) tour[k] = t[k];
   if (sweeps_out && tid == 0) sweeps_out[blk] = (int32_t)it;
@@ -334,10 +362,24 @@ int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, lo
                        uint32_t w_switch, int final_pass) {
   const int np2 = (n + 2) & ~1;
   const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)(2 * np2 + 2) * 4 + (size_t)NBR_QUEUE * 4 + 4 * 8 + 4 * 4 + 32;
+  unsigned long long *prof = nullptr;
+  if (getenv("DACO_TWO_OPT_PROFILE")) {                       // debugging aid: synchronises and prints
+    if (hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)) != hipSuccess) prof = nullptr;
+    else (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s);
+  }
   hipLaunchKernelGGL(two_opt_nbr_kernel, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
                      (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
-                     sweeps, state, w_switch, final_pass);
+                     sweeps, state, w_switch, final_pass, prof);
   hipError_t e = hipGetLastError();
+  if (prof) {
+    unsigned long long h[8] = {0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(prof);
+    fprintf(stderr, "[two_opt_nbr profile] tours %d sweeps %llu candidates/sweep %.0f | cycles per sweep: prefix %.0f eval %.0f reduce %.0f "
+            "apply %.0f | set-up per tour %.0f\n", B * T, h[6], h[6] ? (double)h[7] / h[6] : 0.0, h[6] ? (double)h[1] / h[6] : 0.0,
+            h[6] ? (double)h[2] / h[6] : 0.0, h[6] ? (double)h[3] / h[6] : 0.0, h[6] ? (double)h[4] / h[6] : 0.0, (double)h[0] / (B * T));
+  }
   if (e != hipSuccess) { set_error("two_opt_nbr_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
 }
