@@ -26,6 +26,8 @@ if total:
                "source": "profiles/${TAG}_pmc_2opt_nls_c3.txt: sum over the 2-opt kernels of TCP_TCC_READ_REQ_sum x dispatches x 128 B / "
                          "(3 iterations x 16 instances x 256 tours) of tools/run_nls_c3.py 16 (rocprofv3 --pmc)"},
               open("$R/profiles/two_opt_l2.json", "w"), indent=1)
+    import shutil
+    shutil.copy("$R/profiles/two_opt_l2.json", "$OUT/two_opt_l2.json")      # (profiles/ on the GPU box does not travel back)
 EOF
 # 2. the bench line, its kernel trace, its counters
 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
