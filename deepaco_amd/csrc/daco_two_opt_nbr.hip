@@ -141,6 +141,11 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
   return ((uint64_t)(uint32_t)readlane_i((int)hi, 63) << 32) | (uint32_t)readlane_i((int)lo, 63);
 }
 
+// SYM (the matrix equals its transpose, one table set): the two lists a tour node is the centre of -- side A of the edge
+// leaving it, side B of the edge entering it -- are prefixes of the SAME sorted list, wanted at later resp. earlier tour
+// positions.  They are walked once, up to the longer of the two ranks, and every entry goes to the side its position
+// selects: half the table loads and position look-ups, and no candidate that is rejected on position alone.
+template <bool SYM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))   // 8 waves per SIMD (800 SGPRs per SIMD)
 two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *tabs, const unsigned char *tabsT,
                    size_t tab_stride, uint16_t *tours, long max_iterations, int32_t *sweeps_out, int32_t *state,
@@ -198,11 +203,16 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
   for (int m = tid; m < n; m += 256) refresh_edge(m);
   __syncthreads();
 
-  // candidate lists: item m < n = side A of edge m, item n + m = side B of edge m (all A lists first: the lanes of a wave are
-  // then on the same side, except in the one wave that straddles the boundary, and each side's code runs unselected)
-  lap(0);                                                     // set-up: tour, positions, all edges' records and ranks
-  const int items = 2 * n, ipt = (items + 255) / 256;
+  // candidate lists.  General: item m < n = side A of edge m, item n + m = side B of edge m (all A lists first: the lanes of
+  // a wave are then on the same side, except in the one wave that straddles the boundary, and each side's code runs
+  // unselected).  SYM: item m = the list of node t[m], m = 0 .. n (t[n] = t[0]: the closing edge's side B), serving side A
+  // of edge m and side B of edge m-1.
+  const int items = SYM ? n + 1 : 2 * n, ipt = (items + 255) / 256;
   auto count_of = [&](int item) -> uint32_t {
+    if (SYM) {
+      const uint32_t ca = item <= n - 3 ? rA[item] : 0, cb = item >= 3 ? rB[item - 1] : 0;
+      return ca > cb ? ca : cb;
+    }
     const int m = item < n ? item : item - n;
     return item >= n ? (m >= 2 ? rB[m] : 0) : (m <= n - 3 ? rA[m] : 0);
   };
@@ -268,7 +278,40 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
         const uint32_t qr = queue[w];
         const uint32_t item = qr >> 16, k = qr & 0xffff;
         const uint32_t inc = *incumbent;
-        if (item < un) {
+        if (SYM) {
+          const uint32_t m = item;                                                           // list of node t[m]
+          const NbrEntry en = nb[(uint32_t)t[m] * un + k];
+          const uint32_t pw = pos[en.id];
+          if (pw > m + 1) {
+            // side A of edge m: i = m + 1, j = pw: a = table, b = d[t[i]][t[j+1]] gathered
+            if (m + 3 <= un && k < rA[m]) {
+              const int2 r1 = rec[m], r2 = rec[pw];
+              const float c = __int_as_float(r1.y), ej = __int_as_float(r2.y);
+              const float lb = ((en.d + dmin) - c) - ej;
+              if (!(ord_f32(lb) > inc)) {
+                const float g = d[((uint32_t)r1.x >> 16) * un + ((uint32_t)r2.x >> 16)];
+                const uint32_t oc = ord_f32(((en.d + g) - c) - ej);
+                const uint64_t key = ((uint64_t)oc << 32) | ((m + 1) << 16) | pw;
+                best = key < best ? key : best;
+                if (oc < inc) atomicMin(incumbent, oc);
+              }
+            }
+          } else if (pw >= 1 && pw + 1 < m) {
+            // side B of edge m - 1: i = pw, j = m - 1: b = d[t[i]][t[j+1]] = table (by symmetry), a = d[t[i-1]][t[j]] gathered
+            if (k < rB[m - 1]) {
+              const int2 rm = rec[m - 1], r2 = rec[pw - 1];
+              const float c = __int_as_float(r2.y), ej = __int_as_float(rm.y);
+              const float lb = ((en.d + dmin) - c) - ej;
+              if (!(ord_f32(lb) > inc)) {
+                const float g = d[(uint32_t)(r2.x & 0xffff) * un + (uint32_t)(rm.x & 0xffff)];
+                const uint32_t oc = ord_f32(((g + en.d) - c) - ej);
+                const uint64_t key = ((uint64_t)oc << 32) | (pw << 16) | (m - 1);
+                best = key < best ? key : best;
+                if (oc < inc) atomicMin(incumbent, oc);
+              }
+            }
+          }
+        } else if (item < un) {
           // side A: i = m + 1, j = pos[v]: a = d[t[m]][v] from the table, b = d[t[i]][t[j+1]] gathered
           const uint32_t m = item;
           const int2 r1 = rec[m];
@@ -367,9 +410,14 @@ int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, lo
     if (hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)) != hipSuccess) prof = nullptr;
     else (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s);
   }
-  hipLaunchKernelGGL(two_opt_nbr_kernel, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
-                     (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
-                     sweeps, state, w_switch, final_pass, prof);
+  if (tables == tables_T)
+    hipLaunchKernelGGL(two_opt_nbr_kernel<true>, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
+                       (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
+                       sweeps, state, w_switch, final_pass, prof);
+  else
+    hipLaunchKernelGGL(two_opt_nbr_kernel<false>, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
+                       (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
+                       sweeps, state, w_switch, final_pass, prof);
   hipError_t e = hipGetLastError();
   if (prof) {
     unsigned long long h[8] = {0};
