@@ -606,10 +606,11 @@ extern "C" int daco_two_opt_auto(void *stream, int B, int T, int n, const float 
   if (max_iterations >= TWO_OPT_DONE) max_iterations = TWO_OPT_DONE - 1;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sweeps, 0, (size_t)B * T * sizeof(int32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
-  // measured crossover at n = 500 (tools/bench_two_opt_nbr.py, profiles/r02_two_opt_nbr.txt): the dense kernel's cost grows with
-  // the length of the reversed segment, the candidate kernel's with the entries it walks; the dense kernel wins from ~25 k
-  // walked entries per sweep (tours fresh from a dense heuristic start at 80-160 k)
-  uint32_t w_switch = (uint32_t)((double)n * n / 10.0);      // (symmetric: every list entry is one candidate, see two_opt_nbr_kernel<SYM>)
+  // measured crossovers at n = 500 (tools/bench_two_opt_nbr.py, profiles/r02_two_opt_nbr.txt): the dense kernel's cost grows with
+  // the length of the reversed segment, the candidate kernel's with the list entries it walks.  Symmetric matrix (every
+  // entry is one candidate; repairs reverse long segments): the dense kernel wins from ~40 k entries per sweep; the 20
+  // perturbation sweeps on the heuristic-derived (non-symmetric: two lists per edge) matrix reverse short segments: ~25 k.
+  uint32_t w_switch = (uint32_t)((double)n * n / (tables == tables_T ? 6.0 : 10.0));
   if (const char *ev = getenv("DACO_TWO_OPT_SWITCH")) w_switch = (uint32_t)atol(ev);
   int slice = n / 6 < 48 ? 48 : n / 6, slices = 3;          // (every launch costs ~30 us even when all its tours are elsewhere)
   if (const char *ev = getenv("DACO_TWO_OPT_SLICE")) slice = atoi(ev);
