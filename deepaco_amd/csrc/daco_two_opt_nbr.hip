@@ -23,7 +23,8 @@
 // records (two 8-byte LDS records, one table entry, one matrix gather per candidate), a workgroup arg-min on the packed
 // key (ordered change, i, j), the reversal, and the refresh of the records / ranks of the edges p-1 .. q.
 // W is a few thousand for tours near a local optimum (perturbation and repair sweeps of the NLS: ~3-6 k at n = 500
-// against 125 k pairs) and approaches 2 n^2 / 2 for tours with many long edges; callers choose (engine.two_opt_).
+// against 125 k pairs) and approaches 2 n^2 / 2 for tours with many long edges: daco_two_opt_auto (daco_two_opt.hip) hands such
+// tours to the dense incremental kernel and takes them back when their lists have become short.
 #include <cstdio>
 #include <cstdlib>
 
