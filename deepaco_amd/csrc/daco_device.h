@@ -32,6 +32,21 @@ __device__ inline int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+// ------------------------------------------------------------------ 2-opt neighbour tables (daco_two_opt_prepare)
+// per instance: header | nb[n][n] sorted (d, id) entries | rk[n][n] tolerance ranks; daco_two_opt_nbr.hip documents them
+struct NbrEntry { float d; uint32_t id; };
+
+constexpr size_t NBR_HEADER = 256;            // per-instance header: [0] bits of M = max off-diagonal |d|, [1] ~ordered(min off-diagonal d)
+__host__ __device__ inline size_t nbr_align(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t nbr_instance_bytes(int n) {
+  return NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)) + nbr_align((size_t)n * n * sizeof(uint16_t));
+}
+__device__ inline const NbrEntry *nbr_nb(const unsigned char *tab) { return reinterpret_cast<const NbrEntry *>(tab + NBR_HEADER); }
+__device__ inline const uint16_t *nbr_rk(const unsigned char *tab, int n) {
+  return reinterpret_cast<const uint16_t *>(tab + NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)));
+}
+
+
 // ------------------------------------------------------------------ DPP helpers
 template <int CTRL, int ROW_MASK, bool BOUND>
 __device__ inline float dpp_f(float old, float src) {

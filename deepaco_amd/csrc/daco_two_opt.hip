@@ -315,7 +315,8 @@ two_opt_incr_kernel(int n, int T, const float *dist, long dist_bs, uint16_t *tou
 template <int W>
 __global__ void __launch_bounds__(64 * W)
 two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long dist_bs, uint16_t *tours, long max_iterations,
-                     int32_t *sweeps_out, int32_t *state, int budget) {
+                     int32_t *sweeps_out, int32_t *state, int budget, const unsigned char *tabs, const unsigned char *tabsT,
+                     size_t tab_stride, int w_exit) {
   // state (daco_two_opt_auto's hand-over between this kernel and the candidate-list kernel): sweeps done so far per tour,
   // TWO_OPT_DONE set once the search ended; this launch resumes there and does at most `budget` sweeps
   const int blk = xcd_remap(blockIdx.x, gridDim.x);      // an XCD walks consecutive tours: few instances' rows in its L2 at a time
@@ -342,6 +343,23 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     pe[k] = make_int2(u | (v << 16), __float_as_int(d[(size_t)u * n + v]));
   }
   __syncthreads();
+  // tabs (daco_two_opt_auto): the neighbour tables' ranks of the tour's edges, summed = the number of list entries the
+  // candidate-list kernel would walk per sweep (x 1/2 when one list serves both sides).  It is kept up to date move by
+  // move -- a reversal changes the ranks of edges p-1 and q only, the inner edges swap sides -- and the tour is handed
+  // back (the loop below ends, the state word stays unfinished) once it has fallen under w_exit.
+  const uint16_t *rk = tabs ? nbr_rk(tabs + (size_t)b * tab_stride, n) : nullptr;
+  const uint16_t *rkT = tabs ? nbr_rk(tabsT + (size_t)b * tab_stride, n) : nullptr;
+  auto rank_sum = [&](int x, int y) { return (int)rk[(size_t)x * n + y] + (int)rkT[(size_t)y * n + x]; };
+  if (tabs) {
+    if (tid == 0) cnt[2] = 0;
+    __syncthreads();
+    int w = 0;
+    for (int k = tid; k < n; k += NT) w += rank_sum(pe[k].x & 0xFFFF, (unsigned)pe[k].x >> 16);
+    for (int o = 32; o >= 1; o >>= 1) w += __shfl_xor(w, o);
+    if (lane == 0) atomicAdd(&cnt[2], w);
+    __syncthreads();
+  }
+  const int w_scale = tabs == tabsT ? 2 : 1;              // symmetric: one walk per node list
   auto stage = [&](float *dst, int node) {                // coalesced copy of row d[node][0..n) into the wave's slot
     const float *src = d + (size_t)node * n;
     for (int k = lane; k < n; k += 64) dst[k] = src[k];
@@ -372,6 +390,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   const long stop_at = state ? min(max_iterations, it + (long)budget) : max_iterations;
   bool ended = false;
   while (it < stop_at) {
+    if (tabs && cnt[2] < w_exit * w_scale) break;         // uniform (cnt[2] was last written before the previous barrier)
     const int blo = first ? 1 : p, bhi = first ? n - 1 : min(q + 2, n - 1);       // block rows [blo, bhi)
     // (the rows below the block were classified while the previous move was applied: lists and counts are ready)
     const int nfull = first ? 0 : cnt[0], npart = first ? 0 : cnt[1];
@@ -507,6 +526,11 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     // ---- apply the move and, in the same phase, classify the rows below the block for the next sweep: recompute in
     // full (cached minimiser inside the changed range) or patch.  (pe was last read before the previous barrier.)
     const int half = (q - p + 1) >> 1;
+    if (tabs && tid == 0) {
+      // (thread 0 owns the swap of positions p and q below; t[p-1] and t[q+1] are not written in this phase)
+      const int a = pe[p - 1].x & 0xFFFF, bq = pe[p].x & 0xFFFF, c = pe[q].x & 0xFFFF, dn = pe[q + 1 < n ? q + 1 : 0].x & 0xFFFF;
+      atomicAdd(&cnt[2], rank_sum(a, c) + rank_sum(bq, dn) - rank_sum(a, bq) - rank_sum(c, dn));
+    }
     for (int k = tid; k < half; k += NT) {
       const int x = pe[p + k].x, y = pe[q - k].x;
       pe[p + k].x = (x & 0xFFFF0000) | (y & 0xFFFF);
@@ -567,8 +591,8 @@ extern "C" int daco_two_opt(void *stream, int B, int T, int n, const float *dist
   auto lds_incr = [&](int W) { return (2 * np4 + 2 * np4 + np4 + np4 + 4 * W + 2 + 6) * sizeof(int); };
   auto lds_incr2 = [&](int W) { return lds_incr(W) + 8 * sizeof(int) + (size_t)W * 2 * np4 * sizeof(float); };
   switch (variant) {
-    case 32: hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds_incr2(4), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps, (int32_t *)nullptr, 0); break;
-    case 33: hipLaunchKernelGGL((two_opt_incr2_kernel<2>), dim3(B * T), dim3(128), lds_incr2(2), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps, (int32_t *)nullptr, 0); break;
+    case 32: hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds_incr2(4), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps, (int32_t *)nullptr, 0, (const unsigned char *)nullptr, (const unsigned char *)nullptr, (size_t)0, 0); break;
+    case 33: hipLaunchKernelGGL((two_opt_incr2_kernel<2>), dim3(B * T), dim3(128), lds_incr2(2), s, n, T, dist, dist_T, dist_bstride, tours, max_iterations, sweeps, (int32_t *)nullptr, 0, (const unsigned char *)nullptr, (const unsigned char *)nullptr, (size_t)0, 0); break;
     case 16: hipLaunchKernelGGL((two_opt_incr_kernel<1>), dim3(B * T), dim3(64), lds_incr(1), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
     case 17: hipLaunchKernelGGL((two_opt_incr_kernel<2>), dim3(B * T), dim3(128), lds_incr(2), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
     case 18: hipLaunchKernelGGL((two_opt_incr_kernel<4>), dim3(B * T), dim3(256), lds_incr(4), s, n, T, dist, dist_bstride, tours, max_iterations, sweeps); break;
@@ -589,6 +613,7 @@ namespace daco {
 int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
                        const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps, int32_t *state,
                        uint32_t w_switch, int final_pass);
+static size_t tables_bytes_per_instance(int n) { return nbr_instance_bytes(n); }
 }
 
 // Both kernels on one call: the candidate-list kernel while a tour's candidate count W stays below w_switch, the dense
@@ -612,18 +637,17 @@ extern "C" int daco_two_opt_auto(void *stream, int B, int T, int n, const float 
   // perturbation sweeps on the heuristic-derived (non-symmetric: two lists per edge) matrix reverse short segments: ~25 k.
   uint32_t w_switch = (uint32_t)((double)n * n / (tables == tables_T ? 6.0 : 10.0));
   if (const char *ev = getenv("DACO_TWO_OPT_SWITCH")) w_switch = (uint32_t)atol(ev);
-  int slice = n / 6 < 48 ? 48 : n / 6, slices = 3;          // (every launch costs ~30 us even when all its tours are elsewhere)
-  if (const char *ev = getenv("DACO_TWO_OPT_SLICE")) slice = atoi(ev);
-  if (const char *ev = getenv("DACO_TWO_OPT_SLICES")) slices = atoi(ev);
+  // hand-over hysteresis: a tour goes to the dense kernel above w_switch walked entries per sweep and comes back below half
+  uint32_t w_back = w_switch / 2;
+  if (const char *ev = getenv("DACO_TWO_OPT_BACK")) w_back = (uint32_t)atol(ev);
   const size_t np4 = (size_t)(n + 3) / 4 * 4;
   const size_t lds = (2 * np4 + 2 * np4 + np4 + np4 + 4 * 4 + 2 + 6) * sizeof(int) + 8 * sizeof(int) + (size_t)4 * 2 * np4 * sizeof(float);
-  for (int r = 0; r < slices; ++r) {
-    int rc = launch_two_opt_nbr(s, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, nullptr, sweeps, w_switch, 0);
-    if (rc != DACO_OK) return rc;
-    hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds, s, n, T, dist, dist_T, dist_bstride, tours,
-                       max_iterations, (int32_t *)nullptr, sweeps, slice);
-  }
-  int rc = launch_two_opt_nbr(s, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, nullptr, sweeps, 0xffffffffu, 1);
+  int rc = launch_two_opt_nbr(s, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, nullptr, sweeps, w_switch, 0);
+  if (rc != DACO_OK) return rc;
+  hipLaunchKernelGGL((two_opt_incr2_kernel<4>), dim3(B * T), dim3(256), lds, s, n, T, dist, dist_T, dist_bstride, tours,
+                     max_iterations, (int32_t *)nullptr, sweeps, (int)(TWO_OPT_DONE - 1), (const unsigned char *)tables,
+                     (const unsigned char *)tables_T, tables_bytes_per_instance(n), (int)w_back);
+  rc = launch_two_opt_nbr(s, B, T, n, dist, dist_bstride, tables, tables_T, tours, max_iterations, nullptr, sweeps, 0xffffffffu, 1);
   if (rc != DACO_OK) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("two_opt_auto launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }

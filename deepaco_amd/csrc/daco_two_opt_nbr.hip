@@ -33,18 +33,6 @@
 
 namespace daco {
 
-struct NbrEntry { float d; uint32_t id; };
-
-constexpr size_t NBR_HEADER = 256;            // per-instance header: [0] bits of M = max off-diagonal |d|, [1] ~ordered(min off-diagonal d)
-__host__ __device__ inline size_t nbr_align(size_t x) { return (x + 255) & ~(size_t)255; }
-__host__ __device__ inline size_t nbr_instance_bytes(int n) {
-  return NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)) + nbr_align((size_t)n * n * sizeof(uint16_t));
-}
-__device__ inline const NbrEntry *nbr_nb(const unsigned char *tab) { return reinterpret_cast<const NbrEntry *>(tab + NBR_HEADER); }
-__device__ inline const uint16_t *nbr_rk(const unsigned char *tab, int n) {
-  return reinterpret_cast<const uint16_t *>(tab + NBR_HEADER + nbr_align((size_t)n * n * sizeof(NbrEntry)));
-}
-
 // f32 -> u32 with the same order (negative values reversed, sign flipped)
 __device__ inline uint32_t ord_f32(float x) {
   const uint32_t u = __float_as_uint(x);

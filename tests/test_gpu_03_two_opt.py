@@ -252,12 +252,15 @@ def test_candidate_list_kernel_on_perturbation_and_asymmetric_matrices():
     v3, q3 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True, tables=td)           # sampled tours to convergence
     w3, p3 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True)
     assert torch.equal(v3, w3) and torch.equal(q3, p3)
-    os.environ["DACO_TWO_OPT_SLICE"], os.environ["DACO_TWO_OPT_SLICES"] = "7", "3"   # hand-overs at odd places, unfinished heavy tours
-    try:
-        v4, q4 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True, tables=td)
-    finally:
-        os.environ.pop("DACO_TWO_OPT_SLICE"); os.environ.pop("DACO_TWO_OPT_SLICES")
-    assert torch.equal(v4, w3) and torch.equal(q4, p3)
+    for sw, back in (("3000", "2500"), ("60000", "59000"), ("1", "0")):        # hand-overs at other places / none / never back
+        os.environ["DACO_TWO_OPT_SWITCH"], os.environ["DACO_TWO_OPT_BACK"] = sw, back
+        try:
+            v4, q4 = engine.two_opt_(d, tours.clone(), 10000, want_sweeps=True, tables=td)
+            v5, q5 = engine.two_opt_(hd, t1.clone(), 20, want_sweeps=True, tables=th)
+        finally:
+            os.environ.pop("DACO_TWO_OPT_SWITCH"); os.environ.pop("DACO_TWO_OPT_BACK")
+        assert torch.equal(v4, w3) and torch.equal(q4, p3), sw
+        assert torch.equal(v5, t2) and torch.equal(q5, s2), sw
     # sparse learned-heuristic style matrix: a plateau of 1e5 off the k-NN graph
     k = 20
     _, idx = torch.topk(d, k=k, dim=2, largest=False)
