@@ -636,6 +636,10 @@ extern "C" int daco_two_opt_auto(void *stream, int B, int T, int n, const float 
   // entry is one candidate; repairs reverse long segments): the dense kernel wins from ~40 k entries per sweep; the 20
   // perturbation sweeps on the heuristic-derived (non-symmetric: two lists per edge) matrix reverse short segments: ~25 k.
   uint32_t w_switch = (uint32_t)((double)n * n / (tables == tables_T ? 6.0 : 10.0));
+  // ... when the device is full.  With at most one workgroup round (256 CUs x 8) a sweep is latency, not throughput, and the
+  // candidate kernel's chain is several times shorter than the dense kernel's at any list length (training steps, 240-600
+  // tours: 13.6 -> 9.4 ms at TSP-100, 68 -> 54 ms at TSP-500 without the dense kernel)
+  if ((long)B * T <= 2048) w_switch = 0xffffffffu;
   if (const char *ev = getenv("DACO_TWO_OPT_SWITCH")) w_switch = (uint32_t)atol(ev);
   // hand-over hysteresis: a tour goes to the dense kernel above w_switch walked entries per sweep and comes back below half
   uint32_t w_back = w_switch / 2;
