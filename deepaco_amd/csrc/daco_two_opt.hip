@@ -390,7 +390,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   const long stop_at = state ? min(max_iterations, it + (long)budget) : max_iterations;
   bool ended = false;
   while (it < stop_at) {
-    if (tabs && cnt[2] < w_exit * w_scale) break;         // uniform (cnt[2] was last written before the previous barrier)
+    if (tabs && (long)cnt[2] < (long)w_exit * w_scale) break;         // uniform (cnt[2] was last written before the previous barrier)
     const int blo = first ? 1 : p, bhi = first ? n - 1 : min(q + 2, n - 1);       // block rows [blo, bhi)
     // (the rows below the block were classified while the previous move was applied: lists and counts are ready)
     const int nfull = first ? 0 : cnt[0], npart = first ? 0 : cnt[1];
