@@ -109,7 +109,7 @@ nbr_sort_rows_kernel(int n, int P2, const float *dist, long bstride, unsigned ch
 
 // ------------------------------------------------------------------ the search
 // LDS: rec[n] {t[k] | t[k+1] << 16, e[k]} | t[n+1] u16 | pos[n] u16 | rA[n] u16 | rB[n] u16 | pre[2n+1] u32 |
-//      queue[NBR_QUEUE] u32 | red[4] u64 | wsum[4] u32
+//      queue[NBR_QUEUE] u32 | red[NT/64] u64 | wsum[NT/64] u32 | incumbent u32
 constexpr int NBR_QUEUE = 2048;               // candidates expanded per pass, one u32 (item << 16 | k) each
 
 // minimum of a 64-bit key over the wave on the DPP network of daco_device.h (no LDS traffic), broadcast from lane 63
@@ -134,8 +134,11 @@ __device__ inline uint64_t wave_min_u64(uint64_t v) {
 // leaving it, side B of the edge entering it -- are prefixes of the SAME sorted list, wanted at later resp. earlier tour
 // positions.  They are walked once, up to the longer of the two ranks, and every entry goes to the side its position
 // selects: half the table loads and position look-ups, and no candidate that is rejected on position alone.
-template <bool SYM>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96)))   // 8 waves per SIMD (800 SGPRs per SIMD)
+// NT threads per tour: 256 when the device is full (eight tours per CU hide each other's latencies), 1024 when there are fewer
+// tours than CUs can hold (training batches, one instance with a few dozen ants): a sweep is then a latency chain whose
+// evaluation part shrinks with the threads walking it.
+template <bool SYM, int NT>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(96)))    // 8 waves per SIMD at NT = 256 (800 SGPRs per SIMD)
 two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *tabs, const unsigned char *tabsT,
                    size_t tab_stride, uint16_t *tours, long max_iterations, int32_t *sweeps_out, int32_t *state,
                    uint32_t w_switch, int final_pass, unsigned long long *prof) {
@@ -162,8 +165,9 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
   uint32_t *pre = reinterpret_cast<uint32_t *>(rB + np2);     // 2n + 1
   uint32_t *queue = pre + 2 * np2 + 2;                        // NBR_QUEUE records: item << 16 | k
   uint64_t *red = reinterpret_cast<uint64_t *>(queue + NBR_QUEUE);
-  uint32_t *wsum = reinterpret_cast<uint32_t *>(red + 4);
-  uint32_t *incumbent = wsum + 4;                             // ordered image of the best change any thread has seen this sweep
+  constexpr int NW = NT / 64;
+  uint32_t *wsum = reinterpret_cast<uint32_t *>(red + NW);
+  uint32_t *incumbent = wsum + NW;                             // ordered image of the best change any thread has seen this sweep
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // prof (DACO_TWO_OPT_PROFILE=1, a debugging aid): shader-clock cycles per phase as thread 0 sees them, summed over tours
   unsigned long long tmark = prof ? clock64() : 0;
@@ -178,7 +182,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
   // smallest off-diagonal entry: the unknown load of a candidate is at least this
   const float dmin = unord_f32(~reinterpret_cast<const unsigned int *>(tabs + (size_t)b * tab_stride)[1]);
 
-  for (int k = tid; k < n; k += 256) { const uint16_t v = tour[k]; t[k] = v; pos[v] = (uint16_t)k; }
+  for (int k = tid; k < n; k += NT) { const uint16_t v = tour[k]; t[k] = v; pos[v] = (uint16_t)k; }
   __syncthreads();
   if (tid == 0) t[n] = t[0];
   __syncthreads();
@@ -189,14 +193,14 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
     rA[m] = rk[(size_t)x * n + y];
     rB[m] = rkT[(size_t)y * n + x];
   };
-  for (int m = tid; m < n; m += 256) refresh_edge(m);
+  for (int m = tid; m < n; m += NT) refresh_edge(m);
   __syncthreads();
 
   // candidate lists.  General: item m < n = side A of edge m, item n + m = side B of edge m (all A lists first: the lanes of
   // a wave are then on the same side, except in the one wave that straddles the boundary, and each side's code runs
   // unselected).  SYM: item m = the list of node t[m], m = 0 .. n (t[n] = t[0]: the closing edge's side B), serving side A
   // of edge m and side B of edge m-1.
-  const int items = SYM ? n + 1 : 2 * n, ipt = (items + 255) / 256;
+  const int items = SYM ? n + 1 : 2 * n, ipt = (items + NT - 1) / NT;
   auto count_of = [&](int item) -> uint32_t {
     if (SYM) {
       const uint32_t ca = item <= n - 3 ? rA[item] : 0, cb = item >= 3 ? rB[item - 1] : 0;
@@ -229,7 +233,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
           for (uint32_t w = base; w < base + cq && w < (uint32_t)NBR_QUEUE; ++w) queue[w] = ((uint32_t)(i0 + q) << 16) | (w - base);
           base += cq;
         }
-      if (tid == 255) pre[items] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (tid == NT - 1) pre[items] = base;             // (the last thread's running offset is the total)
       if (tid == 0) *incumbent = ord_f32(0.0f);               // the reference's `delta = 0`: only negative changes can win
       __syncthreads();
     }
@@ -243,7 +247,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
       // ---- expand the items overlapping [c0, c0 + NBR_QUEUE) into (item, k) records (the first chunk: done above)
       if (c0 > 0) {
         __syncthreads();                                      // the previous chunk's records have been consumed
-        for (int item = tid; item < items; item += 256) {
+        for (int item = tid; item < items; item += NT) {
           const uint32_t lo = pre[item], hi = pre[item + 1];
           if (hi > c0 && lo < c0 + NBR_QUEUE) {
             const uint32_t from = lo > c0 ? lo : c0, to = hi < c0 + NBR_QUEUE ? hi : c0 + NBR_QUEUE;
@@ -263,7 +267,7 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
       // incumbent is shared through one LDS word (atomic minimum of the ordered image); which candidates get skipped
       // depends on timing, the minimum that is found does not.
       const uint32_t un = (uint32_t)n;
-      for (uint32_t w = tid; w < cnt; w += 256) {
+      for (uint32_t w = tid; w < cnt; w += NT) {
         const uint32_t qr = queue[w];
         const uint32_t item = qr >> 16, k = qr & 0xffff;
         const uint32_t inc = *incumbent;
@@ -342,20 +346,20 @@ two_opt_nbr_kernel(int n, int T, const float *dist, long dist_bs, const unsigned
     lap(3);                                                   // waiting for the other waves + reduction
     uint64_t g = red[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) g = red[w] < g ? red[w] : g;
+    for (int w = 1; w < NW; ++w) g = red[w] < g ? red[w] : g;
     const float delta = g == ~(uint64_t)0 ? 0.0f : unord_f32((uint32_t)(g >> 32));
     if (!((double)delta < -1e-6)) break;                      // `if delta < -1e-6` (two_opt.py:25); uniform
     const int p = (int)((g >> 16) & 0xffff), q = (int)(g & 0xffff);
     // ---- reverse t[p..q], refresh what depends on it
     const int L = q - p + 1;
-    for (int k = tid; k < (L >> 1); k += 256) { const uint16_t u = t[p + k], v = t[q - k]; t[p + k] = v; t[q - k] = u; }
+    for (int k = tid; k < (L >> 1); k += NT) { const uint16_t u = t[p + k], v = t[q - k]; t[p + k] = v; t[q - k] = u; }
     __syncthreads();
-    for (int k = tid; k < L; k += 256) pos[t[p + k]] = (uint16_t)(p + k);
-    for (int m = p - 1 + tid; m <= q; m += 256) refresh_edge(m);   // (q <= n-1: edge n-1 ends at t[n] = t[0], unchanged as p >= 1)
+    for (int k = tid; k < L; k += NT) pos[t[p + k]] = (uint16_t)(p + k);
+    for (int m = p - 1 + tid; m <= q; m += NT) refresh_edge(m);   // (q <= n-1: edge n-1 ends at t[n] = t[0], unchanged as p >= 1)
     __syncthreads();
     lap(4);                                                   // reversal, positions, records and ranks of edges p-1 .. q
   }
-  for (int k = tid; k < n; k += 256) tour[k] = t[k];
+  for (int k = tid; k < n; k += NT) tour[k] = t[k];
   if (sweeps_out && tid == 0) sweeps_out[blk] = (int32_t)it;
   if (state && tid == 0) state[blk] = (int32_t)it | ((handed_over || final_pass) ? 0 : TWO_OPT_DONE);
 }
@@ -393,20 +397,22 @@ int launch_two_opt_nbr(hipStream_t s, int B, int T, int n, const float *dist, lo
                        const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps, int32_t *state,
                        uint32_t w_switch, int final_pass) {
   const int np2 = (n + 2) & ~1;
-  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)(2 * np2 + 2) * 4 + (size_t)NBR_QUEUE * 4 + 4 * 8 + 4 * 4 + 32;
+  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)(2 * np2 + 2) * 4 + (size_t)NBR_QUEUE * 4 + 16 * 8 + 16 * 4 + 32;
   unsigned long long *prof = nullptr;
   if (getenv("DACO_TWO_OPT_PROFILE")) {                       // debugging aid: synchronises and prints
     if (hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)) != hipSuccess) prof = nullptr;
     else (void)hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s);
   }
-  if (tables == tables_T)
-    hipLaunchKernelGGL(two_opt_nbr_kernel<true>, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
-                       (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
-                       sweeps, state, w_switch, final_pass, prof);
-  else
-    hipLaunchKernelGGL(two_opt_nbr_kernel<false>, dim3((unsigned)B * T), dim3(256), lds, s, n, T, dist, dist_bstride,
-                       (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours, max_iterations,
-                       sweeps, state, w_switch, final_pass, prof);
+  // fewer tours than two per CU: 1024 threads each
+  int wide = (long)B * T <= 512;
+  if (const char *ev = getenv("DACO_TWO_OPT_WIDE")) wide = atoi(ev);
+#define DACO_NBR_LAUNCH(SYM_, NT_)                                                                                              \
+  hipLaunchKernelGGL((two_opt_nbr_kernel<SYM_, NT_>), dim3((unsigned)B * T), dim3(NT_), lds, s, n, T, dist, dist_bstride,      \
+                     (const unsigned char *)tables, (const unsigned char *)tables_T, nbr_instance_bytes(n), tours,              \
+                     max_iterations, sweeps, state, w_switch, final_pass, prof)
+  if (tables == tables_T) { if (wide) DACO_NBR_LAUNCH(true, 1024); else DACO_NBR_LAUNCH(true, 256); }
+  else { if (wide) DACO_NBR_LAUNCH(false, 1024); else DACO_NBR_LAUNCH(false, 256); }
+#undef DACO_NBR_LAUNCH
   hipError_t e = hipGetLastError();
   if (prof) {
     unsigned long long h[8] = {0};

@@ -215,19 +215,26 @@ def test_candidate_list_kernel_vs_oracle(n, Tn, B, maxit):
     tours = np.stack([[rng.permutation(n) for _ in range(Tn)] for _ in range(B)]).astype(np.int16)
     dd = d.to(dev())
     tabs = engine.TwoOptTables(dd)
-    for kernel in ("nbr", "auto"):
-        out, sweeps = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel=kernel)
+    refs = [oracle.two_opt_batch(d[b].numpy(), tours[b].astype(np.uint16), maxit) for b in range(B)]
+    for kernel, wide in (("nbr", "0"), ("nbr", "1"), ("auto", "0"), ("auto", "1")):     # 256 / 1024 threads per tour
+        os.environ["DACO_TWO_OPT_WIDE"] = wide
+        try:
+            out, sweeps = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel=kernel)
+        finally:
+            os.environ.pop("DACO_TWO_OPT_WIDE")
         for b in range(B):
-            ref, rs = oracle.two_opt_batch(d[b].numpy(), tours[b].astype(np.uint16), maxit)
-            assert np.array_equal(out[b].cpu().numpy().astype(np.uint16), ref), (n, b, kernel)
-            assert np.array_equal(sweeps[b].cpu().numpy(), rs), kernel
+            ref, rs = refs[b]
+            assert np.array_equal(out[b].cpu().numpy().astype(np.uint16), ref), (n, b, kernel, wide)
+            assert np.array_equal(sweeps[b].cpu().numpy(), rs), (kernel, wide)
 
 
-def test_candidate_list_kernel_on_perturbation_and_asymmetric_matrices():
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_candidate_list_kernel_on_perturbation_and_asymmetric_matrices(wide, monkeypatch):
     """The NLS schedule (2-opt on dist, 20 sweeps on the asymmetric heuristic-derived matrix, 2-opt on dist again) with
     the candidate-list kernel equals the dense kernels at every stage; a random non-symmetric matrix with values of very
     different magnitude (tolerance ranks from the largest entry) and a shared [n,n] matrix as well."""
     from deepaco_amd import engine
+    monkeypatch.setenv("DACO_TWO_OPT_WIDE", wide)                # 256 / 1024 threads per tour
     B, n, A = 2, 300, 48
     d = tsp_instance(n, 99, B).to(dev())
     eta = 1 / d
@@ -308,6 +315,7 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
         tours = np.stack([rng.permutation(n) for _ in range(Tn)]).astype(np.int16)
         dd = T(d)
         tabs = engine.TwoOptTables(dd)
+        os.environ["DACO_TWO_OPT_WIDE"] = str((case // 4) % 2)   # 256 / 1024 threads per tour
         a, sa = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True)
         b, sb = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel="nbr")
         c2, sc = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs)
@@ -316,3 +324,4 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
         if case % 3 == 0:
             ref, rs = oracle.two_opt_batch(d, tours.astype(np.uint16), maxit)
             assert np.array_equal(a.cpu().numpy().astype(np.uint16), ref) and np.array_equal(sa[0].cpu().numpy(), rs), (case, n, kind)
+    os.environ.pop("DACO_TWO_OPT_WIDE", None)
