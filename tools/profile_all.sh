@@ -44,6 +44,9 @@ python $R/tools/run_train_step.py 5 2>/dev/null | grep "^{" > $OUT/train_step.js
 python $R/tools/run_train_step_500.py 5 2>/dev/null | grep "^{" >> $OUT/train_step.json
 python $R/tools/bench_two_opt_nbr.py 16 > $OUT/two_opt_nbr.txt 2>/dev/null
 python $R/tools/gnn_fused_check.py > $OUT/gnn_fused_check.txt 2>/dev/null
+python $R/tools/run_single_instance_nls.py 500 2>/dev/null | grep "^{" > $OUT/single_instance_nls.txt
+python $R/tools/run_single_instance_nls.py 200 2>/dev/null | grep "^{" >> $OUT/single_instance_nls.txt
+python $R/tools/nls_sweep_stats.py 64 auto 2>/dev/null > $OUT/nls_sweep_stats.txt
 # 5. GNN batch inference profile, shapes microbenchmarks
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gnn_stats -o p -- python $R/tools/run_gnn_batch.py > /dev/null 2>&1
 cp $OUT/gnn_stats/p_kernel_stats.csv $OUT/kernel_stats_gnn_batch64_n500.csv
