@@ -58,6 +58,35 @@ tour_costs_kernel(int B, int n, int len, int A, const float *dist, long dist_bs,
   costs[idx] = s;
 }
 
+// The same sums, one wavefront per tour: the thread-per-tour kernel above is a chain of `len` dependent-latency gathers
+// (152 us for 240 tours of 500 nodes, 113 us for 16 384); here 64 edges are gathered at once and added in the same order
+// (lane values read back one by one), so a tour costs len/64 memory latencies instead of len/8.
+__global__ void __launch_bounds__(256)
+tour_costs_wave_kernel(int B, int n, int len, int A, const float *dist, long dist_bs, const int64_t *paths, int closed,
+                       float *costs) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= B * A) return;
+  const int b = idx / A, a = idx - b * A;
+  const int64_t *p = paths + (size_t)b * len * A + a;
+  const float *d = dist + b * dist_bs;
+  const int first = (int)p[0];
+  int carry = first;                                      // node before this chunk's first edge
+  float s = 0.0f;
+  for (int k0 = 1; k0 < len; k0 += 64) {
+    const int k = k0 + lane, cnt = min(64, len - k0);
+    const int u = k < len ? (int)p[(size_t)k * A] : 0;
+    int before = __shfl_up(u, 1, 64);
+    if (lane == 0) before = carry;
+    // closed tours: d[u_k][u_{k-1}] (the fused sampler's orientation); open routes: d[u_{k-1}][u_k]
+    const float e = k < len ? (closed ? d[(size_t)u * n + before] : d[(size_t)before * n + u]) : 0.0f;
+    for (int j = 0; j < cnt; ++j) s = s + readlane_f(e, j);
+    carry = readlane_i(u, cnt - 1);
+  }
+  if (closed) s = s + d[(size_t)first * n + carry];
+  if (lane == 0) costs[idx] = s;
+}
+
 // nbr[b][node][a] = prev(node) | next(node) << 16 along ant a's closed tour
 __global__ void __launch_bounds__(256)
 build_nbr_kernel(int B, int n, int A, const int64_t *paths, uint32_t *nbr) {
@@ -351,8 +380,12 @@ extern "C" int daco_tour_costs(void *stream, int B, int n, int len, int A, const
     return DACO_E_BADARG;
   }
   const int total = B * A;
-  hipLaunchKernelGGL(tour_costs_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n,
-                     len, A, dist, dist_bstride, paths, closed, costs);
+  if (len >= 64)
+    hipLaunchKernelGGL(tour_costs_wave_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, n, len, A, dist,
+                       dist_bstride, paths, closed, costs);
+  else
+    hipLaunchKernelGGL(tour_costs_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, n,
+                       len, A, dist, dist_bstride, paths, closed, costs);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("tour_costs_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;

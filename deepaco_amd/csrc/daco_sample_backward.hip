@@ -33,6 +33,7 @@ struct BackwardParams {
   const float *demand;           // [B][n] (CVRP) or null
   float capacity;
   float *grad_eta;               // [B][n][n], accumulated into (caller zeroes)
+  int segs;                      // waves per (instance, ant): each replays the whole route but differentiates 1/segs of its steps
 };
 
 template <bool CVRP>
@@ -40,8 +41,12 @@ __global__ void __launch_bounds__(256)
 sample_backward_kernel(const BackwardParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bpi = (p.A + 3) >> 2;
-  const int b = blockIdx.x / bpi;
-  const int a = (blockIdx.x - b * bpi) * 4 + wave;
+  // Small batches (a training step has a few hundred ants) leave most of the device idle with one wave per ant, and a wave's
+  // route is a chain of ~n dependent steps: `segs` waves share an ant, each replays the cheap bookkeeping of the whole
+  // route (visited set, capacity) and differentiates only the steps of its own contiguous segment.
+  const int seg = blockIdx.x % p.segs, blk = blockIdx.x / p.segs;
+  const int b = blk / bpi;
+  const int a = (blk - b * bpi) * 4 + wave;
   if (a >= p.A) return;
   const int n = p.n, A = p.A;
   const float *tau = p.tau + (size_t)b * p.tau_bs, *eta = p.eta + (size_t)b * p.eta_bs;
@@ -50,7 +55,9 @@ sample_backward_kernel(const BackwardParams p) {
   const float *gl = p.grad_logp + (size_t)b * (p.rows - 1) * A + a;
   float *grad = p.grad_eta + (size_t)b * n * n;
   const float *demand = CVRP ? p.demand + (size_t)b * n : nullptr;
-  const int len = CVRP ? p.lens[(size_t)b * A + a] : n;
+  const int len_all = CVRP ? p.lens[(size_t)b * A + a] : n;
+  const int per = (len_all - 1 + p.segs - 1) / p.segs;
+  const int t_lo = 1 + seg * per, len = min(len_all, t_lo + per);       // this wave differentiates steps [t_lo, len)
   const int chunks = (n + 63) / 64;            // lane owns k = lane + 64*c (visited bit c)
 
   uint64_t vis = 0;                            // n <= 4096 -> <= 64 chunks
@@ -63,7 +70,7 @@ sample_backward_kernel(const BackwardParams p) {
     const float g = gl[(size_t)(t - 1) * A];
     const float S = rs[(size_t)(t - 1) * A];
     const float *trow = tau + (size_t)prev * n, *erow = eta + (size_t)prev * n;
-    if (g != 0.0f) {
+    if (t >= t_lo && g != 0.0f) {
       const float pj = pw(trow[j], p.alpha) * pw(erow[j], p.beta);
       const float pr = pj / S;
       if (pr > DACO_EPS_F32 && pr < 1.0f - DACO_EPS_F32) {      // inside the clamp: gradient flows
@@ -251,7 +258,7 @@ extern "C" int daco_sibling_backward(void *stream, int kind, int B, int n, int A
   BackwardParams &bp = sp.b;
   bp.B = B; bp.n = n; bp.A = A; bp.rows = rows; bp.tau = tau; bp.eta = eta; bp.tau_bs = tau_bstride;
   bp.eta_bs = eta_bstride; bp.alpha = alpha; bp.beta = beta; bp.paths = paths; bp.rowsum = rowsum;
-  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = nullptr; bp.capacity = 0.0f; bp.grad_eta = grad_eta;
+  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = nullptr; bp.capacity = 0.0f; bp.grad_eta = grad_eta; bp.segs = 1;
   sp.aux_vec = aux_vec; sp.aux_mat = aux_mat; sp.aux_bs = aux_mat_bstride; sp.scalar0 = scalar0; sp.wts = item_weights; sp.m = m;
   dim3 grid((unsigned)(B * ((A + 3) / 4))), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -285,7 +292,11 @@ extern "C" int daco_sample_backward(void *stream, int B, int n, int A, int rows,
   bp.B = B; bp.n = n; bp.A = A; bp.rows = rows; bp.tau = tau; bp.eta = eta; bp.tau_bs = tau_bstride;
   bp.eta_bs = eta_bstride; bp.alpha = alpha; bp.beta = beta; bp.paths = paths; bp.rowsum = rowsum;
   bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = demand; bp.capacity = capacity; bp.grad_eta = grad_eta;
-  dim3 grid((unsigned)(B * ((A + 3) / 4))), block(256);
+  // waves per ant so that a small batch still fills the device's ~2048 wave slots with independent chains
+  int segs = 1;
+  while (segs < 8 && (long)B * A * segs * 2 <= 2048) segs *= 2;
+  bp.segs = segs;
+  dim3 grid((unsigned)(B * ((A + 3) / 4) * segs)), block(256);
   if (cvrp) hipLaunchKernelGGL(sample_backward_kernel<true>, grid, block, 0, (hipStream_t)stream, bp);
   else hipLaunchKernelGGL(sample_backward_kernel<false>, grid, block, 0, (hipStream_t)stream, bp);
   hipError_t e = hipGetLastError();
