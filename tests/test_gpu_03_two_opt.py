@@ -290,13 +290,18 @@ def test_candidate_list_kernel_on_perturbation_and_asymmetric_matrices(wide, mon
 def test_candidate_list_kernel_many_small_cases_with_ties():
     """Sixty small searches, candidate-list kernel vs dense kernel vs (a third of them) the oracle: integer grid
     coordinates (many equal distances: tie-breaking on (i, j), tolerance ranks with ties), duplicate points (zero
-    distances), row-scaled and random asymmetric matrices, sweep caps that stop the search midway."""
+    distances), row-scaled and random asymmetric matrices, signed entries with a zero diagonal, sweep caps that stop
+    the search midway."""
     from deepaco_amd import engine
     rng = np.random.default_rng(2026)
     for case in range(60):
         n = int(rng.integers(4, 160))
-        kind = case % 4
-        if kind == 0:                                            # integer grid: ties everywhere
+        kind = case % 5
+        if kind == 4:                                            # signed entries, zero diagonal (nothing the kernels assume)
+            d = rng.uniform(-1.0, 1.0, size=(n, n)).astype(np.float32)
+            if case % 2:
+                d = ((d + d.T) / 2).astype(np.float32)
+        elif kind == 0:                                          # integer grid: ties everywhere
             c = rng.integers(0, 6, size=(n, 2)).astype(np.float32)
             d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
         elif kind == 1:                                          # uniform points, a few duplicated
@@ -309,7 +314,7 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
             d = (d * rng.uniform(1.0, 300.0, size=(n, 1))).astype(np.float32)
         else:                                                    # random asymmetric
             d = (rng.random((n, n)) * 10 ** rng.uniform(-2, 4)).astype(np.float32)
-        np.fill_diagonal(d, 1e9)
+        np.fill_diagonal(d, 0.0 if kind == 4 else 1e9)
         Tn = int(rng.integers(1, 9))
         maxit = int(rng.choice([1, 3, 17, 10000]))
         tours = np.stack([rng.permutation(n) for _ in range(Tn)]).astype(np.int16)
