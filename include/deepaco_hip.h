@@ -314,7 +314,7 @@ int daco_two_opt(void *stream, int B, int T, int n, const float *dist, const flo
  * minimum: for the tour edge (x, y) the nodes v with d[x][v] < d[x][y] + tol and the nodes u with d[u][y] < d[x][y] + tol
  * (tol = 4 ulp(2 max|d|) covers the three f32 roundings of the reference's expression; csrc/daco_two_opt_nbr.hip has
  * the argument).  A few thousand evaluations per sweep instead of n^2/2 once tours are near a local optimum (the
- * perturbation / repair passes of the NLS); more than n^2/2 for tours with many long edges -- callers choose per call.
+ * perturbation / repair passes of the NLS); more than n^2/2 for tours with many long edges (daco_two_opt_auto chooses).
  *   daco_two_opt_prepare: builds, per instance, the sorted neighbour lists and tolerance ranks of `dist` [B][n][n]
  *          (n <= 1024) into `tables` (daco_two_opt_tables_bytes(B, n) bytes).  Once per matrix.
  *   daco_two_opt_nbr: tables = prepare(dist); tables_T = prepare(transposed dist), or the same pointer when dist is
@@ -325,9 +325,11 @@ int daco_two_opt_prepare(void *stream, int B, int n, const float *dist, long dis
 int daco_two_opt_nbr(void *stream, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
                      const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps);
 /*   daco_two_opt_auto: both kernels on one call, chosen per tour and per phase of its search without a host round
- *          trip: the candidate-list kernel while the tour's candidate count is below ~n^2/10, the dense incremental
- *          kernel (daco_two_opt's; dist_T as there, may be NULL) in slices of sweeps while it is above -- tours fresh
- *          from sampling start dense and finish on the candidate lists.  Same result as either kernel alone.
+ *          trip (three launches: candidates, dense, candidates): the candidate-list kernel while a tour's lists hold
+ *          fewer than ~n^2/6 entries (n^2/10 for a non-symmetric matrix), the dense incremental kernel (daco_two_opt's;
+ *          dist_T as there, may be NULL) above, until its running rank sum has fallen under half of that -- tours fresh
+ *          from a dense heuristic start dense and finish on the candidate lists; with at most 2048 tours the candidate
+ *          kernel keeps them all (and runs 1024 threads per tour below 512 tours).  Same result as either kernel alone.
  *          sweeps [B][T] int32 is REQUIRED here (it carries the per-tour state between the launches).
  */
 int daco_two_opt_auto(void *stream, int B, int T, int n, const float *dist, const float *dist_T, long dist_bstride,
