@@ -41,7 +41,7 @@ SIGNATURES = {
     "daco_gnn_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "daco_gnn_train_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_gnn_train_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
-    "daco_gnn_train_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "daco_gnn_train_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "daco_cvrp_local_search": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _f, _vp, _i, _vp, _vp]),
     "daco_sibling_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_sibling_sample": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _l, _f, _vp, _i, _i, _vp, _vp,
@@ -57,7 +57,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 116          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 117          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

@@ -24,6 +24,8 @@
 //   node_lin_bwd                      gx (in place: residual + gX Wv), gWv += gX^T x (MFMA), gbv
 // Parameter gradients land in a flat block with the layout of the parameter block (see daco_gnn.hip), BatchNorm
 // slots holding d/dgamma, d/dbeta.
+#include <cstdlib>
+
 #include "daco_device.h"
 #include "../../include/deepaco_hip.h"
 
@@ -400,7 +402,8 @@ gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const
 __global__ void __launch_bounds__(256)
 gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, const float *gamma, const float *beta,
                const float2 *fsums, const float2 *bsums, const float *X, const float *w0, const float *ze, const float *gmsg,
-               float *gw /* in: grad wrt w', out: grad wrt w */, float *gX, float *gWe, float *gbe) {
+               float *gw /* in: grad wrt w', out: grad wrt w */, float *gX, float *gWe, float *gbe,
+               float *c2buf /* [E][32] d/d x2[dst] per edge, or null */, float *gzbuf /* [E][32] g_ze per edge */) {
   __shared__ __attribute__((aligned(16))) float tw_s[4][32][36], tg_s[4][32][36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
@@ -424,7 +427,7 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
         const float4 go = *reinterpret_cast<const float4 *>(gw + (size_t)e * TU + c0);
         gres[q] = go;
         const float zc[4] = {zz.x, zz.y, zz.z, zz.w}, gc[4] = {go.x, go.y, go.z, go.w}, wc[4] = {wv.x, wv.y, wv.z, wv.w};
-        float gzc[4], gt[4];
+        float gzc[4], gt[4], c2c[4];
         const float4 gm = *reinterpret_cast<const float4 *>(gmsg + (size_t)s * TU + c0);
         const float4 x2 = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 32 + c0);
         const float gmc[4] = {gm.x, gm.y, gm.z, gm.w}, x2c[4] = {x2.x, x2.y, x2.z, x2.w};
@@ -434,11 +437,20 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
           gzc[k] = bn_bwd(gc[k], zc[k], st, gamma[c0 + k], beta[c0 + k], bsums, g, c0 + k, Eg);
           const float gate = t_sigmoid(wc[k]);
           gt[k] = gmc[k] * x2c[k] * gate * (1.0f - gate);                   // d msg / d w through the gate
-          unsafeAtomicAdd(gX + (size_t)d * 128 + 32 + c0 + k, gmc[k] * gate);   // d / d x2[dst]
-          unsafeAtomicAdd(gX + (size_t)s * 128 + 64 + c0 + k, gzc[k]);          // d / d x3[src]
-          unsafeAtomicAdd(gX + (size_t)d * 128 + 96 + c0 + k, gzc[k]);          // d / d x4[dst]
+          c2c[k] = gmc[k] * gate;                                           // d / d x2[dst]
+          if (!c2buf) {
+            unsafeAtomicAdd(gX + (size_t)d * 128 + 32 + c0 + k, c2c[k]);        // d / d x2[dst]
+            unsafeAtomicAdd(gX + (size_t)s * 128 + 64 + c0 + k, gzc[k]);        // d / d x3[src]
+            unsafeAtomicAdd(gX + (size_t)d * 128 + 96 + c0 + k, gzc[k]);        // d / d x4[dst]
+          }
         }
         gz = make_float4(gzc[0], gzc[1], gzc[2], gzc[3]);
+        if (c2buf) {
+          // per-edge contributions for gnn_t_gather_bwd (f32 atomics into gX run at ~16 per clock on this chip: 19 M of them
+          // were 0.5 ms per layer at 200 k edges; two coalesced row stores here, three CSR row sums there)
+          *reinterpret_cast<float4 *>(c2buf + (size_t)e * TU + c0) = make_float4(c2c[0], c2c[1], c2c[2], c2c[3]);
+          *reinterpret_cast<float4 *>(gzbuf + (size_t)e * TU + c0) = gz;
+        }
         gate_term[q] = make_float4(gt[0], gt[1], gt[2], gt[3]);
       }
       *reinterpret_cast<float4 *>(&tw[el][c0]) = wv;
@@ -470,6 +482,90 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
   }
   flush_acc(gWe, aW, lane);
   unsafeAtomicAdd(gbe + o, ab);
+}
+
+// gX[:, x2 | x3 | x4 blocks] as sums over CSR rows of the per-edge contributions edge_bwd stored (no atomics, fixed order):
+// x2[i] and x4[i] over the edges entering i (perm_dst / rowptr_dst), x3[i] over the edges leaving it (perm / rowptr).
+// 8 nodes per workgroup, lane = channel.
+__global__ void __launch_bounds__(256)
+gnn_t_gather_bwd(int n, const int *rowptr, const int *perm, const int *rowptr_dst, const int *perm_dst, const float *c2buf,
+                 const float *gzbuf, float *gX) {
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  if (i >= n) return;
+  // edge ids are fetched 32 at a time by the node's lanes and handed round by shuffles: the row loads then depend on a
+  // lane exchange, not on a second trip to memory, and several of them are in flight
+  float a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
+  for (int q0 = rowptr_dst[i], hi = rowptr_dst[i + 1]; q0 < hi; q0 += 32) {
+    const int m = min(32, hi - q0);
+    const int ev = o < m ? perm_dst[q0 + o] : 0;
+#pragma unroll 4
+    for (int j = 0; j < m; ++j) {
+      const int e = __shfl(ev, j, 32);
+      a2 += c2buf[(size_t)e * TU + o];
+      a4 += gzbuf[(size_t)e * TU + o];
+    }
+  }
+  for (int q0 = rowptr[i], hi = rowptr[i + 1]; q0 < hi; q0 += 32) {
+    const int m = min(32, hi - q0);
+    const int ev = o < m ? (perm ? perm[q0 + o] : q0 + o) : 0;
+#pragma unroll 4
+    for (int j = 0; j < m; ++j) a3 += gzbuf[(size_t)__shfl(ev, j, 32) * TU + o];
+  }
+  gX[(size_t)i * 128 + 32 + o] = a2;
+  gX[(size_t)i * 128 + 64 + o] = a3;
+  gX[(size_t)i * 128 + 96 + o] = a4;
+}
+
+// The edges grouped by destination, built on the device when the caller has no such CSR: count, scan, fill (cursor order is
+// whatever the hardware schedules), then every row's ids are put in ascending order so that the sums have a fixed order.
+__global__ void csr_count_kernel(int E, const int *dst, int *cnt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) atomicAdd(cnt + dst[e], 1);
+}
+__global__ void __launch_bounds__(1024) csr_scan_kernel(int n, const int *cnt, int *rowptr, int *cursor) {
+  __shared__ int wsum[16], carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? cnt[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(inc, s, 64); if (lane >= s) inc += o; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = carry_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (i < n) { rowptr[i] = off + inc - v; cursor[i] = off + inc - v; }
+    __syncthreads();
+    if (tid == 1023) carry_s = off + inc;
+    __syncthreads();
+  }
+  if (tid == 0) rowptr[n] = carry_s;
+}
+__global__ void csr_fill_kernel(int E, const int *dst, int *cursor, int *perm) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) perm[atomicAdd(cursor + dst[e], 1)] = e;
+}
+// rank sort of every row's ids (distinct), 32 lanes per row out of LDS; rows longer than CSR_SORT_MAX keep the fill order
+constexpr int CSR_SORT_MAX = 512;
+__global__ void __launch_bounds__(256) csr_sort_rows_kernel(int n, const int *rowptr, int *perm) {
+  __shared__ int ids[8][CSR_SORT_MAX];
+  const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + il;
+  if (i >= n) return;
+  const int lo = rowptr[i], L = rowptr[i + 1] - lo;
+  if (L > CSR_SORT_MAX) return;
+  for (int k = o; k < L; k += 32) ids[il][k] = perm[lo + k];
+  __builtin_amdgcn_wave_barrier();                         // (a row belongs to one half-wave: LDS accesses of a wave are in order)
+  for (int k = o; k < L; k += 32) {
+    const int v = ids[il][k];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) rank += ids[il][j] < v;
+    perm[lo + rank] = v;
+  }
 }
 
 // node linears backward: gx (in: grad wrt x', out: grad wrt x) += gX Wv; gWvT[c][c'] += sum_i x[i][c] gX[i][c'];
@@ -592,6 +688,8 @@ struct TrainWs {
   float2 *btab;    // [2][G][32] (mean g_y, mean g_y zhat) of the layer being differentiated
   // backward scratch
   float *gx, *gw, *gX, *gmsg;
+  float *c2buf, *gzbuf;   // [E][32] per-edge contributions of the layer being differentiated (gather path)
+  int *csr_rowptr, *csr_perm, *csr_cursor;   // destination CSR built by the backward when the caller passes none
   double *bsums;   // [2][G][32][2]
   size_t total;
 };
@@ -612,6 +710,11 @@ static TrainWs carve(void *base, int n, int E, int G) {
   t.gw = (float *)take((size_t)E * 32 * 4);
   t.gX = (float *)take((size_t)n * 128 * 4);
   t.gmsg = (float *)take((size_t)n * 32 * 4);
+  t.c2buf = (float *)take((size_t)E * 32 * 4);
+  t.gzbuf = (float *)take((size_t)E * 32 * 4);
+  t.csr_rowptr = (int *)take((size_t)(n + 1) * 4);
+  t.csr_perm = (int *)take((size_t)E * 4);
+  t.csr_cursor = (int *)take((size_t)n * 4);
   t.bsums = (double *)take((size_t)2 * G * 32 * 2 * 8);
   t.total = (size_t)(p - (char *)base);
   return t;
@@ -673,9 +776,9 @@ extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int
 }
 
 extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
-                                       const int32_t *dst, const int32_t *rowptr, const float *edge_attr, const float *params,
-                                       const float *heu, const float *grad_heu, float *grad_params, void *workspace,
-                                       size_t workspace_bytes) {
+                                       const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const int32_t *rowptr_dst,
+                                       const int32_t *perm_dst, const float *edge_attr, const float *params, const float *heu,
+                                       const float *grad_heu, float *grad_params, void *workspace, size_t workspace_bytes) {
   if (int rc = check_train_args("daco_gnn_train_backward", n, E, feats, G)) return rc;
   if (!x || !src || !dst || !rowptr || !edge_attr || !params || !heu || !grad_heu || !grad_params || !workspace) { set_error("daco_gnn_train_backward: null pointer"); return DACO_E_BADARG; }
   if (workspace_bytes < daco_gnn_train_workspace_bytes(n, E, G)) { set_error("daco_gnn_train_backward: workspace too small"); return DACO_E_WORKSPACE; }
@@ -688,6 +791,18 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
   const size_t pfloats = t_off_head(feats) + 2 * (1024 + 32) + 32 + 1;
   if (hipMemsetAsync(grad_params, 0, pfloats * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
   if (hipMemsetAsync(t.gx, 0, (size_t)n * 32 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+  const bool caller_csr = rowptr_dst && perm_dst;
+  const int force_gather = getenv("DACO_GNN_TRAIN_GATHER") ? atoi(getenv("DACO_GNN_TRAIN_GATHER")) : -1;   // read per call
+  const bool use_gather = force_gather >= 0 ? force_gather != 0 : (E >= 100000 || caller_csr);
+  if (use_gather && !caller_csr) {
+    if (hipMemsetAsync(t.csr_cursor, 0, (size_t)n * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    hipLaunchKernelGGL(csr_count_kernel, dim3((E + 255) / 256), dim3(256), 0, s, E, dst, t.csr_cursor);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, n, t.csr_cursor, t.csr_rowptr, t.csr_cursor);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3((E + 255) / 256), dim3(256), 0, s, E, dst, t.csr_cursor, t.csr_perm);
+    hipLaunchKernelGGL(csr_sort_rows_kernel, dim3((n + 7) / 8), dim3(256), 0, s, n, t.csr_rowptr, t.csr_perm);
+    rowptr_dst = t.csr_rowptr;
+    perm_dst = t.csr_perm;
+  }
   hipLaunchKernelGGL(gnn_t_head_bwd, dim3(egrid), dim3(256), 0, s, E, params + t_off_head(feats), t.w[12], heu, grad_heu, t.gw,
                      grad_params + t_off_head(feats));
   for (int l = 11; l >= 0; --l) {
@@ -697,7 +812,10 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     float *gWT = glp, *gbv = glp + 32 * 128, *gWe = gbv + 128, *gbe = gWe + 1024, *ggv = gbe + 32, *gbv_ = ggv + 32, *gge = gbv_ + 32, *gbee = gge + 32;
     double *be_s = t.bsums, *bv_s = t.bsums + (size_t)G * 64;
     if (hipMemsetAsync(t.bsums, 0, (size_t)2 * G * 64 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
-    if (hipMemsetAsync(t.gX, 0, (size_t)n * 128 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    // the gather path pays four small CSR kernels per call and one gather launch per layer: it wins from ~100 k edges
+    // (8 x TSP-500: edge_bwd 508 -> 303 + 47 us per layer); below, the f32 atomics are cheaper.  DACO_GNN_TRAIN_GATHER=0/1 forces.
+    const bool gather = use_gather;
+    if (!gather && hipMemsetAsync(t.gX, 0, (size_t)n * 128 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
     const float2 *fte = t.ftab + ((size_t)l * 2 + 0) * G * 32, *ftv = t.ftab + ((size_t)l * 2 + 1) * G * 32;
     float2 *bte = t.btab, *btv = t.btab + (size_t)G * 32;
     const unsigned tb = (unsigned)((G * 32 + 255) / 256);
@@ -708,7 +826,10 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     hipLaunchKernelGGL(gnn_t_node_bwd_apply, dim3(node_blocks), dim3(256), 0, s, n, ng, rowptr, gv, bv_, ftv, btv, t.zv[l], t.gx,
                        t.gX, t.gmsg);
     hipLaunchKernelGGL(gnn_t_edge_bwd, dim3(egrid), dim3(256), 0, s, E, Eg, src, dst, We, ge, bee, fte, bte, t.X[l], t.w[l], t.ze[l],
-                       t.gmsg, t.gw, t.gX, gWe, gbe);
+                       t.gmsg, t.gw, t.gX, gWe, gbe, gather ? t.c2buf : nullptr, gather ? t.gzbuf : nullptr);
+    if (gather)
+      hipLaunchKernelGGL(gnn_t_gather_bwd, dim3(node_blocks), dim3(256), 0, s, n, rowptr, perm, rowptr_dst, perm_dst, t.c2buf,
+                         t.gzbuf, t.gX);
     hipLaunchKernelGGL(gnn_t_node_lin_bwd, dim3(ngrid), dim3(256), 0, s, n, WT, t.x[l], t.gX, t.gx, gWT, gbv);
     hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, be_s, gge, gbee);
     hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, bv_s, ggv, gbv_);

@@ -157,6 +157,7 @@ class _GnnTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, x, attr, src, dst, rowptr, perm, feats, G):
+        # (perm may be None; the destination CSR is derived here, once per forward, for the backward)
         n, E = x.shape[0], src.numel()
         L = _lib.lib()
         dev = x.device
@@ -171,7 +172,7 @@ class _GnnTrainFn(torch.autograd.Function):
                                           flat.data_ptr(), heu.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel())
         _lib.check(rc, "daco_gnn_train_forward")
         ctx.save_for_backward(flat, x, attr, src, dst, rowptr, heu)
-        ctx.ws, ctx.feats, ctx.G = ws, feats, G
+        ctx.ws, ctx.feats, ctx.G, ctx.perm = ws, feats, G, perm
         ctx.mark_non_differentiable(stats)
         return heu, stats
 
@@ -184,8 +185,10 @@ class _GnnTrainFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             gflat = torch.empty_like(flat)
             gheu = gheu.float().contiguous()
+            perm = ctx.perm                     # (destination CSR: None -> the library builds it in the workspace)
             rc = L.daco_gnn_train_backward(engine._stream(dev), n, E, ctx.feats, ctx.G, x.data_ptr(), src.data_ptr(),
-                                           dst.data_ptr(), rowptr.data_ptr(), attr.data_ptr(), flat.data_ptr(),
+                                           dst.data_ptr(), rowptr.data_ptr(), perm.data_ptr() if perm is not None else None,
+                                           None, None, attr.data_ptr(), flat.data_ptr(),
                                            heu.data_ptr(), gheu.data_ptr(), gflat.data_ptr(), ctx.ws.data_ptr(),
                                            ctx.ws.numel())
         _lib.check(rc, "daco_gnn_train_backward")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 116 /* 0.1.15: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 117 /* 0.1.16: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -369,6 +369,10 @@ int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, cons
  *   workspace  daco_gnn_train_workspace_bytes(n, E, G) bytes; the forward leaves the activations the backward needs
  *              there: pass the SAME, untouched block to daco_gnn_train_backward
  *   grad_heu   [E] d loss / d heu;   grad_params out: d loss / d params, same layout as params
+ *   rowptr_dst, perm_dst (backward)  CSR of the edges grouped by DESTINATION (offsets [n+1], edge ids [E]) or NULL/NULL
+ *              (the backward then builds it in the workspace: count, scan, fill, ids ascending per row).  The node
+ *              gradients are CSR row sums of per-edge contributions: fixed order, no float atomics.
+ *              perm (backward): as in the forward.
  * No library GEMM is called: the 32x32 linears and their weight gradients run on v_mfma_f32_32x32x2_f32.
  */
 size_t daco_gnn_train_workspace_bytes(int n, int E, int G);
@@ -376,9 +380,9 @@ int daco_gnn_train_forward(void *stream, int n, int E, int feats, int G, const f
                            const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const float *edge_attr,
                            const float *params, float *heu, float *stats_out, void *workspace, size_t workspace_bytes);
 int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
-                            const int32_t *dst, const int32_t *rowptr, const float *edge_attr, const float *params,
-                            const float *heu, const float *grad_heu, float *grad_params, void *workspace,
-                            size_t workspace_bytes);
+                            const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const int32_t *rowptr_dst,
+                            const int32_t *perm_dst, const float *edge_attr, const float *params, const float *heu,
+                            const float *grad_heu, float *grad_params, void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_cvrp_local_search -- replaces ACO.multiple_swap_star's per-ant CPU tasks

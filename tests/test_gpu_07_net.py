@@ -82,11 +82,14 @@ def _grad_close(got, ref, what, rel=3e-4, floor=1e-7):
     assert err <= rel * scale + floor, (what, err, scale)
 
 
+@pytest.mark.parametrize("gather", ["0", "1"])
 @pytest.mark.parametrize("name", names("g7_netgrad"))
-def test_net_training_step_hip_matches_reference(name):
-    """G7: train-mode forward (BatchNorm on the graph's own statistics), loss = sum(heu * coef), backward -- all in the
+def test_net_training_step_hip_matches_reference(name, gather, monkeypatch):
+    """(gather: the backward's node gradients as f32 atomics / as CSR row sums of per-edge contributions.)
+    G7: train-mode forward (BatchNorm on the graph's own statistics), loss = sum(heu * coef), backward -- all in the
     HIP kernels (csrc/daco_gnn_train.hip) -- against what the reference network and torch autograd produced on the
     same weights and graph: heu, every parameter gradient, and the BatchNorm running statistics after the step."""
+    monkeypatch.setenv("DACO_GNN_TRAIN_GATHER", gather)
     g7 = load_golden(name)
     g = load_golden(name.replace("g7_netgrad", "g5_net"))
     net = make_net(name)
@@ -128,9 +131,11 @@ def test_net_training_step_hip_matches_reference(name):
             np.testing.assert_allclose(v.cpu().numpy(), g7["rs__" + k], rtol=2e-4, atol=1e-6, err_msg=k)
 
 
-def test_net_training_hip_equals_torch_autograd_on_random_graph():
+@pytest.mark.parametrize("gather", ["0", "1"])
+def test_net_training_hip_equals_torch_autograd_on_random_graph(gather, monkeypatch):
     """Random weights, unsorted edge list with uneven degrees and isolated sources: HIP training forward/backward
-    against the same math as torch ops + autograd on the GPU."""
+    against the same math as torch ops + autograd on the GPU (both forms of the backward's scatter)."""
+    monkeypatch.setenv("DACO_GNN_TRAIN_GATHER", gather)
     from deepaco_amd.cvrp.net import Net
     from deepaco_amd.net import GraphData
     torch.manual_seed(0)
