@@ -77,3 +77,27 @@ def test_net_refuses_cpu():
                     edge_attr=torch.from_numpy(g["edge_attr"]))
     with pytest.raises(_lib.DacoError):
         net(pyg)
+
+
+def test_regular_knn_csr_shortcut_equals_derived_csr():
+    """Net.forward_batch(k_sparse=...) writes the CSR arrays of the regular k-NN layout down directly; they must be what
+    _csr_graph derives from the same merged edge list (sortedness check, bincount, cumsum)."""
+    from deepaco_amd.net import _csr_graph, _merge_graphs
+    from deepaco_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    for B, n, k in ((1, 7, 3), (3, 20, 5), (4, 33, 1)):
+        src = torch.arange(n).repeat_interleave(k)
+        ei = torch.stack([torch.stack([src, torch.randint(0, n, (n * k,), generator=g)]) for _ in range(B)])   # [B, 2, n*k]
+        x = torch.rand(B, n, 2, generator=g)
+        ea = torch.rand(B, n * k, 1, generator=g)
+        hinted = _merge_graphs(x, ei, ea, k_sparse=k)
+        plain = _merge_graphs(x, ei, ea)
+        assert not hasattr(plain, "_daco_graph")
+        a = hinted._daco_graph
+        b = _csr_graph(plain, B * n, x.device)
+        assert b[3] is None and a[3] is None                       # already sorted by source: no permutation
+        for u, v in zip(a[:3], b[:3]):
+            assert u.dtype == torch.int32 and torch.equal(u, v)
+        assert torch.equal(hinted.edge_index, plain.edge_index) and torch.equal(hinted.x, plain.x)
+    with pytest.raises(_lib.DacoError):
+        _merge_graphs(torch.rand(2, 5, 2), torch.zeros(2, 2, 12, dtype=torch.long), torch.rand(2, 12, 1), k_sparse=3)
