@@ -79,3 +79,21 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "daco_oracle" not in src or f.endswith(".h") and "restated in" in src, f
+
+
+def test_two_opt_candidate_entry_points_validate_arguments():
+    import torch
+    from deepaco_amd import engine
+    L = _lib.lib()
+    n = 500
+    al = lambda x: (x + 255) & ~255
+    assert L.daco_two_opt_tables_bytes(3, n) == 3 * (256 + al(8 * n * n) + al(2 * n * n))
+    assert L.daco_two_opt_tables_bytes(0, n) == 0
+    assert L.daco_two_opt_prepare(None, 0, n, None, 0, None, 0) == -1
+    assert L.daco_two_opt_prepare(None, 1, 2000, 1, 0, 1, 1 << 40) == -2 and b"1024" in L.daco_last_error()
+    assert L.daco_two_opt_prepare(None, 1, n, 1, 0, 1, 16) == -4                      # tables buffer too small
+    assert L.daco_two_opt_nbr(None, 1, 1, 2000, 1, 0, 1, 1, 1, 10, None) == -2
+    assert L.daco_two_opt_nbr(None, 1, 1, n, 1, 0, None, None, 1, 10, None) == -1
+    assert L.daco_two_opt_auto(None, 1, 1, n, 1, None, 0, 1, 1, 1, 10, None) == -1    # sweeps is required (hand-over state)
+    # above the table kernels' size the host falls back to the dense kernel (no tables)
+    assert engine.two_opt_tables(torch.zeros(1, 1025, 1025)) is None
