@@ -54,10 +54,11 @@ SIGNATURES = {
     "daco_two_opt_prepare": (_i, [_vp, _i, _i, _vp, _l, _vp, _sz]),
     "daco_two_opt_nbr": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _vp]),
     "daco_two_opt_auto": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp, _vp, _vp, _l, _vp]),
+    "daco_tsp_nls": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _i, _l, _vp, _vp, _vp]),
 }
 
 
-ABI_VERSION = 117          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 118          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

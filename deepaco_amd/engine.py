@@ -5,6 +5,8 @@ current torch stream and returns torch tensors; nothing here synchronises with t
 Layouts follow the reference with a leading batch dimension:
 paths [B, n, A] int64, log_probs [B, n-1, A] f32, costs [B, A] f32.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -456,6 +458,7 @@ class TwoOptTables:
         if dist_t is None:
             dist_t = transposed_for_two_opt(dist)
         self.n = n
+        self.B = 1 if dist.dim() == 2 else dist.shape[0]      # instances the tables were built for
         self.dist_t = dist_t                       # what two_opt_'s dense kernel wants as well
         self.tables = self._build(dist)
         self.tables_t = self.tables if isinstance(dist_t, str) or dist_t is dist else self._build(dist_t)
@@ -493,9 +496,16 @@ def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None, t
         if dist.dim() == 2:                         # one matrix (and one table set) for every tour
             t3 = t3.view(1, -1, n)
         B, T, _ = t3.shape
+        assert tables.B == B, f"two_opt_: tables built for {tables.B} instances, launch has {B}"
         dev = tours.device
         with torch.cuda.device(dev):
-            if kernel == "nbr":
+            if kernel == "cached":                  # one launch of the NLS kernel without rounds: dirty-list sweeps
+                sweeps = torch.empty(tuple(shape), dtype=torch.int32, device=dev) if want_sweeps else None
+                rc = _lib.lib().daco_tsp_nls(_stream(dev), B, T, n, dist.data_ptr(), dbs, tables.tables.data_ptr(),
+                                             tables.tables_t.data_ptr(), None, 0, None, None, t3.data_ptr(),
+                                             int(max_iterations), 0, 0, sweeps.data_ptr() if want_sweeps else None,
+                                             None, None)
+            elif kernel == "nbr":
                 sweeps = torch.empty(tuple(shape), dtype=torch.int32, device=dev) if want_sweeps else None
                 rc = _lib.lib().daco_two_opt_nbr(_stream(dev), B, T, n, dist.data_ptr(), dbs, tables.tables.data_ptr(),
                                                  tables.tables_t.data_ptr(), t3.data_ptr(), int(max_iterations),
@@ -572,11 +582,14 @@ def two_opt_tables(dist, dist_t=None):
 
 
 def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuristic_dist_t=None, tables=None,
-         heuristic_tables=None):
+         heuristic_tables=None, fused=None, want_costs=False, counters=None):
     """Batched NLS driver (tsp_nls/aco.py:241-258) fully on the device.
-    dist, heuristic_dist [B,n,n]; tours [B,T,n] int16 (one row per tour).  Returns improved tours.
+    dist, heuristic_dist [B,n,n]; tours [B,T,n] int16 (one row per tour).  Returns improved tours (and, with want_costs,
+    their f32 lengths as daco_tour_costs computes them).
     dist_t / heuristic_dist_t, tables / heuristic_tables: see two_opt_ (callers that run many iterations pass them once;
-    the tables are built here otherwise -- one sort of every matrix row -- since the 21 passes of one NLS amortise them)."""
+    the tables are built here otherwise -- one sort of every matrix row -- since the 21 passes of one NLS amortise them).
+    fused (default: whenever the tables exist, i.e. n <= 1024; DACO_NLS_FUSED=0 turns it off): the whole search of a tour
+    in one launch of daco_tsp_nls; otherwise 2 T_nls + 1 two_opt_ passes driven from here (the same tours either way)."""
     B, T, n = tours.shape
     if dist_t is None:
         dist_t = transposed_for_two_opt(dist) if tables is None else tables.dist_t
@@ -586,9 +599,30 @@ def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuri
         tables = two_opt_tables(dist, dist_t)
     if heuristic_tables is None:
         heuristic_tables = two_opt_tables(heuristic_dist, heuristic_dist_t)
+    if fused is None:
+        fused = os.environ.get("DACO_NLS_FUSED", "1") != "0"
 
     def lengths(t):
         return tour_costs(dist, t.permute(0, 2, 1).to(torch.int64).contiguous())
+
+    if fused and tables is not None and heuristic_tables is not None:
+        _require_gpu(dist, heuristic_dist, tours)
+        assert tours.dtype in (torch.int16, torch.uint16)
+        assert tables.B == B and heuristic_tables.B == B and dist.dim() == 3 and heuristic_dist.dim() == 3
+        best = tours.clone().contiguous()
+        d, dbs = _bstride(dist, n)
+        h, hbs = _bstride(heuristic_dist, n)
+        dev = tours.device
+        with torch.cuda.device(dev):
+            costs = torch.empty((B, T), dtype=torch.float32, device=dev) if want_costs else None
+            rc = _lib.lib().daco_tsp_nls(_stream(dev), B, T, n, d.data_ptr(), dbs, tables.tables.data_ptr(),
+                                         tables.tables_t.data_ptr(), h.data_ptr(), hbs,
+                                         heuristic_tables.tables.data_ptr(), heuristic_tables.tables_t.data_ptr(),
+                                         best.data_ptr(), int(maxt), int(T_nls), int(T_p), None,
+                                         costs.data_ptr() if want_costs else None,
+                                         counters.data_ptr() if counters is not None else None)
+        _lib.check(rc, "daco_tsp_nls")
+        return (best, costs) if want_costs else best
 
     best = tours.clone().contiguous()
     two_opt_(dist, best, maxt, dist_t=dist_t, tables=tables)
@@ -603,7 +637,7 @@ def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuri
         improved = new_costs < best_costs
         best = torch.where(improved.unsqueeze(2), new, best)
         best_costs = torch.where(improved, new_costs, best_costs)
-    return best
+    return (best, best_costs) if want_costs else best
 
 
 class BatchedTSP:
@@ -645,6 +679,7 @@ class BatchedTSP:
         self._dist_t = None
         self._tables = self._htables = None
         self._cmin = None
+        self.nls_counters = None                  # optional int64[2] on the device: sweeps, list entries walked (bench)
 
     def _heuristic_dist(self):
         if self._hdist is None:
@@ -671,6 +706,7 @@ class BatchedTSP:
         if _iter_dev is None:
             self.iteration += 1
         if self.local_search is not None:
+            ls_costs = None
             tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
             maxt = 10000 if self.inference else self.n // 4
             if self._dist_t is None:
@@ -683,10 +719,12 @@ class BatchedTSP:
                 if self._hdist_t is None:
                     self._hdist_t = transposed_for_two_opt(hd)
                     self._htables = two_opt_tables(hd, self._hdist_t)
-                tours = nls_(self.distances, hd, tours, maxt, dist_t=self._dist_t, heuristic_dist_t=self._hdist_t,
-                             tables=self._tables, heuristic_tables=self._htables)
+                # (costs: the fused search sums the tour lengths in daco_tour_costs' order, bit for bit)
+                tours, ls_costs = nls_(self.distances, hd, tours, maxt, dist_t=self._dist_t,
+                                       heuristic_dist_t=self._hdist_t, tables=self._tables,
+                                       heuristic_tables=self._htables, want_costs=True, counters=self.nls_counters)
             paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
-            costs, nbr = tour_costs(self.distances, paths), None
+            costs, nbr = (tour_costs(self.distances, paths) if ls_costs is None else ls_costs), None
         # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)
         new_max = track_best_(costs, paths, self.lowest_cost, self.shortest_path,
                               mmas_scale=self.n if self.min_max else None)

@@ -159,21 +159,11 @@ class ACO(_TspACO):
 
     @torch.no_grad()
     def nls(self, paths, inference=False, T_nls=10, T_p=20):
+        """tsp_nls/aco.py:241-258.  One launch for the whole search of every tour (engine.nls_: daco_tsp_nls) where the
+        candidate tables exist (n <= 1024), the pass-by-pass driver otherwise; the same tours either way."""
         maxt = 10000 if inference else self.problem_size // 4
         dist = self.distances.to(torch.float32)
-        dist_t, hd_t = self._transposed("distances"), self._transposed("heuristic_dist")
         tabs, hd_tabs = self._tables("distances"), self._tables("heuristic_dist")
-        best_paths = two_opt_device(dist, self._tours(paths), maxt, dist_t, tabs)
-        best_costs = self._tour_costs(best_paths)
-        new_paths = best_paths
-
-        for _ in range(T_nls):
-            perturbed_paths = two_opt_device(self.heuristic_dist, new_paths, T_p, hd_t, hd_tabs)
-            new_paths = two_opt_device(dist, perturbed_paths, maxt, dist_t, tabs)
-            new_costs = self._tour_costs(new_paths)
-
-            improved = new_costs < best_costs
-            best_paths = torch.where(improved.unsqueeze(1), new_paths, best_paths)
-            best_costs = torch.where(improved, new_costs, best_costs)
-
-        return self._paths(best_paths)
+        best = engine.nls_(dist.unsqueeze(0), self.heuristic_dist.unsqueeze(0), self._tours(paths).unsqueeze(0), maxt,
+                           T_nls=T_nls, T_p=T_p, tables=tabs, heuristic_tables=hd_tabs)
+        return self._paths(best[0])

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 117 /* 0.1.16: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 118 /* 0.1.17: bumped whenever an entry point's signature changes */
 
 /* error codes */
 #define DACO_OK 0
@@ -334,6 +334,25 @@ int daco_two_opt_nbr(void *stream, int B, int T, int n, const float *dist, long 
  */
 int daco_two_opt_auto(void *stream, int B, int T, int n, const float *dist, const float *dist_T, long dist_bstride,
                       const void *tables, const void *tables_T, uint16_t *tours, long max_iterations, int32_t *sweeps);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_tsp_nls -- replaces ACO.nls (and, with T_nls = 0, ACO.two_opt) in ONE launch
+ *   tsp_nls/aco.py:234-258 over tsp_nls/two_opt.py:6-39
+ * Per tour: 2-opt on `dist` (at most max_iterations sweeps); then T_nls rounds of { T_p sweeps of 2-opt on `hdist` (the
+ * perturbation matrix 1/(eta/rowmax + 1e-5), tsp_nls/aco.py:230-232), 2-opt on `dist` again, keep the tour if its f32
+ * length (daco_tour_costs' summation order) is strictly below the best so far }.  The moves of every pass are the
+ * reference's (same candidate rule and pair arithmetic as daco_two_opt_nbr); a sweep re-walks only the candidate lists
+ * that the previous move can have changed and reuses the cached minimum of every other list (csrc/daco_nls.hip).
+ *   tables / tables_T, htables / htables_T: daco_two_opt_prepare of dist / hdist and of their transposes (the same
+ *          pointer when the matrix is symmetric); hdist and its tables may be NULL when T_nls = 0
+ *   tours  in/out [B][T][n] uint16: the best tour found
+ *   sweeps out [B][T] int32 or NULL: sweeps over all passes;  costs out [B][T] f32 or NULL: length of the returned tour
+ *   counters NULL or two uint64 on the device, incremented by: [0] sweeps, [1] list entries walked (bench bookkeeping)
+ */
+int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist, long dist_bstride, const void *tables,
+                 const void *tables_T, const float *hdist, long hdist_bstride, const void *htables, const void *htables_T,
+                 uint16_t *tours, long max_iterations, int T_nls, long T_p, int32_t *sweeps, float *costs,
+                 unsigned long long *counters);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_gnn_forward -- replaces Net.forward in eval mode

@@ -330,3 +330,125 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
             ref, rs = oracle.two_opt_batch(d, tours.astype(np.uint16), maxit)
             assert np.array_equal(a.cpu().numpy().astype(np.uint16), ref) and np.array_equal(sa[0].cpu().numpy(), rs), (case, n, kind)
     os.environ.pop("DACO_TWO_OPT_WIDE", None)
+
+
+# ------------------------------------------------------------------ daco_tsp_nls: dirty-list sweeps, the whole NLS in one launch
+NLS_SHAPES = (("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"))     # threads per tour, entries per thread and round
+
+
+@pytest.mark.parametrize("n,Tn,B,maxit", [(4, 3, 1, 50), (5, 4, 2, 50), (33, 6, 1, 1000), (129, 5, 2, 1000), (257, 4, 1, 30),
+                                           (500, 6, 1, 125), (511, 3, 1, 60), (512, 3, 1, 60), (1000, 2, 1, 40),
+                                           (1024, 2, 1, 25)])
+def test_cached_list_kernel_vs_oracle(n, Tn, B, maxit, monkeypatch):
+    """daco_tsp_nls without rounds = one 2-opt search whose sweeps re-walk only the candidate lists the previous move
+    can have changed: tours and sweep counts equal the oracle's full evaluation bit for bit, from random permutations
+    (long segments, every list dirty) to convergence (short ones), for every thread / queue shape."""
+    from deepaco_amd import engine
+    d = tsp_instance(n, 7 + n, B)
+    rng = np.random.default_rng(n)
+    tours = np.stack([[rng.permutation(n) for _ in range(Tn)] for _ in range(B)]).astype(np.int16)
+    dd = d.to(dev())
+    tabs = engine.TwoOptTables(dd)
+    refs = [oracle.two_opt_batch(d[b].numpy(), tours[b].astype(np.uint16), maxit) for b in range(B)]
+    for nt, queue in NLS_SHAPES:
+        monkeypatch.setenv("DACO_NLS_THREADS", nt)
+        monkeypatch.setenv("DACO_NLS_GROUP", queue)
+        out, sweeps = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel="cached")
+        for b in range(B):
+            ref, rs = refs[b]
+            assert np.array_equal(out[b].cpu().numpy().astype(np.uint16), ref), (n, b, nt, queue)
+            assert np.array_equal(sweeps[b].cpu().numpy(), rs), (nt, queue)
+
+
+def _nls_case(B, n, A, seed, kind):
+    from deepaco_amd import engine
+    d = tsp_instance(n, seed, B).to(dev())
+    if kind == "asym_dist":                      # a distance matrix that is not symmetric (nothing the search assumes)
+        g = torch.Generator().manual_seed(seed)
+        d = (d * (1 + 0.2 * torch.rand(B, n, n, generator=g).to(dev()))).contiguous()
+    eta = 1 / d
+    if kind == "sparse":                         # the k-sparse heuristic of config 3: a plateau of 1e5 in the perturbation matrix
+        _, idx = torch.topk(d, k=max(4, n // 10), dim=2, largest=False)
+        sp = torch.full_like(d, 1e10).scatter_(2, idx, torch.gather(d, 2, idx))
+        eta = 1 / sp
+    elif kind == "learned":                      # dense positive heuristic of very different magnitudes
+        g = torch.Generator().manual_seed(seed + 1)
+        eta = (torch.rand(B, n, n, generator=g).to(dev()) ** 4 + 1e-10).contiguous()
+    paths, _, _, _ = engine.tsp_sample(torch.ones_like(d), eta if kind != "learned" else 1 / d, A, mode="scan", seed=seed,
+                                       fixed_start=0)
+    tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+    hd = (1 / (eta / eta.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+    if kind == "sym_hd":                         # a symmetric perturbation matrix takes the one-walk path in both kinds of pass
+        hd = ((hd + hd.transpose(1, 2)) / 2).contiguous()
+    return d, hd, tours
+
+
+@pytest.mark.parametrize("kind,B,n,A,maxt", [("dense", 2, 300, 24, 75), ("sparse", 2, 500, 16, 125), ("sparse", 1, 200, 40, 10000),
+                                              ("learned", 2, 150, 32, 37), ("asym_dist", 2, 120, 24, 30), ("sym_hd", 1, 257, 12, 64),
+                                              ("dense", 3, 40, 20, 10), ("sparse", 1, 1000, 3, 250)])
+def test_fused_nls_equals_pass_by_pass_driver(kind, B, n, A, maxt, monkeypatch):
+    """engine.nls_ fused (one launch of daco_tsp_nls per colony iteration) against the pass-by-pass driver over the
+    round-2 kernels -- which test_nls_driver_matches_reference pins on the reference's output and the tests above on
+    the oracle: the same tours, and lengths equal to daco_tour_costs bit for bit."""
+    from deepaco_amd import engine
+    d, hd, tours = _nls_case(B, n, A, 11 + n, kind)
+    td, th = engine.TwoOptTables(d), engine.TwoOptTables(hd)
+    ref = engine.nls_(d, hd, tours, maxt, tables=td, heuristic_tables=th, fused=False)
+    ref_costs = engine.tour_costs(d, ref.permute(0, 2, 1).to(torch.int64).contiguous())
+    for nt, queue in NLS_SHAPES:
+        monkeypatch.setenv("DACO_NLS_THREADS", nt)
+        monkeypatch.setenv("DACO_NLS_GROUP", queue)
+        counters = torch.zeros(2, dtype=torch.int64, device=dev())
+        out, costs = engine.nls_(d, hd, tours, maxt, tables=td, heuristic_tables=th, fused=True, want_costs=True,
+                                 counters=counters)
+        assert torch.equal(out, ref), (kind, nt, queue)
+        assert torch.equal(costs.view(torch.int32), ref_costs.view(torch.int32)), (kind, nt, queue)
+        assert int(counters[0]) >= 21 * B * A and int(counters[1]) > 0
+    # other schedules: no rounds, one round, a single perturbation sweep
+    for T_nls, T_p in ((0, 20), (1, 1), (3, 5)):
+        a = engine.nls_(d, hd, tours, maxt, T_nls=T_nls, T_p=T_p, tables=td, heuristic_tables=th, fused=False)
+        b = engine.nls_(d, hd, tours, maxt, T_nls=T_nls, T_p=T_p, tables=td, heuristic_tables=th, fused=True)
+        assert torch.equal(a, b), (kind, T_nls, T_p)
+
+
+def test_cached_list_kernel_many_small_cases_with_ties(monkeypatch):
+    """Ninety small searches, dirty-list kernel vs dense kernel (and the oracle for a third): integer grids (ties on
+    (i, j), tolerance ranks with ties), duplicate points, row-scaled and random asymmetric matrices, signed entries,
+    sweep caps that stop the search midway, every thread shape."""
+    from deepaco_amd import engine
+    rng = np.random.default_rng(3031)
+    for case in range(90):
+        n = int(rng.integers(4, 200))
+        kind = case % 5
+        if kind == 4:
+            d = rng.uniform(-1.0, 1.0, size=(n, n)).astype(np.float32)
+            if case % 2:
+                d = ((d + d.T) / 2).astype(np.float32)
+        elif kind == 0:
+            c = rng.integers(0, 6, size=(n, 2)).astype(np.float32)
+            d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
+        elif kind == 1:
+            c = rng.random((n, 2)).astype(np.float32)
+            c[rng.integers(0, n, size=max(1, n // 10))] = c[0]
+            d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
+        elif kind == 2:
+            c = rng.random((n, 2)).astype(np.float32)
+            d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
+            d = (d * rng.uniform(1.0, 300.0, size=(n, 1))).astype(np.float32)
+        else:
+            d = (rng.random((n, n)) * 10 ** rng.uniform(-2, 4)).astype(np.float32)
+        np.fill_diagonal(d, 0.0 if kind == 4 else 1e9)
+        Tn = int(rng.integers(1, 9))
+        maxit = int(rng.choice([1, 3, 17, 10000]))
+        tours = np.stack([rng.permutation(n) for _ in range(Tn)]).astype(np.int16)
+        dd = T(d)
+        tabs = engine.TwoOptTables(dd)
+        nt, queue = NLS_SHAPES[case % 5]
+        monkeypatch.setenv("DACO_NLS_THREADS", nt)
+        monkeypatch.setenv("DACO_NLS_GROUP", queue)
+        a, sa = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True)
+        b, sb = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True, tables=tabs, kernel="cached")
+        assert torch.equal(a, b) and torch.equal(sa, sb), (case, n, kind, maxit, nt)
+        if case % 3 == 0:
+            ref, rs = oracle.two_opt_batch(d, tours.astype(np.uint16), maxit)
+            assert np.array_equal(b.cpu().numpy().astype(np.uint16), ref) and np.array_equal(sb[0].cpu().numpy(), rs), (case, n, kind)
