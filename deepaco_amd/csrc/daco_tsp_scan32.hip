@@ -223,7 +223,7 @@ tsp_scan32_kernel(const SampleParams p) {
     // paths[b][t][abase + k]: 8 lanes = one 64-byte run per step row
     int64_t *pb = p.paths + (size_t)b * n * A + abase;
     const int k = threadIdx.x & 7;
-    if (k < nant)
+    if (k < nant && p.paths)
       for (int t = threadIdx.x >> 3; t < n; t += 32) pb[(size_t)t * A + k] = (int64_t)tour_s[k][t];
   }
   if (p.costs) {
@@ -235,28 +235,39 @@ tsp_scan32_kernel(const SampleParams p) {
     const float *mine = dstage[wave][up];
     float cost = 0.0f;
     if (active) {
-      for (int base = 1; base < n; base += 64) {
-        const int t = base + lane;
-        float d0 = 0.0f, d1 = 0.0f;
-        if (t < n) {
-          d0 = dist_b[(uint32_t)t0[t] * (uint32_t)n + t0[t - 1]];
-          d1 = dist_b[(uint32_t)t1[t] * (uint32_t)n + t1[t - 1]];
-        }
-        dstage[wave][0][lane] = d0;
-        dstage[wave][1][lane] = d1;
-        __builtin_amdgcn_wave_barrier();
-        if (lead) {
+      // every gather of the two tours is issued before the first one is used (one trip to the L2 instead of one per
+      // 64-edge chunk: the chunks' trips in sequence were 0.08 ms of the launch), the closing edges included
+      constexpr int NCH = (FL + 63) / 64;
+      float d0[NCH], d1[NCH];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const float4 v = *(const float4 *)(mine + 4 * q);      // (slots past the tour's end hold +0.0f)
-            cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
-          }
+      for (int c = 0; c < NCH; ++c) {
+        const int t = 1 + c * 64 + lane;
+        d0[c] = 0.0f; d1[c] = 0.0f;
+        if (t < n) {
+          d0[c] = dist_b[(uint32_t)t0[t] * (uint32_t)n + t0[t - 1]];
+          d1[c] = dist_b[(uint32_t)t1[t] * (uint32_t)n + t1[t - 1]];
         }
-        __builtin_amdgcn_wave_barrier();
+      }
+      const uint16_t *tm = up ? t1 : t0;
+      const float closing = dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (1 + c * 64 < n) {                               // uniform
+          dstage[wave][0][lane] = d0[c];
+          dstage[wave][1][lane] = d1[c];
+          __builtin_amdgcn_wave_barrier();
+          if (lead) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float4 v = *(const float4 *)(mine + 4 * q);      // (slots past the tour's end hold +0.0f)
+              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
       }
       if (lead && a0 + up < A) {
-        const uint16_t *tm = up ? t1 : t0;
-        cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+        cost = cost + closing;
         p.costs[(size_t)b * A + a0 + up] = cost;
       }
     }
