@@ -34,8 +34,9 @@ SIGNATURES = {
     "daco_directed_table_bytes": (_sz, [_i, _i, _i]),
     "daco_track_best": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f]),
     "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _vp, _u32, _i,
-                              _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz]),
-    "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp]),
+                              _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, C.c_double]),
+    "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                                  C.c_double]),
     "daco_gnn_param_floats": (_sz, [_i]),
     "daco_gnn_workspace_bytes": (_sz, [_i, _i]),
     "daco_gnn_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),

@@ -1,0 +1,14 @@
+"""Net of bpp/net.py: one node feature (item size), no par_net_phe head.  `from net import Net`."""
+import os
+import sys
+
+try:
+    from deepaco_amd.net import Net as _Net, EmbNet, MLP, ParNet  # noqa: F401
+except ImportError:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd.net import Net as _Net, EmbNet, MLP, ParNet  # noqa: F401
+
+
+class Net(_Net):
+    def __init__(self):
+        super().__init__(feats=1, with_phe=False)

@@ -32,6 +32,8 @@ struct BackwardParams {
   const int32_t *lens;           // [B][A] (CVRP) or null
   const float *demand;           // [B][n] (CVRP) or null
   float capacity;
+  const double *demand64;        // [B][n] or null: load bookkeeping in double (cvrp_nls/, as daco_cvrp_sample's demand64)
+  double capacity64;
   float *grad_eta;               // [B][n][n], accumulated into (caller zeroes)
   int segs;                      // waves per (instance, ant): each replays the whole route but differentiates 1/segs of its steps
 };
@@ -55,6 +57,7 @@ sample_backward_kernel(const BackwardParams p) {
   const float *gl = p.grad_logp + (size_t)b * (p.rows - 1) * A + a;
   float *grad = p.grad_eta + (size_t)b * n * n;
   const float *demand = CVRP ? p.demand + (size_t)b * n : nullptr;
+  const double *demand64 = (CVRP && p.demand64) ? p.demand64 + (size_t)b * n : nullptr;   // (uniform) load bookkeeping in double
   const int len_all = CVRP ? p.lens[(size_t)b * A + a] : n;
   const int per = (len_all - 1 + p.segs - 1) / p.segs;
   const int t_lo = 1 + seg * per, len = min(len_all, t_lo + per);       // this wave differentiates steps [t_lo, len)
@@ -65,6 +68,7 @@ sample_backward_kernel(const BackwardParams p) {
   if (!CVRP && (prev & 63) == lane) vis |= 1ull << (prev >> 6);
   int remaining = n - 1;
   float used = CVRP ? demand[0] : 0.0f;
+  double used64 = demand64 ? 0.0 + demand64[0] : 0.0;
   for (int t = 1; t < len; ++t) {
     const int j = (int)path[(size_t)t * A];
     const float g = gl[(size_t)(t - 1) * A];
@@ -75,6 +79,7 @@ sample_backward_kernel(const BackwardParams p) {
       const float pr = pj / S;
       if (pr > DACO_EPS_F32 && pr < 1.0f - DACO_EPS_F32) {      // inside the clamp: gradient flows
         const float rem = CVRP ? p.capacity - used : 0.0f;
+        const double rem64 = p.capacity64 - used64;
         const float c = g / S;
         float *grow = grad + (size_t)prev * n;
         for (int ch = 0; ch < chunks; ++ch) {
@@ -83,7 +88,7 @@ sample_backward_kernel(const BackwardParams p) {
           bool open = !((vis >> ch) & 1);
           if (CVRP) {
             if (k == 0) open = !(prev == 0 && remaining > 0);
-            open = open && !(demand[k] > rem);
+            open = open && !(demand64 ? demand64[k] > rem64 : demand[k] > rem);
           }
           if (!open) continue;
           const float e = erow[k];
@@ -97,8 +102,9 @@ sample_backward_kernel(const BackwardParams p) {
     }
     if (CVRP) {
       if (j != 0) { if ((j & 63) == lane) vis |= 1ull << (j >> 6); --remaining; }
-      else used = 0.0f;
+      else { used = 0.0f; used64 = 0.0; }
       used = used + demand[j];
+      if (demand64) used64 = used64 + demand64[j];
     } else {
       if ((j & 63) == lane) vis |= 1ull << (j >> 6);
     }
@@ -258,7 +264,7 @@ extern "C" int daco_sibling_backward(void *stream, int kind, int B, int n, int A
   BackwardParams &bp = sp.b;
   bp.B = B; bp.n = n; bp.A = A; bp.rows = rows; bp.tau = tau; bp.eta = eta; bp.tau_bs = tau_bstride;
   bp.eta_bs = eta_bstride; bp.alpha = alpha; bp.beta = beta; bp.paths = paths; bp.rowsum = rowsum;
-  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = nullptr; bp.capacity = 0.0f; bp.grad_eta = grad_eta; bp.segs = 1;
+  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = nullptr; bp.capacity = 0.0f; bp.demand64 = nullptr; bp.capacity64 = 0.0; bp.grad_eta = grad_eta; bp.segs = 1;
   sp.aux_vec = aux_vec; sp.aux_mat = aux_mat; sp.aux_bs = aux_mat_bstride; sp.scalar0 = scalar0; sp.wts = item_weights; sp.m = m;
   dim3 grid((unsigned)(B * ((A + 3) / 4))), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -279,7 +285,7 @@ extern "C" int daco_sample_backward(void *stream, int B, int n, int A, int rows,
                                     long tau_bstride, const float *eta, long eta_bstride, float alpha,
                                     float beta, const int64_t *paths, const float *rowsum,
                                     const float *grad_logp, const int32_t *lens, const float *demand,
-                                    float capacity, float *grad_eta) {
+                                    float capacity, float *grad_eta, const double *demand64, double capacity64) {
   if (B <= 0 || n < 2 || A <= 0 || rows < 2 || !tau || !eta || !paths || !rowsum || !grad_logp || !grad_eta) {
     set_error("daco_sample_backward: bad argument (B=%d n=%d A=%d rows=%d)", B, n, A, rows);
     return DACO_E_BADARG;
@@ -291,7 +297,7 @@ extern "C" int daco_sample_backward(void *stream, int B, int n, int A, int rows,
   BackwardParams bp;
   bp.B = B; bp.n = n; bp.A = A; bp.rows = rows; bp.tau = tau; bp.eta = eta; bp.tau_bs = tau_bstride;
   bp.eta_bs = eta_bstride; bp.alpha = alpha; bp.beta = beta; bp.paths = paths; bp.rowsum = rowsum;
-  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = demand; bp.capacity = capacity; bp.grad_eta = grad_eta;
+  bp.grad_logp = grad_logp; bp.lens = lens; bp.demand = demand; bp.capacity = capacity; bp.demand64 = demand64; bp.capacity64 = capacity64; bp.grad_eta = grad_eta;
   // waves per ant so that a small batch still fills the device's ~2048 wave slots with independent chains
   int segs = 1;
   while (segs < 8 && (long)B * A * segs * 2 <= 2048) segs *= 2;

@@ -44,6 +44,8 @@ struct SampleParams {
   int step;              // PROB_STEP: step index (RNG counter word)
   const float *demand;   // [B][n]
   float capacity;
+  const double *demand64;  // PROB_CVRP64: [B][n] float64 demands (cvrp_nls/ keeps its data in double) and capacity
+  double capacity64;
   int Lmax;              // rows of paths (and Lmax-1 rows of logp)
   int noise_steps;       // rows of the noise tensor
   int32_t *lens;         // [B][A] rows used by each ant
@@ -99,15 +101,17 @@ struct Visited {
   }
 };
 
-enum { PROB_TSP = 0, PROB_CVRP = 1, PROB_STEP = 2, PROB_SOP = 3, PROB_PCTSP = 4, PROB_OP = 5, PROB_MKP = 6 };
+enum { PROB_TSP = 0, PROB_CVRP = 1, PROB_STEP = 2, PROB_SOP = 3, PROB_PCTSP = 4, PROB_OP = 5, PROB_MKP = 6, PROB_CVRP64 = 7 };
 
-// PROB_TSP: whole closed tour; PROB_CVRP: whole capacity-constrained route sequence;
+// PROB_TSP: whole closed tour; PROB_CVRP: whole capacity-constrained route sequence; PROB_CVRP64: the same with the load
+// bookkeeping of cvrp_nls/aco.py:254-272 in float64 (used = used + demand[cur]; demand > capacity - used, all double there:
+// with demands k/50 a customer that fits exactly is common, and whether it passes is a matter of the last bit);
 // PROB_STEP: ONE draw per ant from an externally maintained mask (ACO.pick_move for the sibling
 // problems, whose feasibility logic stays with the caller).
 template <int VEC, int CH, int MODE, bool LOGP, int PROB>
 __global__ void __launch_bounds__(256)
 tsp_sample_kernel(const SampleParams p) {
-  constexpr bool CVRP = PROB == PROB_CVRP, STEP = PROB == PROB_STEP, SOP = PROB == PROB_SOP,
+  constexpr bool CVRP = PROB == PROB_CVRP || PROB == PROB_CVRP64, DEM64 = PROB == PROB_CVRP64, STEP = PROB == PROB_STEP, SOP = PROB == PROB_SOP,
                  PCTSP = PROB == PROB_PCTSP, OP = PROB == PROB_OP, MKP = PROB == PROB_MKP;
   constexpr bool VARLEN = CVRP || PCTSP || OP || MKP;   // solution length differs between ants
   constexpr bool DUMMY = OP || MKP;                     // last node = absorbing dummy, never drawn
@@ -138,7 +142,8 @@ tsp_sample_kernel(const SampleParams p) {
   const float *dist_b = (CVRP && p.costs) ? p.dist + (size_t)b * p.dist_bs : nullptr;      // (TSP: in the epilogue)
   uint32_t *nbr_a = nullptr;                            // (TSP: the neighbour table is written by the epilogue)
   int pprev = 0, second = 0;                            // neighbour-table bookkeeping
-  const float *demand_b = CVRP ? p.demand + (size_t)b * n : nullptr;
+  const float *demand_b = (CVRP && !DEM64) ? p.demand + (size_t)b * n : nullptr;
+  const double *demand64_b = DEM64 ? p.demand64 + (size_t)b * n : nullptr;
 
   // ---- start node
   int prev;
@@ -169,6 +174,8 @@ tsp_sample_kernel(const SampleParams p) {
   // per-candidate constants / counters of the constrained problems (this lane's candidates):
   //   CVRP demand, SOP number of unvisited predecessors, OP distance back to the depot
   float dem[CH][VEC];
+  double dem64[DEM64 ? CH : 1][VEC];                    // PROB_CVRP64: the demands and the load in double
+  double used64 = 0.0;
   int remaining = n - 1;                                // CVRP/PCTSP: customers / nodes not yet visited
   float used = 0.0f;                                    // CVRP load on the route; PCTSP prize; OP length
   bool finished = false;
@@ -182,9 +189,11 @@ tsp_sample_kernel(const SampleParams p) {
     static_for<NJ>([&](auto J) {
       constexpr int j = J, c = j / VEC, v = j % VEC;
       const int k = (c * 64 + lane) * VEC + v;
-      dem[c][v] = k < n ? demand_b[k] : __builtin_inff();
+      if constexpr (DEM64) dem64[c][v] = k < n ? demand64_b[k] : (double)__builtin_inff();
+      else dem[c][v] = k < n ? demand_b[k] : __builtin_inff();
     });
-    used = used + demand_b[0];
+    if constexpr (DEM64) used64 = used64 + demand64_b[0];
+    else used = used + demand_b[0];
   }
   if constexpr (SOP) {                                  // sop/aco.py:118-126: node 0 is visited first
     float r0[CH][VEC];
@@ -277,11 +286,19 @@ tsp_sample_kernel(const SampleParams p) {
     }
     if constexpr (CVRP) {
       if (MODE == DACO_RACE_NOISE && t - 1 >= p.noise_steps) { overflow = true; break; }
-      const float rem = p.capacity - used;
-      static_for<NJ>([&](auto J) {
-        constexpr int j = J;
-        blk.template set_if<j>(dem[j / VEC][j % VEC] > rem);          // strict, cvrp/aco.py:200
-      });
+      if constexpr (DEM64) {
+        const double rem = p.capacity64 - used64;
+        static_for<NJ>([&](auto J) {
+          constexpr int j = J;
+          blk.template set_if<j>(dem64[j / VEC][j % VEC] > rem);      // strict, in double: cvrp_nls/aco.py:267-270
+        });
+      } else {
+        const float rem = p.capacity - used;
+        static_for<NJ>([&](auto J) {
+          constexpr int j = J;
+          blk.template set_if<j>(dem[j / VEC][j % VEC] > rem);        // strict, cvrp/aco.py:200
+        });
+      }
       if (lane == 0 && prev == 0 && remaining > 0) blk.lo |= 1u;       // cvrp/aco.py:179
     }
     // ---- stream the row of `prev`
@@ -426,8 +443,9 @@ tsp_sample_kernel(const SampleParams p) {
     }
     if constexpr (CVRP) {
       if (choice != 0) { mark(choice); --remaining; }
-      else used = 0.0f;
-      used = used + demand_b[choice];                  // scalar load
+      else { used = 0.0f; used64 = 0.0; }
+      if constexpr (DEM64) used64 = used64 + demand64_b[choice];
+      else used = used + demand_b[choice];             // scalar load
       finished = remaining == 0 && choice == 0;
     } else if constexpr (SOP) {
       mark(choice);

@@ -92,7 +92,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr; sp.hubmask = nullptr; sp.tab_lens = nullptr;
-  sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 0; sp.lens = nullptr;
+  sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 0; sp.lens = nullptr; sp.demand64 = nullptr; sp.capacity64 = 0.0;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
   const bool lp = logp != nullptr;
@@ -110,14 +110,16 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
                                 int noise_steps, uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax,
                                 int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
                                 const float *dist, long dist_bstride, float *costs, void *next_table,
-                                void *workspace, size_t workspace_bytes) {
+                                void *workspace, size_t workspace_bytes, const double *demand64, double capacity64) {
   if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !demand || !paths || !workspace || Lmax < 2) {
     set_error("daco_cvrp_sample: bad argument (B=%d n=%d A=%d Lmax=%d)", B, n, A, Lmax);
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
   const bool packed = mode == DACO_SCAN && (size_t)n * A * 8 < ((size_t)1 << 32);
-  const bool four_per_wave = packed && n <= DACO_SCAN16_MAX_N, two_per_wave = packed && n > DACO_SCAN16_MAX_N && n <= DACO_SCAN32_MAX_N;
+  // (float64 load bookkeeping: the one-ant-per-wavefront kernel's PROB_CVRP64 policy)
+  const bool four_per_wave = packed && !demand64 && n <= DACO_SCAN16_MAX_N,
+             two_per_wave = packed && !demand64 && n > DACO_SCAN16_MAX_N && n <= DACO_SCAN32_MAX_N;
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
@@ -155,10 +157,12 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = (uint32_t *)next_table; sp.hubmask = hubmask; sp.tab_lens = tab_lens;
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;
+  sp.demand64 = demand64; sp.capacity64 = capacity64;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
   hipError_t e = four_per_wave ? launch_cvrp_scan16(sp, logp != nullptr, s)
                : two_per_wave ? launch_cvrp_scan32(sp, logp != nullptr, s)
+               : demand64     ? dispatch_sample<PROB_CVRP64>(sp, vec, CH, mode, logp != nullptr, s)
                               : dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
   if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
@@ -207,7 +211,7 @@ extern "C" int daco_pick_move(void *stream, int B, int n, int A, const void *pro
   sp.norm_passes = 1; sp.start = prev; sp.fixed_start = -1; sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = nullptr; sp.gid_bstride = 0;
   sp.ant_gid0 = ant_gid0; sp.paths = actions; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = nullptr; sp.dist_bs = 0; sp.costs = nullptr; sp.nbr = nullptr;
-  sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 1; sp.lens = nullptr;
+  sp.demand = nullptr; sp.capacity = 0.0f; sp.Lmax = 0; sp.noise_steps = 1; sp.lens = nullptr; sp.demand64 = nullptr; sp.capacity64 = 0.0;
   sp.mask = mask; sp.step = step;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
   hipError_t e = dispatch_sample<PROB_STEP>(sp, vec, CH, mode, logp != nullptr, (hipStream_t)stream);

@@ -1,8 +1,11 @@
 """ACO for CVRP with the constructor, sampler and local-search surface of the reference's cvrp_nls/aco.py.
 
 The tour construction, costing and pheromone update of cvrp_nls/aco.py:35-272 are the same code
-as cvrp/aco.py (float64 instance data, capacity normalised to 1.0) and run on the same HIP
-kernels here (instance data are cast to float32 on the device).  `sample()` returns
+as cvrp/aco.py on float64 instance data with the capacity normalised to 1.0.  They run on the same HIP
+kernels here; probabilities, costs and pheromone are float32, the vehicle-load bookkeeping (which customer still
+fits -- with demands k / capacity an exact fit is common and float32 decides 5-10 % of the steps differently,
+tests/golden/gen_g1_cvrp_nls.py) is float64 as in the reference whenever `demand` is a float64 tensor
+(fixtures g1f64_cvrp_nls_*: the reference's float64 routes on recorded noise).  `sample()` returns
 `(costs, log_probs, paths)` as in cvrp_nls/aco.py:100-104.
 
 Local search (`swapstar=True`; cvrp_nls/aco.py:106-128, 443-448).  The reference hands every ant's routes to the
@@ -55,7 +58,9 @@ class ACO(_CvrpACO):
     def __init__(self, distances, demand, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
                  pheromone=None, heuristic=None, min=None, device='cpu', adaptive=False, capacity=CAPACITY,
                  swapstar=False, positions=None, inference=False, *, sampler='scan', seed=None):
-        super().__init__(distances.float(), demand.float(), n_ants, decay, alpha, beta, elitist, min_max,
+        # demand keeps its dtype: float64 demands (cvrp_nls/utils.py:12-26) select the float64 load bookkeeping of the
+        # sampler (cvrp_nls/aco.py:254-272 runs it in double; with demands k / capacity the last bit decides exact fits)
+        super().__init__(distances.float(), demand, n_ants, decay, alpha, beta, elitist, min_max,
                          None if pheromone is None else pheromone.float(),
                          None if heuristic is None else heuristic.float(), min, device, adaptive, float(capacity),
                          sampler=sampler, seed=seed)
@@ -71,7 +76,7 @@ class ACO(_CvrpACO):
     def sample_nls(self):
         paths, log_probs = self.gen_path(require_prob=True)
         costs_raw = self.gen_path_costs(paths).detach()
-        paths = self.multiple_swap_star(paths)
+        paths = self.multiple_swap_star(paths.clone())     # (the sampled routes stay as drawn: the backward pass replays them)
         costs = self.gen_path_costs(paths).detach()
         return costs, log_probs, costs_raw
 

@@ -129,13 +129,20 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
     or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, rowsum|None, lens [B,A], flags [B]);
     the reference's result is paths[:, :lens.max()].
     dist: if given, route costs are fused into the kernel; want_table: also return the successor table
-    the directed pheromone update consumes.  With either, (..., costs|None, table|None) is appended."""
+    the directed pheromone update consumes.  With either, (..., costs|None, table|None) is appended.
+    A float64 `demand` (cvrp_nls/ keeps its instance data in double) selects the float64 load bookkeeping
+    (cvrp_nls/aco.py:254-272: used + demand, demand > capacity - used in double), see include/deepaco_hip.h."""
     _require_gpu(tau, eta, demand, noise)
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
     dev = tau.device
     tau, tbs = _bstride(tau, n)
     eta, ebs = _bstride(eta, n)
+    demand64 = None
+    if demand.dtype == torch.float64:
+        demand64 = demand.detach().contiguous()
+        if demand64.dim() == 1:
+            demand64 = demand64.unsqueeze(0).expand(B, n).contiguous()
     demand = _f32c(demand)
     if demand.dim() == 1:
         demand = demand.unsqueeze(0).expand(B, n).contiguous()
@@ -172,7 +179,8 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
                                 rowsum.data_ptr() if require_prob else None, lens.data_ptr(),
                                 flags.data_ptr(), dist.data_ptr() if dist is not None else None, dbs,
                                 costs.data_ptr() if costs is not None else None,
-                                table.data_ptr() if table is not None else None, ws.data_ptr(), ws.numel())
+                                table.data_ptr() if table is not None else None, ws.data_ptr(), ws.numel(),
+                                demand64.data_ptr() if demand64 is not None else None, float(capacity))
     _lib.check(rc, "daco_cvrp_sample")
     if dist is not None or want_table:
         return paths, logp, rowsum, lens, flags, costs, table
@@ -190,7 +198,12 @@ def sample_backward(tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, 
     paths = paths.contiguous()
     rowsum, grad_logp = _f32c(rowsum), _f32c(grad_logp)
     dev = paths.device
+    demand64 = None
     if demand is not None:
+        if demand.dtype == torch.float64:                  # replay the capacity rule in double, as the sampler applied it
+            demand64 = demand.detach().contiguous()
+            if demand64.dim() == 1:
+                demand64 = demand64.unsqueeze(0).expand(B, n).contiguous()
         demand = _f32c(demand)
         if demand.dim() == 1:
             demand = demand.unsqueeze(0).expand(B, n).contiguous()
@@ -201,7 +214,8 @@ def sample_backward(tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, 
                                              float(alpha), float(beta), paths.data_ptr(), rowsum.data_ptr(),
                                              grad_logp.data_ptr(), lens.data_ptr() if demand is not None else None,
                                              demand.data_ptr() if demand is not None else None, float(capacity),
-                                             grad.data_ptr())
+                                             grad.data_ptr(), demand64.data_ptr() if demand64 is not None else None,
+                                             float(capacity))
     _lib.check(rc, "daco_sample_backward")
     return grad
 

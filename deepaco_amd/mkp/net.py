@@ -1,0 +1,15 @@
+"""Net of mkp/net.py: five node features (the item's weights in the m = 5 knapsack dimensions), par_net_phe present.
+`from net import Net`."""
+import os
+import sys
+
+try:
+    from deepaco_amd.net import Net as _Net, EmbNet, MLP, ParNet  # noqa: F401
+except ImportError:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd.net import Net as _Net, EmbNet, MLP, ParNet  # noqa: F401
+
+
+class Net(_Net):
+    def __init__(self):
+        super().__init__(feats=5, with_phe=True)

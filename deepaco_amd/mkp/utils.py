@@ -1,0 +1,47 @@
+"""Instance / graph construction with the surface of the reference's mkp/utils.py (multidimensional knapsack)."""
+import numpy as np
+import os
+import sys
+
+import torch
+
+try:
+    from deepaco_amd.net import GraphData as Data
+except ImportError:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from deepaco_amd.net import GraphData as Data
+
+
+def gen_instance(n, m, device):
+    """*Well-stated* instances (mkp/utils.py:6-25): U(0,1) prizes [n] and weights [n, m]; per dimension a capacity drawn
+    with numpy between the largest single weight and the total weight; weights rescaled so every capacity is n // 2."""
+    prize = torch.rand(size=(n,), device=device)
+    weight_matrix = torch.rand(size=(n, m), device=device)
+    heaviest, _ = torch.max(weight_matrix, dim=0)
+    total = torch.sum(weight_matrix, dim=0)
+    caps = [np.random.uniform(low=heaviest[j].item(), high=total[j].item()) for j in range(m)]
+    constraints = torch.tensor(caps, device=device)
+    return prize, weight_matrix * (n // 2) / constraints.unsqueeze(0)
+
+
+def gen_pyg_data(prize, weight_matrix):
+    """Complete graph, edge e = (e % n, e // n) with attribute prize[e % n]; node features = the item's m weights
+    (mkp/utils.py:27-35)."""
+    n = prize.size(0)
+    nodes = torch.arange(n, device=prize.device)
+    edge_index = torch.stack((nodes.repeat(n), torch.repeat_interleave(nodes, n)))
+    return Data(x=weight_matrix, edge_index=edge_index, edge_attr=prize.repeat(n).unsqueeze(-1))
+
+
+def _load(path, device):
+    dataset = torch.load(path, map_location=device)
+    return [(inst[:, 0], inst[:, 1:]) for inst in dataset]
+
+
+def load_val_dataset(problem_size, device):
+    """[(prize, weight_matrix)] from ./data/mkp/valDataset-<n>.pt (column 0 = prize, the rest = weights)."""
+    return _load(f'./data/mkp/valDataset-{problem_size}.pt', device)
+
+
+def load_test_dataset(problem_size, device):
+    return _load(f'./data/mkp/testDataset-{problem_size}.pt', device)

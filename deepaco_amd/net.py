@@ -60,10 +60,13 @@ def mean_by_source(values, src, n):
 class EmbNet(nn.Module):
     """12 residual layers updating node states x and edge states w (tsp/net.py:8-45)."""
 
-    def __init__(self, depth=DEPTH, feats=2, units=UNITS, act_fn='silu', agg_fn='mean'):
+    def __init__(self, depth=DEPTH, feats=2, units=UNITS, act_fn='silu', agg_fn='mean', node_update=True):
         super().__init__()
         assert act_fn == 'silu' and agg_fn == 'mean' and units == UNITS and depth == DEPTH
         self.depth, self.feats, self.units = depth, feats, units
+        # sop/net.py:43 and smtwtp/net.py:42 have the node update commented out: x stays the input embedding, v_lins1/2 and
+        # v_bns exist (checkpoints hold them) but nothing reads them
+        self.node_update = node_update
         self.v_lin0 = nn.Linear(feats, units)
         self.v_lins1 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
         self.v_lins2 = nn.ModuleList([nn.Linear(units, units) for _ in range(depth)])
@@ -81,9 +84,10 @@ class EmbNet(nn.Module):
         w = F.silu(self.e_lin0(edge_attr))
         for i in range(self.depth):
             gate = torch.sigmoid(w)
-            msg = mean_by_source(gate * self.v_lins2[i](x)[dst], src, n)
+            msg = mean_by_source(gate * self.v_lins2[i](x)[dst], src, n) if self.node_update else None
             w_new = w + F.silu(self.e_bns[i](self.e_lins0[i](w) + self.v_lins3[i](x)[src] + self.v_lins4[i](x)[dst]))
-            x = x + F.silu(self.v_bns[i](self.v_lins1[i](x) + msg))
+            if self.node_update:
+                x = x + F.silu(self.v_bns[i](self.v_lins1[i](x) + msg))
             w = w_new
         return w
 
@@ -198,13 +202,15 @@ class _GnnTrainFn(torch.autograd.Function):
 
 class Net(nn.Module):
     """feats: node-feature width (2 = coordinates in tsp/, 1 in tsp_nls/ and cvrp/);
-    with_phe: also create the unused par_net_phe head that tsp/ checkpoints contain."""
+    with_phe: also create the unused par_net_phe head that tsp/ checkpoints contain;
+    node_update=False: the sop/ and smtwtp/ variant whose node states are never updated (sop/net.py:43).  The kernels
+    run it as the same layer with the node BatchNorm's scale and shift set to zero: x + silu(0) = x exactly."""
 
     train_backend = "hip"          # "torch": training forward/backward as torch ops + autograd (cross-check)
 
-    def __init__(self, feats=2, with_phe=True):
+    def __init__(self, feats=2, with_phe=True, node_update=True):
         super().__init__()
-        self.emb_net = EmbNet(feats=feats)
+        self.emb_net = EmbNet(feats=feats, node_update=node_update)
         if with_phe:
             self.par_net_phe = ParNet()
         self.par_net_heu = ParNet()
@@ -246,8 +252,11 @@ class Net(nn.Module):
         for i in range(DEPTH):
             Wv = torch.cat([m[i].weight for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)   # [128, 32]
             bv = torch.cat([m[i].bias for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)
+            vg, vb = e.v_bns[i].module.weight, e.v_bns[i].module.bias
+            if not e.node_update:                              # gamma = beta = 0: the node state passes through unchanged
+                vg, vb = torch.zeros_like(vg), torch.zeros_like(vb)
             parts += [Wv.t().reshape(-1), bv, e.e_lins0[i].weight.reshape(-1), e.e_lins0[i].bias,
-                      e.v_bns[i].module.weight, e.v_bns[i].module.bias, e.e_bns[i].module.weight, e.e_bns[i].module.bias]
+                      vg, vb, e.e_bns[i].module.weight, e.e_bns[i].module.bias]
         h = self.par_net_heu.lins
         parts += [h[0].weight.reshape(-1), h[0].bias, h[1].weight.reshape(-1), h[1].bias, h[2].weight.reshape(-1), h[2].bias]
         return torch.cat([p.float().reshape(-1) for p in parts])
@@ -259,6 +268,8 @@ class Net(nn.Module):
         G = stats.shape[2]
         for i in range(DEPTH):
             for which, bn, cnt in ((0, self.emb_net.e_bns[i].module, count_e), (1, self.emb_net.v_bns[i].module, count_v)):
+                if which == 1 and not self.emb_net.node_update:
+                    continue                                  # the reference never calls these modules
                 m = bn.momentum if bn.momentum is not None else 0.1
                 decay = (1 - m) ** torch.arange(G - 1, -1, -1, device=stats.device, dtype=torch.float32)     # oldest graph first
                 mean, var = stats[i, which, :, :, 0], stats[i, which, :, :, 1] * (cnt / max(cnt - 1, 1))
@@ -300,7 +311,10 @@ class Net(nn.Module):
                 parts += [Wv.t().contiguous().reshape(-1), bv, e.e_lins0[i].weight.reshape(-1), e.e_lins0[i].bias]
                 for bn in (e.v_bns[i].module, e.e_bns[i].module):
                     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-                    parts += [scale, bn.bias - bn.running_mean * scale]
+                    shift = bn.bias - bn.running_mean * scale
+                    if bn is e.v_bns[i].module and not e.node_update:
+                        scale, shift = torch.zeros_like(scale), torch.zeros_like(shift)
+                    parts += [scale, shift]
             h = self.par_net_heu.lins
             parts += [h[0].weight.reshape(-1), h[0].bias, h[1].weight.reshape(-1), h[1].bias, h[2].weight.reshape(-1),
                       h[2].bias]

@@ -141,6 +141,11 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *            follows it plus, per ant, the set of nodes that follow the depot -- the form
  *            daco_pheromone_update(symmetric = 0, nbr = next_table, hub = 0) consumes.
  *   workspace daco_tsp_sample_workspace_bytes(B, n, mode)
+ *   demand64, capacity64   NULL / 0, or [B][n] float64 demands and the capacity as a double: the load bookkeeping of
+ *            cvrp_nls/aco.py:254-272 (used = used + demand[cur]; demand > capacity - used) then runs in double, as it
+ *            does in the reference for that directory's float64 instance data (demands k / capacity: a customer that
+ *            fits exactly is common and the last bit decides); `demand` / `capacity` must still be given (their float32
+ *            images); the construction then runs on the one-ant-per-wavefront kernel for every n.
  */
 size_t daco_directed_table_bytes(int B, int n, int A);
 int daco_cvrp_sample(void *stream, int B, int n, int A,
@@ -150,7 +155,7 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
                      int32_t *lens, int32_t *flags,
                      const float *dist, long dist_bstride, float *costs, void *next_table,
-                     void *workspace, size_t workspace_bytes);
+                     void *workspace, size_t workspace_bytes, const double *demand64, double capacity64);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_track_best -- replaces the best-so-far bookkeeping inside ACO.run
@@ -238,12 +243,14 @@ int daco_sibling_backward(void *stream, int kind, int B, int n, int A, int rows,
  * probability was clamped.  rows = n (TSP) or Lmax (CVRP: pass demand, capacity and lens; NULL
  * demand selects TSP).  rowsum is what the sampler wrote.  grad_eta [B][n][n] must be zeroed (or
  * hold a gradient to accumulate into).  f32 hardware atomics: reproducible to rounding.
+ * demand64 / capacity64: NULL / 0, or the float64 demands and capacity daco_cvrp_sample drew the routes with (the
+ * capacity rule is then replayed in double as well; demand must still be given).
  */
 int daco_sample_backward(void *stream, int B, int n, int A, int rows,
                          const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                          float alpha, float beta, const int64_t *paths, const float *rowsum,
                          const float *grad_logp, const int32_t *lens, const float *demand,
-                         float capacity, float *grad_eta);
+                         float capacity, float *grad_eta, const double *demand64, double capacity64);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_tour_costs -- replaces ACO.gen_path_costs

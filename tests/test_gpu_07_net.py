@@ -394,3 +394,96 @@ def test_fused_layer_kernel_at_bench_size_equals_per_graph():
     for b in (0, 4, 8):
         one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
         torch.testing.assert_close(heu[b], one.view(-1), rtol=1e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------ per-directory nets (b-double-dagger: `from net import Net` everywhere)
+@pytest.mark.parametrize("name", ["op", "pctsp", "sop", "smtwtp", "bpp", "mkp", "cvrp_nls"])
+def test_sibling_nets_hip_equals_torch_ops(name):
+    """The networks of the sibling directories (other feature widths; sop / smtwtp without the node update,
+    sop/net.py:43) on the HIP kernels against the same module evaluated with torch ops: eval-mode forward, and
+    training-mode forward + parameter gradients."""
+    import importlib
+    from deepaco_amd.net import GraphData
+    Net = importlib.import_module(f"deepaco_amd.{name}.net").Net
+    torch.manual_seed(5)
+    net = Net().to(dev())
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    feats = net.emb_net.v_lin0.in_features
+    n, k = 30, 6
+    gen = torch.Generator().manual_seed(2)
+    src = torch.repeat_interleave(torch.arange(n), k)
+    dst = torch.randint(0, n, (n * k,), generator=gen)
+    pyg = GraphData(x=torch.rand(n, feats, generator=gen), edge_index=torch.stack([src, dst]),
+                    edge_attr=torch.rand(n * k, 1, generator=gen)).to(dev())
+    net.eval()
+    with torch.no_grad():
+        hip = net(pyg)
+        ref = net.par_net_heu(net.emb_net(pyg.x, pyg.edge_index, pyg.edge_attr))
+    torch.testing.assert_close(hip, ref, atol=ATOL_HEU, rtol=1e-4)
+    # training mode: HIP kernels vs torch ops + autograd
+    coef = torch.randn(n * k, generator=gen).to(dev())
+    net.train()
+    grads, stats = {}, {}
+    state = {k_: v.clone() for k_, v in net.state_dict().items()}
+    for backend in ("hip", "torch"):
+        net.load_state_dict(state)
+        net.train_backend = backend
+        net.zero_grad()
+        heu = net(pyg)
+        torch.sum(heu * coef).backward()
+        grads[backend] = (heu.detach().clone(), {k_: p.grad.clone() for k_, p in net.named_parameters() if p.grad is not None})
+        stats[backend] = {k_: v.clone() for k_, v in net.state_dict().items() if "running_" in k_}
+    net.train_backend = "hip"
+    torch.testing.assert_close(grads["hip"][0], grads["torch"][0], atol=ATOL_TORCH, rtol=5e-4)
+    gmax = max(float(v.abs().max()) for v in grads["torch"][1].values())
+    for k_ in grads["torch"][1]:
+        if _zero_in_exact_arithmetic(k_):
+            continue
+        _grad_close(grads["hip"][1][k_].cpu().numpy(), grads["torch"][1][k_].cpu().numpy(), k_, rel=2e-3, floor=4e-6 * gmax)
+    for k_ in stats["torch"]:
+        torch.testing.assert_close(stats["hip"][k_], stats["torch"][k_], rtol=1e-4, atol=1e-6)
+    if not net.emb_net.node_update:                                      # nothing may flow into the unused node-update modules
+        for k_, g in grads["hip"][1].items():
+            if ".v_lins1." in k_ or ".v_lins2." in k_ or ".v_bns." in k_:
+                assert float(g.abs().max()) == 0.0, k_
+
+
+def test_cvrp_nls_train_instance_on_the_drop_in():
+    """The body of cvrp_nls/train.py:train_instance (:15-50) on the drop-in modules of deepaco_amd/cvrp_nls: instance and
+    sparse graph from utils (float64 data, capacity 1), Net in training mode, ACO(swapstar=True, positions=...),
+    sample_nls(), the REINFORCE loss on the improved costs, clipped AdamW step."""
+    from deepaco_amd.cvrp_nls.net import Net
+    from deepaco_amd.cvrp_nls.aco import ACO
+    from deepaco_amd.cvrp_nls.utils import gen_instance, gen_pyg_data
+    EPS = 1e-5
+    torch.manual_seed(77)
+    n = 30
+    model = Net().to(dev())
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    data = []
+    for _ in range(2):
+        demands, distances, positions = gen_instance(n, "cuda:0", True)
+        data.append((gen_pyg_data(demands, distances, "cuda:0", k_sparse=max(n // 5, 4)), demands, distances, positions))
+    before = [p.detach().clone() for p in model.parameters()]
+    model.train()
+    sum_loss, count = 0.0, 0
+    for pyg_data, demands, distances, positions in data:
+        heu_vec = model(pyg_data)
+        heu_mat = model.reshape(pyg_data, heu_vec) + EPS
+        aco = ACO(n_ants=10, distances=distances, demand=demands, heuristic=heu_mat, device="cuda:0", swapstar=True,
+                  positions=positions)
+        costs_2opt, log_probs, costs_raw = aco.sample_nls()
+        assert bool((costs_2opt <= costs_raw + 1e-4).all()) and float(costs_2opt.mean()) < float(costs_raw.mean())
+        cost = costs_2opt - costs_2opt.mean()
+        sum_loss = sum_loss + torch.sum(cost.detach() * log_probs.sum(dim=0)) / aco.n_ants
+        count += 1
+    sum_loss = sum_loss / count
+    optimizer.zero_grad()
+    sum_loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=3.0, norm_type=2)
+    assert torch.isfinite(gn) and float(gn) > 0
+    optimizer.step()
+    assert sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, model.parameters())) > 100
