@@ -20,11 +20,15 @@ Objects on the JSON line besides the contract's keys:
                 compulsory floor.
   sustained     the same step loop run for >= --min-seconds after the timed region (so that samplers outside
                 this process can see the GPU busy); not the metric.
-  cpu_baseline  torch-CPU port of the reference's op sequence (oracle/torch_port.py) on this host's cores,
-                16 instances x 20 iterations of the same workload run as 16 parallel processes
-                (rank 0, N = 1 only), and the best-cost gap against the GPU path on the same instances.
-  extras        BASELINE.json's other single-GPU configurations (2, 3, 4, the per-GPU share of 5), the 2-opt
-                kernel and the GNN forward, each with its own roofline object (N = 1 only; --no-extras skips).
+  cpu_baseline  torch-CPU port of the reference's op sequence (oracle/torch_port.py) on this host's cores:
+                min(instances, host CPUs / 4) colonies of the same workload side by side (one process each, two
+                intra-op threads: 128 of the 256 hardware threads on the GPU box = its physical cores; the host's
+                aggregate rate is flat from ~16 colonies on, the op sequence is memory-bound), --cpu-iters iterations
+                each (rank 0, N = 1 only), and the best-cost gap against the GPU path on the same instances at the same
+                number of iterations.
+  extras        BASELINE.json's other single-GPU configurations (2, 3, 4, the per-GPU share of 5), the parity modes of
+                the sampler, the learned heuristic and the GNN forward, each with its own roofline object and its own
+                cpu_baseline on a bounded sample (N = 1 only; --no-extras skips).
   rccl          N > 1: ranks, backend and the measured all-reduce bus bandwidth of a [B, n, n] f32 buffer.
 """
 import argparse
@@ -54,9 +58,14 @@ def parse_args():
     ap.add_argument("--k-sparse", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations")
-    ap.add_argument("--cpu-instances", type=int, default=16)
-    ap.add_argument("--cpu-iters", type=int, default=20)
-    ap.add_argument("--min-seconds", type=float, default=2.0, help="length of the sustained (untimed-by-metric) loop")
+    ap.add_argument("--cpu-instances", type=int, default=0,
+                    help="colonies of the cpu_baseline leg, side by side (0 = min(instances, host CPUs // 4))")
+    ap.add_argument("--cpu-iters", type=int, default=3,
+                    help="colony iterations of every cpu_baseline colony (the best-cost gap is taken at this many iterations)")
+    ap.add_argument("--cpu-seconds", type=float, default=150.0, help="safety stop of a cpu_baseline colony")
+    ap.add_argument("--config", default="headline", choices=["headline", "c5"],
+                    help="c5: the per-GPU share of BASELINE config 5 (TSP-1000, 2048 ants, 64 instances per GPU)")
+    ap.add_argument("--min-seconds", type=float, default=12.0, help="length of the sustained (untimed-by-metric) loop")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
     ap.add_argument("--shard", default="instances", choices=["instances", "ants"],
@@ -67,7 +76,14 @@ def parse_args():
                     help="--shard ants: all-gather of the tours (int16; exact, default) or all-reduce of delta-tau")
     ap.add_argument("--force-device", type=int, default=None,
                     help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
-    return ap.parse_args()
+    return apply_config(ap.parse_args())
+
+
+def apply_config(args):
+    if args.config == "c5":
+        args.nodes, args.ants, args.batch = 1000, 2048, 64
+        args.steps = min(args.steps, 5)
+    return args
 
 
 def log(msg):
@@ -85,7 +101,10 @@ def launch_ranks(args):
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # dmabuf IPC (this image's driver has no legacy IPC: RCCL / tensor sharing across processes fail with
+        # hipIpcGetMemHandle otherwise); whatever the caller exported wins
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
@@ -99,7 +118,9 @@ def make_instances(B, n, seed):
     import torch
     g = torch.Generator().manual_seed(seed)
     coords = torch.rand(B, n, 2, generator=g)
-    dist = torch.cdist(coords, coords)
+    # the reference's expression (torch.norm of the coordinate differences); torch.cdist's matmul form returns exact zeros
+    # for close pairs, i.e. an infinite 1/d
+    dist = torch.cat([torch.norm(c[:, None] - c, dim=2, p=2).unsqueeze(0) for c in coords])
     idx = torch.arange(n)
     dist[:, idx, idx] = 1e9
     return dist
@@ -216,97 +237,230 @@ def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0):
 
 
 # ---------------------------------------------------------------------------------------------- extras
-def extra_configs(dev, headline_colony):
-    """BASELINE.json's other single-GPU configurations, each one timed end to end (all kernels of an iteration) with
-    a roofline object for its dominant kernel (timed by HIP events inside the library where the entry offers it)."""
+def _cpu_small(job):
+    """CPU legs of the extras (worker process): the reference's op sequence on this host, a bounded sample each."""
+    import numpy as np
+    import torch
+    kind, threads, budget_s = job[0], job[1], job[2]
+    torch.set_num_threads(threads)
+    from oracle import torch_port
+    t0 = time.perf_counter()
+    if kind == "tsp":
+        d, k_sparse, n_ants, seed = job[3:]
+        torch.manual_seed(seed)
+        _, idx = torch.topk(d, k=k_sparse, dim=1, largest=False)
+        sparse = torch.full_like(d, 1e10)
+        sparse.scatter_(1, idx, torch.gather(d, 1, idx))
+        heu, tau, its = 1 / sparse, torch.ones_like(d), 0
+        while True:
+            paths = torch_port.rollout(tau, heu, n_ants)
+            costs = torch_port.tour_lengths(d, paths)
+            tau = torch_port.deposit(tau, paths, costs, 0.9)
+            its += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return its * n_ants, time.perf_counter() - t0
+    if kind == "cvrp":
+        d, dem, cap, n_ants, seed = job[3:]
+        torch.manual_seed(seed)
+        heu, tau, its = 1 / d, torch.ones_like(d), 0
+        while True:
+            paths = torch_port.cvrp_rollout(tau, heu, dem, cap, n_ants)
+            costs = torch_port.route_lengths(d, paths)
+            tau = torch_port.deposit_directed(tau, paths, costs, 0.9)
+            its += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return its * n_ants, time.perf_counter() - t0
+    if kind == "nls":
+        import oracle
+        d, hd, tours, maxt = job[3:]
+        done = sweeps = 0
+        for i in range(0, tours.shape[0], 2):                       # two tours at a time until the budget is spent
+            _, sw = oracle.nls_batch(d, hd, tours[i:i + 2], maxt)
+            done += min(2, tours.shape[0] - i)
+            sweeps += sw
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return done, time.perf_counter() - t0, sweeps
+    raise ValueError(kind)
+
+
+def _cpu_leg(jobs):
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        return pool.map(_cpu_small, jobs, chunksize=1)
+
+
+def extra_configs(dev, headline_colony, cpu=True):
+    """BASELINE.json's other single-GPU configurations, each one timed end to end (all kernels of an iteration) with a
+    roofline object for its dominant kernel (timed by HIP events around that kernel), the counter-measured HBM-side bytes
+    where a PMC pass of this library version is committed under profiles/, and a cpu_baseline: the reference's CPU op
+    sequence (oracle/torch_port.py, the C restatement of two_opt.py, torch ops for the network) on a bounded sample of
+    the same workload on this host."""
+    import numpy as np
     import torch
     from deepaco_amd import engine
     out = {}
+    ncpu = os.cpu_count() or 1
+    traffic = load_traffic()
 
-    def tsp(tag, n, A, B, k, steps):
-        col = engine.BatchedTSP(make_instances(B, n, 77).to(dev), n_ants=A, seed=5)
-        col.sparsify(k)
-        col.heuristic = col.heuristic.contiguous()
-        col.step(); col.step()
+    def events(steps):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         for a, b in ev:
             a.record(); b.record()
         torch.cuda.synchronize()
+        return ev
+
+    def cpu_tsp(d_cpu, k, A, budget):
+        if not cpu:
+            return None
+        procs = min(d_cpu.shape[0], 4, max(1, ncpu // 2))
+        res = _cpu_leg([("tsp", 2, budget, d_cpu[b].clone(), k, A, 99 + b) for b in range(procs)])
+        busy = max(r[1] for r in res)
+        return {"value": sum(r[0] for r in res) / busy, "unit": "ant-tours/s", "cores": 2 * procs, "kind": "port",
+                "sample": f"{procs} instances of the same workload side by side, {[r[0] // A for r in res]} colony iterations "
+                          f"in {busy:.1f} s (oracle/torch_port.py: the aten op sequence of tsp/aco.py), 2 intra-op threads each"}
+
+    def tsp(tag, n, A, B, k, steps, cpu_budget):
+        d_cpu = make_instances(B, n, 77)
+        col = engine.BatchedTSP(d_cpu.to(dev), n_ants=A, seed=5)
+        col.sparsify(k)
+        col.heuristic = col.heuristic.contiguous()
+        col.step(); col.step()
+        ev = events(steps)
         t0 = time.perf_counter()
         for s in range(steps):
             col.step(events=ev[s])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        tr, src = traffic.get(f"tsp{n}_a{A}_b{B}_scan", (None, None))
         out[tag] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, AS iteration", "value": B * A / dt,
-                    "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "roofline": roofline_rows(n, A, B, "scan", kms)}
+                    "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "steps": steps,
+                    "roofline": roofline_rows(n, A, B, "scan", kms, traffic=tr, traffic_source=src),
+                    "cpu_baseline": cpu_tsp(d_cpu, k, A, cpu_budget)}
         del col
 
-    tsp("c2_tsp100_a512_b256", 100, 512, 256, 20, 10)
-    tsp("c5_share_tsp1000_a2048_b64", 1000, 2048, 64, 100, 2)
+    tsp("c2_tsp100_a512_b256", 100, 512, 256, 20, 10, 6.0)
+    tsp("c5_share_tsp1000_a2048_b64", 1000, 2048, 64, 100, 3, 20.0)
 
     # config 4: CVRP-100, capacity mask in the sampling kernel
     n, A, B = 100, 512, 256
     g = torch.Generator().manual_seed(3)
     loc = torch.cat((torch.full((B, 1, 2), 0.5), torch.rand(B, n, 2, generator=g)), 1)
     dem = torch.cat((torch.zeros(B, 1), torch.randint(1, 10, (B, n), generator=g).float()), 1)
-    d = torch.cdist(loc, loc)
+    d = torch.cat([torch.norm(c[:, None] - c, dim=2, p=2).unsqueeze(0) for c in loc])
     i = torch.arange(n + 1)
     d[:, i, i] = 1e-10
     col = engine.BatchedCVRP(d.to(dev), dem.to(dev), n_ants=A, capacity=50, seed=1)
-    dt = time_launches(col.step, 10)
+    col.step(); col.step()
+    steps = 10
+    ev = events(steps)
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        col.step(events=ev[s_])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kms = sum(a.elapsed_time(b) for a, b in ev) / steps
     L = float(col.last_lens.float().mean())
-    # kernel time ~ iteration minus the deposit (no event hook on this entry): the whole iteration is charged
-    rf = roofline_rows(n + 1, A, B, "scan", dt * 1e3, steps_per_tour=L)
-    rf["kernel"] = "scan16_kernel<CVRP> (whole iteration charged: sampler + deposit)"
+    tr, src = traffic.get("cvrp100_a512_b256_scan", (None, None))
+    rf = roofline_rows(n + 1, A, B, "scan", kms, steps_per_tour=L - 1, traffic=tr, traffic_source=src)
+    rf["kernel"] = "scan16_kernel<CVRP> (HIP events around the construction kernel)"
+    cb = None
+    if cpu:
+        procs = min(4, max(1, ncpu // 2))
+        res = _cpu_leg([("cvrp", 2, 6.0, d[b].clone(), dem[b].clone(), 50.0, A, 7 + b) for b in range(procs)])
+        busy = max(r[1] for r in res)
+        cb = {"value": sum(r[0] for r in res) / busy, "unit": "ant-tours/s", "cores": 2 * procs, "kind": "port",
+              "sample": f"{procs} instances side by side, {[r[0] // A for r in res]} colony iterations in {busy:.1f} s "
+                        f"(oracle/torch_port.py cvrp_rollout / route_lengths / deposit_directed: the aten op sequence of "
+                        f"cvrp/aco.py, its per-step all-done sync included), 2 intra-op threads each"}
     out["c4_cvrp100_a512_b256"] = {"workload": f"CVRP-{n} (capacity mask), n_ants={A}, {B} instances, AS iteration",
-                                   "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3,
-                                   "mean_route_len": L, "roofline": rf}
+                                   "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "steps": steps,
+                                   "mean_route_len": L, "roofline": rf, "cpu_baseline": cb}
     del col
 
-    # config 3: TSP-500 + NLS; the 2-opt kernel is 99 % of it
+    # config 3: TSP-500 + NLS; the local search is 99 % of it: ONE launch of daco_tsp_nls per iteration
     n, A, B = 500, 256, 64
-    col = engine.BatchedTSP(make_instances(B, n, 2).to(dev), n_ants=A, seed=1, local_search="nls", fixed_start=0)
+    d_cpu = make_instances(B, n, 2)
+    col = engine.BatchedTSP(d_cpu.to(dev), n_ants=A, seed=1, local_search="nls", fixed_start=0)
     col.sparsify(50)
-    dt = time_launches(col.step, 1, warm=1)
-    paths, _, _, _ = engine.tsp_sample(col.pheromone, col.heuristic, A, seed=3, batch=B, fixed_start=0)
-    tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
-    # the first 2-opt pass of the iteration alone (sampled tours, <= n // 4 sweeps), as the colony runs it: candidate-list
-    # kernel / dense incremental kernel chosen per tour (daco_two_opt_auto), tables built once per matrix
+    col.nls_counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    col.step()
     torch.cuda.synchronize()
+    col.nls_counters.zero_()
+    steps = 5
+    ev = events(steps)
     t0 = time.perf_counter()
-    _, sweeps = engine.two_opt_(col.distances, tours, n // 4, want_sweeps=True, dist_t=col._dist_t, tables=col._tables)
+    for s_ in range(steps):
+        col.step(ls_events=ev[s_])
     torch.cuda.synchronize()
-    t2 = time.perf_counter() - t0
-    nsw = float(sweeps.sum())
-    # Bound of the 2-opt kernels: L2 line requests (rocprofv3 TCP_TCC_READ_REQ x 128 B; a candidate is one table entry and
-    # one matrix gather out of an L2-resident instance).  The per-tour figure comes from the counter passes committed
-    # under profiles/ (same workload, 16 instances); it is not collected in this run.
-    l2_per_tour = l2_src = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "two_opt_l2.json")))
-        l2_per_tour, l2_src = tj["l2_read_bytes_per_tour_iteration"], tj["source"]
-    except Exception:
-        pass
-    ach = B * A * l2_per_tour / dt / 1e9 if l2_per_tour else None
+    dt = (time.perf_counter() - t0) / steps
+    kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    sweeps, walked = [float(v) / steps for v in col.nls_counters.tolist()]
+    # what a walked list entry costs by definition: its 8-byte table entry and the 4-byte matrix gather of its pair; a sweep
+    # also re-reads the (<= n) changed edges' matrix entry and two ranks (8 bytes).  L2 -> L1 moves a 128-byte line for each.
+    alg = walked * 12.0 + sweeps * 8.0 * 16
+    tr, src = traffic.get("nls500_a256_b64", (None, None))
+    cb = None
+    if cpu:
+        paths, _, _, _ = engine.tsp_sample(col.pheromone[:1], col.heuristic[:1], 16, seed=3, batch=1, fixed_start=0)
+        tours = paths[0].T.contiguous().cpu().numpy().astype(np.uint16)
+        hd = col._heuristic_dist()[0].cpu().numpy()
+        procs = min(8, max(1, ncpu // 2))
+        res = _cpu_leg([("nls", 1, 8.0, d_cpu[0].numpy(), hd, tours[2 * r:2 * r + 2], n // 4) for r in range(procs)])
+        busy = max(r[1] for r in res)
+        cb = {"value": sum(r[0] for r in res) / busy, "unit": "ant-tours/s (local search only)", "cores": procs, "kind": "port",
+              "sample": f"{sum(r[0] for r in res)} sampled tours of one instance through the NLS schedule (oracle.nls_batch: the C "
+                        f"restatement of tsp_nls/two_opt.py -- the reference runs it numba-compiled in a thread pool -- "
+                        f"{sum(r[2] for r in res)} sweeps), {procs} processes, {busy:.1f} s; construction and update not included",
+              "sweeps_per_s": sum(r[2] for r in res) / busy}
     out["c3_tsp500_nls_a256_b64"] = {
-        "workload": f"TSP-{n} + NLS (T_nls=10, T_p=20, maxt={n // 4}; 21 2-opt passes per iteration), n_ants={A}, {B} instances",
-        "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3,
-        "two_opt_first_pass": {"tours": B * A, "sweeps": nsw, "seconds": t2, "sweeps_per_s": nsw / t2,
-                               "reference_pair_evaluations_per_s": nsw * (n - 1) * (n - 2) / 2 / t2},
-        "roofline": {"bound": "l2", "achieved": ach, "peak": PEAK_L2_GBS, "unit": "GB/s",
-                     "frac": ach / PEAK_L2_GBS if ach else None, "traffic": None, "traffic_source": l2_src,
-                     "kernel": "two_opt_nbr_kernel (+ two_opt_incr2_kernel for tours with long candidate lists)",
-                     "note": "L2 read requests x 128 B of the 2-opt kernels per tour and NLS iteration (counter-measured on "
-                             "this workload) x tours / iteration time; the kernels wait on dependent gathers (waves parked on "
-                             "memory most of the time, DESIGN.md 3.4), they are not bound by this bandwidth"}}
+        "workload": f"TSP-{n} + NLS (T_nls=10, T_p=20, maxt={n // 4}; 21 2-opt searches per tour and iteration, one launch), "
+                    f"n_ants={A}, {B} instances",
+        "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "steps": steps,
+        "local_search": {"kernel_ms": kms, "sweeps_per_iteration": sweeps, "sweeps_per_s": sweeps / (kms * 1e-3),
+                         "list_entries_walked_per_sweep": walked / sweeps if sweeps else None,
+                         "reference_pair_evaluations_per_s": sweeps * (n - 1) * (n - 2) / 2 / (kms * 1e-3)},
+        "roofline": {"bound": "l2", "achieved": alg / (kms * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
+                     "frac": alg / (kms * 1e-3) / 1e9 / PEAK_L2_GBS, "traffic": tr, "traffic_source": src,
+                     "kernel": "nls_kernel (daco_tsp_nls; HIP events around the launch)", "kernel_ms": kms,
+                     "algorithmic_bytes_per_launch": alg,
+                     "note": "algorithmic bytes = 12 B per walked list entry (table entry + matrix gather) + 128 B per sweep for "
+                             "the changed edges, from the in-run counters; the kernel is a chain of dependent L2 round trips and "
+                             "LDS phases per sweep (latency / issue bound, profiles/r03_pmc_nls_*), not bound by this bandwidth"},
+        "cpu_baseline": cb}
     del col
+
+    # headline workload in the reference's exponential-race arithmetic (what the bit-exact fixtures pin) -- the price of it
+    try:
+        n, A, B = 500, 512, 64
+        col = engine.BatchedTSP(headline_colony.distances, n_ants=A, sampler="race", seed=11)
+        col.heuristic = headline_colony.heuristic
+        col.step(); col.step()
+        dtr = time_launches(col.step, 5, warm=0)
+        del col
+        Bn = 4                                                    # recorded-noise mode: q [B, n-1, A, n] f32 = 0.5 GB per instance
+        noise = torch.empty((Bn, n - 1, A, n), device=dev).exponential_(1)
+        tau, eta = headline_colony.pheromone[:Bn], headline_colony.heuristic[:Bn]
+        dtn = time_launches(lambda: engine.tsp_sample(tau, eta, A, mode="race_noise", noise=noise, batch=Bn), 3, warm=1)
+        del noise
+        out["headline_parity_modes"] = {
+            "workload": f"TSP-{n}, n_ants={A}: the draw as torch.multinomial makes it (argmax of p / q, q ~ Exp(1))",
+            "race_philox": {"value": B * A / dtr, "unit": "ant-tours/s", "ms_per_step": dtr * 1e3, "instances": B,
+                            "note": "in-kernel Philox noise, whole iteration"},
+            "race_noise": {"value": Bn * A / dtn, "unit": "ant-tours/s (construction only)", "ms_per_launch": dtn * 1e3,
+                           "instances": Bn,
+                           "note": "noise read from memory (the mode the reference-recorded fixtures are replayed in): "
+                                   f"{4.0 * (n - 1) * n * A * Bn / 1e9:.1f} GB of q per launch"}}
+    except Exception as e:
+        out["headline_parity_modes"] = {"error": repr(e)}
 
     # headline workload with the LEARNED heuristic (SURVEY 8d (ii)): Net + the reference's pretrained tsp500 weights
     # (tests/golden/w_tsp_tsp500.npz: the checkpoint as plain arrays), heu + 1e-10, next to the vanilla 1/d on the
     # same instances and seeds
     try:
-        import numpy as np
         from deepaco_amd.tsp.net import Net as TspNet
         wz = np.load(os.path.join(ROOT, "tests", "golden", "w_tsp_tsp500.npz"))
         lnet = TspNet()
@@ -316,12 +470,14 @@ def extra_configs(dev, headline_colony):
         g = torch.Generator().manual_seed(4242)
         coords = torch.rand(B, n, 2, generator=g).to(dev)
         dist, ei, ea = engine.tsp_knn_graph(coords, k)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            heu = lnet.reshape_batch(n, ei, lnet.forward_batch(coords, ei, ea, k_sparse=k)) + 1e-10
-        torch.cuda.synchronize()
-        t_net = time.perf_counter() - t0
+        t_net = []
+        for _ in range(3):                                   # first call: workspace and CSR set-up, then steady state
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                heu = lnet.reshape_batch(n, ei, lnet.forward_batch(coords, ei, ea, k_sparse=k)) + 1e-10
+            torch.cuda.synchronize()
+            t_net.append((time.perf_counter() - t0) * 1e3)
         res = {}
         for tag, kw in (("learned", dict(heuristic=heu)), ("vanilla_1_over_d_sparsified", {})):
             col = engine.BatchedTSP(dist, n_ants=A, seed=7, **kw)
@@ -341,7 +497,7 @@ def extra_configs(dev, headline_colony):
                         "mean_best_cost_after_1_10_20_iterations": best}
         out["headline_learned_heuristic"] = {
             "workload": f"TSP-{n}, n_ants={A}, {B} instances, heuristic = Net(pretrained tsp500) + 1e-10 vs 1/d sparsified k={k}",
-            "gnn_forward_ms_for_the_batch": t_net * 1e3, **res}
+            "gnn_forward_plus_reshape_ms_for_the_batch": {"first_call": t_net[0], "steady": min(t_net[1:])}, **res}
         del lnet
     except Exception as e:
         out["headline_learned_heuristic"] = {"error": repr(e)}
@@ -354,18 +510,59 @@ def extra_configs(dev, headline_colony):
     coords = torch.rand(B, n, 2, device=dev)
     _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
     with torch.no_grad():
-        dt = time_launches(lambda: net.forward_batch(coords, ei, ea, k_sparse=k), 5)
+        dt = time_launches(lambda: net.forward_batch(coords, ei, ea, k_sparse=k), 10)
     E = n * k
     per_layer = 2.0 * E * 32 * 4 + 6.0 * n * 32 * 4 + 20e3
     alg = B * 12 * per_layer
     flops = B * 12 * 2.0 * 32 * 32 * (4 * n + E)
+    tr, src = traffic.get("gnn_tsp500_k50_b64", (None, None))
+    cb = None
+    if cpu:
+        # the network's own module tree evaluated with torch ops on the host (the aten op sequence of tsp/net.py:27-45),
+        # one graph after the other as the reference does
+        cnet = Net().eval()
+        cnet.load_state_dict(net.state_dict())
+        cx, cei, cea = coords.cpu(), ei.cpu(), ea.cpu()
+        torch.set_num_threads(min(32, ncpu))
+        t0 = time.perf_counter()
+        graphs = 0
+        with torch.no_grad():
+            while time.perf_counter() - t0 < 6.0 and graphs < B:
+                cnet.par_net_heu(cnet.emb_net(cx[graphs], cei[graphs], cea[graphs].view(-1, 1)))
+                graphs += 1
+        busy = time.perf_counter() - t0
+        cb = {"value": graphs / busy, "unit": "graphs/s", "cores": min(32, ncpu), "kind": "port",
+              "sample": f"{graphs} of the same graphs, one after the other, {busy:.1f} s: the module tree of tsp/net.py as torch "
+                        f"CPU ops (torch {torch.__version__}, {min(32, ncpu)} intra-op threads; torch_geometric's mean "
+                        f"pooling as index_add / bincount)"}
     out["gnn_tsp500_k50_b64"] = {"workload": f"Net.forward eval, {B} graphs of TSP-{n} (k={k}) in one pass",
                                  "value": B / dt, "unit": "graphs/s", "ms_per_step": dt * 1e3,
                                  "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": PEAK_HBM_GBS,
-                                              "unit": "GB/s", "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                              "unit": "GB/s", "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "traffic": tr,
+                                              "traffic_source": src,
                                               "kernel": "gnn_fused_layer_kernel x 12 layers + init + head (whole forward)",
-                                              "mfma_tflops": flops / dt / 1e12}}
+                                              "mfma_tflops": flops / dt / 1e12},
+                                 "cpu_baseline": cb}
     return out
+
+
+def load_traffic():
+    """profiles/hbm_traffic.json: counter-measured HBM-side bytes per launch of the dominant kernels (rocprofv3 --pmc passes,
+    corrected as MI355X_MICROARCH.md prescribes), stamped with the library version they were collected with.  Figures of
+    another version are dropped: a kernel change that was not re-profiled must not keep an old number."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        tj = json.load(open(path))
+        from deepaco_amd import _lib
+        if int(tj.get("daco_version", -1)) != _lib.lib().daco_version():
+            log(f"profiles/hbm_traffic.json is for library version {tj.get('daco_version')}, this is "
+                f"{_lib.lib().daco_version()}: counter-measured traffic not reported")
+            return {}
+        src = tj.get("source", "profiles/hbm_traffic.json")
+        return {k: (float(v), f"{src} (rocprofv3 --pmc passes of this workload and library version, not collected in this run)")
+                for k, v in tj.items() if isinstance(v, (int, float)) and k != "daco_version"}
+    except Exception:
+        return {}
 
 
 # ---------------------------------------------------------------------------------------------- one rank
@@ -477,16 +674,7 @@ def worker(args):
             rccl["allreduce_busbw_GBps"] = 2 * (world - 1) / world * nbytes / t_ar / 1e9
 
     if rank == 0:
-        traffic = tsrc = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj.get(f"tsp{n}_a{A}_b{B}_{args.sampler}")
-                tsrc = "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this workload, not collected in this run)" \
-                    if traffic else None
-            except Exception:
-                traffic = None
+        traffic, tsrc = load_traffic().get(f"tsp{n}_a{A}_b{B}_{args.sampler}", (None, None))
         line = {
             "metric": "ant-tours/sec, TSP-500 n_ants=512", "value": value, "unit": "ant-tours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -506,12 +694,13 @@ def worker(args):
             line["rccl"] = rccl
         if world == 1 and not args.no_extras and not ant_sharded:
             try:
-                line["extras"] = extra_configs(dev, colony)
+                line["extras"] = extra_configs(dev, colony, cpu=not args.no_cpu)
             except Exception as e:          # the headline must still be reported
                 log(f"extras failed: {e!r}")
                 line["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu and not ant_sharded:
-            cb, cpu_best, done = cpu_baseline(dist_cpu, k_sparse, A, args.cpu_instances, args.cpu_iters)
+            ncol = args.cpu_instances or max(1, min(B, (os.cpu_count() or 1) // 4))
+            cb, cpu_best, done = cpu_baseline(dist_cpu, k_sparse, A, ncol, args.cpu_iters, budget_s=args.cpu_seconds)
             line["cpu_baseline"] = cb
             # best-cost gap: the same instances, equal iterations, fresh GPU colonies
             ni = len(cpu_best)

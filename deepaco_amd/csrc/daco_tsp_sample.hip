@@ -110,7 +110,8 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
                                 int noise_steps, uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax,
                                 int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
                                 const float *dist, long dist_bstride, float *costs, void *next_table,
-                                void *workspace, size_t workspace_bytes, const double *demand64, double capacity64) {
+                                void *workspace, size_t workspace_bytes, const double *demand64, double capacity64,
+                                void *ev_begin, void *ev_end) {
   if (B <= 0 || n < 2 || A <= 0 || !tau || !eta || !demand || !paths || !workspace || Lmax < 2) {
     set_error("daco_cvrp_sample: bad argument (B=%d n=%d A=%d Lmax=%d)", B, n, A, Lmax);
     return DACO_E_BADARG;
@@ -160,11 +161,13 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.demand64 = demand64; sp.capacity64 = capacity64;
   sp.mask = nullptr; sp.step = 0;
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
+  if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   hipError_t e = four_per_wave ? launch_cvrp_scan16(sp, logp != nullptr, s)
                : two_per_wave ? launch_cvrp_scan32(sp, logp != nullptr, s)
                : demand64     ? dispatch_sample<PROB_CVRP64>(sp, vec, CH, mode, logp != nullptr, s)
                               : dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
   if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
   return DACO_OK;
 }
 

@@ -124,12 +124,13 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
 
 def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
                 it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False,
-                iter_dev=None):
+                iter_dev=None, events=None):
     """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
     or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, rowsum|None, lens [B,A], flags [B]);
     the reference's result is paths[:, :lens.max()].
     dist: if given, route costs are fused into the kernel; want_table: also return the successor table
     the directed pheromone update consumes.  With either, (..., costs|None, table|None) is appended.
+    events: as in tsp_sample (a pair of recorded torch.cuda.Event re-recorded around the construction kernel).
     A float64 `demand` (cvrp_nls/ keeps its instance data in double) selects the float64 load bookkeeping
     (cvrp_nls/aco.py:254-272: used + demand, demand > capacity - used in double), see include/deepaco_hip.h."""
     _require_gpu(tau, eta, demand, noise)
@@ -180,7 +181,8 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
                                 flags.data_ptr(), dist.data_ptr() if dist is not None else None, dbs,
                                 costs.data_ptr() if costs is not None else None,
                                 table.data_ptr() if table is not None else None, ws.data_ptr(), ws.numel(),
-                                demand64.data_ptr() if demand64 is not None else None, float(capacity))
+                                demand64.data_ptr() if demand64 is not None else None, float(capacity),
+                                events[0].cuda_event if events else None, events[1].cuda_event if events else None)
     _lib.check(rc, "daco_cvrp_sample")
     if dist is not None or want_table:
         return paths, logp, rowsum, lens, flags, costs, table
@@ -710,8 +712,10 @@ class BatchedTSP:
         self.heuristic = 1 / sparse
 
     @torch.no_grad()
-    def step(self, events=None, _iter_dev=None):
+    def step(self, events=None, _iter_dev=None, ls_events=None):
         # (_iter_dev: device-side iteration counter of a captured graph; self.iteration then stays frozen)
+        # events: torch.cuda.Event pair re-recorded around the construction kernel; ls_events: a pair recorded (on the
+        # current stream, which is the stream the library launches on) right before / after the local-search launches
         paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
                                                 self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,
                                                 ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
@@ -722,6 +726,8 @@ class BatchedTSP:
         if self.local_search is not None:
             ls_costs = None
             tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+            if ls_events:
+                ls_events[0].record()
             maxt = 10000 if self.inference else self.n // 4
             if self._dist_t is None:
                 self._dist_t = transposed_for_two_opt(self.distances)
@@ -737,6 +743,8 @@ class BatchedTSP:
                 tours, ls_costs = nls_(self.distances, hd, tours, maxt, dist_t=self._dist_t,
                                        heuristic_dist_t=self._hdist_t, tables=self._tables,
                                        heuristic_tables=self._htables, want_costs=True, counters=self.nls_counters)
+            if ls_events:
+                ls_events[1].record()
             paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
             costs, nbr = (tour_costs(self.distances, paths) if ls_costs is None else ls_costs), None
         # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)
@@ -809,14 +817,15 @@ class BatchedCVRP:
         self.seed = torch.initial_seed() if seed is None else seed
 
     @torch.no_grad()
-    def step(self, Lmax=None, trim=False):
+    def step(self, Lmax=None, trim=False, events=None):
         """One colony iteration without a host round trip: the sampler also produces the route costs and the
         successor table the directed deposit consumes.  Returns (paths [B, Lmax, A], costs [B, A]); rows past
-        an ant's route are 0 (self.last_lens holds the used rows; trim=True cuts to their maximum, which syncs)."""
+        an ant's route are 0 (self.last_lens holds the used rows; trim=True cuts to their maximum, which syncs).
+        events: see cvrp_sample."""
         paths, _, _, lens, flags, costs, table = cvrp_sample(
             self.pheromone, self.heuristic, self.demand, self.capacity, self.n_ants, self.alpha, self.beta,
             mode=self.sampler, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0, Lmax=Lmax, batch=self.B,
-            dist=self.distances, want_table=True)
+            dist=self.distances, want_table=True, events=events)
         self.iteration += 1
         self.last_lens, self.last_flags = lens, flags
         if self.shortest_path is None or self.shortest_path.shape[1] != paths.shape[1]:

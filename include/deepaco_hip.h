@@ -146,6 +146,8 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *            does in the reference for that directory's float64 instance data (demands k / capacity: a customer that
  *            fits exactly is common and the last bit decides); `demand` / `capacity` must still be given (their float32
  *            images); the construction then runs on the one-ant-per-wavefront kernel for every n.
+ *   ev_begin, ev_end   optional hipEvent_t recorded on `stream` right before / after the construction kernel (as in
+ *            daco_tsp_sample: the kernel alone, without the weight-matrix kernel and the table memsets before it).
  */
 size_t daco_directed_table_bytes(int B, int n, int A);
 int daco_cvrp_sample(void *stream, int B, int n, int A,
@@ -155,7 +157,8 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
                      int32_t *lens, int32_t *flags,
                      const float *dist, long dist_bstride, float *costs, void *next_table,
-                     void *workspace, size_t workspace_bytes, const double *demand64, double capacity64);
+                     void *workspace, size_t workspace_bytes, const double *demand64, double capacity64,
+                     void *ev_begin, void *ev_end);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_track_best -- replaces the best-so-far bookkeeping inside ACO.run

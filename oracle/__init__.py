@@ -167,6 +167,26 @@ def two_opt_batch(dist, tours, max_iterations=1000):
     return t, sweeps
 
 
+def nls_batch(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20):
+    """tsp_nls/aco.py:241-258 (ACO.nls) over orc_two_opt_batch: 2-opt, then T_nls x {T_p sweeps on the perturbation
+    matrix, 2-opt, keep the tour if shorter}.  Lengths summed like tour_costs.  Returns (tours, total sweeps)."""
+    def lengths(t):
+        return tour_costs(dist, np.ascontiguousarray(t.T.astype(np.int64)), closed=True)
+    best, sw = two_opt_batch(dist, tours, maxt)
+    total = int(sw.sum())
+    best_costs = lengths(best)
+    new = best
+    for _ in range(T_nls):
+        pert, s1 = two_opt_batch(heuristic_dist, new, T_p)
+        new, s2 = two_opt_batch(dist, pert, maxt)
+        total += int(s1.sum()) + int(s2.sum())
+        c = lengths(new)
+        better = c < best_costs
+        best = np.where(better[:, None], new, best)
+        best_costs = np.where(better, c, best_costs)
+    return best, total
+
+
 def roulette_route(probmat, uniforms, start=0):
     probmat = _f32(probmat)
     uniforms = np.ascontiguousarray(uniforms, dtype=np.float64)

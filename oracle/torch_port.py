@@ -69,3 +69,53 @@ def colony_iterations(distances, heuristic, n_ants, iterations, decay=0.9):
         lowest = min(lowest, float(costs.min()))
         tau = deposit(tau, paths, costs, decay)
     return lowest, tau
+
+
+# ------------------------------------------------------------------ CVRP (cvrp/aco.py:138-205, :107-136)
+def cvrp_rollout(pheromone, heuristic, demand, capacity, n_ants, alpha=1, beta=1):
+    """cvrp/aco.py:138-205 gen_path: depot start, visit mask with the depot rule (:176-180), capacity mask rebuilt per
+    step (:182-202), the all-done test with its host sync (:204-205).  Returns paths [L, n_ants]."""
+    n = pheromone.shape[0]
+    ants = torch.arange(n_ants)
+
+    def visit_update(mask, cur):
+        mask[ants, cur] = 0
+        mask[:, 0] = 1
+        mask[(cur == 0) * (mask[:, 1:] != 0).any(dim=1), 0] = 0
+        return mask
+
+    def capacity_update(cur, used):
+        cap_mask = torch.ones(size=(n_ants, n))
+        used[cur == 0] = 0
+        used = used + demand[cur]
+        room = (capacity - used).unsqueeze(-1).repeat(1, n)
+        cap_mask[demand.unsqueeze(0).repeat(n_ants, 1) > room] = 0
+        return used, cap_mask
+
+    cur = torch.zeros((n_ants,), dtype=torch.long)
+    open_mask = visit_update(torch.ones(size=(n_ants, n)), cur)
+    used, cap_mask = capacity_update(cur, torch.zeros(size=(n_ants,)))
+    route = [cur]
+    while not ((open_mask[:, 1:] == 0).all() and (cur == 0).all()):
+        weights = (pheromone[cur] ** alpha) * (heuristic[cur] ** beta) * open_mask * cap_mask
+        cur = Categorical(weights).sample()
+        route.append(cur)
+        open_mask = visit_update(open_mask, cur)
+        used, cap_mask = capacity_update(cur, used)
+    return torch.stack(route)
+
+
+def route_lengths(distances, paths):
+    """cvrp/aco.py:133-136."""
+    u = paths.permute(1, 0)
+    return torch.sum(distances[u[:, :-1], u[:, 1:]], dim=1)
+
+
+def deposit_directed(pheromone, paths, costs, decay=0.9):
+    """cvrp/aco.py:107-130 (AS): directed, non-accumulating index_put per ant, floor 1e-10."""
+    tau = pheromone * decay
+    for a in range(paths.shape[1]):
+        t, c = paths[:, a], costs[a]
+        tau[t[:-1], torch.roll(t, shifts=-1)[:-1]] += 1.0 / c
+    tau[tau < 1e-10] = 1e-10
+    return tau
