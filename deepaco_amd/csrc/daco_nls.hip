@@ -88,7 +88,8 @@ struct NlsMatrix {                            // one matrix of the search: dista
 struct NlsLds {
   int2 *rec;                                  // position k: {t[k] | t[k+1] << 16, bits of e[k] = d[t[k]][t[k+1]]}
   uint16_t *t, *pos, *rA, *rB;                // t[n] = t[0]; rA / rB: list lengths of the two sides of edge m
-  uint32_t *pre;                              // items + 1 offsets of the dirty lists' entries
+  uint32_t *pre;                              // offsets of the (compacted) non-empty dirty lists' entries, D + 1 values
+  uint16_t *ditem;                            // their items
   uint64_t *ckey, *sig;                       // per list: minimum key of its candidates, position buckets of its walked entries
   uint64_t *red;
   uint32_t *wsum;
@@ -129,8 +130,6 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
   __syncthreads();
   lap(0);
   const int items = SYM ? n + 1 : n, ipt = (items + NT - 1) / NT;
-  int steps = 0;
-  while ((1 << steps) < items) ++steps;
   auto count_a = [&](int m) -> uint32_t { return m <= n - 3 ? rA[m] : 0; };
   auto count_of = [&](int item) -> uint32_t {
     if (SYM) {
@@ -148,7 +147,7 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
     const uint64_t span = (bhi - blo >= 63) ? ~(uint64_t)0 : ((((uint64_t)1 << (bhi - blo + 1)) - 1) << blo);
     const int i0 = tid * ipt;
     uint32_t cq[MAXIPT];
-    uint32_t local = 0;
+    uint32_t local = 0;                                       // entries of my dirty lists | (non-empty dirty lists) << 22
 #pragma unroll
     for (int q = 0; q < MAXIPT; ++q) {
       cq[q] = 0;
@@ -156,7 +155,7 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
       if (q < ipt && item < items) {
         const bool dirty = (item >= dlo && item <= dhi) || (L.sig[item] & span) != 0;
         if (dirty) { cq[q] = count_of(item); L.ckey[item] = NLS_NONE; L.sig[item] = 0; }
-        local += cq[q];
+        local += cq[q] + (cq[q] ? 1u << 22 : 0u);             // (n <= 1024: fewer than 2^22 entries, fewer than 2^10 lists)
       }
     }
     const uint32_t inc = nls_wave_scan_u32(local);            // inclusive, on the DPP network (no LDS traffic)
@@ -165,17 +164,15 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
     lap(1);
     uint32_t base = inc - local;
     for (int w = 0; w < wave; ++w) base += L.wsum[w];
+    // the non-empty dirty lists, compacted: list j = item ditem[j], entries pre[j] .. pre[j+1]
+    uint32_t at = base & 0x3fffff, j = base >> 22;
 #pragma unroll
     for (int q = 0; q < MAXIPT; ++q) {
-      const int item = i0 + q;
-      if (q < ipt && item < items) {
-        L.pre[item] = base;
-        base += cq[q];
-      }
+      if (cq[q]) { L.pre[j] = at; L.ditem[j] = (uint16_t)(i0 + q); at += cq[q]; ++j; }
     }
-    if (tid == NT - 1) L.pre[items] = base;
+    if (tid == NT - 1) { L.pre[j] = at; L.wsum[NW] = j; }
     __syncthreads();
-    const uint32_t W = L.pre[items];
+    const uint32_t D = L.wsum[NW], W = L.pre[D];
     walked += W;
     lap(2);
     {
@@ -184,33 +181,36 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
       // then every matrix gather (a sweep near a local optimum walks a few hundred entries: one round, two memory round
       // trips; entry by entry it was a chain of two dependent trips per entry, which is what a sweep's time was made of).
       // Both sides evaluate ((table + gathered) - c) - e: f32 addition commutes, so one expression serves the two.
-      for (uint32_t w0 = tid; w0 < cnt; w0 += NT * NLS_G) {
+      // (A thread's NLS_G entries are neighbours in the flat order: one binary search over the compacted lists finds the first
+      // one's list, each following entry is in the same list or the next -- every compacted list has at least one entry.)
+      const int steps = D > 1 ? 32 - __builtin_clz(D - 1) : 0;            // ceil(log2 D), uniform
+      for (uint32_t w0 = tid * NLS_G; w0 < cnt; w0 += NT * NLS_G) {
         if (prof && tid == 0) L.lap[7] += 1;
-        uint32_t mm[NLS_G], lo[NLS_G], ga[NLS_G], ww[NLS_G], hi[NLS_G];
+        uint32_t mm[NLS_G], lo[NLS_G], ga[NLS_G], ww[NLS_G];
         bool ok[NLS_G];
-        // entry w of the sweep belongs to the list `item` with pre[item] <= w < pre[item + 1] (clean lists are empty ranges):
-        // binary search with a fixed number of steps, the searches of the thread's entries side by side
-#pragma unroll
-        for (int j = 0; j < NLS_G; ++j) {
-          const uint32_t w = w0 + j * NT;
-          ok[j] = w < cnt;
-          ww[j] = ok[j] ? w : cnt - 1;                        // (entries past the end repeat the last one and drop it)
-          lo[j] = 0; hi[j] = (uint32_t)items;
-        }
-        for (int st = 0; st < steps; ++st) {
+        {
+          uint32_t a = 0, b = D;                              // pre[a] <= w0 < pre[b]
+          for (int st = 0; st < steps; ++st) {
+            const uint32_t mid = (a + b) >> 1;
+            const bool ge = L.pre[mid] <= w0;
+            a = ge ? mid : a;
+            b = ge ? b : mid;
+          }
+          uint32_t start = L.pre[a], next = L.pre[a + 1];
 #pragma unroll
           for (int j = 0; j < NLS_G; ++j) {
-            const uint32_t mid = (lo[j] + hi[j]) >> 1;
-            const bool ge = L.pre[mid] <= ww[j];
-            lo[j] = ge ? mid : lo[j];
-            hi[j] = ge ? hi[j] : mid;
+            const uint32_t w = w0 + j;
+            ok[j] = w < cnt;
+            if (j > 0 && ok[j] && w >= next) { ++a; start = next; next = L.pre[a + 1]; }
+            lo[j] = L.ditem[a];
+            ww[j] = ok[j] ? w - start : 0;                    // (entries past the end read their list's first entry and drop it)
           }
         }
         float c[NLS_G], ej[NLS_G], g[NLS_G];
         NbrEntry en[NLS_G];
 #pragma unroll
         for (int j = 0; j < NLS_G; ++j) {
-          const uint32_t m = lo[j], k = ww[j] - L.pre[m];
+          const uint32_t m = lo[j], k = ww[j];
           mm[j] = m;
           if (SYM) {
             en[j] = nls_ld(M.nb, (uint32_t)t[m] * un + k);
@@ -324,7 +324,8 @@ nls_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *t
   L.lap = reinterpret_cast<unsigned long long *>(L.red + 16);
   L.pre = reinterpret_cast<uint32_t *>(L.lap + 8);
   L.wsum = L.pre + np2 + 2;
-  L.scal = reinterpret_cast<float *>(L.wsum + 16);
+  L.ditem = reinterpret_cast<uint16_t *>(L.wsum + 32);
+  L.scal = reinterpret_cast<float *>(L.ditem + np2);
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = blk / T;
   uint16_t *tour = tours + (size_t)blk * n;
@@ -405,7 +406,7 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   // them), more when there are fewer tours than the device holds (a sweep is a latency chain: more threads shorten it)
   int nt = (long)B * T <= 512 ? 1024 : ((long)B * T <= 1536 ? 512 : 256);
   if (const char *ev = getenv("DACO_NLS_THREADS")) nt = atoi(ev);
-  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)np2 * 8 * 2 + 24 * 8 + (size_t)(np2 + 2) * 4 + 16 * 4 + 16;
+  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)np2 * 8 * 2 + 24 * 8 + (size_t)(np2 + 2) * 4 + 32 * 4 + (size_t)np2 * 2 + 16;
   // threads per tour: 256 when there are tours to fill the device several times over (a CU then interleaves six of them),
   // more when there are fewer tours than the device holds (a sweep is a latency chain: more threads shorten its evaluation)
   hipStream_t s = (hipStream_t)stream;

@@ -1,14 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3e
-timeout 900 python bench.py --min-seconds 3 > gpurun_out/r3e/bench.json 2> gpurun_out/r3e/bench.err
-tail -5 gpurun_out/r3e/bench.err
-python - <<'PY'
-import json
-j=json.loads(open('gpurun_out/r3e/bench.json').read().strip().splitlines()[-1])
-def show(d,ind=0):
-    for k,v in d.items():
-        if isinstance(v,dict): print(' '*ind+k+':'); show(v,ind+2)
-        else: print(' '*ind+f'{k}: {v if not isinstance(v,str) else v[:110]}')
-show(j)
-PY
+mkdir -p gpurun_out/r3g
+timeout 900 python -m pytest tests/test_gpu_03_two_opt.py -x -q 2>&1 | tail -5 > gpurun_out/r3g/pytest_03.log
+timeout 900 python tools/bench_nls_fused.py 64 4 prof,g2,g4,g1,g2,g4 > gpurun_out/r3g/bench_nls.log 2>&1
+cat gpurun_out/r3g/pytest_03.log gpurun_out/r3g/bench_nls.log
