@@ -116,6 +116,14 @@ class AntShardedColony:
         self.exchange, self.update_fn = exchange, update_fn
         self.lowest_cost = torch.full((tau.shape[0],), float("inf"), device=tau.device)
         self.iteration = 0
+        self._buffers = {}          # exchange buffers, allocated once (a [B,n,n] delta or B*n*A tours per iteration otherwise)
+
+    def _buffer(self, tag, shape, dtype, device):
+        key = (tag, tuple(shape), dtype)
+        buf = self._buffers.get(key)
+        if buf is None:
+            buf = self._buffers[key] = torch.zeros(tuple(shape), dtype=dtype, device=device)
+        return buf
 
     def _gather_ants(self, x, dim):
         """all-gather along the ant dimension (ranks may own one ant more or less: padded, then trimmed)."""
@@ -124,9 +132,9 @@ class AntShardedColony:
         q = -(-self.n_ants // self.world)
         shape = list(x.shape)
         shape[dim] = q
-        pad = torch.zeros(shape, dtype=x.dtype, device=x.device)
+        pad = self._buffer("pad", shape, x.dtype, x.device)            # (rows past this rank's ants stay zero)
         pad.narrow(dim, 0, x.shape[dim]).copy_(x)
-        out = [torch.empty_like(pad) for _ in range(self.world)]
+        out = [self._buffer(("out", r), shape, x.dtype, x.device) for r in range(self.world)]
         if pad.dtype == torch.int16:          # neither gloo nor RCCL moves int16: ship the same bytes as uint8
             all_gather_([o.view(torch.uint8) for o in out], pad.view(torch.uint8))
         else:
@@ -149,12 +157,12 @@ class AntShardedColony:
             self.lowest_cost = torch.minimum(self.lowest_cost, all_costs.min(dim=1).values)
             self.iteration += 1
             return paths, costs
-        delta = self.deposit_fn(torch.zeros_like(self.tau), paths, costs)
+        delta = self.deposit_fn(self._buffer("delta", self.tau.shape, self.tau.dtype, self.tau.device).zero_(), paths, costs)
         best = costs.min(dim=1).values
         if self.world > 1:
             all_reduce_(delta, dist.ReduceOp.SUM)                 # the one data-path collective
             all_reduce_(best, dist.ReduceOp.MIN)
-        self.tau = self.tau * self.decay + delta
+        self.tau.mul_(self.decay).add_(delta)                     # in place: tau * decay (rounded), then + delta, as before
         self.lowest_cost = torch.minimum(self.lowest_cost, best)
         self.iteration += 1
         return paths, costs

@@ -338,6 +338,22 @@ def test_scan_kernels_reproduce_reference_roulette_routes(mode):
     assert np.array_equal(paths[0].cpu().numpy(), rp)
 
 
+@pytest.mark.parametrize("n", [100, 300, 600])
+def test_scan_kernels_reproduce_reference_roulette_routes_lane_order(n):
+    """g6w: the reference's roulette on the instance relabelled by a layout's lane order (tests/golden/gen_g6_wide.py), rows
+    with exact zeros and a k-sparse row: the HIP scan kernels (four / two ants per wavefront; one ant per wavefront) fed the
+    recorded uniforms build exactly the reference's routes."""
+    from deepaco_amd import engine
+    g = load_golden(f"g6w_roulette_n{n}")
+    P = T(g["probmat"])[None]
+    for lanes, mode in (((16 if n <= 256 else 32), "scan"), (64, "scan_wave")):
+        u = torch.from_numpy(g[f"uniforms_l{lanes}"].T.copy()).to(dev())[None]          # [1][n-1][A]
+        A = u.shape[2]
+        paths, _, _, flags = engine.tsp_sample(P, torch.ones(1, n, n, device=dev()), A, mode=mode, fixed_start=0, noise=u)
+        assert int(flags.sum()) == 0
+        assert np.array_equal(paths[0].cpu().numpy().T.astype(np.uint16), g[f"routes_l{lanes}"]), (n, mode)
+
+
 def _layout_order(n, lanes):
     """position of candidate k in the order the lanes of a layout walk a row: (lane, chunk, slot)."""
     vec = 4 if lanes < 64 else (4 if n > 128 else (2 if n > 64 else 1))

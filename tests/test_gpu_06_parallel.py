@@ -107,3 +107,17 @@ def test_bench_launches_its_own_ranks():
     # ant-sharded, exact exchange: strong scaling, same colony on both ranks
     ants = _bench_line("--gpus", "2", "--dist-backend", "gloo", "--force-device", "0", "--shard", "ants", *common)
     assert ants["n_gpus"] == 2 and ants["scaling"] == "strong"
+
+
+def test_bench_four_ranks_on_one_gpu_both_shardings():
+    """Four ranks (all on cuda:0, gloo rendezvous): instance-sharded (weak: four times the tours per step), and the
+    ant-sharded colony with the delta-tau all-reduce as its one data-path collective (strong), pre-allocated exchange
+    buffers.  What the driver's --gpus 4 run does, short of four devices."""
+    common = ("--no-cpu", "--no-extras", "--min-seconds", "0", "--steps", "3", "--warmup", "1", "--nodes", "120",
+              "--ants", "64", "--batch", "4", "--gpus", "4", "--dist-backend", "gloo", "--force-device", "0")
+    inst = _bench_line(*common)
+    assert inst["n_gpus"] == 4 and inst["rccl"]["ranks"] == 4 and inst["scaling"] == "weak"
+    assert inst["config"]["parallelism"] == "instance-sharded x4" and inst["value"] > 0
+    delta = _bench_line("--shard", "ants", "--exchange", "delta", *common)
+    assert delta["n_gpus"] == 4 and delta["scaling"] == "strong" and "all-reduce of delta-tau" in delta["rccl"]["data_path_collective"]
+    assert delta["gpu_mean_best_cost"] > 0

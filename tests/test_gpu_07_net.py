@@ -487,3 +487,36 @@ def test_cvrp_nls_train_instance_on_the_drop_in():
     assert torch.isfinite(gn) and float(gn) > 0
     optimizer.step()
     assert sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, model.parameters())) > 100
+
+
+@pytest.mark.parametrize("n,n_ants,k_sparse,wfix", [(20, 20, 10, "g5_net_tsp_tsp20"), (100, 20, 20, "g5_net_tsp_tsp100"),
+                                                    (500, 50, 50, "w_tsp_tsp500")])
+def test_notebook_validation_protocol_reproduces_the_published_costs(n, n_ants, k_sparse, wfix):
+    """SURVEY 8(c)'s end-to-end check of the network path (the fixtures were generated through a torch_geometric
+    stand-in): tsp/train.ipynb's `validation` on the reference's own validation set with the checkpoint it saved --
+    infer_instance (cell 1): heuristic = Net(pyg) + 1e-10, ACO(n_ants).sample(), run(T = 5) -- prints, for the final
+    epoch, (avg sample cost, best sample cost, best ACO cost) = g10 `notebook<n>`.  The drop-in classes on the same 100
+    instances and weights must land on the same three numbers up to sampling noise (1.5 %; a wrong aggregation or
+    normalisation in the network moves them by far more: an untrained net gives 64.9 at n = 500)."""
+    from deepaco_amd.tsp.net import Net
+    from deepaco_amd.tsp.aco import ACO
+    from deepaco_amd.tsp.utils import gen_pyg_data
+    g = np.load(os.path.join(GOLDEN, "g10_val_tsp.npz"))
+    wz = np.load(os.path.join(GOLDEN, wfix + ".npz"))
+    prefix = "w__"
+    net = Net()
+    net.load_state_dict({k[len(prefix):]: torch.from_numpy(wz[k]) for k in wz.files if k.startswith(prefix)}, strict=False)
+    net = net.to(dev()).eval()
+    torch.manual_seed(1234)
+    sums = np.zeros(3)
+    coords = torch.from_numpy(g[f"coords{n}"]).to(dev())
+    with torch.no_grad():
+        for inst in coords:
+            pyg, distances = gen_pyg_data(inst, k_sparse=k_sparse)
+            heu_mat = net.reshape(pyg, net(pyg)) + 1e-10
+            aco = ACO(n_ants=n_ants, heuristic=heu_mat, distances=distances, device="cuda:0")
+            costs, _ = aco.sample()
+            aco.run(n_iterations=5)
+            sums += (float(costs.mean()), float(costs.min()), float(aco.lowest_cost))
+    got, want = sums / len(coords), g[f"notebook{n}"]
+    np.testing.assert_allclose(got, want, rtol=0.015)

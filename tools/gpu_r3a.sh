@@ -1,6 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3g
-timeout 900 python -m pytest tests/test_gpu_03_two_opt.py -x -q 2>&1 | tail -5 > gpurun_out/r3g/pytest_03.log
-timeout 900 python tools/bench_nls_fused.py 64 4 prof,g2,g4,g1,g2,g4 > gpurun_out/r3g/bench_nls.log 2>&1
-cat gpurun_out/r3g/pytest_03.log gpurun_out/r3g/bench_nls.log
+mkdir -p gpurun_out/r3h
+timeout 1700 python -m pytest tests -q -m gpu -x tests/test_gpu_00_tsp.py tests/test_gpu_06_parallel.py tests/test_gpu_07_net.py 2>&1 | tail -15 > gpurun_out/r3h/pytest.log
+cat gpurun_out/r3h/pytest.log
