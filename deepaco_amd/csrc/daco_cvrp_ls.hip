@@ -3,38 +3,50 @@
 // Reference behaviour replaced: cvrp_nls/aco.py:114-126 (multiple_swap_star: one thread-pool task per ant), :443-448
 // (neural_swapstar: search on the distances, a short search on the heuristic-derived matrix as perturbation, search
 // on the distances again) and the path it takes into the vendored HGS-CVRP C++ through /tmp files
-// (cvrp_nls/swapstar.py:240-271, HGS-CVRP-main/Program/C_Interface.cpp:128-172).  HGS's LocalSearch is third-party
-// code with a randomised neighbourhood order; it is not restated here.  This kernel is a deterministic
-// best-improvement search over the classical neighbourhoods HGS also uses, specified in this file and restated on
-// the CPU in oracle/cvrp_ls.py (PARITY UNPINNED against the reference: the tests pin it against that restatement,
-// and against feasibility / monotonicity / local-optimality properties).
+// (cvrp_nls/swapstar.py:240-271, HGS-CVRP-main/Program/C_Interface.cpp:128-172 -> LocalSearch.cpp).  HGS's LocalSearch is
+// first improvement over a granular neighbourhood in a shuffled order (std::minstd_rand + std::shuffle), with load
+// penalties instead of hard capacity and SWAP* on top; it is NOT reproduced move for move.  This kernel is a deterministic
+// BEST-improvement search over HGS's classical move families (LocalSearch.cpp move1 .. move9), hard capacity, specified
+// below and restated on the CPU in oracle/cvrp_ls.py (the tests hold the kernel bit-exact against that restatement).
+// Parity with the reference is pinned on COST: tests/golden/g8_cvrp_ls_*.npz are routes in / routes out of the
+// reference's own swapstar() / neural_swapstar() built from its sources; the schedule of cvrp_nls.ACO has to reach their
+// mean cost to within the tolerance stated in tests/test_gpu_09_cvrp_ls.py.
 //
-// A solution is the reference's route sequence: 0 a b c 0 d e 0 ... 0 (cvrp/aco.py:138-165), zero-padded.  After
-// removing empty routes it has L entries, s[0] = s[L-1] = 0.  Per iteration every move of three kinds is evaluated
-// (f32, the expression order written below) and the one with the smallest change is applied if it is below -1e-6;
-// ties go to the smallest (kind, i, j):
-//   RELOCATE i -> j   customer u = s[i] moves between s[j] and s[j+1] (j != i-1, i); another route must have room
-//                     change = ((d[a][c] - d[a][u]) - d[u][c]) + ((d[v][u] + d[u][w]) - d[v][w])
-//   SWAP i <-> j      customers u = s[i], v = s[j], i < j; both routes must keep within capacity
-//                     non-adjacent: ((d[a][v] + d[v][c]) - (d[a][u] + d[u][c])) + ((d[e][u] + d[u][g]) - (d[e][v] + d[v][g]))
-//                     adjacent    : ((d[a][v] + d[v][u]) + d[u][g]) - ((d[a][u] + d[u][v]) + d[v][g])
-//   2-OPT i..j        reverse s[i..j] inside one route, i < j
-//                     change = ((d[a][v] + d[u][g]) - (d[a][u] + d[v][g])) + (float)(asym[j] - asym[i])
-//                     (asym[k] = sum_{t<k} (d[s[t+1]][s[t]] - d[s[t]][s[t+1]]) in f64: what the inner edges cost more
-//                      when walked backwards.  Exactly 0 for a symmetric matrix; the perturbation matrix
-//                      1/(eta/rowmax + 1e-5) is not symmetric.  f64 because a difference of f32 running sums carries
-//                      ~1e-5 of rounding noise at n = 200 -- above the 1e-6 acceptance threshold, and the search cycled)
-// with a = s[i-1], c = s[i+1], e = s[j-1], g = s[j+1], v/w = s[j], s[j+1].  The distance matrix is staged in LDS when
-// it fits (n <= 160: every gather of the search is then an LDS read), demands and route loads always are.
+// Specification.  A solution is the reference's route sequence 0 a b c 0 d e 0 ... 0 (cvrp/aco.py:138-165) without empty
+// routes, L entries, s[0] = s[L-1] = 0.  Per move every candidate (kind, i, j) is evaluated in f32 as
+//     change = (((a1 + a2) + a3) + a4) - (((r1 + r2) + r3) + r4)  [+ (float)(reversal term, f64)]
+// (a* = lengths of the edges the move adds, r* = of those it removes, in the order listed; missing terms are skipped); the
+// smallest change wins, ties to the smallest (kind, i, j), and the move is applied if its change is below -1e-6.  Loads are
+// f64 sums of the f32 demands along a route; a route is feasible if its load is <= capacity * (1 + 1e-6) (an exactly full
+// route of normalised demands must pass: the reference hands HGS capacity 1000.001 for the same reason, swapstar.py:254).
+// With u = s[i], a = s[i-1], c = s[i+1], x = s[i+1], c2 = s[i+2], v = s[j], w = s[j+1], e = s[j-1], g = s[j+1], y = s[j+1],
+// g2 = s[j+2]:
+//   0 REL1   u between v and w (j != i-1, i)                            add (a,c) (v,u) (u,w)       rem (a,u) (u,c) (v,w)
+//   1 REL2   the pair u x between v and w (j not in i-1 .. i+1)          add (a,c2) (v,u) (x,w)      rem (a,u) (x,c2) (v,w)
+//   2 REL2R  the pair reversed: ... v x u w ...                          add (a,c2) (v,x) (x,u) (u,w)  rem (a,u) (u,x) (x,c2) (v,w)
+//   3 SWAP11 u <-> v, i < j; j = i+1:                                    add (a,v) (v,u) (u,g)       rem (a,u) (u,v) (v,g)
+//                            else:                                        add (a,v) (v,c) (e,u) (u,g) rem (a,u) (u,c) (e,v) (v,g)
+//   4 SWAP21 the pair u x <-> v (j >= i+3 or j <= i-2)                   add (a,v) (v,c2) (e,u) (x,g)  rem (a,u) (x,c2) (e,v) (v,g)
+//   5 SWAP22 the pair u x <-> the pair v y (j >= i+3)                    add (a,v) (y,c2) (e,u) (x,g2) rem (a,u) (x,c2) (e,v) (y,g2)
+//   6 2OPT   reverse s[i..j] inside one route, i < j                     add (a,v) (u,g)             rem (a,u) (v,g)     + asym[j] - asym[i]
+//   7 TAILS  routes r1 < r2 cut after i and after j, tails exchanged     add (u,y) (v,x)             rem (u,x) (v,y)
+//   8 CROSS  r1 = head1 + reversed head2, r2 = reversed tail1 + tail2    add (u,v) (x,y)             rem (u,x) (v,y)     + reversal of head2 and tail1
+// (asym[k]: f64 sum over the route's edges before position k of d[s[t+1]][s[t]] - d[s[t]][s[t+1]] -- what the edges cost
+// more walked backwards; exactly 0 for a symmetric matrix, the perturbation matrix 1/(eta/rowmax + 1e-5) is not symmetric.)
+// Moves between routes must keep every route within capacity.  The distance matrix is staged in LDS when it fits
+// (n <= 160: every gather of the search is then an LDS read).
+// Bookkeeping per move is wave-parallel: route ids from ballots over 64 positions at a time, one lane per route for the
+// (sequential, f64) loads and reversal sums, the new sequence gathered by all threads through a table of at most six source
+// ranges, empty routes squeezed out with ballots.
 #include "daco_device.h"
 #include "../../include/deepaco_hip.h"
 
 namespace daco {
 
 constexpr int LS_MAXL = 1024;      // longest sequence (2n+1 entries at most)
+constexpr int LS_MAXR = 512;       // routes
 constexpr int LS_STAGE_MAX_N = 160;
 
-struct LsBest { float delta; uint32_t code; };
 __device__ inline bool ls_better(float d1, uint32_t c1, float d2, uint32_t c2) { return d1 < d2 || (d1 == d2 && c1 < c2); }
 
 template <bool STAGE>
@@ -42,111 +54,183 @@ __global__ void __launch_bounds__(256)
 cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const float *demand, float capacity, int64_t *paths,
                int count, int32_t *lens_out, int32_t *moves_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint16_t *s = reinterpret_cast<uint16_t *>(smem);                 // [LS_MAXL] sequence
-  uint16_t *rid = s + LS_MAXL;                                      // [LS_MAXL] route of position k (of the gap after a depot)
-  double *asym = reinterpret_cast<double *>(rid + LS_MAXL);         // [LS_MAXL] sum of d[s[t+1]][s[t]] - d[s[t]][s[t+1]], t < k
-  float *load = reinterpret_cast<float *>(asym + LS_MAXL);          // [LS_MAXL] route loads
-  float *dem = load + LS_MAXL;                                      // [n] demands (padded to n4)
-  const int n4 = (n + 3) & ~3;
-  float *redd = dem + n4;                                           // [4] reduction
+  double *pf = reinterpret_cast<double *>(smem);                    // [LS_MAXL] load of the route up to and including k
+  double *asym = pf + LS_MAXL;                                      // [LS_MAXL]
+  double *rl = asym + LS_MAXL;                                      // [LS_MAXR + 1] route loads
+  double *asymT = rl + LS_MAXR + 1;                                 // [LS_MAXR + 1] reversal sum of the whole route
+  uint16_t *s = reinterpret_cast<uint16_t *>(asymT + LS_MAXR + 1);  // [LS_MAXL + 4] sequence (4 spare entries of padding)
+  uint16_t *s2 = s + LS_MAXL + 4;                                   // [LS_MAXL + 4] the sequence being built
+  uint16_t *rid = s2 + LS_MAXL + 4;                                 // [LS_MAXL] route of position k
+  uint16_t *rstart = rid + LS_MAXL;                                 // [LS_MAXR + 2] opening depot of route r
+  float *redd = reinterpret_cast<float *>(rstart + LS_MAXR + 2);    // [4] reduction
   uint32_t *redc = reinterpret_cast<uint32_t *>(redd + 4);          // [4]
-  int *shared_i = reinterpret_cast<int *>(redc + 4);                // [4]: L, applied flag
-  float *dl = reinterpret_cast<float *>(shared_i + 4);              // [n*n] staged distances (STAGE)
+  int *shared_i = reinterpret_cast<int *>(redc + 4);                // [0] L, [1] R, [2..] piece table (6 x {lo, hi, rev})
+  const int n4 = (n + 3) & ~3;
+  float *dem = reinterpret_cast<float *>(shared_i + 24);            // [n4] demands
+  float *dl = dem + n4;                                             // [n*n] staged distances (STAGE)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / A, a = blockIdx.x - b * A;
+  const int b = blockIdx.x / A, a_ = blockIdx.x - b * A;
   const float *dg = dist + (size_t)b * dist_bs;
-  int64_t *col = paths + (size_t)b * Lmax * A + a;
+  int64_t *col = paths + (size_t)b * Lmax * A + a_;
+  const double capT = (double)capacity * (1.0 + 1e-6);
 
   for (int k = tid; k < n; k += 256) dem[k] = demand[(size_t)b * n + k];
   if constexpr (STAGE) for (int k = tid; k < n * n; k += 256) dl[k] = dg[k];
   auto D = [&](int u, int v) -> float { return STAGE ? dl[u * n + v] : dg[(size_t)u * n + v]; };
-  // ---- read the column, drop empty routes (serial: the sequence is a few hundred entries)
-  if (tid == 0) {
-    int L = 0;
-    int prev = -1;
-    for (int t = 0; t < Lmax; ++t) {
-      const int v = (int)col[(size_t)t * A];
-      if (v == 0 && prev == 0) continue;
-      s[L++] = (uint16_t)v;
-      prev = v;
+  // squeeze doubled depots out of src[0..len) into dst (wave 0, 64 entries per step); returns the new length (all lanes)
+  auto squeeze = [&](const uint16_t *src, int len, uint16_t *dst, bool from_col) -> int {
+    int out = 0, last = -1;                                 // last entry written so far (-1: none)
+    for (int k0 = 0; k0 < len; k0 += 64) {
+      const int k = k0 + lane;
+      const int v = k < len ? (from_col ? (int)col[(size_t)k * A] : (int)src[k]) : -1;
+      int before = __shfl_up(v, 1, 64);
+      if (lane == 0) before = last;
+      const bool keep = k < len && !(v == 0 && before == 0);
+      const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+      if (keep) dst[out + __builtin_popcountll(m & ((1ull << lane) - 1))] = (uint16_t)v;
+      out += __builtin_popcountll(m);
+      const int cnt = len - k0 < 64 ? len - k0 : 64;
+      last = __builtin_amdgcn_readlane(v, cnt - 1);
     }
-    if (L == 0 || s[L - 1] != 0) s[L++] = 0;
-    shared_i[0] = L;
+    return out;
+  };
+  if (wave == 0) {
+    int L0 = squeeze(nullptr, Lmax, s, true);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      if (L0 == 0 || s[L0 - 1] != 0) s[L0++] = 0;           // the column had no closing depot
+      shared_i[0] = L0;
+    }
   }
   __syncthreads();
   int L = shared_i[0];
   int moves = 0;
   for (; moves < count; ++moves) {
-    // ---- bookkeeping for this sequence: route ids, loads, running edge sums (one thread; L is small)
-    if (tid == 0) {
+    // ---- tables.  Wave 0: route of every position and the routes' opening depots (ballots over 64 positions)
+    if (wave == 0) {
       int r = -1;
-      double w = 0.0;
-      for (int k = 0; k < L; ++k) {
-        if (s[k] == 0) { ++r; load[r] = 0.0f; }
-        else load[r] = load[r] + dem[s[k]];
-        rid[k] = (uint16_t)r;
-        asym[k] = w;
-        if (k + 1 < L) w = w + ((double)D(s[k + 1], s[k]) - (double)D(s[k], s[k + 1]));
+      for (int k0 = 0; k0 < L; k0 += 64) {
+        const int k = k0 + lane;
+        const bool dep = k < L && s[k] == 0;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(dep);
+        const int mine = r + __builtin_popcountll(m & ((2ull << lane) - 1));
+        if (k < L) rid[k] = (uint16_t)mine;
+        if (dep) rstart[mine] = (uint16_t)k;
+        r += __builtin_popcountll(m);
       }
+      if (lane == 0) shared_i[1] = r;                       // R: routes (the last depot opened the empty sentinel route R)
+      if (lane < 4) s[L + lane] = 0;                        // padding read by the pair moves at the sequence's end
     }
     __syncthreads();
-    float bd = 0.0f;                    // only improving moves qualify
+    const int R = shared_i[1];
+    // one lane per route: loads and reversal sums along it, sequentially in f64
+    for (int r = tid; r <= R; r += 256) {
+      const int k0 = rstart[r], k1 = r < R ? rstart[r + 1] : k0;
+      double load = 0.0, rev = 0.0;
+      pf[k0] = 0.0; asym[k0] = 0.0;
+      for (int k = k0 + 1; k < k1; ++k) {
+        rev = rev + ((double)D(s[k], s[k - 1]) - (double)D(s[k - 1], s[k]));
+        load = load + (double)dem[s[k]];
+        pf[k] = load; asym[k] = rev;
+      }
+      rl[r] = load;
+      asymT[r] = r < R ? rev + ((double)D(s[k1], s[k1 - 1]) - (double)D(s[k1 - 1], s[k1])) : 0.0;
+    }
+    __syncthreads();
+    float bd = __builtin_inff();
     uint32_t bc = 0xFFFFFFFFu;
-    // ---- RELOCATE: i in [1, L-2] customer, j in [0, L-2]
-    const int nrel = (L - 2) * (L - 1);
-    for (int x = tid; x < nrel; x += 256) {
-      const int i = 1 + x / (L - 1), j = x - (i - 1) * (L - 1);
-      const int u = s[i];
-      if (u == 0 || j == i || j == i - 1) continue;
-      if (rid[j] != rid[i] && load[rid[j]] + dem[u] > capacity) continue;
-      const int pa = s[i - 1], pc = s[i + 1], v = s[j], w = s[j + 1];
-      float rem = D(pa, pc) - D(pa, u);
-      rem = rem - D(u, pc);
-      float add = D(v, u) + D(u, w);
-      add = add - D(v, w);
-      const float delta = rem + add;
-      const uint32_t code = (0u << 28) | ((uint32_t)i << 14) | (uint32_t)j;
+    auto offer = [&](float delta, uint32_t kind, int i, int j) {
+      const uint32_t code = (kind << 28) | ((uint32_t)i << 14) | (uint32_t)j;
       if (ls_better(delta, code, bd, bc)) { bd = delta; bc = code; }
-    }
-    // ---- SWAP: i < j customers
-    const int nsw = (L - 2) * (L - 2);
-    for (int x = tid; x < nsw; x += 256) {
-      const int i = 1 + x / (L - 2), j = 1 + x - (i - 1) * (L - 2);
-      if (j <= i) continue;
+    };
+    // ---- every (i, j), i, j in [0, L-2]
+    const int W = L - 1;
+    int i = tid / W, j = tid - i * W;
+    for (; i < W; ) {
       const int u = s[i], v = s[j];
-      if (u == 0 || v == 0) continue;
-      if (rid[i] != rid[j]) {
-        if (load[rid[i]] - dem[u] + dem[v] > capacity || load[rid[j]] - dem[v] + dem[u] > capacity) continue;
+      const int ri = rid[i], rj = rid[j];
+      if (u != 0) {
+        const int pa = s[i - 1], pc = s[i + 1], w = s[j + 1];
+        const bool other = ri != rj;
+        const float du = dem[u];
+        if (j != i && j != i - 1 && (!other || rl[rj] + (double)du <= capT)) {
+          const float add = (D(pa, pc) + D(v, u)) + D(u, w);
+          const float rem = (D(pa, u) + D(u, pc)) + D(v, w);
+          offer(add - rem, 0u, i, j);
+        }
+        const bool pair = pc != 0;                          // x = s[i+1] is a customer
+        const int c2 = s[i + 2];
+        if (pair && j != i - 1 && j != i && j != i + 1 && (!other || rl[rj] + (double)du + (double)dem[pc] <= capT)) {
+          const float add1 = (D(pa, c2) + D(v, u)) + D(pc, w);
+          const float rem1 = (D(pa, u) + D(pc, c2)) + D(v, w);
+          offer(add1 - rem1, 1u, i, j);
+          const float add2 = ((D(pa, c2) + D(v, pc)) + D(pc, u)) + D(u, w);
+          const float rem2 = ((D(pa, u) + D(u, pc)) + D(pc, c2)) + D(v, w);
+          offer(add2 - rem2, 2u, i, j);
+        }
+        if (v != 0) {
+          const int pe = s[j - 1], pg = w;
+          const float dv = dem[v];
+          if (j > i) {
+            bool ok = true;
+            if (other) ok = rl[ri] - (double)du + (double)dv <= capT && rl[rj] - (double)dv + (double)du <= capT;
+            if (ok) {
+              if (j == i + 1) {
+                const float add = (D(pa, v) + D(v, u)) + D(u, pg);
+                const float rem = (D(pa, u) + D(u, v)) + D(v, pg);
+                offer(add - rem, 3u, i, j);
+              } else {
+                const float add = ((D(pa, v) + D(v, pc)) + D(pe, u)) + D(u, pg);
+                const float rem = ((D(pa, u) + D(u, pc)) + D(pe, v)) + D(v, pg);
+                offer(add - rem, 3u, i, j);
+              }
+            }
+            if (!other) {
+              const float add = D(pa, v) + D(u, pg);
+              const float rem = D(pa, u) + D(v, pg);
+              offer((add - rem) + (float)(asym[j] - asym[i]), 6u, i, j);
+            }
+          }
+          if (pair && (j >= i + 3 || j <= i - 2)) {
+            const double dp = (double)du + (double)dem[pc];
+            bool ok = true;
+            if (other) ok = rl[ri] - dp + (double)dv <= capT && rl[rj] - (double)dv + dp <= capT;
+            if (ok) {
+              const float add = ((D(pa, v) + D(v, c2)) + D(pe, u)) + D(pc, pg);
+              const float rem = ((D(pa, u) + D(pc, c2)) + D(pe, v)) + D(v, pg);
+              offer(add - rem, 4u, i, j);
+            }
+            if (j >= i + 3 && pg != 0) {                    // y = s[j+1] is a customer too
+              const int g2 = s[j + 2];
+              const double dq = (double)dv + (double)dem[pg];
+              bool ok2 = true;
+              if (other) ok2 = rl[ri] - dp + dq <= capT && rl[rj] - dq + dp <= capT;
+              if (ok2) {
+                const float add = ((D(pa, v) + D(pg, c2)) + D(pe, u)) + D(pc, g2);
+                const float rem = ((D(pa, u) + D(pc, c2)) + D(pe, v)) + D(pg, g2);
+                offer(add - rem, 5u, i, j);
+              }
+            }
+          }
+        }
       }
-      const int pa = s[i - 1], pg = s[j + 1];
-      float delta;
-      if (j == i + 1) {
-        float nw = D(pa, v) + D(v, u);
-        nw = nw + D(u, pg);
-        float od = D(pa, u) + D(u, v);
-        od = od + D(v, pg);
-        delta = nw - od;
-      } else {
-        const int pc = s[i + 1], pe = s[j - 1];
-        const float t1 = (D(pa, v) + D(v, pc)) - (D(pa, u) + D(u, pc));
-        const float t2 = (D(pe, u) + D(u, pg)) - (D(pe, v) + D(v, pg));
-        delta = t1 + t2;
+      if (ri < rj && rj < R) {
+        const int x = s[i + 1], y = s[j + 1];
+        const double hi_ = pf[i], hj = pf[j], ti = rl[ri] - hi_, tj = rl[rj] - hj;
+        if (hi_ + tj <= capT && hj + ti <= capT) {
+          const float add = D(u, y) + D(v, x);
+          const float rem = D(u, x) + D(v, y);
+          offer(add - rem, 7u, i, j);
+        }
+        if (hi_ + hj <= capT && ti + tj <= capT) {
+          const float add = D(u, v) + D(x, y);
+          const float rem = D(u, x) + D(v, y);
+          const double rev = asym[j] + (x != 0 ? asymT[ri] - asym[i + 1] : 0.0);
+          offer((add - rem) + (float)rev, 8u, i, j);
+        }
       }
-      const uint32_t code = (1u << 28) | ((uint32_t)i << 14) | (uint32_t)j;
-      if (ls_better(delta, code, bd, bc)) { bd = delta; bc = code; }
-    }
-    // ---- 2-OPT inside a route: i < j, same route, both customers
-    for (int x = tid; x < nsw; x += 256) {
-      const int i = 1 + x / (L - 2), j = 1 + x - (i - 1) * (L - 2);
-      if (j <= i) continue;
-      const int u = s[i], v = s[j];
-      if (u == 0 || v == 0 || rid[i] != rid[j]) continue;
-      const int pa = s[i - 1], pg = s[j + 1];
-      const float ends = (D(pa, v) + D(u, pg)) - (D(pa, u) + D(v, pg));
-      const float inner = (float)(asym[j] - asym[i]);
-      const float delta = ends + inner;
-      const uint32_t code = (2u << 28) | ((uint32_t)i << 14) | (uint32_t)j;
-      if (ls_better(delta, code, bd, bc)) { bd = delta; bc = code; }
+      j += 256;
+      while (j >= W) { j -= W; ++i; }
     }
     // ---- workgroup minimum
     for (int o = 32; o >= 1; o >>= 1) {
@@ -160,23 +244,50 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
 #pragma unroll
     for (int w = 1; w < 4; ++w) if (ls_better(redd[w], redc[w], bd, bc)) { bd = redd[w]; bc = redc[w]; }
     if (!(bd < -1e-6f) || bc == 0xFFFFFFFFu) break;
-    __syncthreads();
-    // ---- apply (one thread: shifts of a few hundred 2-byte entries)
+    // ---- apply: the new sequence is at most six ranges of the old one (some reversed)
     if (tid == 0) {
-      const int kind = (int)(bc >> 28), i = (int)((bc >> 14) & 0x3FFF), j = (int)(bc & 0x3FFF);
-      if (kind == 0) {
-        const uint16_t u = s[i];
-        if (j > i) { for (int k = i; k < j; ++k) s[k] = s[k + 1]; s[j] = u; }
-        else { for (int k = i; k > j + 1; --k) s[k] = s[k - 1]; s[j + 1] = u; }
-        // the route u left may be empty now: drop the doubled depot
-        int Lnew = 0;
-        for (int k = 0; k < L; ++k) { if (k > 0 && s[k] == 0 && s[Lnew - 1] == 0) continue; s[Lnew++] = s[k]; }
-        shared_i[0] = Lnew;
-      } else if (kind == 1) {
-        const uint16_t u = s[i]; s[i] = s[j]; s[j] = u;
+      const int kind = (int)(bc >> 28), mi = (int)((bc >> 14) & 0x3FFF), mj = (int)(bc & 0x3FFF);
+      int *pt = shared_i + 2;
+      int np = 0;
+      auto piece = [&](int lo, int hi, int rev) { if (lo <= hi) { pt[3 * np] = lo; pt[3 * np + 1] = hi; pt[3 * np + 2] = rev; ++np; } };
+      if (kind <= 2) {
+        const int len = kind == 0 ? 1 : 2, rv = kind == 2;
+        if (mj > mi) { piece(0, mi - 1, 0); piece(mi + len, mj, 0); piece(mi, mi + len - 1, rv); piece(mj + 1, L - 1, 0); }
+        else { piece(0, mj, 0); piece(mi, mi + len - 1, rv); piece(mj + 1, mi - 1, 0); piece(mi + len, L - 1, 0); }
+      } else if (kind == 3) {
+        piece(0, mi - 1, 0); piece(mj, mj, 0); piece(mi + 1, mj - 1, 0); piece(mi, mi, 0); piece(mj + 1, L - 1, 0);
+      } else if (kind == 4) {
+        if (mj > mi) { piece(0, mi - 1, 0); piece(mj, mj, 0); piece(mi + 2, mj - 1, 0); piece(mi, mi + 1, 0); piece(mj + 1, L - 1, 0); }
+        else { piece(0, mj - 1, 0); piece(mi, mi + 1, 0); piece(mj + 1, mi - 1, 0); piece(mj, mj, 0); piece(mi + 2, L - 1, 0); }
+      } else if (kind == 5) {
+        piece(0, mi - 1, 0); piece(mj, mj + 1, 0); piece(mi + 2, mj - 1, 0); piece(mi, mi + 1, 0); piece(mj + 2, L - 1, 0);
+      } else if (kind == 6) {
+        piece(0, mi - 1, 0); piece(mi, mj, 1); piece(mj + 1, L - 1, 0);
       } else {
-        for (int x = i, y = j; x < y; ++x, --y) { const uint16_t u = s[x]; s[x] = s[y]; s[y] = u; }
+        const int e1 = rstart[rid[mi] + 1], b2 = rstart[rid[mj]], e2 = rstart[rid[mj] + 1];
+        if (kind == 7) { piece(0, mi, 0); piece(mj + 1, e2 - 1, 0); piece(e1, mj, 0); piece(mi + 1, e1 - 1, 0); piece(e2, L - 1, 0); }
+        else { piece(0, mi, 0); piece(b2 + 1, mj, 1); piece(e1, b2, 0); piece(mi + 1, e1 - 1, 1); piece(mj + 1, e2 - 1, 0); piece(e2, L - 1, 0); }
       }
+      for (int q = np; q < 6; ++q) { pt[3 * q] = 1; pt[3 * q + 1] = 0; pt[3 * q + 2] = 0; }      // empty
+    }
+    __syncthreads();
+    for (int k = tid; k < L; k += 256) {
+      const int *pt = shared_i + 2;
+      int rest = k, src = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int lo = pt[3 * q], hi = pt[3 * q + 1], len = hi - lo + 1;
+        if (len > 0) {
+          if (rest >= 0 && rest < len) src = pt[3 * q + 2] ? hi - rest : lo + rest;
+          rest -= len;
+        }
+      }
+      s2[k] = s[src];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int Ln = squeeze(s2, L, s, false);               // a route may have become empty: drop the doubled depot
+      if (lane == 0) shared_i[0] = Ln;
     }
     __syncthreads();
     L = shared_i[0];
@@ -200,10 +311,12 @@ extern "C" int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lma
     set_error("daco_cvrp_local_search: bad argument (B=%d n=%d A=%d Lmax=%d)", B, n, A, Lmax);
     return DACO_E_BADARG;
   }
-  if (Lmax > LS_MAXL || n > 16383) { set_error("daco_cvrp_local_search: Lmax=%d exceeds %d", Lmax, LS_MAXL); return DACO_E_TOOLARGE; }
+  // (a column without a closing depot gets one appended: one entry of head room)
+  if (Lmax >= LS_MAXL || n > 16383) { set_error("daco_cvrp_local_search: Lmax=%d must stay below %d", Lmax, LS_MAXL); return DACO_E_TOOLARGE; }
   const int n4 = (n + 3) & ~3;
   const bool stage = n <= LS_STAGE_MAX_N;
-  const size_t lds = (size_t)2 * LS_MAXL * 2 + (size_t)3 * LS_MAXL * 4 + (size_t)n4 * 4 + 12 * 4 + (stage ? (size_t)n * n * 4 : 0);
+  const size_t lds = (size_t)2 * LS_MAXL * 8 + (size_t)2 * (LS_MAXR + 1) * 8 + (size_t)2 * (LS_MAXL + 4) * 2 + (size_t)LS_MAXL * 2 +
+                     (size_t)(LS_MAXR + 2) * 2 + 8 * 4 + 24 * 4 + (size_t)n4 * 4 + (stage ? (size_t)n * n * 4 : 0) + 16;
   hipStream_t s = (hipStream_t)stream;
   if (stage) {
     if (lds > 64 * 1024) {

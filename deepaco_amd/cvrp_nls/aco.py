@@ -10,11 +10,13 @@ tests/golden/gen_g1_cvrp_nls.py) is float64 as in the reference whenever `demand
 
 Local search (`swapstar=True`; cvrp_nls/aco.py:106-128, 443-448).  The reference hands every ant's routes to the
 vendored HGS-CVRP C++ (one thread-pool task per ant, /tmp files, ctypes).  Here `multiple_swap_star` improves all
-selected ants in ONE launch of daco_cvrp_local_search (csrc/daco_cvrp_ls.hip: relocate / swap / intra-route 2-opt, best
-improvement) and keeps the reference's three-stage schedule `neural_swapstar`: search on the distances, `disturb` = 10
-moves on the heuristic-derived matrix, search on the distances again.  HGS's own LocalSearch (randomised neighbourhood
-order, SWAP* reinsertion) is third-party code and is not reproduced move for move; what is guaranteed -- and tested -- is
-a feasible solution that is never worse and a local optimum of the three neighbourhoods.
+selected ants in ONE launch per stage of daco_cvrp_local_search (csrc/daco_cvrp_ls.hip: best improvement over HGS's move
+families 1-9 -- relocate 1 / 2 / 2 reversed, swap 1-1 / 2-1 / 2-2, 2-opt, 2-opt* both ways -- with hard capacity) and
+keeps the reference's three-stage schedule `neural_swapstar`: search on the distances, `disturb` = 10 moves on the
+heuristic-derived matrix, search on the distances again.  HGS's own LocalSearch (first improvement in a shuffled order,
+load penalties, SWAP*) is not reproduced move for move; parity is pinned on cost: on solutions sampled by the reference
+the schedule reaches the mean cost of the reference's own neural_swapstar to within 0.5 % (tests/golden/g8_*,
+tests/test_gpu_09_cvrp_ls.py), every result feasible, never worse than its input, a local optimum of the move set.
 """
 import os
 import sys
@@ -91,9 +93,11 @@ class ACO(_CvrpACO):
     # ------------------------------------------------------------------ cvrp_nls/aco.py:114-126, 443-448
     @torch.no_grad()
     def multiple_swap_star(self, paths, indexes=None, disturb=10):
-        """Improve the ants' solutions (all, or the columns `indexes`) in place and return `paths`
-        ([L, A] int64; a longer buffer is returned if a column does not end with two depots to spare)."""
-        limit = 100000 if self.inference else max(self.problem_size, 50)
+        """Improve the ants' solutions (all, or the columns `indexes`) in place and return `paths` ([L, A] int64).
+        The reference's `count` (cvrp_nls/aco.py:443-448: limit / disturb / limit) bounds LOOPS of HGS's LocalSearch::run
+        (LocalSearch.cpp:17: up to count + 1 passes over all nodes, each applying many moves), not moves: the searches on
+        the distances run until no move improves, the perturbation on the heuristic-derived matrix applies `disturb` moves."""
+        limit = 100000
         sel = paths if indexes is None else paths[:, indexes]
         work = sel.contiguous().unsqueeze(0).clone()
         dist = self.distances.detach().float().contiguous()

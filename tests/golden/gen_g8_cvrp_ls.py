@@ -49,7 +49,7 @@ def as_column(routes, length):
 
 
 def main():
-    for n, A in ((20, 12), (50, 12), (100, 10)):
+    for n, A in ((20, 24), (50, 24), (100, 16)):
         torch.manual_seed(1000 + n)
         np.random.seed(n)
         demands, distances, positions = ref_utils.gen_instance(n, "cpu", True)          # float64, as the reference keeps them
