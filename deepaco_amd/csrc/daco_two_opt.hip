@@ -345,7 +345,7 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   __syncthreads();
   // tabs (daco_two_opt_auto): the neighbour tables' ranks of the tour's edges, summed = the number of list entries the
   // candidate-list kernel would walk per sweep (x 1/2 when one list serves both sides).  It is kept up to date move by
-  // move -- a reversal changes the ranks of edges p-1 and q only, the inner edges swap sides -- and the tour is handed
+  // move (symmetric matrix: two edges change; otherwise rebuilt per sweep) and the tour is handed
   // back (the loop below ends, the state word stays unfinished) once it has fallen under w_exit.
   const uint16_t *rk = tabs ? nbr_rk(tabs + (size_t)b * tab_stride, n) : nullptr;
   const uint16_t *rkT = tabs ? nbr_rk(tabsT + (size_t)b * tab_stride, n) : nullptr;
@@ -390,6 +390,17 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
   const long stop_at = state ? min(max_iterations, it + (long)budget) : max_iterations;
   bool ended = false;
   while (it < stop_at) {
+    if (tabs && tabs != tabsT && !first) {
+      // non-symmetric matrix: the inner edges of a reversed segment change their ranks too (rank_sum(y, x) != rank_sum(x, y)),
+      // so the two-edge update below would drift -- the sum is rebuilt from the records instead (n / NT gathers per thread)
+      if (tid == 0) cnt[2] = 0;
+      __syncthreads();
+      int w = 0;
+      for (int k = tid; k < n; k += NT) w += rank_sum(pe[k].x & 0xFFFF, (unsigned)pe[k].x >> 16);
+      for (int o = 32; o >= 1; o >>= 1) w += __shfl_xor(w, o);
+      if (lane == 0) atomicAdd(&cnt[2], w);
+      __syncthreads();
+    }
     if (tabs && (long)cnt[2] < (long)w_exit * w_scale) break;         // uniform (cnt[2] was last written before the previous barrier)
     const int blo = first ? 1 : p, bhi = first ? n - 1 : min(q + 2, n - 1);       // block rows [blo, bhi)
     // (the rows below the block were classified while the previous move was applied: lists and counts are ready)
@@ -526,7 +537,8 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     // ---- apply the move and, in the same phase, classify the rows below the block for the next sweep: recompute in
     // full (cached minimiser inside the changed range) or patch.  (pe was last read before the previous barrier.)
     const int half = (q - p + 1) >> 1;
-    if (tabs && tid == 0) {
+    if (tabs && tabs == tabsT && tid == 0) {
+      // symmetric matrix: a reversal changes the ranks of edges p-1 and q only, the inner edges swap sides
       // (thread 0 owns the swap of positions p and q below; t[p-1] and t[q+1] are not written in this phase)
       const int a = pe[p - 1].x & 0xFFFF, bq = pe[p].x & 0xFFFF, c = pe[q].x & 0xFFFF, dn = pe[q + 1 < n ? q + 1 : 0].x & 0xFFFF;
       atomicAdd(&cnt[2], rank_sum(a, c) + rank_sum(bq, dn) - rank_sum(a, bq) - rank_sum(c, dn));

@@ -182,6 +182,10 @@ class _GnnTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gheu, _gstats):
+        if ctx.ws is None:
+            raise RuntimeError("Net (HIP training path): the saved activations of this forward were already consumed by a "
+                               "backward pass -- backward through the same forward a second time is not supported "
+                               "(run the forward again, or set Net.train_backend = 'torch')")
         flat, x, attr, src, dst, rowptr, heu = ctx.saved_tensors
         n, E = x.shape[0], src.numel()
         L = _lib.lib()
@@ -223,12 +227,18 @@ class Net(nn.Module):
         if not x.is_cuda:
             raise _lib.DacoError("deepaco_amd.Net runs on a HIP device only (got CPU tensors)")
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self.training and self.train_backend == "hip":
+        if self.training and self.train_backend == "hip" and self._hip_train_supported():
             return self.forward_train_hip(pyg)
         if self.training or needs_graph:
             emb = self.emb_net(x, edge_index, edge_attr)
             return self.par_net_heu(emb)
         return self.forward_hip(pyg)
+
+    def _hip_train_supported(self):
+        """The training kernels implement BatchNorm1d's default bookkeeping (running statistics tracked, a numeric momentum);
+        other configurations (momentum=None: cumulative average; track_running_stats=False) go through the torch ops."""
+        return all(bn.module.track_running_stats and bn.module.momentum is not None and bn.module.running_mean is not None
+                   for bn in list(self.emb_net.v_bns) + list(self.emb_net.e_bns))
 
     def freeze_gnn(self):
         for param in self.emb_net.parameters():
