@@ -1,9 +1,10 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3k
-timeout 600 python -m pytest tests/test_gpu_07_net.py -x -q -k "fused or batched_forward or eval_hip" 2>&1 | tail -3 > gpurun_out/r3k/log.txt
-timeout 300 python tools/measure_configs.py gnn 2>/dev/null | python -c "
-import sys,json
-j=json.loads(sys.stdin.read())
-for s in j['sizes']: print(s['n'], 'batch64 ms', round(s['hip_batch64_ms'],3))" >> gpurun_out/r3k/log.txt
-cat gpurun_out/r3k/log.txt
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r3o
+mkdir -p $O
+(cd $R && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python bench.py --no-cpu --no-extras --min-seconds 0 > $O/bench_profiled.log 2>&1)
+cp $O/stats/p_kernel_stats.csv $O/kernel_stats_bench_default.csv
+find $O -name "*.db" -delete
+grep "^{" $O/bench_profiled.log | cut -c1-600
+head -5 $O/kernel_stats_bench_default.csv
