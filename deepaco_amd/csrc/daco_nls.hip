@@ -67,6 +67,10 @@ __device__ inline uint32_t nls_wave_scan_u32(uint32_t v) {
   return (uint32_t)x;
 }
 
+// row * n + column with the 24-bit multiplier (n <= 1024: every index is below 2^21; v_mad_u32_u24 runs at full rate, the 32-bit
+// v_mul_lo_u32 / v_mad_u64_u32 the compiler picks otherwise at a quarter of it -- four of them per walked entry)
+__device__ inline uint32_t nls_idx(uint32_t row, uint32_t n, uint32_t col) { return __umul24(row, n) + col; }
+
 // loads at 32-bit byte offsets from a wave-uniform base (n <= 1024: every table is below 2^24 bytes)
 template <typename T>
 __device__ inline T nls_ld(const T *base, uint32_t idx) {
@@ -113,7 +117,7 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
   uint16_t *t = L.t, *pos = L.pos, *rA = L.rA, *rB = L.rB;
   auto refresh_edge = [&](int m) {
     const int x = t[m], y = t[m + 1];
-    const uint32_t xy = (uint32_t)x * un + (uint32_t)y, yx = (uint32_t)y * un + (uint32_t)x;
+    const uint32_t xy = nls_idx((uint32_t)x, un, (uint32_t)y), yx = nls_idx((uint32_t)y, un, (uint32_t)x);
     const float e = nls_ld(M.d, xy);                          // three independent loads, one trip to memory
     const uint16_t ra = nls_ld(M.rk, xy), rb = nls_ld(M.rkT, yx);
     __builtin_amdgcn_sched_barrier(0);
@@ -213,13 +217,14 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
           const uint32_t m = lo[j], k = ww[j];
           mm[j] = m;
           if (SYM) {
-            en[j] = nls_ld(M.nb, (uint32_t)t[m] * un + k);
+            en[j] = nls_ld(M.nb, nls_idx((uint32_t)t[m], un, k));
             lo[j] = k;
           } else {
             const int2 r1 = rec[m];
             const uint32_t ca = m + 3 <= un ? rA[m] : 0;
             const bool side_a = k < ca;
-            en[j] = nls_ld(side_a ? M.nb : M.nbT, side_a ? (uint32_t)(r1.x & 0xffff) * un + k : ((uint32_t)r1.x >> 16) * un + (k - ca));
+            // (one multiply: the row is selected first, then row * n + entry)
+            en[j] = nls_ld(side_a ? M.nb : M.nbT, nls_idx(side_a ? (uint32_t)(r1.x & 0xffff) : (uint32_t)r1.x >> 16, un, side_a ? k : k - ca));
             lo[j] = side_a;
           }
         }
@@ -238,8 +243,8 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
             const uint32_t e1 = side_a ? m : (side_b ? pw - 1 : 0), e2 = side_a ? pw : (side_b ? m - 1 : 0);
             const int2 r1 = rec[e1], r2 = rec[e2];
             c[j] = __int_as_float(r1.y); ej[j] = __int_as_float(r2.y);
-            ga[j] = side_a ? ((uint32_t)r1.x >> 16) * un + ((uint32_t)r2.x >> 16)
-                           : (uint32_t)(r1.x & 0xffff) * un + (uint32_t)(r2.x & 0xffff);
+            ga[j] = nls_idx(side_a ? (uint32_t)r1.x >> 16 : (uint32_t)(r1.x & 0xffff), un,
+                            side_a ? (uint32_t)r2.x >> 16 : (uint32_t)(r2.x & 0xffff));
             lo[j] = side_a ? (((m + 1) << 16) | pw) : ((pw << 16) | (m - 1));
           } else {
             const bool side_a = lo[j] != 0;
@@ -249,8 +254,8 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
             const uint32_t e1 = side_a ? m : (pw >= 1 ? pw - 1 : 0), e2 = side_a ? pw : m;
             const int2 r1 = rec[e1], r2 = rec[e2];
             c[j] = __int_as_float(r1.y); ej[j] = __int_as_float(r2.y);
-            ga[j] = side_a ? ((uint32_t)r1.x >> 16) * un + ((uint32_t)r2.x >> 16)
-                           : (uint32_t)(r1.x & 0xffff) * un + (uint32_t)(r2.x & 0xffff);
+            ga[j] = nls_idx(side_a ? (uint32_t)r1.x >> 16 : (uint32_t)(r1.x & 0xffff), un,
+                            side_a ? (uint32_t)r2.x >> 16 : (uint32_t)(r2.x & 0xffff));
             lo[j] = side_a ? (((m + 1) << 16) | pw) : ((pw << 16) | m);
           }
         }
@@ -420,14 +425,15 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
                      (const unsigned char *)tables, (const unsigned char *)tables_T, hdist, hdist_bstride,                     \
                      (const unsigned char *)htables, (const unsigned char *)htables_T, nbr_instance_bytes(n), tours,          \
                      max_iterations, T_nls, T_p, sweeps, costs, counters, prof)
-  int group = 2;
+  int group = 3;                                            // (measured on config 3: 1 / 2 / 3 / 4 entries -> 58.9 / 48.4 / 45.8 / 50.8 ms)
   if (const char *ev = getenv("DACO_NLS_GROUP")) group = atoi(ev);
   if (nt >= 1024) DACO_NLS_LAUNCH(1024, 2, 2);
   else if (nt >= 512) DACO_NLS_LAUNCH(512, 3, 2);
   else if (n + 1 > 512) DACO_NLS_LAUNCH(256, 5, 2);
   else if (group <= 1) DACO_NLS_LAUNCH(256, 2, 1);
   else if (group >= 4) DACO_NLS_LAUNCH(256, 2, 4);
-  else DACO_NLS_LAUNCH(256, 2, 2);
+  else if (group == 2) DACO_NLS_LAUNCH(256, 2, 2);
+  else DACO_NLS_LAUNCH(256, 2, 3);
 #undef DACO_NLS_LAUNCH
   hipError_t e = hipGetLastError();
   if (prof) {

@@ -61,7 +61,7 @@ while time.time() < t_end:
     for kernel in ("nbr", "auto", "cached"):
         os.environ["DACO_TWO_OPT_WIDE"] = str(int(rng.integers(0, 2)))
         os.environ["DACO_NLS_THREADS"] = str(rng.choice([256, 512, 1024]))
-        os.environ["DACO_NLS_GROUP"] = str(rng.choice([1, 2, 4]))
+        os.environ["DACO_NLS_GROUP"] = str(rng.choice([1, 2, 3, 4]))
         if kernel == "auto" and rng.random() < 0.5:
             sw = int(rng.integers(1, n * n))
             os.environ["DACO_TWO_OPT_SWITCH"], os.environ["DACO_TWO_OPT_BACK"] = str(sw), str(int(rng.integers(0, sw + 1)))
@@ -81,7 +81,7 @@ while time.time() < t_end:
         T_nls, T_p = int(rng.integers(0, 4)), int(rng.integers(1, 8))
         cap = int(min(maxit, 200))
         os.environ["DACO_NLS_THREADS"] = str(rng.choice([256, 512, 1024]))
-        os.environ["DACO_NLS_GROUP"] = str(rng.choice([1, 2, 4]))
+        os.environ["DACO_NLS_GROUP"] = str(rng.choice([1, 2, 3, 4]))
         try:
             a = engine.nls_(dd, hd, tours, cap, T_nls=T_nls, T_p=T_p, tables=tabs, heuristic_tables=th, fused=False, want_costs=True)
             b = engine.nls_(dd, hd, tours, cap, T_nls=T_nls, T_p=T_p, tables=tabs, heuristic_tables=th, fused=True, want_costs=True)
