@@ -654,7 +654,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to
 // DACO_SCAN16_MAX_N nodes, two up to DACO_SCAN32_MAX_N, one above (the oracle restates the rule)
-constexpr int DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
+constexpr int DACO_SCAN8_MAX_N = 128, DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
+// eight ants per wavefront up to DACO_SCAN8_MAX_N nodes (DACO_SCAN_LAYOUT=16: measurement knob, four per wavefront for every n <= 256)
+inline int scan8_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 16) ? 0 : DACO_SCAN8_MAX_N; return v; }
 // TSP: the two-ants-per-wavefront kernel serves n <= 1024 (DACO_SCAN_LAYOUT=64: measurement knob, one ant per wavefront above 512)
 inline int tsp_scan32_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 64) ? 512 : 1024; return v; }
 // DACO_SCAN_LAYOUT=16 (measurement knob): four ants per wavefront up to n = 512 (TSP)
@@ -662,7 +664,7 @@ inline int scan16_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && 
 // daco_tsp_scan32.hip: TSP / CVRP scan draw with two ants per wavefront
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
 hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
-// daco_scan16.hip: four ants per wavefront (n <= 128)
+// daco_scan16.hip: four (n <= 256) or eight (n <= 128) ants per wavefront
 hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s);
 hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s);
 

@@ -15,75 +15,121 @@
 //     an epilogue (128-byte runs of 16 ants).
 // Draw semantics: the scan specification of DESIGN.md section 4 with 16 lanes; the GPU tests hold it bit-exact
 // against the CPU restatement of that specification.
+// Round 3: the kernel is a template over LPA, the lanes per ant.  LPA = 8 (EIGHT ants per wavefront, candidate k in lane
+// (k/4) % 8 of its group, chunk k/32, up to 16 slots per lane) serves n <= 128: at TSP-100 / CVRP-100 a row is 400 bytes and the
+// step is all per-step overhead (scan, search, selects: ~65 VALU instructions per wave-step whatever the row length), so
+// sharing it between eight ants instead of four halves the instructions per ant-step.  Two 8-lane groups share a 16-lane DPP
+// row: the row scan masks the steps that would cross the group boundary, S comes from two row broadcasts and a select, the
+// step's uniform from the LDS crossbar (ds_bpermute, issued at the top of the step), the choice reaches the group through a
+// quad / half-mirror OR butterfly.
 #include "daco_sample_kernel.h"
 
 namespace daco {
 
 constexpr int FCMP16_OGT = 2, FCMP16_OGE = 3;
 
-// inclusive add-scan inside each 16-lane row (Kogge-Stone, DPP row_shr)
-__device__ inline float row_scan_add(float x) {
-  x = x + dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x);
-  x = x + dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x);
-  x = x + dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x);
-  x = x + dpp_f<DPP_ROW_SHR(8), 0xF, true>(0.0f, x);
+// inclusive add-scan inside each group of LPA lanes (Kogge-Stone, DPP row_shr).  LPA = 8: lanes 8..15 of a DPP row are a
+// group of their own -- a step of d lanes adds +0.0f where it would reach across the boundary (s < d), as the specification
+// (oracle: lane_scan restricted to the first 8 lanes of a row) has it
+template <int LPA>
+__device__ inline float group_scan_add(float x, int s) {
+  if constexpr (LPA == 16) {
+    x = x + dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x);
+    x = x + dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x);
+    x = x + dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x);
+    x = x + dpp_f<DPP_ROW_SHR(8), 0xF, true>(0.0f, x);
+  } else {
+    float t = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x); x = x + (s >= 1 ? t : 0.0f);
+    t = dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x); x = x + (s >= 2 ? t : 0.0f);
+    t = dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x); x = x + (s >= 4 ? t : 0.0f);
+  }
   return x;
 }
 // lane N of each row to all lanes of the row (gfx90a+ DPP row_newbcast)
 template <int N> __device__ inline float row_bcast(float x) { return dpp_f<0x150 + N, 0xF, false>(x, x); }
 template <int N> __device__ inline int row_ror(int x) { return dpp_i<0x120 + N, 0xF, false>(x, x); }
-// of the lanes set in m, the first one of every 16-lane row: per 16-bit field x, x & ~((x | 0x8000) - 1)
-__device__ inline uint64_t row_first(uint64_t m) {
-  return m & ~((m | 0x8000800080008000ull) - 0x0001000100010001ull);
+// of the lanes set in m, the first one of every group of LPA lanes: per LPA-bit field x, x & ~((x | top) - 1)
+template <int LPA>
+__device__ inline uint64_t group_first(uint64_t m) {
+  constexpr uint64_t TOP = LPA == 16 ? 0x8000800080008000ull : 0x8080808080808080ull;
+  constexpr uint64_t ONE = LPA == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;
+  return m & ~((m | TOP) - ONE);
+}
+// last lane of the group to all of its lanes
+template <int LPA>
+__device__ inline float group_bcast_last(float x, int lane) {
+  if constexpr (LPA == 16) return row_bcast<15>(x);
+  const float lo = row_bcast<7>(x), hi = row_bcast<15>(x);
+  return (lane & 8) ? hi : lo;
+}
+// OR over the lanes of the group, in every lane
+template <int LPA>
+__device__ inline int group_or(int x) {
+  if constexpr (LPA == 16) {
+    x |= row_ror<1>(x); x |= row_ror<2>(x); x |= row_ror<4>(x); x |= row_ror<8>(x);
+  } else {
+    x |= dpp_i<0xB1 /* quad_perm [1,0,3,2] */, 0xF, false>(x, x);
+    x |= dpp_i<0x4E /* quad_perm [2,3,0,1] */, 0xF, false>(x, x);
+    x |= dpp_i<0x141 /* row_half_mirror */, 0xF, false>(x, x);
+  }
+  return x;
 }
 
 // CH: chunks of 64 candidates (n <= 64 * CH; CH <= 4 in production, TSP up to 8 = n <= 512 as a measured alternative
 // to the two-ants-per-wavefront kernel).
-template <int CH, bool LOGP, bool CVRP>
+template <int LPA, int CH, bool LOGP, bool CVRP>
 __global__ void __launch_bounds__(256)
 scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) {
+  static_assert(LPA == 16 || LPA == 8, "lanes per ant");
+  constexpr int APW = 64 / LPA, APB = 4 * APW;          // ants per wavefront / per workgroup
   constexpr int NJ = CH * 4;                            // candidates per lane
   constexpr int NG = (NJ + 7) / 8;                      // 16-byte flag groups per lane
-  constexpr int ROWF = CH * 64;                         // padded row length of this layout
-  constexpr int FL = CH <= 4 ? 256 : 512;               // flag / inverse-table entries per ant
+  constexpr int ROWF = CH * LPA * 4;                    // padded row length of this layout
+  constexpr int GS = LPA * 8;                           // flags of one 16-byte group across the ant's lanes
+  constexpr int FL = (CH <= 4 ? 2 : 4) * GS;            // flag / inverse-table entries per ant (>= n)
+  constexpr int CB = LPA * 16;                          // bytes of a row chunk
   static_assert(!CVRP || CH <= 4, "CVRP: n <= 256 (hub bitmap, demand row)");
+  static_assert(LPA == 16 || CH <= 4, "eight ants per wavefront: n <= 128");
   // open[ant][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited, else 0.0; slot
-  // j = c*4 + v of lane s is node c*64 + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
-  __shared__ __attribute__((aligned(16))) _Float16 open_flags[16][FL];
-  __shared__ __attribute__((aligned(16))) float dstage[4][4][64];    // epilogue: edge lengths of one 64-step chunk
+  // j = c*4 + v of lane s is node c*(4 LPA) + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
+  __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];
+  __shared__ __attribute__((aligned(16))) float dstage[4][APW][64];  // epilogue: edge lengths of one 64-step chunk
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
-  __shared__ uint32_t hub_s[16][8];                     // CVRP: per ant, set of nodes that follow the depot (n <= 256)
-  __shared__ int len_s[16];                             // CVRP: rows used by each ant (0: slot holds no ant)
-  extern __shared__ __attribute__((aligned(16))) uint16_t tour_s[];   // [16][TL]
+  __shared__ uint32_t hub_s[APB][8];                    // CVRP: per ant, set of nodes that follow the depot (n <= 256)
+  __shared__ int len_s[APB];                            // CVRP: rows used by each ant (0: slot holds no ant)
+  extern __shared__ __attribute__((aligned(16))) uint16_t tour_s[];   // [APB][TL]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int q = lane >> 4, s = lane & 15;
+  const int q = lane / LPA, s = lane & (LPA - 1);
   const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bpi = (p.A + 15) >> 4;                      // workgroups per instance (16 ants each)
+  const int bpi = (p.A + APB - 1) / APB;                // workgroups per instance (APB ants each)
   const int b = w / bpi;
-  const int abase = (w - b * bpi) * 16;                 // first ant of the workgroup
-  const int a0 = abase + wave * 4;                      // ants a0 .. a0+3, one per row
+  const int abase = (w - b * bpi) * APB;                // first ant of the workgroup
+  const int a0 = abase + wave * APW;                    // ants a0 .. a0+APW-1, one per group of LPA lanes
   const int n = p.n, A = p.A, ld = p.ld;
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   if constexpr (CVRP) {
     for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
-    if (threadIdx.x < 16 * 8) hub_s[threadIdx.x >> 3][threadIdx.x & 7] = 0u;
-    if (threadIdx.x < 16) len_s[threadIdx.x] = 0;
+    if (threadIdx.x < APB * 8) hub_s[threadIdx.x >> 3][threadIdx.x & 7] = 0u;
+    if (threadIdx.x < APB) len_s[threadIdx.x] = 0;
     __syncthreads();
   }
   const bool active = a0 < A;                           // (a wave without ants still joins the epilogue's barriers)
-  // A not a multiple of 4: the spare rows build ant A-1 again (same counters, same tour; their copy is not written)
+  // A not a multiple of APW: the spare groups build ant A-1 again (same counters, same tour; their copy is not written)
   const int a = a0 + q < A ? a0 + q : A - 1;
-  const uint64_t LEAD = 0x0001000100010001ull;          // lane 0 of each row
+  const uint64_t LEAD = LPA == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;      // lane 0 of each group
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
   const int rows = CVRP ? p.Lmax : n;                   // rows of paths for one instance
   float *logp_a = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_a = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
-  _Float16 *fl = open_flags[wave * 4 + q];
-  uint16_t *tour = tour_s + (size_t)(wave * 4 + q) * TL;
-  // flag index of node k: group (k>>7), lane (k>>2)&15, element ((k>>6)&1)*4 + (k&3)
-  auto flag_index = [](int k) { return ((k >> 7) << 7) | (((k >> 2) & 15) << 3) | (((k >> 6) & 1) << 2) | (k & 3); };
+  _Float16 *fl = open_flags[wave * APW + q];
+  uint16_t *tour = tour_s + (size_t)(wave * APW + q) * TL;
+  // flag index of node k (chunk c = k / (4 LPA)): 16-byte group c >> 1, lane (k>>2) % LPA, element (c & 1)*4 + (k&3)
+  auto flag_index = [](int k) {
+    const int c = k / (LPA * 4);
+    return (c >> 1) * GS + (((k >> 2) & (LPA - 1)) << 3) + ((c & 1) << 2) + (k & 3);
+  };
   uint64_t feasible = ~0ull;
   bool finished = false;
   int len = 1;
@@ -93,9 +139,9 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     {
       const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
-      for (int g = 0; g < FL / 128; ++g) *(f16x8 *)(fl + g * 128 + s * 8) = ones;
+      for (int g = 0; g < FL / GS; ++g) *(f16x8 *)(fl + g * GS + s * 8) = ones;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) { if constexpr (CVRP) dm[c] = *(const float4 *)(dem_s + (c * 16 + s) * 4); else dm[c] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      for (int c = 0; c < CH; ++c) { if constexpr (CVRP) dm[c] = *(const float4 *)(dem_s + (c * LPA + s) * 4); else dm[c] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
     int prev;
     if constexpr (CVRP) prev = 0;
@@ -114,8 +160,9 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     int remaining = n - 1;
     float used = CVRP ? 0.0f + dem_s[0] : 0.0f;
     finished = CVRP ? remaining == 0 : false;
-    u32x4 ublk = {0, 0, 0, 0};                          // 64 cached uniforms per ant
-    float ucur = 0.0f;                                  // rotated once per step: lane 15 holds the current step's uniform
+    u32x4 ublk = {0, 0, 0, 0};                          // 4 LPA cached uniforms per ant
+    float ucur = 0.0f;                                  // LPA = 16: rotated once per step, lane 15 holds the current step's uniform
+    const int ubase = (lane & ~(LPA - 1)) << 2;         // LPA = 8: byte address of the group's lane 0 for ds_bpermute
     uint64_t act = CVRP ? __builtin_amdgcn_ballot_w64(!finished) : ~0ull;     // lanes of the rows still building
     const int tend = CVRP ? p.Lmax : n;
     const float *uin = (!CVRP && p.noise) ? p.noise + (size_t)b * (n - 1) * A + a : nullptr;
@@ -126,19 +173,30 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       float4 row[CH];
       f16x8 fo[NG];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) row[c] = *(const float4 *)(Pb + voff + c * 256);
-      // uniform of step t: component (t>>4)&3 of Philox block ((t>>6)<<4) + (t&15).  Lane s computes the one of step
-      // (t & ~15) + 15 - s; after every step the row is rotated by one lane, so lane 15 always holds the current one
-      if ((t & 15) == 0 || t == 1) {
-        if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 6) << 4) + (15 - s)));
-        ucur = u01(comp(ublk, (t >> 4) & 3));
-        if (t == 1) ucur = __int_as_float(row_ror<1>(__float_as_int(ucur)));    // step 1 starts at element 1 of the block
+      for (int c = 0; c < CH; ++c) row[c] = *(const float4 *)(Pb + voff + c * CB);
+      float u;
+      if constexpr (LPA == 16) {
+        // uniform of step t: component (t>>4)&3 of Philox block ((t>>6)<<4) + (t&15).  Lane s computes the one of step
+        // (t & ~15) + 15 - s; after every step the row is rotated by one lane, so lane 15 always holds the current one
+        if ((t & 15) == 0 || t == 1) {
+          if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 6) << 4) + (15 - s)));
+          ucur = u01(comp(ublk, (t >> 4) & 3));
+          if (t == 1) ucur = __int_as_float(row_ror<1>(__float_as_int(ucur)));    // step 1 starts at element 1 of the block
+        }
+        u = row_bcast<15>(ucur);
+        ucur = __int_as_float(row_ror<1>(__float_as_int(ucur)));
+      } else {
+        // uniform of step t: component (t>>3)&3 of Philox block ((t>>5)<<3) + (t&7).  Lane s of the group holds the one of
+        // step (t & ~7) + s; the group reads lane t & 7 through the LDS crossbar (no VALU slot; issued here, used after the scan)
+        if ((t & 7) == 0 || t == 1) {
+          if ((t & 31) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 5) << 3) + s));
+          ucur = u01(comp(ublk, (t >> 3) & 3));
+        }
+        u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase + ((t & 7) << 2), __float_as_int(ucur)));
       }
-      float u = row_bcast<15>(ucur);
-      ucur = __int_as_float(row_ror<1>(__float_as_int(ucur)));
       if constexpr (!CVRP) { if (uin) u = uin[(size_t)(t - 1) * A]; }       // injected uniform stream (tests): [B][n-1][A]
 #pragma unroll
-      for (int g = 0; g < NG; ++g) fo[g] = *(const f16x8 *)(fl + g * 128 + s * 8);
+      for (int g = 0; g < NG; ++g) fo[g] = *(const f16x8 *)(fl + g * GS + s * 8);
 
       // ---- the lane's running sums in slot order (closed slots add p*0 = +0.0f; the product with a 0/1 factor is exact)
       const float rem = CVRP ? p.capacity - used : 0.0f;
@@ -164,25 +222,26 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       }
       // ---- level 1: which lane
       const float part = acc;
-      const float incl = row_scan_add(part);
-      const float S = row_bcast<15>(incl);
+      const float incl = group_scan_add<LPA>(part, s);
+      const float S = group_bcast_last<LPA>(incl, lane);
       const float r = fmaxf(u * S, 1.401298464e-45f);     // keep r > 0 if u*S underflows
       const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP16_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP16_OGT) & act;
       const uint64_t alive = __builtin_amdgcn_fcmpf(S, 0.0f, FCMP16_OGT);   // S > 0 <=> some open candidate has p > 0
       feasible &= alive | ~act;
       // ---- level 2 in every lane (only the chosen lane's result is used)
-      const float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
+      float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
+      if constexpr (LPA == 8) excl = s == 0 ? 0.0f : excl;      // (lane 8 of a DPP row starts a group)
       const float thr = fmaxf(r - excl, 1.401298464e-45f);
       int cnt = count_below32<NJ>(run, thr);
-      const bool mine = __builtin_amdgcn_inverse_ballot_w64(row_first(m));
+      const bool mine = __builtin_amdgcn_inverse_ballot_w64(group_first<LPA>(m));
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(mine && cnt >= NJ) != 0, 0)) {
         // rounding: no running sum reached thr -> the lane's last open candidate with p > 0 (rare: the row and the flags
         // are read again; "where the running sum reaches its final value" is not the same -- a term can be absorbed)
         int last = 0;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          const float4 rw = *(const float4 *)(Pb + voff + c * 256);
-          const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * 128 + s * 8);
+          const float4 rw = *(const float4 *)(Pb + voff + c * CB);
+          const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * GS + s * 8);
           const int e = (c & 1) * 4;
           const float rv[4] = {rw.x, rw.y, rw.z, rw.w};
           const float dv[4] = {dm[c].x, dm[c].y, dm[c].z, dm[c].w};
@@ -198,12 +257,11 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
         }
         cnt = cnt >= NJ ? last : cnt;
       }
-      const int node = ((cnt >> 2) << 6) | (s << 2) | (cnt & 3);
-      int x = mine ? node + 1 : 0;
-      x |= row_ror<1>(x); x |= row_ror<2>(x); x |= row_ror<4>(x); x |= row_ror<8>(x);
+      const int node = (cnt >> 2) * (LPA * 4) + (s << 2) + (cnt & 3);
+      int x = group_or<LPA>(mine ? node + 1 : 0);
       // a row without a winner (no feasible candidate: flagged, the reference raises; or finished) moves to node 0
       const int choice = x ? x - 1 : 0;
-      if (mine && (!CVRP || node != 0)) fl[((cnt >> 3) << 7) | (s << 3) | (cnt & 7)] = (_Float16)0.0f;   // visited (the CVRP depot stays open)
+      if (mine && (!CVRP || node != 0)) fl[(cnt >> 3) * GS + (s << 3) + (cnt & 7)] = (_Float16)0.0f;   // visited (the CVRP depot stays open)
       if constexpr (!CVRP) { if (s == 0 && !(S > 0.0f)) fl[flag_index(0)] = (_Float16)0.0f; }
 
       // ---- outputs: lane 0 of every row that is still building
@@ -232,26 +290,27 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
         prev = choice;
       }
     }
-    if constexpr (CVRP) { if (s == 0 && a0 + q < A) len_s[wave * 4 + q] = len; }
+    if constexpr (CVRP) { if (s == 0 && a0 + q < A) len_s[wave * APW + q] = len; }
   }
   if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
 
   // ------------------------------------------------------------------ epilogue: the workgroup's 16 tours leave LDS
   __syncthreads();
-  const int nant = A - abase < 16 ? A - abase : 16;      // ants of this workgroup (the last one may hold fewer)
-  const int k16 = threadIdx.x & 15;
+  const int nant = A - abase < APB ? A - abase : APB;     // ants of this workgroup (the last one may hold fewer)
+  const int k16 = threadIdx.x & (APB - 1);               // this thread's ant in the epilogue: APB lanes = one run per row
+  constexpr int TSTEP = 256 / APB;
   {
     // paths[b][t][abase + k]: 16 lanes = one 128-byte run per step row; CVRP pads a finished route with the depot
     int64_t *pb = p.paths + (size_t)b * rows * A + abase;
     if (k16 < nant) {
       const int lk = CVRP ? len_s[k16] : n;
-      for (int t = threadIdx.x >> 4; t < rows; t += 16) pb[(size_t)t * A + k16] = t < lk ? (int64_t)tour_s[(size_t)k16 * TL + t] : 0;
+      for (int t = threadIdx.x / APB; t < rows; t += TSTEP) pb[(size_t)t * A + k16] = t < lk ? (int64_t)tour_s[(size_t)k16 * TL + t] : 0;
       if constexpr (CVRP && LOGP) {
         // the reference steps every ant until the slowest one is done: a done ant keeps drawing the depot
         // (probability 1), so its log-prob column is padded with log(1-eps)
         float *lp = p.logp + (size_t)b * (rows - 1) * A + abase;
         const float lp1 = clamp_log(1.0f);
-        for (int t = threadIdx.x >> 4; t < rows; t += 16) if (t >= lk && t >= 1) lp[(size_t)(t - 1) * A + k16] = lp1;
+        for (int t = threadIdx.x / APB; t < rows; t += TSTEP) if (t >= lk && t >= 1) lp[(size_t)(t - 1) * A + k16] = lp1;
       }
     }
   }
@@ -270,16 +329,20 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     const float *dist_b = p.dist + (size_t)b * p.dist_bs;
     if (active) {
       int lmax = n;
-      if constexpr (CVRP) lmax = max(max(len_s[wave * 4], len_s[wave * 4 + 1]), max(len_s[wave * 4 + 2], len_s[wave * 4 + 3]));
-      const int myl = CVRP ? len_s[wave * 4 + q] : n;
+      if constexpr (CVRP) {
+        lmax = 0;
+#pragma unroll
+        for (int r4 = 0; r4 < APW; ++r4) lmax = max(lmax, len_s[wave * APW + r4]);
+      }
+      const int myl = CVRP ? len_s[wave * APW + q] : n;
       float cost = 0.0f;
       const float *mine_d = dstage[wave][q];
       for (int base = 1; base < lmax; base += 64) {
         const int t = base + lane;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const uint16_t *tr = tour_s + (size_t)(wave * 4 + r4) * TL;
-          const int lr = CVRP ? len_s[wave * 4 + r4] : n;
+        for (int r4 = 0; r4 < APW; ++r4) {
+          const uint16_t *tr = tour_s + (size_t)(wave * APW + r4) * TL;
+          const int lr = CVRP ? len_s[wave * APW + r4] : n;
           float dv = 0.0f;
           if (t < lr) dv = CVRP ? dist_b[(uint32_t)tr[t - 1] * (uint32_t)n + tr[t]] : dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]];
           dstage[wave][r4][lane] = dv;
@@ -306,12 +369,12 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     // never read -- the depot's successors are a SET, kept as a bitmap per ant).
     __syncthreads();
     uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(open_flags);
-    for (int e = threadIdx.x; e < 16 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+    for (int e = threadIdx.x; e < APB * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     if (k16 < nant) {
       const int lk = CVRP ? len_s[k16] : n;
       const uint16_t *tk = tour_s + (size_t)k16 * TL;
-      for (int t = threadIdx.x >> 4; t < lk; t += 16) {
+      for (int t = threadIdx.x / APB; t < lk; t += TSTEP) {
         const int v = tk[t];
         if (!CVRP || v != 0) inv[k16][v] = (uint16_t)t;
         if constexpr (CVRP) { if (t >= 1 && tk[t - 1] == 0 && v != 0) atomicOr(&hub_s[k16][v >> 5], 1u << (v & 31)); }
@@ -321,7 +384,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     uint32_t *nb = p.nbr + (size_t)b * n * A + abase;
     if (k16 < nant) {
       const uint16_t *tk = tour_s + (size_t)k16 * TL;
-      for (int node = threadIdx.x >> 4; node < n; node += 16) {
+      for (int node = threadIdx.x / APB; node < n; node += TSTEP) {
         const int t = inv[k16][node];
         if constexpr (CVRP) {
           if (node != 0) nb[(size_t)node * A + k16] = (uint32_t)tk[t + 1] << 16;
@@ -333,43 +396,59 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       if constexpr (CVRP) {
         const int W32 = (n + 31) >> 5;
         uint32_t *hub_a = p.hubmask + ((size_t)b * A + abase + k16) * W32;
-        for (int i = threadIdx.x >> 4; i < W32; i += 16) hub_a[i] = hub_s[k16][i];
+        for (int i = threadIdx.x / APB; i < W32; i += TSTEP) hub_a[i] = hub_s[k16][i];
       }
     }
   }
 }
 
-template <int CH, bool CVRP>
+template <int LPA, int CH, bool CVRP>
 static hipError_t launch16(const SampleParams &sp, bool logp, hipStream_t s) {
-  const int bpi = (sp.A + 15) / 16;
+  constexpr int APB = 4 * (64 / LPA);
+  const int bpi = (sp.A + APB - 1) / APB;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
   const int rows = CVRP ? sp.Lmax : sp.n;
   const int TL = (rows + 7) & ~7;
-  const size_t dyn = (size_t)16 * TL * sizeof(uint16_t);
-  if (logp) hipLaunchKernelGGL((scan16_kernel<CH, true, CVRP>), grid, block, dyn, s, sp, TL);
-  else hipLaunchKernelGGL((scan16_kernel<CH, false, CVRP>), grid, block, dyn, s, sp, TL);
+  const size_t dyn = (size_t)APB * TL * sizeof(uint16_t);
+  if (logp) hipLaunchKernelGGL((scan16_kernel<LPA, CH, true, CVRP>), grid, block, dyn, s, sp, TL);
+  else hipLaunchKernelGGL((scan16_kernel<LPA, CH, false, CVRP>), grid, block, dyn, s, sp, TL);
   return hipGetLastError();
 }
 
-// entries used by daco_tsp_sample / daco_cvrp_sample for n <= DACO_SCAN16_MAX_N in DACO_SCAN mode
+// entries used by daco_tsp_sample / daco_cvrp_sample for n <= DACO_SCAN16_MAX_N in DACO_SCAN mode: eight ants per wavefront up
+// to DACO_SCAN8_MAX_N nodes, four above (DACO_SCAN_LAYOUT=16: four for every n, the layout before round 3)
 hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
+  if (sp.n <= scan8_max_n())
+    switch ((sp.n + 31) / 32) {
+      case 1: return launch16<8, 1, false>(sp, logp, s);
+      case 2: return launch16<8, 2, false>(sp, logp, s);
+      case 3: return launch16<8, 3, false>(sp, logp, s);
+      default: return launch16<8, 4, false>(sp, logp, s);
+    }
   switch ((sp.n + 63) / 64) {
-    case 1: return launch16<1, false>(sp, logp, s);
-    case 2: return launch16<2, false>(sp, logp, s);
-    case 3: return launch16<3, false>(sp, logp, s);
-    case 4: return launch16<4, false>(sp, logp, s);
-    case 5: return launch16<5, false>(sp, logp, s);
-    case 6: return launch16<6, false>(sp, logp, s);
-    case 7: return launch16<7, false>(sp, logp, s);
-    default: return launch16<8, false>(sp, logp, s);
+    case 1: return launch16<16, 1, false>(sp, logp, s);
+    case 2: return launch16<16, 2, false>(sp, logp, s);
+    case 3: return launch16<16, 3, false>(sp, logp, s);
+    case 4: return launch16<16, 4, false>(sp, logp, s);
+    case 5: return launch16<16, 5, false>(sp, logp, s);
+    case 6: return launch16<16, 6, false>(sp, logp, s);
+    case 7: return launch16<16, 7, false>(sp, logp, s);
+    default: return launch16<16, 8, false>(sp, logp, s);
   }
 }
 hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
+  if (sp.n <= scan8_max_n())
+    switch ((sp.n + 31) / 32) {
+      case 1: return launch16<8, 1, true>(sp, logp, s);
+      case 2: return launch16<8, 2, true>(sp, logp, s);
+      case 3: return launch16<8, 3, true>(sp, logp, s);
+      default: return launch16<8, 4, true>(sp, logp, s);
+    }
   switch ((sp.n + 63) / 64) {
-    case 1: return launch16<1, true>(sp, logp, s);
-    case 2: return launch16<2, true>(sp, logp, s);
-    case 3: return launch16<3, true>(sp, logp, s);
-    default: return launch16<4, true>(sp, logp, s);
+    case 1: return launch16<16, 1, true>(sp, logp, s);
+    case 2: return launch16<16, 2, true>(sp, logp, s);
+    case 3: return launch16<16, 3, true>(sp, logp, s);
+    default: return launch16<16, 4, true>(sp, logp, s);
   }
 }
 

@@ -338,15 +338,15 @@ def test_scan_kernels_reproduce_reference_roulette_routes(mode):
     assert np.array_equal(paths[0].cpu().numpy(), rp)
 
 
-@pytest.mark.parametrize("n", [100, 300, 600])
+@pytest.mark.parametrize("n", [100, 200, 300, 600])
 def test_scan_kernels_reproduce_reference_roulette_routes_lane_order(n):
     """g6w: the reference's roulette on the instance relabelled by a layout's lane order (tests/golden/gen_g6_wide.py), rows
-    with exact zeros and a k-sparse row: the HIP scan kernels (four / two ants per wavefront; one ant per wavefront) fed the
+    with exact zeros and a k-sparse row: the HIP scan kernels (eight / four / two ants per wavefront; one ant per wavefront) fed the
     recorded uniforms build exactly the reference's routes."""
     from deepaco_amd import engine
     g = load_golden(f"g6w_roulette_n{n}")
     P = T(g["probmat"])[None]
-    for lanes, mode in (((16 if n <= 256 else 32), "scan"), (64, "scan_wave")):
+    for lanes, mode in (((8 if n <= 128 else 16 if n <= 256 else 32), "scan"), (64, "scan_wave")):
         u = torch.from_numpy(g[f"uniforms_l{lanes}"].T.copy()).to(dev())[None]          # [1][n-1][A]
         A = u.shape[2]
         paths, _, _, flags = engine.tsp_sample(P, torch.ones(1, n, n, device=dev()), A, mode=mode, fixed_start=0, noise=u)
@@ -362,7 +362,7 @@ def _layout_order(n, lanes):
     return np.argsort(key, kind="stable")
 
 
-@pytest.mark.parametrize("n,lanes", [(200, 16), (500, 32), (640, 32), (1100, 64)])
+@pytest.mark.parametrize("n,lanes", [(100, 8), (128, 8), (200, 16), (500, 32), (640, 32), (1100, 64)])
 def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
     """The benchmarked sampler against the LITERAL arithmetic of the reference's roulette (tsp_nls/aco.py:266-274:
     r = U * sum(prob_row * mask) in f64, subtract prob[k] one after the other until r <= 0), step by step along
@@ -379,7 +379,7 @@ def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
     u = torch.rand(1, n - 1, A, generator=g).clamp_(1e-7, 1 - 1e-7)
     paths, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", fixed_start=0, noise=u.to(dev()))
     assert int(flags.sum()) == 0
-    assert {16: n <= 256, 32: 256 < n <= 1024, 64: n > 1024}[lanes]
+    assert {8: n <= 128, 16: 128 < n <= 256, 32: 256 < n <= 1024, 64: n > 1024}[lanes]
     P = oracle.prob_matrix(tau[0].numpy(), eta[0].numpy())
     order = _layout_order(n, lanes)
     p = paths[0].cpu().numpy()

@@ -163,14 +163,14 @@ def test_scan_draw_with_injected_uniforms_is_the_reference_roulette(wave):
     assert np.array_equal(paths.T.astype(np.uint16), g["routes"])
 
 
-@pytest.mark.parametrize("n", [100, 300, 600])
+@pytest.mark.parametrize("n", [100, 200, 300, 600])
 def test_scan_draw_is_the_reference_roulette_where_lane_order_differs_from_index_order(n):
-    """g6w (tests/golden/gen_g6_wide.py): at n = 100 / 300 / 600 the layouts walk a row lane by lane, not in index order, so
+    """g6w (tests/golden/gen_g6_wide.py): at n = 100 / 200 / 300 / 600 the layouts walk a row lane by lane, not in index order, so
     the reference's `_inference_sample` was run on the instance RELABELLED by that order (its index order = the layout's
     lane order) and its routes mapped back.  The scan specification fed the same uniforms must give exactly those routes
-    -- rows with exact zeros and a k-sparse row included -- for the packed layouts (16 / 32 lanes) and the 64-lane one."""
+    -- rows with exact zeros and a k-sparse row included -- for the packed layouts (8 / 16 / 32 lanes) and the 64-lane one."""
     g = load_golden(f"g6w_roulette_n{n}")
-    for lanes in ((16, 64) if n <= 256 else (32, 64)):
+    for lanes in ((8 if n <= 128 else 16 if n <= 256 else 32), 64):
         u = g[f"uniforms_l{lanes}"].T.copy()                       # [n-1][A] float32
         paths, _, rc = oracle.tsp_sample_scan_injected(g["probmat"], u, fixed_start=0, wave=(lanes == 64))
         assert rc == 0
