@@ -135,8 +135,8 @@ def bytes_per_tour(n, A, steps=None):
 
 def sampler_layout(n, sampler):
     """daco_tsp_sample's layout rule -> (kernel name, floats per fused row as the kernel streams it)."""
-    lanes = 64 if sampler != "scan" or n > 1024 else (8 if n <= 128 else 16 if n <= 256 else 32)
-    name = {8: "scan16_kernel", 16: "scan16_kernel", 32: "tsp_scan32_kernel", 64: "tsp_sample_kernel"}[lanes]
+    lanes = 64 if sampler != "scan" or n > 1024 else (4 if n <= 128 else 8 if n <= 256 else 32)
+    name = {4: "scan16_kernel", 8: "scan16_kernel", 32: "tsp_scan32_kernel", 64: "tsp_sample_kernel"}[lanes]
     if lanes < 64:
         row = (n + 4 * lanes - 1) // (4 * lanes) * (4 * lanes)
     else:

@@ -652,11 +652,19 @@ __device__ inline int count_below32(const float (&run)[32], float t) {
 }
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// layout rule of the scan draw (measured, tools/sweep_layouts.py): four ants per wavefront up to
-// DACO_SCAN16_MAX_N nodes, two up to DACO_SCAN32_MAX_N, one above (the oracle restates the rule)
-constexpr int DACO_SCAN8_MAX_N = 128, DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
-// eight ants per wavefront up to DACO_SCAN8_MAX_N nodes (DACO_SCAN_LAYOUT=16: measurement knob, four per wavefront for every n <= 256)
-inline int scan8_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 16) ? 0 : DACO_SCAN8_MAX_N; return v; }
+// layout rule of the scan draw (measured; the oracle restates it): sixteen ants per wavefront (4 lanes per ant) up to
+// DACO_SCAN4_MAX_N nodes, eight (8 lanes) up to DACO_SCAN16_MAX_N, two up to DACO_SCAN32_MAX_N (TSP: 1024), one above.
+// DACO_SCAN_LAYOUT = 4 | 8 | 16 (measurement knob): that many lanes per ant wherever the kernel supports it
+// (4: n <= 128; 8, 16: n <= 256; 16 for TSP: n <= 512), the default rule elsewhere
+constexpr int DACO_SCAN4_MAX_N = 128, DACO_SCAN16_MAX_N = 256, DACO_SCAN32_MAX_N = 512;
+inline int scan_layout_env() { static const int v = getenv("DACO_SCAN_LAYOUT") ? atoi(getenv("DACO_SCAN_LAYOUT")) : 0; return v; }
+inline int scan_small_lanes(int n) {
+  const int e = scan_layout_env();
+  if (e == 16) return 16;
+  if (e == 8 && n <= DACO_SCAN16_MAX_N) return 8;
+  if (e == 4 && n <= DACO_SCAN4_MAX_N) return 4;
+  return n <= DACO_SCAN4_MAX_N ? 4 : (n <= DACO_SCAN16_MAX_N ? 8 : 16);
+}
 // TSP: the two-ants-per-wavefront kernel serves n <= 1024 (DACO_SCAN_LAYOUT=64: measurement knob, one ant per wavefront above 512)
 inline int tsp_scan32_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 64) ? 512 : 1024; return v; }
 // DACO_SCAN_LAYOUT=16 (measurement knob): four ants per wavefront up to n = 512 (TSP)

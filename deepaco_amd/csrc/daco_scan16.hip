@@ -41,7 +41,7 @@ __device__ inline float group_scan_add(float x, int s) {
   } else {
     float t = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x); x = x + (s >= 1 ? t : 0.0f);
     t = dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x); x = x + (s >= 2 ? t : 0.0f);
-    t = dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x); x = x + (s >= 4 ? t : 0.0f);
+    if constexpr (LPA == 8) { t = dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x); x = x + (s >= 4 ? t : 0.0f); }
   }
   return x;
 }
@@ -51,14 +51,15 @@ template <int N> __device__ inline int row_ror(int x) { return dpp_i<0x120 + N, 
 // of the lanes set in m, the first one of every group of LPA lanes: per LPA-bit field x, x & ~((x | top) - 1)
 template <int LPA>
 __device__ inline uint64_t group_first(uint64_t m) {
-  constexpr uint64_t TOP = LPA == 16 ? 0x8000800080008000ull : 0x8080808080808080ull;
-  constexpr uint64_t ONE = LPA == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;
+  constexpr uint64_t TOP = LPA == 16 ? 0x8000800080008000ull : LPA == 8 ? 0x8080808080808080ull : 0x8888888888888888ull;
+  constexpr uint64_t ONE = LPA == 16 ? 0x0001000100010001ull : LPA == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
   return m & ~((m | TOP) - ONE);
 }
 // last lane of the group to all of its lanes
 template <int LPA>
 __device__ inline float group_bcast_last(float x, int lane) {
   if constexpr (LPA == 16) return row_bcast<15>(x);
+  if constexpr (LPA == 4) return dpp_f<0xFF /* quad_perm [3,3,3,3] */, 0xF, false>(x, x);
   const float lo = row_bcast<7>(x), hi = row_bcast<15>(x);
   return (lane & 8) ? hi : lo;
 }
@@ -70,7 +71,7 @@ __device__ inline int group_or(int x) {
   } else {
     x |= dpp_i<0xB1 /* quad_perm [1,0,3,2] */, 0xF, false>(x, x);
     x |= dpp_i<0x4E /* quad_perm [2,3,0,1] */, 0xF, false>(x, x);
-    x |= dpp_i<0x141 /* row_half_mirror */, 0xF, false>(x, x);
+    if constexpr (LPA == 8) x |= dpp_i<0x141 /* row_half_mirror */, 0xF, false>(x, x);
   }
   return x;
 }
@@ -80,20 +81,22 @@ __device__ inline int group_or(int x) {
 template <int LPA, int CH, bool LOGP, bool CVRP>
 __global__ void __launch_bounds__(256)
 scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) {
-  static_assert(LPA == 16 || LPA == 8, "lanes per ant");
+  static_assert(LPA == 16 || LPA == 8 || LPA == 4, "lanes per ant");
+  constexpr int LG = LPA == 16 ? 4 : LPA == 8 ? 3 : 2;
   constexpr int APW = 64 / LPA, APB = 4 * APW;          // ants per wavefront / per workgroup
   constexpr int NJ = CH * 4;                            // candidates per lane
   constexpr int NG = (NJ + 7) / 8;                      // 16-byte flag groups per lane
   constexpr int ROWF = CH * LPA * 4;                    // padded row length of this layout
   constexpr int GS = LPA * 8;                           // flags of one 16-byte group across the ant's lanes
-  constexpr int FL = (CH <= 4 ? 2 : 4) * GS;            // flag / inverse-table entries per ant (>= n)
+  constexpr int FL0 = (CH <= 4 ? 2 : 4) * GS;
+  constexpr int FL = FL0 < 128 ? 128 : FL0;             // flag / inverse-table entries per ant (>= n; >= 128: the edge staging below)
   constexpr int CB = LPA * 16;                          // bytes of a row chunk
-  static_assert(!CVRP || CH <= 4, "CVRP: n <= 256 (hub bitmap, demand row)");
-  static_assert(LPA == 16 || CH <= 4, "eight ants per wavefront: n <= 128");
+  static_assert(!CVRP || ROWF <= 256, "CVRP: n <= 256 (hub bitmap, demand row)");
+  static_assert(LPA == 16 || NJ <= 32, "eight / sixteen ants per wavefront: up to 32 candidates per lane");
+  constexpr bool DEM_REGS = LPA == 16;                  // CVRP: the lane's demands stay in registers / are read from LDS every step
   // open[ant][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited, else 0.0; slot
   // j = c*4 + v of lane s is node c*(4 LPA) + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
   __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];
-  __shared__ __attribute__((aligned(16))) float dstage[4][APW][64];  // epilogue: edge lengths of one 64-step chunk
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
   __shared__ uint32_t hub_s[APB][8];                    // CVRP: per ant, set of nodes that follow the depot (n <= 256)
   __shared__ int len_s[APB];                            // CVRP: rows used by each ant (0: slot holds no ant)
@@ -109,14 +112,14 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   if constexpr (CVRP) {
     for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
-    if (threadIdx.x < APB * 8) hub_s[threadIdx.x >> 3][threadIdx.x & 7] = 0u;
+    for (int k = threadIdx.x; k < APB * 8; k += 256) hub_s[k >> 3][k & 7] = 0u;
     if (threadIdx.x < APB) len_s[threadIdx.x] = 0;
     __syncthreads();
   }
   const bool active = a0 < A;                           // (a wave without ants still joins the epilogue's barriers)
   // A not a multiple of APW: the spare groups build ant A-1 again (same counters, same tour; their copy is not written)
   const int a = a0 + q < A ? a0 + q : A - 1;
-  const uint64_t LEAD = LPA == 16 ? 0x0001000100010001ull : 0x0101010101010101ull;      // lane 0 of each group
+  const uint64_t LEAD = LPA == 16 ? 0x0001000100010001ull : LPA == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;   // lane 0 of each group
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
@@ -135,13 +138,13 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   int len = 1;
 
   if (active) {
-    float4 dm[CH];
+    float4 dm[DEM_REGS ? CH : 1];
     {
       const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
       for (int g = 0; g < FL / GS; ++g) *(f16x8 *)(fl + g * GS + s * 8) = ones;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) { if constexpr (CVRP) dm[c] = *(const float4 *)(dem_s + (c * LPA + s) * 4); else dm[c] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      for (int c = 0; c < (DEM_REGS ? CH : 1); ++c) { if constexpr (CVRP && DEM_REGS) dm[c] = *(const float4 *)(dem_s + (c * LPA + s) * 4); else dm[c] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
     int prev;
     if constexpr (CVRP) prev = 0;
@@ -186,13 +189,13 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
         u = row_bcast<15>(ucur);
         ucur = __int_as_float(row_ror<1>(__float_as_int(ucur)));
       } else {
-        // uniform of step t: component (t>>3)&3 of Philox block ((t>>5)<<3) + (t&7).  Lane s of the group holds the one of
+        // uniform of step t (LPA = 8): component (t>>3)&3 of Philox block ((t>>5)<<3) + (t&7).  Lane s of the group holds the one of
         // step (t & ~7) + s; the group reads lane t & 7 through the LDS crossbar (no VALU slot; issued here, used after the scan)
-        if ((t & 7) == 0 || t == 1) {
-          if ((t & 31) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 5) << 3) + s));
-          ucur = u01(comp(ublk, (t >> 3) & 3));
+        if ((t & (LPA - 1)) == 0 || t == 1) {
+          if ((t & (4 * LPA - 1)) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> (LG + 2)) << LG) + s));
+          ucur = u01(comp(ublk, (t >> LG) & 3));
         }
-        u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase + ((t & 7) << 2), __float_as_int(ucur)));
+        u = __int_as_float(__builtin_amdgcn_ds_bpermute(ubase + ((t & (LPA - 1)) << 2), __float_as_int(ucur)));
       }
       if constexpr (!CVRP) { if (uin) u = uin[(size_t)(t - 1) * A]; }       // injected uniform stream (tests): [B][n-1][A]
 #pragma unroll
@@ -206,7 +209,8 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       for (int c = 0; c < CH; ++c) {
         const int e = (c & 1) * 4;
         const float rv[4] = {row[c].x, row[c].y, row[c].z, row[c].w};
-        const float dv[4] = {dm[c].x, dm[c].y, dm[c].z, dm[c].w};
+        const float4 dmc = (CVRP && !DEM_REGS) ? *(const float4 *)(dem_s + (c * LPA + s) * 4) : dm[DEM_REGS ? c : 0];
+        const float dv[4] = {dmc.x, dmc.y, dmc.z, dmc.w};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if constexpr (CVRP) {
@@ -230,7 +234,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       feasible &= alive | ~act;
       // ---- level 2 in every lane (only the chosen lane's result is used)
       float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
-      if constexpr (LPA == 8) excl = s == 0 ? 0.0f : excl;      // (lane 8 of a DPP row starts a group)
+      if constexpr (LPA < 16) excl = s == 0 ? 0.0f : excl;      // (lane 8 of a DPP row starts a group)
       const float thr = fmaxf(r - excl, 1.401298464e-45f);
       int cnt = count_below32<NJ>(run, thr);
       const bool mine = __builtin_amdgcn_inverse_ballot_w64(group_first<LPA>(m));
@@ -244,7 +248,8 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
           const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * GS + s * 8);
           const int e = (c & 1) * 4;
           const float rv[4] = {rw.x, rw.y, rw.z, rw.w};
-          const float dv[4] = {dm[c].x, dm[c].y, dm[c].z, dm[c].w};
+          const float4 dmc = (CVRP && !DEM_REGS) ? *(const float4 *)(dem_s + (c * LPA + s) * 4) : dm[DEM_REGS ? c : 0];
+          const float dv[4] = {dmc.x, dmc.y, dmc.z, dmc.w};
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             float f = (float)ff[e + v];
@@ -327,6 +332,8 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     // d[u_{t-1}][u_t], cvrp/aco.py:135).  64 edges of each of the wave's four ants are gathered with every lane active
     // and staged in LDS; lane 0 of each row adds its ant's 64 values one after the other.
     const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+    float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(&open_flags[0][0]);   // (the flags are dead; 256 B per ant)
+    static_assert(sizeof(open_flags) >= sizeof(float) * 4 * APW * 64, "edge staging inside the flag array");
     if (active) {
       int lmax = n;
       if constexpr (CVRP) {
@@ -415,40 +422,44 @@ static hipError_t launch16(const SampleParams &sp, bool logp, hipStream_t s) {
   return hipGetLastError();
 }
 
-// entries used by daco_tsp_sample / daco_cvrp_sample for n <= DACO_SCAN16_MAX_N in DACO_SCAN mode: eight ants per wavefront up
-// to DACO_SCAN8_MAX_N nodes, four above (DACO_SCAN_LAYOUT=16: four for every n, the layout before round 3)
-hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
-  if (sp.n <= scan8_max_n())
-    switch ((sp.n + 31) / 32) {
-      case 1: return launch16<8, 1, false>(sp, logp, s);
-      case 2: return launch16<8, 2, false>(sp, logp, s);
-      case 3: return launch16<8, 3, false>(sp, logp, s);
-      default: return launch16<8, 4, false>(sp, logp, s);
+template <int LPA, bool CVRP>
+static hipError_t launch_by_chunks(const SampleParams &sp, bool logp, hipStream_t s) {
+  constexpr int W = LPA * 4;                            // candidates per chunk
+  constexpr int MAXCH = CVRP && LPA == 16 ? 4 : 8;
+  const int ch = (sp.n + W - 1) / W;
+  if (ch > MAXCH) return hipErrorInvalidValue;
+  switch (ch) {
+    case 1: return launch16<LPA, 1, CVRP>(sp, logp, s);
+    case 2: return launch16<LPA, 2, CVRP>(sp, logp, s);
+    case 3: return launch16<LPA, 3, CVRP>(sp, logp, s);
+    case 4: return launch16<LPA, 4, CVRP>(sp, logp, s);
+    default: break;
+  }
+  if constexpr (MAXCH == 8) {
+    switch (ch) {
+      case 5: return launch16<LPA, 5, CVRP>(sp, logp, s);
+      case 6: return launch16<LPA, 6, CVRP>(sp, logp, s);
+      case 7: return launch16<LPA, 7, CVRP>(sp, logp, s);
+      default: return launch16<LPA, 8, CVRP>(sp, logp, s);
     }
-  switch ((sp.n + 63) / 64) {
-    case 1: return launch16<16, 1, false>(sp, logp, s);
-    case 2: return launch16<16, 2, false>(sp, logp, s);
-    case 3: return launch16<16, 3, false>(sp, logp, s);
-    case 4: return launch16<16, 4, false>(sp, logp, s);
-    case 5: return launch16<16, 5, false>(sp, logp, s);
-    case 6: return launch16<16, 6, false>(sp, logp, s);
-    case 7: return launch16<16, 7, false>(sp, logp, s);
-    default: return launch16<16, 8, false>(sp, logp, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// entries used by daco_tsp_sample / daco_cvrp_sample in DACO_SCAN mode for n <= DACO_SCAN16_MAX_N (TSP under
+// DACO_SCAN_LAYOUT=16: 512): lanes per ant by scan_small_lanes() -- 4 up to DACO_SCAN4_MAX_N nodes, 8 above
+hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
+  switch (scan_small_lanes(sp.n)) {
+    case 4: return launch_by_chunks<4, false>(sp, logp, s);
+    case 8: return launch_by_chunks<8, false>(sp, logp, s);
+    default: return launch_by_chunks<16, false>(sp, logp, s);
   }
 }
 hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s) {
-  if (sp.n <= scan8_max_n())
-    switch ((sp.n + 31) / 32) {
-      case 1: return launch16<8, 1, true>(sp, logp, s);
-      case 2: return launch16<8, 2, true>(sp, logp, s);
-      case 3: return launch16<8, 3, true>(sp, logp, s);
-      default: return launch16<8, 4, true>(sp, logp, s);
-    }
-  switch ((sp.n + 63) / 64) {
-    case 1: return launch16<16, 1, true>(sp, logp, s);
-    case 2: return launch16<16, 2, true>(sp, logp, s);
-    case 3: return launch16<16, 3, true>(sp, logp, s);
-    default: return launch16<16, 4, true>(sp, logp, s);
+  switch (scan_small_lanes(sp.n)) {
+    case 4: return launch_by_chunks<4, true>(sp, logp, s);
+    case 8: return launch_by_chunks<8, true>(sp, logp, s);
+    default: return launch_by_chunks<16, true>(sp, logp, s);
   }
 }
 

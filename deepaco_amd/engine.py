@@ -12,8 +12,8 @@ import torch
 from . import _lib
 from ._lib import RACE_NOISE, RACE_PHILOX, SCAN, SCAN_WAVE  # noqa: F401
 
-# "scan": daco_tsp_sample / daco_cvrp_sample pack four ants per wavefront for n <= 256 and two for
-# 256 < n <= 512 (measured crossovers, tools/sweep_layouts.py); "scan_wave" keeps the one-ant-per-wavefront draw for every n (what the step-wise
+# "scan": daco_tsp_sample / daco_cvrp_sample pack sixteen ants per wavefront for n <= 128, eight for n <= 256 and two for
+# 256 < n <= 512 (TSP: 1024; measured crossovers, tools/sweep_layouts.py); "scan_wave" keeps the one-ant-per-wavefront draw for every n (what the step-wise
 # service and the fused siblings use)
 MODES = {"race_noise": RACE_NOISE, "race": RACE_PHILOX, "scan": SCAN, "scan_wave": SCAN_WAVE}
 

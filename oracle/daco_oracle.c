@@ -190,11 +190,11 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
 }
 
 /* prefix-scan (roulette) draw -- the wave-shaped analogue of tsp_nls/aco.py:266-274.
- * `lanes` = 64 (one ant per wavefront), 32 (two ants per wavefront, 256 < n <= 512), 16 (four ants
- * per wavefront, 128 < n <= 256) or 8 (eight ants per wavefront, n <= 128); vec = 4 below 64 lanes:
+ * `lanes` = 64 (one ant per wavefront), 32 (two ants per wavefront, 256 < n <= 512), 8 (eight ants per
+ * wavefront, 128 < n <= 256) or 4 (sixteen, n <= 128); 16 (four, the layout before round 3) by knob; vec = 4 below 64 lanes:
  *   candidate k sits in lane (k/vec) % lanes, chunk k / (lanes*vec)
  *   part[l]  = lane-partial sum (c asc, v asc) of the unblocked p;  incl = lane scan of part
- *              (Kogge-Stone in rows of 16 -- lanes = 8: steps 1, 2, 4 only; lanes = 32: lanes 16..31 then add lane 15;
+ *              (Kogge-Stone in rows of 16 -- lanes = 8: steps 1, 2, 4 only, lanes = 4: steps 1, 2; lanes = 32: lanes 16..31 then add lane 15;
  *               lanes = 64: rows 1, 3 add the row before, then lanes 32..63 add lane 31)
  *   S = incl[lanes-1];  r = max(u * S, denorm_min)
  *     u = component ((t>>lg)&3) of Philox(ctr=(((t>>(lg+2))<<lg) + (t&(lanes-1)), gid, iter, STREAM_SCAN)),
@@ -204,15 +204,25 @@ static int draw_race(int n, const float *row, const unsigned char *blocked, uint
  *     walk its candidates in (c,v) order with the lane's own running sum (from +0.0f, closed
  *       candidates add +0.0f); pick the first whose running sum >= thr, else the last open
  *       candidate with p > 0 of the lane (the several-ants-per-wave kernels find it by binary
- *       search over the running sums they keep in registers).  One rule for all four layouts. */
-int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 128 ? 8 : (n <= 256 ? 16 : (n <= 512 ? 32 : 64))); }
+ *       search over the running sums they keep in registers).  One rule for all five layouts. */
+/* DACO_SCAN_LAYOUT (the library's measurement knob, daco_sample_kernel.h scan_small_lanes) is honoured here too, so that
+ * the layouts it selects can be held against this restatement */
+static int small_lanes(int n) {
+  const char *e = getenv("DACO_SCAN_LAYOUT");
+  int v = e ? atoi(e) : 0;
+  if (v == 16) return 16;
+  if (v == 8 && n <= 256) return 8;
+  if (v == 4 && n <= 128) return 4;
+  return n <= 128 ? 4 : 8;
+}
+int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? small_lanes(n) : (n <= 512 ? 32 : 64)); }
 /* TSP: the two-ants-per-wavefront kernel serves n <= 1024 (its LDS tour / flag buffers hold 1024 entries) */
-int orc_scan_lanes_tsp(int n, int mode) { return mode != 2 ? 64 : (n <= 128 ? 8 : (n <= 256 ? 16 : (n <= 1024 ? 32 : 64))); }
+int orc_scan_lanes_tsp(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? small_lanes(n) : (n <= 1024 ? 32 : 64)); }
 
 static int draw_scan(int n, const float *row, const unsigned char *blocked, uint64_t seed,
                      uint64_t iter, uint32_t gid, int t, float *pr, int lanes, const float *u_inj) {
   int vec = lanes < 64 ? 4 : orc_vec_for_n(n), w = lanes * vec, ch = (n + w - 1) / w;
-  int lg = lanes == 64 ? 6 : (lanes == 32 ? 5 : (lanes == 16 ? 4 : 3));
+  int lg = lanes == 64 ? 6 : (lanes == 32 ? 5 : (lanes == 16 ? 4 : (lanes == 8 ? 3 : 2)));
   float part[64], incl[64];
   uint32_t r4[4];
   for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
@@ -225,7 +235,7 @@ static int draw_scan(int n, const float *row, const unsigned char *blocked, uint
       }
     part[l] = s; incl[l] = s;
   }
-  lane_scan(incl);                /* lanes 0..31 (0..15, 0..7) of the 64-lane scan are exactly the half-wave (row, half-row) scan */
+  lane_scan(incl);                /* lanes 0..31 (0..15, 0..7, 0..3) of the 64-lane scan are exactly the half-wave (row, half-row, quad) scan */
   float S = incl[lanes - 1];
   uint32_t ut = (uint32_t)t;
   rng_block(seed, iter, STREAM_SCAN, gid, ((ut >> (lg + 2)) << lg) + (ut & (uint32_t)(lanes - 1)), r4);

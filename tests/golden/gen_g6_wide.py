@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""g6 at n = 100 / 200 / 300 / 600: the reference's roulette sampler (tsp_nls/aco.py:260-275, `_inference_sample`) pinned where the
+"""g6 at n = 30 / 100 / 200 / 300 / 600: the reference's roulette sampler (tsp_nls/aco.py:260-275, `_inference_sample`) pinned where the
 kernels' candidate order differs from the index order (this container only: imports the reference, numba replaced by the
 identity shim).
 
@@ -13,8 +13,8 @@ the entries) and one row is k-sparse (support 40); uniform streams whose route r
 candidate has probability 0 -- the reference then returns a non-permutation) are not recorded, and the number of
 streams dropped because the scan specification (oracle) disagrees with the reference is printed.
 
-Run:  python tests/golden/gen_g6_wide.py [n ...]   (writes tests/golden/g6w_roulette_n*.npz; default: all four sizes.
-n = 100 was recorded again in round 3 when n <= 128 moved to the eight-lane layout; n = 200 covers the sixteen-lane one)
+Run:  python tests/golden/gen_g6_wide.py [n ...]   (writes tests/golden/g6w_roulette_n*.npz; default: all five sizes.
+n = 30, 100 and 200 were recorded in round 3 on the four- and eight-lane layouts that serve n <= 128 and n <= 256 since then)
 """
 import importlib.util
 import os
@@ -55,7 +55,7 @@ def reference_route(prob, start, uniforms):
 
 
 def main():
-    for n in ([int(a) for a in sys.argv[1:]] or [100, 200, 300, 600]):
+    for n in ([int(a) for a in sys.argv[1:]] or [30, 100, 200, 300, 600]):
         rng = np.random.default_rng(7000 + n)
         c = rng.random((n, 2)).astype(np.float32)
         d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
@@ -63,12 +63,12 @@ def main():
         P = (1.0 / d).astype(np.float32) * (0.2 + rng.random((n, n))).astype(np.float32)
         P[rng.random((n, n)) < 0.10] = 0.0                                   # exact zeros
         sparse_row = 7
-        keep = rng.choice(np.delete(np.arange(n), sparse_row), size=40, replace=False)
+        keep = rng.choice(np.delete(np.arange(n), sparse_row), size=min(40, n // 3), replace=False)
         row = np.zeros(n, dtype=np.float32)
         row[keep] = P[sparse_row, keep] + np.float32(0.01)
         P[sparse_row] = row
         out = {"probmat": P}
-        for lanes in ((8 if n <= 128 else 16 if n <= 256 else 32), 64):
+        for lanes in ((4 if n <= 128 else 8 if n <= 256 else 32), 64):
             sigma = layout_order(n, lanes)
             rho = np.argsort(sigma)
             Pp = np.ascontiguousarray(P[sigma][:, sigma])

@@ -108,8 +108,9 @@ def test_aco_class_run_trace(name):
 SHAPES = [(2, 1, 1), (3, 2, 1), (5, 4, 1), (20, 7, 2), (63, 5, 1), (64, 9, 1), (65, 5, 2), (100, 33, 1),
           (128, 6, 1), (129, 6, 1), (200, 17, 2), (256, 4, 1), (257, 4, 1), (500, 12, 1), (777, 5, 1),
           (1000, 6, 1), (1025, 3, 1),
-          # four / two ants per wavefront (n <= 128 / <= 1024): every chunk count, odd ant counts
-          (130, 3, 1), (384, 7, 1), (385, 5, 2), (512, 9, 1), (640, 3, 1), (700, 4, 1), (896, 3, 1), (1024, 5, 1)]
+          # sixteen / eight / two ants per wavefront (n <= 128 / <= 256 / <= 1024): every chunk count, odd ant counts
+          (16, 3, 1), (17, 18, 1), (40, 35, 2), (50, 65, 1), (70, 5, 1), (90, 19, 1), (112, 70, 1), (113, 16, 1), (170, 9, 1),
+          (224, 11, 1), (225, 8, 1), (130, 3, 1), (384, 7, 1), (385, 5, 2), (512, 9, 1), (640, 3, 1), (700, 4, 1), (896, 3, 1), (1024, 5, 1)]
 
 
 @pytest.mark.parametrize("mode", ["scan", "race"])
@@ -321,11 +322,11 @@ def test_infeasible_row_sets_flag():
 
 
 # ------------------------------------------------------------------ I1: the scan draw IS the reference's roulette
-@pytest.mark.parametrize("mode", ["scan", "scan_wave"])
-def test_scan_kernels_reproduce_reference_roulette_routes(mode):
+def test_scan_kernels_reproduce_reference_roulette_routes(mode="scan_wave"):
     """g6: routes the reference's `_inference_sample` (tsp_nls/aco.py:260-275) built from an injected uniform
-    stream.  The same uniforms fed to the HIP scan kernels (four ants per wavefront / one ant per wavefront)
-    give the same routes (n = 30: one chunk, the lanes walk the candidates in index order like the reference)."""
+    stream.  The same uniforms fed to the HIP scan kernel with one ant per wavefront give the same routes (n = 30: one
+    chunk, the lanes walk the candidates in index order like the reference; the packed layouts -- sixteen candidates per
+    chunk at this size since round 3 -- are pinned on the relabelled instances of g6w below, n = 30 included)."""
     from deepaco_amd import engine
     g = load_golden("g6_roulette_n30")
     n, A = g["probmat"].shape[0], g["uniforms"].shape[0]
@@ -338,15 +339,15 @@ def test_scan_kernels_reproduce_reference_roulette_routes(mode):
     assert np.array_equal(paths[0].cpu().numpy(), rp)
 
 
-@pytest.mark.parametrize("n", [100, 200, 300, 600])
+@pytest.mark.parametrize("n", [30, 100, 200, 300, 600])
 def test_scan_kernels_reproduce_reference_roulette_routes_lane_order(n):
     """g6w: the reference's roulette on the instance relabelled by a layout's lane order (tests/golden/gen_g6_wide.py), rows
-    with exact zeros and a k-sparse row: the HIP scan kernels (eight / four / two ants per wavefront; one ant per wavefront) fed the
+    with exact zeros and a k-sparse row: the HIP scan kernels (sixteen / eight / two ants per wavefront; one ant per wavefront) fed the
     recorded uniforms build exactly the reference's routes."""
     from deepaco_amd import engine
     g = load_golden(f"g6w_roulette_n{n}")
     P = T(g["probmat"])[None]
-    for lanes, mode in (((8 if n <= 128 else 16 if n <= 256 else 32), "scan"), (64, "scan_wave")):
+    for lanes, mode in (((4 if n <= 128 else 8 if n <= 256 else 32), "scan"), (64, "scan_wave")):
         u = torch.from_numpy(g[f"uniforms_l{lanes}"].T.copy()).to(dev())[None]          # [1][n-1][A]
         A = u.shape[2]
         paths, _, _, flags = engine.tsp_sample(P, torch.ones(1, n, n, device=dev()), A, mode=mode, fixed_start=0, noise=u)
@@ -362,7 +363,7 @@ def _layout_order(n, lanes):
     return np.argsort(key, kind="stable")
 
 
-@pytest.mark.parametrize("n,lanes", [(100, 8), (128, 8), (200, 16), (500, 32), (640, 32), (1100, 64)])
+@pytest.mark.parametrize("n,lanes", [(100, 4), (128, 4), (200, 8), (256, 8), (500, 32), (640, 32), (1100, 64)])
 def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
     """The benchmarked sampler against the LITERAL arithmetic of the reference's roulette (tsp_nls/aco.py:266-274:
     r = U * sum(prob_row * mask) in f64, subtract prob[k] one after the other until r <= 0), step by step along
@@ -379,7 +380,7 @@ def test_scan_draw_equals_reference_roulette_arithmetic(n, lanes):
     u = torch.rand(1, n - 1, A, generator=g).clamp_(1e-7, 1 - 1e-7)
     paths, _, _, flags = engine.tsp_sample(tau.to(dev()), eta.to(dev()), A, mode="scan", fixed_start=0, noise=u.to(dev()))
     assert int(flags.sum()) == 0
-    assert {8: n <= 128, 16: 128 < n <= 256, 32: 256 < n <= 1024, 64: n > 1024}[lanes]
+    assert {4: n <= 128, 8: 128 < n <= 256, 32: 256 < n <= 1024, 64: n > 1024}[lanes]
     P = oracle.prob_matrix(tau[0].numpy(), eta[0].numpy())
     order = _layout_order(n, lanes)
     p = paths[0].cpu().numpy()

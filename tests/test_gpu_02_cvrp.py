@@ -63,7 +63,10 @@ def test_cvrp_golden(name):
 
 @pytest.mark.parametrize("mode", ["scan", "race"])
 @pytest.mark.parametrize("n,A,B,cap", [(5, 3, 1, 50), (20, 9, 2, 50), (63, 5, 1, 30), (64, 5, 1, 50), (100, 17, 2, 50),
-                                        (128, 4, 1, 50), (200, 6, 1, 40), (300, 4, 1, 50), (500, 3, 1, 60)])
+                                        (128, 4, 1, 50), (200, 6, 1, 40), (300, 4, 1, 50), (500, 3, 1, 60),
+                                        # every chunk count of the sixteen- / eight-ants-per-wavefront layouts, ragged ant counts
+                                        (17, 35, 1, 30), (40, 18, 1, 30), (50, 65, 1, 40), (70, 70, 1, 40), (90, 19, 2, 50), (113, 16, 1, 50),
+                                        (130, 9, 1, 50), (170, 33, 1, 50), (225, 5, 1, 50), (256, 12, 1, 50)])
 def test_cvrp_philox_bit_exact_vs_oracle(mode, n, A, B, cap):
     from deepaco_amd import engine
     d, demand, tau, eta = cvrp_instance(n, 50 + n, B)
