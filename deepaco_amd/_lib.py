@@ -59,7 +59,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 118          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 119          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 118 /* 0.1.17: bumped whenever an entry point's signature changes */
+#define DACO_VERSION 119 /* 0.1.18: bumped whenever an entry point's signature or the draw stream of a mode changes (119: lanes per ant of the scan draw for n <= 256) */
 
 /* error codes */
 #define DACO_OK 0
