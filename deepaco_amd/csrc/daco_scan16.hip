@@ -214,10 +214,11 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if constexpr (CVRP) {
-            float f = (float)fo[c >> 1][e + v];
-            f = dv[v] > rem ? 0.0f : f;                                      // strict, cvrp/aco.py:200
-            if (c == 0 && v == 0) f = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f;   // the depot, cvrp/aco.py:179
-            acc = __builtin_fmaf(rv[v], f, acc);
+            // the capacity and depot rules select on the f32 row value, the visited flag stays the f16 operand of the fma
+            // (a blocked candidate adds 0*f = +0.0f like a visited one adds p*0)
+            float pv = dv[v] > rem ? 0.0f : rv[v];                           // strict, cvrp/aco.py:200
+            if (c == 0 && v == 0) pv = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : pv;   // the depot, cvrp/aco.py:179
+            acc = __builtin_fmaf(pv, (float)fo[c >> 1][e + v], acc);
           } else {
             acc = __builtin_fmaf(rv[v], (float)fo[c >> 1][e + v], acc);
           }

@@ -1,11 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3u
-O=gpurun_out/r3u
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1
-tail -4 $O/tests.txt
-timeout 600 python tests/soak_parity.py 3000 1234 > $O/soak_parity.txt 2>&1
-tail -3 $O/soak_parity.txt
-timeout 1500 bash tools/profile_r3.sh r03 > $O/profile.log 2>&1
-tail -3 $O/profile.log
-grep -h '^{' gpurun_out/r03/bench_default.json | cut -c1-600
+mkdir -p gpurun_out/r3v
+O=gpurun_out/r3v
+timeout 900 python -m pytest tests/test_gpu_02_cvrp.py tests/test_gpu_09_cvrp_ls.py -x -q -m gpu > $O/tests.txt 2>&1
+tail -3 $O/tests.txt
+timeout 300 python tools/measure_configs.py c4 2>&1 | grep '^{'
+timeout 300 python tools/measure_configs.py c4 2>&1 | grep '^{'
+timeout 300 python tests/soak_parity.py 600 99 > $O/soak.txt 2>&1
+tail -3 $O/soak.txt
