@@ -403,6 +403,7 @@ def extra_configs(dev, headline_colony, cpu=True):
     # also re-reads the (<= n) changed edges' matrix entry and two ranks (8 bytes).  L2 -> L1 moves a 128-byte line for each.
     alg = walked * 12.0 + sweeps * 8.0 * 16
     tr, src = traffic.get("nls500_a256_b64", (None, None))
+    lines_req = traffic.get("nls500_a256_b64_l2_line_requests", (None, None))[0]
     cb = None
     if cpu:
         paths, _, _, _ = engine.tsp_sample(col.pheromone[:1], col.heuristic[:1], 16, seed=3, batch=1, fixed_start=0)
@@ -427,6 +428,12 @@ def extra_configs(dev, headline_colony, cpu=True):
                      "frac": alg / (kms * 1e-3) / 1e9 / PEAK_L2_GBS, "traffic": tr, "traffic_source": src,
                      "kernel": "nls_kernel (daco_tsp_nls; HIP events around the launch)", "kernel_ms": kms,
                      "algorithmic_bytes_per_launch": alg,
+                     # what the L2 actually moves for them: every 8-byte table entry / 4-byte gather pulls a 128-byte line
+                     "l2_lines": None if lines_req is None else {
+                         "requests_per_launch": lines_req, "GBps": lines_req * 128 / (kms * 1e-3) / 1e9,
+                         "frac": lines_req * 128 / (kms * 1e-3) / 1e9 / PEAK_L2_GBS,
+                         "source": "TCP_TCC_READ_REQ_sum of the kernel (profiles/r03_pmc_nls.txt; same workload and library "
+                                   "version, not collected in this run) x 128 B / this run's kernel time"},
                      "note": "algorithmic bytes = 12 B per walked list entry (table entry + matrix gather) + 128 B per sweep for "
                              "the changed edges, from the in-run counters; the kernel is a chain of dependent L2 round trips and "
                              "LDS phases per sweep (latency / issue bound, profiles/r03_pmc_nls_*), not bound by this bandwidth"},
