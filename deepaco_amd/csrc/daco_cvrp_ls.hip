@@ -5,8 +5,8 @@
 // on the distances again) and the path it takes into the vendored HGS-CVRP C++ through /tmp files
 // (cvrp_nls/swapstar.py:240-271, HGS-CVRP-main/Program/C_Interface.cpp:128-172 -> LocalSearch.cpp).  HGS's LocalSearch is
 // first improvement over a granular neighbourhood in a shuffled order (std::minstd_rand + std::shuffle), with load
-// penalties instead of hard capacity and SWAP* on top; it is NOT reproduced move for move.  This kernel is a deterministic
-// BEST-improvement search over HGS's classical move families (LocalSearch.cpp move1 .. move9), hard capacity, specified
+// penalties instead of hard capacity; it is NOT reproduced move for move.  This kernel is a deterministic
+// BEST-improvement search over HGS's move families (LocalSearch.cpp move1 .. move9 and swapStar), hard capacity, specified
 // below and restated on the CPU in oracle/cvrp_ls.py (the tests hold the kernel bit-exact against that restatement).
 // Parity with the reference is pinned on COST: tests/golden/g8_cvrp_ls_*.npz are routes in / routes out of the
 // reference's own swapstar() / neural_swapstar() built from its sources; the schedule of cvrp_nls.ACO has to reach their
@@ -16,7 +16,10 @@
 // routes, L entries, s[0] = s[L-1] = 0.  Per move every candidate (kind, i, j) is evaluated in f32 as
 //     change = (((a1 + a2) + a3) + a4) - (((r1 + r2) + r3) + r4)  [+ (float)(reversal term, f64)]
 // (a* = lengths of the edges the move adds, r* = of those it removes, in the order listed; missing terms are skipped); the
-// smallest change wins, ties to the smallest (kind, i, j), and the move is applied if its change is below -1e-6.  Loads are
+// smallest change wins, ties to the smallest (kind, i, j), and the move is applied if its change is below -eps,
+// eps = max(1e-6, M * 2^-17), M = the largest |entry| of the matrix (a change sums up to a dozen f32 terms of size <= M: its
+// rounding error stays below 2e-6 * M, so every applied move lowers the true cost and the search cannot cycle; with an
+// absolute 1e-6 it did on matrices with entries in the hundreds once SWAP* was in the move set).  Loads are
 // f64 sums of the f32 demands along a route; a route is feasible if its load is <= capacity * (1 + 1e-6) (an exactly full
 // route of normalised demands must pass: the reference hands HGS capacity 1000.001 for the same reason, swapstar.py:254).
 // With u = s[i], a = s[i-1], c = s[i+1], x = s[i+1], c2 = s[i+2], v = s[j], w = s[j+1], e = s[j-1], g = s[j+1], y = s[j+1],
@@ -31,6 +34,16 @@
 //   6 2OPT   reverse s[i..j] inside one route, i < j                     add (a,v) (u,g)             rem (a,u) (v,g)     + asym[j] - asym[i]
 //   7 TAILS  routes r1 < r2 cut after i and after j, tails exchanged     add (u,y) (v,x)             rem (u,x) (v,y)
 //   8 CROSS  r1 = head1 + reversed head2, r2 = reversed tail1 + tail2    add (u,v) (x,y)             rem (u,x) (v,y)     + reversal of head2 and tail1
+//   9 SWAP*  (LocalSearch.cpp swapStar) customers u in route r1 and v in route r2, r1 < r2, change routes, EACH AT ITS BEST
+//            POSITION of the other route:  change = ((remU + remV) + insU) + insV  with
+//              remU = D(a,c) - (D(a,u) + D(u,c)),  remV = D(e,g) - (D(e,v) + D(v,g))            (what the removals save)
+//              insU = min( in place: (D(e,u) + D(u,g)) - D(e,g),
+//                          best of (D(s[p],u) + D(u,s[p+1])) - D(s[p],s[p+1]) over the positions p of r2, opening depot
+//                          included, not next to v (p != j, j-1); ties to the smallest p; the place of v wins a tie )
+//              insV likewise in r1 without u.
+//            Evaluated ONLY when no move of kinds 0-8 improves (HGS tries SWAP* after its classical moves too): the search
+//            stops at a solution that no move of the ten families improves.  Every pair of routes is considered (HGS: only
+//            pairs whose polar sectors overlap); O(n^2 * route length) direct evaluation, no insertion tables.
 // (asym[k]: f64 sum over the route's edges before position k of d[s[t+1]][s[t]] - d[s[t]][s[t+1]] -- what the edges cost
 // more walked backwards; exactly 0 for a symmetric matrix, the perturbation matrix 1/(eta/rowmax + 1e-5) is not symmetric.)
 // Moves between routes must keep every route within capacity.  The distance matrix is staged in LDS when it fits
@@ -64,9 +77,9 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
   uint16_t *rstart = rid + LS_MAXL;                                 // [LS_MAXR + 2] opening depot of route r
   float *redd = reinterpret_cast<float *>(rstart + LS_MAXR + 2);    // [4] reduction
   uint32_t *redc = reinterpret_cast<uint32_t *>(redd + 4);          // [4]
-  int *shared_i = reinterpret_cast<int *>(redc + 4);                // [0] L, [1] R, [2..] piece table (6 x {lo, hi, rev})
+  int *shared_i = reinterpret_cast<int *>(redc + 4);                // [0] L, [1] R, [2..] piece table (8 x {lo, hi, rev})
   const int n4 = (n + 3) & ~3;
-  float *dem = reinterpret_cast<float *>(shared_i + 24);            // [n4] demands
+  float *dem = reinterpret_cast<float *>(shared_i + 32);            // [n4] demands
   float *dl = dem + n4;                                             // [n*n] staged distances (STAGE)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / A, a_ = blockIdx.x - b * A;
@@ -75,7 +88,17 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
   const double capT = (double)capacity * (1.0 + 1e-6);
 
   for (int k = tid; k < n; k += 256) dem[k] = demand[(size_t)b * n + k];
-  if constexpr (STAGE) for (int k = tid; k < n * n; k += 256) dl[k] = dg[k];
+  float mx = 0.0f;                                          // M: largest |entry| (one pass over the matrix per launch)
+  for (int k = tid; k < n * n; k += 256) {
+    const float x = dg[k];
+    if constexpr (STAGE) dl[k] = x;
+    mx = fmaxf(mx, fabsf(x));
+  }
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) redd[wave] = mx;
+  __syncthreads();
+  const float neg_eps = -fmaxf(1e-6f, fmaxf(fmaxf(redd[0], redd[1]), fmaxf(redd[2], redd[3])) * 7.62939453125e-6f);   // 2^-17
+  __syncthreads();
   // (24-bit multiply: v_mad_u32_u24 runs at full rate, the 32-bit multiply at a quarter -- a candidate is six to eight look-ups)
   auto D = [&](int u, int v) -> float { return STAGE ? dl[__mul24(u, n) + v] : dg[(uint32_t)(__mul24(u, n) + v)]; };
   // squeeze doubled depots out of src[0..len) into dst (wave 0, 64 entries per step); returns the new length (all lanes)
@@ -234,18 +257,66 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
       while (j >= W) { j -= W; ++i; }
     }
     // ---- workgroup minimum
-    for (int o = 32; o >= 1; o >>= 1) {
-      const float od = __shfl_xor(bd, o);
-      const uint32_t oc = (uint32_t)__shfl_xor((int)bc, o);
-      if (ls_better(od, oc, bd, bc)) { bd = od; bc = oc; }
-    }
-    if (lane == 0) { redd[wave] = bd; redc[wave] = bc; }
-    __syncthreads();
-    bd = redd[0]; bc = redc[0];
+    auto block_min = [&]() {
+      for (int o = 32; o >= 1; o >>= 1) {
+        const float od = __shfl_xor(bd, o);
+        const uint32_t oc = (uint32_t)__shfl_xor((int)bc, o);
+        if (ls_better(od, oc, bd, bc)) { bd = od; bc = oc; }
+      }
+      if (lane == 0) { redd[wave] = bd; redc[wave] = bc; }
+      __syncthreads();
+      bd = redd[0]; bc = redc[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) if (ls_better(redd[w], redc[w], bd, bc)) { bd = redd[w]; bc = redc[w]; }
-    if (!(bd < -1e-6f) || bc == 0xFFFFFFFFu) break;
-    // ---- apply: the new sequence is at most six ranges of the old one (some reversed)
+      for (int w = 1; w < 4; ++w) if (ls_better(redd[w], redc[w], bd, bc)) { bd = redd[w]; bc = redc[w]; }
+    };
+    block_min();
+    // cheapest insertion of `node` into route r without the customer at position skip (kind 9): cost, and the position it
+    // goes behind (skip itself: the place of the removed customer)
+    auto ins_best = [&](int node, int r, int skip, int &where) -> float {
+      const int k0 = rstart[r], k1 = rstart[r + 1];
+      float best = __builtin_inff();
+      int bp = skip;
+      int sp = s[k0];
+      for (int p = k0; p < k1; ++p) {
+        const int sn = s[p + 1];
+        if (p != skip && p != skip - 1) {
+          const float cst = (D(sp, node) + D(node, sn)) - D(sp, sn);
+          if (cst < best) { best = cst; bp = p; }
+        }
+        sp = sn;
+      }
+      const int e = s[skip - 1], g = s[skip + 1];
+      const float cin = (D(e, node) + D(node, g)) - D(e, g);
+      where = cin <= best ? skip : bp;
+      return cin <= best ? cin : best;
+    };
+    if (!(bd < neg_eps) || bc == 0xFFFFFFFFu) {
+      // ---- no classical move improves: SWAP* over every pair of customers in different routes
+      __syncthreads();                                      // (everyone has read the reduction slots)
+      bd = __builtin_inff(); bc = 0xFFFFFFFFu;
+      int i2 = tid / W, j2 = tid - i2 * W;
+      for (; i2 < W; ) {
+        const int u = s[i2], v = s[j2];
+        if (u != 0 && v != 0 && rid[i2] < rid[j2]) {
+          const int ri = rid[i2], rj = rid[j2];
+          const double du = (double)dem[u], dv = (double)dem[v];
+          if (rl[ri] - du + dv <= capT && rl[rj] - dv + du <= capT) {
+            const int pa = s[i2 - 1], pc = s[i2 + 1], pe = s[j2 - 1], pg = s[j2 + 1];
+            const float remU = D(pa, pc) - (D(pa, u) + D(u, pc));
+            const float remV = D(pe, pg) - (D(pe, v) + D(v, pg));
+            int w_;
+            const float insU = ins_best(u, rj, j2, w_);
+            const float insV = ins_best(v, ri, i2, w_);
+            offer(((remU + remV) + insU) + insV, 9u, i2, j2);
+          }
+        }
+        j2 += 256;
+        while (j2 >= W) { j2 -= W; ++i2; }
+      }
+      block_min();
+      if (!(bd < neg_eps) || bc == 0xFFFFFFFFu) break;
+    }
+    // ---- apply: the new sequence is at most eight ranges of the old one (some reversed)
     if (tid == 0) {
       const int kind = (int)(bc >> 28), mi = (int)((bc >> 14) & 0x3FFF), mj = (int)(bc & 0x3FFF);
       int *pt = shared_i + 2;
@@ -264,19 +335,30 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
         piece(0, mi - 1, 0); piece(mj, mj + 1, 0); piece(mi + 2, mj - 1, 0); piece(mi, mi + 1, 0); piece(mj + 2, L - 1, 0);
       } else if (kind == 6) {
         piece(0, mi - 1, 0); piece(mi, mj, 1); piece(mj + 1, L - 1, 0);
+      } else if (kind == 9) {
+        int pu, pv;                                         // u goes behind pu in r2 (pu == mj: where v was), v behind pv in r1
+        ins_best(s[mi], rid[mj], mj, pu);
+        ins_best(s[mj], rid[mi], mi, pv);
+        int next;
+        if (pv == mi) { piece(0, mi - 1, 0); piece(mj, mj, 0); next = mi + 1; }
+        else if (pv < mi) { piece(0, pv, 0); piece(mj, mj, 0); piece(pv + 1, mi - 1, 0); next = mi + 1; }
+        else { piece(0, mi - 1, 0); piece(mi + 1, pv, 0); piece(mj, mj, 0); next = pv + 1; }
+        if (pu == mj) { piece(next, mj - 1, 0); piece(mi, mi, 0); piece(mj + 1, L - 1, 0); }
+        else if (pu < mj) { piece(next, pu, 0); piece(mi, mi, 0); piece(pu + 1, mj - 1, 0); piece(mj + 1, L - 1, 0); }
+        else { piece(next, mj - 1, 0); piece(mj + 1, pu, 0); piece(mi, mi, 0); piece(pu + 1, L - 1, 0); }
       } else {
         const int e1 = rstart[rid[mi] + 1], b2 = rstart[rid[mj]], e2 = rstart[rid[mj] + 1];
         if (kind == 7) { piece(0, mi, 0); piece(mj + 1, e2 - 1, 0); piece(e1, mj, 0); piece(mi + 1, e1 - 1, 0); piece(e2, L - 1, 0); }
         else { piece(0, mi, 0); piece(b2 + 1, mj, 1); piece(e1, b2, 0); piece(mi + 1, e1 - 1, 1); piece(mj + 1, e2 - 1, 0); piece(e2, L - 1, 0); }
       }
-      for (int q = np; q < 6; ++q) { pt[3 * q] = 1; pt[3 * q + 1] = 0; pt[3 * q + 2] = 0; }      // empty
+      for (int q = np; q < 8; ++q) { pt[3 * q] = 1; pt[3 * q + 1] = 0; pt[3 * q + 2] = 0; }      // empty
     }
     __syncthreads();
     for (int k = tid; k < L; k += 256) {
       const int *pt = shared_i + 2;
       int rest = k, src = 0;
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const int lo = pt[3 * q], hi = pt[3 * q + 1], len = hi - lo + 1;
         if (len > 0) {
           if (rest >= 0 && rest < len) src = pt[3 * q + 2] ? hi - rest : lo + rest;
@@ -317,7 +399,7 @@ extern "C" int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lma
   const int n4 = (n + 3) & ~3;
   const bool stage = n <= LS_STAGE_MAX_N;
   const size_t lds = (size_t)2 * LS_MAXL * 8 + (size_t)2 * (LS_MAXR + 1) * 8 + (size_t)2 * (LS_MAXL + 4) * 2 + (size_t)LS_MAXL * 2 +
-                     (size_t)(LS_MAXR + 2) * 2 + 8 * 4 + 24 * 4 + (size_t)n4 * 4 + (stage ? (size_t)n * n * 4 : 0) + 16;
+                     (size_t)(LS_MAXR + 2) * 2 + 8 * 4 + 32 * 4 + (size_t)n4 * 4 + (stage ? (size_t)n * n * 4 : 0) + 16;
   hipStream_t s = (hipStream_t)stream;
   if (stage) {
     if (lds > 64 * 1024) {

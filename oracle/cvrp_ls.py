@@ -4,8 +4,9 @@ The reference's CVRP local search is the vendored HGS-CVRP C++ (cvrp_nls/aco.py:
 -> HGS-CVRP-main/Program/C_Interface.cpp:128-172 -> LocalSearch.cpp): first improvement over a granular neighbourhood in
 a shuffled order (std::minstd_rand, std::shuffle), load penalties instead of hard capacity, SWAP* on top.  It is NOT
 restated move for move.  What is restated here is THIS repository's deterministic best-improvement search over HGS's
-classical move families (LocalSearch.cpp move1 .. move9: relocate one / two / two reversed, swap 1-1 / 2-1 / 2-2,
-2-opt, 2-opt* in both reconnections), hard capacity, so that the kernel can be held bit-exact against an independent
+move families (LocalSearch.cpp move1 .. move9: relocate one / two / two reversed, swap 1-1 / 2-1 / 2-2, 2-opt, 2-opt* in
+both reconnections; swapStar: two customers of different routes change routes, each at its best position, tried when no
+classical move improves), hard capacity, so that the kernel can be held bit-exact against an independent
 implementation; parity with the reference is pinned on COST: tests/golden/g8_cvrp_ls_*.npz hold routes in / routes out of
 the reference's own swapstar() / neural_swapstar() built from its sources (oracle/_ref), and the kernel's schedule has to
 reach their mean cost (tests/test_gpu_09_cvrp_ls.py).
@@ -14,15 +15,22 @@ Specification (the kernel's header has the same text).  A solution is the route 
 empty routes, L entries.  Per move every candidate (kind, i, j) below is evaluated in float32 as
     change = (((+a1 + a2) + a3) + a4) - (((r1 + r2) + r3) + r4)  [+ (float32)(reversal term, float64)]
 (a* = lengths of the edges the move adds, r* = of those it removes, in the order listed; missing terms are skipped), the
-smallest change wins, ties to the smallest (kind, i, j), and it is applied if it is below -1e-6.  Loads are float64 sums
+smallest change wins, ties to the smallest (kind, i, j), and it is applied if it is below -eps, eps = max(1e-6, M * 2^-17)
+with M the largest |entry| of the matrix: a change is a sum of up to a dozen f32 terms of size <= M, so its rounding error
+stays below 2e-6 * M and every applied move lowers the true cost -- the search cannot cycle (with an absolute 1e-6 it did,
+on matrices with entries in the hundreds, once SWAP* with its different association of the terms was in the move set).  Loads are float64 sums
 of the float32 demands along a route; a route is feasible if its load is <= capacity * (1 + 1e-6) (an exactly full route
 of normalised demands must pass: the reference hands HGS capacity 1000.001 for the same reason, swapstar.py:254).
+SWAP* (kind 9, evaluated only when no candidate of kinds 0-8 is below -1e-6): u = s[i] in route r1, v = s[j] in route
+r2 > r1, change = ((remU + remV) + insU) + insV, remU = D(a,c) - (D(a,u) + D(u,c)), insU = the cheaper of "in place of v"
+(D(e,u) + D(u,g)) - D(e,g) and the cheapest (D(s[p],u) + D(u,s[p+1])) - D(s[p],s[p+1]) over r2's positions p (opening depot
+included) not next to v; ties: the smallest p, and the place of v before any p.
 Pure Python / numpy scalars: small cases only.
 """
 import numpy as np
 
 F = np.float32
-KINDS = ("rel1", "rel2", "rel2r", "swap11", "swap21", "swap22", "2opt", "tails", "cross")
+KINDS = ("rel1", "rel2", "rel2r", "swap11", "swap21", "swap22", "2opt", "tails", "cross", "swapstar")
 
 
 def compress(seq):
@@ -147,8 +155,58 @@ def candidates(s, d, dem, cap):
     return out
 
 
+def _ins_best(s, d, node, k0, k1, skip):
+    """cheapest insertion of `node` between s[p] and s[p+1], p in [k0, k1), without the customer at position skip:
+    (cost, position it goes behind; skip = the place of the removed customer)."""
+    best, bp = F(np.inf), skip
+    for p in range(k0, k1):
+        if p == skip or p == skip - 1:
+            continue
+        c = F(F(d[s[p], node] + d[node, s[p + 1]]) - d[s[p], s[p + 1]])
+        if c < best:
+            best, bp = c, p
+    e, g = s[skip - 1], s[skip + 1]
+    cin = F(F(d[e, node] + d[node, g]) - d[e, g])
+    return (cin, skip) if cin <= best else (best, bp)
+
+
+def swap_star_candidates(s, d, dem, cap):
+    """Every SWAP* candidate as (change, 9, i, j): u = s[i] and v = s[j] customers, route of i before route of j."""
+    L = len(s)
+    rid, pf, rl, start, asym, asymT = _tables(s, d, dem)
+    capT = float(cap) * (1.0 + 1e-6)
+    out = []
+    for i in range(L - 1):
+        for j in range(L - 1):
+            u, v = s[i], s[j]
+            if u == 0 or v == 0 or not rid[i] < rid[j]:
+                continue
+            du, dv = float(dem[u]), float(dem[v])
+            if not (rl[rid[i]] - du + dv <= capT and rl[rid[j]] - dv + du <= capT):
+                continue
+            a, c, e, g = s[i - 1], s[i + 1], s[j - 1], s[j + 1]
+            rem_u = F(d[a, c] - F(d[a, u] + d[u, c]))
+            rem_v = F(d[e, g] - F(d[e, v] + d[v, g]))
+            ins_u, _ = _ins_best(s, d, u, start[rid[j]], start[rid[j] + 1], j)
+            ins_v, _ = _ins_best(s, d, v, start[rid[i]], start[rid[i] + 1], i)
+            out.append((F(F(F(rem_u + rem_v) + ins_u) + ins_v), 9, i, j))
+    return out
+
+
+def _best_of(cands):
+    best = None
+    for c in cands:
+        if best is None or c[0] < best[0] or (c[0] == best[0] and c[1:] < best[1:]):
+            best = c
+    return best
+
+
+def best_swap_star(s, d, dem, cap):
+    return _best_of(swap_star_candidates(s, d, dem, cap))
+
+
 def best_move(s, d, dem, cap):
-    """(change, kind, i, j) of the best move (smallest change, ties to the smallest (kind, i, j)), or None."""
+    """(change, kind, i, j) of the best classical move (kinds 0-8; smallest change, ties to the smallest (kind, i, j)), or None."""
     best = None
     for c in candidates(s, d, dem, cap):
         if best is None or c[0] < best[0] or (c[0] == best[0] and c[1:] < best[1:]):
@@ -156,9 +214,30 @@ def best_move(s, d, dem, cap):
     return best
 
 
-def apply_move(s, kind, i, j):
+def apply_move(s, kind, i, j, d=None):
     s = list(s)
     L = len(s)
+    if kind == 9:
+        rid, _, _, start, _, _ = _tables(s, d, np.zeros(int(max(s)) + 1, dtype=np.float32))
+        u, v = s[i], s[j]
+        _, pu = _ins_best(s, d, u, start[rid[j]], start[rid[j] + 1], j)
+        _, pv = _ins_best(s, d, v, start[rid[i]], start[rid[i] + 1], i)
+        new = []
+        for k in range(L):
+            if k == i:
+                if pv == i:
+                    new.append(v)
+                continue
+            if k == j:
+                if pu == j:
+                    new.append(u)
+                continue
+            new.append(s[k])
+            if k == pv:
+                new.append(v)
+            if k == pu:
+                new.append(u)
+        return compress(new)
     if kind in (0, 1, 2):
         n = 1 if kind == 0 else 2
         seg = s[i:i + n]
@@ -190,18 +269,30 @@ def apply_move(s, kind, i, j):
     return compress(s)
 
 
-def local_search(seq, dist, demand, capacity, max_moves):
-    """seq: route sequence (zero-padded) -> (improved sequence without empty routes, moves applied)."""
+def threshold(dist):
+    """eps of the acceptance rule: max(1e-6, M * 2^-17), M = largest |entry| (f32)."""
+    m = F(np.abs(np.asarray(dist, dtype=np.float32)).max())
+    return max(F(1e-6), F(m * F(2.0 ** -17)))
+
+
+def local_search(seq, dist, demand, capacity, max_moves, kinds=None):
+    """seq: route sequence (zero-padded) -> (improved sequence without empty routes, moves applied); the kinds of the
+    applied moves are appended to `kinds` if a list is given."""
     d = np.asarray(dist, dtype=np.float32)
     dem = np.asarray(demand, dtype=np.float32)
     s = compress(seq)
+    eps = threshold(d)
     moves = 0
     while moves < max_moves:
         mv = best_move(s, d, dem, capacity)
-        if mv is None or not (mv[0] < F(-1e-6)):
-            break
-        s = apply_move(s, *mv[1:])
+        if mv is None or not (mv[0] < -eps):
+            mv = best_swap_star(s, d, dem, capacity)            # only when no classical move improves
+            if mv is None or not (mv[0] < -eps):
+                break
+        s = apply_move(s, *mv[1:], d=d)
         moves += 1
+        if kinds is not None:
+            kinds.append(mv[1])
     return s, moves
 
 

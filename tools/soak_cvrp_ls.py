@@ -22,6 +22,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260927
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 cases = sols = moves_total = 0
+applied = []
 kinds = {}
 while time.time() < t_end:
     n = int(rng.integers(4, 34))                               # customers
@@ -49,11 +50,11 @@ while time.time() < t_end:
     if int(flags.sum()) != 0:
         continue
     paths = paths[:, :int(lens.max()) + 2].contiguous()
-    maxm = int(rng.choice([1, 3, 10, 100000]))
+    maxm = int(rng.choice([1, 3, 10, 2000]))                   # (2000: never reached -- the search ends by itself; bounds a runaway)
     before = paths.clone()
     out, ln, nm = engine.cvrp_local_search_(dd, dm, cap, paths, maxm, want_stats=True)
     for a in range(A):
-        ref, ref_moves = ols.local_search(before[0, :, a].cpu().numpy(), d, dem, cap, maxm)
+        ref, ref_moves = ols.local_search(before[0, :, a].cpu().numpy(), d, dem, cap, maxm, kinds=applied)
         got = out[0, :, a].cpu().numpy()
         if not (int(ln[0, a]) == len(ref) and int(nm[0, a]) == ref_moves and np.array_equal(got[:len(ref)], np.array(ref))
                 and not got[len(ref):].any()):
@@ -61,7 +62,10 @@ while time.time() < t_end:
             sys.exit(1)
         moves_total += ref_moves
     cases += 1
+    if cases % 50 == 0:
+        print(json.dumps({"progress": cases, "moves": moves_total}), flush=True)
     sols += A
     kinds[kind] = kinds.get(kind, 0) + 1
 print(json.dumps({"soak": "cvrp_ls_kernel == oracle/cvrp_ls.py (sequences, lengths, move counts)", "seconds": budget, "seed": seed,
-                  "cases": cases, "solutions": sols, "moves": moves_total, "kinds": kinds, "mismatches": 0}))
+                  "cases": cases, "solutions": sols, "moves": moves_total,
+                  "moves_by_kind": {ols.KINDS[k]: applied.count(k) for k in range(len(ols.KINDS))}, "kinds": kinds, "mismatches": 0}))
