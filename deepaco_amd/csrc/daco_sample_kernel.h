@@ -669,10 +669,9 @@ inline int scan_small_lanes(int n) {
 inline int tsp_scan32_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 64) ? 512 : 1024; return v; }
 // DACO_SCAN_LAYOUT=16 (measurement knob): four ants per wavefront up to n = 512 (TSP)
 inline int scan16_max_n() { static const int v = (getenv("DACO_SCAN_LAYOUT") && atoi(getenv("DACO_SCAN_LAYOUT")) == 16) ? 512 : DACO_SCAN16_MAX_N; return v; }
-// daco_tsp_scan32.hip: TSP / CVRP scan draw with two ants per wavefront
+// daco_tsp_scan32.hip: TSP scan draw with two ants per wavefront
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
-hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s);
-// daco_scan16.hip: four (n <= 256) or eight (n <= 128) ants per wavefront
+// daco_scan16.hip: sixteen (n <= 128), eight (n <= 256) or four (CVRP: 256 < n <= 512; DACO_SCAN_LAYOUT=16) ants per wavefront
 hipError_t launch_tsp_scan16(const SampleParams &sp, bool logp, hipStream_t s);
 hipError_t launch_cvrp_scan16(const SampleParams &sp, bool logp, hipStream_t s);
 

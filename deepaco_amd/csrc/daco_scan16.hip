@@ -91,14 +91,14 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   constexpr int FL0 = (CH <= 4 ? 2 : 4) * GS;
   constexpr int FL = FL0 < 128 ? 128 : FL0;             // flag / inverse-table entries per ant (>= n; >= 128: the edge staging below)
   constexpr int CB = LPA * 16;                          // bytes of a row chunk
-  static_assert(!CVRP || ROWF <= 256, "CVRP: n <= 256 (hub bitmap, demand row)");
+  static_assert(!CVRP || ROWF <= 512, "CVRP: n <= 512 (hub bitmap, demand row)");
   static_assert(LPA == 16 || NJ <= 32, "eight / sixteen ants per wavefront: up to 32 candidates per lane");
-  constexpr bool DEM_REGS = LPA == 16;                  // CVRP: the lane's demands stay in registers / are read from LDS every step
+  constexpr bool DEM_REGS = LPA == 16 && CH <= 4;       // CVRP: the lane's demands stay in registers / are read from LDS every step
   // open[ant][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited, else 0.0; slot
   // j = c*4 + v of lane s is node c*(4 LPA) + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
   __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
-  __shared__ uint32_t hub_s[APB][8];                    // CVRP: per ant, set of nodes that follow the depot (n <= 256)
+  __shared__ uint32_t hub_s[APB][16];                   // CVRP: per ant, set of nodes that follow the depot (n <= 512)
   __shared__ int len_s[APB];                            // CVRP: rows used by each ant (0: slot holds no ant)
   extern __shared__ __attribute__((aligned(16))) uint16_t tour_s[];   // [APB][TL]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -112,7 +112,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   if constexpr (CVRP) {
     for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
-    for (int k = threadIdx.x; k < APB * 8; k += 256) hub_s[k >> 3][k & 7] = 0u;
+    for (int k = threadIdx.x; k < APB * 16; k += 256) hub_s[k >> 4][k & 15] = 0u;
     if (threadIdx.x < APB) len_s[threadIdx.x] = 0;
     __syncthreads();
   }
@@ -426,7 +426,7 @@ static hipError_t launch16(const SampleParams &sp, bool logp, hipStream_t s) {
 template <int LPA, bool CVRP>
 static hipError_t launch_by_chunks(const SampleParams &sp, bool logp, hipStream_t s) {
   constexpr int W = LPA * 4;                            // candidates per chunk
-  constexpr int MAXCH = CVRP && LPA == 16 ? 4 : 8;
+  constexpr int MAXCH = 8;
   const int ch = (sp.n + W - 1) / W;
   if (ch > MAXCH) return hipErrorInvalidValue;
   switch (ch) {

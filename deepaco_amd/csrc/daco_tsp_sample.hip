@@ -119,8 +119,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
   const bool packed = mode == DACO_SCAN && (size_t)n * A * 8 < ((size_t)1 << 32);
   // (float64 load bookkeeping: the one-ant-per-wavefront kernel's PROB_CVRP64 policy)
-  const bool four_per_wave = packed && !demand64 && n <= DACO_SCAN16_MAX_N,
-             two_per_wave = packed && !demand64 && n > DACO_SCAN16_MAX_N && n <= DACO_SCAN32_MAX_N;
+  const bool four_per_wave = packed && !demand64 && n <= DACO_SCAN32_MAX_N;      // scan16_kernel family (4 / 8 / 16 lanes per ant)
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }
@@ -163,7 +162,6 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   sp.aux_vec = nullptr; sp.aux_mat = nullptr; sp.scalar0 = 0.0f; sp.wts = nullptr; sp.m = 0;
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   hipError_t e = four_per_wave ? launch_cvrp_scan16(sp, logp != nullptr, s)
-               : two_per_wave ? launch_cvrp_scan32(sp, logp != nullptr, s)
                : demand64     ? dispatch_sample<PROB_CVRP64>(sp, vec, CH, mode, logp != nullptr, s)
                               : dispatch_sample<PROB_CVRP>(sp, vec, CH, mode, logp != nullptr, s);
   if (e != hipSuccess) { set_error("cvrp sample kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }

@@ -303,212 +303,6 @@ static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ CVRP (cvrp/aco.py:138-205)
-// Same draw, the closed set now also holds the customers whose demand exceeds the remaining
-// capacity (strict, cvrp/aco.py:200) and the depot while the ant stands on it with customers left
-// (:179).  Lanes multiply the row by the combined 0/1 factor, the chosen lane deals those masked
-// values.  The two ants of a wave finish at different steps: a finished half keeps stepping with
-// its stores and state updates switched off until its neighbour is done.
-template <int CH2, bool LOGP, bool FUSED>
-__global__ void __launch_bounds__(256)
-cvrp_scan32_kernel(const SampleParams p) {
-  constexpr int NJ = CH2 * 4, ROWF = CH2 * 128;
-  __shared__ __attribute__((aligned(16))) float open_flags[8][ROWF];
-  __shared__ __attribute__((aligned(16))) float dem_s[ROWF];          // demand of this instance, +inf padding
-  __shared__ uint32_t hub_s[8][CH2 * 4];                               // per ant: set of nodes that follow the depot
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int up = lane >> 5, s = lane & 31;
-  const int w = xcd_remap(blockIdx.x, gridDim.x);
-  const int bpi = (p.A + 7) >> 3;
-  const int b = w / bpi;
-  const int a0 = ((w - b * bpi) * 4 + wave) * 2;
-  const int n = p.n, A = p.A, ld = p.ld, Lmax = p.Lmax;
-  const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);
-  for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
-  __syncthreads();
-  if (a0 >= A) return;
-  const int a = a0 + up < A ? a0 + up : A - 1;          // odd A: the last upper half repeats ant A-1
-  const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);
-  const bool upper = __builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFF00000000ull);
-  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
-  const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
-  const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
-  int64_t *path_a = p.paths + (size_t)b * Lmax * A + a;
-  float *logp_a = LOGP ? p.logp + (size_t)b * (Lmax - 1) * A + a : nullptr;
-  float *rs_a = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (Lmax - 1) * A + a : nullptr;
-  float *fl = open_flags[wave * 2 + up];
-  const char *dist_b = (FUSED || p.costs) ? (const char *)(p.dist + (size_t)b * p.dist_bs) : nullptr;
-  char *next_b = (FUSED || p.nbr) ? (char *)(p.nbr + (size_t)b * n * A) : nullptr;           // [n][A] table of this instance
-  const uint32_t A4 = (uint32_t)A * 4u, a4 = (uint32_t)a * 4u;
-  uint32_t *hub_l = hub_s[wave * 2 + up];
-  if (s < CH2 * 4) hub_l[s] = 0u;
-  float cost = 0.0f, dpend = 0.0f;
-  float4 dm[CH2];
-#pragma unroll
-  for (int c = 0; c < CH2; ++c) {
-    *(float4 *)(fl + (c * 32 + s) * 4) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    dm[c] = *(const float4 *)(dem_s + (c * 32 + s) * 4);
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (lead) path_a[0] = 0;
-
-  int prev = 0, remaining = n - 1, len = 1;
-  float used = 0.0f + dem_s[0];
-  bool finished = remaining == 0;
-  u32x4 ublk = {0, 0, 0, 0};
-  float ucur = 0.0f;
-  uint64_t feasible = ~0ull;
-  uint64_t act = __builtin_amdgcn_ballot_w64(!finished);               // lanes of the halves still building
-
-  for (int t = 1; t < Lmax && act != 0; ++t) {
-    const uint32_t voff = __umul24((uint32_t)prev, ldb) + lane_off;
-    float4 row[CH2], fo[CH2];
-#pragma unroll
-    for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
-    if ((t & 31) == 0 || t == 1) {
-      if ((t & 127) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((t >> 7) << 5) + s));
-      ucur = u01(comp(ublk, (t >> 5) & 3));
-    }
-    const int ucur_i = __float_as_int(ucur);
-    const int u_lo = __builtin_amdgcn_readlane(ucur_i, t & 31), u_hi = __builtin_amdgcn_readlane(ucur_i, (t & 31) + 32);
-    const float u = __int_as_float(upper ? u_hi : u_lo);
-#pragma unroll
-    for (int c = 0; c < CH2; ++c) fo[c] = *(const float4 *)(fl + (c * 32 + s) * 4);
-    const float rem = p.capacity - used;
-    // the lane's running sums in slot order; a closed slot (visited, over capacity, or the depot while standing on
-    // it) adds p*0 = +0.0f
-    float run[16];
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < CH2; ++c) {
-      float4 f = fo[c];
-      f.x = dm[c].x > rem ? 0.0f : f.x;  f.y = dm[c].y > rem ? 0.0f : f.y;
-      f.z = dm[c].z > rem ? 0.0f : f.z;  f.w = dm[c].w > rem ? 0.0f : f.w;
-      if (c == 0) f.x = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f.x;       // the depot, cvrp/aco.py:179
-      acc = __builtin_fmaf(row[c].x, f.x, acc); run[4 * c + 0] = acc;
-      acc = __builtin_fmaf(row[c].y, f.y, acc); run[4 * c + 1] = acc;
-      acc = __builtin_fmaf(row[c].z, f.z, acc); run[4 * c + 2] = acc;
-      acc = __builtin_fmaf(row[c].w, f.w, acc); run[4 * c + 3] = acc;
-    }
-    const float part = acc;
-    const float incl = half_scan_add<true>(part);
-    const int incl_i = __float_as_int(incl);
-    const float S0 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 31)), S1 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 63));
-    const float S = upper ? S1 : S0;
-    const float r = fmaxf(u * S, 1.401298464e-45f);
-    const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT) & act;
-    feasible &= __builtin_amdgcn_fcmpf(S, 0.0f, FCMP_OGT) | ~act;
-    float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
-    excl = s == 0 ? 0.0f : excl;
-    const float thr = fmaxf(r - excl, 1.401298464e-45f);
-    const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-    const int L0 = m0 ? __builtin_ctz(m0) : 0, L1 = m1 ? __builtin_ctz(m1) : 0;         // chosen lane of each half
-    // level 2 inside the chosen lane: first slot whose running sum reaches thr (see tsp_scan32_kernel)
-    const int cnt = count_below<NJ>(run, thr);
-    int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
-    if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
-      // rounding: no running sum reached thr -> the lane's last open candidate with p > 0 (row and flags read again)
-      int last = 0;
-#pragma unroll
-      for (int c = 0; c < CH2; ++c) {
-        const float4 rw = *(const float4 *)(Pb + voff + c * 512);
-        float4 f = *(const float4 *)(fl + (c * 32 + s) * 4);
-        f.x = dm[c].x > rem ? 0.0f : f.x;  f.y = dm[c].y > rem ? 0.0f : f.y;
-        f.z = dm[c].z > rem ? 0.0f : f.z;  f.w = dm[c].w > rem ? 0.0f : f.w;
-        if (c == 0) f.x = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f.x;
-        last = rw.x * f.x > 0.0f ? 4 * c + 0 : last;
-        last = rw.y * f.y > 0.0f ? 4 * c + 1 : last;
-        last = rw.z * f.z > 0.0f ? 4 * c + 2 : last;
-        last = rw.w * f.w > 0.0f ? 4 * c + 3 : last;
-      }
-      if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
-      if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 + 32);
-    }
-    // a half without a feasible candidate (flagged) or already finished moves to the depot
-    const int c0 = m0 ? (((j0 >> 2) << 7) | (j0 & 3)) + (L0 << 2) : 0;
-    const int c1 = m1 ? (((j1 >> 2) << 7) | (j1 & 3)) + (L1 << 2) : 0;
-    const int choice = upper ? c1 : c0;
-    if (lead && choice != 0) fl[choice] = 0.0f;          // customers are visited once, the depot stays open
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- outputs: lane 0 of every half that is still building (one EXEC mask, no nesting)
-    const bool writer = __builtin_amdgcn_inverse_ballot_w64(act & 0x0000000100000001ull);
-    if (writer) {
-      path_a[(size_t)t * A] = choice;
-      if constexpr (LOGP) {
-        const float pc = *(const float *)(Pb + __umul24((uint32_t)prev, ldb) + (uint32_t)choice * 4u);
-        logp_a[(size_t)(t - 1) * A] = clamp_log(pc / S);
-        if (rs_a) rs_a[(size_t)(t - 1) * A] = S;
-      }
-      if (FUSED || dist_b) {                             // fused route length, edge added one step late
-        cost = cost + dpend;
-        dpend = *(const float *)(dist_b + ((__umul24((uint32_t)prev, (uint32_t)n) + (uint32_t)choice) << 2));
-      }
-      if (FUSED || next_b) {
-        // who follows `prev`.  Row 0 of the table is never read (the depot's successors are a set,
-        // kept as a bitmap), so the store needs no branch on prev
-        *(uint32_t *)(next_b + __umul24((uint32_t)prev, A4) + a4) = (uint32_t)choice << 16;
-        __hip_atomic_fetch_or(hub_l + (choice >> 5), prev == 0 ? 1u << (choice & 31) : 0u, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-    }
-    // ---- state of each half, as selects (a finished half keeps its values)
-    const bool live = !finished;
-    const bool moved = live && choice != 0;
-    remaining -= moved ? 1 : 0;
-    const float load = moved ? used : 0.0f;              // back at the depot the load restarts from 0
-    used = live ? load + dem_s[choice] : used;
-    finished = finished || (remaining == 0 && choice == 0);
-    len = live ? t + 1 : len;
-    prev = finished ? 0 : choice;
-    act = __builtin_amdgcn_ballot_w64(!finished);
-  }
-  // the reference steps every ant until the slowest one is done: a done ant keeps drawing the
-  // depot (probability 1), so its column is padded with 0 / log(1-eps)
-  if (s == 0) {
-    if (p.lens) p.lens[(size_t)b * A + a] = len;
-    if (p.tab_lens) p.tab_lens[(size_t)b * A + a] = len;
-    const float lp1 = clamp_log(1.0f);
-    for (int tt = len; tt < Lmax; ++tt) {
-      path_a[(size_t)tt * A] = 0;
-      if constexpr (LOGP) logp_a[(size_t)(tt - 1) * A] = lp1;
-    }
-    if (!finished && p.flags) atomicOr(p.flags + b, 2);
-    if (dist_b) p.costs[(size_t)b * A + a] = cost + dpend;
-    if (next_b) {
-      uint32_t *hub_a = p.hubmask + ((size_t)b * A + a) * ((n + 31) >> 5);
-      for (int i = 0; i < ((n + 31) >> 5); ++i) hub_a[i] = hub_l[i];
-    }
-  }
-  if (feasible != ~0ull && p.flags && lane == 0) atomicOr(p.flags + b, 1);
-}
-
-template <int CH2>
-static hipError_t launch_cvrp32(const SampleParams &sp, bool logp, hipStream_t s) {
-  const int bpi = (sp.A + 7) / 8;
-  dim3 grid((unsigned)(sp.B * bpi)), block(256);
-  const bool fused = sp.costs && sp.nbr;
-#define DACO_C32(L, F) hipLaunchKernelGGL((cvrp_scan32_kernel<CH2, L, F>), grid, block, 0, s, sp)
-  if (logp) { if (fused) DACO_C32(true, true); else DACO_C32(true, false); }
-  else { if (fused) DACO_C32(false, true); else DACO_C32(false, false); }
-#undef DACO_C32
-  return hipGetLastError();
-}
-
-// entry used by daco_cvrp_sample when the two-ants-per-wave layout applies
-hipError_t launch_cvrp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
-  switch ((sp.n + 127) / 128) {
-    case 1: return launch_cvrp32<1>(sp, logp, s);
-    case 2: return launch_cvrp32<2>(sp, logp, s);
-    case 3: return launch_cvrp32<3>(sp, logp, s);
-    case 4: return launch_cvrp32<4>(sp, logp, s);
-    case 5: return launch_cvrp32<5>(sp, logp, s);
-    case 6: return launch_cvrp32<6>(sp, logp, s);
-    case 7: return launch_cvrp32<7>(sp, logp, s);
-    default: return launch_cvrp32<8>(sp, logp, s);
-  }
-}
-
 // entry used by daco_tsp_sample (daco_tsp_sample.hip) when the two-ants-per-wave layout applies
 hipError_t launch_tsp_scan32(const SampleParams &sp, bool logp, hipStream_t s) {
   switch ((sp.n + 127) / 128) {

@@ -215,7 +215,7 @@ static int small_lanes(int n) {
   if (v == 4 && n <= 128) return 4;
   return n <= 128 ? 4 : 8;
 }
-int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? small_lanes(n) : (n <= 512 ? 32 : 64)); }
+int orc_scan_lanes(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? small_lanes(n) : (n <= 512 ? 16 : 64)); }
 /* TSP: the two-ants-per-wavefront kernel serves n <= 1024 (its LDS tour / flag buffers hold 1024 entries) */
 int orc_scan_lanes_tsp(int n, int mode) { return mode != 2 ? 64 : (n <= 256 ? small_lanes(n) : (n <= 1024 ? 32 : 64)); }
 
