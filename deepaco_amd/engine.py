@@ -560,8 +560,10 @@ def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None, t
 
 def cvrp_local_search_(dist, demand, capacity, paths, max_moves, want_stats=False):
     """In-place local search on CVRP solutions (cvrp_nls/aco.py:114-126): dist [B,n,n] or [n,n], demand [B,n] or [n],
-    paths [B,Lmax,A] or [Lmax,A] int64 (route sequences as gen_path returns them).  Relocate / swap / intra-route
-    2-opt, best improvement, at most max_moves moves per solution.  Returns paths (and lens, moves [B,A])."""
+    paths [B,Lmax,A] or [Lmax,A] int64 (route sequences as gen_path returns them).  Best improvement over HGS's move
+    families (relocate 1 / 2 / 2 reversed, swap 1-1 / 2-1 / 2-2, 2-opt, 2-opt* both ways; SWAP* when none of them
+    improves), hard capacity, at most max_moves moves per solution (csrc/daco_cvrp_ls.hip has the specification).
+    Returns paths (and lens, moves [B,A])."""
     _require_gpu(dist, demand, paths)
     n = dist.shape[-1]
     assert paths.dtype == torch.int64
