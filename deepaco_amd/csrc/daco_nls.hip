@@ -38,21 +38,27 @@ __device__ inline uint32_t nls_ord_f32(float x) {
 }
 __device__ inline float nls_unord_f32(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 
-template <int CTRL, int ROW_MASK>
-__device__ inline void nls_min_step(uint32_t &hi, uint32_t &lo) {
-  const uint32_t ohi = (uint32_t)dpp_i<CTRL, ROW_MASK, false>((int)hi, (int)hi);
-  const uint32_t olo = (uint32_t)dpp_i<CTRL, ROW_MASK, false>((int)lo, (int)lo);
-  if (ohi < hi || (ohi == hi && olo < lo)) { hi = ohi; lo = olo; }
+// minimum of an unsigned value over the wave (in lane 63, read back as a wave-uniform value): six v_min_u32 on the DPP network
+__device__ inline uint32_t nls_wave_min_u32(uint32_t x) {
+  // (lanes without a source keep their value: the instruction is disabled there; a DPP read needs two wait states after
+  // the VALU write of its source)
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(x));
+  return (uint32_t)readlane_i((int)x, 63);
 }
+// minimum of 64-bit keys over the wave, lexicographically: the smallest high word first, then the smallest low word among the
+// lanes that hold it (two 32-bit reductions instead of one with a 64-bit compare-and-select per step)
 __device__ inline uint64_t nls_wave_min(uint64_t v) {
-  uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-  nls_min_step<DPP_ROW_SHR(1), 0xF>(hi, lo);
-  nls_min_step<DPP_ROW_SHR(2), 0xF>(hi, lo);
-  nls_min_step<DPP_ROW_SHR(4), 0xF>(hi, lo);
-  nls_min_step<DPP_ROW_SHR(8), 0xF>(hi, lo);
-  nls_min_step<DPP_ROW_BCAST15, 0xA>(hi, lo);
-  nls_min_step<DPP_ROW_BCAST31, 0xC>(hi, lo);
-  return ((uint64_t)(uint32_t)readlane_i((int)hi, 63) << 32) | (uint32_t)readlane_i((int)lo, 63);
+  const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+  const uint32_t mh = nls_wave_min_u32(hi);
+  const uint32_t ml = nls_wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return ((uint64_t)mh << 32) | ml;
 }
 
 // inclusive integer add-scan over the wave: rows of 16 (row_shr), then the rows' totals (row_bcast 15 / 31)
@@ -409,7 +415,10 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   const int np2 = (n + 2) & ~1;
   // threads per tour: 256 when there are tours to fill the device several times over (a CU then interleaves several of
   // them), more when there are fewer tours than the device holds (a sweep is a latency chain: more threads shorten it)
-  int nt = (long)B * T <= 512 ? 1024 : ((long)B * T <= 1536 ? 512 : 256);
+  // (the sweeps are bound by instruction issue once the device is full: three wavefronts per tour walk a sweep's ~850 entries in
+  // two rounds like four do, with a quarter less of the per-wave work -- scans, reductions, the dirty tests' set-up; measured on
+  // config 3: 128 / 192 / 256 / 320 / 384 threads -> 48.1 / 42.1 / 45.8 / 70.0 / 76.8 ms)
+  int nt = (long)B * T <= 512 ? 1024 : ((long)B * T <= 1536 ? 512 : (n + 1 <= 576 ? 192 : 256));
   if (const char *ev = getenv("DACO_NLS_THREADS")) nt = atoi(ev);
   const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)np2 * 8 * 2 + 24 * 8 + (size_t)(np2 + 2) * 4 + 32 * 4 + (size_t)np2 * 2 + 16;
   // threads per tour: 256 when there are tours to fill the device several times over (a CU then interleaves six of them),
@@ -429,6 +438,7 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   if (const char *ev = getenv("DACO_NLS_GROUP")) group = atoi(ev);
   if (nt >= 1024) DACO_NLS_LAUNCH(1024, 2, 2);
   else if (nt >= 512) DACO_NLS_LAUNCH(512, 3, 2);
+  else if (nt == 192 && n + 1 <= 576) DACO_NLS_LAUNCH(192, 3, 3);
   else if (n + 1 > 512) DACO_NLS_LAUNCH(256, 5, 2);
   else if (group <= 1) DACO_NLS_LAUNCH(256, 2, 1);
   else if (group >= 4) DACO_NLS_LAUNCH(256, 2, 4);

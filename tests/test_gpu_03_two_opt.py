@@ -333,7 +333,7 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
 
 
 # ------------------------------------------------------------------ daco_tsp_nls: dirty-list sweeps, the whole NLS in one launch
-NLS_SHAPES = (("256", "3"), ("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"))     # threads per tour, entries per thread and round
+NLS_SHAPES = (("192", "3"), ("256", "3"), ("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"))     # threads per tour, entries per thread and round
 
 
 @pytest.mark.parametrize("n,Tn,B,maxit", [(4, 3, 1, 50), (5, 4, 2, 50), (33, 6, 1, 1000), (129, 5, 2, 1000), (257, 4, 1, 30),
@@ -443,7 +443,7 @@ def test_cached_list_kernel_many_small_cases_with_ties(monkeypatch):
         tours = np.stack([rng.permutation(n) for _ in range(Tn)]).astype(np.int16)
         dd = T(d)
         tabs = engine.TwoOptTables(dd)
-        nt, queue = NLS_SHAPES[case % 6]
+        nt, queue = NLS_SHAPES[case % len(NLS_SHAPES)]
         monkeypatch.setenv("DACO_NLS_THREADS", nt)
         monkeypatch.setenv("DACO_NLS_GROUP", queue)
         a, sa = engine.two_opt_(dd, T(tours), maxit, want_sweeps=True)

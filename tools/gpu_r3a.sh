@@ -1,10 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3y
-O=gpurun_out/r3y
-timeout 600 python -m pytest tests/test_gpu_02_cvrp.py -x -q -m gpu > $O/tests.txt 2>&1
-tail -3 $O/tests.txt
-for n in 500 300; do
-for E in 0 1; do DACO_CVRP_SCAN32=$E timeout 200 python tools/time_layouts.py $n 256 32 2>&1 | tail -1; done
-done
-timeout 200 python tests/soak_parity.py 400 5 > $O/soak.txt 2>&1; tail -3 $O/soak.txt
+mkdir -p gpurun_out/r3z
+O=gpurun_out/r3z
+timeout 600 python -m pytest tests/test_gpu_03_two_opt.py -x -q -m gpu > $O/tests3.txt 2>&1
+tail -2 $O/tests3.txt
+timeout 300 python tools/soak_two_opt.py 100 777 > $O/soak_two_opt.txt 2>&1
+tail -1 $O/soak_two_opt.txt | cut -c1-500
+timeout 300 python tools/bench_nls_fused.py 64 3 g3 > $O/nls3.txt 2>&1
+grep variant $O/nls3.txt

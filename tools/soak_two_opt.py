@@ -60,7 +60,7 @@ while time.time() < t_end:
     ref, rs = engine.two_opt_(dd, tours.clone(), maxit, want_sweeps=True)
     for kernel in ("nbr", "auto", "cached"):
         os.environ["DACO_TWO_OPT_WIDE"] = str(int(rng.integers(0, 2)))
-        os.environ["DACO_NLS_THREADS"] = str(rng.choice([256, 512, 1024]))
+        os.environ["DACO_NLS_THREADS"] = str(rng.choice([192, 256, 512, 1024]))
         os.environ["DACO_NLS_GROUP"] = str(rng.choice([1, 2, 3, 4]))
         if kernel == "auto" and rng.random() < 0.5:
             sw = int(rng.integers(1, n * n))
@@ -80,7 +80,7 @@ while time.time() < t_end:
         th = engine.TwoOptTables(hd)
         T_nls, T_p = int(rng.integers(0, 4)), int(rng.integers(1, 8))
         cap = int(min(maxit, 200))
-        os.environ["DACO_NLS_THREADS"] = str(rng.choice([256, 512, 1024]))
+        os.environ["DACO_NLS_THREADS"] = str(rng.choice([192, 256, 512, 1024]))
         os.environ["DACO_NLS_GROUP"] = str(rng.choice([1, 2, 3, 4]))
         try:
             a = engine.nls_(dd, hd, tours, cap, T_nls=T_nls, T_p=T_p, tables=tabs, heuristic_tables=th, fused=False, want_costs=True)
