@@ -57,27 +57,38 @@
 namespace daco {
 
 constexpr int LS_MAXL = 1024;      // longest sequence (2n+1 entries at most)
-constexpr int LS_MAXR = 512;       // routes
 constexpr int LS_STAGE_MAX_N = 160;
+
+// capacities of the per-launch LDS arrays: positions (Lmax + the appended closing depot, rounded up to a multiple of 8) and
+// routes (a route takes at least two positions)
+__host__ __device__ inline int ls_cap_l(int Lmax) { return (Lmax + 1 + 7) & ~7; }
+__host__ __device__ inline int ls_cap_r(int Lmax) { return ((Lmax + 1) / 2 + 2 + 1) & ~1; }
+__host__ __device__ inline size_t ls_fixed_bytes(int Lmax, int n) {
+  const size_t Lc = ls_cap_l(Lmax), Rc = ls_cap_r(Lmax);
+  return 2 * Lc * 8 + 2 * (Rc + 1) * 8 + 2 * (Lc + 4) * 2 + Lc * 2 + (Rc + 2) * 2 + 32 * 4 + 32 * 4 + (size_t)((n + 3) & ~3) * 4 + 16;
+}
 
 __device__ inline bool ls_better(float d1, uint32_t c1, float d2, uint32_t c2) { return d1 < d2 || (d1 == d2 && c1 < c2); }
 
-template <bool STAGE>
-__global__ void __launch_bounds__(256)
+template <bool STAGE, int NT>
+__global__ void __launch_bounds__(NT)
 cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const float *demand, float capacity, int64_t *paths,
                int count, int32_t *lens_out, int32_t *moves_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *pf = reinterpret_cast<double *>(smem);                    // [LS_MAXL] load of the route up to and including k
-  double *asym = pf + LS_MAXL;                                      // [LS_MAXL]
-  double *rl = asym + LS_MAXL;                                      // [LS_MAXR + 1] route loads
-  double *asymT = rl + LS_MAXR + 1;                                 // [LS_MAXR + 1] reversal sum of the whole route
-  uint16_t *s = reinterpret_cast<uint16_t *>(asymT + LS_MAXR + 1);  // [LS_MAXL + 4] sequence (4 spare entries of padding)
-  uint16_t *s2 = s + LS_MAXL + 4;                                   // [LS_MAXL + 4] the sequence being built
-  uint16_t *rid = s2 + LS_MAXL + 4;                                 // [LS_MAXL] route of position k
-  uint16_t *rstart = rid + LS_MAXL;                                 // [LS_MAXR + 2] opening depot of route r
-  float *redd = reinterpret_cast<float *>(rstart + LS_MAXR + 2);    // [4] reduction
-  uint32_t *redc = reinterpret_cast<uint32_t *>(redd + 4);          // [4]
-  int *shared_i = reinterpret_cast<int *>(redc + 4);                // [0] L, [1] R, [2..] piece table (8 x {lo, hi, rev})
+  // (sized by this launch's Lmax, not by the largest sequence the kernel accepts: at CVRP-100 the workgroup needs 45 KB with
+  // the staged matrix instead of 71 KB, i.e. three instead of two of them share a CU)
+  const int Lc = ls_cap_l(Lmax), Rc = ls_cap_r(Lmax);
+  double *pf = reinterpret_cast<double *>(smem);                    // [Lc] load of the route up to and including k
+  double *asym = pf + Lc;                                           // [Lc]
+  double *rl = asym + Lc;                                           // [Rc + 1] route loads
+  double *asymT = rl + Rc + 1;                                      // [Rc + 1] reversal sum of the whole route
+  uint16_t *s = reinterpret_cast<uint16_t *>(asymT + Rc + 1);       // [Lc + 4] sequence (4 spare entries of padding)
+  uint16_t *s2 = s + Lc + 4;                                        // [Lc + 4] the sequence being built
+  uint16_t *rid = s2 + Lc + 4;                                      // [Lc] route of position k
+  uint16_t *rstart = rid + Lc;                                      // [Rc + 2] opening depot of route r
+  float *redd = reinterpret_cast<float *>(rstart + Rc + 2);         // [16] reduction   (Lc, Rc even: 4-byte aligned)
+  uint32_t *redc = reinterpret_cast<uint32_t *>(redd + 16);         // [16]
+  int *shared_i = reinterpret_cast<int *>(redc + 16);                // [0] L, [1] R, [2..] piece table (8 x {lo, hi, rev})
   const int n4 = (n + 3) & ~3;
   float *dem = reinterpret_cast<float *>(shared_i + 32);            // [n4] demands
   float *dl = dem + n4;                                             // [n*n] staged distances (STAGE)
@@ -87,9 +98,10 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
   int64_t *col = paths + (size_t)b * Lmax * A + a_;
   const double capT = (double)capacity * (1.0 + 1e-6);
 
-  for (int k = tid; k < n; k += 256) dem[k] = demand[(size_t)b * n + k];
+  constexpr int NW = NT / 64;
+  for (int k = tid; k < n; k += NT) dem[k] = demand[(size_t)b * n + k];
   float mx = 0.0f;                                          // M: largest |entry| (one pass over the matrix per launch)
-  for (int k = tid; k < n * n; k += 256) {
+  for (int k = tid; k < n * n; k += NT) {
     const float x = dg[k];
     if constexpr (STAGE) dl[k] = x;
     mx = fmaxf(mx, fabsf(x));
@@ -97,7 +109,10 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   if (lane == 0) redd[wave] = mx;
   __syncthreads();
-  const float neg_eps = -fmaxf(1e-6f, fmaxf(fmaxf(redd[0], redd[1]), fmaxf(redd[2], redd[3])) * 7.62939453125e-6f);   // 2^-17
+  float mall = redd[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mall = fmaxf(mall, redd[w]);
+  const float neg_eps = -fmaxf(1e-6f, mall * 7.62939453125e-6f);   // 2^-17
   __syncthreads();
   // (24-bit multiply: v_mad_u32_u24 runs at full rate, the 32-bit multiply at a quarter -- a candidate is six to eight look-ups)
   auto D = [&](int u, int v) -> float { return STAGE ? dl[__mul24(u, n) + v] : dg[(uint32_t)(__mul24(u, n) + v)]; };
@@ -148,7 +163,7 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
     __syncthreads();
     const int R = shared_i[1];
     // one lane per route: loads and reversal sums along it, sequentially in f64
-    for (int r = tid; r <= R; r += 256) {
+    for (int r = tid; r <= R; r += NT) {
       const int k0 = rstart[r], k1 = r < R ? rstart[r + 1] : k0;
       double load = 0.0, rev = 0.0;
       pf[k0] = 0.0; asym[k0] = 0.0;
@@ -253,7 +268,7 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
           offer((add - rem) + (float)rev, 8u, i, j);
         }
       }
-      j += 256;
+      j += NT;
       while (j >= W) { j -= W; ++i; }
     }
     // ---- workgroup minimum
@@ -267,7 +282,7 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
       __syncthreads();
       bd = redd[0]; bc = redc[0];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) if (ls_better(redd[w], redc[w], bd, bc)) { bd = redd[w]; bc = redc[w]; }
+      for (int w = 1; w < NW; ++w) if (ls_better(redd[w], redc[w], bd, bc)) { bd = redd[w]; bc = redc[w]; }
     };
     block_min();
     // cheapest insertion of `node` into route r without the customer at position skip (kind 9): cost, and the position it
@@ -310,7 +325,7 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
             offer(((remU + remV) + insU) + insV, 9u, i2, j2);
           }
         }
-        j2 += 256;
+        j2 += NT;
         while (j2 >= W) { j2 -= W; ++i2; }
       }
       block_min();
@@ -354,7 +369,7 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
       for (int q = np; q < 8; ++q) { pt[3 * q] = 1; pt[3 * q + 1] = 0; pt[3 * q + 2] = 0; }      // empty
     }
     __syncthreads();
-    for (int k = tid; k < L; k += 256) {
+    for (int k = tid; k < L; k += NT) {
       const int *pt = shared_i + 2;
       int rest = k, src = 0;
 #pragma unroll
@@ -376,7 +391,7 @@ cvrp_ls_kernel(int n, int A, int Lmax, const float *dist, long dist_bs, const fl
     L = shared_i[0];
   }
   __syncthreads();
-  for (int t = tid; t < Lmax; t += 256) col[(size_t)t * A] = t < L ? (int64_t)s[t] : 0;
+  for (int t = tid; t < Lmax; t += NT) col[(size_t)t * A] = t < L ? (int64_t)s[t] : 0;
   if (tid == 0) {
     if (lens_out) lens_out[blockIdx.x] = L;
     if (moves_out) moves_out[blockIdx.x] = moves;
@@ -396,22 +411,27 @@ extern "C" int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lma
   }
   // (a column without a closing depot gets one appended: one entry of head room)
   if (Lmax >= LS_MAXL || n > 16383) { set_error("daco_cvrp_local_search: Lmax=%d must stay below %d", Lmax, LS_MAXL); return DACO_E_TOOLARGE; }
-  const int n4 = (n + 3) & ~3;
   const bool stage = n <= LS_STAGE_MAX_N;
-  const size_t lds = (size_t)2 * LS_MAXL * 8 + (size_t)2 * (LS_MAXR + 1) * 8 + (size_t)2 * (LS_MAXL + 4) * 2 + (size_t)LS_MAXL * 2 +
-                     (size_t)(LS_MAXR + 2) * 2 + 8 * 4 + 32 * 4 + (size_t)n4 * 4 + (stage ? (size_t)n * n * 4 : 0) + 16;
+  const size_t lds = ls_fixed_bytes(Lmax, n) + (stage ? (size_t)n * n * 4 : 0);
   hipStream_t s = (hipStream_t)stream;
-  if (stage) {
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void *)cvrp_ls_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) { set_error("daco_cvrp_local_search: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return DACO_E_HIP; }
-    }
-    hipLaunchKernelGGL((cvrp_ls_kernel<true>), dim3(B * A), dim3(256), lds, s, n, A, Lmax, dist, dist_bstride, demand, capacity, paths,
-                       max_moves, lens, moves);
-  } else {
-    hipLaunchKernelGGL((cvrp_ls_kernel<false>), dim3(B * A), dim3(256), lds, s, n, A, Lmax, dist, dist_bstride, demand, capacity, paths,
-                       max_moves, lens, moves);
-  }
+  // threads per solution: the pair loop is a chain of LDS look-ups -- with the matrix staged only three workgroups fit a CU, and
+  // eight wavefronts each keep it busier than four (DACO_CVRP_LS_THREADS: 256 | 512)
+  static const int nt_env = getenv("DACO_CVRP_LS_THREADS") ? atoi(getenv("DACO_CVRP_LS_THREADS")) : 0;
+  // (measured at CVRP-100, 64 x 512 solutions: 256 / 512 / 1024 threads -> 67.8 / 93.2 / 57.5 k solutions/s; without the staged
+  // matrix a workgroup's LDS is small and eight of 256 threads fill the CU: unchanged)
+  const int nt = nt_env == 256 || nt_env == 512 || nt_env == 1024 ? nt_env : (stage ? 512 : 256);
+#define DACO_LS_LAUNCH(STAGE_, NT_)                                                                                              \
+  do {                                                                                                                             \
+    if (lds > 64 * 1024) {                                                                                                         \
+      hipError_t e_ = hipFuncSetAttribute((const void *)cvrp_ls_kernel<STAGE_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e_ != hipSuccess) { set_error("daco_cvrp_local_search: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e_)); return DACO_E_HIP; } \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((cvrp_ls_kernel<STAGE_, NT_>), dim3(B * A), dim3(NT_), lds, s, n, A, Lmax, dist, dist_bstride, demand, capacity, \
+                       paths, max_moves, lens, moves);                                                                             \
+  } while (0)
+  if (stage) { if (nt == 1024) DACO_LS_LAUNCH(true, 1024); else if (nt == 512) DACO_LS_LAUNCH(true, 512); else DACO_LS_LAUNCH(true, 256); }
+  else { if (nt == 1024) DACO_LS_LAUNCH(false, 1024); else if (nt == 512) DACO_LS_LAUNCH(false, 512); else DACO_LS_LAUNCH(false, 256); }
+#undef DACO_LS_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("cvrp_ls_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
