@@ -22,6 +22,7 @@
 // row: the row scan masks the steps that would cross the group boundary, S comes from two row broadcasts and a select, the
 // step's uniform from the LDS crossbar (ds_bpermute, issued at the top of the step), the choice reaches the group through a
 // quad / half-mirror OR butterfly.
+#include <type_traits>
 #include "daco_sample_kernel.h"
 
 namespace daco {
@@ -79,7 +80,7 @@ __device__ inline int group_or(int x) {
 // CH: chunks of 64 candidates (n <= 64 * CH; CH <= 4 in production, TSP up to 8 = n <= 512 as a measured alternative
 // to the two-ants-per-wavefront kernel).
 template <int LPA, int CH, bool LOGP, bool CVRP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256)   // (asking for five waves per SIMD at CVRP-100 -- 96 registers instead of 102 -- was measured: 0.546 -> 0.59 ms)
 scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) {
   static_assert(LPA == 16 || LPA == 8 || LPA == 4, "lanes per ant");
   constexpr int LG = LPA == 16 ? 4 : LPA == 8 ? 3 : 2;
@@ -98,9 +99,14 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   // j = c*4 + v of lane s is node c*(4 LPA) + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
   __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
-  __shared__ uint32_t hub_s[APB][16];                   // CVRP: per ant, set of nodes that follow the depot (n <= 512)
+  constexpr int HW = (ROWF + 31) / 32;
+  __shared__ uint32_t hub_s[APB][HW];                   // CVRP: per ant, set of nodes that follow the depot (bitmap over the padded row)
   __shared__ int len_s[APB];                            // CVRP: rows used by each ant (0: slot holds no ant)
-  extern __shared__ __attribute__((aligned(16))) uint16_t tour_s[];   // [APB][TL]
+  // the tours: node ids as bytes when every id fits one (n <= 256) -- half the LDS of the workgroup's largest array, i.e. one
+  // more workgroup per CU at CVRP-100 (routes of up to 2n + 1 entries)
+  using tour_t = std::conditional_t<(ROWF <= 256), uint8_t, uint16_t>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tour_raw[];
+  tour_t *tour_s = reinterpret_cast<tour_t *>(tour_raw);   // [APB][TL]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane / LPA, s = lane & (LPA - 1);
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -112,7 +118,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   if constexpr (CVRP) {
     for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
-    for (int k = threadIdx.x; k < APB * 16; k += 256) hub_s[k >> 4][k & 15] = 0u;
+    for (int k = threadIdx.x; k < APB * HW; k += 256) (&hub_s[0][0])[k] = 0u;
     if (threadIdx.x < APB) len_s[threadIdx.x] = 0;
     __syncthreads();
   }
@@ -127,7 +133,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   float *logp_a = LOGP ? p.logp + (size_t)b * (rows - 1) * A + a : nullptr;
   float *rs_a = (LOGP && p.rowsum) ? p.rowsum + (size_t)b * (rows - 1) * A + a : nullptr;
   _Float16 *fl = open_flags[wave * APW + q];
-  uint16_t *tour = tour_s + (size_t)(wave * APW + q) * TL;
+  tour_t *tour = tour_s + (size_t)(wave * APW + q) * TL;
   // flag index of node k (chunk c = k / (4 LPA)): 16-byte group c >> 1, lane (k>>2) % LPA, element (c & 1)*4 + (k&3)
   auto flag_index = [](int k) {
     const int c = k / (LPA * 4);
@@ -157,7 +163,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     __builtin_amdgcn_wave_barrier();
     if (s == 0) {
       if constexpr (!CVRP) fl[flag_index(prev)] = (_Float16)0.0f;        // the depot is never closed for good
-      tour[0] = (uint16_t)prev;
+      tour[0] = (tour_t)prev;
     }
     __builtin_amdgcn_wave_barrier();
     int remaining = n - 1;
@@ -273,7 +279,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
       // ---- outputs: lane 0 of every row that is still building
       const bool writer = __builtin_amdgcn_inverse_ballot_w64(act & LEAD);
       if (writer) {
-        tour[t] = (uint16_t)choice;
+        tour[t] = (tour_t)choice;
         if constexpr (LOGP) {
           const float pc = *(const float *)(Pb + rowoff + (uint32_t)choice * 4u);
           logp_a[(size_t)(t - 1) * A] = clamp_log(pc / S);
@@ -349,7 +355,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
         const int t = base + lane;
 #pragma unroll
         for (int r4 = 0; r4 < APW; ++r4) {
-          const uint16_t *tr = tour_s + (size_t)(wave * APW + r4) * TL;
+          const tour_t *tr = tour_s + (size_t)(wave * APW + r4) * TL;
           const int lr = CVRP ? len_s[wave * APW + r4] : n;
           float dv = 0.0f;
           if (t < lr) dv = CVRP ? dist_b[(uint32_t)tr[t - 1] * (uint32_t)n + tr[t]] : dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]];
@@ -381,7 +387,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     __syncthreads();
     if (k16 < nant) {
       const int lk = CVRP ? len_s[k16] : n;
-      const uint16_t *tk = tour_s + (size_t)k16 * TL;
+      const tour_t *tk = tour_s + (size_t)k16 * TL;
       for (int t = threadIdx.x / APB; t < lk; t += TSTEP) {
         const int v = tk[t];
         if (!CVRP || v != 0) inv[k16][v] = (uint16_t)t;
@@ -391,7 +397,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     __syncthreads();
     uint32_t *nb = p.nbr + (size_t)b * n * A + abase;
     if (k16 < nant) {
-      const uint16_t *tk = tour_s + (size_t)k16 * TL;
+      const tour_t *tk = tour_s + (size_t)k16 * TL;
       for (int node = threadIdx.x / APB; node < n; node += TSTEP) {
         const int t = inv[k16][node];
         if constexpr (CVRP) {
@@ -417,7 +423,7 @@ static hipError_t launch16(const SampleParams &sp, bool logp, hipStream_t s) {
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
   const int rows = CVRP ? sp.Lmax : sp.n;
   const int TL = (rows + 7) & ~7;
-  const size_t dyn = (size_t)APB * TL * sizeof(uint16_t);
+  const size_t dyn = (size_t)APB * TL * (CH * LPA * 4 <= 256 ? 1 : 2);
   if (logp) hipLaunchKernelGGL((scan16_kernel<LPA, CH, true, CVRP>), grid, block, dyn, s, sp, TL);
   else hipLaunchKernelGGL((scan16_kernel<LPA, CH, false, CVRP>), grid, block, dyn, s, sp, TL);
   return hipGetLastError();
