@@ -1,27 +1,26 @@
-// daco_scan16.hip -- tour construction for small instances (n <= 256), prefix-scan draw, FOUR ants
-// per wavefront: TSP (tsp/aco.py:134-177, tsp_nls/aco.py:184-220) and CVRP (cvrp/aco.py:138-205).
+// daco_scan16.hip -- tour construction for small instances, prefix-scan draw, SEVERAL ants per wavefront:
+// TSP (tsp/aco.py:134-177, tsp_nls/aco.py:184-220; n <= 256) and CVRP (cvrp/aco.py:138-205; n <= 512).
 //
-// At n <= 256 a row is at most 1 KiB: the step is bound by instruction issue and by the latency of its
-// dependent chain, not by bytes, so the per-step overhead is shared by four ants.  Each 16-lane DPP row of
-// a wave builds one tour (candidate k of an ant sits in lane s = (k/4) % 16 of its row, chunk c = k/64).
+// scan16_kernel<LPA, CH, LOGP, CVRP>: LPA lanes per ant -- 4 for n <= 128 (sixteen ants per wavefront), 8 for n <= 256 (eight),
+// 16 for CVRP with 256 < n <= 512 and behind DACO_SCAN_LAYOUT=16 (four: the layout of rounds 1-2).  At these sizes a row is at
+// most 2 KiB and the step is bound by instruction issue and by the latency of its dependent chain, not by bytes: the per-step
+// overhead (scan, compare, search, OR-reduce, flag and tour stores: ~55 instructions whatever the row length) is shared by the
+// ants of a wavefront, an ant-step costs about 55 * LPA / 64 + 5 instructions.  Candidate k of an ant sits in
+// lane s = (k/4) % LPA of its group, chunk c = k / (4 LPA).
 // Same structure as tsp_scan32_kernel (daco_tsp_scan32.hip), which an ablation study motivated:
-//   * level 1: DPP row scan of the 16 lane sums (no cross-row step), S and the step's uniform by row_newbcast,
-//     the first lane with incl >= u*S per row from the compare mask with bit arithmetic on its four 16-bit fields;
-//   * level 2 INSIDE the chosen lane: every lane keeps the running sums of its own <= 16 masked candidates and the
-//     chosen one finds its candidate by a binary search over them (count_below); the choice reaches the lanes of
-//     the row by a rotate-OR all-reduce (four v_or_b32_dpp) -- nothing is handed through LDS;
-//   * visited flags are f16 0/1 in LDS (v_fma_mix_f32 for TSP; CVRP combines them with the capacity and depot
-//     rules first), the tour stays in LDS and paths / route costs / the update's table leave the workgroup together in
-//     an epilogue (128-byte runs of 16 ants).
-// Draw semantics: the scan specification of DESIGN.md section 4 with 16 lanes; the GPU tests hold it bit-exact
-// against the CPU restatement of that specification.
-// Round 3: the kernel is a template over LPA, the lanes per ant.  LPA = 8 (EIGHT ants per wavefront, candidate k in lane
-// (k/4) % 8 of its group, chunk k/32, up to 16 slots per lane) serves n <= 128: at TSP-100 / CVRP-100 a row is 400 bytes and the
-// step is all per-step overhead (scan, search, selects: ~65 VALU instructions per wave-step whatever the row length), so
-// sharing it between eight ants instead of four halves the instructions per ant-step.  Two 8-lane groups share a 16-lane DPP
-// row: the row scan masks the steps that would cross the group boundary, S comes from two row broadcasts and a select, the
-// step's uniform from the LDS crossbar (ds_bpermute, issued at the top of the step), the choice reaches the group through a
-// quad / half-mirror OR butterfly.
+//   * level 1: DPP scan of the group's lane sums (Kogge-Stone; with several groups per 16-lane DPP row the steps that would
+//     cross a group boundary add +0.0f), S by quad_perm / row_newbcast, the step's uniform from the group's cached Philox block
+//     (LPA = 16: rotated through lane 15; else read through the LDS crossbar, ds_bpermute), the first lane with incl >= u*S per
+//     group from the compare mask with bit arithmetic on its LPA-bit fields;
+//   * level 2 INSIDE the chosen lane: every lane keeps the running sums of its own <= 32 masked candidates and the
+//     chosen one finds its candidate by a binary search over them (count_below32); the choice reaches the lanes of
+//     the group by a rotate-OR / quad-perm butterfly all-reduce -- nothing is handed through LDS;
+//   * visited flags are f16 0/1 in LDS (the second operand of v_fma_mix_f32; CVRP applies the capacity and depot rules to
+//     the f32 row value first), the tours stay in LDS (bytes for n <= 256) and paths / route costs / the update's table
+//     leave the workgroup together in an epilogue (runs of 16 / 32 / 64 ants; the edge staging of the costs lives in the
+//     flag array, dead by then).
+// Draw semantics: the scan specification of DESIGN.md section 4 with `lanes` = LPA; the GPU tests hold every layout
+// bit-exact against the CPU restatement of that specification (which honours DACO_SCAN_LAYOUT like the library).
 #include <type_traits>
 #include "daco_sample_kernel.h"
 
