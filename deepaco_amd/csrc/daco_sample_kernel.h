@@ -72,10 +72,10 @@ __device__ inline void load_vec(const float *p, float (&out)[VEC]) {
   }
 }
 
-// P = tau^alpha * eta^beta with zero padding; R = 1/P with +inf padding (optional); defined in
-// daco_tsp_sample.hip
-__global__ void prob_matrix_kernel(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs,
-                                   float alpha, float beta, float *P, float *R);
+// P = tau^alpha * eta^beta with zero padding; R = 1/P with +inf padding (optional): launches prob_matrix_kernel
+// (daco_tsp_sample.hip)
+void launch_prob_matrix(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha,
+                        float beta, float *P, float *R, hipStream_t s);
 
 // visited bitset: bit (c*VEC+v) of a 64-bit word kept as two 32-bit halves so every test is a
 // single 32-bit v_and/v_cmp (the upper half folds away when CH*VEC <= 32)

@@ -70,8 +70,7 @@ extern "C" int daco_sibling_sample(void *stream, int kind, int B, int n, int A, 
   const long total = (long)B * n * ld;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha,
-                     beta, P, R);
+  launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, R, s);
   if (aux_mat)
     hipLaunchKernelGGL(pad_matrix_kernel, dim3(blocks), dim3(256), 0, s, B, n, ld, aux_mat, aux_mat_bstride, auxp, 0.0f);
   SampleParams sp;

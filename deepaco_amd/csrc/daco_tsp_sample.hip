@@ -15,24 +15,49 @@
 
 namespace daco {
 
-// P = tau^alpha * eta^beta with zero padding; R = 1/P with +inf padding (optional)
+// P = tau^alpha * eta^beta with zero padding; R = 1/P with +inf padding (optional).  A pure stream (two matrices in, one or
+// two out): one workgroup per row and grid-stride over the rows, 16-byte accesses when the rows allow it (n % 4 == 0 and
+// aligned bases; the padded output rows always do), no integer division per element.
+template <bool VEC4>
 __global__ void __launch_bounds__(256)
 prob_matrix_kernel(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs,
                    float alpha, float beta, float *P, float *R) {
-  const long total = (long)B * n * ld;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % ld);
-    const long row = i / ld;            // b*n + r
-    const int b = (int)(row / n), r = (int)(row % n);
-    float p = 0.0f;
-    if (k < n) {
-      const float t = tau[b * tau_bs + (long)r * n + k];
-      const float e = eta[b * eta_bs + (long)r * n + k];
-      p = pw(t, alpha) * pw(e, beta);
+  const int rows = B * n;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = row / n, r = row - b * n;
+    const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
+    float *pr = P + (size_t)row * ld, *rr = R ? R + (size_t)row * ld : nullptr;
+    if constexpr (VEC4) {
+      for (int k = threadIdx.x * 4; k < ld; k += 1024) {
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 q = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
+        if (k < n) {                                          // (n % 4 == 0: a vector is inside the row or in the padding)
+          const float4 t = *reinterpret_cast<const float4 *>(tr + k), e = *reinterpret_cast<const float4 *>(er + k);
+          p.x = pw(t.x, alpha) * pw(e.x, beta); p.y = pw(t.y, alpha) * pw(e.y, beta);
+          p.z = pw(t.z, alpha) * pw(e.z, beta); p.w = pw(t.w, alpha) * pw(e.w, beta);
+          if (rr) { q.x = 1.0f / p.x; q.y = 1.0f / p.y; q.z = 1.0f / p.z; q.w = 1.0f / p.w; }
+        }
+        *reinterpret_cast<float4 *>(pr + k) = p;
+        if (rr) *reinterpret_cast<float4 *>(rr + k) = q;
+      }
+    } else {
+      for (int k = threadIdx.x; k < ld; k += 256) {
+        float p = 0.0f;
+        if (k < n) p = pw(tr[k], alpha) * pw(er[k], beta);
+        pr[k] = p;
+        if (rr) rr[k] = k < n ? 1.0f / p : __builtin_inff();
+      }
     }
-    P[i] = p;
-    if (R) R[i] = k < n ? 1.0f / p : __builtin_inff();
   }
+}
+
+void launch_prob_matrix(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha,
+                               float beta, float *P, float *R, hipStream_t s) {
+  const long rows = (long)B * n;
+  const int blocks = (int)(rows < 16384 ? rows : 16384);
+  const bool vec4 = (n & 3) == 0 && (tau_bs & 3) == 0 && (eta_bs & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
+  if (vec4) hipLaunchKernelGGL(prob_matrix_kernel<true>, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bs, eta, eta_bs, alpha, beta, P, R);
+  else hipLaunchKernelGGL(prob_matrix_kernel<false>, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bs, eta, eta_bs, alpha, beta, P, R);
 }
 
 }  // namespace daco
@@ -78,11 +103,7 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
   float *P = (float *)workspace;
   float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
   {
-    const long total = (long)B * n * ld;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta,
-                       eta_bstride, alpha, beta, P, R);
+    launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, R, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("prob_matrix_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   }
@@ -144,11 +165,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   float *P = (float *)workspace;
   float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
   {
-    const long total = (long)B * n * ld;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta,
-                       eta_bstride, alpha, beta, P, R);
+    launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, R, s);
   }
   SampleParams sp;
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
@@ -180,11 +197,7 @@ extern "C" int daco_prob_matrix(void *stream, int B, int n, const float *tau, lo
   const int ld = ld_alloc(n);
   float *P = (float *)workspace;
   float *R = mode == DACO_RACE_PHILOX ? (float *)((char *)workspace + need / 2) : nullptr;
-  const long total = (long)B * n * ld;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(prob_matrix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, n, ld, tau, tau_bstride, eta,
-                     eta_bstride, alpha, beta, P, R);
+  launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, R, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("prob_matrix_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
