@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/exp_nls_relabel.py 2>&1 | grep labelling
+timeout 600 python -m pytest tests/test_gpu_10_layout_knob.py -x -q -m gpu 2>&1 | tail -5
