@@ -1,10 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3h
-O=gpurun_out/r3h
-R=$GRAFT_REPO_ROOT
-(cd $R && python bench.py > $O/bench_default.json 2> $O/bench_default.log)
-cd /tmp; export TMPDIR=/tmp
-(cd $R && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -o p -- python bench.py --no-cpu --min-seconds 0 > $R/$O/bench_profiled.log 2>&1)
-cp $R/$O/stats/p_kernel_stats.csv $R/$O/kernel_stats_bench_default.csv
-grep -h '^{' $R/$O/bench_default.json | cut -c1-260
+mkdir -p gpurun_out/r3i
+O=gpurun_out/r3i
+timeout 900 python -m pytest tests/test_gpu_00_tsp.py tests/test_gpu_02_cvrp.py -x -q -m gpu > $O/tests.txt 2>&1
+tail -2 $O/tests.txt
+for S in lds regs; do DACO_SCAN_SEARCH=$S timeout 300 python tools/measure_configs.py c2 c4 2>&1 | grep '^{' | cut -c1-200; done
