@@ -78,7 +78,7 @@ __device__ inline int group_or(int x) {
 
 // CH: chunks of 64 candidates (n <= 64 * CH; CH <= 4 in production, TSP up to 8 = n <= 512 as a measured alternative
 // to the two-ants-per-wavefront kernel).
-template <int LPA, int CH, bool LOGP, bool CVRP>
+template <int LPA, int CH, bool LOGP, bool CVRP, bool F64 = false>
 __global__ void __launch_bounds__(256)   // (asking for five waves per SIMD at CVRP-100 -- 96 registers instead of 102 -- was measured: 0.546 -> 0.59 ms)
 scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) {
   static_assert(LPA == 16 || LPA == 8 || LPA == 4, "lanes per ant");
@@ -93,11 +93,13 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   constexpr int CB = LPA * 16;                          // bytes of a row chunk
   static_assert(!CVRP || ROWF <= 512, "CVRP: n <= 512 (hub bitmap, demand row)");
   static_assert(LPA == 16 || NJ <= 32, "eight / sixteen ants per wavefront: up to 32 candidates per lane");
-  constexpr bool DEM_REGS = LPA == 16 && CH <= 4;       // CVRP: the lane's demands stay in registers / are read from LDS every step
+  static_assert(!F64 || CVRP, "float64 load bookkeeping is CVRP's (cvrp_nls/aco.py:254-272)");
+  constexpr bool DEM_REGS = LPA == 16 && CH <= 4 && !F64;       // CVRP: the lane's demands stay in registers / are read from LDS every step
   // open[ant][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited, else 0.0; slot
   // j = c*4 + v of lane s is node c*(4 LPA) + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
   __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];
   __shared__ __attribute__((aligned(16))) float dem_s[CVRP ? ROWF : 4];   // CVRP: demand, +inf padding
+  __shared__ __attribute__((aligned(16))) double dem64_s[F64 ? ROWF : 2]; // cvrp_nls: the float64 demands (load bookkeeping in double)
   constexpr int HW = (ROWF + 31) / 32;
   __shared__ uint32_t hub_s[APB][HW];                   // CVRP: per ant, set of nodes that follow the depot (bitmap over the padded row)
   __shared__ int len_s[APB];                            // CVRP: rows used by each ant (0: slot holds no ant)
@@ -117,6 +119,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);   // a captured graph advances *iter_dev
   if constexpr (CVRP) {
     for (int k = threadIdx.x; k < ROWF; k += 256) dem_s[k] = k < n ? p.demand[(size_t)b * n + k] : __builtin_inff();
+    if constexpr (F64) for (int k = threadIdx.x; k < ROWF; k += 256) dem64_s[k] = k < n ? p.demand64[(size_t)b * n + k] : (double)__builtin_inff();
     for (int k = threadIdx.x; k < APB * HW; k += 256) (&hub_s[0][0])[k] = 0u;
     if (threadIdx.x < APB) len_s[threadIdx.x] = 0;
     __syncthreads();
@@ -167,6 +170,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
     __builtin_amdgcn_wave_barrier();
     int remaining = n - 1;
     float used = CVRP ? 0.0f + dem_s[0] : 0.0f;
+    double used64 = F64 ? 0.0 + dem64_s[0] : 0.0;
     finished = CVRP ? remaining == 0 : false;
     u32x4 ublk = {0, 0, 0, 0};                          // 4 LPA cached uniforms per ant
     float ucur = 0.0f;                                  // LPA = 16: rotated once per step, lane 15 holds the current step's uniform
@@ -208,20 +212,26 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
 
       // ---- the lane's running sums in slot order (closed slots add p*0 = +0.0f; the product with a 0/1 factor is exact)
       const float rem = CVRP ? p.capacity - used : 0.0f;
+      const double rem64 = F64 ? p.capacity64 - used64 : 0.0;
       float run[32];
       float acc = 0.0f;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int e = (c & 1) * 4;
         const float rv[4] = {row[c].x, row[c].y, row[c].z, row[c].w};
-        const float4 dmc = (CVRP && !DEM_REGS) ? *(const float4 *)(dem_s + (c * LPA + s) * 4) : dm[DEM_REGS ? c : 0];
+        const float4 dmc = (CVRP && !DEM_REGS && !F64) ? *(const float4 *)(dem_s + (c * LPA + s) * 4) : dm[DEM_REGS ? c : 0];
         const float dv[4] = {dmc.x, dmc.y, dmc.z, dmc.w};
+        double dv64[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (F64) {
+          const double2 d01 = *(const double2 *)(dem64_s + (c * LPA + s) * 4), d23 = *(const double2 *)(dem64_s + (c * LPA + s) * 4 + 2);
+          dv64[0] = d01.x; dv64[1] = d01.y; dv64[2] = d23.x; dv64[3] = d23.y;
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           if constexpr (CVRP) {
             // the capacity and depot rules select on the f32 row value, the visited flag stays the f16 operand of the fma
             // (a blocked candidate adds 0*f = +0.0f like a visited one adds p*0)
-            float pv = dv[v] > rem ? 0.0f : rv[v];                           // strict, cvrp/aco.py:200
+            float pv = (F64 ? dv64[v] > rem64 : dv[v] > rem) ? 0.0f : rv[v];   // strict, cvrp/aco.py:200 (cvrp_nls: in double, :267-270)
             if (c == 0 && v == 0) pv = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : pv;   // the depot, cvrp/aco.py:179
             acc = __builtin_fmaf(pv, (float)fo[c >> 1][e + v], acc);
           } else {
@@ -254,13 +264,13 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
           const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * GS + s * 8);
           const int e = (c & 1) * 4;
           const float rv[4] = {rw.x, rw.y, rw.z, rw.w};
-          const float4 dmc = (CVRP && !DEM_REGS) ? *(const float4 *)(dem_s + (c * LPA + s) * 4) : dm[DEM_REGS ? c : 0];
+          const float4 dmc = (CVRP && !DEM_REGS && !F64) ? *(const float4 *)(dem_s + (c * LPA + s) * 4) : dm[DEM_REGS ? c : 0];
           const float dv[4] = {dmc.x, dmc.y, dmc.z, dmc.w};
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
             float f = (float)ff[e + v];
             if constexpr (CVRP) {
-              f = dv[v] > rem ? 0.0f : f;
+              f = (F64 ? dem64_s[(c * LPA + s) * 4 + v] > rem64 : dv[v] > rem) ? 0.0f : f;
               if (c == 0 && v == 0) f = (s == 0 && prev == 0 && remaining > 0) ? 0.0f : f;
             }
             last = rv[v] * f > 0.0f ? 4 * c + v : last;
@@ -293,6 +303,7 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
         remaining -= moved ? 1 : 0;
         const float load = moved ? used : 0.0f;            // back at the depot the load restarts from 0
         used = live ? load + dem_s[choice] : used;
+        if constexpr (F64) { const double load64 = moved ? used64 : 0.0; used64 = live ? load64 + dem64_s[choice] : used64; }
         finished = finished || (remaining == 0 && choice == 0);
         len = live ? t + 1 : len;
         prev = finished ? 0 : choice;
@@ -417,6 +428,17 @@ scan16_kernel(const SampleParams p, const int TL /* entries per tour buffer */) 
 
 template <int LPA, int CH, bool CVRP>
 static hipError_t launch16(const SampleParams &sp, bool logp, hipStream_t s) {
+  if constexpr (CVRP) {                                 // cvrp_nls: float64 demands
+    if (sp.demand64) {
+      constexpr int APB64 = 4 * (64 / LPA);
+      dim3 grid64((unsigned)(sp.B * ((sp.A + APB64 - 1) / APB64))), block64(256);
+      const int TL64 = (sp.Lmax + 7) & ~7;
+      const size_t dyn64 = (size_t)APB64 * TL64 * (CH * LPA * 4 <= 256 ? 1 : 2);
+      if (logp) hipLaunchKernelGGL((scan16_kernel<LPA, CH, true, true, true>), grid64, block64, dyn64, s, sp, TL64);
+      else hipLaunchKernelGGL((scan16_kernel<LPA, CH, false, true, true>), grid64, block64, dyn64, s, sp, TL64);
+      return hipGetLastError();
+    }
+  }
   constexpr int APB = 4 * (64 / LPA);
   const int bpi = (sp.A + APB - 1) / APB;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);

@@ -140,7 +140,9 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
   const bool packed = mode == DACO_SCAN && (size_t)n * A * 8 < ((size_t)1 << 32);
   // (float64 load bookkeeping: the one-ant-per-wavefront kernel's PROB_CVRP64 policy)
-  const bool four_per_wave = packed && !demand64 && n <= DACO_SCAN32_MAX_N;      // scan16_kernel family (4 / 8 / 16 lanes per ant)
+  // scan16_kernel family (4 / 8 / 16 lanes per ant), float32 or float64 load bookkeeping (above 512 nodes and in the race modes: the
+  // one-ant-per-wavefront kernel's PROB_CVRP / PROB_CVRP64 policies)
+  const bool four_per_wave = packed && n <= DACO_SCAN32_MAX_N;
   if (mode == DACO_SCAN_WAVE) mode = DACO_SCAN;
   if (mode < 0 || mode > 2) { set_error("daco_cvrp_sample: bad mode %d", mode); return DACO_E_BADARG; }
   if (mode == DACO_RACE_NOISE && (!noise || noise_steps <= 0)) { set_error("daco_cvrp_sample: DACO_RACE_NOISE needs a noise tensor"); return DACO_E_BADARG; }

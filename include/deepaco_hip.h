@@ -145,7 +145,8 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *            cvrp_nls/aco.py:254-272 (used = used + demand[cur]; demand > capacity - used) then runs in double, as it
  *            does in the reference for that directory's float64 instance data (demands k / capacity: a customer that
  *            fits exactly is common and the last bit decides); `demand` / `capacity` must still be given (their float32
- *            images); the construction then runs on the one-ant-per-wavefront kernel for every n.
+ *            images).  Every layout of the scan draw has the variant (packed kernels for n <= 512, one ant per wavefront above and in the
+ *            race modes).
  *   ev_begin, ev_end   optional hipEvent_t recorded on `stream` right before / after the construction kernel (as in
  *            daco_tsp_sample: the kernel alone, without the weight-matrix kernel and the table memsets before it).
  */

@@ -211,16 +211,24 @@ def cvrp_sample_noise(P, demand, capacity, noise, Lmax=None, require_prob=True):
 
 
 def cvrp_sample_rng(P, demand, capacity, A, mode, seed, it=0, ant_gid0=0, Lmax=None, require_prob=False):
-    """mode: 'race' or 'scan' (Philox); returns (paths[:L], logp[:L-1] | None, L)."""
+    """mode: 'race' or 'scan' (Philox); returns (paths[:L], logp[:L-1] | None, L).  A float64 `demand` (cvrp_nls/ keeps its
+    data in double) decides the capacity mask in double, cvrp_nls/aco.py:254-272."""
+    f64 = np.asarray(demand).dtype == np.float64
+    demand64 = np.ascontiguousarray(demand, dtype=np.float64) if f64 else None
     P, demand = _f32(P), _f32(demand)
     n1 = P.shape[0]
     Lmax = Lmax or 2 * n1 + 1
     paths = np.zeros((Lmax, A), dtype=np.int64)
     logp = np.zeros((Lmax - 1, A), dtype=np.float32) if require_prob else None
     m = {"race": 1, "scan": 2, "scan_wave": 3}[mode]
-    L = lib().orc_cvrp_sample(m, n1, A, _p(P), _p(demand), C.c_float(capacity), None, 0, C.c_uint64(seed),
-                              C.c_uint64(it), C.c_uint32(ant_gid0), Lmax, _p(paths),
-                              _p(logp) if require_prob else None)
+    if f64:
+        L = lib().orc_cvrp_sample64(m, n1, A, _p(P), _p(demand), _p(demand64), C.c_double(capacity), None, 0, C.c_uint64(seed),
+                                    C.c_uint64(it), C.c_uint32(ant_gid0), Lmax, _p(paths),
+                                    _p(logp) if require_prob else None)
+    else:
+        L = lib().orc_cvrp_sample(m, n1, A, _p(P), _p(demand), C.c_float(capacity), None, 0, C.c_uint64(seed),
+                                  C.c_uint64(it), C.c_uint32(ant_gid0), Lmax, _p(paths),
+                                  _p(logp) if require_prob else None)
     if L < 0:
         return None, None, L
     return paths[:L], (logp[:L - 1] if require_prob else None), L

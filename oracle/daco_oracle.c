@@ -551,9 +551,10 @@ void orc_roulette_route(int n, const float *probmat, const double *uniforms, int
  * candidate, probability 1) and its column is padded with 0.
  * noise: [noise_steps][A][n1]; paths: [Lmax][A] zero-initialised by the caller.
  * Returns L (number of rows used, max over ants) or -1 on infeasible/overflow. */
-int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand, float capacity,
-                    const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
-                    uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp) {
+static int cvrp_sample_impl(int mode, int n1, int A, const float *P, const float *demand, float capacity,
+                            const double *demand64, double capacity64,
+                            const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
+                            uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp) {
   float *p = (float *)malloc(sizeof(float) * n1);
   unsigned char *vis = (unsigned char *)malloc(n1);
   unsigned char *blocked = (unsigned char *)malloc(n1);
@@ -565,14 +566,17 @@ int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand
     int prev = 0, remaining = n1 - 1, len = 1;
     float used = 0.0f;
     used = used + demand[0];
+    double used64 = 0.0;                 /* cvrp_nls keeps its data in float64: the load bookkeeping then runs in double */
+    if (demand64) used64 = used64 + demand64[0];
     paths[a] = 0;
     while (!(remaining == 0 && prev == 0)) {
       if (len >= Lmax || (mode == MODE_NOISE && len - 1 >= noise_steps)) { fail = 1; break; }
       const float *row = P + (long)prev * n1;
       float rem = capacity - used;
+      double rem64 = capacity64 - used64;
       for (int k = 0; k < n1; ++k) {
         int visit_ok = (k == 0) ? !(prev == 0 && remaining > 0) : !vis[k];
-        int cap_ok = !(demand[k] > rem);
+        int cap_ok = demand64 ? !(demand64[k] > rem64) : !(demand[k] > rem);      /* cvrp_nls/aco.py:267-270 in double */
         blocked[k] = !(visit_ok && cap_ok);
       }
       float pr = 0.0f;
@@ -583,8 +587,9 @@ int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand
       if (best < 0) { fail = 1; break; }
       if (logp) logp[(long)(len - 1) * A + a] = clamp_log(pr);
       if (best != 0) { vis[best] = 1; --remaining; }
-      if (best == 0) used = 0.0f;
+      if (best == 0) { used = 0.0f; used64 = 0.0; }
       used = used + demand[best];
+      if (demand64) used64 = used64 + demand64[best];
       paths[(long)len * A + a] = best;
       prev = best;
       ++len;
@@ -598,6 +603,18 @@ int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand
       for (int k = lens[a]; k < L; ++k) logp[(long)(k - 1) * A + a] = clamp_log(1.0f);
   free(p); free(vis); free(blocked); free(lens);
   return fail ? -1 : L;
+}
+int orc_cvrp_sample(int mode, int n1, int A, const float *P, const float *demand, float capacity,
+                    const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
+                    uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp) {
+  return cvrp_sample_impl(mode, n1, A, P, demand, capacity, NULL, 0.0, noise, noise_steps, seed, iter, ant_gid0, Lmax, paths, logp);
+}
+/* float64 demands and capacity (cvrp_nls/): the capacity mask is decided in double; demand = their float32 image (unused by the mask) */
+int orc_cvrp_sample64(int mode, int n1, int A, const float *P, const float *demand, const double *demand64, double capacity64,
+                      const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
+                      uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp) {
+  return cvrp_sample_impl(mode, n1, A, P, demand, (float)capacity64, demand64, capacity64, noise, noise_steps, seed, iter, ant_gid0,
+                          Lmax, paths, logp);
 }
 int orc_cvrp_sample_noise(int n1, int A, const float *P, const float *demand, float capacity,
                           const float *noise, int noise_steps, int Lmax, int64_t *paths,

@@ -244,3 +244,31 @@ def test_cvrp_nls_float64_instances_reproduce_the_reference_routes(name):
     loss.backward()
     assert bool(torch.isfinite(heu.grad).all()) and float(heu.grad.abs().max()) > 0
     assert heu.grad.shape == (len(g["demand"]), len(g["demand"]))
+
+
+@pytest.mark.parametrize("n,A,B", [(21, 18, 1), (51, 65, 1), (101, 33, 2), (128, 9, 1), (201, 12, 1), (256, 5, 1), (301, 4, 1), (512, 3, 1), (600, 2, 1)])
+def test_cvrp_float64_bookkeeping_in_the_scan_kernels_equals_the_oracle(n, A, B):
+    """cvrp_nls/ keeps demands in float64 (k / 50 of capacity 1: exact fits are common): with a float64 `demand` the capacity
+    mask is decided in double (cvrp_nls/aco.py:254-272) -- on every packed scan layout (4 / 8 / 16 lanes per ant, n <= 512; 600:
+    the one-ant-per-wavefront kernel).  Routes and log-probabilities against the oracle's float64 variant; the float32 image of the
+    same demands takes other routes somewhere in the batch (what the float64 path is for)."""
+    from deepaco_amd import engine
+    g = torch.Generator().manual_seed(900 + n)
+    tau = torch.rand(B, n, n, generator=g) + 0.1
+    eta = torch.rand(B, n, n, generator=g) + 1e-10
+    dem64 = torch.cat((torch.zeros(B, 1, dtype=torch.float64),
+                       torch.randint(1, 10, (B, n - 1), generator=g).double() / 50.0), 1)
+    seed, it = 24680, 3
+    paths, logp, _, lens, flags = engine.cvrp_sample(tau.to(dev()), eta.to(dev()), dem64.to(dev()), 1.0, A, mode="scan",
+                                                     seed=seed, it=it, require_prob=True)
+    assert int(flags.sum()) == 0
+    differs = False
+    for b in range(B):
+        P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+        rp, rl, L = oracle.cvrp_sample_rng(P, dem64[b].numpy(), 1.0, A, "scan", seed, it, ant_gid0=b * A, require_prob=True)
+        assert L == int(lens[b].max())
+        assert np.array_equal(paths[b, :L].cpu().numpy(), rp), (n, b)
+        np.testing.assert_allclose(logp[b, :L - 1].cpu().numpy(), rl, atol=3e-6, rtol=1e-5)
+        p32, _, L32 = oracle.cvrp_sample_rng(P, dem64[b].numpy().astype(np.float32), 1.0, A, "scan", seed, it, ant_gid0=b * A)
+        differs = differs or L32 != L or not np.array_equal(p32, rp)
+    assert differs or n < 30

@@ -1,7 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3j
-O=gpurun_out/r3j
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1
-tail -2 $O/tests.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+mkdir -p gpurun_out/r3k
+timeout 600 python -m pytest tests/test_gpu_02_cvrp.py -x -q -m gpu 2>&1 | tail -15
