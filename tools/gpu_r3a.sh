@@ -1,3 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_00_tsp.py tests/test_gpu_02_cvrp.py tests/test_gpu_10_layout_knob.py tests/test_gpu_09_cvrp_ls.py -x -q -m gpu 2>&1 | tail -3
+for L in 0 8 16; do DACO_SCAN_LAYOUT=$L timeout 200 python tools/run_train_step.py 2>&1 | tail -1 | cut -c1-160; done
+for L in 0 16; do DACO_SCAN_LAYOUT=$L timeout 200 python tools/time_layouts.py 100 30 20 2>&1 | tail -1; done
+for L in 0 16; do DACO_SCAN_LAYOUT=$L timeout 200 python tools/time_layouts.py 100 50 1 2>&1 | tail -1; done
