@@ -1,5 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for L in 0 8 16; do DACO_SCAN_LAYOUT=$L timeout 200 python tools/run_train_step.py 2>&1 | tail -1 | cut -c1-160; done
-for L in 0 16; do DACO_SCAN_LAYOUT=$L timeout 200 python tools/time_layouts.py 100 30 20 2>&1 | tail -1; done
-for L in 0 16; do DACO_SCAN_LAYOUT=$L timeout 200 python tools/time_layouts.py 100 50 1 2>&1 | tail -1; done
+mkdir -p gpurun_out/r3l
+O=gpurun_out/r3l
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1
+tail -2 $O/tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 200 python bench.py --no-cpu --no-extras --min-seconds 0 2>/dev/null | grep '^{' | cut -c1-220
