@@ -197,14 +197,22 @@ def roulette_route(probmat, uniforms, start=0):
 
 
 def cvrp_sample_noise(P, demand, capacity, noise, Lmax=None, require_prob=True):
+    """recorded-noise draw (the reference's torch.multinomial arithmetic).  A float64 `demand` decides the capacity mask in
+    double, as cvrp_nls/aco.py:254-272 does on that directory's float64 data."""
+    f64 = np.asarray(demand).dtype == np.float64
+    demand64 = np.ascontiguousarray(demand, dtype=np.float64) if f64 else None
     P, demand, noise = _f32(P), _f32(demand), _f32(noise)
     n1 = P.shape[0]
     steps, A = noise.shape[0], noise.shape[1]
     Lmax = Lmax or 2 * n1 + 1
     paths = np.zeros((Lmax, A), dtype=np.int64)
     logp = np.zeros((Lmax - 1, A), dtype=np.float32) if require_prob else None
-    L = lib().orc_cvrp_sample_noise(n1, A, _p(P), _p(demand), C.c_float(capacity), _p(noise), steps,
-                                    Lmax, _p(paths), _p(logp) if require_prob else None)
+    if f64:
+        L = lib().orc_cvrp_sample64(0, n1, A, _p(P), _p(demand), _p(demand64), C.c_double(capacity), _p(noise), steps,
+                                    C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), Lmax, _p(paths), _p(logp) if require_prob else None)
+    else:
+        L = lib().orc_cvrp_sample_noise(n1, A, _p(P), _p(demand), C.c_float(capacity), _p(noise), steps,
+                                        Lmax, _p(paths), _p(logp) if require_prob else None)
     if L < 0:
         return None, None, L
     return paths[:L], (logp[:L - 1] if require_prob else None), L

@@ -230,3 +230,19 @@ def test_gnn_restatement(name):
     n = g["x"].shape[0]
     if "cvrp" not in name:
         assert np.array_equal(gnn.reshape(n, g["edge_index"], g["heu_eval"]), g["heu_mat"])
+
+
+@pytest.mark.parametrize("name", ["g1f64_cvrp_nls_n20_a8", "g1f64_cvrp_nls_n50_a8", "g1f64_cvrp_nls_n100_a6"])
+def test_cvrp_float64_rule_reproduces_the_reference_routes(name):
+    """g1f64 (tests/golden/gen_g1_cvrp_nls.py): cvrp_nls/ keeps its demands in float64, its capacity mask (cvrp_nls/aco.py:254-272)
+    is decided in double.  The oracle's float64 variant -- what the packed scan kernels' F64 instantiations are held against on the
+    GPU -- reproduces the reference's routes on the recorded noise; the float32 image of the same demands does not."""
+    g = load_golden(name)
+    P = oracle.prob_matrix(g["pheromone"].astype(np.float32), g["heuristic"].astype(np.float32))
+    noise = g["noise"].astype(np.float32)
+    paths, logp, L = oracle.cvrp_sample_noise(P, g["demand"], float(g["capacity"]), noise)
+    assert g["demand"].dtype == np.float64 and L == g["paths"].shape[0]
+    assert np.array_equal(paths, g["paths"])
+    np.testing.assert_allclose(logp, g["log_probs"], atol=3e-6, rtol=2e-5)
+    p32, _, L32 = oracle.cvrp_sample_noise(P, g["demand"].astype(np.float32), float(g["capacity"]), noise)
+    assert L32 != L or not np.array_equal(p32, g["paths"])
