@@ -49,6 +49,7 @@ struct SampleParams {
   int Lmax;              // rows of paths (and Lmax-1 rows of logp)
   int noise_steps;       // rows of the noise tensor
   int32_t *lens;         // [B][A] rows used by each ant
+  int knob = 0;          // measurement knob of a kernel (0 in production)
 };
 
 template <class F, int... I>
@@ -618,20 +619,37 @@ inline int ld_alloc(int n) {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // ---- shared by the several-ants-per-wavefront kernels (daco_tsp_scan32.hip, daco_scan16.hip)
+constexpr int FCMP_OLT = 4;   // LLVM predicate for __builtin_amdgcn_fcmpf
+// x + y + (the lane's bit of carry): one v_addc_co_u32 (the carry-out goes to a scratch SGPR pair).  s_nop 1: gfx950
+// wants two wait states between a VALU write of an SGPR (the compare that made `carry`) and a VALU read of it, and the
+// hazard recogniser does not look inside the asm.
+__device__ inline int add_with_carry(int x, int y, uint64_t carry) {
+  int d;
+  uint64_t co;
+  asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d), "=&s"(co) : "v"(x), "v"(y), "s"(carry));
+  return d;
+}
 // number of j in 0..NJ-1 with run[j] < t for a nondecreasing run[] (binary search written as selects: 5 compares,
-// 11 v_cndmask, no dynamic register index); entries past NJ are +inf and fold away at compile time
+// 11 v_cndmask, no dynamic register index); entries past NJ are +inf and fold away at compile time.  The result is
+// put together by the compares' carries (x <- 2x + bit: one v_addc per level) rather than by selects of constants.
 template <int NJ>
 __device__ inline int count_below(const float (&run)[16], float t) {
   auto R = [&](int j) { return j < NJ ? run[j] : __builtin_inff(); };
-  const bool b3 = R(7) < t;
-  const bool b2 = (b3 ? R(11) : R(3)) < t;
-  const float lo = b2 ? R(5) : R(1), hi = b2 ? R(13) : R(9);
-  const bool b1 = (b3 ? hi : lo) < t;
-  const float e0 = b1 ? R(2) : R(0), e1 = b1 ? R(6) : R(4), e2 = b1 ? R(10) : R(8), e3 = b1 ? R(14) : R(12);
-  const float f0 = b2 ? e1 : e0, f1 = b2 ? e3 : e2;
-  const bool b0 = (b3 ? f1 : f0) < t;
+  auto pick = [](uint64_t m, float a, float b) { return __builtin_amdgcn_inverse_ballot_w64(m) ? a : b; };
+  const uint64_t m3 = __builtin_amdgcn_fcmpf(R(7), t, FCMP_OLT);
+  const uint64_t m2 = __builtin_amdgcn_fcmpf(pick(m3, R(11), R(3)), t, FCMP_OLT);
+  const float lo = pick(m2, R(5), R(1)), hi = pick(m2, R(13), R(9));
+  const uint64_t m1 = __builtin_amdgcn_fcmpf(pick(m3, hi, lo), t, FCMP_OLT);
+  const float e0 = pick(m1, R(2), R(0)), e1 = pick(m1, R(6), R(4)), e2 = pick(m1, R(10), R(8)), e3 = pick(m1, R(14), R(12));
+  const float f0 = pick(m2, e1, e0), f1 = pick(m2, e3, e2);
+  const uint64_t m0 = __builtin_amdgcn_fcmpf(pick(m3, f1, f0), t, FCMP_OLT);
+  int x = __builtin_amdgcn_inverse_ballot_w64(m3) ? 1 : 0;
+  x = add_with_carry(x, x, m2);
+  x = add_with_carry(x, x, m1);
+  x = add_with_carry(x, x, m0);
   // (the four probes leave element 15 untested: it is below t only if all sixteen are)
-  return ((b3 ? 8 : 0) | (b2 ? 4 : 0) | (b1 ? 2 : 0) | (b0 ? 1 : 0)) + ((NJ == 16 && run[15] < t) ? 1 : 0);
+  if constexpr (NJ == 16) x = add_with_carry(x, 0, __builtin_amdgcn_fcmpf(run[15], t, FCMP_OLT));
+  return x;
 }
 
 // the same for up to 32 running sums: one compare picks the half, 16 selects build it, then the 16-entry search

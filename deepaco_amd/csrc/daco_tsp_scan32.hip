@@ -45,7 +45,46 @@ __device__ inline float half_scan_add(float x) {
 __device__ inline float half_bcast_last(float x) {
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x3E0));   // BROADCAST,32,31
 }
-__device__ inline uint32_t lowest_bit(uint32_t x) { return x & (0u - x); }
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---- per-half plumbing of the step loop.  The kernel is bound by VALU issue (profiles/r03_pmc_headline.txt: the
+// pipes busy 0.88 of the launch), so a value that is uniform inside each 32-lane half travels as two SGPRs and reaches
+// the lanes with the upper half's lanes switched on and off by the scalar unit, instead of two v_mov + v_cndmask.
+// Both helpers require EXEC = all lanes (the step loop runs under wave-uniform control flow only) and restore it.
+// lanes 0..31: lo, lanes 32..63: hi
+__device__ inline int half_pick(int lo, int hi) {
+  int v;
+  asm volatile("v_mov_b32 %0, %1\n\ts_mov_b32 exec_lo, 0\n\tv_mov_b32 %0, %2\n\ts_mov_b32 exec_lo, -1"
+               : "=&v"(v) : "s"(lo), "s"(hi));
+  return v;
+}
+// x * (lanes 0..31: lo, lanes 32..63: hi)
+__device__ inline float half_mul(float x, float lo, float hi) {
+  float v;
+  asm volatile("v_mul_f32 %0, %2, %1\n\ts_mov_b32 exec_lo, 0\n\tv_mul_f32 %0, %3, %1\n\ts_mov_b32 exec_lo, -1"
+               : "=&v"(v) : "v"(x), "s"(lo), "s"(hi));
+  return v;
+}
+// r - incl[lane - 1] inside each half (r for the half's first lane): the subtraction reads its operand through DPP
+// wave_shr:1 (lane 0 reads 0); lane 32 would see lane 31, the other ant, and is put right by one select.
+// s_nop 1: two wait states between a VALU write of incl and the DPP read, whatever the scheduler placed before.
+__device__ inline float half_excl_sub(float incl, float r, bool lane32) {
+  float t;
+  asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(t) : "v"(incl), "v"(r));
+  return lane32 ? r : t;
+}
+// max(x, denorm_min) for x that is not a signalling NaN (fmaxf would spend a second v_max on quieting it)
+__device__ inline float at_least_denorm(float x) {
+  float y;
+  asm("v_max_f32 %0, 1, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+// lowest set bit of a scalar, 0 if there is none (s_ff1 gives -1 there)
+__device__ inline int first_bit_or_0(uint32_t x) {
+  int l;
+  asm("s_ff1_i32_b32 %0, %1" : "=s"(l) : "s"(x));
+  return l < 0 ? 0 : l;
+}
 
 // What a step costs was measured piece by piece (tools/scan32_ablate.hip, profiles/r02_scan32_ablation.txt): the
 // row stream itself runs at the L2 ceiling, and everything that made the first version 1.9x slower than that was
@@ -66,15 +105,15 @@ template <int CH2, bool LOGP>
 __global__ void __launch_bounds__(256)
 tsp_scan32_kernel(const SampleParams p) {
   constexpr int NJ = CH2 * 4;                           // candidates per lane (<= 32)
-  constexpr int NG = (NJ + 7) / 8;                      // 16-byte flag groups per lane
   constexpr int FL = CH2 <= 4 ? 512 : 1024;             // flag / tour / inverse-table entries per ant
   static_assert(CH2 >= 1 && CH2 <= 8, "two ants per wavefront: n <= 1024");
-  // open[h][g][lane][8]: f16 1.0 while the node in slot j = 8g + e of that lane is unvisited by ant h, else 0.0.
-  // Slot j = c*4 + v of lane s is node c*128 + s*4 + v.  Reused as the inverse-permutation table in the epilogue.
+  // open[h][k]: f16 1.0 while node k is unvisited by ant h, else 0.0 (node order: the flag of a chosen node is found
+  // without index arithmetic).  Slot j = c*4 + v of lane s is node c*128 + s*4 + v: a lane reads its flags as CH2
+  // 8-byte pieces, 256 B apart.  Reused as the inverse-permutation table in the epilogue.
   __shared__ __attribute__((aligned(16))) _Float16 open_flags[8][FL];
   __shared__ __attribute__((aligned(16))) uint16_t tour_s[8][FL];    // tour_s[h][t] = node visited at step t
   __shared__ __attribute__((aligned(16))) float dstage[4][2][64];    // epilogue: edge lengths of one 64-step chunk
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: wave-uniform branches)
   const int up = lane >> 5, s = lane & 31;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
   const int bpi = (p.A + 7) >> 3;                       // workgroups per instance (8 ants each)
@@ -88,6 +127,7 @@ tsp_scan32_kernel(const SampleParams p) {
   const int a = a0 + up < A ? a0 + up : A - 1;
   const bool lead = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000001ull);   // lane 0 of each half
   const bool upper = __builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFF00000000ull);  // per-half select mask
+  const bool lane32 = __builtin_amdgcn_inverse_ballot_w64(0x0000000100000000ull);
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);           // uniform; lanes add 32-bit offsets
   const uint32_t ldb = (uint32_t)ld * 4u, lane_off = (uint32_t)s * 16u;
@@ -96,10 +136,16 @@ tsp_scan32_kernel(const SampleParams p) {
   char *rs_t = (LOGP && p.rowsum) ? (char *)(p.rowsum + (size_t)b * (n - 1) * A) : nullptr;
   _Float16 *fl = open_flags[wave * 2 + up];
   uint16_t *tour = tour_s[wave * 2 + up];
-  // flag index of node k: group (k>>8), lane (k>>2)&31, element ((k>>7)&1)*4 + (k&3)
-  auto flag_index = [](int k) { return ((k >> 8) << 8) | (((k >> 2) & 31) << 3) | (((k >> 7) & 1) << 2) | (k & 3); };
-  bool feasible = true;
 
+  if (p.knob == 1) {
+    // EXPERIMENT: static issue priorities that differ between the waves of a SIMD (do the waves run in convoy?)
+    switch ((w * 2654435761u) >> 30) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
   if (active) {
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
@@ -113,30 +159,34 @@ tsp_scan32_kernel(const SampleParams p) {
     }
     __builtin_amdgcn_wave_barrier();
     if (lead) {
-      fl[flag_index(prev)] = (_Float16)0.0f;
+      fl[prev] = (_Float16)0.0f;
       tour[0] = (uint16_t)prev;
     }
     __builtin_amdgcn_wave_barrier();
     u32x4 ublk = {0, 0, 0, 0};                          // 128 cached uniforms per ant (lane s: block base+s)
-    const float *uin = p.noise ? p.noise + (size_t)b * (n - 1) * A + a : nullptr;
+    const bool has_noise = p.noise != nullptr;
+    const float *uin = has_noise ? p.noise + (size_t)b * (n - 1) * A + a : nullptr;
 
     for (int tb = 0; tb < n; tb += 32) {
       // uniform of step t: lane (t&31), component (t>>5)&3 of Philox block ((t>>7)<<5) + lane
       if ((tb & 127) == 0) ublk = rng_block(p.seed, iter_now, STREAM_SCAN, gid, (uint32_t)(((tb >> 7) << 5) + s));
       const int ucur = __float_as_int(u01(comp(ublk, (tb >> 5) & 3)));
       const int i1 = n - tb < 32 ? n - tb : 32;
+      uint32_t uaddr = (uint32_t)(lane - s + (tb == 0 ? 1 : 0)) * 4u;   // ds_bpermute address of the half's lane i
       for (int i = tb == 0 ? 1 : 0; i < i1; ++i) {
         const uint32_t rowoff = __umul24((uint32_t)prev, ldb);
         const uint32_t voff = rowoff + lane_off;
         float4 row[CH2];
-        f16x8 fo[NG];
+        f16x4 fo[CH2];
 #pragma unroll
         for (int c = 0; c < CH2; ++c) row[c] = *(const float4 *)(Pb + voff + c * 512);
-        const int u_lo = __builtin_amdgcn_readlane(ucur, i), u_hi = __builtin_amdgcn_readlane(ucur, i + 32);
-        float u = __int_as_float(upper ? u_hi : u_lo);
-        if (uin) u = uin[(size_t)(tb + i - 1) * A];         // injected uniform stream (tests): [B][n-1][A]
+        // the step's uniform sits in lane i of this half of ucur: fetched over the LDS crossbar (no VALU slot; the
+        // row's latency covers it)
+        float u = __int_as_float(__builtin_amdgcn_ds_bpermute((int)uaddr, ucur));
+        uaddr += 4;
+        if (has_noise) u = uin[(size_t)(tb + i - 1) * A];   // injected uniform stream (tests): [B][n-1][A]
 #pragma unroll
-        for (int g = 0; g < NG; ++g) fo[g] = *(const f16x8 *)(fl + g * 256 + s * 8);
+        for (int c = 0; c < CH2; ++c) fo[c] = *(const f16x4 *)(fl + c * 128 + s * 4);
 
         // ---- the lane's running sums in slot order.  A closed slot adds p*0 = +0.0f; the product with the
         // 0/1 flag is exact, so each fma rounds once like an add.
@@ -144,67 +194,75 @@ tsp_scan32_kernel(const SampleParams p) {
         float acc = 0.0f;
 #pragma unroll
         for (int c = 0; c < CH2; ++c) {
-          const int e = (c & 1) * 4;
-          acc = __builtin_fmaf(row[c].x, (float)fo[c >> 1][e + 0], acc); run[4 * c + 0] = acc;
-          acc = __builtin_fmaf(row[c].y, (float)fo[c >> 1][e + 1], acc); run[4 * c + 1] = acc;
-          acc = __builtin_fmaf(row[c].z, (float)fo[c >> 1][e + 2], acc); run[4 * c + 2] = acc;
-          acc = __builtin_fmaf(row[c].w, (float)fo[c >> 1][e + 3], acc); run[4 * c + 3] = acc;
+          acc = __builtin_fmaf(row[c].x, (float)fo[c][0], acc); run[4 * c + 0] = acc;
+          acc = __builtin_fmaf(row[c].y, (float)fo[c][1], acc); run[4 * c + 1] = acc;
+          acc = __builtin_fmaf(row[c].z, (float)fo[c][2], acc); run[4 * c + 2] = acc;
+          acc = __builtin_fmaf(row[c].w, (float)fo[c][3], acc); run[4 * c + 3] = acc;
         }
         // ---- level 1: which lane
         const float part = acc;
         const float incl = half_scan_add<true>(part);
         const int incl_i = __float_as_int(incl);
-        const float S0 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 31));
-        const float S1 = __int_as_float(__builtin_amdgcn_readlane(incl_i, 63));
-        const float S = upper ? S1 : S0;
-        const float r = fmaxf(u * S, 1.401298464e-45f);   // keep r > 0 if u*S underflows
-        const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT);
-        const bool alive0 = S0 > 0.0f, alive1 = S1 > 0.0f;                 // S > 0 <=> some open candidate has p > 0
-        feasible = feasible && alive0 && alive1;
-        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
-        const int L0 = m0 ? __builtin_ctz(m0) : 0, L1 = m1 ? __builtin_ctz(m1) : 0;     // chosen lane of each half
-        // ---- level 2, in every lane (only lane L's result is read): what is left to cover inside the lane is
-        // r - incl[L-1]; the candidate is the first slot whose running sum reaches it (such a slot is open with
-        // p > 0; the threshold is kept > 0 so that a slot is "reached" only by a positive term)
-        float excl = dpp_f<0x138 /* wave_shr:1 */, 0xF, true>(0.0f, incl);
-        excl = s == 0 ? 0.0f : excl;
-        const float thr = fmaxf(r - excl, 1.401298464e-45f);
-        const int cnt = count_below32<NJ>(run, thr);
-        int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 + 32);
-        if (__builtin_expect(j0 >= NJ || j1 >= NJ, 0)) {
-          // rounding: no running sum reached thr -> the lane's last open candidate with p > 0.  (Not "where the
-          // running sum reaches its final value": a positive term can be absorbed by the sum before it -- a randomised
-          // soak found that difference once in 6000 launches.)  Rare: the row and the flags are simply read again.
-          int last = 0;
-#pragma unroll
-          for (int c = 0; c < CH2; ++c) {
-            const float4 rw = *(const float4 *)(Pb + voff + c * 512);
-            const f16x8 ff = *(const f16x8 *)(fl + (c >> 1) * 256 + s * 8);
-            const int e = (c & 1) * 4;
-            last = rw.x * (float)ff[e + 0] > 0.0f ? 4 * c + 0 : last;
-            last = rw.y * (float)ff[e + 1] > 0.0f ? 4 * c + 1 : last;
-            last = rw.z * (float)ff[e + 2] > 0.0f ? 4 * c + 2 : last;
-            last = rw.w * (float)ff[e + 3] > 0.0f ? 4 * c + 3 : last;
+        const int S0i = __builtin_amdgcn_readlane(incl_i, 31), S1i = __builtin_amdgcn_readlane(incl_i, 63);
+        const float S0 = __int_as_float(S0i), S1 = __int_as_float(S1i);
+        const float r0 = half_mul(u, S0, S1);               // u * S of the lane's half
+        // Both row sums in [2^-100, +inf]: u*S cannot underflow (u >= 2^-24) and some open candidate has p > 0 -- decided
+        // on the scalar unit.  Anything else (no feasible candidate, a NaN row, sums near the denormals) takes the
+        // slow way: r is kept > 0 if u*S underflows, and an ant without candidates is flagged and sent to node 0
+        const uint32_t tS0 = (uint32_t)S0i - 0x0D800000u, tS1 = (uint32_t)S1i - 0x0D800000u;
+        const bool plain = (tS0 > tS1 ? tS0 : tS1) <= 0x7F800000u - 0x0D800000u;
+        // the rest of the step; alive_h: some open candidate of ant h has p > 0 (compile-time true on the plain way)
+        auto finish = [&](float r, auto alive0, auto alive1) {
+          const uint64_t m = __builtin_amdgcn_fcmpf(incl, r, FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, FCMP_OGT);
+          const int L0 = first_bit_or_0((uint32_t)m), L1 = first_bit_or_0((uint32_t)(m >> 32));   // chosen lane of each half
+          // ---- level 2, in every lane (only lane L's result is read): what is left to cover inside the lane is
+          // r - incl[L-1]; the candidate is the first slot whose running sum reaches it (such a slot is open with
+          // p > 0; the threshold is kept > 0 so that a slot is "reached" only by a positive term)
+          const float thr = at_least_denorm(half_excl_sub(incl, r, lane32));
+          const int cnt = count_below32<NJ>(run, thr);
+          int j0 = __builtin_amdgcn_readlane(cnt, L0), j1 = __builtin_amdgcn_readlane(cnt, L1 | 32);
+          if (__builtin_expect((j0 > j1 ? j0 : j1) >= NJ, 0)) {
+            // rounding: no running sum reached thr -> the lane's last open candidate with p > 0.  (Not "where the
+            // running sum reaches its final value": a positive term can be absorbed by the sum before it -- a randomised
+            // soak found that difference once in 6000 launches.)  Rare: the row and the flags are simply read again.
+            // (one chunk at a time: the rare way must not cost the loop registers)
+            int last = 0;
+#pragma unroll 1
+            for (int c = 0; c < CH2; ++c) {
+              const float4 rw = *(const float4 *)(Pb + voff + c * 512);
+              const f16x4 ff = *(const f16x4 *)(fl + c * 128 + s * 4);
+              last = rw.x * (float)ff[0] > 0.0f ? 4 * c + 0 : last;
+              last = rw.y * (float)ff[1] > 0.0f ? 4 * c + 1 : last;
+              last = rw.z * (float)ff[2] > 0.0f ? 4 * c + 2 : last;
+              last = rw.w * (float)ff[3] > 0.0f ? 4 * c + 3 : last;
+            }
+            if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
+            if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 | 32);
           }
-          if (j0 >= NJ) j0 = __builtin_amdgcn_readlane(last, L0);
-          if (j1 >= NJ) j1 = __builtin_amdgcn_readlane(last, L1 + 32);
-        }
-        // slot j of lane L is node (j>>2)*128 + L*4 + (j&3), flag ((j>>3)<<8) | L<<3 | (j&7).
-        // No feasible candidate (flagged; the reference raises): move to node 0 like the one-ant kernel and the oracle
-        const int c0 = alive0 ? (((j0 >> 2) << 7) | (j0 & 3)) + (L0 << 2) : 0;
-        const int c1 = alive1 ? (((j1 >> 2) << 7) | (j1 & 3)) + (L1 << 2) : 0;
-        const int f0 = alive0 ? ((j0 >> 3) << 8) | (L0 << 3) | (j0 & 7) : 0;
-        const int f1 = alive1 ? ((j1 >> 3) << 8) | (L1 << 3) | (j1 & 7) : 0;
-        const int choice = upper ? c1 : c0;
-        if (lead) {
-          fl[upper ? f1 : f0] = (_Float16)0.0f;            // visited
-          tour[tb + i] = (uint16_t)choice;
-          if constexpr (LOGP) {
-            const float pc = *(const float *)(Pb + rowoff + (uint32_t)choice * 4u);
-            *(float *)(logp_t + a4) = clamp_log(pc / S);
-            logp_t += (size_t)A * 4;
-            if (rs_t) { *(float *)(rs_t + a4) = S; rs_t += (size_t)A * 4; }
+          // slot j of lane L is node (j>>2)*128 + L*4 + (j&3): j*33 puts j>>2 at bit 7 and keeps j&3 (j < 32).
+          // No feasible candidate (flagged; the reference raises): move to node 0 like the one-ant kernel and the oracle
+          const int c0 = alive0 ? ((j0 * 33) & 0x383) + (L0 << 2) : 0;
+          const int c1 = alive1 ? ((j1 * 33) & 0x383) + (L1 << 2) : 0;
+          const int choice = half_pick(c0, c1);
+          if (lead) {
+            fl[choice] = (_Float16)0.0f;                     // visited
+            tour[tb + i] = (uint16_t)choice;
+            if constexpr (LOGP) {
+              const float S = upper ? S1 : S0;
+              const float pc = *(const float *)(Pb + rowoff + (uint32_t)choice * 4u);
+              *(float *)(logp_t + a4) = clamp_log(pc / S);
+              logp_t += (size_t)A * 4;
+              if (rs_t) { *(float *)(rs_t + a4) = S; rs_t += (size_t)A * 4; }
+            }
           }
+          return choice;
+        };
+        int choice;
+        if (__builtin_expect(plain, 1)) choice = finish(r0, std::true_type{}, std::true_type{});
+        else {
+          const bool alive0 = S0 > 0.0f, alive1 = S1 > 0.0f;     // S > 0 <=> some open candidate has p > 0
+          if (!(alive0 && alive1) && p.flags && lane == 0) atomicOr(p.flags + b, 1);   // (rare: no state carried by the loop)
+          choice = finish(at_least_denorm(r0), alive0, alive1);   // r kept > 0 if u*S underflows
         }
         // the next step's flag loads must follow this store (same wave: the LDS executes them in program order);
         // the compiler barrier keeps the program order
@@ -214,7 +272,6 @@ tsp_scan32_kernel(const SampleParams p) {
       }
     }
   }
-  if (!feasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
 
   // ------------------------------------------------------------------ epilogue: the workgroup's 8 tours leave LDS
   __syncthreads();
@@ -298,8 +355,11 @@ static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 7) / 8;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
   static const int pad = getenv("DACO_SCAN32_LDS_PAD") ? atoi(getenv("DACO_SCAN32_LDS_PAD")) : 0;
-  if (logp) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, true>), grid, block, pad, s, sp);
-  else hipLaunchKernelGGL((tsp_scan32_kernel<CH2, false>), grid, block, pad, s, sp);
+  static const int knob = getenv("DACO_SCAN32_KNOB") ? atoi(getenv("DACO_SCAN32_KNOB")) : 0;
+  SampleParams spk = sp;
+  spk.knob = knob;
+  if (logp) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, true>), grid, block, pad, s, spk);
+  else hipLaunchKernelGGL((tsp_scan32_kernel<CH2, false>), grid, block, pad, s, spk);
   return hipGetLastError();
 }
 

@@ -411,6 +411,45 @@ def test_fused_nls_equals_pass_by_pass_driver(kind, B, n, A, maxt, monkeypatch):
         assert torch.equal(a, b), (kind, T_nls, T_p)
 
 
+@pytest.mark.parametrize("kind", ["sparse", "net"])
+def test_fused_nls_vs_oracle_at_config3_size(kind):
+    """tsp_nls/aco.py:241-258 at BASELINE config 3's size, the fused kernel (daco_tsp_nls, one launch) directly against
+    the oracle's restatement of the schedule (oracle.nls_batch over orc_two_opt_batch = tsp_nls/two_opt.py:6-39): n = 500,
+    maxt = n // 4 = 125, T_nls = 10, T_p = 20, eight sampled tours -- the tours and their f32 lengths bit for bit.
+    kind = sparse: the k-sparse 1/d heuristic of the reference's inference (perturbation matrix with a plateau);
+    kind = net: the heuristic of the pretrained network (the reference's tsp500 checkpoint, w_tsp_tsp500) on the instance."""
+    from deepaco_amd import engine
+    n, A, maxt = 500, 8, 125
+    d = tsp_instance(n, 4242, 1).to(dev())
+    if kind == "sparse":
+        _, idx = torch.topk(d, k=50, dim=2, largest=False)
+        eta = 1 / torch.full_like(d, 1e10).scatter_(2, idx, torch.gather(d, 2, idx))
+    else:
+        from deepaco_amd.tsp.net import Net
+        from deepaco_amd.tsp.utils import gen_pyg_data
+        wz = np.load(os.path.join(GOLDEN, "w_tsp_tsp500.npz"))
+        net = Net()
+        net.load_state_dict({k[3:]: torch.from_numpy(wz[k]) for k in wz.files if k.startswith("w__")}, strict=False)
+        net = net.to(dev()).eval()
+        g = torch.Generator().manual_seed(4242)
+        coords = torch.rand(n, 2, generator=g).to(dev())
+        with torch.no_grad():
+            pyg, distances = gen_pyg_data(coords, k_sparse=50)
+            eta = (net.reshape(pyg, net(pyg)) + 1e-10)[None].contiguous()
+        d = distances[None].contiguous()
+    paths, _, _, _ = engine.tsp_sample(torch.ones_like(d), eta, A, mode="scan", seed=77, fixed_start=0)
+    tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+    hd = (1 / (eta / eta.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()    # tsp_nls/aco.py:58
+    out, costs = engine.nls_(d, hd, tours, maxt, fused=True, want_costs=True)
+    ref, _ = oracle.nls_batch(d[0].cpu().numpy(), hd[0].cpu().numpy(), tours[0].cpu().numpy().astype(np.uint16), maxt)
+    assert np.array_equal(out[0].cpu().numpy().astype(np.uint16), ref), kind
+    ref_costs = oracle.tour_costs(d[0].cpu().numpy(), np.ascontiguousarray(ref.T.astype(np.int64)), closed=True)
+    assert np.array_equal(costs[0].cpu().numpy().view(np.int32), np.asarray(ref_costs, dtype=np.float32).view(np.int32)), kind
+    # the search did something: every tour got shorter than it was sampled
+    raw = oracle.tour_costs(d[0].cpu().numpy(), np.ascontiguousarray(tours[0].cpu().numpy().T.astype(np.int64)), closed=True)
+    assert (np.asarray(ref_costs) < 0.9 * np.asarray(raw)).all()
+
+
 def test_cached_list_kernel_many_small_cases_with_ties(monkeypatch):
     """Ninety small searches, dirty-list kernel vs dense kernel (and the oracle for a third): integer grids (ties on
     (i, j), tolerance ranks with ties), duplicate points, row-scaled and random asymmetric matrices, signed entries,
