@@ -30,3 +30,9 @@ def gen_pyg_data(demands, device='cpu'):
 
 def load_test_dataset(problem_size, device):
     return torch.load(f'../data/bpp/testDataset-{problem_size}.pt', map_location=device)
+
+
+if __name__ == "__main__":      # writes ../data/bpp/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("bpp", sys.modules[__name__])))

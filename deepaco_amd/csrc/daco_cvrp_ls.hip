@@ -56,7 +56,7 @@
 
 namespace daco {
 
-constexpr int LS_MAXL = 1024;      // longest sequence (2n+1 entries at most)
+constexpr int LS_MAXL = 4112;      // longest sequence accepted (2n+1 entries at most: n <= 2000, the largest size of cvrp_nls/utils.py; positions travel in 14-bit fields)
 constexpr int LS_STAGE_MAX_N = 160;
 
 // capacities of the per-launch LDS arrays: positions (Lmax + the appended closing depot, rounded up to a multiple of 8) and

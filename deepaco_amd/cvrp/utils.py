@@ -46,3 +46,9 @@ def gen_pyg_data(demands, distances, device):
 def load_test_dataset(problem_size, device):
     dataset = torch.load(f'./data/cvrp/testDataset-{problem_size}.pt', map_location=device)
     return [(dataset[i, 0, :], dataset[i, 1:, :]) for i in range(len(dataset))]
+
+
+if __name__ == "__main__":      # writes ../data/cvrp/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("cvrp", sys.modules[__name__])))

@@ -81,3 +81,9 @@ def load_val_dataset(n_node, k_sparse, device, start_node=None):
     else:
         dataset = torch.load(path, map_location=device)
     return _unpack(dataset, n_node, device)
+
+
+if __name__ == "__main__":      # writes ../data/cvrp_nls/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("cvrp_nls", sys.modules[__name__])))

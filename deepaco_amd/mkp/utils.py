@@ -45,3 +45,9 @@ def load_val_dataset(problem_size, device):
 
 def load_test_dataset(problem_size, device):
     return _load(f'./data/mkp/testDataset-{problem_size}.pt', device)
+
+
+if __name__ == "__main__":      # writes ../data/mkp/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("mkp", sys.modules[__name__])))

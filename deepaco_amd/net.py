@@ -260,8 +260,11 @@ class Net(nn.Module):
         e = self.emb_net
         parts = [e.v_lin0.weight.reshape(-1), e.v_lin0.bias, e.e_lin0.weight.reshape(-1), e.e_lin0.bias]
         for i in range(DEPTH):
-            Wv = torch.cat([m[i].weight for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)   # [128, 32]
-            bv = torch.cat([m[i].bias for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)
+            # without the node update (sop / smtwtp: the reference never calls v_lins1, v_lins2, v_bns, so their .grad stays
+            # None and AdamW's decoupled weight decay leaves them alone) those slices enter the block detached
+            live = (lambda t: t) if e.node_update else (lambda t: t.detach())
+            Wv = torch.cat([live(e.v_lins1[i].weight), live(e.v_lins2[i].weight), e.v_lins3[i].weight, e.v_lins4[i].weight], 0)   # [128, 32]
+            bv = torch.cat([live(e.v_lins1[i].bias), live(e.v_lins2[i].bias), e.v_lins3[i].bias, e.v_lins4[i].bias], 0)
             vg, vb = e.v_bns[i].module.weight, e.v_bns[i].module.bias
             if not e.node_update:                              # gamma = beta = 0: the node state passes through unchanged
                 vg, vb = torch.zeros_like(vg), torch.zeros_like(vb)

@@ -50,3 +50,9 @@ def load_val_dataset(n_node, k_sparse, device):
 
 def load_test_dataset(n_node, k_sparse, device):
     return _load(f'./data/op/testDataset-{n_node}.pt', k_sparse, device)
+
+
+if __name__ == "__main__":      # writes ../data/op/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("op", sys.modules[__name__])))

@@ -109,7 +109,7 @@ class AntShardedColony:
         evaporate + deposit of the single-GPU colony) instead of deposit_fn."""
         assert exchange in ("delta", "tours")
         assert exchange == "delta" or update_fn is not None
-        self.tau = tau
+        self.tau = tau              # the colony OWNS this tensor from here on: step() updates it in place (pass a clone to keep yours)
         self.n_ants, self.decay, self.rank, self.world = n_ants, decay, rank, world
         self.lo, self.hi = shard_range(n_ants, rank, world)
         self.sample_fn, self.cost_fn, self.deposit_fn = sample_fn, cost_fn, deposit_fn
@@ -157,7 +157,10 @@ class AntShardedColony:
             self.lowest_cost = torch.minimum(self.lowest_cost, all_costs.min(dim=1).values)
             self.iteration += 1
             return paths, costs
-        delta = self.deposit_fn(self._buffer("delta", self.tau.shape, self.tau.dtype, self.tau.device).zero_(), paths, costs)
+        buf = self._buffer("delta", self.tau.shape, self.tau.dtype, self.tau.device).zero_()
+        delta = self.deposit_fn(buf, paths, costs)                # (deposit_fn adds into the buffer it is given and returns it; the
+        if delta is not buf:                                      # buffer is zeroed again next step, so nobody may keep it)
+            delta = buf.copy_(delta)
         best = costs.min(dim=1).values
         if self.world > 1:
             all_reduce_(delta, dist.ReduceOp.SUM)                 # the one data-path collective

@@ -49,3 +49,9 @@ def load_test_dataset(n_node, device):
     """[(dist_mat, prizes, penalties)] from ./data/pctsp/testDataset-<n>.pt (rows: distances, then prizes, then penalties)."""
     dataset = torch.load(f'./data/pctsp/testDataset-{n_node}.pt', map_location=device)
     return [(inst[:-2], inst[-2], inst[-1]) for inst in dataset]
+
+
+if __name__ == "__main__":      # writes ../data/pctsp/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("pctsp", sys.modules[__name__])))

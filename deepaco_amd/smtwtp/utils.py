@@ -31,3 +31,9 @@ def load_test_dataset(n_node, device):
     with open(f"../data/smtwtp/test{n_node}.pkl", "rb") as f:
         loaded = pickle.load(f)
     return [[t.to(device) for t in inst] for inst in loaded]
+
+
+if __name__ == "__main__":      # writes ../data/smtwtp/* as the reference's utils.py does when run as a script
+    import sys
+    from deepaco_amd.datasets import write_datasets
+    print("\n".join(write_datasets("smtwtp", sys.modules[__name__])))

@@ -164,6 +164,10 @@ class ACO(_TspACO):
         maxt = 10000 if inference else self.problem_size // 4
         dist = self.distances.to(torch.float32)
         tabs, hd_tabs = self._tables("distances"), self._tables("heuristic_dist")
+        # (the cached transposes too: without tables -- n > 1024 -- nls_ would otherwise rebuild them, a host sync and an n^2
+        # copy per call)
+        dt, hdt = self._transposed("distances"), self._transposed("heuristic_dist")
         best = engine.nls_(dist.unsqueeze(0), self.heuristic_dist.unsqueeze(0), self._tours(paths).unsqueeze(0), maxt,
-                           T_nls=T_nls, T_p=T_p, tables=tabs, heuristic_tables=hd_tabs)
+                           T_nls=T_nls, T_p=T_p, dist_t=dt.unsqueeze(0) if torch.is_tensor(dt) else dt,
+                           heuristic_dist_t=hdt.unsqueeze(0) if torch.is_tensor(hdt) else hdt, tables=tabs, heuristic_tables=hd_tabs)
         return self._paths(best[0])

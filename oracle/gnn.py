@@ -35,7 +35,9 @@ def bn(x, w, prefix, train):
     return (x - m) / np.sqrt(v + BN_EPS) * g + b
 
 
-def emb_forward(w, x, edge_index, edge_attr, train=False, dtype=np.float64):
+def emb_forward(w, x, edge_index, edge_attr, train=False, dtype=np.float64, node_update=True):
+    """node_update=False: sop/net.py:43 and smtwtp/net.py:43 have the node update commented out -- the node state stays
+    silu(v_lin0(x)) through all layers, only the edge update runs."""
     w = {k: v.astype(dtype) for k, v in w.items()}
     x, e = x.astype(dtype), edge_attr.astype(dtype)
     src, dst = edge_index[0], edge_index[1]
@@ -54,13 +56,14 @@ def emb_forward(w, x, edge_index, edge_attr, train=False, dtype=np.float64):
         agg = np.zeros((n, x.shape[1]), dtype)
         np.add.at(agg, src, w2 * x2[dst])
         agg = agg / deg
-        x = x0 + silu(bn(x1 + agg, w, f"emb_net.v_bns.{i}", train))
+        if node_update:
+            x = x0 + silu(bn(x1 + agg, w, f"emb_net.v_bns.{i}", train))
         e = w0 + silu(bn(w1 + x3[src] + x4[dst], w, f"emb_net.e_bns.{i}", train))
     return e
 
 
-def net_forward(w, x, edge_index, edge_attr, train=False, dtype=np.float64):
-    e = emb_forward(w, x, edge_index, edge_attr, train, dtype)
+def net_forward(w, x, edge_index, edge_attr, train=False, dtype=np.float64, node_update=True):
+    e = emb_forward(w, x, edge_index, edge_attr, train, dtype, node_update)
     wd = {k: v.astype(dtype) for k, v in w.items()}
     h = silu(lin(e, wd["par_net_heu.lins.0.weight"], wd["par_net_heu.lins.0.bias"]))
     h = silu(lin(h, wd["par_net_heu.lins.1.weight"], wd["par_net_heu.lins.1.bias"]))
