@@ -474,6 +474,250 @@ gnn_fused_layer_kernel(int n, int E, int feats, int layer, int npw, const int *s
   }
 }
 
+// ---------------- fused layer, second version (round 4).  Same ownership and arithmetic structure as gnn_fused_layer_kernel;
+// what changed is what the counters of round 3 pointed at (154-168 registers -> 3 waves per SIMD, VALU 0.47 of the time, a
+// third of it 64-bit address arithmetic and quarter-rate transcendentals):
+//   * four waves per SIMD: <= 128 registers and <= 40 KB of LDS per workgroup.  The products gate * x2[dst] go back into the
+//     MFMA tile (all four result rows of a lane are read first), the gate is not kept across the MFMA chain, the MFMA
+//     operands are fetched from LDS in two K-halves;
+//   * the src-side term x3[src] is not gathered: the edge list is src-sorted, a wave's edges start at its own <= 16 nodes,
+//     whose x3 rows sit in 2 KB of LDS;
+//   * the dst-side gathers (x2, x4) are issued BEFORE the MFMA chain of their tile (the ids arrive with the previous
+//     tile's prefetch), so the chain's 1000 cycles cover them;
+//   * one reciprocal serves both activations of an element: r = 1 / ((1 + e^-w0)(1 + e^-y)), sigmoid(w0) = r (1 + e^-y),
+//     sigmoid(y) = r (1 + e^-w0) -- 3 instead of 4 quarter-rate instructions per element (arguments clamped to e^44 so the
+//     product stays finite; sigmoid(-44) = 8e-20 is zero at the network's 1e-5 tolerance either way);
+//   * the accumulator starts from zero (inline constant) and the bias is folded into the BatchNorm shift; every address is
+//     a uniform base plus a 32-bit byte offset (host guarantees E * 128 < 4 GB).
+constexpr int F2_MAX_NPW = 16;
+__device__ inline f32x2 one_plus_exp_neg2(f32x2 x) {       // 1 + e^-x, x clamped at -44
+  // -min(-x, 44) = max(x, -44): one v_max with a literal each (fminf would add a second instruction that quiets NaNs)
+  f32x2 m;
+  asm("v_max_f32 %0, 0xc2300000, %1" : "=v"(m.x) : "v"(x.x));
+  asm("v_max_f32 %0, 0xc2300000, %1" : "=v"(m.y) : "v"(x.y));
+  const f32x2 nx = -m;
+  const f32x2 hi = {L2E_HI, L2E_HI}, lw = {L2E_LO, L2E_LO}, ln2 = {LN2F, LN2F}, one = {1.0f, 1.0f};
+  const f32x2 t = nx * hi;
+  const f32x2 lo = __builtin_elementwise_fma(nx, lw, __builtin_elementwise_fma(nx, hi, -t));
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  return one + __builtin_elementwise_fma(e, lo * ln2, e);
+}
+// INIT (layer 0 only): the old edge state is not read but made on the fly, w0 = silu(e_lin0(edge_attr)) (tsp/net.py:31) --
+// 4 bytes per edge instead of 128, and no separate launch that writes E * 128 bytes first.
+template <bool INIT>
+__global__ void __launch_bounds__(256, 4)
+gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *src, const int *dst, const int *rowptr,
+                        const float *params, const float *x0, const float *X, const float *w0, float *x1out, float *Xnext,
+                        float *w1out, const float *attr) {
+  __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];            // A rows -> MFMA result (edge-major) -> products (channel-major)
+  __shared__ float agg_s[4][F2_MAX_NPW][U];
+  __shared__ __attribute__((aligned(16))) float x3_s[4][F2_MAX_NPW][U];       // x3 rows of the wave's own nodes
+  __shared__ __attribute__((aligned(16))) float we_s[32][36];                 // We
+  const float *lp = params + off_layer(feats, layer);
+  const float *We = lp + 32 * 128 + 128, *be = We + 32 * 32;
+  const float *sv = be + 32, *tv = sv + 32, *se = tv + 32, *te = se + 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  *reinterpret_cast<float4 *>(&we_s[threadIdx.x >> 3][(threadIdx.x & 7) * 4]) = *reinterpret_cast<const float4 *>(We + threadIdx.x * 4);
+  __syncthreads();                                                            // the only workgroup barrier
+  const int per_xcd = (int)gridDim.x >> 3;                                    // XCD x owns one contiguous eighth of the nodes
+  const int block = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  const int i0 = (block * 4 + wave) * npw;
+  if (i0 >= n) return;
+  const int cnt = min(npw, n - i0);
+  const int rp = rowptr[i0 + min(lane, cnt)];
+  auto row_at = [&](int j) { return __builtin_amdgcn_readlane(rp, j); };
+  const int ebeg = row_at(0), eend = row_at(cnt);
+  float (*tile)[36] = tile_s[wave];
+  const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4, g8 = lane >> 3;
+  const char *w0b = reinterpret_cast<const char *>(w0), *Xb = reinterpret_cast<const char *>(X);
+  char *w1b = reinterpret_cast<char *>(w1out);
+  {
+    // the wave's x3 rows: 16 rows x 128 B, two 16-byte pieces per lane (rows past cnt: clamped, never used)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int j = k * 8 + g8, jn = min(i0 + min(j, cnt - 1), n - 1);
+      *reinterpret_cast<float4 *>(&x3_s[wave][j][c0]) = *reinterpret_cast<const float4 *>(Xb + (uint32_t)jn * 512u + 256u + (uint32_t)c0 * 4u);
+    }
+#pragma unroll
+    for (int j = 0; j < F2_MAX_NPW; ++j) agg_s[wave][j][o] = 0.0f;             // nodes without out-edges aggregate 0
+  }
+  const float4 sc = *reinterpret_cast<const float4 *>(se + c0);
+  float4 sh = *reinterpret_cast<const float4 *>(te + c0);
+  {
+    const float4 bb = *reinterpret_cast<const float4 *>(be + c0);             // (g + b + a3 + a4) s + t = (g + a3 + a4) s + (b s + t)
+    sh.x = fmaf(bb.x, sc.x, sh.x); sh.y = fmaf(bb.y, sc.y, sh.y); sh.z = fmaf(bb.z, sc.z, sh.z); sh.w = fmaf(bb.w, sc.w, sh.w);
+  }
+  int cur = 0, seg_end = row_at(1);
+  while (cur < cnt && seg_end <= ebeg) { ++cur; seg_end = cur < cnt ? row_at(cur + 1) : 0x7fffffff; }
+  float run = 0.0f;
+  const int elast = eend - 1;
+  float4 res[4];
+  // INIT: e_lin0's weight and bias of this lane's four channels; a row is silu(attr * W + b)
+  const float4 iw = INIT ? *reinterpret_cast<const float4 *>(params + 32 * feats + 32 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 ib = INIT ? *reinterpret_cast<const float4 *>(params + 32 * feats + 64 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_row = [&](int e) -> float4 {
+    if constexpr (INIT) { const float av = attr[e]; return make_float4(av, av, av, av); }   // (expanded when the tile starts)
+    else return *reinterpret_cast<const float4 *>(w0b + (uint32_t)e * 128u + (uint32_t)c0 * 4u);
+  };
+  auto made_row = [&](float4 r) -> float4 {
+    if constexpr (INIT) {
+      const f32x2 p01 = {fmaf(r.x, iw.x, ib.x), fmaf(r.y, iw.y, ib.y)}, p23 = {fmaf(r.z, iw.z, ib.z), fmaf(r.w, iw.w, ib.w)};
+      const f32x2 s01 = silu2(p01), s23 = silu2(p23);
+      return make_float4(s01.x, s01.y, s23.x, s23.y);
+    } else return r;
+  };
+  // node ids of the next tile's edges, as loaded: they are looked at only when that tile starts (touching them right after
+  // the load would make the wave wait for the row prefetch issued just before -- loads return in order)
+  int sn[4], dn[4];
+  if (ebeg < eend) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = min(ebeg + q * 8 + g8, elast);
+      res[q] = load_row(e);
+      sn[q] = src[e]; dn[q] = dst[e];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int e0 = ebeg; e0 < eend; e0 += 32) {
+    float4 a4[4], x2[4], old[4];
+    uint32_t sl = 0;                                                           // the edges' own nodes (src - i0), four bits per pass
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      old[q] = made_row(res[q]);
+      *reinterpret_cast<float4 *>(&tile[q * 8 + g8][c0]) = old[q];
+      const uint32_t drow_off = (uint32_t)dn[q] * 512u + (uint32_t)c0 * 4u;
+      a4[q] = *reinterpret_cast<const float4 *>(Xb + drow_off + 384u);
+      x2[q] = *reinterpret_cast<const float4 *>(Xb + drow_off + 128u);
+      sl |= (uint32_t)min(max(sn[q] - i0, 0), F2_MAX_NPW - 1) << (4 * q);
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc;
+    {
+      int opaque = 0;
+      asm volatile("" : "+s"(opaque));                                          // (keeps the We operands from being hoisted out of the loop and spilled)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float a[8], bw[8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 t = *reinterpret_cast<const float4 *>(&tile[o][h * 16 + half * 8 + q * 4]);
+          a[q * 4 + 0] = t.x; a[q * 4 + 1] = t.y; a[q * 4 + 2] = t.z; a[q * 4 + 3] = t.w;
+          const float4 u = *reinterpret_cast<const float4 *>(&we_s[o][h * 16 + half * 8 + q * 4 + opaque * 4]);
+          bw[q * 4 + 0] = u.x; bw[q * 4 + 1] = u.y; bw[q * 4 + 2] = u.z; bw[q * 4 + 3] = u.w;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          if (half == 0 && kk == 0) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bw[kk], zero, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bw[kk], acc, 0, 0, 0);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[drow(r, lane)][o] = acc[r];
+    __builtin_amdgcn_wave_barrier();
+    // the next tile's rows and node ids (its gathers are issued at its start)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = min(e0 + 32 + q * 8 + g8, elast);
+      res[q] = load_row(e);
+      sn[q] = src[e]; dn[q] = dst[e];
+    }
+    // epilogue, eight edges per pass.  Pass q reads result rows 8q .. 8q+7 and then writes its 8 x 32 products into the same
+    // rows (channel c, edge j of the pass at tile[8q + c/4][(c%4)*8 + j]): the wave's LDS operations execute in order, a
+    // pass's reads are done before its writes.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int el = q * 8 + g8, e = e0 + el;
+      const bool live = e < eend;
+      const float4 gq = *reinterpret_cast<const float4 *>(&tile[el][c0]);
+      const float4 a3 = *reinterpret_cast<const float4 *>(&x3_s[wave][(sl >> (4 * q)) & 15u][c0]);
+      const f32x2 y01 = {fmaf(gq.x + a3.x + a4[q].x, sc.x, sh.x), fmaf(gq.y + a3.y + a4[q].y, sc.y, sh.y)};
+      const f32x2 y23 = {fmaf(gq.z + a3.z + a4[q].z, sc.z, sh.z), fmaf(gq.w + a3.w + a4[q].w, sc.w, sh.w)};
+      const f32x2 w01 = {old[q].x, old[q].y}, w23 = {old[q].z, old[q].w};
+      const f32x2 gd01 = one_plus_exp_neg2(w01), gd23 = one_plus_exp_neg2(w23);     // 1 + e^-w0
+      const f32x2 sd01 = one_plus_exp_neg2(y01), sd23 = one_plus_exp_neg2(y23);     // 1 + e^-y
+      const f32x2 p01 = gd01 * sd01, p23 = gd23 * sd23;
+      f32x2 r01, r23;
+      r01.x = __builtin_amdgcn_rcpf(p01.x); r01.y = __builtin_amdgcn_rcpf(p01.y);
+      r23.x = __builtin_amdgcn_rcpf(p23.x); r23.y = __builtin_amdgcn_rcpf(p23.y);
+      const f32x2 gate01 = r01 * sd01, gate23 = r23 * sd23;                           // sigmoid(w0)
+      const f32x2 s01 = y01 * (r01 * gd01), s23 = y23 * (r23 * gd23);               // silu(y)
+      if (live) {
+        float4 out;
+        out.x = old[q].x + s01.x; out.y = old[q].y + s01.y; out.z = old[q].z + s23.x; out.w = old[q].w + s23.y;
+        *reinterpret_cast<float4 *>(w1b + (uint32_t)e * 128u + (uint32_t)c0 * 4u) = out;
+      }
+      asm volatile("" ::: "memory");                                         // (the row reads above stay above these writes)
+      float *pr = &tile[q * 8 + (c0 >> 2)][g8];
+      pr[0] = live ? gate01.x * x2[q].x : 0.0f;
+      pr[8] = live ? gate01.y * x2[q].y : 0.0f;
+      pr[16] = live ? gate23.x * x2[q].z : 0.0f;
+      pr[24] = live ? gate23.y * x2[q].w : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane = channel: the tile's 32 products in edge order, cut at the CSR boundaries
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+      const float4 v4 = *reinterpret_cast<const float4 *>(&tile[(j >> 1) * 8 + (o >> 2)][(o & 3) * 8 + (j & 1) * 4]);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        run += v[k];
+        const int enext = e0 + j * 4 + k + 1;
+        if (enext == seg_end) {
+          agg_s[wave][cur][o] = run;
+          run = 0.0f;
+          do { ++cur; seg_end = cur < cnt ? row_at(cur + 1) : 0x7fffffff; } while (cur < cnt && seg_end <= enext);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the wave's nodes, four at a time (as in the first version)
+  const float *WT = params + off_layer(feats, layer + 1), *bv = WT + 32 * 128;
+  for (int j0 = 0; j0 < cnt; j0 += 4) {
+    float xn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xn[j] = 0.0f;
+      if (j0 + j < cnt) {
+        const int i = i0 + j0 + j;
+        const int deg = row_at(j0 + j + 1) - row_at(j0 + j);
+        const float agg = agg_s[wave][j0 + j][o] / (float)max(deg, 1);
+        const float y = fmaf(X[(size_t)i * 128 + o] + agg, sv[o], tv[o]);
+        xn[j] = x0[(size_t)i * U + o] + silu(y);
+        if (h == 0) x1out[(size_t)i * U + o] = xn[j];
+      }
+    }
+    if (layer == 11) continue;
+    float y0[4], y1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { y0[j] = bv[lane]; y1[j] = bv[64 + lane]; }
+    for (int c = 0; c < U; ++c) {
+      const float wa = WT[c * 128 + lane], wb = WT[c * 128 + 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xc = __shfl(xn[j], c, 64);
+        y0[j] = fmaf(xc, wa, y0[j]);
+        y1[j] = fmaf(xc, wb, y1[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j0 + j < cnt) {
+        Xnext[(size_t)(i0 + j0 + j) * 128 + lane] = y0[j];
+        Xnext[(size_t)(i0 + j0 + j) * 128 + 64 + lane] = y1[j];
+      }
+  }
+}
+
 // head: heu = sigmoid(W3 silu(W2 silu(W1 w + b1) + b2) + b3), three chained tile GEMMs
 __global__ void __launch_bounds__(256)
 gnn_head_kernel(int E, int feats, const float *params, const float *w, float *heu) {
@@ -548,12 +792,13 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
   for (int k = 0; k < 2; ++k) { wb[k] = (float *)p; p += align256((size_t)E * 32 * 4); }
   const int node_blocks = (n + 7) / 8, edge_blocks = (E + 127) / 128;
   hipLaunchKernelGGL(gnn_node_init_kernel, dim3(node_blocks), dim3(256), 0, s, n, feats, x, params, xb[0], Xb[0]);
-  hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 8 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
   int cur = 0;
   // tuning / test knobs, read per call: the edge count from which a layer leaves the single-launch kernel, and the fused
   // kernel's nodes per wave (0: the split edge | node kernels)
   const int split_min = getenv("DACO_GNN_SPLIT_MIN_EDGES") ? atoi(getenv("DACO_GNN_SPLIT_MIN_EDGES")) : GNN_SPLIT_MIN_EDGES;
   const int fused_npw = getenv("DACO_GNN_FUSED_NPW") ? atoi(getenv("DACO_GNN_FUSED_NPW")) : -1;
+  // second version of the fused kernel unless the edge array outgrows 32-bit byte offsets (DACO_GNN_FUSED_V=1: the first)
+  const int fused_v = (getenv("DACO_GNN_FUSED_V") && atoi(getenv("DACO_GNN_FUSED_V")) == 1) || (size_t)E * 128 >= ((size_t)1 << 32) || (size_t)n * 512 >= ((size_t)1 << 32) ? 1 : 2;
   // nodes per wave of the fused kernel: the launch should fill the device's wave slots (3 per SIMD at its register
   // budget) a whole number of times -- 1.3 rounds of workgroups cost as much as 2 -- with at most 16 nodes per wave
   int npw = fused_npw;
@@ -562,31 +807,48 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
     if (!slots) {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-      slots = cus * 12;
+      slots = cus * 4;
     }
-    const int rounds = (n + FUSED_MAX_NPW * slots - 1) / (FUSED_MAX_NPW * slots);
-    npw = (n + rounds * slots - 1) / (rounds * slots);
+    const int slots_v = slots * (fused_v == 2 ? 4 : 3);                 // wave slots: 4 (second version) / 3 waves per SIMD
+    const int rounds = (n + FUSED_MAX_NPW * slots_v - 1) / (FUSED_MAX_NPW * slots_v);
+    npw = (n + rounds * slots_v - 1) / (rounds * slots_v);
     if (npw < 4) npw = 4;
   }
   if (npw > FUSED_MAX_NPW) npw = FUSED_MAX_NPW;
+  // EXPERIMENT (DACO_GNN_INPLACE=1, fused kernels only): the edge state is updated in place -- every row is read once, by the
+  // lane that writes it, before it is written -- so the layers cycle through E * 128 B instead of twice that
+  const bool fused2 = E >= split_min && !perm && fused_npw != 0 && fused_v == 2;
+  // (the second fused kernel makes layer 0's edge state itself; every other path reads it from the init launch)
+  if (!fused2) hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 8 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
+  const bool inplace = getenv("DACO_GNN_INPLACE") && atoi(getenv("DACO_GNN_INPLACE")) == 1 && E >= split_min && !perm && fused_npw != 0;
+  int wcur = 0;
   for (int l = 0; l < 12; ++l) {
-    float *wout = (l == 11 && emb) ? emb : wb[cur ^ 1];
-    if (E >= split_min && !perm && fused_npw != 0) {
+    float *wout = (l == 11 && emb) ? emb : wb[inplace ? wcur : (wcur ^ 1)];
+    if (fused2) {
+      const dim3 grid((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8));
+      if (l == 0) hipLaunchKernelGGL(gnn_fused2_layer_kernel<true>, grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
+                                     Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr);
+      else hipLaunchKernelGGL(gnn_fused2_layer_kernel<false>, grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
+                              Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr);
+    } else if (E >= split_min && !perm && fused_npw != 0) {
       hipLaunchKernelGGL(gnn_fused_layer_kernel, dim3((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8)), dim3(256), 0, s, n, E, feats, l,
-                         npw, src, dst, rowptr, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
+                         npw, src, dst, rowptr, params, xb[cur], Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout);
     } else if (E < split_min) {
       hipLaunchKernelGGL(gnn_layer_kernel, dim3(edge_blocks + node_blocks), dim3(256), 0, s, n, E, feats, l, edge_blocks, src,
-                         dst, rowptr, perm, params, xb[cur], Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1], wout);
+                         dst, rowptr, perm, params, xb[cur], Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout);
     } else {
       hipLaunchKernelGGL(gnn_node_kernel, dim3(node_blocks), dim3(256), 0, s, n, feats, l, dst, rowptr, perm, params, xb[cur],
-                         Xb[cur], wb[cur], xb[cur ^ 1], Xb[cur ^ 1]);
-      hipLaunchKernelGGL(gnn_edge_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, l, src, dst, params, Xb[cur], wb[cur],
+                         Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1]);
+      hipLaunchKernelGGL(gnn_edge_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, l, src, dst, params, Xb[cur], wb[wcur],
                          wout);
     }
-    if (l == 11 && emb) { wb[cur ^ 1] = emb; }
+    if (l == 11 && emb) { wb[wcur ^ 1] = emb; wcur ^= 1; }
+    else if (!inplace) wcur ^= 1;
     cur ^= 1;
   }
-  hipLaunchKernelGGL(gnn_head_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, params, wb[cur], heu);
+  // (a head that walks several tiles per wave with the next rows in flight, W1 / W2 in LDS, was measured: 139 us against
+  // this kernel's 131 at 64 x TSP-500 -- not kept)
+  hipLaunchKernelGGL(gnn_head_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, params, wb[wcur], heu);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("gnn kernels launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
