@@ -50,6 +50,10 @@ struct SampleParams {
   int noise_steps;       // rows of the noise tensor
   int32_t *lens;         // [B][A] rows used by each ant
   int knob = 0;          // measurement knob of a kernel (0 in production)
+  // head / tail rows (daco_scan_sparse.hip)
+  const float *hval = nullptr;       // [B][n][64] head values of this iteration, slot 63 = the tail total
+  const uint16_t *hid = nullptr;     // [B][n][64] head node ids, slot 63 = the live count
+  unsigned long long *stats = nullptr;   // [3] dense steps, tail walks, rejections (tests) or null
 };
 
 template <class F, int... I>

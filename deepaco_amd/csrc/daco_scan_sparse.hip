@@ -1,0 +1,426 @@
+// daco_scan_sparse.hip -- TSP tour construction on HEAD / TAIL rows (sampler "scan_sparse"), four ants per wavefront.
+//
+// Reference behaviour: tsp/aco.py:134-177 with the roulette draw of tsp_nls/aco.py:260-275 on the k-sparse heuristic of the
+// reference's inference (tsp/aco.py:52-67: k live entries per row, 1e-10 elsewhere).  The dense scan kernels stream one
+// padded 2 KB row per ant-step and sit on the CU's vector-memory pipe (TA / TD 0.91-0.95 busy, profiles/r04_pmc_headline.txt);
+// nothing in the instruction stream moves that, so this sampler moves fewer bytes: a row is split into a head -- up to
+// 63 candidates chosen by the caller, the colony takes the k largest heuristic entries -- and the tail.  A step draws
+// r = u (H + T), H = the head's live mass, T = the tail's STATIC mass (visited or not): r inside the head is an inverse
+// CDF over 64 slots (384 bytes: values, ids); r past the head walks the whole tail row and, if it lands on a visited
+// node, the step draws again (rejection over a superset: the accepted outcome is the reference's categorical exactly);
+// no live head candidate -> the dense masked draw of the 64-lane scan specification with the same uniform.
+// The CPU restatement of this draw (draw_scan_sparse in the oracle) is the specification (uniform stream, slot order, summation order); the GPU
+// tests hold tours bit-exact against it, the CPU tests hold it against the categorical by chi-square.
+//
+// Layout: ant = 16 lanes (one DPP row), slot m = 4 * lane + v.  Level 1 is the row scan of the 16 lane sums, level 2 a
+// four-entry count; the group's choice reaches its lanes by a rotate-OR.  The two rare ways (tail walk, dense step) are
+// wave-cooperative: the 64 lanes serve one ant at a time (candidate k = (c * 64 + lane) * 4 + v, the 64-lane scan).
+// Tours and f16 visited flags (node order) live in LDS; paths / tour lengths / the update's table leave the workgroup in
+// the epilogue of the scan16 family (16 ants = one 128-byte run per row).
+#include "daco_sample_kernel.h"
+
+namespace daco {
+
+constexpr int SP_KH = 64;                                // head slots per row (slot 63: the tail total / the live count)
+constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3;
+typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
+
+enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
+
+template <int N> __device__ inline float sp_row_bcast(float x) { return dpp_f<0x150 + N, 0xF, false>(x, x); }
+template <int N> __device__ inline int sp_row_ror(int x) { return dpp_i<0x120 + N, 0xF, false>(x, x); }
+__device__ inline int sp_row_or(int x) {
+  x |= sp_row_ror<1>(x); x |= sp_row_ror<2>(x); x |= sp_row_ror<4>(x); x |= sp_row_ror<8>(x);
+  return x;
+}
+__device__ inline float sp_row_scan(float x) {
+  x = x + dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x);
+  x = x + dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x);
+  x = x + dpp_f<DPP_ROW_SHR(4), 0xF, true>(0.0f, x);
+  x = x + dpp_f<DPP_ROW_SHR(8), 0xF, true>(0.0f, x);
+  return x;
+}
+// of the lanes set in m, the first one of every row of 16
+__device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x8000800080008000ull) - 0x0001000100010001ull); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// head values of one iteration: hval[row][m] = P[row][id_m] for the live slots, +0 for the others, slot 63 = the tail total
+// (the 64-lane scan total of the row's non-head entries).  One wavefront per row.
+__global__ void __launch_bounds__(256)
+sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, float *hval) {
+  __shared__ uint32_t bm[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= (long)B * n) return;
+  const float *pr = P + row * ld;
+  const uint16_t *ids = hid + row * SP_KH;
+  const int cnt = ids[63];
+  const int id = ids[lane];
+  const bool live = lane < cnt;
+  if (lane < 32) bm[wave][lane] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  if (live) atomicOr(&bm[wave][id >> 5], 1u << (id & 31));
+  __builtin_amdgcn_wave_barrier();
+  float part = 0.0f;
+  const int ch = ld >> 8;
+  for (int c = 0; c < ch; ++c) {
+    const int k0 = (c * 64 + lane) * 4;
+    const float4 v = *reinterpret_cast<const float4 *>(pr + k0);
+    const uint32_t w = bm[wave][(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
+    part = part + ((w & 1u) ? 0.0f : v.x);
+    part = part + ((w & 2u) ? 0.0f : v.y);
+    part = part + ((w & 4u) ? 0.0f : v.z);
+    part = part + ((w & 8u) ? 0.0f : v.w);
+  }
+  const float T = readlane_f(wave_scan_add(part), 63);
+  hval[row * SP_KH + lane] = lane == 63 ? T : (live ? pr[id] : 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one wave-cooperative draw over a whole row for ONE ant (the rare ways).  TAIL = false: the dense masked draw of the
+// 64-lane scan specification with uniform `ur` (oracle draw_scan, lanes = 64).  TAIL = true: the walk over the row's
+// non-head entries, visited or not, with the threshold `ur` given (oracle draw_scan_sparse, "past the head").
+// Returns the node, -1 if no candidate can be drawn (dense: infeasible; tail: a tail without mass).
+template <int CHD, bool TAIL>
+__device__ inline int sparse_row_walk(const char *rowp, const _Float16 *flg, const uint32_t *bm, int lane, float ur) {
+  constexpr int NJ = CHD * 4;
+  float run[16];
+  float acc = 0.0f;
+  uint32_t pos = 0;                                      // slots with a positive term (a term can be absorbed by the running sum)
+#pragma unroll
+  for (int c = 0; c < CHD; ++c) {
+    const int k0 = (c * 64 + lane) * 4;
+    const float4 rv = *reinterpret_cast<const float4 *>(rowp + (uint32_t)k0 * 4u);
+    float f[4];
+    if constexpr (TAIL) {
+      const uint32_t w = bm[(k0 >> 5) & 31] >> (k0 & 31);
+      f[0] = (w & 1u) ? 0.0f : 1.0f; f[1] = (w & 2u) ? 0.0f : 1.0f; f[2] = (w & 4u) ? 0.0f : 1.0f; f[3] = (w & 8u) ? 0.0f : 1.0f;
+    } else {
+      const sp_f16x4 ff = *reinterpret_cast<const sp_f16x4 *>(flg + k0);
+      f[0] = (float)ff[0]; f[1] = (float)ff[1]; f[2] = (float)ff[2]; f[3] = (float)ff[3];
+    }
+    acc = __builtin_fmaf(rv.x, f[0], acc); run[4 * c + 0] = acc;
+    acc = __builtin_fmaf(rv.y, f[1], acc); run[4 * c + 1] = acc;
+    acc = __builtin_fmaf(rv.z, f[2], acc); run[4 * c + 2] = acc;
+    acc = __builtin_fmaf(rv.w, f[3], acc); run[4 * c + 3] = acc;
+    pos |= (rv.x * f[0] > 0.0f ? 1u : 0u) << (4 * c) | (rv.y * f[1] > 0.0f ? 2u : 0u) << (4 * c) |
+           (rv.z * f[2] > 0.0f ? 4u : 0u) << (4 * c) | (rv.w * f[3] > 0.0f ? 8u : 0u) << (4 * c);
+  }
+#pragma unroll
+  for (int j = NJ; j < 16; ++j) run[j] = __builtin_inff();
+  const float part = acc;
+  const float incl = wave_scan_add(part);
+  float r = ur;
+  if constexpr (!TAIL) {
+    const float S = readlane_f(incl, 63);
+    if (!(S > 0.0f)) return -1;
+    r = ur * S;
+    r = r > 0.0f ? r : 1.401298464e-45f;
+  }
+  uint64_t m = __ballot(incl >= r && part > 0.0f);
+  int L;
+  if (m == 0) {
+    if constexpr (!TAIL) return -1;
+    m = __ballot(part > 0.0f);                           // rounding: the last lane with mass
+    if (m == 0) return -1;
+    L = 63 - __builtin_clzll(m);
+  } else {
+    L = __builtin_ctzll(m);
+  }
+  const float excl = L ? readlane_f(incl, L - 1) : 0.0f;
+  const float thr = fmaxf(r - excl, 1.401298464e-45f);   // (> 0: a slot is reached only by a positive term)
+  const int cnt = count_below<NJ>(run, thr);
+  int jsel = readlane_i(cnt, L);
+  if (jsel >= NJ) {                                      // no running sum reached thr: the lane's last positive entry
+    const uint32_t pl = (uint32_t)readlane_i((int)pos, L);
+    jsel = pl ? 31 - __builtin_clz(pl) : 0;
+  }
+  return ((jsel >> 2) * 64 + L) * 4 + (jsel & 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4
+template <int CHD>
+__global__ void __launch_bounds__(256)
+scan_sparse_kernel(const SampleParams p) {
+  constexpr int APW = 4, APB = 16;
+  constexpr int FL = CHD * 256;                          // flag / tour / inverse-table entries per ant (>= n)
+  __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];      // f16 1.0 while node k is unvisited (node order)
+  extern __shared__ __attribute__((aligned(16))) unsigned char sparse_dyn[];  // the tours (dynamic: static + dynamic pass 64 KB at n > 512)
+  uint16_t (*tour_s)[FL] = reinterpret_cast<uint16_t (*)[FL]>(sparse_dyn);    // [APB][FL]
+  __shared__ uint32_t bm_s[4][32];                       // tail walk: the head of the row as a bitmap over the nodes
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, s = lane & 15;
+  const int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int bpi = (p.A + APB - 1) / APB;
+  const int b = w / bpi;
+  const int abase = (w - b * bpi) * APB;
+  const int a0 = abase + wave * APW;
+  const int n = p.n, A = p.A, ld = p.ld;
+  const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);
+  const bool active = a0 < A;
+  const int a = a0 + q < A ? a0 + q : A - 1;             // spare groups build ant A-1 again (not written)
+  const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
+  const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
+  const char *hvb = (const char *)(p.hval + (size_t)b * n * SP_KH);
+  const char *hib = (const char *)(p.hid + (size_t)b * n * SP_KH);
+  const uint32_t ldb = (uint32_t)ld * 4u;
+  _Float16 *fl = open_flags[wave * APW + q];
+  uint16_t *tour = tour_s[wave * APW + q];
+  const bool lane15 = __builtin_amdgcn_inverse_ballot_w64(0x8000800080008000ull);
+  bool infeasible = false;
+  unsigned long long n_dense = 0, n_tail = 0, n_rej = 0;
+
+  if (active) {
+    {
+      const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+      for (int g = 0; g < FL / 128; ++g) *(f16x8 *)(fl + g * 128 + s * 8) = ones;
+    }
+    int prev;
+    if (p.start) prev = (int)p.start[(size_t)b * A + a];
+    else if (p.fixed_start >= 0) prev = p.fixed_start;
+    else {
+      const u32x4 r = rng_block(p.seed, iter_now, STREAM_START, gid, 0);
+      prev = (int)__umulhi(r.x, (uint32_t)n);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (s == 0) { fl[prev] = (_Float16)0.0f; tour[0] = (uint16_t)prev; }
+    __builtin_amdgcn_wave_barrier();
+    u32x4 ublk = {0, 0, 0, 0};
+    float ucur = 0.0f;
+
+    for (int t = 1; t < n; ++t) {
+      // ---- the head of row `prev`: four values and four ids per lane
+      const float4 hv0 = *reinterpret_cast<const float4 *>(hvb + (uint32_t)prev * (SP_KH * 4u) + (uint32_t)s * 16u);
+      const uint2 hi2 = *reinterpret_cast<const uint2 *>(hib + (uint32_t)prev * (SP_KH * 2u) + (uint32_t)s * 8u);
+      // uniform of step t: component (t>>4)&3 of Philox block ((t>>6)<<4) + (t&15); lane s computes the one of step
+      // (t & ~15) + 15 - s, the row is rotated by one lane per step so that lane 15 holds the current one
+      if ((t & 15) == 0 || t == 1) {
+        if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SPARSE, gid, (uint32_t)(((t >> 6) << 4) + (15 - s)));
+        ucur = u01(comp(ublk, (t >> 4) & 3));
+        if (t == 1) ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
+      }
+      const float u = sp_row_bcast<15>(ucur);
+      ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
+      const int id0 = hi2.x & 0xFFFFu, id1 = hi2.x >> 16, id2 = hi2.y & 0xFFFFu, id3 = hi2.y >> 16;
+      // slot 63 (lane 15, v = 3) holds the tail total, not a candidate; its id field holds the live count (< 64 <= n)
+      const float T = sp_row_bcast<15>(hv0.w);
+      const float hw = lane15 ? 0.0f : hv0.w;
+      const float f0 = (float)fl[id0], f1 = (float)fl[id1], f2 = (float)fl[id2], f3 = (float)fl[id3];
+      const float run0 = __builtin_fmaf(hv0.x, f0, 0.0f);
+      const float run1 = __builtin_fmaf(hv0.y, f1, run0);
+      const float run2 = __builtin_fmaf(hv0.z, f2, run1);
+      const float run3 = __builtin_fmaf(hw, f3, run2);
+      const float part = run3;
+      const float incl = sp_row_scan(part);
+      const float H = sp_row_bcast<15>(incl);
+      float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
+      const float tot = H + T;
+      float r = u * tot;
+      r = r > 0.0f ? r : 1.401298464e-45f;
+
+      // the lane's last slot with a positive term (not "where the running sum stops growing": a term can be absorbed)
+      const int last_pos = hw * f3 > 0.0f ? 3 : (hv0.z * f2 > 0.0f ? 2 : (hv0.y * f1 > 0.0f ? 1 : 0));
+      // level 1 + 2 for a given threshold: node + 1 of the group's winner in every lane of the group, 0 if r is past the head
+      auto head_decide = [&](float rr) -> int {
+        const uint64_t m = __builtin_amdgcn_fcmpf(incl, rr, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, SP_FCMP_OGT);
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(sp_row_first(m));
+        const float thr = fmaxf(rr - excl, 1.401298464e-45f);
+        int c4 = (run0 < thr ? 1 : 0) + (run1 < thr ? 1 : 0) + (run2 < thr ? 1 : 0) + (run3 < thr ? 1 : 0);
+        if (__builtin_expect(__ballot(mine && c4 >= 4) != 0, 0)) c4 = c4 >= 4 ? last_pos : c4;    // rounding: the lane's last positive slot
+        const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
+        const int node = (int)((ids64 >> (16 * c4)) & 0xFFFFu);
+        return sp_row_or(mine ? node + 1 : 0);
+      };
+      int x = head_decide(r);
+
+      // ---- the rare ways, one ant at a time with the whole wavefront
+      const bool hpos = H > 0.0f;
+      uint64_t rare = __ballot(!hpos || x == 0) & 0x0001000100010001ull;
+      while (rare) {
+        const int gl = __builtin_ctzll(rare);             // lane 0 of the group
+        rare &= rare - 1;
+        const int g = gl >> 4;
+        const int pv = readlane_i(prev, gl);
+        const float Hg = readlane_f(H, gl), Tg = readlane_f(T, gl);
+        float ug = readlane_f(u, gl), rg = readlane_f(r, gl);
+        const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
+        const _Float16 *flg = open_flags[wave * APW + g];
+        const char *rowp = Pb + (uint32_t)pv * ldb;
+        int choice_g = -1;
+        bool bitmap_ready = false;
+        const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
+        for (int att = 0;; ++att) {
+          if (!(Hg > 0.0f) || att > 1023) {               // no live head candidate: the dense masked draw with this uniform
+            n_dense += real;
+            choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
+            if (choice_g < 0) { infeasible = true; choice_g = 0; }
+            break;
+          }
+          if (att > 0) {                                  // a new uniform: is r inside the head now?
+            const int x2 = head_decide(q == g ? rg : r);
+            const int xg = readlane_i(x2, gl);
+            if (xg) { choice_g = xg - 1; break; }
+          }
+          n_tail += real;
+          if (!bitmap_ready) {
+            const uint16_t *ids = reinterpret_cast<const uint16_t *>(hib + (uint32_t)pv * (SP_KH * 2u));
+            const int cntg = ids[63];
+            if (lane < 32) bm_s[wave][lane] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < cntg) { const int idl = ids[lane]; atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31)); }
+            __builtin_amdgcn_wave_barrier();
+            bitmap_ready = true;
+          }
+          float rp = rg - Hg;
+          rp = rp > 0.0f ? rp : 1.401298464e-45f;
+          int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
+          if (j < 0) {                                    // a tail without mass: the head's last live candidate
+            const bool live_lane = q == g && part > 0.0f;
+            const uint64_t ml = __ballot(live_lane);
+            if (ml == 0) { infeasible = true; choice_g = 0; break; }
+            const int Ll = 63 - __builtin_clzll(ml);
+            const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
+            choice_g = readlane_i((int)((ids64 >> (16 * last_pos)) & 0xFFFFu), Ll);
+            break;
+          }
+          if ((float)flg[j] != 0.0f) { choice_g = j; break; }      // open: accepted
+          n_rej += real;                                  // visited: draw again
+          const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
+          ug = u01(comp(rb, att & 3));
+          rg = ug * (Hg + Tg);
+          rg = rg > 0.0f ? rg : 1.401298464e-45f;
+        }
+        x = q == g ? choice_g + 1 : x;
+      }
+      const int choice = x - 1;
+      if (s == 0) { fl[choice] = (_Float16)0.0f; tour[t] = (uint16_t)choice; }
+      asm volatile("" ::: "memory");                      // the next step's flag reads follow these stores
+      __builtin_amdgcn_wave_barrier();
+      prev = choice;
+    }
+  }
+  if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
+  if (p.stats && lane == 0 && (n_dense | n_tail | n_rej)) {
+    atomicAdd(p.stats + 0, n_dense); atomicAdd(p.stats + 1, n_tail); atomicAdd(p.stats + 2, n_rej);
+  }
+
+  // ------------------------------------------------------------------ epilogue: the workgroup's 16 tours leave LDS
+  __syncthreads();
+  const int nant = A - abase < APB ? A - abase : APB;
+  const int k16 = threadIdx.x & (APB - 1);
+  constexpr int TSTEP = 256 / APB;
+  if (p.paths && k16 < nant) {
+    int64_t *pb = p.paths + (size_t)b * n * A + abase;
+    for (int t = threadIdx.x / APB; t < n; t += TSTEP) pb[(size_t)t * A + k16] = (int64_t)tour_s[k16][t];
+  }
+  if (p.costs) {
+    // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of each
+    // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
+    __syncthreads();
+    const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+    float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(&open_flags[0][0]);
+    if (active) {
+      float cost = 0.0f;
+      const float *mine_d = dstage[wave][q];
+      for (int base = 1; base < n; base += 64) {
+        const int t = base + lane;
+#pragma unroll
+        for (int r4 = 0; r4 < APW; ++r4) {
+          const uint16_t *tr = tour_s[wave * APW + r4];
+          dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (s == 0) {
+#pragma unroll
+          for (int v4 = 0; v4 < 16; ++v4) {
+            const float4 v = *(const float4 *)(mine_d + 4 * v4);
+            cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (s == 0 && a0 + q < A) {
+        const uint16_t *tm = tour_s[wave * APW + q];
+        cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+        p.costs[(size_t)b * A + a0 + q] = cost;
+      }
+    }
+  }
+  if (p.nbr) {
+    __syncthreads();
+    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(open_flags);
+    for (int e = threadIdx.x; e < APB * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (k16 < nant)
+      for (int t = threadIdx.x / APB; t < n; t += TSTEP) inv[k16][tour_s[k16][t]] = (uint16_t)t;
+    __syncthreads();
+    uint32_t *nb = p.nbr + (size_t)b * n * A + abase;
+    if (k16 < nant)
+      for (int node = threadIdx.x / APB; node < n; node += TSTEP) {
+        const int t = inv[k16][node];
+        const uint32_t pv = tour_s[k16][t == 0 ? n - 1 : t - 1], nx = tour_s[k16][t == n - 1 ? 0 : t + 1];
+        nb[(size_t)node * A + k16] = pv | (nx << 16);
+      }
+  }
+}
+
+}  // namespace daco
+
+using namespace daco;
+
+extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n) {
+  if (B <= 0 || n <= 128 || n > 1024) return 0;
+  const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
+  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * SP_KH * sizeof(float));
+}
+
+extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
+                                      int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
+                                      uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
+                                      long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
+                                      size_t workspace_bytes, void *ev_begin, void *ev_end) {
+  if (B <= 0 || A <= 0 || !tau || !eta || !head_id || !workspace || (!paths && !nbr)) {
+    set_error("daco_tsp_sample_sparse: bad argument (B=%d n=%d A=%d)", B, n, A);
+    return DACO_E_BADARG;
+  }
+  if (n <= 128 || n > 1024) { set_error("daco_tsp_sample_sparse: n=%d outside 129..1024 (the dense samplers serve the other sizes)", n); return DACO_E_TOOLARGE; }
+  if ((size_t)n * A * 8 >= ((size_t)1 << 32)) { set_error("daco_tsp_sample_sparse: n * A too large for 32-bit offsets"); return DACO_E_TOOLARGE; }
+  if (fixed_start >= n) { set_error("daco_tsp_sample_sparse: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
+  if (costs && !dist) { set_error("daco_tsp_sample_sparse: fused costs need the distance matrix"); return DACO_E_BADARG; }
+  const size_t need = daco_tsp_sparse_workspace_bytes(B, n);
+  if (workspace_bytes < need) { set_error("daco_tsp_sample_sparse: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int ld = n <= 512 ? 512 : 1024;
+  float *P = (float *)workspace;
+  float *hval = (float *)((char *)workspace + align256((size_t)B * n * ld * sizeof(float)));
+  launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, nullptr, s);
+  hipLaunchKernelGGL(sparse_head_kernel, dim3((unsigned)(((long)B * n + 3) / 4)), dim3(256), 0, s, B, n, ld, P, head_id, hval);
+  SampleParams sp{};
+  sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = ld / 256;
+  sp.P = P; sp.start = start; sp.fixed_start = fixed_start;
+  sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
+  sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
+  sp.hval = hval; sp.hid = head_id; sp.stats = stats;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("daco_tsp_sample_sparse pre-pass: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
+  const int bpi = (A + 15) / 16;
+  if (ld <= 512) hipLaunchKernelGGL((scan_sparse_kernel<2>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 512 * 2, s, sp);
+  else {
+    static bool attr_set = false;                        // 32.5 KB static + 32 KB dynamic: past the default 64 KB per workgroup
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void *)scan_sparse_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024 * 2) != hipSuccess) {
+        set_error("daco_tsp_sample_sparse: cannot reserve the LDS of the n > 512 kernel"); return DACO_E_HIP;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_sparse_kernel<4>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 1024 * 2, s, sp);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) { set_error("scan_sparse_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
+  return DACO_OK;
+}

@@ -122,6 +122,69 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
     return paths, logp, rowsum, flags
 
 
+def sparse_head(weights, k):
+    """Head table of scan_sparse for `weights` [B,n,n] or [n,n] (the colony passes its heuristic): per row the k (<= 63)
+    largest entries, ids ascending (ties at the k-th value: the smaller id) -- [B,n,64] int16 holding uint16 ids, the
+    unused slots 0, slot 63 = k (include/deepaco_hip.h daco_tsp_sample_sparse; oracle.sparse_head_ids is the same rule)."""
+    _require_gpu(weights)
+    w = weights if weights.dim() == 3 else weights.unsqueeze(0)
+    B, n, _ = w.shape
+    assert 1 <= k <= 63 and k <= n
+    # by value descending, then id ascending: a stable sort of the ids by descending value
+    order = torch.sort(w.to(torch.float64), dim=2, descending=True, stable=True).indices[:, :, :k]
+    ids = torch.zeros((B, n, 64), dtype=torch.int64, device=w.device)
+    ids[:, :, :k] = torch.sort(order, dim=2).values
+    ids[:, :, 63] = k
+    return ids.to(torch.int16).contiguous()          # (bit pattern of uint16: ids < 32768 here, n <= 1024)
+
+
+def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
+                      batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
+                      want_paths=True):
+    """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
+    distribution of tsp_sample(mode="scan"), 384 bytes per step instead of a row while the head has a live candidate.
+    head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats])."""
+    _require_gpu(tau, eta, start, head)
+    n = tau.shape[-1]
+    B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
+    dev = tau.device
+    tau, tbs = _bstride(tau, n)
+    eta, ebs = _bstride(eta, n)
+    assert head.dtype == torch.int16 and head.is_contiguous() and tuple(head.shape) == (B, n, 64)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        paths = torch.empty((B, n, n_ants), dtype=torch.int64, device=dev) if want_paths else None
+        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if start is not None:
+            start = start.to(torch.int64).contiguous().view(B, n_ants)
+        costs = nbr = None
+        dbs = 0
+        if dist is not None:
+            _require_gpu(dist)
+            dist, dbs = _bstride(dist, n)
+            costs = torch.empty((B, n_ants), dtype=torch.float32, device=dev)
+        if want_nbr:
+            nbr = torch.empty((B, n, n_ants), dtype=torch.int32, device=dev)
+        stats = torch.zeros(3, dtype=torch.int64, device=dev) if want_stats else None
+        nbytes = L.daco_tsp_sparse_workspace_bytes(B, n)
+        if nbytes == 0:
+            raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
+        ws = _workspace(dev, nbytes, "sample_sparse")
+        rc = L.daco_tsp_sample_sparse(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+                                      float(beta), head.data_ptr(), start.data_ptr() if start is not None else None,
+                                      int(fixed_start), int(seed) & (2 ** 64 - 1), int(it),
+                                      iter_dev.data_ptr() if iter_dev is not None else None, int(ant_gid0) & 0xFFFFFFFF,
+                                      int(ant_gid_bstride), paths.data_ptr() if paths is not None else None, flags.data_ptr(),
+                                      dist.data_ptr() if dist is not None else None, dbs,
+                                      costs.data_ptr() if costs is not None else None,
+                                      nbr.data_ptr() if nbr is not None else None,
+                                      stats.data_ptr() if stats is not None else None, ws.data_ptr(), ws.numel(),
+                                      events[0].cuda_event if events else None, events[1].cuda_event if events else None)
+    _lib.check(rc, "daco_tsp_sample_sparse")
+    out = (paths, flags, costs, nbr)
+    return out + (stats,) if want_stats else out
+
+
 def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
                 it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False,
                 iter_dev=None, events=None):
@@ -698,6 +761,10 @@ class BatchedTSP:
         self._tables = self._htables = None
         self._cmin = None
         self.nls_counters = None                  # optional int64[2] on the device: sweeps, list entries walked (bench)
+        # sampler="scan_sparse": head / tail rows (tsp_sample_sparse).  The head of a row = the k largest heuristic entries:
+        # k from sparsify(k), else `head_k` (default n // 10, at most 63); rebuilt when the heuristic object changes.
+        self.head_k = None
+        self._head = None
 
     def _heuristic_dist(self):
         if self._hdist is None:
@@ -712,17 +779,34 @@ class BatchedTSP:
         sparse = torch.full_like(self.distances, 1e10)
         sparse.scatter_(2, idx, torch.gather(self.distances, 2, idx))
         self.heuristic = 1 / sparse
+        self.head_k = min(int(k_sparse), 63)
+        self._head = None
+
+    def _head_table(self):
+        """(heuristic object it was built from, [B,n,64] head ids) for sampler='scan_sparse'."""
+        if self._head is None or self._head[0] is not self.heuristic:
+            k = self.head_k if self.head_k is not None else max(1, min(63, self.n // 10))
+            h = self.heuristic.detach()
+            h = h if h.dim() == 3 else h.unsqueeze(0).expand(self.B, self.n, self.n)
+            self._head = (self.heuristic, sparse_head(_f32c(h), k))
+        return self._head[1]
 
     @torch.no_grad()
     def step(self, events=None, _iter_dev=None, ls_events=None):
         # (_iter_dev: device-side iteration counter of a captured graph; self.iteration then stays frozen)
         # events: torch.cuda.Event pair re-recorded around the construction kernel; ls_events: a pair recorded (on the
         # current stream, which is the stream the library launches on) right before / after the local-search launches
-        paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
-                                                self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,
-                                                ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
-                                                batch=self.B, events=events, dist=self.distances, want_nbr=True,
-                                                iter_dev=_iter_dev)
+        if self.sampler == "scan_sparse":
+            paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, self._head_table(), self.alpha,
+                                                     self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
+                                                     fixed_start=self.fixed_start, batch=self.B, events=events,
+                                                     dist=self.distances, want_nbr=True, iter_dev=_iter_dev)
+        else:
+            paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
+                                                    self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,
+                                                    ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
+                                                    batch=self.B, events=events, dist=self.distances, want_nbr=True,
+                                                    iter_dev=_iter_dev)
         if _iter_dev is None:
             self.iteration += 1
         if self.local_search is not None:

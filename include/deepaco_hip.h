@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 119 /* 0.1.18: bumped whenever an entry point's signature or the draw stream of a mode changes (119: lanes per ant of the scan draw for n <= 256) */
+#define DACO_VERSION 120 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse) */
 
 /* error codes */
 #define DACO_OK 0
@@ -113,6 +113,38 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
                     int64_t *paths, float *logp, float *rowsum, int32_t *flags,
                     const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                     void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_tsp_sample_sparse -- ACO.gen_path on HEAD / TAIL rows (sampler "scan_sparse"); replaces
+ *   tsp/aco.py:134-177 with the roulette of tsp_nls/aco.py:260-275, for heuristics made k-sparse by
+ *   tsp/aco.py:52-67 (sparsify: k live entries per row, 1e-10 elsewhere) -- the reference's inference setting.
+ *
+ * Same distribution as daco_tsp_sample(DACO_SCAN): p_k = tau^alpha * eta^beta * [k unvisited].  A row is split into a
+ * head (up to 63 candidates, head_id) and the tail (the rest).  A step draws r = u * (H + T) with H the head's live
+ * mass and T the tail's static mass: inside the head -> inverse CDF over 64 slots (384 bytes instead of a row of
+ * 4n); past the head -> inverse CDF over all tail entries, a visited one is rejected and the step draws again
+ * (rejection over a superset: the accepted outcome is the categorical above); no live head candidate -> the dense
+ * masked draw of the 64-lane scan specification.  Its own uniform stream (one per attempt): tours differ from
+ * DACO_SCAN's under the same seed, the distribution does not.  Specification: oracle/daco_oracle.c draw_scan_sparse.
+ *   129 <= n <= 1024.
+ *   head_id  [B][n][64] uint16: slots 0..cnt-1 the head's node ids (any subset of the row; the colony passes the k
+ *            largest heuristic entries, ids ascending), the other slots 0, slot 63 = cnt (<= 63)
+ *   paths, flags, dist / costs, nbr, start / fixed_start, seed / iter / iter_offset / ant_gid0 / ant_gid_bstride,
+ *   ev_begin / ev_end: as daco_tsp_sample (log-probabilities are not produced: an inference sampler)
+ *   stats    optional out [3] uint64 (caller zeroes): steps that took the dense draw, tail walks, rejections
+ *   workspace  daco_tsp_sparse_workspace_bytes(B, n) bytes of device scratch
+ */
+size_t daco_tsp_sparse_workspace_bytes(int B, int n);
+int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
+                           const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                           float alpha, float beta, const uint16_t *head_id,
+                           const int64_t *start, int fixed_start,
+                           uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
+                           int ant_gid_bstride,
+                           int64_t *paths, int32_t *flags,
+                           const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
+                           unsigned long long *stats,
+                           void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_cvrp_sample -- replaces the CVRP ACO.gen_path / pick_move / update_visit_mask /

@@ -327,6 +327,162 @@ int orc_tsp_sample_scan_wave(int n, int A, const float *P, uint64_t seed, uint64
   return tsp_sample(MODE_SCAN_WAVE, n, A, P, NULL, NULL, 0, seed, iter, ant_gid0, fixed_start, paths, logp);
 }
 
+/* ------------------------------------------------------------------ scan_sparse: the roulette draw on head / tail rows
+ * (tsp/aco.py:52-67 sparsify + tsp_nls/aco.py:260-275 roulette).
+ * The reference's inference heuristic is k-sparse: k live entries per row, 1e-10 elsewhere.  A row is split into a HEAD --
+ * up to 63 candidates given by the caller (ids, any subset; the colony takes the k largest heuristic entries) -- and the
+ * TAIL, everything else.  A step draws r = u * (H + T): H = the head's LIVE mass (its open candidates), T = the tail's
+ * STATIC mass (all tail entries, visited or not).  r inside the head -> inverse CDF over the open head candidates.  r past
+ * the head -> inverse CDF over ALL tail entries, and if the one it lands on is visited the step draws again with a new
+ * uniform: rejection over a superset, the accepted outcome j has probability P_ij / sum(open P) exactly as in the
+ * reference's categorical (up to float rounding, like every draw here).  No live head candidate (H = 0) -> the dense
+ * masked draw of the 64-lane scan specification with the same uniform.  So most steps read 384 bytes instead of a row.
+ *   head slot m = 4 * lane + v, 16 lanes; w_m = val_m if m < cnt and its node is open, else +0; lane partial = its four
+ *   slots in order from +0.0f; incl = Kogge-Stone over the 16 lanes; H = incl[15]; T = head_val[63] (so cnt <= 63), made
+ *   by orc_sparse_head_values as the 64-lane (vec 4) scan total of the row's non-head entries.
+ *   u(t, attempt 0) = component (t>>4)&3 of Philox(ctr = ((t>>6)<<4) + (t&15), gid, iter, STREAM_SPARSE)
+ *   u(t, attempt a) = component (a-1)&3 of Philox(ctr = (t<<8) | ((a-1)>>2), gid, iter, STREAM_SPARSE_RETRY), a <= 1023
+ *   in-lane picks as in draw_scan (first running sum >= thr over the positive terms, else the last positive one).
+ * stats: [0] dense steps (H = 0), [1] tail walks, [2] rejections. */
+enum { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
+#define SPARSE_KH 64
+
+static void sparse_tail_scan(int n, const float *row, const unsigned char *is_head, float part[64], float incl[64]) {
+  int ch = (n + 255) / 256;
+  for (int l = 0; l < 64; ++l) {
+    float s = 0.0f;
+    for (int c = 0; c < ch; ++c)
+      for (int v = 0; v < 4; ++v) {
+        int k = (c * 64 + l) * 4 + v;
+        s = s + ((k < n && !is_head[k]) ? row[k] : 0.0f);
+      }
+    part[l] = s; incl[l] = s;
+  }
+  lane_scan(incl);
+}
+
+/* head_val [n][64] from the dense matrix P [n][n], the head ids [n][64] (uint16) and counts [n] (<= 63): slot m < cnt holds
+ * P[i][id_m], the other slots +0, slot 63 the tail total T_i */
+void orc_sparse_head_values(int n, const float *P, const uint16_t *head_id, const uint8_t *head_cnt, float *head_val) {
+  unsigned char *is_head = (unsigned char *)malloc(n);
+  float part[64], incl[64];
+  for (int i = 0; i < n; ++i) {
+    memset(is_head, 0, n);
+    for (int m = 0; m < SPARSE_KH; ++m) {
+      int live = m < head_cnt[i];
+      head_val[(long)i * SPARSE_KH + m] = live ? P[(long)i * n + head_id[(long)i * SPARSE_KH + m]] : 0.0f;
+      if (live) is_head[head_id[(long)i * SPARSE_KH + m]] = 1;
+    }
+    sparse_tail_scan(n, P + (long)i * n, is_head, part, incl);
+    head_val[(long)i * SPARSE_KH + 63] = incl[63];
+  }
+  free(is_head);
+}
+
+static int draw_scan_sparse(int n, const float *row, const float *hval, const uint16_t *hid, int cnt,
+                            const unsigned char *blocked, unsigned char *is_head, uint64_t seed, uint64_t iter,
+                            uint32_t gid, int t, long stats[3]) {
+  float part[64], incl[64], w[SPARSE_KH];
+  uint32_t r4[4];
+  for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
+  for (int l = 0; l < 16; ++l) {
+    float s = 0.0f;
+    for (int v = 0; v < 4; ++v) {
+      int m = 4 * l + v;
+      w[m] = (m < cnt && !blocked[hid[m]]) ? hval[m] : 0.0f;
+      s = s + w[m];
+    }
+    part[l] = s; incl[l] = s;
+  }
+  lane_scan(incl);                                       /* lanes 0..15 of the 64-lane scan = the 16-lane row scan */
+  const float H = incl[15], T = hval[63];
+  const uint32_t ut = (uint32_t)t;
+  for (int a = 0;; ++a) {
+    float u;
+    if (a == 0) { rng_block(seed, iter, STREAM_SPARSE, gid, ((ut >> 6) << 4) + (ut & 15u), r4); u = u01(r4[(ut >> 4) & 3u]); }
+    else { rng_block(seed, iter, STREAM_SPARSE_RETRY, gid, (ut << 8) | ((uint32_t)(a - 1) >> 2), r4); u = u01(r4[(a - 1) & 3]); }
+    if (!(H > 0.0f) || a > 1023) {                       /* no live head candidate (or a thousand rejections): the dense masked draw */
+      if (stats) stats[0]++;
+      return draw_scan(n, row, blocked, 0, 0, 0, t, NULL, 64, &u);
+    }
+    float r = u * (H + T);
+    if (!(r > 0.0f)) r = 1.401298464e-45f;
+    int L = -1;
+    for (int l = 0; l < 16; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
+    if (L >= 0) {
+      float thr = r - (L ? incl[L - 1] : 0.0f), run = 0.0f;
+      int best = -1, last = -1;
+      for (int v = 0; v < 4; ++v) {
+        int m = 4 * L + v;
+        if (!(w[m] > 0.0f)) continue;
+        run = run + w[m];
+        last = m;
+        if (run >= thr) { best = m; break; }
+      }
+      if (best < 0) best = last;
+      return hid[best];
+    }
+    /* past the head: walk the whole tail, visited entries included */
+    if (stats) stats[1]++;
+    float rp = r - H;
+    if (!(rp > 0.0f)) rp = 1.401298464e-45f;
+    memset(is_head, 0, n);
+    for (int m = 0; m < cnt; ++m) is_head[hid[m]] = 1;
+    float tpart[64], tincl[64];
+    sparse_tail_scan(n, row, is_head, tpart, tincl);
+    int Lt = -1;
+    for (int l = 0; l < 64; ++l) if (tincl[l] >= rp && tpart[l] > 0.0f) { Lt = l; break; }
+    if (Lt < 0) for (int l = 63; l >= 0; --l) if (tpart[l] > 0.0f) { Lt = l; break; }      /* rounding: the last lane with mass */
+    int j = -1;
+    if (Lt >= 0) {
+      float thr = rp - (Lt ? tincl[Lt - 1] : 0.0f), run = 0.0f;
+      int last = -1, ch = (n + 255) / 256;
+      for (int c = 0; c < ch && j < 0; ++c)
+        for (int v = 0; v < 4; ++v) {
+          int k = (c * 64 + Lt) * 4 + v;
+          if (k >= n || is_head[k] || !(row[k] > 0.0f)) continue;
+          run = run + row[k];
+          last = k;
+          if (run >= thr) { j = k; break; }
+        }
+      if (j < 0) j = last;
+    }
+    if (j < 0) {                                         /* a tail without mass: the head's last live candidate */
+      for (int m = cnt - 1; m >= 0; --m) if (w[m] > 0.0f) return hid[m];
+      return -1;
+    }
+    if (!blocked[j]) return j;
+    if (stats) stats[2]++;
+  }
+}
+
+/* P [n][n] dense, head_id [n][64] uint16, head_cnt [n] uint8 (<= 63), head_val [n][64] from orc_sparse_head_values */
+int orc_tsp_sample_scan_sparse(int n, int A, const float *P, const uint16_t *head_id, const uint8_t *head_cnt,
+                               const float *head_val, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int fixed_start,
+                               int64_t *paths, long *stats) {
+  int rc = ORC_OK;
+  unsigned char *vis = (unsigned char *)malloc(n), *is_head = (unsigned char *)malloc(n);
+  for (int a = 0; a < A; ++a) {
+    uint32_t gid = ant_gid0 + (uint32_t)a, r4[4];
+    int prev;
+    if (fixed_start >= 0) prev = fixed_start;
+    else { rng_block(seed, iter, STREAM_START, gid, 0, r4); prev = (int)(((uint64_t)r4[0] * (uint64_t)n) >> 32); }
+    memset(vis, 0, n);
+    vis[prev] = 1;
+    paths[a] = prev;
+    for (int t = 1; t < n; ++t) {
+      int best = draw_scan_sparse(n, P + (long)prev * n, head_val + (long)prev * SPARSE_KH, head_id + (long)prev * SPARSE_KH,
+                                  head_cnt[prev], vis, is_head, seed, iter, gid, t, stats);
+      if (best < 0) { rc = ORC_INFEASIBLE; best = 0; }
+      vis[best] = 1;
+      paths[(long)t * A + a] = best;
+      prev = best;
+    }
+  }
+  free(vis); free(is_head);
+  return rc;
+}
+
 /* ------------------------------------------------------------------ T4 / C5: tour costs
  * closed: sum_k dist[u_k][u_{k-1 mod n}]  (tsp/aco.py:121-132)
  * open:   sum_{k<len-1} dist[u_k][u_{k+1}] (cvrp/aco.py:133-136)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The headline launch alone, for profilers: tsp_scan32_kernel<4,false> at TSP-500 x 512 ants x 64 instances with the fused
 tour lengths and neighbour table (what a BatchedTSP.step launches), `reps` times.  Prints the median HIP-event time.
-usage: tools/run_headline_kernel.py [reps=8] [B=64] [A=512] [n=500]"""
+usage: tools/run_headline_kernel.py [reps=8] [B=64] [A=512] [n=500] [mode=scan]"""
 import json
 import os
 import sys
@@ -15,6 +15,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 500
+mode = sys.argv[5] if len(sys.argv) > 5 else "scan"
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
 c = torch.rand(B, n, 2, generator=g)
@@ -32,8 +33,8 @@ for a, b in ev:
     a.record(); b.record()
 torch.cuda.synchronize()
 for r in range(reps):
-    engine.tsp_sample(tau, eta, A, seed=3, it=r, batch=B, events=ev[r], dist=d, want_nbr=True)
+    engine.tsp_sample(tau, eta, A, mode=mode, seed=3, it=r, batch=B, events=ev[r], dist=d, want_nbr=True)
 torch.cuda.synchronize()
 t = sorted(a.elapsed_time(b) for a, b in ev[2:])
 print(json.dumps({"n": n, "B": B, "A": A, "reps": reps, "kernel_ms_median": round(t[len(t) // 2], 4), "kernel_ms_min": round(t[0], 4),
-                  "knob": os.environ.get("DACO_SCAN32_KNOB", "0")}))
+                  "mode": mode, "knob": os.environ.get("DACO_SCAN32_KNOB", "0")}))
