@@ -23,7 +23,6 @@ namespace daco {
 
 constexpr int SP_KH = 64;                                // head slots per row (slot 63: the tail total / the live count)
 constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3;
-typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
 
 enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
 
@@ -82,7 +81,7 @@ sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, fl
 // non-head entries, visited or not, with the threshold `ur` given (oracle draw_scan_sparse, "past the head").
 // Returns the node, -1 if no candidate can be drawn (dense: infeasible; tail: a tail without mass).
 template <int CHD, bool TAIL>
-__device__ inline int sparse_row_walk(const char *rowp, const _Float16 *flg, const uint32_t *bm, int lane, float ur) {
+__device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, const uint32_t *bm, int lane, float ur) {
   constexpr int NJ = CHD * 4;
   float run[16];
   float acc = 0.0f;
@@ -96,8 +95,8 @@ __device__ inline int sparse_row_walk(const char *rowp, const _Float16 *flg, con
       const uint32_t w = bm[(k0 >> 5) & 31] >> (k0 & 31);
       f[0] = (w & 1u) ? 0.0f : 1.0f; f[1] = (w & 2u) ? 0.0f : 1.0f; f[2] = (w & 4u) ? 0.0f : 1.0f; f[3] = (w & 8u) ? 0.0f : 1.0f;
     } else {
-      const sp_f16x4 ff = *reinterpret_cast<const sp_f16x4 *>(flg + k0);
-      f[0] = (float)ff[0]; f[1] = (float)ff[1]; f[2] = (float)ff[2]; f[3] = (float)ff[3];
+      const uint32_t ff = *reinterpret_cast<const uint32_t *>(flg + k0);          // four flag bytes (v_cvt_f32_ubyte0..3)
+      f[0] = (float)(ff & 0xFFu); f[1] = (float)((ff >> 8) & 0xFFu); f[2] = (float)((ff >> 16) & 0xFFu); f[3] = (float)(ff >> 24);
     }
     acc = __builtin_fmaf(rv.x, f[0], acc); run[4 * c + 0] = acc;
     acc = __builtin_fmaf(rv.y, f[1], acc); run[4 * c + 1] = acc;
@@ -141,11 +140,14 @@ __device__ inline int sparse_row_walk(const char *rowp, const _Float16 *flg, con
 // ---------------------------------------------------------------------------------------------------------------
 // CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4
 template <int CHD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, CHD == 2 ? 6 : 3)
 scan_sparse_kernel(const SampleParams p) {
   constexpr int APW = 4, APB = 16;
   constexpr int FL = CHD * 256;                          // flag / tour / inverse-table entries per ant (>= n)
-  __shared__ __attribute__((aligned(16))) _Float16 open_flags[APB][FL];      // f16 1.0 while node k is unvisited (node order)
+  // visited flags as BYTES (1 while node k is unvisited, node order): with the u16 tours 1.5 KB of LDS per ant at n <= 512, six
+  // workgroups per CU.  A step is one L2 trip, four LDS gathers and two DPP networks in a chain (2 600 cycles at the headline shape,
+  // profiles/r04_pmc_scan_sparse.txt) -- the rate is ants in flight over that, and LDS is what caps the ants.
+  __shared__ __attribute__((aligned(16))) uint8_t open_flags[APB][FL];
   extern __shared__ __attribute__((aligned(16))) unsigned char sparse_dyn[];  // the tours (dynamic: static + dynamic pass 64 KB at n > 512)
   uint16_t (*tour_s)[FL] = reinterpret_cast<uint16_t (*)[FL]>(sparse_dyn);    // [APB][FL]
   __shared__ uint32_t bm_s[4][32];                       // tail walk: the head of the row as a bitmap over the nodes
@@ -165,7 +167,7 @@ scan_sparse_kernel(const SampleParams p) {
   const char *hvb = (const char *)(p.hval + (size_t)b * n * SP_KH);
   const char *hib = (const char *)(p.hid + (size_t)b * n * SP_KH);
   const uint32_t ldb = (uint32_t)ld * 4u;
-  _Float16 *fl = open_flags[wave * APW + q];
+  uint8_t *fl = open_flags[wave * APW + q];
   uint16_t *tour = tour_s[wave * APW + q];
   const bool lane15 = __builtin_amdgcn_inverse_ballot_w64(0x8000800080008000ull);
   bool infeasible = false;
@@ -173,9 +175,9 @@ scan_sparse_kernel(const SampleParams p) {
 
   if (active) {
     {
-      const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
+      const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
 #pragma unroll
-      for (int g = 0; g < FL / 128; ++g) *(f16x8 *)(fl + g * 128 + s * 8) = ones;
+      for (int g = 0; g < FL / 256; ++g) *(uint4 *)(fl + g * 256 + s * 16) = ones;
     }
     int prev;
     if (p.start) prev = (int)p.start[(size_t)b * A + a];
@@ -185,7 +187,7 @@ scan_sparse_kernel(const SampleParams p) {
       prev = (int)__umulhi(r.x, (uint32_t)n);
     }
     __builtin_amdgcn_wave_barrier();
-    if (s == 0) { fl[prev] = (_Float16)0.0f; tour[0] = (uint16_t)prev; }
+    if (s == 0) { fl[prev] = 0; tour[0] = (uint16_t)prev; }
     __builtin_amdgcn_wave_barrier();
     u32x4 ublk = {0, 0, 0, 0};
     float ucur = 0.0f;
@@ -246,7 +248,7 @@ scan_sparse_kernel(const SampleParams p) {
         const float Hg = readlane_f(H, gl), Tg = readlane_f(T, gl);
         float ug = readlane_f(u, gl), rg = readlane_f(r, gl);
         const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
-        const _Float16 *flg = open_flags[wave * APW + g];
+        const uint8_t *flg = open_flags[wave * APW + g];
         const char *rowp = Pb + (uint32_t)pv * ldb;
         int choice_g = -1;
         bool bitmap_ready = false;
@@ -285,7 +287,7 @@ scan_sparse_kernel(const SampleParams p) {
             choice_g = readlane_i((int)((ids64 >> (16 * last_pos)) & 0xFFFFu), Ll);
             break;
           }
-          if ((float)flg[j] != 0.0f) { choice_g = j; break; }      // open: accepted
+          if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
           n_rej += real;                                  // visited: draw again
           const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
           ug = u01(comp(rb, att & 3));
@@ -295,7 +297,7 @@ scan_sparse_kernel(const SampleParams p) {
         x = q == g ? choice_g + 1 : x;
       }
       const int choice = x - 1;
-      if (s == 0) { fl[choice] = (_Float16)0.0f; tour[t] = (uint16_t)choice; }
+      if (s == 0) { fl[choice] = 0; tour[t] = (uint16_t)choice; }
       asm volatile("" ::: "memory");                      // the next step's flag reads follow these stores
       __builtin_amdgcn_wave_barrier();
       prev = choice;
@@ -349,20 +351,28 @@ scan_sparse_kernel(const SampleParams p) {
     }
   }
   if (p.nbr) {
-    __syncthreads();
-    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(open_flags);
-    for (int e = threadIdx.x; e < APB * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    if (k16 < nant)
-      for (int t = threadIdx.x / APB; t < n; t += TSTEP) inv[k16][tour_s[k16][t]] = (uint16_t)t;
-    __syncthreads();
-    uint32_t *nb = p.nbr + (size_t)b * n * A + abase;
-    if (k16 < nant)
-      for (int node = threadIdx.x / APB; node < n; node += TSTEP) {
-        const int t = inv[k16][node];
-        const uint32_t pv = tour_s[k16][t == 0 ? n - 1 : t - 1], nx = tour_s[k16][t == n - 1 ? 0 : t + 1];
-        nb[(size_t)node * A + k16] = pv | (nx << 16);
-      }
+    // the update's table through an inverse-permutation table in the (dead) flag array, eight ants at a time
+    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(&open_flags[0][0]);
+    static_assert(sizeof(open_flags) >= 8 * FL * sizeof(uint16_t), "inverse table of eight ants inside the flag array");
+    const int k8 = threadIdx.x & 7;
+    for (int half = 0; half < 2; ++half) {
+      const int nh = nant - half * 8 < 8 ? nant - half * 8 : 8;
+      __syncthreads();
+      if (nh <= 0) break;
+      for (int e = threadIdx.x; e < 8 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+      const uint16_t *tk = tour_s[half * 8 + (k8 < nh ? k8 : 0)];
+      if (k8 < nh)
+        for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k8][tk[t]] = (uint16_t)t;
+      __syncthreads();
+      uint32_t *nb = p.nbr + (size_t)b * n * A + abase + half * 8;
+      if (k8 < nh)
+        for (int node = threadIdx.x >> 3; node < n; node += 32) {
+          const int t = inv[k8][node];
+          const uint32_t pv = tk[t == 0 ? n - 1 : t - 1], nx = tk[t == n - 1 ? 0 : t + 1];
+          nb[(size_t)node * A + k8] = pv | (nx << 16);
+        }
+    }
   }
 }
 
@@ -409,16 +419,7 @@ extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const f
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   const int bpi = (A + 15) / 16;
   if (ld <= 512) hipLaunchKernelGGL((scan_sparse_kernel<2>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 512 * 2, s, sp);
-  else {
-    static bool attr_set = false;                        // 32.5 KB static + 32 KB dynamic: past the default 64 KB per workgroup
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void *)scan_sparse_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024 * 2) != hipSuccess) {
-        set_error("daco_tsp_sample_sparse: cannot reserve the LDS of the n > 512 kernel"); return DACO_E_HIP;
-      }
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((scan_sparse_kernel<4>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 1024 * 2, s, sp);
-  }
+  else hipLaunchKernelGGL((scan_sparse_kernel<4>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 1024 * 2, s, sp);
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("scan_sparse_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }

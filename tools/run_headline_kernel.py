@@ -32,9 +32,17 @@ ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 for a, b in ev:
     a.record(); b.record()
 torch.cuda.synchronize()
+head = engine.sparse_head(eta, min(63, max(5, n // 10))) if mode == "scan_sparse" else None
+stats = None
 for r in range(reps):
-    engine.tsp_sample(tau, eta, A, mode=mode, seed=3, it=r, batch=B, events=ev[r], dist=d, want_nbr=True)
+    if mode == "scan_sparse":
+        plain = os.environ.get("SPARSE_PLAIN") == "1"
+        out = engine.tsp_sample_sparse(tau, eta, A, head, seed=3, it=r, batch=B, events=ev[r], dist=None if plain else d,
+                                       want_nbr=not plain, want_stats=(r == reps - 1))
+        stats = out[4].cpu().tolist() if r == reps - 1 else stats
+    else:
+        engine.tsp_sample(tau, eta, A, mode=mode, seed=3, it=r, batch=B, events=ev[r], dist=d, want_nbr=True)
 torch.cuda.synchronize()
 t = sorted(a.elapsed_time(b) for a, b in ev[2:])
 print(json.dumps({"n": n, "B": B, "A": A, "reps": reps, "kernel_ms_median": round(t[len(t) // 2], 4), "kernel_ms_min": round(t[0], 4),
-                  "mode": mode, "knob": os.environ.get("DACO_SCAN32_KNOB", "0")}))
+                  "mode": mode, "sparse_stats": stats, "knob": os.environ.get("DACO_SCAN32_KNOB", "0")}))
