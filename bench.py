@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--nodes", type=int, default=500)
     ap.add_argument("--ants", type=int, default=512)
     ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
-    ap.add_argument("--sampler", default="scan", choices=["scan", "scan_wave", "race"])
+    ap.add_argument("--sampler", default="scan", choices=["scan", "scan_wave", "race", "scan_sparse"])
     ap.add_argument("--k-sparse", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations")
@@ -144,18 +144,23 @@ def sampler_layout(n, sampler):
     return name, row
 
 
-def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, traffic_source=None):
+def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, traffic_source=None, pipes=None):
     """Roofline object of a tour-construction launch: L2 row stream as the bound, SURVEY 8(d)'s algorithmic bytes and
-    the HBM-side picture next to it."""
+    the HBM-side picture next to it; `pipes`: the counter-measured occupancy of the CU's units for this kernel."""
     name, row = sampler_layout(n, sampler)
     steps = n - 1 if steps_per_tour is None else steps_per_tour
     row_bytes = B * A * steps * 4.0 * row
+    if sampler == "scan_sparse":            # a head step reads 64 values + 64 ids; the dense steps (counted in the run) a row
+        name, row_bytes = "scan_sparse_kernel", B * A * steps * 384.0
     alg_bytes = B * A * bytes_per_tour(n, A, steps)
     ach = row_bytes / (kern_ms * 1e-3) / 1e9
     compulsory = B * (8.0 * n * n + 8.0 * A * n)
     return {"bound": "l2", "achieved": ach, "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": ach / PEAK_L2_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": name, "kernel_ms": kern_ms, "row_bytes_per_launch": row_bytes,
+            # valu_busy = SQ_INSTS_VALU x 2 cycles (a wave64 VALU instruction issues over two cycles on gfx950's SIMD-32)
+            # / (SIMDs x kernel cycles); ta / td_busy: the CU's vector-memory address and data-return units
+            "pipes": pipes, "valu_busy": (pipes or {}).get("valu_busy"),
             "algorithmic": {"bytes_per_launch": alg_bytes, "GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
                             "over_hbm_peak": alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                             "note": "SURVEY 8(d) bytes / kernel time; above the HBM peak because the rows are "
@@ -304,6 +309,7 @@ def extra_configs(dev, headline_colony, cpu=True):
     out = {}
     ncpu = os.cpu_count() or 1
     traffic = load_traffic()
+    counters = load_counters()
 
     def events(steps):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -338,12 +344,13 @@ def extra_configs(dev, headline_colony, cpu=True):
         tr, src = traffic.get(f"tsp{n}_a{A}_b{B}_scan", (None, None))
         out[tag] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, AS iteration", "value": B * A / dt,
                     "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "steps": steps,
-                    "roofline": roofline_rows(n, A, B, "scan", kms, traffic=tr, traffic_source=src),
+                    "roofline": roofline_rows(n, A, B, "scan", kms, traffic=tr, traffic_source=src,
+                                              pipes=counters.get(f"tsp{n}_a{A}_b{B}_scan")),
                     "cpu_baseline": cpu_tsp(d_cpu, k, A, cpu_budget)}
         del col
 
     tsp("c2_tsp100_a512_b256", 100, 512, 256, 20, 10, 6.0)
-    tsp("c5_share_tsp1000_a2048_b64", 1000, 2048, 64, 100, 3, 20.0)
+    tsp("c5_share_tsp1000_a2048_b64", 1000, 2048, 64, 100, 5, 20.0)
 
     # config 4: CVRP-100, capacity mask in the sampling kernel
     n, A, B = 100, 512, 256
@@ -456,13 +463,115 @@ def extra_configs(dev, headline_colony, cpu=True):
         out["headline_parity_modes"] = {
             "workload": f"TSP-{n}, n_ants={A}: the draw as torch.multinomial makes it (argmax of p / q, q ~ Exp(1))",
             "race_philox": {"value": B * A / dtr, "unit": "ant-tours/s", "ms_per_step": dtr * 1e3, "instances": B,
-                            "note": "in-kernel Philox noise, whole iteration"},
+                            "note": "in-kernel Philox noise, whole iteration",
+                            "roofline": (lambda pc: {
+                                "bound": "valu", "unit": "wave-instructions/s", "pipes": pc, "valu_busy": (pc or {}).get("valu_busy"),
+                                "achieved": None if not pc else pc.get("valu_insts_per_launch", 0) / (dtr),
+                                "peak": 1024 * 2.4e9 / 2, "frac": (pc or {}).get("valu_busy"), "traffic": None,
+                                "note": "one Philox4x32-10 block per four candidates and a degree-8 log polynomial per candidate, both "
+                                        "fixed by the specification (bit-identical to the oracle): ~50 VALU instructions per candidate-"
+                                        "lane; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; "
+                                        "profiles/r04_pmc_race.txt"})(counters.get("tsp500_a512_b64_race"))},
             "race_noise": {"value": Bn * A / dtn, "unit": "ant-tours/s (construction only)", "ms_per_launch": dtn * 1e3,
                            "instances": Bn,
                            "note": "noise read from memory (the mode the reference-recorded fixtures are replayed in): "
                                    f"{4.0 * (n - 1) * n * A * Bn / 1e9:.1f} GB of q per launch"}}
     except Exception as e:
         out["headline_parity_modes"] = {"error": repr(e)}
+
+    # headline workload on HEAD / TAIL rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the same
+    # distribution, 384 bytes per step while a row's k live entries last.  Its own uniform stream, so it is reported here
+    # and the headline stays on the dense scan; best costs of the two samplers side by side on the same instances.
+    try:
+        n, A, B, k = 500, 512, 64, 50
+        res = {}
+        for tag in ("scan_sparse", "scan"):
+            col = engine.BatchedTSP(headline_colony.distances, n_ants=A, sampler=tag, seed=21)
+            col.sparsify(k)
+            col.heuristic = col.heuristic.contiguous()
+            col.step(); col.step()
+            ev = events(10)
+            t0 = time.perf_counter()
+            for s_ in range(10):
+                col.step(events=ev[s_])
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / 10
+            kms = sum(a.elapsed_time(b) for a, b in ev) / 10
+            col.run(20 - col.iteration)
+            res[tag] = {"value": B * A / dts, "unit": "ant-tours/s", "ms_per_step": dts * 1e3, "kernel_ms": kms,
+                        "mean_best_cost_after_20_iterations": float(col.lowest_cost.mean())}
+            if tag == "scan_sparse":
+                _, _, _, _, st = engine.tsp_sample_sparse(col.pheromone, col.heuristic, A, col._head_table(), seed=1, batch=B,
+                                                          want_stats=True, want_paths=True)
+                st = st.tolist()
+                res[tag]["steps_dense_tailwalk_rejected"] = st
+                pc = counters.get("tsp500_a512_b64_scan_sparse")
+                res[tag]["roofline"] = {
+                    "bound": "l2", "achieved": B * A * (n - 1) * 384.0 / (kms * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
+                    "frac": B * A * (n - 1) * 384.0 / (kms * 1e-3) / 1e9 / PEAK_L2_GBS, "traffic": None,
+                    "kernel": "scan_sparse_kernel<2> (HIP events around the launch)", "kernel_ms": kms, "pipes": pc,
+                    "valu_busy": (pc or {}).get("valu_busy"),
+                    "note": "384 B per head step (64 values + 64 ids) over the kernel time against the L2 rate: the kernel is not "
+                            "bound by it -- a step is a chain of one L2 round trip, four LDS gathers and two DPP networks "
+                            "(2 600 cycles at this shape) and the rate is ants in flight (96 per CU: 1.5 KB of LDS each) over "
+                            "that chain; profiles/r04_pmc_scan_sparse.txt"}
+            del col
+        res["speedup_whole_iteration"] = res["scan_sparse"]["value"] / res["scan"]["value"]
+        out["headline_scan_sparse"] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, 1/d sparsified k={k}: sampler "
+                                                   f"scan_sparse (head of {k} per row) next to the dense scan", **res}
+    except Exception as e:
+        out["headline_scan_sparse"] = {"error": repr(e)}
+
+    # CVRP local search (cvrp_nls/aco.py:114-126 through csrc/daco_cvrp_ls.hip): CVRP-100, 512 ants, 16 instances, the
+    # schedule of cvrp_nls/aco.py:443-448 (to convergence, 10 moves on the perturbation matrix, to convergence)
+    try:
+        n, A, B = 100, 512, 16
+        g = torch.Generator().manual_seed(3)
+        loc = torch.cat((torch.full((B, 1, 2), 0.5), torch.rand(B, n, 2, generator=g)), 1)
+        dem = torch.cat((torch.zeros(B, 1), torch.randint(1, 10, (B, n), generator=g).float()), 1).to(dev)
+        dls = (loc[:, :, None] - loc[:, None]).norm(dim=-1)
+        ii = torch.arange(n + 1)
+        dls[:, ii, ii] = 1e-10
+        dls = dls.to(dev)
+        heu = 1 / dls
+        hdl = (1 / (heu / heu.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+        col = engine.BatchedCVRP(dls, dem, n_ants=A, capacity=50, seed=1)
+        paths, costs0 = col.step(trim=True)
+        Lm = float(col.last_lens.float().mean())
+
+        def search(pw):
+            tot = 0.0
+            for mtx, cnt in ((dls, 100000), (hdl, 10), (dls, 100000)):
+                _, _, mv = engine.cvrp_local_search_(mtx, dem, 50.0, pw, cnt, want_stats=True)
+                tot += float(mv.float().sum())
+            return tot
+        search(paths.clone())
+        torch.cuda.synchronize()
+        wk = paths.clone()
+        t0 = time.perf_counter()
+        nm = search(wk)
+        torch.cuda.synchronize()
+        dtl = time.perf_counter() - t0
+        c1 = engine.tour_costs(dls, wk, closed=False)
+        pairs = nm * Lm * Lm
+        # a candidate pair costs 6-8 look-ups into the staged matrix (4 bytes each, LDS); ds_read_b32 peak 128 B/clk/CU
+        lds_peak = 128.0 * 256 * 2.4e9 / 1e9
+        ach = pairs * 7 * 4.0 / dtl / 1e9
+        pc = counters.get("cvrp_ls_100_a512_b16")
+        out["cvrp_local_search_100_a512_b16"] = {
+            "workload": f"CVRP-{n} local search (nine move families + SWAP*), {B} x {A} sampled solutions, the schedule of "
+                        f"cvrp_nls/aco.py:443-448", "value": B * A / dtl, "unit": "solutions/s", "seconds": dtl,
+            "moves_per_solution": nm / (B * A), "pairs_evaluated_per_s": pairs / dtl, "mean_sequence_length": Lm,
+            "mean_cost_before": float(costs0.mean()), "mean_cost_after": float(c1.mean()),
+            "roofline": {"bound": "lds", "achieved": ach, "peak": lds_peak, "unit": "GB/s", "frac": ach / lds_peak, "traffic": None,
+                         "kernel": "cvrp_ls_kernel<true, 512> (three launches; wall clock around them)", "pipes": pc,
+                         "valu_busy": (pc or {}).get("valu_busy"),
+                         "note": "pair evaluations x 7 matrix look-ups x 4 B against the LDS gather rate (ds_read_b32: 128 B/clk/CU, "
+                                 "MI355X_MICROARCH.md LDS table); the matrix of an instance is staged in LDS, the pair loop is a chain "
+                                 "of dependent look-ups (profiles/r04_pmc_cvrp_ls.txt)"}}
+        del col
+    except Exception as e:
+        out["cvrp_local_search_100_a512_b16"] = {"error": repr(e)}
 
     # headline workload with the LEARNED heuristic: Net + the reference's pretrained tsp500 weights
     # (tests/golden/w_tsp_tsp500.npz: the checkpoint as plain arrays), heu + 1e-10, next to the vanilla 1/d on the
@@ -547,7 +656,7 @@ def extra_configs(dev, headline_colony, cpu=True):
                                  "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": PEAK_HBM_GBS,
                                               "unit": "GB/s", "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "traffic": tr,
                                               "traffic_source": src,
-                                              "kernel": "gnn_fused_layer_kernel x 12 layers + init + head (whole forward)",
+                                              "kernel": "gnn_fused2_layer_kernel x 12 layers (layer 0 makes the edge state, edge state in place) + node init + head (whole forward)",
                                               "mfma_tflops": flops / dt / 1e12},
                                  "cpu_baseline": cb}
     return out
@@ -570,6 +679,28 @@ def load_traffic():
                 for k, v in tj.items() if isinstance(v, (int, float)) and k != "daco_version"}
     except Exception:
         return {}
+
+
+def load_counters():
+    """profiles/counters.json: what the kernels' hardware counters said (rocprofv3 --pmc passes of the workloads below,
+    tools/profile_r4.sh), stamped with the library version like hbm_traffic.json and dropped when it differs.  Pipe
+    occupancies of the dominant kernel next to its roofline: which unit the kernel sits on is a counter, not a guess."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        cj = json.load(open(path))
+        from deepaco_amd import _lib
+        if int(cj.get("daco_version", -1)) != _lib.lib().daco_version():
+            return {}
+        return {k: dict(v, source=cj.get("source", "profiles/counters.json") + " (PMC passes of this workload and library "
+                                                                                 "version, not collected in this run)")
+                for k, v in cj.items() if isinstance(v, dict)}
+    except Exception:
+        return {}
+
+
+def active_knobs():
+    """DACO_* environment variables set for this run (three of them select which kernel a result comes from)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("DACO_")}
 
 
 # ---------------------------------------------------------------------------------------------- one rank
@@ -692,8 +823,10 @@ def worker(args):
                                    f"AS update, heuristic 1/d sparsified k={k_sparse}, sampler={args.sampler}",
                        "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": args.sampler,
                        "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}"},
-            "roofline": roofline_rows(n, A, B, args.sampler, kern_ms, traffic=traffic, traffic_source=tsrc)
+            "roofline": roofline_rows(n, A, B, args.sampler, kern_ms, traffic=traffic, traffic_source=tsrc,
+                                      pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{args.sampler}"))
             if kern_ms else None,
+            "knobs": active_knobs(),
             "sustained": sustained,
             "gpu_mean_best_cost": float(gpu_best.mean()),
         }
@@ -706,7 +839,9 @@ def worker(args):
                 log(f"extras failed: {e!r}")
                 line["extras"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu and not ant_sharded:
-            ncol = args.cpu_instances or max(1, min(B, (os.cpu_count() or 1) // 4))
+            # 16 colonies x 2 threads: the best aggregate found on this host class (round 2: 2 103 ant-tours/s; 64 x 2 on the
+            # same 128 cores gave 1 594 -- the op sequence is memory-bound and slows down as colonies are added)
+            ncol = args.cpu_instances or max(1, min(B, 16, (os.cpu_count() or 1) // 2))
             cb, cpu_best, done = cpu_baseline(dist_cpu, k_sparse, A, ncol, args.cpu_iters, budget_s=args.cpu_seconds)
             line["cpu_baseline"] = cb
             # best-cost gap: the same instances, equal iterations, fresh GPU colonies
