@@ -45,6 +45,9 @@ __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x800080
 // ---------------------------------------------------------------------------------------------------------------
 // head values of one iteration: hval[row][m] = P[row][id_m] for the live slots, +0 for the others, slot 63 = the tail total
 // (the 64-lane scan total of the row's non-head entries).  One wavefront per row.
+// RACE (the exponential race on head rows, race_head_kernel below): hval[row][m] = 1 / P[row][id_m] (+inf for the other
+// slots), slot 63 = the smallest 1 / P of the tail, i.e. the reciprocal of its largest entry.
+template <bool RACE>
 __global__ void __launch_bounds__(256)
 sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, float *hval) {
   __shared__ uint32_t bm[4][32];
@@ -60,19 +63,33 @@ sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, fl
   __builtin_amdgcn_wave_barrier();
   if (live) atomicOr(&bm[wave][id >> 5], 1u << (id & 31));
   __builtin_amdgcn_wave_barrier();
-  float part = 0.0f;
+  float part = RACE ? __builtin_inff() : 0.0f;
   const int ch = ld >> 8;
   for (int c = 0; c < ch; ++c) {
     const int k0 = (c * 64 + lane) * 4;
     const float4 v = *reinterpret_cast<const float4 *>(pr + k0);
     const uint32_t w = bm[wave][(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
-    part = part + ((w & 1u) ? 0.0f : v.x);
-    part = part + ((w & 2u) ? 0.0f : v.y);
-    part = part + ((w & 4u) ? 0.0f : v.z);
-    part = part + ((w & 8u) ? 0.0f : v.w);
+    if constexpr (RACE) {
+      part = fminf(part, (w & 1u) ? __builtin_inff() : 1.0f / v.x);
+      part = fminf(part, (w & 2u) ? __builtin_inff() : 1.0f / v.y);
+      part = fminf(part, (w & 4u) ? __builtin_inff() : 1.0f / v.z);
+      part = fminf(part, (w & 8u) ? __builtin_inff() : 1.0f / v.w);
+    } else {
+      part = part + ((w & 1u) ? 0.0f : v.x);
+      part = part + ((w & 2u) ? 0.0f : v.y);
+      part = part + ((w & 4u) ? 0.0f : v.z);
+      part = part + ((w & 8u) ? 0.0f : v.w);
+    }
   }
-  const float T = readlane_f(wave_scan_add(part), 63);
-  hval[row * SP_KH + lane] = lane == 63 ? T : (live ? pr[id] : 0.0f);
+  float T;
+  if constexpr (RACE) {
+    for (int o = 32; o >= 1; o >>= 1) part = fminf(part, __shfl_xor(part, o));
+    T = part;
+    hval[row * SP_KH + lane] = lane == 63 ? T : (live ? 1.0f / pr[id] : __builtin_inff());
+  } else {
+    T = readlane_f(wave_scan_add(part), 63);
+    hval[row * SP_KH + lane] = lane == 63 ? T : (live ? pr[id] : 0.0f);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -138,9 +155,17 @@ __device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4
-template <int CHD>
-__global__ void __launch_bounds__(256, CHD == 2 ? 6 : 3)
+// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4.
+// RACE: the exponential race of DACO_RACE_PHILOX (the reference's torch.multinomial arithmetic, tsp/aco.py:174-175, with in-kernel
+// noise) on the same head rows, with the SAME result as the dense race kernel: the winner over the head's open candidates is the
+// winner over the whole row whenever its key is below every key a tail candidate could possibly draw --
+// key_j = L_j / p_j >= L_min / max_tail(p), L_min = the smallest value the noise can take (u = 2^-24) -- and that is checked each
+// step (with a factor 1/2 of margin); otherwise the step runs the dense race for that ant.  Noise indexed by node id exactly as in
+// the dense kernel (Philox block (t << 12) | (k >> 2), component k & 3): bit-identical tours, a head step generates 64 variates
+// instead of 512 (the dense race kernel is bound by VALU issue: one Philox block per four candidates and a degree-8 polynomial
+// per candidate, profiles/r04_pmc_race.txt).
+template <int CHD, bool RACE>
+__global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 3)
 scan_sparse_kernel(const SampleParams p) {
   constexpr int APW = 4, APB = 16;
   constexpr int FL = CHD * 256;                          // flag / tour / inverse-table entries per ant (>= n)
@@ -193,110 +218,169 @@ scan_sparse_kernel(const SampleParams p) {
     float ucur = 0.0f;
 
     for (int t = 1; t < n; ++t) {
-      // ---- the head of row `prev`: four values and four ids per lane
-      const float4 hv0 = *reinterpret_cast<const float4 *>(hvb + (uint32_t)prev * (SP_KH * 4u) + (uint32_t)s * 16u);
-      const uint2 hi2 = *reinterpret_cast<const uint2 *>(hib + (uint32_t)prev * (SP_KH * 2u) + (uint32_t)s * 8u);
-      // uniform of step t: component (t>>4)&3 of Philox block ((t>>6)<<4) + (t&15); lane s computes the one of step
-      // (t & ~15) + 15 - s, the row is rotated by one lane per step so that lane 15 holds the current one
-      if ((t & 15) == 0 || t == 1) {
-        if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SPARSE, gid, (uint32_t)(((t >> 6) << 4) + (15 - s)));
-        ucur = u01(comp(ublk, (t >> 4) & 3));
-        if (t == 1) ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
-      }
-      const float u = sp_row_bcast<15>(ucur);
-      ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
-      const int id0 = hi2.x & 0xFFFFu, id1 = hi2.x >> 16, id2 = hi2.y & 0xFFFFu, id3 = hi2.y >> 16;
-      // slot 63 (lane 15, v = 3) holds the tail total, not a candidate; its id field holds the live count (< 64 <= n)
-      const float T = sp_row_bcast<15>(hv0.w);
-      const float hw = lane15 ? 0.0f : hv0.w;
-      const float f0 = (float)fl[id0], f1 = (float)fl[id1], f2 = (float)fl[id2], f3 = (float)fl[id3];
-      const float run0 = __builtin_fmaf(hv0.x, f0, 0.0f);
-      const float run1 = __builtin_fmaf(hv0.y, f1, run0);
-      const float run2 = __builtin_fmaf(hv0.z, f2, run1);
-      const float run3 = __builtin_fmaf(hw, f3, run2);
-      const float part = run3;
-      const float incl = sp_row_scan(part);
-      const float H = sp_row_bcast<15>(incl);
-      float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
-      const float tot = H + T;
-      float r = u * tot;
-      r = r > 0.0f ? r : 1.401298464e-45f;
-
-      // the lane's last slot with a positive term (not "where the running sum stops growing": a term can be absorbed)
-      const int last_pos = hw * f3 > 0.0f ? 3 : (hv0.z * f2 > 0.0f ? 2 : (hv0.y * f1 > 0.0f ? 1 : 0));
-      // level 1 + 2 for a given threshold: node + 1 of the group's winner in every lane of the group, 0 if r is past the head
-      auto head_decide = [&](float rr) -> int {
-        const uint64_t m = __builtin_amdgcn_fcmpf(incl, rr, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, SP_FCMP_OGT);
-        const bool mine = __builtin_amdgcn_inverse_ballot_w64(sp_row_first(m));
-        const float thr = fmaxf(rr - excl, 1.401298464e-45f);
-        int c4 = (run0 < thr ? 1 : 0) + (run1 < thr ? 1 : 0) + (run2 < thr ? 1 : 0) + (run3 < thr ? 1 : 0);
-        if (__builtin_expect(__ballot(mine && c4 >= 4) != 0, 0)) c4 = c4 >= 4 ? last_pos : c4;    // rounding: the lane's last positive slot
-        const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
-        const int node = (int)((ids64 >> (16 * c4)) & 0xFFFFu);
-        return sp_row_or(mine ? node + 1 : 0);
-      };
-      int x = head_decide(r);
-
-      // ---- the rare ways, one ant at a time with the whole wavefront
-      const bool hpos = H > 0.0f;
-      uint64_t rare = __ballot(!hpos || x == 0) & 0x0001000100010001ull;
-      while (rare) {
-        const int gl = __builtin_ctzll(rare);             // lane 0 of the group
-        rare &= rare - 1;
-        const int g = gl >> 4;
-        const int pv = readlane_i(prev, gl);
-        const float Hg = readlane_f(H, gl), Tg = readlane_f(T, gl);
-        float ug = readlane_f(u, gl), rg = readlane_f(r, gl);
-        const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
-        const uint8_t *flg = open_flags[wave * APW + g];
-        const char *rowp = Pb + (uint32_t)pv * ldb;
-        int choice_g = -1;
-        bool bitmap_ready = false;
-        const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
-        for (int att = 0;; ++att) {
-          if (!(Hg > 0.0f) || att > 1023) {               // no live head candidate: the dense masked draw with this uniform
-            n_dense += real;
-            choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
-            if (choice_g < 0) { infeasible = true; choice_g = 0; }
-            break;
-          }
-          if (att > 0) {                                  // a new uniform: is r inside the head now?
-            const int x2 = head_decide(q == g ? rg : r);
-            const int xg = readlane_i(x2, gl);
-            if (xg) { choice_g = xg - 1; break; }
-          }
-          n_tail += real;
-          if (!bitmap_ready) {
-            const uint16_t *ids = reinterpret_cast<const uint16_t *>(hib + (uint32_t)pv * (SP_KH * 2u));
-            const int cntg = ids[63];
-            if (lane < 32) bm_s[wave][lane] = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < cntg) { const int idl = ids[lane]; atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31)); }
-            __builtin_amdgcn_wave_barrier();
-            bitmap_ready = true;
-          }
-          float rp = rg - Hg;
-          rp = rp > 0.0f ? rp : 1.401298464e-45f;
-          int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
-          if (j < 0) {                                    // a tail without mass: the head's last live candidate
-            const bool live_lane = q == g && part > 0.0f;
-            const uint64_t ml = __ballot(live_lane);
-            if (ml == 0) { infeasible = true; choice_g = 0; break; }
-            const int Ll = 63 - __builtin_clzll(ml);
-            const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
-            choice_g = readlane_i((int)((ids64 >> (16 * last_pos)) & 0xFFFFu), Ll);
-            break;
-          }
-          if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
-          n_rej += real;                                  // visited: draw again
-          const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
-          ug = u01(comp(rb, att & 3));
-          rg = ug * (Hg + Tg);
-          rg = rg > 0.0f ? rg : 1.401298464e-45f;
+      int choice;
+      if constexpr (RACE) {
+        // ---- the race on the head: 1 / p and node id of four slots per lane, one variate each
+        const float4 hr = *reinterpret_cast<const float4 *>(hvb + (uint32_t)prev * (SP_KH * 4u) + (uint32_t)s * 16u);
+        const uint2 hi2 = *reinterpret_cast<const uint2 *>(hib + (uint32_t)prev * (SP_KH * 2u) + (uint32_t)s * 8u);
+        const int idv[4] = {(int)(hi2.x & 0xFFFFu), (int)(hi2.x >> 16), (int)(hi2.y & 0xFFFFu), (int)(hi2.y >> 16)};
+        const float rv[4] = {hr.x, hr.y, hr.z, lane15 ? __builtin_inff() : hr.w};      // (slot 63 is the tail's bound, not a candidate)
+        const float rtail = sp_row_bcast<15>(hr.w);
+        float bk = __builtin_inff();
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int k = idv[v];
+          const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
+          const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
+          const float key = fl[k] != 0 ? Lk * rv[v] : __builtin_inff();
+          if (prefer<false>(key, k, bk, bi)) { bk = key; bi = k; }
         }
-        x = q == g ? choice_g + 1 : x;
+        arg_step<false, DPP_ROW_SHR(1), 0xF>(bk, bi);
+        arg_step<false, DPP_ROW_SHR(2), 0xF>(bk, bi);
+        arg_step<false, DPP_ROW_SHR(4), 0xF>(bk, bi);
+        arg_step<false, DPP_ROW_SHR(8), 0xF>(bk, bi);
+        const float best = sp_row_bcast<15>(bk);
+        choice = __float_as_int(sp_row_bcast<15>(__int_as_float(bi)));
+        // no tail candidate can beat `best` if best < L_min * min_tail(1/p) (half of it: margin for the polynomial's last bits)
+        const float lmin = neg_log2_1m(0x1p-24f);
+        uint64_t rare = __ballot(!(best < 0.5f * lmin * rtail)) & 0x0001000100010001ull;
+        while (rare) {                                    // the dense race for one ant, all 64 lanes
+          const int gl = __builtin_ctzll(rare);
+          rare &= rare - 1;
+          const int g = gl >> 4;
+          const int pv = readlane_i(prev, gl);
+          const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
+          const uint8_t *flg = open_flags[wave * APW + g];
+          const char *rowp = Pb + (uint32_t)pv * ldb;
+          n_dense += a0 + g < A ? 1ull : 0ull;
+          float dk = __builtin_inff();
+          int di = 0x7fffffff;
+#pragma unroll
+          for (int c = 0; c < CHD; ++c) {
+            const int k0 = (c * 64 + lane) * 4;
+            const float4 pvv = *reinterpret_cast<const float4 *>(rowp + (uint32_t)k0 * 4u);
+            const uint32_t ff = *reinterpret_cast<const uint32_t *>(flg + k0);
+            const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gidg, ((uint32_t)t << 12) | (uint32_t)(c * 64 + lane));
+            const float pp[4] = {pvv.x, pvv.y, pvv.z, pvv.w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const float Lk = neg_log2_1m(u01(comp(r4, v)));
+              const float key = ((ff >> (8 * v)) & 0xFFu) ? Lk * (1.0f / pp[v]) : __builtin_inff();     // (padding: p = 0 -> inf)
+              if (key < dk) { dk = key; di = k0 + v; }
+            }
+          }
+          const KeyIdx rr = wave_arg<false>(dk, di);
+          int cg = rr.idx;
+          if (!(rr.key < __builtin_inff())) { infeasible = true; cg = 0; }
+          choice = q == g ? cg : choice;
+        }
+      } else {
+        // ---- the head of row `prev`: four values and four ids per lane
+        const float4 hv0 = *reinterpret_cast<const float4 *>(hvb + (uint32_t)prev * (SP_KH * 4u) + (uint32_t)s * 16u);
+        const uint2 hi2 = *reinterpret_cast<const uint2 *>(hib + (uint32_t)prev * (SP_KH * 2u) + (uint32_t)s * 8u);
+        // uniform of step t: component (t>>4)&3 of Philox block ((t>>6)<<4) + (t&15); lane s computes the one of step
+        // (t & ~15) + 15 - s, the row is rotated by one lane per step so that lane 15 holds the current one
+        if ((t & 15) == 0 || t == 1) {
+          if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SPARSE, gid, (uint32_t)(((t >> 6) << 4) + (15 - s)));
+          ucur = u01(comp(ublk, (t >> 4) & 3));
+          if (t == 1) ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
+        }
+        const float u = sp_row_bcast<15>(ucur);
+        ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
+        const int id0 = hi2.x & 0xFFFFu, id1 = hi2.x >> 16, id2 = hi2.y & 0xFFFFu, id3 = hi2.y >> 16;
+        // slot 63 (lane 15, v = 3) holds the tail total, not a candidate; its id field holds the live count (< 64 <= n)
+        const float T = sp_row_bcast<15>(hv0.w);
+        const float hw = lane15 ? 0.0f : hv0.w;
+        const float f0 = (float)fl[id0], f1 = (float)fl[id1], f2 = (float)fl[id2], f3 = (float)fl[id3];
+        const float run0 = __builtin_fmaf(hv0.x, f0, 0.0f);
+        const float run1 = __builtin_fmaf(hv0.y, f1, run0);
+        const float run2 = __builtin_fmaf(hv0.z, f2, run1);
+        const float run3 = __builtin_fmaf(hw, f3, run2);
+        const float part = run3;
+        const float incl = sp_row_scan(part);
+        const float H = sp_row_bcast<15>(incl);
+        float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
+        const float tot = H + T;
+        float r = u * tot;
+        r = r > 0.0f ? r : 1.401298464e-45f;
+
+        // the lane's last slot with a positive term (not "where the running sum stops growing": a term can be absorbed)
+        const int last_pos = hw * f3 > 0.0f ? 3 : (hv0.z * f2 > 0.0f ? 2 : (hv0.y * f1 > 0.0f ? 1 : 0));
+        // level 1 + 2 for a given threshold: node + 1 of the group's winner in every lane of the group, 0 if r is past the head
+        auto head_decide = [&](float rr) -> int {
+          const uint64_t m = __builtin_amdgcn_fcmpf(incl, rr, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, SP_FCMP_OGT);
+          const bool mine = __builtin_amdgcn_inverse_ballot_w64(sp_row_first(m));
+          const float thr = fmaxf(rr - excl, 1.401298464e-45f);
+          int c4 = (run0 < thr ? 1 : 0) + (run1 < thr ? 1 : 0) + (run2 < thr ? 1 : 0) + (run3 < thr ? 1 : 0);
+          if (__builtin_expect(__ballot(mine && c4 >= 4) != 0, 0)) c4 = c4 >= 4 ? last_pos : c4;    // rounding: the lane's last positive slot
+          const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
+          const int node = (int)((ids64 >> (16 * c4)) & 0xFFFFu);
+          return sp_row_or(mine ? node + 1 : 0);
+        };
+        int x = head_decide(r);
+
+        // ---- the rare ways, one ant at a time with the whole wavefront
+        const bool hpos = H > 0.0f;
+        uint64_t rare = __ballot(!hpos || x == 0) & 0x0001000100010001ull;
+        while (rare) {
+          const int gl = __builtin_ctzll(rare);             // lane 0 of the group
+          rare &= rare - 1;
+          const int g = gl >> 4;
+          const int pv = readlane_i(prev, gl);
+          const float Hg = readlane_f(H, gl), Tg = readlane_f(T, gl);
+          float ug = readlane_f(u, gl), rg = readlane_f(r, gl);
+          const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
+          const uint8_t *flg = open_flags[wave * APW + g];
+          const char *rowp = Pb + (uint32_t)pv * ldb;
+          int choice_g = -1;
+          bool bitmap_ready = false;
+          const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
+          for (int att = 0;; ++att) {
+            if (!(Hg > 0.0f) || att > 1023) {               // no live head candidate: the dense masked draw with this uniform
+              n_dense += real;
+              choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
+              if (choice_g < 0) { infeasible = true; choice_g = 0; }
+              break;
+            }
+            if (att > 0) {                                  // a new uniform: is r inside the head now?
+              const int x2 = head_decide(q == g ? rg : r);
+              const int xg = readlane_i(x2, gl);
+              if (xg) { choice_g = xg - 1; break; }
+            }
+            n_tail += real;
+            if (!bitmap_ready) {
+              const uint16_t *ids = reinterpret_cast<const uint16_t *>(hib + (uint32_t)pv * (SP_KH * 2u));
+              const int cntg = ids[63];
+              if (lane < 32) bm_s[wave][lane] = 0u;
+              __builtin_amdgcn_wave_barrier();
+              if (lane < cntg) { const int idl = ids[lane]; atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31)); }
+              __builtin_amdgcn_wave_barrier();
+              bitmap_ready = true;
+            }
+            float rp = rg - Hg;
+            rp = rp > 0.0f ? rp : 1.401298464e-45f;
+            int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
+            if (j < 0) {                                    // a tail without mass: the head's last live candidate
+              const bool live_lane = q == g && part > 0.0f;
+              const uint64_t ml = __ballot(live_lane);
+              if (ml == 0) { infeasible = true; choice_g = 0; break; }
+              const int Ll = 63 - __builtin_clzll(ml);
+              const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
+              choice_g = readlane_i((int)((ids64 >> (16 * last_pos)) & 0xFFFFu), Ll);
+              break;
+            }
+            if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
+            n_rej += real;                                  // visited: draw again
+            const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
+            ug = u01(comp(rb, att & 3));
+            rg = ug * (Hg + Tg);
+            rg = rg > 0.0f ? rg : 1.401298464e-45f;
+          }
+          x = q == g ? choice_g + 1 : x;
+        }
+        choice = x - 1;
       }
-      const int choice = x - 1;
       if (s == 0) { fl[choice] = 0; tour[t] = (uint16_t)choice; }
       asm volatile("" ::: "memory");                      // the next step's flag reads follow these stores
       __builtin_amdgcn_wave_barrier();
@@ -386,28 +470,29 @@ extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n) {
   return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * SP_KH * sizeof(float));
 }
 
-extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+static int sample_sparse_impl(bool race, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                       long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
                                       int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                       long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                       size_t workspace_bytes, void *ev_begin, void *ev_end) {
   if (B <= 0 || A <= 0 || !tau || !eta || !head_id || !workspace || (!paths && !nbr)) {
-    set_error("daco_tsp_sample_sparse: bad argument (B=%d n=%d A=%d)", B, n, A);
+    set_error("%s: bad argument (B=%d n=%d A=%d)", what, B, n, A);
     return DACO_E_BADARG;
   }
-  if (n <= 128 || n > 1024) { set_error("daco_tsp_sample_sparse: n=%d outside 129..1024 (the dense samplers serve the other sizes)", n); return DACO_E_TOOLARGE; }
-  if ((size_t)n * A * 8 >= ((size_t)1 << 32)) { set_error("daco_tsp_sample_sparse: n * A too large for 32-bit offsets"); return DACO_E_TOOLARGE; }
-  if (fixed_start >= n) { set_error("daco_tsp_sample_sparse: fixed_start %d >= n %d", fixed_start, n); return DACO_E_BADARG; }
-  if (costs && !dist) { set_error("daco_tsp_sample_sparse: fused costs need the distance matrix"); return DACO_E_BADARG; }
+  if (n <= 128 || n > 1024) { set_error("%s: n=%d outside 129..1024 (the dense samplers serve the other sizes)", what, n); return DACO_E_TOOLARGE; }
+  if ((size_t)n * A * 8 >= ((size_t)1 << 32)) { set_error("%s: n * A too large for 32-bit offsets", what); return DACO_E_TOOLARGE; }
+  if (fixed_start >= n) { set_error("%s: fixed_start %d >= n %d", what, fixed_start, n); return DACO_E_BADARG; }
+  if (costs && !dist) { set_error("%s: fused costs need the distance matrix", what); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sparse_workspace_bytes(B, n);
-  if (workspace_bytes < need) { set_error("daco_tsp_sample_sparse: workspace %zu < %zu bytes", workspace_bytes, need); return DACO_E_WORKSPACE; }
+  if (workspace_bytes < need) { set_error("%s: workspace %zu < %zu bytes", what, workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   const int ld = n <= 512 ? 512 : 1024;
   float *P = (float *)workspace;
   float *hval = (float *)((char *)workspace + align256((size_t)B * n * ld * sizeof(float)));
   launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, nullptr, s);
-  hipLaunchKernelGGL(sparse_head_kernel, dim3((unsigned)(((long)B * n + 3) / 4)), dim3(256), 0, s, B, n, ld, P, head_id, hval);
+  if (race) hipLaunchKernelGGL(sparse_head_kernel<true>, dim3((unsigned)(((long)B * n + 3) / 4)), dim3(256), 0, s, B, n, ld, P, head_id, hval);
+  else hipLaunchKernelGGL(sparse_head_kernel<false>, dim3((unsigned)(((long)B * n + 3) / 4)), dim3(256), 0, s, B, n, ld, P, head_id, hval);
   SampleParams sp{};
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = ld / 256;
   sp.P = P; sp.start = start; sp.fixed_start = fixed_start;
@@ -415,13 +500,39 @@ extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const f
   sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
   sp.hval = hval; sp.hid = head_id; sp.stats = stats;
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error("daco_tsp_sample_sparse pre-pass: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  if (e != hipSuccess) { set_error("%s pre-pass: %s", what, hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   const int bpi = (A + 15) / 16;
-  if (ld <= 512) hipLaunchKernelGGL((scan_sparse_kernel<2>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 512 * 2, s, sp);
-  else hipLaunchKernelGGL((scan_sparse_kernel<4>), dim3((unsigned)(B * bpi)), dim3(256), 16 * 1024 * 2, s, sp);
+  const dim3 grid((unsigned)(B * bpi));
+  if (ld <= 512) {
+    if (race) hipLaunchKernelGGL((scan_sparse_kernel<2, true>), grid, dim3(256), 16 * 512 * 2, s, sp);
+    else hipLaunchKernelGGL((scan_sparse_kernel<2, false>), grid, dim3(256), 16 * 512 * 2, s, sp);
+  } else {
+    if (race) hipLaunchKernelGGL((scan_sparse_kernel<4, true>), grid, dim3(256), 16 * 1024 * 2, s, sp);
+    else hipLaunchKernelGGL((scan_sparse_kernel<4, false>), grid, dim3(256), 16 * 1024 * 2, s, sp);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("scan_sparse_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
   return DACO_OK;
+}
+
+#define DACO_SPARSE_ARGS stream, B, n, A, tau, tau_bstride, eta, eta_bstride, alpha, beta, head_id, start, fixed_start, seed, iter, \
+                         iter_offset, ant_gid0, ant_gid_bstride, paths, flags, dist, dist_bstride, costs, nbr, stats, workspace, \
+                         workspace_bytes, ev_begin, ev_end
+extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
+                                      int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
+                                      uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
+                                      long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
+                                      size_t workspace_bytes, void *ev_begin, void *ev_end) {
+  return sample_sparse_impl(false, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
+}
+extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+                                         long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
+                                         int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
+                                         uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
+                                         long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
+                                         size_t workspace_bytes, void *ev_begin, void *ev_end) {
+  return sample_sparse_impl(true, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
 }

@@ -140,10 +140,12 @@ def sparse_head(weights, k):
 
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
-                      want_paths=True):
+                      want_paths=True, race=False):
     """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
     distribution of tsp_sample(mode="scan"), 384 bytes per step instead of a row while the head has a live candidate.
-    head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats])."""
+    head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats]).
+    race=True: daco_tsp_sample_race_head -- the exponential race of mode="race" on the head rows, with the tours of the dense
+    race kernel (same seed), 64 variates per step instead of n."""
     _require_gpu(tau, eta, start, head)
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
@@ -170,7 +172,8 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
         if nbytes == 0:
             raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
         ws = _workspace(dev, nbytes, "sample_sparse")
-        rc = L.daco_tsp_sample_sparse(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+        fn = L.daco_tsp_sample_race_head if race else L.daco_tsp_sample_sparse
+        rc = fn(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
                                       float(beta), head.data_ptr(), start.data_ptr() if start is not None else None,
                                       int(fixed_start), int(seed) & (2 ** 64 - 1), int(it),
                                       iter_dev.data_ptr() if iter_dev is not None else None, int(ant_gid0) & 0xFFFFFFFF,
@@ -180,7 +183,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
                                       nbr.data_ptr() if nbr is not None else None,
                                       stats.data_ptr() if stats is not None else None, ws.data_ptr(), ws.numel(),
                                       events[0].cuda_event if events else None, events[1].cuda_event if events else None)
-    _lib.check(rc, "daco_tsp_sample_sparse")
+    _lib.check(rc, "daco_tsp_sample_race_head" if race else "daco_tsp_sample_sparse")
     out = (paths, flags, costs, nbr)
     return out + (stats,) if want_stats else out
 
@@ -796,11 +799,13 @@ class BatchedTSP:
         # (_iter_dev: device-side iteration counter of a captured graph; self.iteration then stays frozen)
         # events: torch.cuda.Event pair re-recorded around the construction kernel; ls_events: a pair recorded (on the
         # current stream, which is the stream the library launches on) right before / after the local-search launches
-        if self.sampler == "scan_sparse":
+        # sampler="race" after sparsify(k): the same tours from the head rows (daco_tsp_sample_race_head), an eighth of the noise
+        race_head = self.sampler == "race" and self.head_k is not None and 128 < self.n <= 1024
+        if self.sampler == "scan_sparse" or race_head:
             paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, self._head_table(), self.alpha,
                                                      self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
-                                                     dist=self.distances, want_nbr=True, iter_dev=_iter_dev)
+                                                     dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head)
         else:
             paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
                                                     self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,

@@ -146,6 +146,22 @@ int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
                            unsigned long long *stats,
                            void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
 
+/* daco_tsp_sample_race_head -- daco_tsp_sample(DACO_RACE_PHILOX) on the same head rows, with the SAME tours (same seed,
+ * same noise indexing by node id): the exponential race of torch.multinomial's one-sample path (tsp/aco.py:174-175) is won
+ * by a head candidate whenever its key L/p is below what any tail candidate could draw, L_min / max_tail(p); that is checked
+ * every step and the dense race runs for the ant otherwise.  64 variates per step instead of n.  Arguments as
+ * daco_tsp_sample_sparse (stats[0] = steps that took the dense race). */
+int daco_tsp_sample_race_head(void *stream, int B, int n, int A,
+                              const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                              float alpha, float beta, const uint16_t *head_id,
+                              const int64_t *start, int fixed_start,
+                              uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
+                              int ant_gid_bstride,
+                              int64_t *paths, int32_t *flags,
+                              const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
+                              unsigned long long *stats,
+                              void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
+
 /* ---------------------------------------------------------------------------------------------
  * daco_cvrp_sample -- replaces the CVRP ACO.gen_path / pick_move / update_visit_mask /
  * update_capacity_mask / check_done  (cvrp/aco.py:138-205 = cvrp_nls/aco.py:205-272)

@@ -124,3 +124,48 @@ def test_scan_sparse_colony_surface():
     for _ in range(6):
         dense.step()
     assert abs(float(col.lowest_cost.mean()) / float(dense.lowest_cost.mean()) - 1) < 0.05
+
+
+@pytest.mark.parametrize("n,A,B,kind,fixed", [(200, 40, 2, "ksparse", -1), (160, 24, 1, "random_head", 0), (300, 21, 1, "tiny_head", 3),
+                                            (500, 32, 2, "ksparse", -1), (1000, 10, 1, "ksparse", -1), (640, 9, 1, "random_head", 2)])
+def test_race_on_head_rows_equals_the_dense_race(n, A, B, kind, fixed):
+    """daco_tsp_sample_race_head: the exponential race of DACO_RACE_PHILOX (torch.multinomial's arithmetic, tsp/aco.py:174-175)
+    generated for the 64 head slots only, the dense race for an ant whenever a tail candidate could still win.  Same noise
+    indexing by node id: the tours must be the dense race's bit for bit -- against the oracle's race and against the dense
+    kernel -- whatever the head is (k-sparse: a few dense steps late in the tours; an arbitrary subset of a dense heuristic:
+    the bound fails at almost every step)."""
+    from deepaco_amd import engine
+    d, tau, eta, heads = instance(n, 300 + n, kind, B)
+    td, ed, dd = tau.to(dev()), eta.to(dev()), d.to(dev())
+    paths, flags, costs, nbr, stats = engine.tsp_sample_sparse(td, ed, A, pack(heads), seed=13, it=2, fixed_start=fixed, dist=dd,
+                                                               want_nbr=True, want_stats=True, race=True)
+    assert int(flags.sum()) == 0
+    dense, _, _, dflags, dcosts, dnbr = engine.tsp_sample(td, ed, A, mode="race", seed=13, it=2, fixed_start=fixed, dist=dd, want_nbr=True)
+    assert torch.equal(paths, dense) and torch.equal(costs.view(torch.int32), dcosts.view(torch.int32)) and torch.equal(nbr, dnbr)
+    for b in range(B):
+        P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+        ref, _, rc = oracle.tsp_sample_race(P, A, seed=13, it=2, ant_gid0=b * A, fixed_start=fixed)
+        assert rc == 0 and np.array_equal(paths[b].cpu().numpy(), ref), (n, kind, b)
+    st = int(stats[0])
+    if kind == "ksparse" and n // 10 <= 63:             # (n = 1000: 100 live entries per row, 63 in the head -- the bound never holds)
+        assert 0 < st < 0.1 * B * A * n
+    if kind == "random_head":
+        assert st > 0.5 * B * A * n
+
+
+def test_race_colony_takes_the_head_rows_after_sparsify():
+    """BatchedTSP(sampler='race') after sparsify(k) draws from the head rows: the same colony, iteration for iteration, as one
+    that is kept on the dense race kernel."""
+    from deepaco_amd import engine
+    B, n, A = 2, 300, 64
+    d = instance(n, 4, "ksparse", B)[0].to(dev())
+    a = engine.BatchedTSP(d, n_ants=A, seed=9, sampler="race")
+    a.sparsify(30)
+    b = engine.BatchedTSP(d, n_ants=A, seed=9, sampler="race")
+    b.sparsify(30)
+    b.head_k = None                                      # (stays on the dense kernel)
+    for _ in range(4):
+        pa, ca = a.step()
+        pb, cb = b.step()
+        assert torch.equal(pa, pb) and torch.equal(ca, cb)
+    assert torch.equal(a.pheromone, b.pheromone)
