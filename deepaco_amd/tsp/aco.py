@@ -96,6 +96,16 @@ class ACO():
         sparse_distances = torch.full_like(self.distances, 1e10)
         sparse_distances.scatter_(1, topk_indices, torch.gather(self.distances, 1, topk_indices))
         self.heuristic = 1 / sparse_distances
+        self._head_k = min(int(k_sparse), 63)              # sampler='scan_sparse': the head of a row = these k entries
+
+    def _head_table(self):
+        """[1, n, 64] head ids for sampler='scan_sparse' (engine.sparse_head), once per heuristic object."""
+        hit = self.__dict__.get("_head")
+        if hit is None or hit[0] is not self.heuristic:
+            k = self.__dict__.get("_head_k") or max(1, min(63, self.problem_size // 10))
+            hit = (self.heuristic, engine.sparse_head(self.heuristic.detach().float().contiguous(), k))
+            self._head = hit
+        return hit[1]
 
     # ------------------------------------------------------------------ tsp/aco.py:69-72
     def sample(self):
@@ -124,11 +134,17 @@ class ACO():
         tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
         eta = self.heuristic.detach()
         cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
+        sparse = self.sampler == "scan_sparse"              # head / tail rows (inference on a k-sparse heuristic, 129 <= n <= 1024)
         for _ in range(n_iterations):
-            paths, _, _, flags, costs, nbr = engine.tsp_sample(
-                tau, eta, self.n_ants, self.alpha, self.beta, mode=self.sampler,
-                norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
-                dist=dist, want_nbr=True)
+            if sparse:
+                paths, flags, costs, nbr = engine.tsp_sample_sparse(
+                    tau, eta, self.n_ants, self._head_table(), self.alpha, self.beta, fixed_start=self.FIXED_START,
+                    seed=self.seed, it=self._calls, batch=1, dist=dist, want_nbr=True)
+            else:
+                paths, _, _, flags, costs, nbr = engine.tsp_sample(
+                    tau, eta, self.n_ants, self.alpha, self.beta, mode=self.sampler,
+                    norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
+                    dist=dist, want_nbr=True)
             self._calls += 1
             self._last_flags = flags
             # `if best_cost < self.lowest_cost: ...` (tsp/aco.py:78-88) on the device

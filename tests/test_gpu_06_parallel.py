@@ -121,3 +121,34 @@ def test_bench_four_ranks_on_one_gpu_both_shardings():
     delta = _bench_line("--shard", "ants", "--exchange", "delta", *common)
     assert delta["n_gpus"] == 4 and delta["scaling"] == "strong" and "all-reduce of delta-tau" in delta["rccl"]["data_path_collective"]
     assert delta["gpu_mean_best_cost"] > 0
+
+
+def test_bench_eight_ranks_the_drivers_launch_path():
+    """Eight ranks on one GPU (gloo rendezvous): the world size of the driver's `--gpus 8` scaling run, instance-sharded
+    (BASELINE config 5's partitioning: no data-path collective, weak scaling) and `--shard ants --exchange delta` (what
+    `--config c5 --shard ants --exchange delta` runs at TSP-1000 x 2048 x 64, here at a test size: the delta-tau all-reduce on
+    the data path).  And through torchrun, as the driver starts it."""
+    import subprocess
+    import sys
+    common = ("--no-cpu", "--no-extras", "--min-seconds", "0", "--steps", "2", "--warmup", "1", "--nodes", "130",
+              "--ants", "32", "--batch", "2", "--gpus", "8", "--dist-backend", "gloo", "--force-device", "0")
+    inst = _bench_line(*common)
+    assert inst["n_gpus"] == 8 and inst["rccl"]["ranks"] == 8 and inst["scaling"] == "weak"
+    assert inst["config"]["parallelism"] == "instance-sharded x8" and inst["value"] > 0
+    delta = _bench_line("--shard", "ants", "--exchange", "delta", *common)
+    assert delta["n_gpus"] == 8 and delta["scaling"] == "strong" and "all-reduce of delta-tau" in delta["rccl"]["data_path_collective"]
+    # the driver's own command line: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                          "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "4", "--no-cpu",
+                          "--no-extras", "--min-seconds", "0", "--steps", "2", "--warmup", "1", "--nodes", "130", "--ants", "32",
+                          "--batch", "2", "--dist-backend", "gloo", "--force-device", "0"], capture_output=True, text=True,
+                         timeout=600, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    import json
+    assert json.loads(lines[0])["n_gpus"] == 4

@@ -169,3 +169,18 @@ def test_race_colony_takes_the_head_rows_after_sparsify():
         pb, cb = b.step()
         assert torch.equal(pa, pb) and torch.equal(ca, cb)
     assert torch.equal(a.pheromone, b.pheromone)
+
+
+def test_class_surface_runs_on_head_rows():
+    """tsp/test.ipynb's inference pattern on the drop-in class: ACO(..., sampler='scan_sparse'); sparsify(k); run(T) -- the
+    colony runs on head / tail rows and lands where the dense sampler lands."""
+    from deepaco_amd.tsp.aco import ACO
+    n = 300
+    d = instance(n, 8, "ksparse", 1)[0][0].to(dev())
+    best = {}
+    for smp in ("scan_sparse", "scan"):
+        aco = ACO(d, n_ants=64, device="cuda:0", sampler=smp, seed=3)
+        aco.sparsify(30)
+        best[smp] = float(aco.run(8))
+        assert aco.shortest_path.sort().values.tolist() == list(range(n))
+    assert abs(best["scan_sparse"] / best["scan"] - 1) < 0.06
