@@ -622,6 +622,41 @@ def extra_configs(dev, headline_colony, cpu=True):
     except Exception as e:
         out["headline_learned_heuristic"] = {"error": repr(e)}
 
+    # config 5's LEARNED variant: TSP-1000, 2048 ants, heuristic = Net(pretrained tsp_nls/tsp1000.pt, start node 0)
+    # + 1e-10 on the k = 100 nearest-neighbour graph; 8 instances (a share of the per-GPU 64: the n x n heuristic is dense)
+    try:
+        from deepaco_amd.tsp_nls.net import Net as NlsNet
+        wz = np.load(os.path.join(ROOT, "tests", "golden", "w_tsp_nls_tsp1000.npz"))
+        lnet = NlsNet()
+        lnet.load_state_dict({k[3:]: torch.from_numpy(wz[k]) for k in wz.files}, strict=False)
+        lnet = lnet.to(dev).eval()
+        n, A, B, k = 1000, 2048, 8, 100
+        g = torch.Generator().manual_seed(1000)
+        coords = torch.rand(B, n, 2, generator=g).to(dev)
+        dist, ei, ea = engine.tsp_knn_graph(coords, k)
+        x = torch.zeros((B, n, 1), device=dev)
+        x[:, 0, 0] = 1.0                                       # tsp_nls/utils.py:30-33: the start node's one-hot
+        with torch.no_grad():
+            heu = lnet.reshape_batch(n, ei, lnet.forward_batch(x, ei, ea, k_sparse=k)) + 1e-10
+        res = {}
+        for tag, kw in (("learned", dict(heuristic=heu)), ("vanilla_1_over_d_sparsified", {})):
+            col = engine.BatchedTSP(dist, n_ants=A, seed=7, fixed_start=0, **kw)
+            if not kw:
+                col.sparsify(k)
+            col.heuristic = col.heuristic.contiguous()
+            col.step()
+            dtl = time_launches(col.step, 5, warm=1)
+            col.run(10 - col.iteration)
+            res[tag] = {"value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3,
+                        "mean_best_cost_after_10_iterations": float(col.lowest_cost.mean())}
+            del col
+        out["c5_learned_tsp1000_a2048_b8"] = {
+            "workload": f"TSP-{n}, n_ants={A}, {B} instances, start node 0, heuristic = Net(pretrained tsp_nls/tsp1000) + 1e-10 vs 1/d "
+                        f"sparsified k={k} (construction + update, no local search)", **res}
+        del lnet, heu
+    except Exception as e:
+        out["c5_learned_tsp1000_a2048_b8"] = {"error": repr(e)}
+
     # GNN forward (eval), 64 graphs of TSP-500 k=50 side by side
     from deepaco_amd.tsp.net import Net
     torch.manual_seed(0)

@@ -538,7 +538,8 @@ two_opt_incr2_kernel(int n, int T, const float *dist, const float *distT, long d
     // full (cached minimiser inside the changed range) or patch.  (pe was last read before the previous barrier.)
     const int half = (q - p + 1) >> 1;
     if (tabs && tabs == tabsT && tid == 0) {
-      // symmetric matrix: a reversal changes the ranks of edges p-1 and q only, the inner edges swap sides
+      // symmetric matrix (tabs == tabsT; only then: the non-symmetric case rebuilds cnt[2] from all n edges at the top of every
+      // sweep, above): a reversal changes the ranks of edges p-1 and q only, the inner edges swap sides
       // (thread 0 owns the swap of positions p and q below; t[p-1] and t[q+1] are not written in this phase)
       const int a = pe[p - 1].x & 0xFFFF, bq = pe[p].x & 0xFFFF, c = pe[q].x & 0xFFFF, dn = pe[q + 1 < n ? q + 1 : 0].x & 0xFFFF;
       atomicAdd(&cnt[2], rank_sum(a, c) + rank_sum(bq, dn) - rank_sum(a, bq) - rank_sum(c, dn));

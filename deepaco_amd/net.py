@@ -14,6 +14,8 @@ forward(pyg):
     eval mode with gradients required) runs the same math as torch ops with autograd instead.
 `pyg` only needs `.x`, `.edge_index`, `.edge_attr` (torch_geometric is not required).
 """
+import warnings
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -221,6 +223,8 @@ class Net(nn.Module):
         self._packed = None
         self._packed_key = None
 
+    _warned_torch_path = False
+
     # ------------------------------------------------------------------ reference surface
     def forward(self, pyg):
         x, edge_index, edge_attr = pyg.x, pyg.edge_index, pyg.edge_attr
@@ -230,6 +234,13 @@ class Net(nn.Module):
         if self.training and self.train_backend == "hip" and self._hip_train_supported():
             return self.forward_train_hip(pyg)
         if self.training or needs_graph:
+            # the module tree evaluated with torch ops (rocBLAS GEMMs, autograd): a second backend on the product path, taken
+            # only where the HIP kernels have no implementation -- said once, so that nobody measures it by accident
+            if not Net._warned_torch_path and not (self.training and self.train_backend != "hip"):
+                Net._warned_torch_path = True
+                why = ("eval mode with autograd enabled: wrap the call in torch.no_grad() for the HIP inference kernels"
+                       if not self.training else "BatchNorm configured away from its defaults (momentum=None or no running statistics)")
+                warnings.warn(f"deepaco_amd.Net.forward: torch-op path ({why})", RuntimeWarning, stacklevel=2)
             emb = self.emb_net(x, edge_index, edge_attr)
             return self.par_net_heu(emb)
         return self.forward_hip(pyg)

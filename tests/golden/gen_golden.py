@@ -437,6 +437,9 @@ def gen_bench_weights():
     not code): bench.py's learned-heuristic variant loads them into deepaco_amd's Net."""
     sd = torch.load(os.path.join(REF, "pretrained", "tsp", "tsp500.pt"), map_location="cpu")
     save("w_tsp_tsp500", **{"w__" + k: v.float().numpy() for k, v in sd.items() if v.numel() > 0 and v.dtype.is_floating_point})
+    # ... and the one SURVEY 8(d) names for config 5's learned variant: pretrained/tsp_nls/tsp1000.pt
+    sd = torch.load(os.path.join(REF, "pretrained", "tsp_nls", "tsp1000.pt"), map_location="cpu")
+    save("w_tsp_nls_tsp1000", **{"w__" + k: v.float().numpy() for k, v in sd.items() if v.numel() > 0 and v.dtype.is_floating_point})
 
 
 def load_ref_dir(subdir, alias):
