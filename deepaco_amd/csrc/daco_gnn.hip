@@ -509,7 +509,7 @@ template <bool INIT>
 __global__ void __launch_bounds__(256, 4)
 gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *src, const int *dst, const int *rowptr,
                         const float *params, const float *x0, const float *X, const float *w0, float *x1out, float *Xnext,
-                        float *w1out, const float *attr) {
+                        float *w1out, const float *attr, int nt) {
   __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];            // A rows -> MFMA result (edge-major) -> products (channel-major)
   __shared__ float agg_s[4][F2_MAX_NPW][U];
   __shared__ __attribute__((aligned(16))) float x3_s[4][F2_MAX_NPW][U];       // x3 rows of the wave's own nodes
@@ -559,7 +559,17 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
   const float4 ib = INIT ? *reinterpret_cast<const float4 *>(params + 32 * feats + 64 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_row = [&](int e) -> float4 {
     if constexpr (INIT) { const float av = attr[e]; return make_float4(av, av, av, av); }   // (expanded when the tile starts)
-    else return *reinterpret_cast<const float4 *>(w0b + (uint32_t)e * 128u + (uint32_t)c0 * 4u);
+    else {
+      // the edge rows are a stream (each read once per layer, by one lane): with the non-temporal policy (DACO_GNN_NT=0 turns
+      // it off) they do not push the node rows -- which every edge of a node gathers again -- out of the L2
+      const float4 *ptr = reinterpret_cast<const float4 *>(w0b + (uint32_t)e * 128u + (uint32_t)c0 * 4u);
+      if (nt) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(ptr));
+        return make_float4(v.x, v.y, v.z, v.w);
+      }
+      return *ptr;
+    }
   };
   auto made_row = [&](float4 r) -> float4 {
     if constexpr (INIT) {
@@ -652,7 +662,13 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
       if (live) {
         float4 out;
         out.x = old[q].x + s01.x; out.y = old[q].y + s01.y; out.z = old[q].z + s23.x; out.w = old[q].w + s23.y;
-        *reinterpret_cast<float4 *>(w1b + (uint32_t)e * 128u + (uint32_t)c0 * 4u) = out;
+        if (nt) {
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          const f4v ov = {out.x, out.y, out.z, out.w};
+          __builtin_nontemporal_store(ov, reinterpret_cast<f4v *>(w1b + (uint32_t)e * 128u + (uint32_t)c0 * 4u));
+        } else {
+          *reinterpret_cast<float4 *>(w1b + (uint32_t)e * 128u + (uint32_t)c0 * 4u) = out;
+        }
       }
       asm volatile("" ::: "memory");                                         // (the row reads above stay above these writes)
       float *pr = &tile[q * 8 + (c0 >> 2)][g8];
@@ -817,6 +833,7 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
   if (npw > FUSED_MAX_NPW) npw = FUSED_MAX_NPW;
   // EXPERIMENT (DACO_GNN_INPLACE=1, fused kernels only): the edge state is updated in place -- every row is read once, by the
   // lane that writes it, before it is written -- so the layers cycle through E * 128 B instead of twice that
+  const int nt_rows = getenv("DACO_GNN_NT") ? atoi(getenv("DACO_GNN_NT")) : 1;      // non-temporal edge rows (measured 1.81 -> 1.72 ms per forward)
   const bool fused2 = E >= split_min && !perm && fused_npw != 0 && fused_v == 2;
   // (the second fused kernel makes layer 0's edge state itself; every other path reads it from the init launch)
   if (!fused2) hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 8 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
@@ -827,9 +844,9 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
     if (fused2) {
       const dim3 grid((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8));
       if (l == 0) hipLaunchKernelGGL(gnn_fused2_layer_kernel<true>, grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
-                                     Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr);
+                                     Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows);
       else hipLaunchKernelGGL(gnn_fused2_layer_kernel<false>, grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
-                              Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr);
+                              Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows);
     } else if (E >= split_min && !perm && fused_npw != 0) {
       hipLaunchKernelGGL(gnn_fused_layer_kernel, dim3((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8)), dim3(256), 0, s, n, E, feats, l,
                          npw, src, dst, rowptr, params, xb[cur], Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout);
