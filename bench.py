@@ -372,7 +372,8 @@ def extra_configs(dev, headline_colony, cpu=True):
     kms = sum(a.elapsed_time(b) for a, b in ev) / steps
     L = float(col.last_lens.float().mean())
     tr, src = traffic.get("cvrp100_a512_b256_scan", (None, None))
-    rf = roofline_rows(n + 1, A, B, "scan", kms, steps_per_tour=L - 1, traffic=tr, traffic_source=src)
+    rf = roofline_rows(n + 1, A, B, "scan", kms, steps_per_tour=L - 1, traffic=tr, traffic_source=src,
+                       pipes=counters.get("cvrp100_a512_b256_scan"))
     rf["kernel"] = "scan16_kernel<CVRP> (HIP events around the construction kernel)"
     cb = None
     if cpu:
@@ -434,12 +435,13 @@ def extra_configs(dev, headline_colony, cpu=True):
         "roofline": {"bound": "l2", "achieved": alg / (kms * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
                      "frac": alg / (kms * 1e-3) / 1e9 / PEAK_L2_GBS, "traffic": tr, "traffic_source": src,
                      "kernel": "nls_kernel (daco_tsp_nls; HIP events around the launch)", "kernel_ms": kms,
+                     "pipes": counters.get("nls500_a256_b64"), "valu_busy": (counters.get("nls500_a256_b64") or {}).get("valu_busy"),
                      "algorithmic_bytes_per_launch": alg,
                      # what the L2 actually moves for them: every 8-byte table entry / 4-byte gather pulls a 128-byte line
                      "l2_lines": None if lines_req is None else {
                          "requests_per_launch": lines_req, "GBps": lines_req * 128 / (kms * 1e-3) / 1e9,
                          "frac": lines_req * 128 / (kms * 1e-3) / 1e9 / PEAK_L2_GBS,
-                         "source": "TCP_TCC_READ_REQ_sum of the kernel (profiles/r03_pmc_nls.txt; same workload and library "
+                         "source": "TCP_TCC_READ_REQ_sum of the kernel (profiles/r04_pmc_nls.txt; same workload and library "
                                    "version, not collected in this run) x 128 B / this run's kernel time"},
                      "note": "algorithmic bytes = 12 B per walked list entry (table entry + matrix gather) + 128 B per sweep for "
                              "the changed edges, from the in-run counters; the kernel is a chain of dependent L2 round trips and "
@@ -696,7 +698,9 @@ def extra_configs(dev, headline_colony, cpu=True):
                                               "unit": "GB/s", "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "traffic": tr,
                                               "traffic_source": src,
                                               "kernel": "gnn_fused2_layer_kernel x 12 layers (layer 0 makes the edge state, edge state in place) + node init + head (whole forward)",
-                                              "mfma_tflops": flops / dt / 1e12},
+                                              "mfma_tflops": flops / dt / 1e12,
+                                              "pipes": counters.get("gnn_fused2_layer_tsp500_k50_b64"),
+                                              "valu_busy": (counters.get("gnn_fused2_layer_tsp500_k50_b64") or {}).get("valu_busy")},
                                  "cpu_baseline": cb}
     return out
 

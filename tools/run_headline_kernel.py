@@ -32,13 +32,13 @@ ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 for a, b in ev:
     a.record(); b.record()
 torch.cuda.synchronize()
-head = engine.sparse_head(eta, min(63, max(5, n // 10))) if mode == "scan_sparse" else None
+head = engine.sparse_head(eta, min(63, max(5, n // 10))) if mode in ("scan_sparse", "race_head") else None
 stats = None
 for r in range(reps):
-    if mode == "scan_sparse":
+    if mode in ("scan_sparse", "race_head"):
         plain = os.environ.get("SPARSE_PLAIN") == "1"
         out = engine.tsp_sample_sparse(tau, eta, A, head, seed=3, it=r, batch=B, events=ev[r], dist=None if plain else d,
-                                       want_nbr=not plain, want_stats=(r == reps - 1))
+                                       want_nbr=not plain, want_stats=(r == reps - 1), race=(mode == "race_head"))
         stats = out[4].cpu().tolist() if r == reps - 1 else stats
     else:
         engine.tsp_sample(tau, eta, A, mode=mode, seed=3, it=r, batch=B, events=ev[r], dist=d, want_nbr=True)
