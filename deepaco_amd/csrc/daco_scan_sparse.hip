@@ -22,7 +22,7 @@
 namespace daco {
 
 constexpr int SP_KH = 64;                                // head slots per row (slot 63: the tail total / the live count)
-constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3;
+constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3, SP_FCMP_OLT = 4;
 
 enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
 
@@ -43,18 +43,25 @@ __device__ inline float sp_row_scan(float x) {
 __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x8000800080008000ull) - 0x0001000100010001ull); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// head values of one iteration: hval[row][m] = P[row][id_m] for the live slots, +0 for the others, slot 63 = the tail total
-// (the 64-lane scan total of the row's non-head entries).  One wavefront per row.
-// RACE (the exponential race on head rows, race_head_kernel below): hval[row][m] = 1 / P[row][id_m] (+inf for the other
-// slots), slot 63 = the smallest 1 / P of the tail, i.e. the reciprocal of its largest entry.
-template <bool RACE>
+// the pre-pass of one iteration, one wavefront per row: the padded row P[row][.] = tau^alpha * eta^beta (the arithmetic of
+// prob_matrix_kernel; only the rare ways read it back) and, from the same registers, the HEAD ROW the scan reads each step:
+// 16 lanes x ls bytes, lane s = {values of slots 4s..4s+3 (f32), their node ids (u16)}.  Value of slot m = P[row][id_m] for the
+// live slots, +0 for the others; slot 63 = the tail total (the 64-lane scan total of the row's non-head entries).  The id of an
+// empty slot and of slot 63 is `dead` (>= n): its visited flag is never set, so the scan needs no "is a candidate" select.
+// tau and eta are read once (2 x 4n bytes per row), nothing is read back.
+// RACE (the exponential race on head rows): value = 1 / P[row][id_m] (+inf for the other slots), slot 63 = the smallest
+// 1 / P of the tail, i.e. the reciprocal of its largest entry.
+template <bool RACE, bool VEC4>
 __global__ void __launch_bounds__(256)
-sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, float *hval) {
+sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha, float beta,
+                      const uint16_t *hid, float *P, char *hrow, int ls, int dead) {
   __shared__ uint32_t bm[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= (long)B * n) return;
-  const float *pr = P + row * ld;
+  const int b = (int)(row / n), r = (int)(row - (long)b * n);
+  const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
+  float *pr = P + row * ld;
   const uint16_t *ids = hid + row * SP_KH;
   const int cnt = ids[63];
   const int id = ids[lane];
@@ -67,7 +74,20 @@ sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, fl
   const int ch = ld >> 8;
   for (int c = 0; c < ch; ++c) {
     const int k0 = (c * 64 + lane) * 4;
-    const float4 v = *reinterpret_cast<const float4 *>(pr + k0);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (VEC4) {
+      if (k0 < n) {                                           // (n % 4 == 0: a vector is inside the row or in the padding)
+        const float4 t = *reinterpret_cast<const float4 *>(tr + k0), e = *reinterpret_cast<const float4 *>(er + k0);
+        v.x = pw(t.x, alpha) * pw(e.x, beta); v.y = pw(t.y, alpha) * pw(e.y, beta);
+        v.z = pw(t.z, alpha) * pw(e.z, beta); v.w = pw(t.w, alpha) * pw(e.w, beta);
+      }
+    } else {
+      if (k0 + 0 < n) v.x = pw(tr[k0 + 0], alpha) * pw(er[k0 + 0], beta);
+      if (k0 + 1 < n) v.y = pw(tr[k0 + 1], alpha) * pw(er[k0 + 1], beta);
+      if (k0 + 2 < n) v.z = pw(tr[k0 + 2], alpha) * pw(er[k0 + 2], beta);
+      if (k0 + 3 < n) v.w = pw(tr[k0 + 3], alpha) * pw(er[k0 + 3], beta);
+    }
+    *reinterpret_cast<float4 *>(pr + k0) = v;
     const uint32_t w = bm[wave][(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
     if constexpr (RACE) {
       part = fminf(part, (w & 1u) ? __builtin_inff() : 1.0f / v.x);
@@ -81,15 +101,19 @@ sparse_head_kernel(int B, int n, int ld, const float *P, const uint16_t *hid, fl
       part = part + ((w & 8u) ? 0.0f : v.w);
     }
   }
-  float T;
+  const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
+  float T, val;
   if constexpr (RACE) {
     for (int o = 32; o >= 1; o >>= 1) part = fminf(part, __shfl_xor(part, o));
     T = part;
-    hval[row * SP_KH + lane] = lane == 63 ? T : (live ? 1.0f / pr[id] : __builtin_inff());
+    val = lane == 63 ? T : (live ? 1.0f / pid : __builtin_inff());
   } else {
     T = readlane_f(wave_scan_add(part), 63);
-    hval[row * SP_KH + lane] = lane == 63 ? T : (live ? pr[id] : 0.0f);
+    val = lane == 63 ? T : (live ? pid : 0.0f);
   }
+  char *hl = hrow + row * (16 * ls) + (lane >> 2) * ls;
+  *reinterpret_cast<float *>(hl + (lane & 3) * 4) = val;
+  *reinterpret_cast<uint16_t *>(hl + 16 + (lane & 3) * 2) = (uint16_t)(live && lane != 63 ? id : dead);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -155,7 +179,7 @@ __device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4.
+// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4.  LS: bytes per lane of a head row (24, or 32 = aligned).
 // RACE: the exponential race of DACO_RACE_PHILOX (the reference's torch.multinomial arithmetic, tsp/aco.py:174-175, with in-kernel
 // noise) on the same head rows, with the SAME result as the dense race kernel: the winner over the head's open candidates is the
 // winner over the whole row whenever its key is below every key a tail candidate could possibly draw --
@@ -164,15 +188,32 @@ __device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, cons
 // the dense kernel (Philox block (t << 12) | (k >> 2), component k & 3): bit-identical tours, a head step generates 64 variates
 // instead of 512 (the dense race kernel is bound by VALU issue: one Philox block per four candidates and a degree-8 polynomial
 // per candidate, profiles/r04_pmc_race.txt).
-template <int CHD, bool RACE>
+//
+// The step of the scan is bound by instruction issue (profiles/r04_scan_sparse_ablation.txt: the kernel without any memory access
+// runs at 0.72 of its time, and twelve more VALU instructions per step cost 13 %), so the loop is written for few instructions:
+// one buffer address per step (the row index scales into the 384-byte row), the visited flag of slot 63 and of the empty slots
+// comes from a flag byte that is never set (no select for "not a candidate"), lane 15 forms r = u (H + T) from its own registers
+// and broadcasts the product, the chosen slot is a three-deep select on the running sums, the WINNING lane of each ant stores the
+// flag byte and the tour entry, and the row reads the tour entry back as the next row index (one LDS read instead of a
+// four-stage DPP OR network).  All of that leaves the arithmetic (summation order, thresholds, rounding cases) as the oracle has it.
+typedef uint32_t sp_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t sp_u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline float sp_at_least_denorm(float x) {     // max(x, denorm_min) for x that is not a signalling NaN
+  float y;
+  asm("v_max_f32 %0, 1, %1" : "=v"(y) : "v"(x));
+  return y;
+}
+
+template <int CHD, bool RACE, int LS>
 __global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 3)
 scan_sparse_kernel(const SampleParams p) {
   constexpr int APW = 4, APB = 16;
-  constexpr int FL = CHD * 256;                          // flag / tour / inverse-table entries per ant (>= n)
+  constexpr int FL = CHD * 256;                          // tour / inverse-table entries per ant (>= n)
+  constexpr int FLP = FL + 16;                           // flag bytes per ant: entry FL is never set (the id of slot 63 and of empty slots)
+  constexpr uint32_t ROWB = 16u * LS;                    // bytes of a head row: lane s holds {4 f32 values, 4 u16 ids} at s * LS
   // visited flags as BYTES (1 while node k is unvisited, node order): with the u16 tours 1.5 KB of LDS per ant at n <= 512, six
-  // workgroups per CU.  A step is one L2 trip, four LDS gathers and two DPP networks in a chain (2 600 cycles at the headline shape,
-  // profiles/r04_pmc_scan_sparse.txt) -- the rate is ants in flight over that, and LDS is what caps the ants.
-  __shared__ __attribute__((aligned(16))) uint8_t open_flags[APB][FL];
+  // workgroups per CU.
+  __shared__ __attribute__((aligned(16))) uint8_t open_flags[APB][FLP];
   extern __shared__ __attribute__((aligned(16))) unsigned char sparse_dyn[];  // the tours (dynamic: static + dynamic pass 64 KB at n > 512)
   uint16_t (*tour_s)[FL] = reinterpret_cast<uint16_t (*)[FL]>(sparse_dyn);    // [APB][FL]
   __shared__ uint32_t bm_s[4][32];                       // tail walk: the head of the row as a bitmap over the nodes
@@ -189,12 +230,13 @@ scan_sparse_kernel(const SampleParams p) {
   const int a = a0 + q < A ? a0 + q : A - 1;             // spare groups build ant A-1 again (not written)
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
-  const char *hvb = (const char *)(p.hval + (size_t)b * n * SP_KH);
-  const char *hib = (const char *)(p.hid + (size_t)b * n * SP_KH);
+  const char *hrb = (const char *)p.hval + (size_t)b * n * ROWB;
+  const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void *)hrb, 0, (int)((uint32_t)n * ROWB), 0x00020000);
   const uint32_t ldb = (uint32_t)ld * 4u;
+  uint32_t sls = (uint32_t)s * LS;
+  asm volatile("" : "+v"(sls));                          // (kept in a register: the loop adds it to the row offset)
   uint8_t *fl = open_flags[wave * APW + q];
   uint16_t *tour = tour_s[wave * APW + q];
-  const bool lane15 = __builtin_amdgcn_inverse_ballot_w64(0x8000800080008000ull);
   bool infeasible = false;
   unsigned long long n_dense = 0, n_tail = 0, n_rej = 0;
 
@@ -203,6 +245,7 @@ scan_sparse_kernel(const SampleParams p) {
       const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
 #pragma unroll
       for (int g = 0; g < FL / 256; ++g) *(uint4 *)(fl + g * 256 + s * 16) = ones;
+      fl[FL + s] = 0;
     }
     int prev;
     if (p.start) prev = (int)p.start[(size_t)b * A + a];
@@ -213,178 +256,193 @@ scan_sparse_kernel(const SampleParams p) {
     }
     __builtin_amdgcn_wave_barrier();
     if (s == 0) { fl[prev] = 0; tour[0] = (uint16_t)prev; }
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     u32x4 ublk = {0, 0, 0, 0};
     float ucur = 0.0f;
 
-    for (int t = 1; t < n; ++t) {
-      int choice;
-      if constexpr (RACE) {
-        // ---- the race on the head: 1 / p and node id of four slots per lane, one variate each
-        const float4 hr = *reinterpret_cast<const float4 *>(hvb + (uint32_t)prev * (SP_KH * 4u) + (uint32_t)s * 16u);
-        const uint2 hi2 = *reinterpret_cast<const uint2 *>(hib + (uint32_t)prev * (SP_KH * 2u) + (uint32_t)s * 8u);
-        const int idv[4] = {(int)(hi2.x & 0xFFFFu), (int)(hi2.x >> 16), (int)(hi2.y & 0xFFFFu), (int)(hi2.y >> 16)};
-        const float rv[4] = {hr.x, hr.y, hr.z, lane15 ? __builtin_inff() : hr.w};      // (slot 63 is the tail's bound, not a candidate)
-        const float rtail = sp_row_bcast<15>(hr.w);
-        float bk = __builtin_inff();
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int k = idv[v];
-          const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
-          const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
-          const float key = fl[k] != 0 ? Lk * rv[v] : __builtin_inff();
-          if (prefer<false>(key, k, bk, bi)) { bk = key; bi = k; }
-        }
-        arg_step<false, DPP_ROW_SHR(1), 0xF>(bk, bi);
-        arg_step<false, DPP_ROW_SHR(2), 0xF>(bk, bi);
-        arg_step<false, DPP_ROW_SHR(4), 0xF>(bk, bi);
-        arg_step<false, DPP_ROW_SHR(8), 0xF>(bk, bi);
-        const float best = sp_row_bcast<15>(bk);
-        choice = __float_as_int(sp_row_bcast<15>(__int_as_float(bi)));
-        // no tail candidate can beat `best` if best < L_min * min_tail(1/p) (half of it: margin for the polynomial's last bits)
-        const float lmin = neg_log2_1m(0x1p-24f);
-        uint64_t rare = __ballot(!(best < 0.5f * lmin * rtail)) & 0x0001000100010001ull;
-        while (rare) {                                    // the dense race for one ant, all 64 lanes
-          const int gl = __builtin_ctzll(rare);
-          rare &= rare - 1;
-          const int g = gl >> 4;
-          const int pv = readlane_i(prev, gl);
-          const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
-          const uint8_t *flg = open_flags[wave * APW + g];
-          const char *rowp = Pb + (uint32_t)pv * ldb;
-          n_dense += a0 + g < A ? 1ull : 0ull;
-          float dk = __builtin_inff();
-          int di = 0x7fffffff;
-#pragma unroll
-          for (int c = 0; c < CHD; ++c) {
-            const int k0 = (c * 64 + lane) * 4;
-            const float4 pvv = *reinterpret_cast<const float4 *>(rowp + (uint32_t)k0 * 4u);
-            const uint32_t ff = *reinterpret_cast<const uint32_t *>(flg + k0);
-            const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gidg, ((uint32_t)t << 12) | (uint32_t)(c * 64 + lane));
-            const float pp[4] = {pvv.x, pvv.y, pvv.z, pvv.w};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const float Lk = neg_log2_1m(u01(comp(r4, v)));
-              const float key = ((ff >> (8 * v)) & 0xFFu) ? Lk * (1.0f / pp[v]) : __builtin_inff();     // (padding: p = 0 -> inf)
-              if (key < dk) { dk = key; di = k0 + v; }
-            }
-          }
-          const KeyIdx rr = wave_arg<false>(dk, di);
-          int cg = rr.idx;
-          if (!(rr.key < __builtin_inff())) { infeasible = true; cg = 0; }
-          choice = q == g ? cg : choice;
-        }
-      } else {
-        // ---- the head of row `prev`: four values and four ids per lane
-        const float4 hv0 = *reinterpret_cast<const float4 *>(hvb + (uint32_t)prev * (SP_KH * 4u) + (uint32_t)s * 16u);
-        const uint2 hi2 = *reinterpret_cast<const uint2 *>(hib + (uint32_t)prev * (SP_KH * 2u) + (uint32_t)s * 8u);
+    for (int t0 = 0; t0 < n; t0 += 16) {
+      int t = t0;
+      if constexpr (!RACE) {
         // uniform of step t: component (t>>4)&3 of Philox block ((t>>6)<<4) + (t&15); lane s computes the one of step
-        // (t & ~15) + 15 - s, the row is rotated by one lane per step so that lane 15 holds the current one
-        if ((t & 15) == 0 || t == 1) {
-          if ((t & 63) == 0 || t == 1) ublk = rng_block(p.seed, iter_now, STREAM_SPARSE, gid, (uint32_t)(((t >> 6) << 4) + (15 - s)));
-          ucur = u01(comp(ublk, (t >> 4) & 3));
-          if (t == 1) ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
-        }
-        const float u = sp_row_bcast<15>(ucur);
-        ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
-        const int id0 = hi2.x & 0xFFFFu, id1 = hi2.x >> 16, id2 = hi2.y & 0xFFFFu, id3 = hi2.y >> 16;
-        // slot 63 (lane 15, v = 3) holds the tail total, not a candidate; its id field holds the live count (< 64 <= n)
-        const float T = sp_row_bcast<15>(hv0.w);
-        const float hw = lane15 ? 0.0f : hv0.w;
-        const float f0 = (float)fl[id0], f1 = (float)fl[id1], f2 = (float)fl[id2], f3 = (float)fl[id3];
-        const float run0 = __builtin_fmaf(hv0.x, f0, 0.0f);
-        const float run1 = __builtin_fmaf(hv0.y, f1, run0);
-        const float run2 = __builtin_fmaf(hv0.z, f2, run1);
-        const float run3 = __builtin_fmaf(hw, f3, run2);
-        const float part = run3;
-        const float incl = sp_row_scan(part);
-        const float H = sp_row_bcast<15>(incl);
-        float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
-        const float tot = H + T;
-        float r = u * tot;
-        r = r > 0.0f ? r : 1.401298464e-45f;
-
-        // the lane's last slot with a positive term (not "where the running sum stops growing": a term can be absorbed)
-        const int last_pos = hw * f3 > 0.0f ? 3 : (hv0.z * f2 > 0.0f ? 2 : (hv0.y * f1 > 0.0f ? 1 : 0));
-        // level 1 + 2 for a given threshold: node + 1 of the group's winner in every lane of the group, 0 if r is past the head
-        auto head_decide = [&](float rr) -> int {
-          const uint64_t m = __builtin_amdgcn_fcmpf(incl, rr, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(part, 0.0f, SP_FCMP_OGT);
-          const bool mine = __builtin_amdgcn_inverse_ballot_w64(sp_row_first(m));
-          const float thr = fmaxf(rr - excl, 1.401298464e-45f);
-          int c4 = (run0 < thr ? 1 : 0) + (run1 < thr ? 1 : 0) + (run2 < thr ? 1 : 0) + (run3 < thr ? 1 : 0);
-          if (__builtin_expect(__ballot(mine && c4 >= 4) != 0, 0)) c4 = c4 >= 4 ? last_pos : c4;    // rounding: the lane's last positive slot
-          const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
-          const int node = (int)((ids64 >> (16 * c4)) & 0xFFFFu);
-          return sp_row_or(mine ? node + 1 : 0);
-        };
-        int x = head_decide(r);
-
-        // ---- the rare ways, one ant at a time with the whole wavefront
-        const bool hpos = H > 0.0f;
-        uint64_t rare = __ballot(!hpos || x == 0) & 0x0001000100010001ull;
-        while (rare) {
-          const int gl = __builtin_ctzll(rare);             // lane 0 of the group
-          rare &= rare - 1;
-          const int g = gl >> 4;
-          const int pv = readlane_i(prev, gl);
-          const float Hg = readlane_f(H, gl), Tg = readlane_f(T, gl);
-          float ug = readlane_f(u, gl), rg = readlane_f(r, gl);
-          const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
-          const uint8_t *flg = open_flags[wave * APW + g];
-          const char *rowp = Pb + (uint32_t)pv * ldb;
-          int choice_g = -1;
-          bool bitmap_ready = false;
-          const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
-          for (int att = 0;; ++att) {
-            if (!(Hg > 0.0f) || att > 1023) {               // no live head candidate: the dense masked draw with this uniform
-              n_dense += real;
-              choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
-              if (choice_g < 0) { infeasible = true; choice_g = 0; }
-              break;
-            }
-            if (att > 0) {                                  // a new uniform: is r inside the head now?
-              const int x2 = head_decide(q == g ? rg : r);
-              const int xg = readlane_i(x2, gl);
-              if (xg) { choice_g = xg - 1; break; }
-            }
-            n_tail += real;
-            if (!bitmap_ready) {
-              const uint16_t *ids = reinterpret_cast<const uint16_t *>(hib + (uint32_t)pv * (SP_KH * 2u));
-              const int cntg = ids[63];
-              if (lane < 32) bm_s[wave][lane] = 0u;
-              __builtin_amdgcn_wave_barrier();
-              if (lane < cntg) { const int idl = ids[lane]; atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31)); }
-              __builtin_amdgcn_wave_barrier();
-              bitmap_ready = true;
-            }
-            float rp = rg - Hg;
-            rp = rp > 0.0f ? rp : 1.401298464e-45f;
-            int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
-            if (j < 0) {                                    // a tail without mass: the head's last live candidate
-              const bool live_lane = q == g && part > 0.0f;
-              const uint64_t ml = __ballot(live_lane);
-              if (ml == 0) { infeasible = true; choice_g = 0; break; }
-              const int Ll = 63 - __builtin_clzll(ml);
-              const uint64_t ids64 = ((uint64_t)hi2.y << 32) | hi2.x;
-              choice_g = readlane_i((int)((ids64 >> (16 * last_pos)) & 0xFFFFu), Ll);
-              break;
-            }
-            if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
-            n_rej += real;                                  // visited: draw again
-            const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
-            ug = u01(comp(rb, att & 3));
-            rg = ug * (Hg + Tg);
-            rg = rg > 0.0f ? rg : 1.401298464e-45f;
-          }
-          x = q == g ? choice_g + 1 : x;
-        }
-        choice = x - 1;
+        // t0 + 15 - s, the row is rotated by one lane per step so that lane 15 holds the current one
+        if ((t0 & 63) == 0) ublk = rng_block(p.seed, iter_now, STREAM_SPARSE, gid, (uint32_t)(((t0 >> 6) << 4) + (15 - s)));
+        ucur = u01(comp(ublk, (t0 >> 4) & 3));
+        if (t0 == 0) ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));      // (there is no step 0)
       }
-      if (s == 0) { fl[choice] = 0; tour[t] = (uint16_t)choice; }
-      asm volatile("" ::: "memory");                      // the next step's flag reads follow these stores
-      __builtin_amdgcn_wave_barrier();
-      prev = choice;
+      if (t0 == 0) t = 1;
+      const int te = t0 + 16 < n ? t0 + 16 : n;
+#pragma unroll 1
+      for (; t < te; ++t) {
+        // ---- the head of row `prev`: four values and four ids per lane
+        const uint32_t off = __umul24((uint32_t)prev, ROWB) + sls;
+        const sp_u32x4 hvr = __builtin_amdgcn_raw_buffer_load_b128(hres, off, 0, 0);
+        const sp_u32x2 hi2 = __builtin_amdgcn_raw_buffer_load_b64(hres, off + 16u, 0, 0);
+        const float h0 = __uint_as_float(hvr.x), h1 = __uint_as_float(hvr.y), h2 = __uint_as_float(hvr.z), h3 = __uint_as_float(hvr.w);
+        const int id0 = hi2.x & 0xFFFFu, id1 = hi2.x >> 16, id2 = hi2.y & 0xFFFFu, id3 = hi2.y >> 16;
+        if constexpr (RACE) {
+          // ---- the race on the head: 1 / p and node id of four slots per lane, one variate each (slot 63 and the empty slots:
+          // a flag that is never set -> +inf)
+          const int idv[4] = {id0, id1, id2, id3};
+          const float rv[4] = {h0, h1, h2, h3};
+          const float rtail = sp_row_bcast<15>(h3);       // slot 63: the tail's bound
+          float bk = __builtin_inff();
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int k = idv[v];
+            const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
+            const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
+            const float key = fl[k] != 0 ? Lk * rv[v] : __builtin_inff();
+            if (prefer<false>(key, k, bk, bi)) { bk = key; bi = k; }
+          }
+          arg_step<false, DPP_ROW_SHR(1), 0xF>(bk, bi);
+          arg_step<false, DPP_ROW_SHR(2), 0xF>(bk, bi);
+          arg_step<false, DPP_ROW_SHR(4), 0xF>(bk, bi);
+          arg_step<false, DPP_ROW_SHR(8), 0xF>(bk, bi);
+          const float best = sp_row_bcast<15>(bk);
+          int choice = __float_as_int(sp_row_bcast<15>(__int_as_float(bi)));
+          // no tail candidate can beat `best` if best < L_min * min_tail(1/p) (half of it: margin for the polynomial's last bits)
+          const float lmin = neg_log2_1m(0x1p-24f);
+          uint64_t rare = __ballot(!(best < 0.5f * lmin * rtail)) & 0x0001000100010001ull;
+          while (rare) {                                    // the dense race for one ant, all 64 lanes
+            const int gl = __builtin_ctzll(rare);
+            rare &= rare - 1;
+            const int g = gl >> 4;
+            const int pv = readlane_i(prev, gl);
+            const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
+            const uint8_t *flg = open_flags[wave * APW + g];
+            const char *rowp = Pb + (uint32_t)pv * ldb;
+            n_dense += a0 + g < A ? 1ull : 0ull;
+            float dk = __builtin_inff();
+            int di = 0x7fffffff;
+#pragma unroll
+            for (int c = 0; c < CHD; ++c) {
+              const int k0 = (c * 64 + lane) * 4;
+              const float4 pvv = *reinterpret_cast<const float4 *>(rowp + (uint32_t)k0 * 4u);
+              const uint32_t ff = *reinterpret_cast<const uint32_t *>(flg + k0);
+              const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gidg, ((uint32_t)t << 12) | (uint32_t)(c * 64 + lane));
+              const float pp[4] = {pvv.x, pvv.y, pvv.z, pvv.w};
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const float Lk = neg_log2_1m(u01(comp(r4, v)));
+                const float key = ((ff >> (8 * v)) & 0xFFu) ? Lk * (1.0f / pp[v]) : __builtin_inff();     // (padding: p = 0 -> inf)
+                if (key < dk) { dk = key; di = k0 + v; }
+              }
+            }
+            const KeyIdx rr = wave_arg<false>(dk, di);
+            int cg = rr.idx;
+            if (!(rr.key < __builtin_inff())) { infeasible = true; cg = 0; }
+            choice = q == g ? cg : choice;
+          }
+          if (s == 0) { fl[choice] = 0; tour[t] = (uint16_t)choice; }
+          asm volatile("" ::: "memory");                    // the next step's flag reads follow these stores
+          __builtin_amdgcn_wave_barrier();
+          prev = choice;
+        } else {
+          const float f0 = (float)fl[id0], f1 = (float)fl[id1], f2 = (float)fl[id2], f3 = (float)fl[id3];
+          const float run0 = __builtin_fmaf(h0, f0, 0.0f);
+          const float run1 = __builtin_fmaf(h1, f1, run0);
+          const float run2 = __builtin_fmaf(h2, f2, run1);
+          const float run3 = __builtin_fmaf(h3, f3, run2);  // (lane 15: h3 = the tail total T, its flag is never set)
+          const float incl = sp_row_scan(run3);
+          const float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
+          // r = u (H + T), kept > 0: lane 15 has all three
+          const float r = sp_row_bcast<15>(sp_at_least_denorm(ucur * (incl + h3)));
+          ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
+
+          // the node of the lane's last slot with a positive term (not "where the running sum stops growing": a term can be absorbed)
+          auto last_positive = [&]() -> int {
+            const int lp = h3 * f3 > 0.0f ? 3 : (h2 * f2 > 0.0f ? 2 : (h1 * f1 > 0.0f ? 1 : 0));
+            return (int)(((((uint64_t)hi2.y << 32) | hi2.x) >> (16 * lp)) & 0xFFFFu);
+          };
+          // level 1 + 2 for a given threshold: the lanes in `first` (one per ant, none if rr is past the head) hold the winner in sel
+          int sel;
+          auto head_decide = [&](float rr) -> uint64_t {
+            const uint64_t m = __builtin_amdgcn_fcmpf(incl, rr, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(run3, 0.0f, SP_FCMP_OGT);
+            const uint64_t first = sp_row_first(m);
+            const float thr = sp_at_least_denorm(rr - excl);
+            sel = run2 < thr ? id3 : id2;
+            sel = run1 < thr ? sel : id1;
+            sel = run0 < thr ? sel : id0;
+            const uint64_t bad = first & __builtin_amdgcn_fcmpf(run3, thr, SP_FCMP_OLT);
+            if (__builtin_expect(bad != 0, 0)) {            // rounding: no running sum reached thr -> the lane's last positive slot
+              sel = run3 < thr ? last_positive() : sel;
+            }
+            return first;
+          };
+          const uint64_t first = head_decide(r);
+
+          // ---- the rare ways (an ant without a winner), one ant at a time with the whole wavefront
+          if (__builtin_expect(__builtin_popcountll(first) != APW, 0)) {
+            uint64_t any = first | (first >> 8);
+            any |= any >> 4; any |= any >> 2; any |= any >> 1;
+            uint64_t rare = ~any & 0x0001000100010001ull;
+            while (rare) {
+              const int gl = __builtin_ctzll(rare);           // lane 0 of the group
+              rare &= rare - 1;
+              const int g = gl >> 4;
+              const int pv = readlane_i(prev, gl);
+              const float Hg = readlane_f(incl, gl + 15), Tg = readlane_f(h3, gl + 15);
+              float ug = readlane_f(ucur, gl), rg = readlane_f(r, gl);     // (ucur: already rotated, lane 0 holds this step's)
+              const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
+              const uint8_t *flg = open_flags[wave * APW + g];
+              const char *rowp = Pb + (uint32_t)pv * ldb;
+              int choice_g = -1;
+              bool bitmap_ready = false;
+              const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
+              for (int att = 0;; ++att) {
+                if (!(Hg > 0.0f) || att > 1023) {               // no live head candidate: the dense masked draw with this uniform
+                  n_dense += real;
+                  choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
+                  if (choice_g < 0) { infeasible = true; choice_g = 0; }
+                  break;
+                }
+                if (att > 0) {                                  // a new uniform: is r inside the head now?
+                  const int keep = sel;
+                  const uint64_t f2m = head_decide(q == g ? rg : r);
+                  const int sel2 = sel;
+                  sel = keep;
+                  const uint32_t fg = (uint32_t)(f2m >> gl) & 0xFFFFu;
+                  if (fg) { choice_g = readlane_i(sel2, gl + __builtin_ctz(fg)); break; }
+                }
+                n_tail += real;
+                if (!bitmap_ready) {                            // the head's nodes (an empty slot holds an id >= n)
+                  const int idl = *reinterpret_cast<const uint16_t *>(hrb + (uint32_t)pv * ROWB + (uint32_t)(lane >> 2) * LS + 16u + (uint32_t)(lane & 3) * 2u);
+                  if (lane < 32) bm_s[wave][lane] = 0u;
+                  __builtin_amdgcn_wave_barrier();
+                  if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
+                  __builtin_amdgcn_wave_barrier();
+                  bitmap_ready = true;
+                }
+                float rp = rg - Hg;
+                rp = rp > 0.0f ? rp : 1.401298464e-45f;
+                int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
+                if (j < 0) {                                    // a tail without mass: the head's last live candidate
+                  const bool live_lane = q == g && run3 > 0.0f;
+                  const uint64_t ml = __ballot(live_lane);
+                  if (ml == 0) { infeasible = true; choice_g = 0; break; }
+                  const int Ll = 63 - __builtin_clzll(ml);
+                  choice_g = readlane_i(last_positive(), Ll);
+                  break;
+                }
+                if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
+                n_rej += real;                                  // visited: draw again
+                const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
+                ug = u01(comp(rb, att & 3));
+                rg = ug * (Hg + Tg);
+                rg = rg > 0.0f ? rg : 1.401298464e-45f;
+              }
+              if (lane == gl) { fl[choice_g] = 0; tour[t] = (uint16_t)choice_g; }
+            }
+          }
+          // the winning lane of every ant marks the node and appends it; the ant's lanes read it back as the next row
+          if (__builtin_amdgcn_inverse_ballot_w64(first)) { fl[sel] = 0; tour[t] = (uint16_t)sel; }
+          asm volatile("" ::: "memory");                    // (same wavefront: the LDS executes these in program order)
+          prev = tour[t];
+          asm volatile("" ::: "memory");
+        }
+      }
     }
   }
   if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
@@ -464,10 +522,12 @@ scan_sparse_kernel(const SampleParams p) {
 
 using namespace daco;
 
+constexpr int SP_LS = 24;                               // bytes per lane of a head row
+
 extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n) {
   if (B <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
-  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * SP_KH * sizeof(float));
+  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * 16 * 32);
 }
 
 static int sample_sparse_impl(bool race, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
@@ -489,28 +549,38 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   hipStream_t s = (hipStream_t)stream;
   const int ld = n <= 512 ? 512 : 1024;
   float *P = (float *)workspace;
-  float *hval = (float *)((char *)workspace + align256((size_t)B * n * ld * sizeof(float)));
-  launch_prob_matrix(B, n, ld, tau, tau_bstride, eta, eta_bstride, alpha, beta, P, nullptr, s);
-  if (race) hipLaunchKernelGGL(sparse_head_kernel<true>, dim3((unsigned)(((long)B * n + 3) / 4)), dim3(256), 0, s, B, n, ld, P, head_id, hval);
-  else hipLaunchKernelGGL(sparse_head_kernel<false>, dim3((unsigned)(((long)B * n + 3) / 4)), dim3(256), 0, s, B, n, ld, P, head_id, hval);
+  char *hrow = (char *)workspace + align256((size_t)B * n * ld * sizeof(float));
+  const char *lsv = getenv("DACO_SPARSE_LS");
+  const int ls = lsv && atoi(lsv) == 32 ? 32 : SP_LS;
+  {
+    const bool vec4 = (n & 3) == 0 && (tau_bstride & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
+    const dim3 pg((unsigned)(((long)B * n + 3) / 4));
+#define DACO_PREPASS(R, V) hipLaunchKernelGGL((sparse_prepass_kernel<R, V>), pg, dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta, eta_bstride, \
+                                              alpha, beta, head_id, P, hrow, ls, ld)
+    if (race) { if (vec4) DACO_PREPASS(true, true); else DACO_PREPASS(true, false); }
+    else { if (vec4) DACO_PREPASS(false, true); else DACO_PREPASS(false, false); }
+#undef DACO_PREPASS
+  }
   SampleParams sp{};
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = ld / 256;
   sp.P = P; sp.start = start; sp.fixed_start = fixed_start;
   sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
-  sp.hval = hval; sp.hid = head_id; sp.stats = stats;
+  sp.hval = (const float *)hrow; sp.hid = head_id; sp.stats = stats;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("%s pre-pass: %s", what, hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   const int bpi = (A + 15) / 16;
   const dim3 grid((unsigned)(B * bpi));
+#define DACO_SPARSE_LAUNCH(C, R, L) hipLaunchKernelGGL((scan_sparse_kernel<C, R, L>), grid, dim3(256), 16 * C * 256 * 2, s, sp)
   if (ld <= 512) {
-    if (race) hipLaunchKernelGGL((scan_sparse_kernel<2, true>), grid, dim3(256), 16 * 512 * 2, s, sp);
-    else hipLaunchKernelGGL((scan_sparse_kernel<2, false>), grid, dim3(256), 16 * 512 * 2, s, sp);
+    if (race) { if (ls == 32) DACO_SPARSE_LAUNCH(2, true, 32); else DACO_SPARSE_LAUNCH(2, true, 24); }
+    else { if (ls == 32) DACO_SPARSE_LAUNCH(2, false, 32); else DACO_SPARSE_LAUNCH(2, false, 24); }
   } else {
-    if (race) hipLaunchKernelGGL((scan_sparse_kernel<4, true>), grid, dim3(256), 16 * 1024 * 2, s, sp);
-    else hipLaunchKernelGGL((scan_sparse_kernel<4, false>), grid, dim3(256), 16 * 1024 * 2, s, sp);
+    if (race) { if (ls == 32) DACO_SPARSE_LAUNCH(4, true, 32); else DACO_SPARSE_LAUNCH(4, true, 24); }
+    else { if (ls == 32) DACO_SPARSE_LAUNCH(4, false, 32); else DACO_SPARSE_LAUNCH(4, false, 24); }
   }
+#undef DACO_SPARSE_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("scan_sparse_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_end && hipEventRecord((hipEvent_t)ev_end, s) != hipSuccess) { set_error("hipEventRecord(ev_end) failed"); return DACO_E_HIP; }
