@@ -26,9 +26,9 @@ SIGNATURES = {
     "daco_tsp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _i, _vp, _i, _vp, _u64, _u64, _vp,
                              _u32, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sparse_workspace_bytes": (_sz, [_i, _i]),
-    "daco_tsp_sample_sparse": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
+    "daco_tsp_sample_sparse": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                     _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
+    "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                        _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tour_costs": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp]),
     "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -64,7 +64,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 120          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 121          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

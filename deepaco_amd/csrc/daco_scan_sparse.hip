@@ -21,7 +21,12 @@
 
 namespace daco {
 
-constexpr int SP_KH = 64;                                // head slots per row (slot 63: the tail total / the live count)
+// head slots per row: 64 or 128 (SPL = 4 or 8 per lane, 16 lanes); the last slot holds the tail total (its id field: the live
+// count in the caller's table).  Bytes per lane of a head row: SPL f32 values, SPL u16 ids -- 24 or 48.  (32-byte lanes for
+// SPL = 4 -- every 16-byte load aligned, four cache lines per row instead of three -- measured 0.61 ms against 0.58 at the
+// headline shape.)
+constexpr int SP_KH_MAX = 128;
+__host__ __device__ constexpr int sp_lane_bytes(int spl) { return spl * 6; }
 constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3, SP_FCMP_OLT = 4;
 
 enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
@@ -54,7 +59,7 @@ __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x800080
 template <bool RACE, bool VEC4>
 __global__ void __launch_bounds__(256)
 sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha, float beta,
-                      const uint16_t *hid, float *P, char *hrow, int ls, int dead) {
+                      const uint16_t *hid, float *P, char *hrow, int spl, int dead) {
   __shared__ uint32_t bm[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
@@ -62,13 +67,12 @@ sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const
   const int b = (int)(row / n), r = (int)(row - (long)b * n);
   const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
   float *pr = P + row * ld;
-  const uint16_t *ids = hid + row * SP_KH;
-  const int cnt = ids[63];
-  const int id = ids[lane];
-  const bool live = lane < cnt;
+  const int kh = 16 * spl, ls = sp_lane_bytes(spl);
+  const uint16_t *ids = hid + row * kh;
+  const int cnt = ids[kh - 1];
   if (lane < 32) bm[wave][lane] = 0u;
   __builtin_amdgcn_wave_barrier();
-  if (live) atomicOr(&bm[wave][id >> 5], 1u << (id & 31));
+  for (int m = lane; m < cnt; m += 64) { const int id = ids[m]; atomicOr(&bm[wave][id >> 5], 1u << (id & 31)); }
   __builtin_amdgcn_wave_barrier();
   float part = RACE ? __builtin_inff() : 0.0f;
   const int ch = ld >> 8;
@@ -101,19 +105,24 @@ sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const
       part = part + ((w & 8u) ? 0.0f : v.w);
     }
   }
-  const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
-  float T, val;
+  float T;
   if constexpr (RACE) {
     for (int o = 32; o >= 1; o >>= 1) part = fminf(part, __shfl_xor(part, o));
     T = part;
-    val = lane == 63 ? T : (live ? 1.0f / pid : __builtin_inff());
   } else {
     T = readlane_f(wave_scan_add(part), 63);
-    val = lane == 63 ? T : (live ? pid : 0.0f);
   }
-  char *hl = hrow + row * (16 * ls) + (lane >> 2) * ls;
-  *reinterpret_cast<float *>(hl + (lane & 3) * 4) = val;
-  *reinterpret_cast<uint16_t *>(hl + 16 + (lane & 3) * 2) = (uint16_t)(live && lane != 63 ? id : dead);
+  for (int m = lane; m < kh; m += 64) {                         // slot m: lane m / spl of the row, element m % spl
+    const bool live = m < cnt;
+    const int id = ids[m];
+    const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
+    float val;
+    if constexpr (RACE) val = m == kh - 1 ? T : (live ? 1.0f / pid : __builtin_inff());
+    else val = m == kh - 1 ? T : (live ? pid : 0.0f);
+    char *hl = hrow + row * (16 * ls) + (m / spl) * ls;
+    *reinterpret_cast<float *>(hl + (m % spl) * 4) = val;
+    *reinterpret_cast<uint16_t *>(hl + spl * 4 + (m % spl) * 2) = (uint16_t)(live && m != kh - 1 ? id : dead);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -179,7 +188,7 @@ __device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4.  LS: bytes per lane of a head row (24, or 32 = aligned).
+// CHD: 256-candidate chunks of the dense row (n <= 256 * CHD): 2 or 4.
 // RACE: the exponential race of DACO_RACE_PHILOX (the reference's torch.multinomial arithmetic, tsp/aco.py:174-175, with in-kernel
 // noise) on the same head rows, with the SAME result as the dense race kernel: the winner over the head's open candidates is the
 // winner over the whole row whenever its key is below every key a tail candidate could possibly draw --
@@ -204,13 +213,15 @@ __device__ inline float sp_at_least_denorm(float x) {     // max(x, denorm_min) 
   return y;
 }
 
-template <int CHD, bool RACE, int LS>
+template <int CHD, bool RACE, int SPL>
 __global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 3)
 scan_sparse_kernel(const SampleParams p) {
   constexpr int APW = 4, APB = 16;
+  constexpr int LS = sp_lane_bytes(SPL);                 // bytes per lane of a head row
+  constexpr int LAST = SPL - 1;                          // (lane 15: the slot of the tail total)
   constexpr int FL = CHD * 256;                          // tour / inverse-table entries per ant (>= n)
   constexpr int FLP = FL + 16;                           // flag bytes per ant: entry FL is never set (the id of slot 63 and of empty slots)
-  constexpr uint32_t ROWB = 16u * LS;                    // bytes of a head row: lane s holds {4 f32 values, 4 u16 ids} at s * LS
+  constexpr uint32_t ROWB = 16u * LS;                    // bytes of a head row: lane s holds {SPL f32 values, SPL u16 ids} at s * LS
   // visited flags as BYTES (1 while node k is unvisited, node order): with the u16 tours 1.5 KB of LDS per ant at n <= 512, six
   // workgroups per CU.
   __shared__ __attribute__((aligned(16))) uint8_t open_flags[APB][FLP];
@@ -274,26 +285,40 @@ scan_sparse_kernel(const SampleParams p) {
       const int te = t0 + 16 < n ? t0 + 16 : n;
 #pragma unroll 1
       for (; t < te; ++t) {
-        // ---- the head of row `prev`: four values and four ids per lane
+        // ---- the head of row `prev`: SPL values and SPL ids per lane
         const uint32_t off = __umul24((uint32_t)prev, ROWB) + sls;
-        const sp_u32x4 hvr = __builtin_amdgcn_raw_buffer_load_b128(hres, off, 0, 0);
-        const sp_u32x2 hi2 = __builtin_amdgcn_raw_buffer_load_b64(hres, off + 16u, 0, 0);
-        const float h0 = __uint_as_float(hvr.x), h1 = __uint_as_float(hvr.y), h2 = __uint_as_float(hvr.z), h3 = __uint_as_float(hvr.w);
-        const int id0 = hi2.x & 0xFFFFu, id1 = hi2.x >> 16, id2 = hi2.y & 0xFFFFu, id3 = hi2.y >> 16;
+        // (the id words stay named scalars, never an array: a select between array elements is turned into an indexed load
+        // and the array then lives in scratch memory)
+        float h[SPL];
+        uint32_t w0, w1, w2 = 0, w3 = 0;                    // the ids, two per word
+        if constexpr (SPL == 4) {
+          const sp_u32x4 hvr = __builtin_amdgcn_raw_buffer_load_b128(hres, off, 0, 0);
+          const sp_u32x2 hi2 = __builtin_amdgcn_raw_buffer_load_b64(hres, off + 16u, 0, 0);
+          h[0] = __uint_as_float(hvr.x); h[1] = __uint_as_float(hvr.y); h[2] = __uint_as_float(hvr.z); h[3] = __uint_as_float(hvr.w);
+          w0 = hi2.x; w1 = hi2.y;
+        } else {
+          const sp_u32x4 hva = __builtin_amdgcn_raw_buffer_load_b128(hres, off, 0, 0);
+          const sp_u32x4 hvb = __builtin_amdgcn_raw_buffer_load_b128(hres, off + 16u, 0, 0);
+          const sp_u32x4 hi4 = __builtin_amdgcn_raw_buffer_load_b128(hres, off + 32u, 0, 0);
+          h[0] = __uint_as_float(hva.x); h[1] = __uint_as_float(hva.y); h[2] = __uint_as_float(hva.z); h[3] = __uint_as_float(hva.w);
+          h[4] = __uint_as_float(hvb.x); h[5] = __uint_as_float(hvb.y); h[6] = __uint_as_float(hvb.z); h[7] = __uint_as_float(hvb.w);
+          w0 = hi4.x; w1 = hi4.y; w2 = hi4.z; w3 = hi4.w;
+        }
+        if constexpr (SPL == 8) asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));   // (no longer elements of one vector: no dynamic extract)
+#define SP_IDW(j) ((j) == 0 ? w0 : (j) == 1 ? w1 : (j) == 2 ? w2 : w3)
+#define SP_ID(v) (((v) & 1) ? (int)(SP_IDW((v) >> 1) >> 16) : (int)(SP_IDW((v) >> 1) & 0xFFFFu))
         if constexpr (RACE) {
-          // ---- the race on the head: 1 / p and node id of four slots per lane, one variate each (slot 63 and the empty slots:
-          // a flag that is never set -> +inf)
-          const int idv[4] = {id0, id1, id2, id3};
-          const float rv[4] = {h0, h1, h2, h3};
-          const float rtail = sp_row_bcast<15>(h3);       // slot 63: the tail's bound
+          // ---- the race on the head: 1 / p and node id of SPL slots per lane, one variate each (the last slot and the empty
+          // slots: a flag that is never set -> +inf)
+          const float rtail = sp_row_bcast<15>(h[LAST]);   // the last slot: the tail's bound
           float bk = __builtin_inff();
           int bi = 0x7fffffff;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int k = idv[v];
+          for (int v = 0; v < SPL; ++v) {
+            const int k = SP_ID(v);
             const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gid, ((uint32_t)t << 12) | (uint32_t)(k >> 2));
             const float Lk = neg_log2_1m(u01(comp(r4, k & 3)));
-            const float key = fl[k] != 0 ? Lk * rv[v] : __builtin_inff();
+            const float key = fl[k] != 0 ? Lk * h[v] : __builtin_inff();
             if (prefer<false>(key, k, bk, bi)) { bk = key; bi = k; }
           }
           arg_step<false, DPP_ROW_SHR(1), 0xF>(bk, bi);
@@ -340,38 +365,56 @@ scan_sparse_kernel(const SampleParams p) {
           __builtin_amdgcn_wave_barrier();
           prev = choice;
         } else {
-          const float f0 = (float)fl[id0], f1 = (float)fl[id1], f2 = (float)fl[id2], f3 = (float)fl[id3];
-          const float run0 = __builtin_fmaf(h0, f0, 0.0f);
-          const float run1 = __builtin_fmaf(h1, f1, run0);
-          const float run2 = __builtin_fmaf(h2, f2, run1);
-          const float run3 = __builtin_fmaf(h3, f3, run2);  // (lane 15: h3 = the tail total T, its flag is never set)
-          const float incl = sp_row_scan(run3);
+          float f[SPL], run[SPL];
+#pragma unroll
+          for (int v = 0; v < SPL; ++v) f[v] = (float)fl[SP_ID(v)];
+          run[0] = __builtin_fmaf(h[0], f[0], 0.0f);
+#pragma unroll
+          for (int v = 1; v < SPL; ++v) run[v] = __builtin_fmaf(h[v], f[v], run[v - 1]);      // (lane 15, last slot: the tail total T, its flag is never set)
+          const float incl = sp_row_scan(run[LAST]);
           const float excl = dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, incl);
           // r = u (H + T), kept > 0: lane 15 has all three
-          const float r = sp_row_bcast<15>(sp_at_least_denorm(ucur * (incl + h3)));
+          const float r = sp_row_bcast<15>(sp_at_least_denorm(ucur * (incl + h[LAST])));
           ucur = __int_as_float(sp_row_ror<1>(__float_as_int(ucur)));
 
+          // (macros, not lambdas: with eight slots per lane the closure of a lambda called from two places was built in scratch memory)
           // the node of the lane's last slot with a positive term (not "where the running sum stops growing": a term can be absorbed)
-          auto last_positive = [&]() -> int {
-            const int lp = h3 * f3 > 0.0f ? 3 : (h2 * f2 > 0.0f ? 2 : (h1 * f1 > 0.0f ? 1 : 0));
-            return (int)(((((uint64_t)hi2.y << 32) | hi2.x) >> (16 * lp)) & 0xFFFFu);
-          };
-          // level 1 + 2 for a given threshold: the lanes in `first` (one per ant, none if rr is past the head) hold the winner in sel
+#define SP_LAST_POSITIVE(out)                                                                                     \
+          do {                                                                                                    \
+            int lp_ = 0;                                                                                          \
+            _Pragma("unroll") for (int v = 1; v < SPL; ++v) lp_ = h[v] * f[v] > 0.0f ? v : lp_;                   \
+            const uint64_t lo_ = ((uint64_t)w1 << 32) | w0, hi_ = ((uint64_t)w3 << 32) | w2;                      \
+            out = (int)(((lp_ >= 4 ? hi_ : lo_) >> (16 * (lp_ & 3))) & 0xFFFFu);                                  \
+          } while (0)
+          // level 1 + 2 for a given threshold: the lanes in `first_out` (one per ant, none if rr is past the head) hold the winner
+          // in sel_out.  The first slot whose running sum reaches thr (the sums do not decrease, so "sums below thr" is a prefix):
+          // the id pair by the odd-numbered sums below, the half of the pair by the parity of the count; rounding (no running sum
+          // reached thr): the lane's last positive slot
+#define SP_HEAD_DECIDE(rr, first_out, sel_out)                                                                    \
+          do {                                                                                                    \
+            const float rr_ = (rr);                                                                               \
+            const uint64_t m_ = __builtin_amdgcn_fcmpf(incl, rr_, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(run[LAST], 0.0f, SP_FCMP_OGT); \
+            first_out = sp_row_first(m_);                                                                         \
+            const float thr_ = sp_at_least_denorm(rr_ - excl);                                                    \
+            bool below_[SPL];                                                                                     \
+            _Pragma("unroll") for (int v = 0; v < SPL - 1; ++v) below_[v] = run[v] < thr_;                        \
+            uint32_t pair_;                                                                                       \
+            if constexpr (SPL == 4) pair_ = below_[1] ? w1 : w0;                                                  \
+            else pair_ = below_[3] ? (below_[5] ? w3 : w2) : (below_[1] ? w1 : w0);                               \
+            bool odd_ = below_[0];                                                                                \
+            _Pragma("unroll") for (int v = 1; v < SPL - 1; ++v) odd_ = odd_ != below_[v];                         \
+            sel_out = odd_ ? (int)(pair_ >> 16) : (int)(pair_ & 0xFFFFu);                                         \
+            const uint64_t bad_ = first_out & __builtin_amdgcn_fcmpf(run[LAST], thr_, SP_FCMP_OLT);               \
+            if (__builtin_expect(bad_ != 0, 0)) {                                                                 \
+              int lastp_;                                                                                         \
+              SP_LAST_POSITIVE(lastp_);                                                                           \
+              sel_out = run[LAST] < thr_ ? lastp_ : sel_out;                                                      \
+            }                                                                                                     \
+          } while (0)
           int sel;
-          auto head_decide = [&](float rr) -> uint64_t {
-            const uint64_t m = __builtin_amdgcn_fcmpf(incl, rr, SP_FCMP_OGE) & __builtin_amdgcn_fcmpf(run3, 0.0f, SP_FCMP_OGT);
-            const uint64_t first = sp_row_first(m);
-            const float thr = sp_at_least_denorm(rr - excl);
-            sel = run2 < thr ? id3 : id2;
-            sel = run1 < thr ? sel : id1;
-            sel = run0 < thr ? sel : id0;
-            const uint64_t bad = first & __builtin_amdgcn_fcmpf(run3, thr, SP_FCMP_OLT);
-            if (__builtin_expect(bad != 0, 0)) {            // rounding: no running sum reached thr -> the lane's last positive slot
-              sel = run3 < thr ? last_positive() : sel;
-            }
-            return first;
-          };
-          const uint64_t first = head_decide(r);
+          uint64_t first;
+          SP_HEAD_DECIDE(r, first, sel);
+
 
           // ---- the rare ways (an ant without a winner), one ant at a time with the whole wavefront
           if (__builtin_expect(__builtin_popcountll(first) != APW, 0)) {
@@ -383,7 +426,7 @@ scan_sparse_kernel(const SampleParams p) {
               rare &= rare - 1;
               const int g = gl >> 4;
               const int pv = readlane_i(prev, gl);
-              const float Hg = readlane_f(incl, gl + 15), Tg = readlane_f(h3, gl + 15);
+              const float Hg = readlane_f(incl, gl + 15), Tg = readlane_f(h[LAST], gl + 15);
               float ug = readlane_f(ucur, gl), rg = readlane_f(r, gl);     // (ucur: already rotated, lane 0 holds this step's)
               const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
               const uint8_t *flg = open_flags[wave * APW + g];
@@ -399,19 +442,21 @@ scan_sparse_kernel(const SampleParams p) {
                   break;
                 }
                 if (att > 0) {                                  // a new uniform: is r inside the head now?
-                  const int keep = sel;
-                  const uint64_t f2m = head_decide(q == g ? rg : r);
-                  const int sel2 = sel;
-                  sel = keep;
+                  uint64_t f2m;
+                  int sel2;
+                  SP_HEAD_DECIDE(q == g ? rg : r, f2m, sel2);
                   const uint32_t fg = (uint32_t)(f2m >> gl) & 0xFFFFu;
                   if (fg) { choice_g = readlane_i(sel2, gl + __builtin_ctz(fg)); break; }
                 }
                 n_tail += real;
                 if (!bitmap_ready) {                            // the head's nodes (an empty slot holds an id >= n)
-                  const int idl = *reinterpret_cast<const uint16_t *>(hrb + (uint32_t)pv * ROWB + (uint32_t)(lane >> 2) * LS + 16u + (uint32_t)(lane & 3) * 2u);
                   if (lane < 32) bm_s[wave][lane] = 0u;
                   __builtin_amdgcn_wave_barrier();
-                  if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
+#pragma unroll
+                  for (int m = lane; m < 16 * SPL; m += 64) {
+                    const int idl = *reinterpret_cast<const uint16_t *>(hrb + (uint32_t)pv * ROWB + (uint32_t)(m / SPL) * LS + SPL * 4u + (uint32_t)(m % SPL) * 2u);
+                    if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
+                  }
                   __builtin_amdgcn_wave_barrier();
                   bitmap_ready = true;
                 }
@@ -419,11 +464,13 @@ scan_sparse_kernel(const SampleParams p) {
                 rp = rp > 0.0f ? rp : 1.401298464e-45f;
                 int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
                 if (j < 0) {                                    // a tail without mass: the head's last live candidate
-                  const bool live_lane = q == g && run3 > 0.0f;
+                  const bool live_lane = q == g && run[LAST] > 0.0f;
                   const uint64_t ml = __ballot(live_lane);
                   if (ml == 0) { infeasible = true; choice_g = 0; break; }
                   const int Ll = 63 - __builtin_clzll(ml);
-                  choice_g = readlane_i(last_positive(), Ll);
+                  int lastp;
+                  SP_LAST_POSITIVE(lastp);
+                  choice_g = readlane_i(lastp, Ll);
                   break;
                 }
                 if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
@@ -445,6 +492,10 @@ scan_sparse_kernel(const SampleParams p) {
       }
     }
   }
+#undef SP_HEAD_DECIDE
+#undef SP_LAST_POSITIVE
+#undef SP_ID
+#undef SP_IDW
   if (infeasible && p.flags && lane == 0) atomicOr(p.flags + b, 1);
   if (p.stats && lane == 0 && (n_dense | n_tail | n_rej)) {
     atomicAdd(p.stats + 0, n_dense); atomicAdd(p.stats + 1, n_tail); atomicAdd(p.stats + 2, n_rej);
@@ -522,16 +573,14 @@ scan_sparse_kernel(const SampleParams p) {
 
 using namespace daco;
 
-constexpr int SP_LS = 24;                               // bytes per lane of a head row
-
 extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n) {
   if (B <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
-  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * 16 * 32);
+  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * 16 * sp_lane_bytes(SP_KH_MAX / 16));
 }
 
 static int sample_sparse_impl(bool race, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
-                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
+                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                       int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                       long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
@@ -540,6 +589,7 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
     set_error("%s: bad argument (B=%d n=%d A=%d)", what, B, n, A);
     return DACO_E_BADARG;
   }
+  if (head_slots != 64 && head_slots != 128) { set_error("%s: head_slots = %d (64 or 128)", what, head_slots); return DACO_E_BADARG; }
   if (n <= 128 || n > 1024) { set_error("%s: n=%d outside 129..1024 (the dense samplers serve the other sizes)", what, n); return DACO_E_TOOLARGE; }
   if ((size_t)n * A * 8 >= ((size_t)1 << 32)) { set_error("%s: n * A too large for 32-bit offsets", what); return DACO_E_TOOLARGE; }
   if (fixed_start >= n) { set_error("%s: fixed_start %d >= n %d", what, fixed_start, n); return DACO_E_BADARG; }
@@ -550,13 +600,12 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   const int ld = n <= 512 ? 512 : 1024;
   float *P = (float *)workspace;
   char *hrow = (char *)workspace + align256((size_t)B * n * ld * sizeof(float));
-  const char *lsv = getenv("DACO_SPARSE_LS");
-  const int ls = lsv && atoi(lsv) == 32 ? 32 : SP_LS;
+  const int spl = head_slots / 16;
   {
     const bool vec4 = (n & 3) == 0 && (tau_bstride & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
     const dim3 pg((unsigned)(((long)B * n + 3) / 4));
 #define DACO_PREPASS(R, V) hipLaunchKernelGGL((sparse_prepass_kernel<R, V>), pg, dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta, eta_bstride, \
-                                              alpha, beta, head_id, P, hrow, ls, ld)
+                                              alpha, beta, head_id, P, hrow, spl, ld)
     if (race) { if (vec4) DACO_PREPASS(true, true); else DACO_PREPASS(true, false); }
     else { if (vec4) DACO_PREPASS(false, true); else DACO_PREPASS(false, false); }
 #undef DACO_PREPASS
@@ -572,14 +621,11 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   const int bpi = (A + 15) / 16;
   const dim3 grid((unsigned)(B * bpi));
-#define DACO_SPARSE_LAUNCH(C, R, L) hipLaunchKernelGGL((scan_sparse_kernel<C, R, L>), grid, dim3(256), 16 * C * 256 * 2, s, sp)
-  if (ld <= 512) {
-    if (race) { if (ls == 32) DACO_SPARSE_LAUNCH(2, true, 32); else DACO_SPARSE_LAUNCH(2, true, 24); }
-    else { if (ls == 32) DACO_SPARSE_LAUNCH(2, false, 32); else DACO_SPARSE_LAUNCH(2, false, 24); }
-  } else {
-    if (race) { if (ls == 32) DACO_SPARSE_LAUNCH(4, true, 32); else DACO_SPARSE_LAUNCH(4, true, 24); }
-    else { if (ls == 32) DACO_SPARSE_LAUNCH(4, false, 32); else DACO_SPARSE_LAUNCH(4, false, 24); }
-  }
+#define DACO_SPARSE_LAUNCH(C, R, S) hipLaunchKernelGGL((scan_sparse_kernel<C, R, S>), grid, dim3(256), 16 * C * 256 * 2, s, sp)
+#define DACO_SPARSE_PICK(C, R) do { if (spl == 4) DACO_SPARSE_LAUNCH(C, R, 4); else DACO_SPARSE_LAUNCH(C, R, 8); } while (0)
+  if (ld <= 512) { if (race) DACO_SPARSE_PICK(2, true); else DACO_SPARSE_PICK(2, false); }
+  else { if (race) DACO_SPARSE_PICK(4, true); else DACO_SPARSE_PICK(4, false); }
+#undef DACO_SPARSE_PICK
 #undef DACO_SPARSE_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("scan_sparse_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
@@ -587,11 +633,11 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   return DACO_OK;
 }
 
-#define DACO_SPARSE_ARGS stream, B, n, A, tau, tau_bstride, eta, eta_bstride, alpha, beta, head_id, start, fixed_start, seed, iter, \
+#define DACO_SPARSE_ARGS stream, B, n, A, tau, tau_bstride, eta, eta_bstride, alpha, beta, head_id, head_slots, start, fixed_start, seed, iter, \
                          iter_offset, ant_gid0, ant_gid_bstride, paths, flags, dist, dist_bstride, costs, nbr, stats, workspace, \
                          workspace_bytes, ev_begin, ev_end
 extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
-                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
+                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                       int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                       long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
@@ -599,7 +645,7 @@ extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const f
   return sample_sparse_impl(false, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
 }
 extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
-                                         long eta_bstride, float alpha, float beta, const uint16_t *head_id, const int64_t *start,
+                                         long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                          int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                          uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                          long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,

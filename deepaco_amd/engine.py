@@ -123,18 +123,20 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
 
 
 def sparse_head(weights, k):
-    """Head table of scan_sparse for `weights` [B,n,n] or [n,n] (the colony passes its heuristic): per row the k (<= 63)
-    largest entries, ids ascending (ties at the k-th value: the smaller id) -- [B,n,64] int16 holding uint16 ids, the
-    unused slots 0, slot 63 = k (include/deepaco_hip.h daco_tsp_sample_sparse; oracle.sparse_head_ids is the same rule)."""
+    """Head table of scan_sparse for `weights` [B,n,n] or [n,n] (the colony passes its heuristic): per row the k (<= 127)
+    largest entries, ids ascending (ties at the k-th value: the smaller id) -- [B,n,S] int16 holding uint16 ids with S = 64
+    slots for k <= 63, else 128; the unused slots 0, the last slot = k (include/deepaco_hip.h daco_tsp_sample_sparse;
+    oracle.sparse_head_ids is the same rule)."""
     _require_gpu(weights)
     w = weights if weights.dim() == 3 else weights.unsqueeze(0)
     B, n, _ = w.shape
-    assert 1 <= k <= 63 and k <= n
+    assert 1 <= k <= 127 and k <= n
+    slots = 64 if k <= 63 else 128
     # by value descending, then id ascending: a stable sort of the ids by descending value
     order = torch.sort(w.to(torch.float64), dim=2, descending=True, stable=True).indices[:, :, :k]
-    ids = torch.zeros((B, n, 64), dtype=torch.int64, device=w.device)
+    ids = torch.zeros((B, n, slots), dtype=torch.int64, device=w.device)
     ids[:, :, :k] = torch.sort(order, dim=2).values
-    ids[:, :, 63] = k
+    ids[:, :, slots - 1] = k
     return ids.to(torch.int16).contiguous()          # (bit pattern of uint16: ids < 32768 here, n <= 1024)
 
 
@@ -142,17 +144,17 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
                       want_paths=True, race=False):
     """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
-    distribution of tsp_sample(mode="scan"), 384 bytes per step instead of a row while the head has a live candidate.
+    distribution of tsp_sample(mode="scan"), 384 / 768 bytes per step instead of a row while the head has a live candidate.
     head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats]).
     race=True: daco_tsp_sample_race_head -- the exponential race of mode="race" on the head rows, with the tours of the dense
-    race kernel (same seed), 64 variates per step instead of n."""
+    race kernel (same seed), one variate per head slot and step instead of n."""
     _require_gpu(tau, eta, start, head)
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
     dev = tau.device
     tau, tbs = _bstride(tau, n)
     eta, ebs = _bstride(eta, n)
-    assert head.dtype == torch.int16 and head.is_contiguous() and tuple(head.shape) == (B, n, 64)
+    assert head.dtype == torch.int16 and head.is_contiguous() and tuple(head.shape) in ((B, n, 64), (B, n, 128))
     L = _lib.lib()
     with torch.cuda.device(dev):
         paths = torch.empty((B, n, n_ants), dtype=torch.int64, device=dev) if want_paths else None
@@ -174,7 +176,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
         ws = _workspace(dev, nbytes, "sample_sparse")
         fn = L.daco_tsp_sample_race_head if race else L.daco_tsp_sample_sparse
         rc = fn(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
-                                      float(beta), head.data_ptr(), start.data_ptr() if start is not None else None,
+                                      float(beta), head.data_ptr(), int(head.shape[2]), start.data_ptr() if start is not None else None,
                                       int(fixed_start), int(seed) & (2 ** 64 - 1), int(it),
                                       iter_dev.data_ptr() if iter_dev is not None else None, int(ant_gid0) & 0xFFFFFFFF,
                                       int(ant_gid_bstride), paths.data_ptr() if paths is not None else None, flags.data_ptr(),
@@ -765,7 +767,7 @@ class BatchedTSP:
         self._cmin = None
         self.nls_counters = None                  # optional int64[2] on the device: sweeps, list entries walked (bench)
         # sampler="scan_sparse": head / tail rows (tsp_sample_sparse).  The head of a row = the k largest heuristic entries:
-        # k from sparsify(k), else `head_k` (default n // 10, at most 63); rebuilt when the heuristic object changes.
+        # k from sparsify(k), else `head_k` (default n // 10, at most 127); rebuilt when the heuristic object changes.
         self.head_k = None
         self._head = None
 
@@ -782,13 +784,13 @@ class BatchedTSP:
         sparse = torch.full_like(self.distances, 1e10)
         sparse.scatter_(2, idx, torch.gather(self.distances, 2, idx))
         self.heuristic = 1 / sparse
-        self.head_k = min(int(k_sparse), 63)
+        self.head_k = min(int(k_sparse), 127)
         self._head = None
 
     def _head_table(self):
         """(heuristic object it was built from, [B,n,64] head ids) for sampler='scan_sparse'."""
         if self._head is None or self._head[0] is not self.heuristic:
-            k = self.head_k if self.head_k is not None else max(1, min(63, self.n // 10))
+            k = self.head_k if self.head_k is not None else max(1, min(127, self.n // 10))
             h = self.heuristic.detach()
             h = h if h.dim() == 3 else h.unsqueeze(0).expand(self.B, self.n, self.n)
             self._head = (self.heuristic, sparse_head(_f32c(h), k))

@@ -96,13 +96,13 @@ class ACO():
         sparse_distances = torch.full_like(self.distances, 1e10)
         sparse_distances.scatter_(1, topk_indices, torch.gather(self.distances, 1, topk_indices))
         self.heuristic = 1 / sparse_distances
-        self._head_k = min(int(k_sparse), 63)              # sampler='scan_sparse': the head of a row = these k entries
+        self._head_k = min(int(k_sparse), 127)              # sampler='scan_sparse': the head of a row = these k entries
 
     def _head_table(self):
         """[1, n, 64] head ids for sampler='scan_sparse' (engine.sparse_head), once per heuristic object."""
         hit = self.__dict__.get("_head")
         if hit is None or hit[0] is not self.heuristic:
-            k = self.__dict__.get("_head_k") or max(1, min(63, self.problem_size // 10))
+            k = self.__dict__.get("_head_k") or max(1, min(127, self.problem_size // 10))
             hit = (self.heuristic, engine.sparse_head(self.heuristic.detach().float().contiguous(), k))
             self._head = hit
         return hit[1]

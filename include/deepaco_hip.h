@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 120 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse) */
+#define DACO_VERSION 121 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots) */
 
 /* error codes */
 #define DACO_OK 0
@@ -120,15 +120,16 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *   tsp/aco.py:52-67 (sparsify: k live entries per row, 1e-10 elsewhere) -- the reference's inference setting.
  *
  * Same distribution as daco_tsp_sample(DACO_SCAN): p_k = tau^alpha * eta^beta * [k unvisited].  A row is split into a
- * head (up to 63 candidates, head_id) and the tail (the rest).  A step draws r = u * (H + T) with H the head's live
- * mass and T the tail's static mass: inside the head -> inverse CDF over 64 slots (384 bytes instead of a row of
- * 4n); past the head -> inverse CDF over all tail entries, a visited one is rejected and the step draws again
+ * head (up to 63 or 127 candidates, head_id) and the tail (the rest).  A step draws r = u * (H + T) with H the head's
+ * live mass and T the tail's static mass: inside the head -> inverse CDF over 64 / 128 slots (384 / 768 bytes instead of a
+ * row of 4n); past the head -> inverse CDF over all tail entries, a visited one is rejected and the step draws again
  * (rejection over a superset: the accepted outcome is the categorical above); no live head candidate -> the dense
  * masked draw of the 64-lane scan specification.  Its own uniform stream (one per attempt): tours differ from
  * DACO_SCAN's under the same seed, the distribution does not.  Specification: oracle/daco_oracle.c draw_scan_sparse.
  *   129 <= n <= 1024.
- *   head_id  [B][n][64] uint16: slots 0..cnt-1 the head's node ids (any subset of the row; the colony passes the k
- *            largest heuristic entries, ids ascending), the other slots 0, slot 63 = cnt (<= 63)
+ *   head_slots  64 or 128: slots per row of head_id (four / eight per lane of the 16-lane row)
+ *   head_id  [B][n][head_slots] uint16: slots 0..cnt-1 the head's node ids (any subset of the row; the colony passes the
+ *            k largest heuristic entries, ids ascending), the other slots 0, the last slot = cnt (<= head_slots - 1)
  *   paths, flags, dist / costs, nbr, start / fixed_start, seed / iter / iter_offset / ant_gid0 / ant_gid_bstride,
  *   ev_begin / ev_end: as daco_tsp_sample (log-probabilities are not produced: an inference sampler)
  *   stats    optional out [3] uint64 (caller zeroes): steps that took the dense draw, tail walks, rejections
@@ -137,7 +138,7 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
 size_t daco_tsp_sparse_workspace_bytes(int B, int n);
 int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
                            const float *tau, long tau_bstride, const float *eta, long eta_bstride,
-                           float alpha, float beta, const uint16_t *head_id,
+                           float alpha, float beta, const uint16_t *head_id, int head_slots,
                            const int64_t *start, int fixed_start,
                            uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
                            int ant_gid_bstride,
@@ -149,11 +150,11 @@ int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
 /* daco_tsp_sample_race_head -- daco_tsp_sample(DACO_RACE_PHILOX) on the same head rows, with the SAME tours (same seed,
  * same noise indexing by node id): the exponential race of torch.multinomial's one-sample path (tsp/aco.py:174-175) is won
  * by a head candidate whenever its key L/p is below what any tail candidate could draw, L_min / max_tail(p); that is checked
- * every step and the dense race runs for the ant otherwise.  64 variates per step instead of n.  Arguments as
+ * every step and the dense race runs for the ant otherwise.  head_slots variates per step instead of n.  Arguments as
  * daco_tsp_sample_sparse (stats[0] = steps that took the dense race). */
 int daco_tsp_sample_race_head(void *stream, int B, int n, int A,
                               const float *tau, long tau_bstride, const float *eta, long eta_bstride,
-                              float alpha, float beta, const uint16_t *head_id,
+                              float alpha, float beta, const uint16_t *head_id, int head_slots,
                               const int64_t *start, int fixed_start,
                               uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
                               int ant_gid_bstride,

@@ -113,25 +113,28 @@ def tsp_sample_scan(P, A, seed, it=0, ant_gid0=0, fixed_start=-1, require_prob=F
 
 
 def sparse_head_ids(weights, k):
-    """Head of every row for scan_sparse: the k (<= 63) largest entries of `weights` [n][n] (the colony passes its heuristic),
-    ids ascending; returns (head_id [n][64] uint16, head_cnt [n] uint8).  Ties at the k-th value: the smaller id."""
+    """Head of every row for scan_sparse: the k (<= 127) largest entries of `weights` [n][n] (the colony passes its heuristic),
+    ids ascending; returns (head_id [n][kh] uint16, head_cnt [n] uint8) with kh = 64 slots for k <= 63, else 128.  Ties at the
+    k-th value: the smaller id."""
     w = np.asarray(weights, dtype=np.float64)
     n = w.shape[0]
-    assert 1 <= k <= 63 and k <= n
+    assert 1 <= k <= 127 and k <= n
+    kh = 64 if k <= 63 else 128
     order = np.lexsort((np.arange(n)[None, :].repeat(n, 0), -w), axis=1)[:, :k]          # by value descending, then id
-    ids = np.zeros((n, 64), dtype=np.uint16)
+    ids = np.zeros((n, kh), dtype=np.uint16)
     ids[:, :k] = np.sort(order, axis=1)
     return ids, np.full(n, k, dtype=np.uint8)
 
 
 def sparse_head_values(P, head_id, head_cnt):
-    """head_val [n][64] f32: P at the head ids, +0 in the empty slots, the tail total T_i in slot 63."""
+    """head_val [n][kh] f32: P at the head ids, +0 in the empty slots, the tail total T_i in slot kh - 1."""
     P = _f32(P)
     n = P.shape[0]
     hid, cnt = np.ascontiguousarray(head_id, dtype=np.uint16), np.ascontiguousarray(head_cnt, dtype=np.uint8)
-    assert hid.shape == (n, 64) and cnt.shape == (n,) and int(cnt.max()) <= 63
-    out = np.zeros((n, 64), dtype=np.float32)
-    lib().orc_sparse_head_values(n, _p(P), _p(hid), _p(cnt), _p(out))
+    kh = hid.shape[1]
+    assert kh in (64, 128) and hid.shape == (n, kh) and cnt.shape == (n,) and int(cnt.max()) <= kh - 1
+    out = np.zeros((n, kh), dtype=np.float32)
+    lib().orc_sparse_head_values(n, _p(P), _p(hid), _p(cnt), _p(out), kh)
     return out
 
 
@@ -144,8 +147,8 @@ def tsp_sample_scan_sparse(P, head_id, head_cnt, A, seed, it=0, ant_gid0=0, fixe
     hval = sparse_head_values(P, hid, cnt)
     paths = np.zeros((n, A), dtype=np.int64)
     stats = np.zeros(3, dtype=np.int64)
-    rc = lib().orc_tsp_sample_scan_sparse(n, A, _p(P), _p(hid), _p(cnt), _p(hval), C.c_uint64(seed), C.c_uint64(it),
-                                          C.c_uint32(ant_gid0), int(fixed_start), _p(paths), _p(stats))
+    rc = lib().orc_tsp_sample_scan_sparse(n, A, _p(P), _p(hid), _p(cnt), _p(hval), int(hid.shape[1]), C.c_uint64(seed),
+                                          C.c_uint64(it), C.c_uint32(ant_gid0), int(fixed_start), _p(paths), _p(stats))
     return paths, rc, stats
 
 

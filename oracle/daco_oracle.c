@@ -345,7 +345,9 @@ int orc_tsp_sample_scan_wave(int n, int A, const float *P, uint64_t seed, uint64
  *   in-lane picks as in draw_scan (first running sum >= thr over the positive terms, else the last positive one).
  * stats: [0] dense steps (H = 0), [1] tail walks, [2] rejections. */
 enum { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
-#define SPARSE_KH 64
+/* kh = head slots per row, 64 or 128 (4 or 8 per lane, 16 lanes): slot m = (kh / 16) * lane + v, cnt <= kh - 1 live slots,
+ * slot kh - 1 = the tail total.  Everything above holds with "four" read as kh / 16 and "63" as kh - 1. */
+#define SPARSE_KH_MAX 128
 
 static void sparse_tail_scan(int n, const float *row, const unsigned char *is_head, float part[64], float incl[64]) {
   int ch = (n + 255) / 256;
@@ -361,41 +363,42 @@ static void sparse_tail_scan(int n, const float *row, const unsigned char *is_he
   lane_scan(incl);
 }
 
-/* head_val [n][64] from the dense matrix P [n][n], the head ids [n][64] (uint16) and counts [n] (<= 63): slot m < cnt holds
- * P[i][id_m], the other slots +0, slot 63 the tail total T_i */
-void orc_sparse_head_values(int n, const float *P, const uint16_t *head_id, const uint8_t *head_cnt, float *head_val) {
+/* head_val [n][kh] from the dense matrix P [n][n], the head ids [n][kh] (uint16) and counts [n] (<= kh - 1): slot m < cnt holds
+ * P[i][id_m], the other slots +0, slot kh - 1 the tail total T_i */
+void orc_sparse_head_values(int n, const float *P, const uint16_t *head_id, const uint8_t *head_cnt, float *head_val, int kh) {
   unsigned char *is_head = (unsigned char *)malloc(n);
   float part[64], incl[64];
   for (int i = 0; i < n; ++i) {
     memset(is_head, 0, n);
-    for (int m = 0; m < SPARSE_KH; ++m) {
+    for (int m = 0; m < kh; ++m) {
       int live = m < head_cnt[i];
-      head_val[(long)i * SPARSE_KH + m] = live ? P[(long)i * n + head_id[(long)i * SPARSE_KH + m]] : 0.0f;
-      if (live) is_head[head_id[(long)i * SPARSE_KH + m]] = 1;
+      head_val[(long)i * kh + m] = live ? P[(long)i * n + head_id[(long)i * kh + m]] : 0.0f;
+      if (live) is_head[head_id[(long)i * kh + m]] = 1;
     }
     sparse_tail_scan(n, P + (long)i * n, is_head, part, incl);
-    head_val[(long)i * SPARSE_KH + 63] = incl[63];
+    head_val[(long)i * kh + kh - 1] = incl[63];
   }
   free(is_head);
 }
 
-static int draw_scan_sparse(int n, const float *row, const float *hval, const uint16_t *hid, int cnt,
+static int draw_scan_sparse(int n, const float *row, const float *hval, const uint16_t *hid, int cnt, int kh,
                             const unsigned char *blocked, unsigned char *is_head, uint64_t seed, uint64_t iter,
                             uint32_t gid, int t, long stats[3]) {
-  float part[64], incl[64], w[SPARSE_KH];
+  float part[64], incl[64], w[SPARSE_KH_MAX];
   uint32_t r4[4];
+  const int spl = kh / 16;
   for (int l = 0; l < 64; ++l) part[l] = incl[l] = 0.0f;
   for (int l = 0; l < 16; ++l) {
     float s = 0.0f;
-    for (int v = 0; v < 4; ++v) {
-      int m = 4 * l + v;
+    for (int v = 0; v < spl; ++v) {
+      int m = spl * l + v;
       w[m] = (m < cnt && !blocked[hid[m]]) ? hval[m] : 0.0f;
       s = s + w[m];
     }
     part[l] = s; incl[l] = s;
   }
   lane_scan(incl);                                       /* lanes 0..15 of the 64-lane scan = the 16-lane row scan */
-  const float H = incl[15], T = hval[63];
+  const float H = incl[15], T = hval[kh - 1];
   const uint32_t ut = (uint32_t)t;
   for (int a = 0;; ++a) {
     float u;
@@ -412,8 +415,8 @@ static int draw_scan_sparse(int n, const float *row, const float *hval, const ui
     if (L >= 0) {
       float thr = r - (L ? incl[L - 1] : 0.0f), run = 0.0f;
       int best = -1, last = -1;
-      for (int v = 0; v < 4; ++v) {
-        int m = 4 * L + v;
+      for (int v = 0; v < spl; ++v) {
+        int m = spl * L + v;
         if (!(w[m] > 0.0f)) continue;
         run = run + w[m];
         last = m;
@@ -456,11 +459,12 @@ static int draw_scan_sparse(int n, const float *row, const float *hval, const ui
   }
 }
 
-/* P [n][n] dense, head_id [n][64] uint16, head_cnt [n] uint8 (<= 63), head_val [n][64] from orc_sparse_head_values */
+/* P [n][n] dense, head_id [n][kh] uint16, head_cnt [n] uint8 (<= kh - 1), head_val [n][kh] from orc_sparse_head_values */
 int orc_tsp_sample_scan_sparse(int n, int A, const float *P, const uint16_t *head_id, const uint8_t *head_cnt,
-                               const float *head_val, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int fixed_start,
+                               const float *head_val, int kh, uint64_t seed, uint64_t iter, uint32_t ant_gid0, int fixed_start,
                                int64_t *paths, long *stats) {
   int rc = ORC_OK;
+  if (kh != 64 && kh != 128) return ORC_INFEASIBLE;
   unsigned char *vis = (unsigned char *)malloc(n), *is_head = (unsigned char *)malloc(n);
   for (int a = 0; a < A; ++a) {
     uint32_t gid = ant_gid0 + (uint32_t)a, r4[4];
@@ -471,8 +475,8 @@ int orc_tsp_sample_scan_sparse(int n, int A, const float *P, const uint16_t *hea
     vis[prev] = 1;
     paths[a] = prev;
     for (int t = 1; t < n; ++t) {
-      int best = draw_scan_sparse(n, P + (long)prev * n, head_val + (long)prev * SPARSE_KH, head_id + (long)prev * SPARSE_KH,
-                                  head_cnt[prev], vis, is_head, seed, iter, gid, t, stats);
+      int best = draw_scan_sparse(n, P + (long)prev * n, head_val + (long)prev * kh, head_id + (long)prev * kh,
+                                  head_cnt[prev], kh, vis, is_head, seed, iter, gid, t, stats);
       if (best < 0) { rc = ORC_INFEASIBLE; best = 0; }
       vis[best] = 1;
       paths[(long)t * A + a] = best;

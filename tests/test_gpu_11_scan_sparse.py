@@ -26,7 +26,7 @@ def instance(n, seed, kind, B=1):
         k = max(5, n // 10)
         _, idx = torch.topk(d, k=k, dim=2, largest=False)
         eta = 1 / torch.full_like(d, 1e10).scatter_(2, idx, torch.gather(d, 2, idx))
-        heads = [oracle.sparse_head_ids(eta[b].numpy(), min(k, 63)) for b in range(B)]
+        heads = [oracle.sparse_head_ids(eta[b].numpy(), min(k, 127)) for b in range(B)]      # (k >= 64: the 128-slot head)
     elif kind == "random_head":                            # every entry matters, the head an arbitrary subset: tail walks, rejections
         eta = 1 / d
         heads = []
@@ -34,6 +34,16 @@ def instance(n, seed, kind, B=1):
         for b in range(B):
             ids = np.zeros((n, 64), dtype=np.uint16)
             cnt = rng.integers(1, 40, n).astype(np.uint8)
+            for r in range(n):
+                ids[r, :cnt[r]] = np.sort(rng.choice(n, int(cnt[r]), replace=False))
+            heads.append((ids, cnt))
+    elif kind == "wide_random_head":                       # the same with 128 slots (eight per lane), 50 .. 126 of them live
+        eta = 1 / d
+        heads = []
+        rng = np.random.default_rng(seed)
+        for b in range(B):
+            ids = np.zeros((n, 128), dtype=np.uint16)
+            cnt = rng.integers(50, 127, n).astype(np.uint8)
             for r in range(n):
                 ids[r, :cnt[r]] = np.sort(rng.choice(n, int(cnt[r]), replace=False))
             heads.append((ids, cnt))
@@ -47,14 +57,16 @@ def pack(heads):
     out = []
     for ids, cnt in heads:
         h = ids.astype(np.int64).copy()
-        h[:, 63] = cnt
+        h[:, h.shape[1] - 1] = cnt
         out.append(h)
     return torch.from_numpy(np.stack(out)).to(torch.int16).contiguous().to(dev())
 
 
 @pytest.mark.parametrize("n,A,B,kind,fixed", [(160, 40, 1, "random_head", 0), (200, 64, 2, "ksparse", -1), (300, 21, 1, "tiny_head", 3),
                                             (500, 32, 2, "ksparse", -1), (512, 16, 1, "random_head", -1), (513, 19, 1, "ksparse", 0),
-                                            (1000, 12, 1, "ksparse", -1), (777, 9, 2, "random_head", 5), (129, 33, 1, "tiny_head", -1)])
+                                            (1000, 12, 1, "ksparse", -1), (777, 9, 2, "random_head", 5), (129, 33, 1, "tiny_head", -1),
+                                            (300, 20, 1, "wide_random_head", 0), (700, 16, 2, "ksparse", -1), (640, 9, 2, "wide_random_head", -1),
+                                            (1024, 8, 1, "wide_random_head", 7)])
 def test_scan_sparse_bit_exact_vs_oracle(n, A, B, kind, fixed):
     from deepaco_amd import engine
     d, tau, eta, heads = instance(n, 100 + n, kind, B)
@@ -77,7 +89,7 @@ def test_scan_sparse_bit_exact_vs_oracle(n, A, B, kind, fixed):
             t = ref[:, a]
             assert np.array_equal(nb[t, a] & 0xFFFF, np.roll(t, 1)) and np.array_equal(nb[t, a] >> 16, np.roll(t, -1))
     assert np.array_equal(stats.cpu().numpy(), ref_stats), (stats.cpu().numpy(), ref_stats)
-    if kind == "random_head":
+    if kind in ("random_head", "wide_random_head"):
         assert ref_stats[1] > 0 and ref_stats[2] > 0
     if kind == "tiny_head":
         assert ref_stats[0] > 0
@@ -127,10 +139,11 @@ def test_scan_sparse_colony_surface():
 
 
 @pytest.mark.parametrize("n,A,B,kind,fixed", [(200, 40, 2, "ksparse", -1), (160, 24, 1, "random_head", 0), (300, 21, 1, "tiny_head", 3),
-                                            (500, 32, 2, "ksparse", -1), (1000, 10, 1, "ksparse", -1), (640, 9, 1, "random_head", 2)])
+                                            (500, 32, 2, "ksparse", -1), (1000, 10, 1, "ksparse", -1), (640, 9, 1, "random_head", 2),
+                                            (400, 12, 1, "wide_random_head", -1)])
 def test_race_on_head_rows_equals_the_dense_race(n, A, B, kind, fixed):
     """daco_tsp_sample_race_head: the exponential race of DACO_RACE_PHILOX (torch.multinomial's arithmetic, tsp/aco.py:174-175)
-    generated for the 64 head slots only, the dense race for an ant whenever a tail candidate could still win.  Same noise
+    generated for the 64 / 128 head slots only, the dense race for an ant whenever a tail candidate could still win.  Same noise
     indexing by node id: the tours must be the dense race's bit for bit -- against the oracle's race and against the dense
     kernel -- whatever the head is (k-sparse: a few dense steps late in the tours; an arbitrary subset of a dense heuristic:
     the bound fails at almost every step)."""
@@ -147,10 +160,32 @@ def test_race_on_head_rows_equals_the_dense_race(n, A, B, kind, fixed):
         ref, _, rc = oracle.tsp_sample_race(P, A, seed=13, it=2, ant_gid0=b * A, fixed_start=fixed)
         assert rc == 0 and np.array_equal(paths[b].cpu().numpy(), ref), (n, kind, b)
     st = int(stats[0])
-    if kind == "ksparse" and n // 10 <= 63:             # (n = 1000: 100 live entries per row, 63 in the head -- the bound never holds)
+    if kind == "ksparse":                               # (n = 1000: 100 live entries per row, the 128-slot head)
         assert 0 < st < 0.1 * B * A * n
-    if kind == "random_head":
+    if kind in ("random_head", "wide_random_head"):
         assert st > 0.5 * B * A * n
+
+
+def test_scan_sparse_config5_shape_with_the_wide_head():
+    """TSP-1000, k = 100 (BASELINE config 5's heuristic) on the 128-slot head: the tail is never walked, dense steps are rare, the
+    tours are permutations with the right lengths and as good as the dense sampler's."""
+    from deepaco_amd import engine
+    B, n, A = 2, 1000, 256
+    d, _, eta, heads = instance(n, 21, "ksparse", B)
+    dd, ee = d.to(dev()), eta.to(dev())
+    tau = torch.ones_like(dd)
+    head = engine.sparse_head(ee, 100)
+    assert head.shape == (B, n, 128) and torch.equal(head.cpu(), pack(heads).cpu())
+    paths, flags, costs, nbr, stats = engine.tsp_sample_sparse(tau, ee, A, head, seed=5, dist=dd, want_nbr=True, want_stats=True)
+    assert int(flags.sum()) == 0
+    assert bool((paths.sort(dim=1).values == torch.arange(n, device=dev()).view(1, n, 1)).all())
+    u = paths.transpose(1, 2)
+    ref = torch.stack([dd[b][u[b], torch.roll(u[b], 1, dims=1)].double().sum(1) for b in range(B)])
+    torch.testing.assert_close(costs.double(), ref, rtol=1e-5, atol=0)
+    st = stats.cpu().numpy()
+    assert st[1] == 0 and st[2] == 0 and 0 <= st[0] < 0.05 * B * A * n, st
+    _, _, _, _, dense_costs, _ = engine.tsp_sample(tau, ee, A, mode="scan", seed=5, dist=dd, want_nbr=True)
+    assert abs(float(costs.mean()) / float(dense_costs.mean()) - 1) < 0.01
 
 
 def test_race_colony_takes_the_head_rows_after_sparsify():

@@ -28,6 +28,18 @@ def _instance(n, seed, kind):
         for i in range(n):
             ids[i, :20] = np.sort(rng.choice(n, 20, replace=False))
         head = (ids, np.full(n, 20, dtype=np.uint8))
+    elif kind == "dense_wide_head":                        # 128 slots (eight per lane): an arbitrary subset of 90
+        eta = (1 / d).astype(np.float32)
+        ids = np.zeros((n, 128), dtype=np.uint16)
+        for i in range(n):
+            ids[i, :90] = np.sort(rng.choice(n, 90, replace=False))
+        head = (ids, np.full(n, 90, dtype=np.uint8))
+    elif kind == "ksparse_wide":                           # k = 100 of 160: the 128-slot head holds every live entry
+        idx = np.argsort(d, axis=1)[:, :100]
+        eta = np.full((n, n), 1e-10, dtype=np.float32)
+        np.put_along_axis(eta, idx, 1 / np.take_along_axis(d, idx, axis=1), axis=1)
+        head = oracle.sparse_head_ids(eta, 100)
+        assert head[0].shape == (n, 128)
     else:                                                  # a head of 3: exhausted after a few steps (dense steps)
         eta = (1 / d).astype(np.float32)
         head = oracle.sparse_head_ids(eta, 3)
@@ -41,7 +53,7 @@ def _chi2(counts, probs):
     return float(((counts[keep] - exp) ** 2 / exp).sum()), int(keep.sum()) - 1, int(counts[~keep].sum())
 
 
-@pytest.mark.parametrize("kind", ["dense_random_head", "ksparse", "tiny_head"])
+@pytest.mark.parametrize("kind", ["dense_random_head", "ksparse", "tiny_head", "dense_wide_head", "ksparse_wide"])
 def test_scan_sparse_draws_the_categorical(kind):
     n, A = 160, 30000
     P, (hid, cnt) = _instance(n, 5, kind)
@@ -61,10 +73,10 @@ def test_scan_sparse_draws_the_categorical(kind):
     c2 = np.bincount(paths[2][sel], minlength=n).astype(np.float64)
     x2, dof, _ = _chi2(c2, p2)
     assert x2 < dof + 5 * np.sqrt(2 * dof) + 10, (kind, "step 2", x2, dof)
-    if kind == "dense_random_head":
+    if kind in ("dense_random_head", "dense_wide_head"):
         assert stats[1] > 0 and stats[2] > 0                                          # tail walks and rejections happened
-    if kind == "ksparse":
-        assert stats[1] == 0 and stats[2] == 0 and 0 < stats[0] < 0.1 * A * n         # never past the head; a few dense steps late in the tours
+    if kind in ("ksparse", "ksparse_wide"):
+        assert stats[1] == 0 and stats[2] == 0 and 0 <= stats[0] < 0.1 * A * n         # never past the head; a few dense steps late in the tours
     if kind == "tiny_head":
         assert stats[0] > 0.1 * A * n                                                  # many dense steps (a quarter, measured)
 

@@ -32,7 +32,7 @@ ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 for a, b in ev:
     a.record(); b.record()
 torch.cuda.synchronize()
-head = engine.sparse_head(eta, min(63, max(5, n // 10))) if mode in ("scan_sparse", "race_head") else None
+head = engine.sparse_head(eta, min(127, max(5, n // 10))) if mode in ("scan_sparse", "race_head") else None
 stats = None
 for r in range(reps):
     if mode in ("scan_sparse", "race_head"):
