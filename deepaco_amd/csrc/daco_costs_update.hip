@@ -160,6 +160,9 @@ track_best_kernel(int len, int A, const float *costs, const int64_t *paths, floa
 // a column within one ant) walk the ants in lock step.  The chain is LDS-latency bound, so the
 // rest is kept off it: the [node][ant] table arrives in coalesced chunks of DEP_CHUNK ants,
 // double-buffered in LDS by all four waves, and the chain reads it four ants at a time.
+// (Measured, round 4: the adds as LDS atomics -- ds_add_f32 without return, a lane's adds still execute in the order it issues
+// them, results bit-identical -- make the launch 2.5 x slower, 205 us against 82 at the headline shape: the LDS atomic unit
+// serialises what the read / add / write chains of 2 x R lanes overlap.)
 constexpr int DEP_CHUNK = 64;
 
 // SYM: symmetric deposit, two lanes per row (prev / next side).  !SYM: directed deposit, one lane
