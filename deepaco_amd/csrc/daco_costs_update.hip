@@ -162,7 +162,9 @@ track_best_kernel(int len, int A, const float *costs, const int64_t *paths, floa
 // double-buffered in LDS by all four waves, and the chain reads it four ants at a time.
 // (Measured, round 4: the adds as LDS atomics -- ds_add_f32 without return, a lane's adds still execute in the order it issues
 // them, results bit-identical -- make the launch 2.5 x slower, 205 us against 82 at the headline shape: the LDS atomic unit
-// serialises what the read / add / write chains of 2 x R lanes overlap.)
+// serialises what the read / add / write chains of 2 x R lanes overlap.  Four ants per LDS round trip -- the four elements
+// read together, sums forwarded inside the group -- would also need the PARTNER lane's columns (the prev side of ant a + 1 can
+// meet the next side of ant a) and bought 82 -> 74 us without them: the chain is not what the launch waits for.)
 constexpr int DEP_CHUNK = 64;
 
 // SYM: symmetric deposit, two lanes per row (prev / next side).  !SYM: directed deposit, one lane
