@@ -355,6 +355,7 @@ def extra_configs(dev, headline_colony, cpu=True):
                 sdt, skms, sbest = colony("scan_sparse")
                 sparse = {"value": B * A / sdt, "unit": "ant-tours/s", "ms_per_step": sdt * 1e3, "kernel_ms": skms,
                           "kernel": "scan_sparse_kernel<4, false, 8> (HIP events around the launch)",
+                          "pipes": counters.get(f"tsp{n}_a{A}_b{B}_scan_sparse"),
                           "mean_best_cost_after_10_iterations": sbest, "dense_mean_best_cost_after_10_iterations": best,
                           "speedup_whole_iteration": dt / sdt}
             except Exception as e:
@@ -534,12 +535,12 @@ def extra_configs(dev, headline_colony, cpu=True):
                 res[tag]["roofline"] = {
                     "bound": "l2", "achieved": B * A * (n - 1) * 384.0 / (kms * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
                     "frac": B * A * (n - 1) * 384.0 / (kms * 1e-3) / 1e9 / PEAK_L2_GBS, "traffic": None,
-                    "kernel": "scan_sparse_kernel<2> (HIP events around the launch)", "kernel_ms": kms, "pipes": pc,
+                    "kernel": "scan_sparse_kernel<2, false, 4> (HIP events around the launch)", "kernel_ms": kms, "pipes": pc,
                     "valu_busy": (pc or {}).get("valu_busy"),
                     "note": "384 B per head step (64 values + 64 ids) over the kernel time against the L2 rate: the kernel is not "
-                            "bound by it -- a step is a chain of one L2 round trip, four LDS gathers and two DPP networks "
-                            "(2 600 cycles at this shape) and the rate is ants in flight (96 per CU: 1.5 KB of LDS each) over "
-                            "that chain; profiles/r04_pmc_scan_sparse.txt"}
+                            "bound by it but by instruction issue (profiles/r04_scan_sparse_ablation.txt: without any memory "
+                            "access the first version still took 0.72 of its time; 93 -> 35 VALU per wave-step bought 0.77 -> "
+                            "0.58 ms); profiles/r04_pmc_scan_sparse.txt"}
             del col
         res["speedup_whole_iteration"] = res["scan_sparse"]["value"] / res["scan"]["value"]
         out["headline_scan_sparse"] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, 1/d sparsified k={k}: sampler "
@@ -660,8 +661,11 @@ def extra_configs(dev, headline_colony, cpu=True):
         with torch.no_grad():
             heu = lnet.reshape_batch(n, ei, lnet.forward_batch(x, ei, ea, k_sparse=k)) + 1e-10
         res = {}
-        for tag, kw in (("learned", dict(heuristic=heu)), ("vanilla_1_over_d_sparsified", {})):
+        # (learned_on_head_rows: the same heuristic through sampler "scan_sparse" -- the k live entries of a row are its head)
+        for tag, kw in (("learned", dict(heuristic=heu)), ("learned_on_head_rows", dict(heuristic=heu, sampler="scan_sparse")),
+                        ("vanilla_1_over_d_sparsified", {})):
             col = engine.BatchedTSP(dist, n_ants=A, seed=7, fixed_start=0, **kw)
+            col.head_k = k
             if not kw:
                 col.sparsify(k)
             col.heuristic = col.heuristic.contiguous()

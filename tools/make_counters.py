@@ -24,9 +24,10 @@ sys.path.insert(0, ROOT)
 # workload directory -> (kernel substring, key in counters.json / hbm_traffic.json)
 WORKLOADS = {
     "headline": ("tsp_scan32_kernel", "tsp500_a512_b64_scan"),
-    "scan_sparse": ("scan_sparse_kernel<2, false>", "tsp500_a512_b64_scan_sparse"),
+    "scan_sparse": ("scan_sparse_kernel<2, false, 4>", "tsp500_a512_b64_scan_sparse"),
+    "c5_sparse": ("scan_sparse_kernel<4, false, 8>", "tsp1000_a2048_b64_scan_sparse"),
     "race": ("tsp_sample_kernel", "tsp500_a512_b64_race"),
-    "race_head": ("scan_sparse_kernel<2, true>", "tsp500_a512_b64_race_head"),
+    "race_head": ("scan_sparse_kernel<2, true, 4>", "tsp500_a512_b64_race_head"),
     "c2": ("scan16_kernel", "tsp100_a512_b256_scan"),
     "c4": ("scan16_kernel", "cvrp100_a512_b256_scan"),
     "c5": ("tsp_scan32_kernel", "tsp1000_a2048_b64_scan"),
@@ -51,7 +52,8 @@ def main():
     version = _lib.ABI_VERSION
     counters = {"daco_version": version,
                 "source": "profiles/r04_pmc_*.txt (tools/profile_r4.sh + tools/make_counters.py: rocprofv3 --pmc, one pass per counter "
-                          "group, mean per launch of the workload's dominant kernel)"}
+                          "group, mean per launch of the workload's dominant kernel; the head / tail kernels' passes are of this library "
+                          "version, the other kernels are unchanged since their passes under version 120)"}
     traffic = {"daco_version": version,
                "source": "profiles/r04_pmc_*.txt (tools/profile_r4.sh: FETCH_SIZE KiB x 1024 x 2 [gfx950 correction] + WRITE_SIZE KiB x "
                          "1024, mean per launch of the dominant kernel)"}

@@ -31,7 +31,7 @@ stats() {  # stats <tag> <command...>: rocprofv3 --kernel-trace --stats of one c
   cp $OUT/stats_$tag/p_kernel_stats.csv $OUT/kernel_stats_$tag.csv 2>/dev/null
   find $OUT/stats_$tag -name "*.db" -delete 2>/dev/null
 }
-if [ "$WHAT" != "pmc" ]; then
+if [ "$WHAT" != "pmc" ] && [ "$WHAT" != "sparse" ]; then
   # the headline launches ONLY (no extras, no learned / gap colonies in the same kernel row), then the whole default bench
   stats headline python bench.py --no-cpu --no-extras --min-seconds 0
   stats bench_default python bench.py --no-cpu --min-seconds 0
@@ -40,11 +40,19 @@ if [ "$WHAT" != "pmc" ]; then
   (cd $R && python tools/run_train_step.py > $OUT/train_step.json 2>&1)
   (cd $R && python tools/run_single_instance_nls.py > $OUT/single_instance_nls.json 2>&1)
 fi
+if [ "$WHAT" = "sparse" ]; then      # the head / tail kernels only (the other kernels' passes stay valid while their code does)
+  pmc scan_sparse python tools/run_headline_kernel.py 5 64 512 500 scan_sparse
+  pmc race_head python tools/run_headline_kernel.py 4 64 512 500 race_head
+  pmc c5_sparse python tools/run_headline_kernel.py 4 64 2048 1000 scan_sparse
+  ls $OUT
+  exit 0
+fi
 if [ "$WHAT" != "stats" ]; then
   pmc headline python tools/run_headline_kernel.py 5 64 512 500 scan
   pmc scan_sparse python tools/run_headline_kernel.py 5 64 512 500 scan_sparse
   pmc race python tools/run_headline_kernel.py 4 64 512 500 race
   pmc race_head python tools/run_headline_kernel.py 4 64 512 500 race_head
+  pmc c5_sparse python tools/run_headline_kernel.py 4 64 2048 1000 scan_sparse
   pmc c2 python tools/measure_configs.py c2
   pmc c4 python tools/measure_configs.py c4
   pmc c5 python tools/measure_configs.py c5shard
