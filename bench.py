@@ -674,6 +674,10 @@ def extra_configs(dev, headline_colony, cpu=True):
             col.run(10 - col.iteration)
             res[tag] = {"value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3,
                         "mean_best_cost_after_10_iterations": float(col.lowest_cost.mean())}
+            if kw.get("sampler") == "scan_sparse":
+                st = engine.tsp_sample_sparse(col.pheromone, col.heuristic, A, col._head_table(), seed=1, batch=B, fixed_start=0,
+                                              want_stats=True)[4].tolist()
+                res[tag]["steps_dense_tailwalk_rejected_of"] = st + [B * A * (n - 1)]
             del col
         out["c5_learned_tsp1000_a2048_b8"] = {
             "workload": f"TSP-{n}, n_ants={A}, {B} instances, start node 0, heuristic = Net(pretrained tsp_nls/tsp1000) + 1e-10 vs 1/d "

@@ -64,7 +64,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 121          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 122          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

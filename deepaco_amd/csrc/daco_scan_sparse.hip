@@ -4,19 +4,20 @@
 // reference's inference (tsp/aco.py:52-67: k live entries per row, 1e-10 elsewhere).  The dense scan kernels stream one
 // padded 2 KB row per ant-step and sit on the CU's vector-memory pipe (TA / TD 0.91-0.95 busy, profiles/r04_pmc_headline.txt);
 // nothing in the instruction stream moves that, so this sampler moves fewer bytes: a row is split into a head -- up to
-// 63 candidates chosen by the caller, the colony takes the k largest heuristic entries -- and the tail.  A step draws
-// r = u (H + T), H = the head's live mass, T = the tail's STATIC mass (visited or not): r inside the head is an inverse
-// CDF over 64 slots (384 bytes: values, ids); r past the head walks the whole tail row and, if it lands on a visited
-// node, the step draws again (rejection over a superset: the accepted outcome is the reference's categorical exactly);
-// no live head candidate -> the dense masked draw of the 64-lane scan specification with the same uniform.
-// The CPU restatement of this draw (draw_scan_sparse in the oracle) is the specification (uniform stream, slot order, summation order); the GPU
-// tests hold tours bit-exact against it, the CPU tests hold it against the categorical by chi-square.
+// 63 or 127 candidates chosen by the caller (64 / 128 slots), the colony takes the k largest heuristic entries -- and the tail.
+// A step draws r = u (H + T), H = the head's live mass, T = the tail's STATIC mass (visited or not): r inside the head is an
+// inverse CDF over the head's slots (384 / 768 bytes: values, ids); r past the head walks the whole tail row and, if it lands
+// on a visited node, the step draws ONCE more -- the dense masked draw over all open candidates with a second uniform
+// (rejection over a superset with an exact fallback: the outcome is the reference's categorical, and a step reads the row at
+// most twice); no live head candidate -> the dense masked draw of the 64-lane scan specification with the first uniform.
+// The CPU restatement of this draw (draw_scan_sparse in the oracle) is the specification (uniform stream, slot order, summation
+// order); the GPU tests hold tours bit-exact against it, the CPU tests hold it against the categorical by chi-square.
 //
-// Layout: ant = 16 lanes (one DPP row), slot m = 4 * lane + v.  Level 1 is the row scan of the 16 lane sums, level 2 a
-// four-entry count; the group's choice reaches its lanes by a rotate-OR.  The two rare ways (tail walk, dense step) are
-// wave-cooperative: the 64 lanes serve one ant at a time (candidate k = (c * 64 + lane) * 4 + v, the 64-lane scan).
-// Tours and f16 visited flags (node order) live in LDS; paths / tour lengths / the update's table leave the workgroup in
-// the epilogue of the scan16 family (16 ants = one 128-byte run per row).
+// Layout: ant = 16 lanes (one DPP row), slot m = SPL * lane + v (SPL = 4 or 8).  Level 1 is the row scan of the 16 lane sums,
+// level 2 a compare tree on the winning lane's running sums; the winning lane stores the choice and the ant's lanes read it back.
+// The rare ways (tail walk, dense draw) are wave-cooperative: the 64 lanes serve one ant at a time (candidate
+// k = (c * 64 + lane) * 4 + v, the 64-lane scan).  Tours (u16) and visited flags (bytes, node order) live in LDS; paths / tour
+// lengths / the update's table leave the workgroup in the epilogue of the scan16 family (16 ants = one 128-byte run per row).
 #include "daco_sample_kernel.h"
 
 namespace daco {
@@ -29,7 +30,7 @@ constexpr int SP_KH_MAX = 128;
 __host__ __device__ constexpr int sp_lane_bytes(int spl) { return spl * 6; }
 constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3, SP_FCMP_OLT = 4;
 
-enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
+enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };   // (retry: the second uniform of a step, block t << 8, component 0)
 
 template <int N> __device__ inline float sp_row_bcast(float x) { return dpp_f<0x150 + N, 0xF, false>(x, x); }
 template <int N> __device__ inline int sp_row_ror(int x) { return dpp_i<0x120 + N, 0xF, false>(x, x); }
@@ -426,60 +427,51 @@ scan_sparse_kernel(const SampleParams p) {
               rare &= rare - 1;
               const int g = gl >> 4;
               const int pv = readlane_i(prev, gl);
-              const float Hg = readlane_f(incl, gl + 15), Tg = readlane_f(h[LAST], gl + 15);
-              float ug = readlane_f(ucur, gl), rg = readlane_f(r, gl);     // (ucur: already rotated, lane 0 holds this step's)
+              const float Hg = readlane_f(incl, gl + 15);
+              const float ug = readlane_f(ucur, gl), rg = readlane_f(r, gl);     // (ucur: already rotated, lane 0 holds this step's)
               const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
               const uint8_t *flg = open_flags[wave * APW + g];
               const char *rowp = Pb + (uint32_t)pv * ldb;
               int choice_g = -1;
-              bool bitmap_ready = false;
               const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
-              for (int att = 0;; ++att) {
-                if (!(Hg > 0.0f) || att > 1023) {               // no live head candidate: the dense masked draw with this uniform
-                  n_dense += real;
-                  choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
-                  if (choice_g < 0) { infeasible = true; choice_g = 0; }
-                  break;
-                }
-                if (att > 0) {                                  // a new uniform: is r inside the head now?
-                  uint64_t f2m;
-                  int sel2;
-                  SP_HEAD_DECIDE(q == g ? rg : r, f2m, sel2);
-                  const uint32_t fg = (uint32_t)(f2m >> gl) & 0xFFFFu;
-                  if (fg) { choice_g = readlane_i(sel2, gl + __builtin_ctz(fg)); break; }
-                }
+              if (!(Hg > 0.0f)) {                               // no live head candidate: the dense masked draw with this uniform
+                n_dense += real;
+                choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
+              } else {
                 n_tail += real;
-                if (!bitmap_ready) {                            // the head's nodes (an empty slot holds an id >= n)
-                  if (lane < 32) bm_s[wave][lane] = 0u;
-                  __builtin_amdgcn_wave_barrier();
+                // the head's nodes as a bitmap (an empty slot holds an id >= n)
+                if (lane < 32) bm_s[wave][lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                  for (int m = lane; m < 16 * SPL; m += 64) {
-                    const int idl = *reinterpret_cast<const uint16_t *>(hrb + (uint32_t)pv * ROWB + (uint32_t)(m / SPL) * LS + SPL * 4u + (uint32_t)(m % SPL) * 2u);
-                    if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
-                  }
-                  __builtin_amdgcn_wave_barrier();
-                  bitmap_ready = true;
+                for (int m = lane; m < 16 * SPL; m += 64) {
+                  const int idl = *reinterpret_cast<const uint16_t *>(hrb + (uint32_t)pv * ROWB + (uint32_t)(m / SPL) * LS + SPL * 4u + (uint32_t)(m % SPL) * 2u);
+                  if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
                 }
+                __builtin_amdgcn_wave_barrier();
                 float rp = rg - Hg;
                 rp = rp > 0.0f ? rp : 1.401298464e-45f;
-                int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
+                const int j = sparse_row_walk<CHD, true>(rowp, flg, bm_s[wave], lane, rp);
                 if (j < 0) {                                    // a tail without mass: the head's last live candidate
                   const bool live_lane = q == g && run[LAST] > 0.0f;
                   const uint64_t ml = __ballot(live_lane);
-                  if (ml == 0) { infeasible = true; choice_g = 0; break; }
-                  const int Ll = 63 - __builtin_clzll(ml);
-                  int lastp;
-                  SP_LAST_POSITIVE(lastp);
-                  choice_g = readlane_i(lastp, Ll);
-                  break;
+                  if (ml != 0) {
+                    const int Ll = 63 - __builtin_clzll(ml);
+                    int lastp;
+                    SP_LAST_POSITIVE(lastp);
+                    choice_g = readlane_i(lastp, Ll);
+                  }
+                } else if (flg[j] != 0) {                       // open: accepted
+                  choice_g = j;
+                } else {
+                  // visited: ONE more draw, the dense masked draw over all open candidates with the step's second uniform --
+                  // x then has probability p_x / (H + T) + (T_visited / (H + T)) p_x / (H + T_open) = p_x / (H + T_open)
+                  n_rej += real;
+                  n_dense += real;
+                  const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, (uint32_t)t << 8);
+                  choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, u01(rb.x));
                 }
-                if (flg[j] != 0) { choice_g = j; break; }      // open: accepted
-                n_rej += real;                                  // visited: draw again
-                const u32x4 rb = rng_block(p.seed, iter_now, STREAM_SPARSE_RETRY, gidg, ((uint32_t)t << 8) | ((uint32_t)att >> 2));
-                ug = u01(comp(rb, att & 3));
-                rg = ug * (Hg + Tg);
-                rg = rg > 0.0f ? rg : 1.401298464e-45f;
               }
+              if (choice_g < 0) { infeasible = true; choice_g = 0; }
               if (lane == gl) { fl[choice_g] = 0; tour[t] = (uint16_t)choice_g; }
             }
           }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 121 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots) */
+#define DACO_VERSION 122 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection) */
 
 /* error codes */
 #define DACO_OK 0
@@ -122,17 +122,18 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  * Same distribution as daco_tsp_sample(DACO_SCAN): p_k = tau^alpha * eta^beta * [k unvisited].  A row is split into a
  * head (up to 63 or 127 candidates, head_id) and the tail (the rest).  A step draws r = u * (H + T) with H the head's
  * live mass and T the tail's static mass: inside the head -> inverse CDF over 64 / 128 slots (384 / 768 bytes instead of a
- * row of 4n); past the head -> inverse CDF over all tail entries, a visited one is rejected and the step draws again
- * (rejection over a superset: the accepted outcome is the categorical above); no live head candidate -> the dense
- * masked draw of the 64-lane scan specification.  Its own uniform stream (one per attempt): tours differ from
- * DACO_SCAN's under the same seed, the distribution does not.  Specification: oracle/daco_oracle.c draw_scan_sparse.
+ * row of 4n); past the head -> inverse CDF over all tail entries, and if that lands on a visited one the step draws once
+ * more, the dense masked draw over all open candidates with a second uniform (rejection over a superset with an exact
+ * fallback: the outcome is the categorical above, a step reads the row at most twice); no live head candidate -> the
+ * dense masked draw of the 64-lane scan specification.  Its own uniform stream: tours differ from DACO_SCAN's under the
+ * same seed, the distribution does not.  Specification: oracle/daco_oracle.c draw_scan_sparse.
  *   129 <= n <= 1024.
  *   head_slots  64 or 128: slots per row of head_id (four / eight per lane of the 16-lane row)
  *   head_id  [B][n][head_slots] uint16: slots 0..cnt-1 the head's node ids (any subset of the row; the colony passes the
  *            k largest heuristic entries, ids ascending), the other slots 0, the last slot = cnt (<= head_slots - 1)
  *   paths, flags, dist / costs, nbr, start / fixed_start, seed / iter / iter_offset / ant_gid0 / ant_gid_bstride,
  *   ev_begin / ev_end: as daco_tsp_sample (log-probabilities are not produced: an inference sampler)
- *   stats    optional out [3] uint64 (caller zeroes): steps that took the dense draw, tail walks, rejections
+ *   stats    optional out [3] uint64 (caller zeroes): dense masked draws (no live head candidate, or after a rejection), tail walks, rejections
  *   workspace  daco_tsp_sparse_workspace_bytes(B, n) bytes of device scratch
  */
 size_t daco_tsp_sparse_workspace_bytes(int B, int n);

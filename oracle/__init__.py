@@ -152,6 +152,13 @@ def tsp_sample_scan_sparse(P, head_id, head_cnt, A, seed, it=0, ant_gid0=0, fixe
     return paths, rc, stats
 
 
+def sparse_rounding_picks():
+    """Head draws of tsp_sample_scan_sparse so far (this process) that took the rounding branch."""
+    fn = lib().orc_sparse_rounding_picks
+    fn.restype = C.c_long
+    return int(fn())
+
+
 def tsp_sample_scan_injected(P, uniforms, fixed_start=0, wave=False, require_prob=False):
     """The scan draw with caller-supplied uniforms [n-1][A] (f32) instead of Philox."""
     P, u = _f32(P), _f32(uniforms)

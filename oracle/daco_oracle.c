@@ -333,17 +333,18 @@ int orc_tsp_sample_scan_wave(int n, int A, const float *P, uint64_t seed, uint64
  * up to 63 candidates given by the caller (ids, any subset; the colony takes the k largest heuristic entries) -- and the
  * TAIL, everything else.  A step draws r = u * (H + T): H = the head's LIVE mass (its open candidates), T = the tail's
  * STATIC mass (all tail entries, visited or not).  r inside the head -> inverse CDF over the open head candidates.  r past
- * the head -> inverse CDF over ALL tail entries, and if the one it lands on is visited the step draws again with a new
- * uniform: rejection over a superset, the accepted outcome j has probability P_ij / sum(open P) exactly as in the
- * reference's categorical (up to float rounding, like every draw here).  No live head candidate (H = 0) -> the dense
+ * the head -> inverse CDF over ALL tail entries, and if the one it lands on is visited the step draws ONCE more: the dense
+ * masked draw over all open candidates with a second uniform.  Rejection over a superset with an exact fallback: the outcome
+ * j has probability P_ij / sum(open P) exactly as in the reference's categorical (up to float rounding, like every draw
+ * here) and a step never reads the row more than twice.  No live head candidate (H = 0) -> the dense
  * masked draw of the 64-lane scan specification with the same uniform.  So most steps read 384 bytes instead of a row.
  *   head slot m = 4 * lane + v, 16 lanes; w_m = val_m if m < cnt and its node is open, else +0; lane partial = its four
  *   slots in order from +0.0f; incl = Kogge-Stone over the 16 lanes; H = incl[15]; T = head_val[63] (so cnt <= 63), made
  *   by orc_sparse_head_values as the 64-lane (vec 4) scan total of the row's non-head entries.
  *   u(t, attempt 0) = component (t>>4)&3 of Philox(ctr = ((t>>6)<<4) + (t&15), gid, iter, STREAM_SPARSE)
- *   u(t, attempt a) = component (a-1)&3 of Philox(ctr = (t<<8) | ((a-1)>>2), gid, iter, STREAM_SPARSE_RETRY), a <= 1023
+ *   u(t, second draw) = component 0 of Philox(ctr = t<<8, gid, iter, STREAM_SPARSE_RETRY)
  *   in-lane picks as in draw_scan (first running sum >= thr over the positive terms, else the last positive one).
- * stats: [0] dense steps (H = 0), [1] tail walks, [2] rejections. */
+ * stats: [0] dense masked draws (H = 0, or after a rejection), [1] tail walks, [2] rejections. */
 enum { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };
 /* kh = head slots per row, 64 or 128 (4 or 8 per lane, 16 lanes): slot m = (kh / 16) * lane + v, cnt <= kh - 1 live slots,
  * slot kh - 1 = the tail total.  Everything above holds with "four" read as kh / 16 and "63" as kh - 1. */
@@ -381,6 +382,11 @@ void orc_sparse_head_values(int n, const float *P, const uint16_t *head_id, cons
   free(is_head);
 }
 
+/* how often a head draw took the rounding branch (no running sum reached the remainder): a soak reads it to know that its
+ * inputs exercise that branch (tools/soak_scan_sparse.py) */
+static long sparse_rounding_picks = 0;
+long orc_sparse_rounding_picks(void) { return sparse_rounding_picks; }
+
 static int draw_scan_sparse(int n, const float *row, const float *hval, const uint16_t *hid, int cnt, int kh,
                             const unsigned char *blocked, unsigned char *is_head, uint64_t seed, uint64_t iter,
                             uint32_t gid, int t, long stats[3]) {
@@ -400,63 +406,66 @@ static int draw_scan_sparse(int n, const float *row, const float *hval, const ui
   lane_scan(incl);                                       /* lanes 0..15 of the 64-lane scan = the 16-lane row scan */
   const float H = incl[15], T = hval[kh - 1];
   const uint32_t ut = (uint32_t)t;
-  for (int a = 0;; ++a) {
-    float u;
-    if (a == 0) { rng_block(seed, iter, STREAM_SPARSE, gid, ((ut >> 6) << 4) + (ut & 15u), r4); u = u01(r4[(ut >> 4) & 3u]); }
-    else { rng_block(seed, iter, STREAM_SPARSE_RETRY, gid, (ut << 8) | ((uint32_t)(a - 1) >> 2), r4); u = u01(r4[(a - 1) & 3]); }
-    if (!(H > 0.0f) || a > 1023) {                       /* no live head candidate (or a thousand rejections): the dense masked draw */
-      if (stats) stats[0]++;
-      return draw_scan(n, row, blocked, 0, 0, 0, t, NULL, 64, &u);
-    }
-    float r = u * (H + T);
-    if (!(r > 0.0f)) r = 1.401298464e-45f;
-    int L = -1;
-    for (int l = 0; l < 16; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
-    if (L >= 0) {
-      float thr = r - (L ? incl[L - 1] : 0.0f), run = 0.0f;
-      int best = -1, last = -1;
-      for (int v = 0; v < spl; ++v) {
-        int m = spl * L + v;
-        if (!(w[m] > 0.0f)) continue;
-        run = run + w[m];
-        last = m;
-        if (run >= thr) { best = m; break; }
-      }
-      if (best < 0) best = last;
-      return hid[best];
-    }
-    /* past the head: walk the whole tail, visited entries included */
-    if (stats) stats[1]++;
-    float rp = r - H;
-    if (!(rp > 0.0f)) rp = 1.401298464e-45f;
-    memset(is_head, 0, n);
-    for (int m = 0; m < cnt; ++m) is_head[hid[m]] = 1;
-    float tpart[64], tincl[64];
-    sparse_tail_scan(n, row, is_head, tpart, tincl);
-    int Lt = -1;
-    for (int l = 0; l < 64; ++l) if (tincl[l] >= rp && tpart[l] > 0.0f) { Lt = l; break; }
-    if (Lt < 0) for (int l = 63; l >= 0; --l) if (tpart[l] > 0.0f) { Lt = l; break; }      /* rounding: the last lane with mass */
-    int j = -1;
-    if (Lt >= 0) {
-      float thr = rp - (Lt ? tincl[Lt - 1] : 0.0f), run = 0.0f;
-      int last = -1, ch = (n + 255) / 256;
-      for (int c = 0; c < ch && j < 0; ++c)
-        for (int v = 0; v < 4; ++v) {
-          int k = (c * 64 + Lt) * 4 + v;
-          if (k >= n || is_head[k] || !(row[k] > 0.0f)) continue;
-          run = run + row[k];
-          last = k;
-          if (run >= thr) { j = k; break; }
-        }
-      if (j < 0) j = last;
-    }
-    if (j < 0) {                                         /* a tail without mass: the head's last live candidate */
-      for (int m = cnt - 1; m >= 0; --m) if (w[m] > 0.0f) return hid[m];
-      return -1;
-    }
-    if (!blocked[j]) return j;
-    if (stats) stats[2]++;
+  float u;
+  rng_block(seed, iter, STREAM_SPARSE, gid, ((ut >> 6) << 4) + (ut & 15u), r4);
+  u = u01(r4[(ut >> 4) & 3u]);
+  if (!(H > 0.0f)) {                                     /* no live head candidate: the dense masked draw */
+    if (stats) stats[0]++;
+    return draw_scan(n, row, blocked, 0, 0, 0, t, NULL, 64, &u);
   }
+  float r = u * (H + T);
+  if (!(r > 0.0f)) r = 1.401298464e-45f;
+  int L = -1;
+  for (int l = 0; l < 16; ++l) if (incl[l] >= r && part[l] > 0.0f) { L = l; break; }
+  if (L >= 0) {
+    float thr = r - (L ? incl[L - 1] : 0.0f), run = 0.0f;
+    int best = -1, last = -1;
+    for (int v = 0; v < spl; ++v) {
+      int m = spl * L + v;
+      if (!(w[m] > 0.0f)) continue;
+      run = run + w[m];
+      last = m;
+      if (run >= thr) { best = m; break; }
+    }
+    if (best < 0) { best = last; sparse_rounding_picks++; }
+    return hid[best];
+  }
+  /* past the head: walk the whole tail, visited entries included */
+  if (stats) stats[1]++;
+  float rp = r - H;
+  if (!(rp > 0.0f)) rp = 1.401298464e-45f;
+  memset(is_head, 0, n);
+  for (int m = 0; m < cnt; ++m) is_head[hid[m]] = 1;
+  float tpart[64], tincl[64];
+  sparse_tail_scan(n, row, is_head, tpart, tincl);
+  int Lt = -1;
+  for (int l = 0; l < 64; ++l) if (tincl[l] >= rp && tpart[l] > 0.0f) { Lt = l; break; }
+  if (Lt < 0) for (int l = 63; l >= 0; --l) if (tpart[l] > 0.0f) { Lt = l; break; }      /* rounding: the last lane with mass */
+  int j = -1;
+  if (Lt >= 0) {
+    float thr = rp - (Lt ? tincl[Lt - 1] : 0.0f), run = 0.0f;
+    int last = -1, ch = (n + 255) / 256;
+    for (int c = 0; c < ch && j < 0; ++c)
+      for (int v = 0; v < 4; ++v) {
+        int k = (c * 64 + Lt) * 4 + v;
+        if (k >= n || is_head[k] || !(row[k] > 0.0f)) continue;
+        run = run + row[k];
+        last = k;
+        if (run >= thr) { j = k; break; }
+      }
+    if (j < 0) j = last;
+  }
+  if (j < 0) {                                           /* a tail without mass: the head's last live candidate */
+    for (int m = cnt - 1; m >= 0; --m) if (w[m] > 0.0f) return hid[m];
+    return -1;
+  }
+  if (!blocked[j]) return j;
+  /* the tail entry is visited: the dense masked draw over ALL open candidates with the step's second uniform.  The outcome x
+   * then has probability p_x / (H + T) + (T_visited / (H + T)) * p_x / (H + T_open) = p_x / (H + T_open): the categorical. */
+  if (stats) { stats[2]++; stats[0]++; }
+  rng_block(seed, iter, STREAM_SPARSE_RETRY, gid, ut << 8, r4);
+  u = u01(r4[0]);
+  return draw_scan(n, row, blocked, 0, 0, 0, t, NULL, 64, &u);
 }
 
 /* P [n][n] dense, head_id [n][kh] uint16, head_cnt [n] uint8 (<= kh - 1), head_val [n][kh] from orc_sparse_head_values */
