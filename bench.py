@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--config", default="headline", choices=["headline", "c5"],
                     help="c5: the per-GPU share of BASELINE config 5 (TSP-1000, 2048 ants, 64 instances per GPU)")
     ap.add_argument("--min-seconds", type=float, default=12.0, help="length of the sustained (untimed-by-metric) loop")
+    ap.add_argument("--precondition-seconds", type=float, default=0.5,
+                    help="untimed steps of a throw-away colony of the same shape before the W warm-up steps: the first ~20 ms "
+                         "of a launch sequence run 5-8 %% slower than the steady state (profiles/r04_headline_clock_ramp.txt)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-time reduce (nccl = RCCL)")
     ap.add_argument("--shard", default="instances", choices=["instances", "ants"],
@@ -821,6 +824,20 @@ def worker(args):
         colony.heuristic = colony.heuristic.contiguous()
 
     log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler}")
+    pre_steps = 0
+    if args.precondition_seconds > 0 and not ant_sharded:
+        # a throw-away colony of the same shape keeps the device busy until its clocks have settled; the measured colony
+        # starts from its own initial state right after
+        pre = engine.BatchedTSP(dist_cpu.to(dev), n_ants=A, sampler=args.sampler, seed=4321)
+        pre.sparsify(k_sparse)
+        pre.heuristic = pre.heuristic.contiguous()
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.precondition_seconds:
+            for _ in range(20):
+                pre.step()
+            torch.cuda.synchronize()
+            pre_steps += 20
+        del pre
     for _ in range(args.warmup):
         colony.step()
     torch.cuda.synchronize()
@@ -897,6 +914,9 @@ def worker(args):
                                       pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{args.sampler}"))
             if kern_ms else None,
             "knobs": active_knobs(),
+            "preconditioning": {"steps": pre_steps, "seconds": args.precondition_seconds,
+                                "note": "untimed steps of a throw-away colony of the same shape before the warm-up steps (device clocks "
+                                        "settle: the first ~20 ms of a launch sequence run 5-8 % slower than the sustained loop)"},
             "sustained": sustained,
             "gpu_mean_best_cost": float(gpu_best.mean()),
         }
