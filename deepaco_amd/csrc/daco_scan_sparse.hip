@@ -439,14 +439,18 @@ scan_sparse_kernel(const SampleParams p) {
                 choice_g = sparse_row_walk<CHD, false>(rowp, flg, nullptr, lane, ug);
               } else {
                 n_tail += real;
-                // the head's nodes as a bitmap (an empty slot holds an id >= n)
+                // the head's nodes as a bitmap, from the ids the ant's own lanes hold (an empty slot holds an id >= n)
                 if (lane < 32) bm_s[wave][lane] = 0u;
+                asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                if (q == g) {
 #pragma unroll
-                for (int m = lane; m < 16 * SPL; m += 64) {
-                  const int idl = *reinterpret_cast<const uint16_t *>(hrb + (uint32_t)pv * ROWB + (uint32_t)(m / SPL) * LS + SPL * 4u + (uint32_t)(m % SPL) * 2u);
-                  if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
+                  for (int v = 0; v < SPL; ++v) {
+                    const int idl = SP_ID(v);
+                    if (idl < n) atomicOr(&bm_s[wave][idl >> 5], 1u << (idl & 31));
+                  }
                 }
+                asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 float rp = rg - Hg;
                 rp = rp > 0.0f ? rp : 1.401298464e-45f;
