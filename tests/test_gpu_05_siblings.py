@@ -26,9 +26,10 @@ def check_update(aco, fn, sols, g, key="pheromone_as"):
     np.testing.assert_allclose(aco.pheromone.cpu().numpy(), g[key], rtol=2e-6, atol=1e-12)
 
 
-def test_smtwtp():
+@pytest.mark.parametrize("fix", ["s4_smtwtp_n20", "s4_smtwtp_n50"])
+def test_smtwtp(fix):
     from deepaco_amd.smtwtp.aco import ACO
-    g = load_golden("s4_smtwtp_n20")
+    g = load_golden(fix)
     A = g["paths"].shape[1]
     aco = ACO(T(g["due_time"]), T(g["weights"]), T(g["processing_time"]), n_ants=A, pheromone=T(g["pheromone"]),
               device="cuda:0")
@@ -61,9 +62,10 @@ def test_smtwtp():
     assert np.array_equal(pn.cpu().numpy(), g["paths"])
 
 
-def test_sop():
+@pytest.mark.parametrize("fix", ["s3_sop_n20", "s3_sop_n50"])
+def test_sop(fix):
     from deepaco_amd.sop.aco import ACO
-    g = load_golden("s3_sop_n20")
+    g = load_golden(fix)
     A = g["paths"].shape[1]
     aco = ACO(T(g["distances"]), T(g["prec_cons"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
     paths, logp = aco.gen_path(True, _noise=noise_list(g))
@@ -78,12 +80,13 @@ def test_sop():
         p = a2.gen_path().cpu().numpy()
         pos = np.argsort(p, axis=0)                       # pos[node, ant]
         jj, kk = np.nonzero(g["prec_cons"])
-        assert (pos[kk] < pos[jj]).all() and (np.sort(p, axis=0) == np.arange(20)[:, None]).all()
+        assert (pos[kk] < pos[jj]).all() and (np.sort(p, axis=0) == np.arange(p.shape[0])[:, None]).all()
 
 
-def test_pctsp():
+@pytest.mark.parametrize("fix", ["s2_pctsp_n20", "s2_pctsp_n100"])
+def test_pctsp(fix):
     from deepaco_amd.pctsp.aco import ACO
-    g = load_golden("s2_pctsp_n20")
+    g = load_golden(fix)
     A = g["sols"].shape[1]
     aco = ACO(T(g["distances"]), T(g["prizes"]), T(g["penalties"]), n_ants=A, device="cuda:0")
     np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
@@ -100,9 +103,10 @@ def test_pctsp():
     assert sol[0] == 0 and float(best) > 0
 
 
-def test_op():
+@pytest.mark.parametrize("fix", ["s1_op_n30", "s1_op_n100"])
+def test_op(fix):
     from deepaco_amd.op.aco import ACO
-    g = load_golden("s1_op_n30")
+    g = load_golden(fix)
     A = g["sols"].shape[1]
     aco = ACO(T(g["distances_in"]), T(g["prizes_in"]), float(g["max_len"]), n_ants=A, k_sparse=int(g["k_sparse"]),
               device="cuda:0")
@@ -137,9 +141,10 @@ def test_op():
     assert float((length + back).max()) <= float(g["max_len"]) + 1e-4
 
 
-def test_bpp():
+@pytest.mark.parametrize("fix", ["s5_bpp_n24", "s5_bpp_n120"])
+def test_bpp(fix):
     from deepaco_amd.bpp.aco import ACO
-    g = load_golden("s5_bpp_n24")
+    g = load_golden(fix)
     A = g["paths"].shape[1]
     aco = ACO(T(g["demand"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
     np.testing.assert_array_equal(aco.heuristic.cpu().numpy(), g["heuristic"])
@@ -154,9 +159,10 @@ def test_bpp():
     assert 0 < float(fit) <= 1
 
 
-def test_mkp():
+@pytest.mark.parametrize("fix", ["s6_mkp_n20", "s6_mkp_n50"])
+def test_mkp(fix):
     from deepaco_amd.mkp.aco import ACO
-    g = load_golden("s6_mkp_n20")
+    g = load_golden(fix)
     A = g["sols"].shape[1]
     aco = ACO(T(g["prize_in"]), T(g["weight_in"]), n_ants=A, pheromone=T(g["pheromone"]), device="cuda:0")
     np.testing.assert_allclose(aco.heuristic.cpu().numpy(), g["heuristic"], rtol=1e-6)
@@ -202,25 +208,26 @@ def _both_paths(make, gen_name, A, **kw):
         torch.testing.assert_close(l1, l2, rtol=1e-5, atol=2e-6)
 
 
-def test_stepwise_service_still_matches_reference():
+@pytest.mark.parametrize("fx", [("s3_sop_n20", "s2_pctsp_n20", "s1_op_n30", "s6_mkp_n20"), ("s3_sop_n50", "s2_pctsp_n100", "s1_op_n100", "s6_mkp_n50")])
+def test_stepwise_service_still_matches_reference(fx):
     """The draw-by-draw path (daco_pick_move) against the fixtures, now that the default is fused."""
     from deepaco_amd.sop.aco import ACO as SOP
     from deepaco_amd.pctsp.aco import ACO as PCTSP
     from deepaco_amd.op.aco import ACO as OP
     from deepaco_amd.mkp.aco import ACO as MKP
-    g = load_golden("s3_sop_n20")
+    g = load_golden(fx[0])
     a = SOP(T(g["distances"]), T(g["prec_cons"]), n_ants=8, pheromone=T(g["pheromone"]), device="cuda:0")
     assert np.array_equal(a.gen_path(True, _noise=noise_list(g), _stepwise=True)[0].cpu().numpy(), g["paths"])
-    g = load_golden("s2_pctsp_n20")
+    g = load_golden(fx[1])
     a = PCTSP(T(g["distances"]), T(g["prizes"]), T(g["penalties"]), n_ants=8, device="cuda:0")
     a.heuristic, a.pheromone = T(g["heuristic"]), T(g["pheromone"])
     assert np.array_equal(a.gen_sol(True, _noise=noise_list(g), _stepwise=True)[0].cpu().numpy(), g["sols"])
-    g = load_golden("s1_op_n30")
+    g = load_golden(fx[2])
     a = OP(T(g["distances_in"]), T(g["prizes_in"]), float(g["max_len"]), n_ants=8, k_sparse=int(g["k_sparse"]),
            device="cuda:0")
     a.heuristic = T(g["heuristic"])
     assert np.array_equal(a.gen_sol(True, _noise=noise_list(g), _stepwise=True)[0].cpu().numpy(), g["sols"])
-    g = load_golden("s6_mkp_n20")
+    g = load_golden(fx[3])
     a = MKP(T(g["prize_in"]), T(g["weight_in"]), n_ants=8, pheromone=T(g["pheromone"]), device="cuda:0")
     a.heuristic = T(g["heuristic"])
     assert np.array_equal(a.gen_sol(True, _noise=noise_list(g), _start=T(g["start"]), _stepwise=True)[0].cpu().numpy(),
