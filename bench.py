@@ -66,6 +66,10 @@ def parse_args():
     ap.add_argument("--config", default="headline", choices=["headline", "c5"],
                     help="c5: the per-GPU share of BASELINE config 5 (TSP-1000, 2048 ants, 64 instances per GPU)")
     ap.add_argument("--min-seconds", type=float, default=12.0, help="length of the sustained (untimed-by-metric) loop")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams per GPU: the instances run as this many independent colonies (engine.StreamedTSP), one per "
+                         "stream -- the same tours, costs and pheromone; 1 = one colony over all instances in lock-step (the default: "
+                         "two streams gain 4 %% in a sustained loop and lose it in a 10-step timed region, profiles/r04_streams.txt)")
     ap.add_argument("--precondition-seconds", type=float, default=0.5,
                     help="untimed steps of a throw-away colony of the same shape before the W warm-up steps: the first ~20 ms "
                          "of a launch sequence run 5-8 %% slower than the steady state (profiles/r04_headline_clock_ramp.txt)")
@@ -838,20 +842,27 @@ def worker(args):
                                         sampler=args.sampler, seed=1234, exchange=args.exchange)
         _step = colony.step
         colony.step = lambda events=None: _step()
-    else:
-        colony = engine.BatchedTSP(dist_cpu.to(dev), n_ants=A, sampler=args.sampler, seed=1234,
-                                   ant_gid0=rank * B * A)
-        colony.sparsify(k_sparse)
-        colony.heuristic = colony.heuristic.contiguous()
+    streams = 1 if ant_sharded else max(1, min(args.streams, B))
+
+    def make_colony(seed, gid0):
+        if streams > 1:      # (StreamedTSP.sparsify keeps the parts' heuristics contiguous)
+            col = engine.StreamedTSP(dist_cpu.to(dev), parts=streams, n_ants=A, sampler=args.sampler, seed=seed, ant_gid0=gid0)
+            col.sparsify(k_sparse)
+        else:
+            col = engine.BatchedTSP(dist_cpu.to(dev), n_ants=A, sampler=args.sampler, seed=seed, ant_gid0=gid0)
+            col.sparsify(k_sparse)
+            col.heuristic = col.heuristic.contiguous()
+        return col
+
+    if not ant_sharded:
+        colony = make_colony(1234, rank * B * A)
 
     log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler}")
     pre_steps = 0
     if args.precondition_seconds > 0 and not ant_sharded:
         # a throw-away colony of the same shape keeps the device busy until its clocks have settled; the measured colony
         # starts from its own initial state right after
-        pre = engine.BatchedTSP(dist_cpu.to(dev), n_ants=A, sampler=args.sampler, seed=4321)
-        pre.sparsify(k_sparse)
-        pre.heuristic = pre.heuristic.contiguous()
+        pre = make_colony(4321, 0)
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < args.precondition_seconds:
             for _ in range(20):
@@ -862,18 +873,22 @@ def worker(args):
     for _ in range(args.warmup):
         colony.step()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:      # create the handles; the library re-records them around the kernel
-        a.record(); b.record()
+    # one event pair per launch of the construction kernel: per step, and per stream when the instances run as several colonies
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(streams)]
+          for _ in range(args.steps)]
+    for row in ev:       # create the handles; the library re-records them around the kernel
+        for a, b in row:
+            a.record(); b.record()
     torch.cuda.synchronize()
 
     def timed():
         for s in range(args.steps):
-            colony.step(events=ev[s])
+            colony.step(events=ev[s] if streams > 1 else ev[s][0])
 
     elapsed = barrier_max_time(timed, dev, distributed)
     log(f"timed region: {elapsed*1e3:.1f} ms for {args.steps} steps")
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps if not ant_sharded else None
+    # average duration of ONE launch of the construction kernel (B / streams instances each)
+    kern_ms = sum(a.elapsed_time(b) for row in ev for a, b in row) / (args.steps * streams) if not ant_sharded else None
     tours_per_step = B * A if ant_sharded else world * B * A
     value = tours_per_step * args.steps / elapsed
     gpu_best = colony.lowest_cost.detach().cpu()
@@ -930,8 +945,17 @@ def worker(args):
             "config": {"workload": f"TSP-{n} random-Euclidean, n_ants={A}, {B} instances per GPU, "
                                    f"AS update, heuristic 1/d sparsified k={k_sparse}, sampler={args.sampler}",
                        "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": args.sampler,
-                       "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}"},
-            "roofline": roofline_rows(n, A, B, args.sampler, kern_ms, traffic=traffic, traffic_source=tsrc,
+                       "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}",
+                       "streams_per_gpu": streams,
+                       "streams": (f"{streams} colonies of {B // streams}-{-(-B // streams)} instances on {streams} HIP streams per GPU "
+                                   f"(engine.StreamedTSP: the results of one colony over all instances, bit for bit)") if streams > 1
+                       else "one colony over all instances"},
+            # per LAUNCH of the construction kernel: B / streams instances (the counter passes are of one launch over all B
+            # instances of the same kernel: their per-launch byte counts are scaled, their occupancies are ratios)
+            "roofline": roofline_rows(n, A, B / streams, args.sampler, kern_ms,
+                                      traffic=traffic / streams if traffic is not None else None,
+                                      traffic_source=(tsrc + f"; one launch here covers 1/{streams} of the instances of that pass: scaled"
+                                                      if tsrc and streams > 1 else tsrc),
                                       pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{args.sampler}"))
             if kern_ms else None,
             "knobs": active_knobs(),
