@@ -51,8 +51,8 @@ struct SampleParams {
   int32_t *lens;         // [B][A] rows used by each ant
   int knob = 0;          // measurement knob of a kernel (0 in production)
   // head / tail rows (daco_scan_sparse.hip)
-  const float *hval = nullptr;       // [B][n][64] head values of this iteration, slot 63 = the tail total
-  const uint16_t *hid = nullptr;     // [B][n][64] head node ids, slot 63 = the live count
+  const float *hval = nullptr;       // [B][n] head rows of this iteration: 16 lanes x {SPL f32 values, SPL u16 ids} (sparse_prepass_kernel)
+  const uint16_t *hid = nullptr;     // the caller's head table [B][n][slots] (the pre-pass reads it; the scan reads the head rows)
   unsigned long long *stats = nullptr;   // [3] dense steps, tail walks, rejections (tests) or null
 };
 

@@ -34,10 +34,6 @@ enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };   // (retry: the
 
 template <int N> __device__ inline float sp_row_bcast(float x) { return dpp_f<0x150 + N, 0xF, false>(x, x); }
 template <int N> __device__ inline int sp_row_ror(int x) { return dpp_i<0x120 + N, 0xF, false>(x, x); }
-__device__ inline int sp_row_or(int x) {
-  x |= sp_row_ror<1>(x); x |= sp_row_ror<2>(x); x |= sp_row_ror<4>(x); x |= sp_row_ror<8>(x);
-  return x;
-}
 __device__ inline float sp_row_scan(float x) {
   x = x + dpp_f<DPP_ROW_SHR(1), 0xF, true>(0.0f, x);
   x = x + dpp_f<DPP_ROW_SHR(2), 0xF, true>(0.0f, x);
