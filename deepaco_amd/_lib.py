@@ -25,7 +25,7 @@ SIGNATURES = {
     "daco_tsp_sample_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_tsp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _i, _vp, _i, _vp, _u64, _u64, _vp,
                              _u32, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "daco_tsp_sparse_workspace_bytes": (_sz, [_i, _i]),
+    "daco_tsp_sparse_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_tsp_sample_sparse": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                     _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
@@ -64,7 +64,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 122          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 123          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

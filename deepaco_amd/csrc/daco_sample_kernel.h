@@ -54,6 +54,7 @@ struct SampleParams {
   const float *hval = nullptr;       // [B][n] head rows of this iteration: 16 lanes x {SPL f32 values, SPL u16 ids} (sparse_prepass_kernel)
   const uint16_t *hid = nullptr;     // the caller's head table [B][n][slots] (the pre-pass reads it; the scan reads the head rows)
   unsigned long long *stats = nullptr;   // [3] dense steps, tail walks, rejections (tests) or null
+  uint16_t *tours16 = nullptr;       // scan_sparse at n > 512: [B][A][ld] the tours as they are built (32 bytes per ant every 16 steps)
 };
 
 template <class F, int... I>

@@ -211,7 +211,7 @@ __device__ inline float sp_at_least_denorm(float x) {     // max(x, denorm_min) 
 }
 
 template <int CHD, bool RACE, int SPL>
-__global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 3)
+__global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 4)
 scan_sparse_kernel(const SampleParams p) {
   constexpr int APW = 4, APB = 16;
   constexpr int LS = sp_lane_bytes(SPL);                 // bytes per lane of a head row
@@ -219,11 +219,16 @@ scan_sparse_kernel(const SampleParams p) {
   constexpr int FL = CHD * 256;                          // tour / inverse-table entries per ant (>= n)
   constexpr int FLP = FL + 16;                           // flag bytes per ant: entry FL is never set (the id of slot 63 and of empty slots)
   constexpr uint32_t ROWB = 16u * LS;                    // bytes of a head row: lane s holds {SPL f32 values, SPL u16 ids} at s * LS
-  // visited flags as BYTES (1 while node k is unvisited, node order): with the u16 tours 1.5 KB of LDS per ant at n <= 512, six
-  // workgroups per CU.
-  __shared__ __attribute__((aligned(16))) uint8_t open_flags[APB][FLP];
-  extern __shared__ __attribute__((aligned(16))) unsigned char sparse_dyn[];  // the tours (dynamic: static + dynamic pass 64 KB at n > 512)
-  uint16_t (*tour_s)[FL] = reinterpret_cast<uint16_t (*)[FL]>(sparse_dyn);    // [APB][FL]
+  // LDS (one dynamic block): visited flags as BYTES (1 while node k is unvisited, node order) and
+  //   n <= 512: the u16 tours -- 1.5 KB per ant, six workgroups per CU (all outputs leave in the epilogue below);
+  //   n > 512 (TG): a 16-step window of each tour only.  The tours go to global memory 32 bytes per ant every 16 steps and come
+  //   back eight at a time for the epilogue, which reuses the block: 3.1 KB per ant would allow three workgroups per CU, 32 KB
+  //   per workgroup allow four, and at this size the launch time follows the occupancy (two instead of three: 6.5 -> 8.6 ms at
+  //   TSP-1000 x 2048 x 64; its 8 192 workgroups run in many rounds, so the epilogue runs under other workgroups' loops).
+  constexpr bool TG = CHD == 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sparse_dyn[];
+  uint8_t *flag_mem = sparse_dyn;                                                   // [APB][FLP]
+  uint16_t *tour_mem = reinterpret_cast<uint16_t *>(sparse_dyn + APB * FLP);      // !TG: [APB][FL]; TG: [APB][16], the window
   __shared__ uint32_t bm_s[4][32];                       // tail walk: the head of the row as a bitmap over the nodes
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, s = lane & 15;
@@ -243,8 +248,12 @@ scan_sparse_kernel(const SampleParams p) {
   const uint32_t ldb = (uint32_t)ld * 4u;
   uint32_t sls = (uint32_t)s * LS;
   asm volatile("" : "+v"(sls));                          // (kept in a register: the loop adds it to the row offset)
-  uint8_t *fl = open_flags[wave * APW + q];
-  uint16_t *tour = tour_s[wave * APW + q];
+  uint8_t *fl = flag_mem + (wave * APW + q) * FLP;
+  uint16_t *tour = tour_mem + (wave * APW + q) * (TG ? 16 : FL);
+  // TG: tour entry t lives at tour[t & 15] until its chunk is flushed to the workgroup's rows of tours16 [B][A][FL]
+  uint16_t *t16b = TG ? p.tours16 + ((size_t)b * A + abase) * FL : nullptr;
+  const uint32_t t16o = (uint32_t)((wave * APW + q) * FL + s);
+#define SP_T(t) ((t) & (TG ? 15 : 0xFFFF))
   bool infeasible = false;
   unsigned long long n_dense = 0, n_tail = 0, n_rej = 0;
 
@@ -333,7 +342,7 @@ scan_sparse_kernel(const SampleParams p) {
             const int g = gl >> 4;
             const int pv = readlane_i(prev, gl);
             const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
-            const uint8_t *flg = open_flags[wave * APW + g];
+            const uint8_t *flg = flag_mem + (wave * APW + g) * FLP;
             const char *rowp = Pb + (uint32_t)pv * ldb;
             n_dense += a0 + g < A ? 1ull : 0ull;
             float dk = __builtin_inff();
@@ -357,7 +366,7 @@ scan_sparse_kernel(const SampleParams p) {
             if (!(rr.key < __builtin_inff())) { infeasible = true; cg = 0; }
             choice = q == g ? cg : choice;
           }
-          if (s == 0) { fl[choice] = 0; tour[t] = (uint16_t)choice; }
+          if (s == 0) { fl[choice] = 0; tour[SP_T(t)] = (uint16_t)choice; }
           asm volatile("" ::: "memory");                    // the next step's flag reads follow these stores
           __builtin_amdgcn_wave_barrier();
           prev = choice;
@@ -426,7 +435,7 @@ scan_sparse_kernel(const SampleParams p) {
               const float Hg = readlane_f(incl, gl + 15);
               const float ug = readlane_f(ucur, gl), rg = readlane_f(r, gl);     // (ucur: already rotated, lane 0 holds this step's)
               const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
-              const uint8_t *flg = open_flags[wave * APW + g];
+              const uint8_t *flg = flag_mem + (wave * APW + g) * FLP;
               const char *rowp = Pb + (uint32_t)pv * ldb;
               int choice_g = -1;
               const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
@@ -472,18 +481,26 @@ scan_sparse_kernel(const SampleParams p) {
                 }
               }
               if (choice_g < 0) { infeasible = true; choice_g = 0; }
-              if (lane == gl) { fl[choice_g] = 0; tour[t] = (uint16_t)choice_g; }
+              if (lane == gl) { fl[choice_g] = 0; tour[SP_T(t)] = (uint16_t)choice_g; }
             }
           }
           // the winning lane of every ant marks the node and appends it; the ant's lanes read it back as the next row
-          if (__builtin_amdgcn_inverse_ballot_w64(first)) { fl[sel] = 0; tour[t] = (uint16_t)sel; }
+          if (__builtin_amdgcn_inverse_ballot_w64(first)) { fl[sel] = 0; tour[SP_T(t)] = (uint16_t)sel; }
           asm volatile("" ::: "memory");                    // (same wavefront: the LDS executes these in program order)
-          prev = tour[t];
+          prev = tour[SP_T(t)];
           asm volatile("" ::: "memory");
         }
       }
+      if constexpr (TG) {
+        // the chunk's sixteen entries leave the window: 32 contiguous bytes per ant (entries past n - 1: never read)
+        asm volatile("" ::: "memory");
+        const uint16_t wv = tour[s];
+        if (a0 + q < A) t16b[t16o + (uint32_t)t0] = wv;
+        asm volatile("" ::: "memory");
+      }
     }
   }
+#undef SP_T
 #undef SP_HEAD_DECIDE
 #undef SP_LAST_POSITIVE
 #undef SP_ID
@@ -493,70 +510,143 @@ scan_sparse_kernel(const SampleParams p) {
     atomicAdd(p.stats + 0, n_dense); atomicAdd(p.stats + 1, n_tail); atomicAdd(p.stats + 2, n_rej);
   }
 
-  // ------------------------------------------------------------------ epilogue: the workgroup's 16 tours leave LDS
-  __syncthreads();
+  // ------------------------------------------------------------------ epilogue: the workgroup's 16 tours leave
   const int nant = A - abase < APB ? A - abase : APB;
-  const int k16 = threadIdx.x & (APB - 1);
-  constexpr int TSTEP = 256 / APB;
-  if (p.paths && k16 < nant) {
-    int64_t *pb = p.paths + (size_t)b * n * A + abase;
-    for (int t = threadIdx.x / APB; t < n; t += TSTEP) pb[(size_t)t * A + k16] = (int64_t)tour_s[k16][t];
-  }
-  if (p.costs) {
-    // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of each
-    // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
+  if constexpr (!TG) {
+    uint16_t (*tour_s)[FL] = reinterpret_cast<uint16_t (*)[FL]>(tour_mem);
     __syncthreads();
-    const float *dist_b = p.dist + (size_t)b * p.dist_bs;
-    float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(&open_flags[0][0]);
-    if (active) {
-      float cost = 0.0f;
-      const float *mine_d = dstage[wave][q];
-      for (int base = 1; base < n; base += 64) {
-        const int t = base + lane;
+    const int k16 = threadIdx.x & (APB - 1);
+    constexpr int TSTEP = 256 / APB;
+    if (p.paths && k16 < nant) {
+      int64_t *pb = p.paths + (size_t)b * n * A + abase;
+      for (int t = threadIdx.x / APB; t < n; t += TSTEP) pb[(size_t)t * A + k16] = (int64_t)tour_s[k16][t];
+    }
+    if (p.costs) {
+      // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of each
+      // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
+      __syncthreads();
+      const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+      float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(flag_mem);
+      if (active) {
+        float cost = 0.0f;
+        const float *mine_d = dstage[wave][q];
+        for (int base = 1; base < n; base += 64) {
+          const int t = base + lane;
 #pragma unroll
-        for (int r4 = 0; r4 < APW; ++r4) {
-          const uint16_t *tr = tour_s[wave * APW + r4];
-          dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (s == 0) {
-#pragma unroll
-          for (int v4 = 0; v4 < 16; ++v4) {
-            const float4 v = *(const float4 *)(mine_d + 4 * v4);
-            cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+          for (int r4 = 0; r4 < APW; ++r4) {
+            const uint16_t *tr = tour_s[wave * APW + r4];
+            dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
           }
+          __builtin_amdgcn_wave_barrier();
+          if (s == 0) {
+#pragma unroll
+            for (int v4 = 0; v4 < 16; ++v4) {
+              const float4 v = *(const float4 *)(mine_d + 4 * v4);
+              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (s == 0 && a0 + q < A) {
-        const uint16_t *tm = tour_s[wave * APW + q];
-        cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
-        p.costs[(size_t)b * A + a0 + q] = cost;
+        if (s == 0 && a0 + q < A) {
+          const uint16_t *tm = tour_s[wave * APW + q];
+          cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+          p.costs[(size_t)b * A + a0 + q] = cost;
+        }
       }
     }
-  }
-  if (p.nbr) {
-    // the update's table through an inverse-permutation table in the (dead) flag array, eight ants at a time
-    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(&open_flags[0][0]);
-    static_assert(sizeof(open_flags) >= 8 * FL * sizeof(uint16_t), "inverse table of eight ants inside the flag array");
+    if (p.nbr) {
+      // the update's table through an inverse-permutation table in the (dead) flag array, eight ants at a time
+      uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(flag_mem);
+      static_assert(APB * FLP >= 8 * FL * (int)sizeof(uint16_t), "inverse table of eight ants inside the flag array");
+      const int k8 = threadIdx.x & 7;
+      for (int half = 0; half < 2; ++half) {
+        const int nh = nant - half * 8 < 8 ? nant - half * 8 : 8;
+        __syncthreads();
+        if (nh <= 0) break;
+        for (int e = threadIdx.x; e < 8 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const uint16_t *tk = tour_s[half * 8 + (k8 < nh ? k8 : 0)];
+        if (k8 < nh)
+          for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k8][tk[t]] = (uint16_t)t;
+        __syncthreads();
+        uint32_t *nb = p.nbr + (size_t)b * n * A + abase + half * 8;
+        if (k8 < nh)
+          for (int node = threadIdx.x >> 3; node < n; node += 32) {
+            const int t = inv[k8][node];
+            const uint32_t pv = tk[t == 0 ? n - 1 : t - 1], nx = tk[t == n - 1 ? 0 : t + 1];
+            nb[(size_t)node * A + k8] = pv | (nx << 16);
+          }
+      }
+    }
+  } else {
+    // TG: eight tours at a time, global -> LDS (this workgroup wrote them: its stores are visible after the barrier's release /
+    // acquire), into the block the loop no longer needs: [8][FL] tours | [8][FL] inverse table (cost staging before it is built)
+    uint16_t (*tl)[FL] = reinterpret_cast<uint16_t (*)[FL]>(sparse_dyn);
+    uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(sparse_dyn + 8 * FL * 2);
     const int k8 = threadIdx.x & 7;
     for (int half = 0; half < 2; ++half) {
       const int nh = nant - half * 8 < 8 ? nant - half * 8 : 8;
       __syncthreads();
       if (nh <= 0) break;
-      for (int e = threadIdx.x; e < 8 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+      {
+        constexpr int V = FL * 2 / 16;                       // 16-byte pieces per tour
+        const uint4 *src = reinterpret_cast<const uint4 *>(t16b + (size_t)half * 8 * FL);
+        for (int e = threadIdx.x; e < 8 * V; e += 256)
+          if (e / V < nh) reinterpret_cast<uint4 *>(&tl[0][0])[e] = src[e];
+      }
       __syncthreads();
-      const uint16_t *tk = tour_s[half * 8 + (k8 < nh ? k8 : 0)];
-      if (k8 < nh)
-        for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k8][tk[t]] = (uint16_t)t;
-      __syncthreads();
-      uint32_t *nb = p.nbr + (size_t)b * n * A + abase + half * 8;
-      if (k8 < nh)
-        for (int node = threadIdx.x >> 3; node < n; node += 32) {
-          const int t = inv[k8][node];
-          const uint32_t pv = tk[t == 0 ? n - 1 : t - 1], nx = tk[t == n - 1 ? 0 : t + 1];
-          nb[(size_t)node * A + k8] = pv | (nx << 16);
+      if (p.paths && k8 < nh) {
+        int64_t *pb = p.paths + (size_t)b * n * A + abase + half * 8;
+        for (int t = threadIdx.x >> 3; t < n; t += 32) pb[(size_t)t * A + k8] = (int64_t)tl[k8][t];
+      }
+      if (p.costs) {
+        // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of
+        // each of the wave's two ants are gathered with every lane active and staged in LDS.
+        const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+        float (*dstage)[2][64] = reinterpret_cast<float (*)[2][64]>(&inv[0][0]);
+        const int hh = lane >> 5;                             // lanes 0 and 32 sum the wave's two ants
+        const int mine = wave * 2 + hh;
+        float cost = 0.0f;
+        for (int base = 1; base < n; base += 64) {
+          const int t = base + lane;
+#pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2) {
+            const uint16_t *tr = tl[wave * 2 + r2];
+            dstage[wave][r2][lane] = t < n && wave * 2 + r2 < nh ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if ((lane & 31) == 0) {
+            const float *md = dstage[wave][hh];
+#pragma unroll
+            for (int v4 = 0; v4 < 16; ++v4) {
+              const float4 v = *(const float4 *)(md + 4 * v4);
+              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
         }
+        if ((lane & 31) == 0 && mine < nh) {
+          const uint16_t *tm = tl[mine];
+          cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+          p.costs[(size_t)b * A + abase + half * 8 + mine] = cost;
+        }
+      }
+      if (p.nbr) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 8 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const uint16_t *tk = tl[k8 < nh ? k8 : 0];
+        if (k8 < nh)
+          for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k8][tk[t]] = (uint16_t)t;
+        __syncthreads();
+        uint32_t *nb = p.nbr + (size_t)b * n * A + abase + half * 8;
+        if (k8 < nh)
+          for (int node = threadIdx.x >> 3; node < n; node += 32) {
+            const int t = inv[k8][node];
+            const uint32_t pv = tk[t == 0 ? n - 1 : t - 1], nx = tk[t == n - 1 ? 0 : t + 1];
+            nb[(size_t)node * A + k8] = pv | (nx << 16);
+          }
+      }
     }
   }
 }
@@ -565,10 +655,12 @@ scan_sparse_kernel(const SampleParams p) {
 
 using namespace daco;
 
-extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n) {
-  if (B <= 0 || n <= 128 || n > 1024) return 0;
+extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A) {
+  if (B <= 0 || A <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
-  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * 16 * sp_lane_bytes(SP_KH_MAX / 16));
+  // the transition rows, the head rows, and (n > 512) the u16 tours as they are built
+  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * 16 * sp_lane_bytes(SP_KH_MAX / 16)) +
+         (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
 }
 
 static int sample_sparse_impl(bool race, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
@@ -586,7 +678,7 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   if ((size_t)n * A * 8 >= ((size_t)1 << 32)) { set_error("%s: n * A too large for 32-bit offsets", what); return DACO_E_TOOLARGE; }
   if (fixed_start >= n) { set_error("%s: fixed_start %d >= n %d", what, fixed_start, n); return DACO_E_BADARG; }
   if (costs && !dist) { set_error("%s: fused costs need the distance matrix", what); return DACO_E_BADARG; }
-  const size_t need = daco_tsp_sparse_workspace_bytes(B, n);
+  const size_t need = daco_tsp_sparse_workspace_bytes(B, n, A);
   if (workspace_bytes < need) { set_error("%s: workspace %zu < %zu bytes", what, workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   const int ld = n <= 512 ? 512 : 1024;
@@ -608,16 +700,21 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
   sp.hval = (const float *)hrow; sp.hid = head_id; sp.stats = stats;
+  sp.tours16 = (uint16_t *)(hrow + align256((size_t)B * n * 16 * sp_lane_bytes(SP_KH_MAX / 16)));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("%s pre-pass: %s", what, hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
   const int bpi = (A + 15) / 16;
   const dim3 grid((unsigned)(B * bpi));
-#define DACO_SPARSE_LAUNCH(C, R, S) hipLaunchKernelGGL((scan_sparse_kernel<C, R, S>), grid, dim3(256), 16 * C * 256 * 2, s, sp)
+  // dynamic LDS: flags + tours (n <= 512); the larger of flags + window and eight tours + their inverse table (n > 512)
+  const int pad_lds = getenv("DACO_SPARSE_PAD_LDS") ? atoi(getenv("DACO_SPARSE_PAD_LDS")) : 0;   // (measurement knob: fewer workgroups per CU)
+#define DACO_SPARSE_LDS(C) ((C) == 2 ? 16 * ((C) * 256 + 16) + 16 * (C) * 256 * 2 : 2 * 8 * (C) * 256 * 2)
+#define DACO_SPARSE_LAUNCH(C, R, S) hipLaunchKernelGGL((scan_sparse_kernel<C, R, S>), grid, dim3(256), DACO_SPARSE_LDS(C) + pad_lds, s, sp)
 #define DACO_SPARSE_PICK(C, R) do { if (spl == 4) DACO_SPARSE_LAUNCH(C, R, 4); else DACO_SPARSE_LAUNCH(C, R, 8); } while (0)
   if (ld <= 512) { if (race) DACO_SPARSE_PICK(2, true); else DACO_SPARSE_PICK(2, false); }
   else { if (race) DACO_SPARSE_PICK(4, true); else DACO_SPARSE_PICK(4, false); }
 #undef DACO_SPARSE_PICK
+#undef DACO_SPARSE_LDS
 #undef DACO_SPARSE_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("scan_sparse_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }

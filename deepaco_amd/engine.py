@@ -170,7 +170,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
         if want_nbr:
             nbr = torch.empty((B, n, n_ants), dtype=torch.int32, device=dev)
         stats = torch.zeros(3, dtype=torch.int64, device=dev) if want_stats else None
-        nbytes = L.daco_tsp_sparse_workspace_bytes(B, n)
+        nbytes = L.daco_tsp_sparse_workspace_bytes(B, n, n_ants)
         if nbytes == 0:
             raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
         ws = _workspace(dev, nbytes, "sample_sparse")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 122 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection) */
+#define DACO_VERSION 123 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count) */
 
 /* error codes */
 #define DACO_OK 0
@@ -134,9 +134,10 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *   paths, flags, dist / costs, nbr, start / fixed_start, seed / iter / iter_offset / ant_gid0 / ant_gid_bstride,
  *   ev_begin / ev_end: as daco_tsp_sample (log-probabilities are not produced: an inference sampler)
  *   stats    optional out [3] uint64 (caller zeroes): dense masked draws (no live head candidate, or after a rejection), tail walks, rejections
- *   workspace  daco_tsp_sparse_workspace_bytes(B, n) bytes of device scratch
+ *   workspace  daco_tsp_sparse_workspace_bytes(B, n, A) bytes of device scratch (the transition rows, the head rows and, for n > 512,
+ *              the tours as they are built)
  */
-size_t daco_tsp_sparse_workspace_bytes(int B, int n);
+size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A);
 int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
                            const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                            float alpha, float beta, const uint16_t *head_id, int head_slots,

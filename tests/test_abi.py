@@ -34,7 +34,7 @@ def test_ctypes_table_matches_header():
 
 def test_version_and_layout_helpers_agree_with_oracle():
     L = _lib.lib()
-    assert L.daco_version() >= 122
+    assert L.daco_version() >= 123
     for n in (2, 5, 63, 64, 65, 100, 128, 129, 255, 256, 257, 500, 1000, 4096):
         assert L.daco_vec_for_n(n) == oracle.vec_for_n(n)
         assert L.daco_ld_for_n(n) == oracle.ld_for_n(n)
