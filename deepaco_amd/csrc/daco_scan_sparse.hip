@@ -211,7 +211,7 @@ __device__ inline float sp_at_least_denorm(float x) {     // max(x, denorm_min) 
 }
 
 template <int CHD, bool RACE, int SPL>
-__global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 4)
+__global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 5)
 scan_sparse_kernel(const SampleParams p) {
   constexpr int APW = 4, APB = 16;
   constexpr int LS = sp_lane_bytes(SPL);                 // bytes per lane of a head row
@@ -229,7 +229,10 @@ scan_sparse_kernel(const SampleParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sparse_dyn[];
   uint8_t *flag_mem = sparse_dyn;                                                   // [APB][FLP]
   uint16_t *tour_mem = reinterpret_cast<uint16_t *>(sparse_dyn + APB * FLP);      // !TG: [APB][FL]; TG: [APB][16], the window
-  __shared__ uint32_t bm_s[4][32];                       // tail walk: the head of the row as a bitmap over the nodes
+  // tail walk: the head of the row as a bitmap over the nodes, one per wavefront (inside the block at n > 512, so that five
+  // workgroups of 32 KB fill a CU's LDS)
+  __shared__ uint32_t bm_static[TG ? 1 : 4][32];
+  uint32_t (*bm_s)[32] = TG ? reinterpret_cast<uint32_t (*)[32]>(sparse_dyn + APB * FLP + APB * 32) : bm_static;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, s = lane & 15;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
