@@ -151,14 +151,15 @@ def sampler_layout(n, sampler):
     return name, row
 
 
-def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, traffic_source=None, pipes=None):
+def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, traffic_source=None, pipes=None, head_k=None):
     """Roofline object of a tour-construction launch: L2 row stream as the bound, SURVEY 8(d)'s algorithmic bytes and
     the HBM-side picture next to it; `pipes`: the counter-measured occupancy of the CU's units for this kernel."""
     name, row = sampler_layout(n, sampler)
     steps = n - 1 if steps_per_tour is None else steps_per_tour
     row_bytes = B * A * steps * 4.0 * row
-    if sampler == "scan_sparse":            # a head step reads 64 values + 64 ids; the dense steps (counted in the run) a row
-        name, row_bytes = "scan_sparse_kernel", B * A * steps * 384.0
+    if sampler == "scan_sparse":            # a head step reads 64 / 128 values + ids; the dense steps (counted in the run) a row
+        head_row = 384.0 if (head_k or max(1, min(127, n // 10))) <= 63 else 768.0
+        name, row_bytes = "scan_sparse_kernel", B * A * steps * head_row
     alg_bytes = B * A * bytes_per_tour(n, A, steps)
     ach = row_bytes / (kern_ms * 1e-3) / 1e9
     compulsory = B * (8.0 * n * n + 8.0 * A * n)
@@ -956,7 +957,7 @@ def worker(args):
                                       traffic=traffic / streams if traffic is not None else None,
                                       traffic_source=(tsrc + f"; one launch here covers 1/{streams} of the instances of that pass: scaled"
                                                       if tsrc and streams > 1 else tsrc),
-                                      pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{args.sampler}"))
+                                      pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{args.sampler}"), head_k=k_sparse)
             if kern_ms else None,
             "knobs": active_knobs(),
             "preconditioning": {"steps": pre_steps, "seconds": args.precondition_seconds,
