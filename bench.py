@@ -97,6 +97,99 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+
+# ---------------------------------------------------------------------------------------------- the line
+HEADLINE_MAX_BYTES = 4096
+
+
+def _r(v, sig=6):
+    """Numbers rounded to `sig` significant digits (the record is read by people and by a size-limited tail parser)."""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def headline_record(full):
+    """The LAST stdout line: the contract's keys + roofline + cpu_baseline, numbers only, <= HEADLINE_MAX_BYTES.
+    Everything else (per-configuration extras, pipe occupancies, notes) lives in bench_extras.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    rec = {k: full[k] for k in keep if k in full}
+    cfg = full.get("config") or {}
+    rec["config"] = {k: cfg[k] for k in ("workload", "nodes", "n_ants", "instances_per_gpu", "sampler", "parallelism") if k in cfg}
+    rf = full.get("roofline")
+    if rf:
+        rec["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms")}
+        rec["roofline"]["valu_busy"] = rf.get("valu_busy")
+        alg, hbm = rf.get("algorithmic") or {}, rf.get("hbm") or {}
+        rec["roofline"]["algorithmic"] = {"GBps": alg.get("GBps"), "over_hbm_peak": alg.get("over_hbm_peak")}
+        rec["roofline"]["hbm"] = {"ratio": hbm.get("ratio"), "GBps": hbm.get("GBps"), "peak": hbm.get("peak")}
+    else:
+        rec["roofline"] = None
+    cb = full.get("cpu_baseline")
+    if cb:
+        rec["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "host_cpus", "kind")}
+        rec["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:400]
+    g = full.get("best_cost_gap")
+    if g:
+        rec["best_cost_gap"] = {k: g.get(k) for k in ("gap", "ci95", "gpu_mean_best", "cpu_mean_best", "instances", "iterations")
+                                if k in g}
+    for k in ("speedup_vs_cpu", "gpu_mean_best_cost"):
+        if k in full:
+            rec[k] = full[k]
+    if full.get("sustained"):
+        rec["sustained"] = {k: full["sustained"].get(k) for k in ("seconds", "steps", "value")}
+    if full.get("rccl"):
+        rec["rccl"] = {k: v for k, v in full["rccl"].items() if not isinstance(v, (dict, list))}
+    ex = full.get("extras")
+    if isinstance(ex, dict):
+        # one number per extra configuration; the objects are in the file
+        rec["extras"] = {k: (_r(v.get("value"), 4) if isinstance(v, dict) and "value" in v else
+                             ("error" if isinstance(v, dict) and "error" in v else None)) for k, v in ex.items()
+                         if k != "error"}
+        rec["extras_file"] = "bench_extras.json"
+    rec = _r(rec)
+    txt = json.dumps(rec, allow_nan=False)
+    if len(txt) > HEADLINE_MAX_BYTES:                   # drop the optional parts first; the contract's keys never
+        for k in ("extras", "sustained", "best_cost_gap"):
+            rec.pop(k, None)
+            txt = json.dumps(rec, allow_nan=False)
+            if len(txt) <= HEADLINE_MAX_BYTES:
+                break
+    assert len(txt) <= HEADLINE_MAX_BYTES, f"headline record is {len(txt)} bytes"
+    return txt
+
+
+def _finite(v):
+    """json.dumps would print NaN / Infinity, which strict parsers reject: they become null."""
+    if isinstance(v, float):
+        return v if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _finite(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_finite(x) for x in v]
+    return v
+
+
+def emit(full):
+    """Full record -> bench_extras.json (repo root, and gpurun_out/ when it exists so that it travels back from a GPU box);
+    compact record -> the last stdout line."""
+    full = _finite(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_extras.json"), "w") as f:
+                    json.dump(full, f, indent=1)
+        except OSError as e:
+            log(f"could not write bench_extras.json under {d}: {e}")
+    sys.stderr.flush()
+    print(headline_record(full), flush=True)
+
+
 # ---------------------------------------------------------------------------------------------- launcher
 def launch_ranks(args):
     """`python bench.py --gpus N` without torchrun: start N copies of this script, one per GPU, wired up through
@@ -156,7 +249,9 @@ def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, 
     the HBM-side picture next to it; `pipes`: the counter-measured occupancy of the CU's units for this kernel."""
     name, row = sampler_layout(n, sampler)
     steps = n - 1 if steps_per_tour is None else steps_per_tour
-    row_bytes = B * A * steps * 4.0 * row
+    # the bytes a step NEEDS: the n live floats of its fused row (the kernel streams the padded row, `padded_row_floats`;
+    # the pad is the kernel's own overhead and does not count as achieved bandwidth)
+    row_bytes = B * A * steps * 4.0 * n
     if sampler == "scan_sparse":            # a head step reads 64 / 128 values + ids; the dense steps (counted in the run) a row
         head_row = 384.0 if (head_k or max(1, min(127, n // 10))) <= 63 else 768.0
         name, row_bytes = "scan_sparse_kernel", B * A * steps * head_row
@@ -165,7 +260,7 @@ def roofline_rows(n, A, B, sampler, kern_ms, steps_per_tour=None, traffic=None, 
     compulsory = B * (8.0 * n * n + 8.0 * A * n)
     return {"bound": "l2", "achieved": ach, "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": ach / PEAK_L2_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": name, "kernel_ms": kern_ms, "row_bytes_per_launch": row_bytes,
+            "kernel": name, "kernel_ms": kern_ms, "row_bytes_per_launch": row_bytes, "padded_row_floats": row,
             # valu_busy = SQ_INSTS_VALU x 2 cycles (a wave64 VALU instruction issues over two cycles on gfx950's SIMD-32)
             # / (SIMDs x kernel cycles); ta / td_busy: the CU's vector-memory address and data-return units
             "pipes": pipes, "valu_busy": (pipes or {}).get("valu_busy"),
@@ -262,10 +357,10 @@ def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0):
     tours = sum(r[1] for r in res) * n_ants
     log(f"cpu port: {instances} instances x {done} iterations on {procs} processes x {threads} threads: "
         f"{busy:.1f}s of colony time ({wall:.1f}s with process start-up)")
-    out = {"value": tours / busy, "unit": "ant-tours/s", "cores": procs * threads, "kind": "port",
+    out = {"value": tours / busy, "unit": "ant-tours/s", "cores": procs * threads, "host_cpus": ncpu, "kind": "port",
            "sample": f"{instances} instances x {n_ants} ants x {done} colony iterations of the same TSP-{n} workload "
                      f"(oracle/torch_port.py: the reference's aten op sequence, torch {torch.__version__} CPU), "
-                     f"{procs} processes x {threads} intra-op threads on a {ncpu}-CPU host, {busy:.1f} s",
+                     f"{procs} processes x {threads} intra-op threads = {procs * threads} of the host's {ncpu} CPUs, {busy:.1f} s",
            "one_process_value": n_ants * res[0][1] / res[0][2]}
     return out, [r[0] for r in res], done
 
@@ -992,7 +1087,7 @@ def worker(args):
                                      "gpu_better_or_equal_on": int(sum(float(gb[i]) <= cpu_best[i] for i in range(ni))),
                                      "note": "same instances, equal iterations, independent RNG streams"}
             line["speedup_vs_cpu"] = value / cb["value"]
-        print(json.dumps(line), flush=True)
+        emit(line)
     if distributed:
         dist_pkg.barrier()
         dist_pkg.destroy_process_group()

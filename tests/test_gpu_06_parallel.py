@@ -90,6 +90,7 @@ def _bench_line(*args, env=None):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]               # ONE JSON line, from rank 0
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) <= 4096   # the LAST line, compact
     return json.loads(lines[0])
 
 
