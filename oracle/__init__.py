@@ -20,8 +20,8 @@ ORC_INFEASIBLE = 1
 
 def build(force=False):
     so = os.path.join(_HERE, "libdaco_oracle.so")
-    src = os.path.join(_HERE, "daco_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("daco_oracle.c", "hgs_ls.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libdaco_oracle.so"])
     return so
 
@@ -313,3 +313,63 @@ def pick_move(P, prev, mask, mode="scan", noise=None, seed=0, it=0, ant_gid0=0, 
                              C.c_uint64(it), C.c_uint32(ant_gid0), int(step), _p(actions),
                              _p(logp) if require_prob else None)
     return actions, logp, rc
+
+
+# ---------------------------------------------------------------------------------------------- HGS local search
+def hgs_local_search(positions, matrix, demands, seq, count, capacity=1000.001, demand_scale=1000.0, nb_granular=20, seed=1,
+                     use_swap_star=False, out_len=None, want_stats=False):
+    """One call of the reference's CVRP local search on one solution (oracle/hgs_ls.c: the restatement of
+    HGS-CVRP-main/Program/LocalSearch.cpp as cvrp_nls/swapstar.py:324-346 drives it: demands * 1000, capacity 1000.001).
+    positions [n,2], matrix [n,n], demands [n] float64 (depot first); seq: zero-separated node sequence (a column of
+    `paths`).  Returns (sequence [out_len] int64 as merge_subroutes lays it out, status) -- status 1: HGS would have thrown and
+    the reference keeps its input -- and, with want_stats, (moves, loops, rng draws, pairs evaluated)."""
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    m = np.ascontiguousarray(matrix, dtype=np.float64)
+    n = m.shape[0]
+    xs, ys = np.ascontiguousarray(pos[:, 0]), np.ascontiguousarray(pos[:, 1])
+    dem = np.ascontiguousarray(np.asarray(demands, dtype=np.float64) * demand_scale)
+    s = np.ascontiguousarray(seq, dtype=np.int32)
+    out_len = len(s) + 2 if out_len is None else out_len
+    out = np.zeros(out_len, dtype=np.int32)
+    st = np.zeros(4, dtype=np.int64)
+    f = lib().hgs_local_search
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                  C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rc = f(n, _p(xs), _p(ys), _p(m), _p(dem), float(capacity), _p(s), len(s), int(count), int(nb_granular), int(seed),
+           int(bool(use_swap_star)), _p(out), out_len, _p(st))
+    if rc < 0:
+        raise ValueError("hgs_local_search: bad argument")
+    return (out.astype(np.int64), rc, st.tolist()) if want_stats else (out.astype(np.int64), rc)
+
+
+def hgs_neural_swapstar(positions, distances, heuristic_dist, demands, seq, limit, disturb=10, **kw):
+    """cvrp_nls/aco.py:443-448: search on the distances, `disturb` loops on the heuristic-derived matrix, search again."""
+    L = len(seq) + 2
+    s1, _ = hgs_local_search(positions, distances, demands, seq, limit, out_len=L, **kw)
+    s2, _ = hgs_local_search(positions, heuristic_dist, demands, s1, disturb, out_len=L, **kw)
+    s3, _ = hgs_local_search(positions, distances, demands, s2, limit, out_len=L, **kw)
+    return s3
+
+
+def hgs_correlated(matrix, nb_granular=20):
+    """Params.cpp:80-103: (lists [n, n-1] int32 row i = ascending neighbours of client i, lens [n])."""
+    m = np.ascontiguousarray(matrix, dtype=np.float64)
+    n = m.shape[0]
+    out = np.zeros((n, max(1, n - 1)), dtype=np.int32)
+    ln = np.zeros(n, dtype=np.int32)
+    f = lib().hgs_correlated
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    f(n, _p(m), int(nb_granular), _p(out), _p(ln))
+    return out, ln
+
+
+def hgs_shuffle(v, seed=1, skip_draws=0):
+    """std::shuffle(v, std::minstd_rand(seed) advanced by skip_draws) as libstdc++ does it; returns (shuffled, draws)."""
+    a = np.ascontiguousarray(v, dtype=np.int32).copy()
+    f = lib().hgs_shuffle
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int]
+    d = f(_p(a), len(a), int(seed), int(skip_draws))
+    return a, d

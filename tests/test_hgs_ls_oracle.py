@@ -1,0 +1,147 @@
+"""oracle/hgs_ls.c (the restatement of HGS-CVRP-main/Program/LocalSearch.cpp as cvrp_nls drives it) against the reference's
+own outputs: fixtures g11 (tests/golden/gen_g11_hgs_ls.py: the reference's Python over HGS built from the reference's
+sources), ROUTE FOR ROUTE -- every loop bound, both matrices, the three-stage neural_swapstar, SWAP* off (the reference as
+it runs) and on (as the sources mean it)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "g11_hgs_ls_n*.npz")))
+
+
+def test_fixtures_present():
+    assert len(FILES) >= 4
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
+def test_oracle_reproduces_the_reference_routes(path):
+    z = np.load(path)
+    po, d, hd, de = z["positions"], z["distances"], z["heuristic_dist"], z["demands"]
+    pin = z["paths_in"].astype(np.int64)
+    L, A = pin.shape[0] + 2, pin.shape[1]
+    moved = 0
+    for a in range(A):
+        seq = pin[:, a]
+        for c in (0, 1, 2, 100):
+            out, rc, st = oracle.hgs_local_search(po, d, de, seq, c, out_len=L, want_stats=True)
+            assert rc == 0
+            np.testing.assert_array_equal(out, z[f"paths_as_run_c{c}"][:, a], err_msg=f"ant {a} count {c}")
+            assert st[1] <= c + 1
+            moved += st[0]
+        out, _ = oracle.hgs_local_search(po, hd, de, seq, 10, out_len=L)
+        np.testing.assert_array_equal(out, z["paths_as_run_hd_c10"][:, a])
+        out = oracle.hgs_neural_swapstar(po, d, hd, de, seq, int(z["limit"]))
+        np.testing.assert_array_equal(out, z["paths_as_run_nls"][:, a])
+        for sw in (0, 1):
+            out, _ = oracle.hgs_local_search(po, d, de, seq, 10, out_len=L, use_swap_star=sw)
+            np.testing.assert_array_equal(out, z[f"paths_ss{sw}_c10"][:, a])
+            out, _ = oracle.hgs_local_search(po, hd, de, seq, 10, out_len=L, use_swap_star=sw)
+            np.testing.assert_array_equal(out, z[f"paths_ss{sw}_hd_c10"][:, a])
+    assert moved > 10 * A
+
+
+def test_seed_zero_and_one_are_the_same_stream():
+    """std::minstd_rand::seed(0) stores 1: what the reference's mislaid structure passes as the seed (1) is seed 0's stream."""
+    z = np.load(FILES[0])
+    seq = z["paths_in"][:, 0].astype(np.int64)
+    a, _ = oracle.hgs_local_search(z["positions"], z["distances"], z["demands"], seq, 100, seed=0)
+    b, _ = oracle.hgs_local_search(z["positions"], z["distances"], z["demands"], seq, 100, seed=1)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_shuffle_is_a_permutation_and_counts_its_draws():
+    for n in (0, 1, 2, 3, 20, 21, 100, 101):
+        v, draws = oracle.hgs_shuffle(np.arange(n), seed=1)
+        assert sorted(v.tolist()) == list(range(n))
+        assert draws >= n // 2                  # one draw per pair (+ one for an even count), rejections aside
+    v, _ = oracle.hgs_shuffle(np.arange(10), seed=1)
+    w, _ = oracle.hgs_shuffle(np.arange(10), seed=1, skip_draws=3)
+    assert v.tolist() != w.tolist()
+
+
+def test_infeasible_or_incomplete_input_is_returned_unchanged():
+    """Individual.cpp:68-71 throws; swapstar.py:341-345 then keeps the input routes."""
+    z = np.load(FILES[0])
+    seq = z["paths_in"][:, 0].astype(np.int64)
+    n = z["demands"].shape[0]
+    one_route = np.concatenate(([0], np.arange(1, n), [0]))            # everything in one route: over capacity
+    out, rc = oracle.hgs_local_search(z["positions"], z["distances"], z["demands"], one_route, 10)
+    assert rc == 1 and out[: n].tolist() == one_route[: n].tolist()
+    missing = seq.copy()
+    missing[np.flatnonzero(missing)[0]] = 0                             # a client dropped
+    out, rc = oracle.hgs_local_search(z["positions"], z["distances"], z["demands"], missing, 10)
+    assert rc == 1
+
+
+def test_correlated_vertices_are_symmetric_and_hold_the_nearest():
+    z = np.load(FILES[1])
+    d = z["distances"]
+    n = d.shape[0]
+    lists, lens = oracle.hgs_correlated(d, 20)
+    sets = [set(lists[i, :lens[i]].tolist()) for i in range(n)]
+    assert lens[0] == 0
+    for i in range(1, n):
+        assert lists[i, :lens[i]].tolist() == sorted(sets[i]) and i not in sets[i] and 0 not in sets[i]
+        order = sorted((d[i, j], j) for j in range(1, n) if j != i)[:20]
+        assert {j for _, j in order} <= sets[i]
+        assert all(i in sets[j] for j in sets[i])
+
+
+@pytest.mark.skipif(not (os.path.isdir("/root/reference/cvrp_nls") and
+                         os.path.isfile(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libhgscvrp.so"))),
+                    reason="needs the reference checkout and oracle/_ref (this container only)")
+def test_oracle_against_the_reference_library_live():
+    """Fresh random solutions (not the committed ones) through oracle/_ref/libhgscvrp.so and the restatement."""
+    import ctypes as C
+    import sys
+    import tempfile
+    lib = C.CDLL(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libhgscvrp.so"))
+
+    class FullAP(C.Structure):
+        _fields_ = [("nbGranular", C.c_int), ("mu", C.c_int), ("lambda_", C.c_int), ("nbElite", C.c_int), ("nbClose", C.c_int),
+                    ("nbIterPenaltyManagement", C.c_int), ("targetFeasible", C.c_double), ("penaltyDecrease", C.c_double),
+                    ("penaltyIncrease", C.c_double), ("seed", C.c_int), ("nbIter", C.c_int), ("nbIterTraces", C.c_int),
+                    ("timeLimit", C.c_double), ("useSwapStar", C.c_int)]
+    dp = C.POINTER(C.c_double)
+    lib.local_search.argtypes = [C.c_int, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_char, C.c_int, C.POINTER(FullAP),
+                                 C.c_char, C.c_int, C.c_int]
+    rng = np.random.default_rng(5)
+    for n, sw in ((15, 0), (40, 1), (90, 0), (90, 1)):
+        pos = rng.random((n + 1, 2))
+        d = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+        d[np.arange(n + 1), np.arange(n + 1)] = 1e-10
+        cap = 30 if n < 50 else 50
+        dem = np.concatenate(([0.0], rng.integers(1, 10, n) / cap))
+        for _ in range(4):
+            # a random feasible solution: clients in random order, cut where the load would pass 1
+            routes, cur, load = [], [], 0.0
+            for c in rng.permutation(np.arange(1, n + 1)):
+                if load + dem[c] > 1.0:
+                    routes.append(cur); cur, load = [], 0.0
+                cur.append(int(c)); load += dem[c]
+            routes.append(cur)
+            seq = np.array([v for r in routes for v in [0] + r] + [0])
+            callid = int(rng.integers(1, 2 ** 30))
+            with open(f"/tmp/route-{callid}", "w") as f:
+                for i, r in enumerate(routes):
+                    f.write(f"Route #{i + 1}: " + " ".join(map(str, r)) + "\n")
+            ap = FullAP(20, 25, 40, 4, 5, 100, 0.2, 0.85, 1.2, 1, 20000, 500, 0.0, sw)
+            x, y = np.ascontiguousarray(pos[:, 0]), np.ascontiguousarray(pos[:, 1])
+            m, s, dm = np.ascontiguousarray(d).reshape(-1), np.zeros(n + 1), np.ascontiguousarray(dem * 1000)
+            lib.local_search(n + 1, x.ctypes.data_as(dp), y.ctypes.data_as(dp), m.ctypes.data_as(dp), s.ctypes.data_as(dp),
+                             dm.ctypes.data_as(dp), 1000.001, sys.float_info.max, b'\0', len(routes), C.byref(ap), b'\0',
+                             callid, 100)
+            got = []
+            with open(f"/tmp/swapstar-result-{callid}") as f:
+                for line in f:
+                    if line.startswith("Route"):
+                        got += [0] + list(map(int, line.split(":")[1].split()))
+            os.remove(f"/tmp/swapstar-result-{callid}")
+            os.remove(f"/tmp/route-{callid}")
+            out, rc = oracle.hgs_local_search(pos, d, dem, seq, 100, out_len=len(seq) + 2, use_swap_star=sw)
+            assert rc == 0 and out[: len(got)].tolist() == got and not out[len(got):].any()
