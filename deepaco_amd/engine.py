@@ -7,6 +7,8 @@ paths [B, n, A] int64, log_probs [B, n-1, A] f32, costs [B, A] f32.
 """
 import os
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -652,6 +654,68 @@ def cvrp_local_search_(dist, demand, capacity, paths, max_moves, want_stats=Fals
                                                moves.data_ptr() if want_stats else None)
     _lib.check(rc, "daco_cvrp_local_search")
     return (paths, lens, moves) if want_stats else paths
+
+
+class HgsTables:
+    """What HGS's Params derives from a matrix (Params.cpp:77-103, LocalSearch.cpp:9): per instance the largest entry, the
+    correlated vertices (nb_granular nearest, symmetric) and the shuffled node order -- daco_hgs_prepare's output, built once
+    per matrix and shared by every ant (and iteration, for the distance matrix)."""
+
+    def __init__(self, matrix, nb_granular=20):
+        _require_gpu(matrix)
+        m = matrix if matrix.dim() == 3 else matrix.unsqueeze(0)
+        self.matrix = m if (m.dtype == torch.float64 and m.is_contiguous()) else m.contiguous().double()
+        self.B, self.n = self.matrix.shape[0], self.matrix.shape[-1]
+        self.nb_granular = int(nb_granular)
+        L = _lib.lib()
+        self.table_bytes = L.daco_hgs_table_bytes(self.n, self.nb_granular)
+        dev = self.matrix.device
+        with torch.cuda.device(dev):
+            self.tables = torch.empty(self.B * self.table_bytes, dtype=torch.uint8, device=dev)
+            rc = L.daco_hgs_prepare(_stream(dev), self.B, self.n, self.matrix.data_ptr(), self.n * self.n, self.nb_granular,
+                                    self.tables.data_ptr())
+        _lib.check(rc, "daco_hgs_prepare")
+
+
+def hgs_local_search_(paths, stages, demand, capacity=1000.001, demand_scale=1000.0, want_stats=False):
+    """The reference's CVRP local search on every column of `paths`, route for route (csrc/daco_hgs_ls.hip; cvrp_nls/aco.py:
+    114-126 -> swapstar.py:324-346 -> HGS LocalSearch::run as the reference runs it: moves 1-9, granular, no SWAP*).
+    paths [B,Lmax,A] or [Lmax,A] int64, rewritten in place in merge_subroutes' layout; stages: up to three
+    (HgsTables, count) pairs run one after the other on each solution (neural_swapstar: (dist, limit), (heuristic_dist, 10),
+    (dist, limit)); demand [B,n] or [n] as the colony holds it (scaled by demand_scale = 1000 as swapstar.py:335 does).
+    Returns paths (and status [B,A], stats [B,A,4] = moves, loops, routes, 0)."""
+    _require_gpu(paths)
+    assert paths.dtype == torch.int64 and 1 <= len(stages) <= 3
+    p3 = paths if paths.dim() == 3 else paths.unsqueeze(0)
+    assert p3.is_contiguous()
+    B, Lmax, A = p3.shape
+    t0 = stages[0][0]
+    n, g = t0.n, t0.nb_granular
+    dev = paths.device
+    dem = demand.to(dev).double()
+    if dem.dim() == 1:
+        dem = dem.unsqueeze(0).expand(B, n)
+    dem = (dem * demand_scale).contiguous()
+    S = len(stages)
+    mats = (C.c_void_p * S)(*[st[0].matrix.data_ptr() for st in stages])
+    strides = (C.c_long * S)(*[(0 if st[0].B == 1 and B > 1 else n * n) for st in stages])
+    tabs = (C.c_void_p * S)(*[st[0].tables.data_ptr() for st in stages])
+    counts = (C.c_int * S)(*[int(st[1]) for st in stages])
+    for st in stages:
+        assert st[0].n == n and st[0].nb_granular == g and st[0].B in (1, B)
+        if st[0].B == 1 and B > 1:
+            raise ValueError("hgs_local_search_: one table set per instance is needed (B tables)")
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        wsb = L.daco_hgs_workspace_bytes(B, n, A, Lmax, g)
+        ws = _workspace(dev, wsb, "hgs_ls")
+        status = torch.empty((B, A), dtype=torch.int32, device=dev)
+        stats = torch.empty((B, A, 4), dtype=torch.int32, device=dev) if want_stats else None
+        rc = L.daco_hgs_local_search(_stream(dev), B, n, A, Lmax, S, mats, strides, tabs, counts, dem.data_ptr(), float(capacity), g,
+                                     p3.data_ptr(), status.data_ptr(), stats.data_ptr() if want_stats else None,
+                                     ws.data_ptr(), ws.numel())
+    _lib.check(rc, "daco_hgs_local_search")
+    return (paths, status, stats) if want_stats else paths
 
 
 @torch.no_grad()

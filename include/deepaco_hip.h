@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 123 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count) */
+#define DACO_VERSION 124 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count) */
 
 /* error codes */
 #define DACO_OK 0
@@ -483,6 +483,47 @@ int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const 
 int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lmax, const float *dist, long dist_bstride,
                            const float *demand, float capacity, int64_t *paths, int max_moves, int32_t *lens,
                            int32_t *moves);
+
+/* ---------------------------------------------------------------------------------------------
+ * daco_hgs_prepare / daco_hgs_local_search -- the reference's CVRP local search, ROUTE FOR ROUTE
+ *   replaces cvrp_nls/aco.py:114-126 (multiple_swap_star: one swapstar() call per ant through a thread pool),
+ *   cvrp_nls/swapstar.py:324-346 (the HGS set-up: demands * 1000, capacity 1000.001, num_vehicles = number of routes),
+ *   swapstar.py:187-271 (/tmp-file hand-over) and the entry it binds, HGS-CVRP-main/Program/C_Interface.cpp:128-172
+ *   `local_search` -> LocalSearch::run (LocalSearch.cpp:3-103): moves 1-9 (LocalSearch.cpp:134-484) under the
+ *   nbGranular-nearest restriction (Params.cpp:77-103), first improvement in the order std::shuffle(std::minstd_rand)
+ *   fixes (libstdc++), load penalty 10 * max(0.1, min(1000, maxDist / maxDemand)), float64 throughout.
+ *   The reference's ctypes structure (swapstar.py:62-74) is 10 fields of the header's 15 (AlgorithmParameters.h:10-28):
+ *   HGS reads useSwapStar beyond it, so the reference RUNS WITHOUT SWAP* and with zero coordinates (Params.cpp:40-54;
+ *   the export order of LocalSearch.cpp:756-778 is then the route index order).  That is what these entries compute: the
+ *   reference's routes entry for entry (oracle/hgs_ls.c use_swap_star = 0; fixtures tests/golden/g11_*).
+ *
+ * daco_hgs_prepare: per instance and matrix, what Params derives from the matrix alone: maxDist, the correlated vertices
+ *   (nb_granular nearest by (cost, index), made symmetric, ascending), the shuffled node order of LocalSearch.cpp:9 and the
+ *   generator state behind it.
+ *   matrix  [B][n][n] f64 (bstride elements between instances); node 0 is the depot
+ *   tables  out, B * daco_hgs_table_bytes(n, nb_granular) bytes
+ * daco_hgs_local_search: nstages (1..3) calls of `local_search` in a row on every solution (cvrp_nls/aco.py:443-448
+ *   neural_swapstar is three: distances / limit, heuristic-derived matrix / 10, distances / limit), the routes of a stage
+ *   handed to the next as the reference's files do (non-empty routes, in export order).
+ *   matrices[s], bstrides[s], tables[s], counts[s]   stage s: its matrix [B][n][n] f64, the tables daco_hgs_prepare made
+ *            of it, and `count` (the loop bound of LocalSearch.cpp:17)
+ *   demand   [B][n] f64 AS HGS GETS THEM (the caller multiplies by 1000, swapstar.py:335), demand[.][0] = 0
+ *   capacity 1000.001 in the reference (swapstar.py:337)
+ *   paths    in/out [B][Lmax][A] int64: column (b, a) is a zero-separated route sequence (cvrp/aco.py:138-165); rewritten
+ *            as cvrp_nls/aco.py:22-33 merge_subroutes lays the result out ("0 c1 .. ck" per route, zero padded)
+ *   status   out [B][A] int32 or NULL: 0 searched; 1 a stage was skipped because HGS throws there (distances or demands
+ *            out of scale Params.cpp:106-111, fleet too small :112, infeasible input Individual.cpp:70) -- the reference
+ *            then keeps that stage's input (swapstar.py:341-345); 2 the column is not a complete solution (left untouched)
+ *   stats    out [B][A][4] int32 or NULL: moves applied, loops run, routes, 0
+ *   workspace daco_hgs_workspace_bytes(B, n, A, Lmax, nb_granular) bytes
+ */
+size_t daco_hgs_table_bytes(int n, int nb_granular);
+int daco_hgs_prepare(void *stream, int B, int n, const double *matrix, long bstride, int nb_granular, void *tables);
+size_t daco_hgs_workspace_bytes(int B, int n, int A, int Lmax, int nb_granular);
+int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax, int nstages, const double *const *matrices,
+                          const long *bstrides, const void *const *tables, const int *counts, const double *demand,
+                          double capacity, int nb_granular, int64_t *paths, int32_t *status, int32_t *stats,
+                          void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_tsp_knn_graph -- replaces gen_distance_matrix + gen_pyg_data for a batch of instances

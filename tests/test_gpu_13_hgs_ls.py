@@ -1,0 +1,190 @@
+"""GPU tests of the route-exact CVRP local search (daco_hgs_prepare / daco_hgs_local_search, csrc/daco_hgs_ls.hip).
+
+The reference: cvrp_nls/aco.py:114-126 -> swapstar.py:324-346 -> HGS-CVRP-main/Program/LocalSearch.cpp.  Parity is ROUTE FOR
+ROUTE: (a) fixtures g11 = the reference's own outputs (its Python over HGS built from its sources) for every loop bound,
+both matrices and the three-stage neural_swapstar; (b) the oracle (oracle/hgs_ls.c, itself pinned on the reference's
+library) on fresh random solutions at sizes up to BASELINE's configuration 4 (CVRP-100, 512 ants)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+FILES = sorted(glob.glob(os.path.join(GOLDEN, "g11_hgs_ls_n*.npz")))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def run(paths_in, stages, demands, Lpad=2, want_stats=False):
+    from deepaco_amd import engine
+    pin = torch.as_tensor(np.asarray(paths_in, dtype=np.int64))
+    if pin.dim() == 2:
+        pin = pin[None]
+    B, L, A = pin.shape
+    p = torch.zeros((B, L + Lpad, A), dtype=torch.int64)
+    p[:, :L] = pin
+    p = p.to(dev()).contiguous()
+    out = engine.hgs_local_search_(p, stages, torch.as_tensor(demands).to(dev()), want_stats=want_stats)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
+def test_fixtures_route_for_route(path):
+    from deepaco_amd import engine
+    z = np.load(path)
+    td = engine.HgsTables(torch.as_tensor(z["distances"]).to(dev()))
+    th = engine.HgsTables(torch.as_tensor(z["heuristic_dist"]).to(dev()))
+    for c in (0, 1, 2, 100):
+        out = run(z["paths_in"], [(td, c)], z["demands"])
+        np.testing.assert_array_equal(out[0].cpu().numpy(), z[f"paths_as_run_c{c}"].astype(np.int64), err_msg=f"count {c}")
+    out = run(z["paths_in"], [(th, 10)], z["demands"])
+    np.testing.assert_array_equal(out[0].cpu().numpy(), z["paths_as_run_hd_c10"].astype(np.int64))
+    lim = int(z["limit"])
+    out, status, stats = run(z["paths_in"], [(td, lim), (th, 10), (td, lim)], z["demands"], want_stats=True)
+    np.testing.assert_array_equal(out[0].cpu().numpy(), z["paths_as_run_nls"].astype(np.int64))
+    assert int(status.abs().sum()) == 0 and int(stats[..., 0].min()) > 0
+
+
+def test_tables_equal_the_oracles_correlated_vertices():
+    from deepaco_amd import engine
+    z = np.load(FILES[2])
+    for key in ("distances", "heuristic_dist"):
+        m = z[key]
+        n = m.shape[0]
+        t = engine.HgsTables(torch.as_tensor(m).to(dev()))
+        torch.cuda.synchronize()
+        raw = t.tables.cpu().numpy()
+        lists, lens = oracle.hgs_correlated(m, 20)
+        a16 = lambda x: (x + 15) & ~15
+        o_order = 64
+        o_len = o_order + a16(2 * (n - 1))
+        o_off = o_len + a16(2 * n)
+        o_ent = o_off + a16(4 * n)
+        assert raw[:8].view(np.float64)[0] == m.max()
+        glen = raw[o_len:o_len + 2 * n].view(np.uint16)
+        goff = raw[o_off:o_off + 4 * n].view(np.uint32)
+        np.testing.assert_array_equal(glen, lens.astype(np.uint16))
+        for i in range(1, n):
+            e = raw[o_ent + 2 * goff[i]: o_ent + 2 * (goff[i] + glen[i])].view(np.uint16)
+            np.testing.assert_array_equal(e, lists[i, :lens[i]].astype(np.uint16))
+        order = raw[o_order:o_order + 2 * (n - 1)].view(np.uint16)
+        nc = n - 1
+        _, d1 = oracle.hgs_shuffle(np.arange(nc), seed=1)                          # the draws of Individual's own shuffle
+        want, _ = oracle.hgs_shuffle(np.arange(1, nc + 1), seed=1, skip_draws=d1)
+        np.testing.assert_array_equal(order, want.astype(np.uint16))
+
+
+def random_solutions(rng, n, cap, A):
+    pos = rng.random((n + 1, 2))
+    d = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+    d[np.arange(n + 1), np.arange(n + 1)] = 1e-10
+    dem = np.concatenate(([0.0], rng.integers(1, 10, n) / cap))
+    cols = []
+    for _ in range(A):
+        seq, load = [0], 0.0
+        for c in rng.permutation(np.arange(1, n + 1)):
+            if load + dem[c] > 1.0:
+                seq.append(0); load = 0.0
+            seq.append(int(c)); load += dem[c]
+        cols.append(seq + [0])
+    L = max(map(len, cols))
+    paths = np.zeros((L, A), dtype=np.int64)
+    for a, s in enumerate(cols):
+        paths[:len(s), a] = s
+    return pos, d, dem, paths
+
+
+@pytest.mark.parametrize("n,cap,A,count", [(12, 20, 64, 100), (33, 30, 64, 3), (100, 50, 96, 100), (150, 50, 24, 100)])
+def test_random_solutions_against_the_oracle(n, cap, A, count):
+    """Random (far from optimal) solutions: hundreds of moves each, empty routes appear and are used."""
+    from deepaco_amd import engine
+    rng = np.random.default_rng(n)
+    pos, d, dem, paths = random_solutions(rng, n, cap, A)
+    hd = 1 / ((1 / d) / (1 / d).max(-1, keepdims=True) * (0.3 + rng.random(d.shape)) + 1e-5)
+    td = engine.HgsTables(torch.as_tensor(d).to(dev()))
+    th = engine.HgsTables(torch.as_tensor(hd).to(dev()))
+    L = paths.shape[0] + 2
+    out, status, stats = run(paths, [(td, count)], dem, want_stats=True)
+    got = out[0].cpu().numpy()
+    moves = 0
+    for a in range(A):
+        want, rc, st = oracle.hgs_local_search(pos, d, dem, paths[:, a], count, out_len=L, want_stats=True)
+        np.testing.assert_array_equal(got[:, a], want, err_msg=f"ant {a}")
+        assert int(stats[0, a, 0]) == st[0] and int(stats[0, a, 1]) == st[1]
+        moves += st[0]
+    assert moves > 5 * A
+    out = run(paths, [(td, count), (th, 10), (td, count)], dem)
+    got = out[0].cpu().numpy()
+    for a in range(0, A, 3):
+        want = oracle.hgs_neural_swapstar(pos, d, hd, dem, paths[:, a], count)
+        np.testing.assert_array_equal(got[:, a], want, err_msg=f"nls ant {a}")
+
+
+def test_batch_of_instances_and_config4_shape():
+    """B instances side by side at BASELINE configuration 4's colony size (CVRP-100, 512 ants): instances 0 and B-1 ant for
+    ant against the oracle (sampled ants), every column a complete solution."""
+    from deepaco_amd import engine
+    B, n, A = 6, 100, 512
+    rng = np.random.default_rng(7)
+    inst = [random_solutions(rng, n, 50, A) for _ in range(B)]
+    L = max(i[3].shape[0] for i in inst) + 2
+    paths = np.zeros((B, L, A), dtype=np.int64)
+    for b, i in enumerate(inst):
+        paths[b, :i[3].shape[0]] = i[3]
+    d = torch.as_tensor(np.stack([i[1] for i in inst])).to(dev())
+    dem = torch.as_tensor(np.stack([i[2] for i in inst])).to(dev())
+    td = engine.HgsTables(d)
+    p = torch.as_tensor(paths).to(dev()).contiguous()
+    out, status, stats = engine.hgs_local_search_(p, [(td, 100)], dem, want_stats=True)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert int(status.abs().sum()) == 0
+    for b in (0, B - 1):
+        pos, dd, de, pin = inst[b]
+        for a in list(range(0, A, 37)) + [A - 1]:
+            want, _ = oracle.hgs_local_search(pos, dd, de, pin[:, a], 100, out_len=L)
+            np.testing.assert_array_equal(got[b, :, a], want, err_msg=f"instance {b} ant {a}")
+    srt = np.sort(got, axis=1)
+    assert (srt[:, -n:, :] == np.arange(1, n + 1)[None, :, None]).all()
+
+
+def test_stage_that_hgs_refuses_keeps_its_input():
+    """A matrix beyond HGS's scale check (Params.cpp:106-108) throws there; the reference keeps the routes (swapstar.py:341-345)."""
+    from deepaco_amd import engine
+    rng = np.random.default_rng(3)
+    pos, d, dem, paths = random_solutions(rng, 30, 30, 16)
+    big = engine.HgsTables(torch.as_tensor(d * 1e6).to(dev()))
+    td = engine.HgsTables(torch.as_tensor(d).to(dev()))
+    out, status, _ = run(paths, [(big, 10)], dem, want_stats=True)
+    assert int(status.min()) == 1
+    L = paths.shape[0] + 2
+    for a in range(16):
+        want, rc = oracle.hgs_local_search(pos, d * 1e6, dem, paths[:, a], 10, out_len=L)
+        assert rc == 1
+        np.testing.assert_array_equal(out[0, :, a].cpu().numpy(), want)
+    out, status, _ = run(paths, [(td, 5), (big, 10), (td, 5)], dem, want_stats=True)
+    for a in range(16):
+        s1, _ = oracle.hgs_local_search(pos, d, dem, paths[:, a], 5, out_len=L)
+        s3, _ = oracle.hgs_local_search(pos, d, dem, s1, 5, out_len=L)
+        np.testing.assert_array_equal(out[0, :, a].cpu().numpy(), s3)
+
+
+def test_incomplete_column_is_left_untouched():
+    from deepaco_amd import engine
+    rng = np.random.default_rng(4)
+    pos, d, dem, paths = random_solutions(rng, 20, 30, 8)
+    bad = paths.copy()
+    bad[np.flatnonzero(bad[:, 3])[0], 3] = 0                       # ant 3 loses a client
+    td = engine.HgsTables(torch.as_tensor(d).to(dev()))
+    out, status, _ = run(bad, [(td, 10)], dem, want_stats=True)
+    assert status[0].tolist() == [0, 0, 0, 2, 0, 0, 0, 0]
+    np.testing.assert_array_equal(out[0, :bad.shape[0], 3].cpu().numpy(), bad[:, 3])
