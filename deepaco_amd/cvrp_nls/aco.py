@@ -9,14 +9,15 @@ tests/golden/gen_g1_cvrp_nls.py) is float64 as in the reference whenever `demand
 `(costs, log_probs, paths)` as in cvrp_nls/aco.py:100-104.
 
 Local search (`swapstar=True`; cvrp_nls/aco.py:106-128, 443-448).  The reference hands every ant's routes to the
-vendored HGS-CVRP C++ (one thread-pool task per ant, /tmp files, ctypes).  Here `multiple_swap_star` improves all
-selected ants in ONE launch per stage of daco_cvrp_local_search (csrc/daco_cvrp_ls.hip: best improvement over HGS's move
-families 1-9 -- relocate 1 / 2 / 2 reversed, swap 1-1 / 2-1 / 2-2, 2-opt, 2-opt* both ways -- and SWAP*, with hard capacity) and
-keeps the reference's three-stage schedule `neural_swapstar`: search on the distances, `disturb` = 10 moves on the
-heuristic-derived matrix, search on the distances again.  HGS's own LocalSearch (first improvement in a shuffled order,
-load penalties) is not reproduced move for move; parity is pinned on cost: on solutions sampled by the reference
-the schedule reaches 0.986-0.999 of the mean cost of the reference's own neural_swapstar (gate: not more than 0.5 % above; tests/golden/g8_*,
-tests/test_gpu_09_cvrp_ls.py), every result feasible, never worse than its input, a local optimum of the move set.
+vendored HGS-CVRP C++ (one thread-pool task per ant, /tmp files, ctypes): `neural_swapstar` = LocalSearch::run on the
+distances, 10 loops on the heuristic-derived matrix, LocalSearch::run on the distances again.  Here `multiple_swap_star`
+improves all selected ants in ONE launch of daco_hgs_local_search (csrc/daco_hgs_ls.hip) that reproduces those three calls
+ROUTE FOR ROUTE: moves 1-9 under the 20-nearest granular restriction, first improvement in the order libstdc++'s
+std::shuffle over std::minstd_rand fixes, penalised loads, float64 -- and no SWAP*, because the reference's ctypes structure
+(swapstar.py:62-74: 10 fields of AlgorithmParameters.h's 15) makes HGS read useSwapStar beyond it (tests/golden/
+gen_g11_hgs_ls.py asserts that on every solution).  Pinned on the reference's own outputs: fixtures g8 / g11
+(tests/test_gpu_09_cvrp_ls.py, tests/test_gpu_13_hgs_ls.py).  `local_search="best_improvement"` selects round 3's
+deterministic best-improvement kernel instead (daco_cvrp_local_search: moves 1-9 + SWAP*, hard capacity; cost-pinned only).
 """
 import os
 import sys
@@ -59,7 +60,7 @@ class ACO(_CvrpACO):
 
     def __init__(self, distances, demand, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
                  pheromone=None, heuristic=None, min=None, device='cpu', adaptive=False, capacity=CAPACITY,
-                 swapstar=False, positions=None, inference=False, *, sampler='scan', seed=None):
+                 swapstar=False, positions=None, inference=False, *, sampler='scan', seed=None, local_search='hgs'):
         # demand keeps its dtype: float64 demands (cvrp_nls/utils.py:12-26) select the float64 load bookkeeping of the
         # sampler (cvrp_nls/aco.py:254-272 runs it in double; with demands k / capacity the last bit decides exact fits)
         super().__init__(distances.float(), demand, n_ants, decay, alpha, beta, elitist, min_max,
@@ -67,7 +68,16 @@ class ACO(_CvrpACO):
                          None if heuristic is None else heuristic.float(), min, device, adaptive, float(capacity),
                          sampler=sampler, seed=seed)
         self.swapstar, self.positions, self.inference = swapstar, positions, inference
+        assert positions is not None if swapstar else True                      # cvrp_nls/aco.py:73
+        assert local_search in ('hgs', 'best_improvement')
+        self.local_search = local_search
         self._heuristic_dist = None
+        # the local search works on the caller's own numbers (the reference hands HGS distances_cpu / heuristic_dist in the
+        # dtype they came in, float64 from cvrp_nls/utils.py): kept next to the float32 copies the sampler uses
+        self._dist_src = engine.stage_to_hip(distances.detach(), like=self.distances)
+        self._heu_src = None if heuristic is None else engine.stage_to_hip(heuristic.detach(), like=self.distances)
+        self._demand_src = engine.stage_to_hip(demand.detach(), like=self.distances)
+        self._hgs = None
 
     def sample(self, inference=False):
         paths, log_probs = self.gen_path(require_prob=True)
@@ -90,19 +100,34 @@ class ACO(_CvrpACO):
             self._heuristic_dist = (1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)).contiguous()
         return self._heuristic_dist
 
+    def _hgs_stage_tables(self):
+        """(tables of the distances, tables of the heuristic-derived matrix): what HGS's Params derives from a matrix, once per
+        colony.  The perturbation matrix is cvrp_nls/aco.py:128-132 in the heuristic's own dtype (numpy there, torch here:
+        the same IEEE divisions), the default heuristic 1 / distances (cvrp_nls/aco.py:92)."""
+        if self._hgs is None:
+            heu = self._heu_src if self._heu_src is not None else 1 / self._dist_src
+            hd = 1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)
+            self._hgs = (engine.HgsTables(self._dist_src), engine.HgsTables(hd))
+        return self._hgs
+
     # ------------------------------------------------------------------ cvrp_nls/aco.py:114-126, 443-448
     @torch.no_grad()
     def multiple_swap_star(self, paths, indexes=None, disturb=10):
-        """Improve the ants' solutions (all, or the columns `indexes`) in place and return `paths` ([L, A] int64).
-        The reference's `count` (cvrp_nls/aco.py:443-448: limit / disturb / limit) bounds LOOPS of HGS's LocalSearch::run
-        (LocalSearch.cpp:17: up to count + 1 passes over all nodes, each applying many moves), not moves: the searches on
-        the distances run until no move improves, the perturbation on the heuristic-derived matrix applies `disturb` moves."""
-        limit = 100000
+        """Improve the ants' solutions (all, or the columns `indexes`) in place and return `paths` ([L, A] int64):
+        neural_swapstar (cvrp_nls/aco.py:443-448) on every selected column, limit = 100000 with `inference`, else
+        max(problem_size, 50) (cvrp_nls/aco.py:123) -- the loop bound of LocalSearch::run (LocalSearch.cpp:17)."""
         sel = paths if indexes is None else paths[:, indexes]
         work = sel.contiguous().unsqueeze(0).clone()
-        dist = self.distances.detach().float().contiguous()
-        for matrix, count in ((dist, limit), (self.heuristic_dist, disturb), (dist, limit)):
-            engine.cvrp_local_search_(matrix, self.demand, self.capacity, work, count)
+        if self.local_search == 'hgs':
+            limit = 100000 if self.inference else max(self.problem_size, 50)
+            td, th = self._hgs_stage_tables()
+            engine.hgs_local_search_(work, [(td, limit), (th, disturb), (td, limit)], self._demand_src,
+                                     capacity=1000.001 * self.capacity, demand_scale=1000.0)
+        else:
+            # best improvement to convergence / `disturb` moves on the perturbation matrix / to convergence
+            dist = self.distances.detach().float().contiguous()
+            for matrix, count in ((dist, 100000), (self.heuristic_dist, disturb), (dist, 100000)):
+                engine.cvrp_local_search_(matrix, self.demand, self.capacity, work, count)
         if indexes is None:
             paths.copy_(work[0])
         else:

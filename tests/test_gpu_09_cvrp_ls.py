@@ -121,7 +121,10 @@ def test_cvrp_nls_class_surface():
     d, dem, _ = instance(30, 77)
     dem = dem / 30.0                                       # cvrp_nls normalises demands, capacity 1.0
     heu = (1 / d).to(dev()).requires_grad_(True)
-    aco = ACO(d.to(dev()), dem.to(dev()), n_ants=12, heuristic=heu, device="cuda:0", swapstar=True, seed=5)
+    with pytest.raises(AssertionError):                    # cvrp_nls/aco.py:73: swapstar needs the positions
+        ACO(d.to(dev()), dem.to(dev()), n_ants=12, heuristic=heu, device="cuda:0", swapstar=True, seed=5)
+    aco = ACO(d.to(dev()), dem.to(dev()), n_ants=12, heuristic=heu, device="cuda:0", swapstar=True, seed=5,
+              positions=torch.rand(31, 2))
     costs, log_probs, costs_raw = aco.sample_nls()
     assert costs.shape == costs_raw.shape == (12,) and bool((costs <= costs_raw + 1e-5).all()) and log_probs.requires_grad
     paths = aco.gen_path()
@@ -145,10 +148,62 @@ def test_cvrp_nls_class_surface():
 
 
 @pytest.mark.parametrize("n", [20, 50, 100])
+def test_class_reproduces_the_reference_routes(n):
+    """g8: solutions sampled by the reference's ACO and improved by the reference's neural_swapstar (its Python over HGS built
+    from its sources).  The drop-in's multiple_swap_star (default local_search='hgs') on the same sampled solutions returns
+    THE SAME `paths`, entry for entry -- and swapstar(count = 10 / 100)'s through one-stage calls."""
+    from deepaco_amd import engine
+    from deepaco_amd.cvrp_nls.aco import ACO
+    g = np.load(os.path.join(GOLDEN, f"g8_cvrp_ls_n{n}.npz"))
+    A = g["paths_in"].shape[1]
+    aco = ACO(torch.from_numpy(g["distances"]).to(dev()), torch.from_numpy(g["demands"]).to(dev()), n_ants=A,
+              heuristic=torch.from_numpy(g["heuristic"]).to(dev()), device="cuda:0", swapstar=True,
+              positions=torch.from_numpy(g["positions"]))
+    assert int(g["limit"]) == max(aco.problem_size, 50)
+    paths = torch.from_numpy(g["paths_in"]).to(dev())
+    out = aco.multiple_swap_star(paths.clone())
+    np.testing.assert_array_equal(out.cpu().numpy(), g["paths_nls"])
+    c64 = np.array([ols.route_cost(ols.compress(out[:, a].cpu().tolist()), g["distances"]) for a in range(A)])
+    np.testing.assert_allclose(c64, g["costs_nls"], rtol=1e-12)
+    td, _ = aco._hgs_stage_tables()
+    for cnt in (10, 100):
+        one = engine.hgs_local_search_(paths.clone().unsqueeze(0).contiguous(), [(td, cnt)], torch.from_numpy(g["demands"]).to(dev()))
+        np.testing.assert_array_equal(one[0].cpu().numpy(), g[f"paths_ls{cnt}"])
+    # only some columns (cvrp_nls/aco.py:143-146: the best 8 of an iteration)
+    idx = torch.tensor([3, 0, A - 1], device=dev())
+    part = aco.multiple_swap_star(paths.clone(), indexes=idx).cpu().numpy()
+    keep = np.ones(A, dtype=bool); keep[idx.cpu().numpy()] = False
+    np.testing.assert_array_equal(part[:, ~keep], g["paths_nls"][:, ~keep])
+    np.testing.assert_array_equal(part[:, keep], g["paths_in"][:, keep])
+
+
+@pytest.mark.parametrize("n", [20, 50, 100, 200, 500])
+def test_class_reproduces_the_reference_costs_on_many_instances(n):
+    """g8b: 36 instances at n = 20 ... 500, eight sampled solutions each; the reference's neural_swapstar under the training
+    (limit = max(n, 50)) and inference (limit = 100000 there, 10000 in the fixture's call) schedules.  The route-exact local
+    search reaches the reference's float64 cost on every one of the 288 solutions (the fixture holds costs, not routes)."""
+    from deepaco_amd.cvrp_nls.aco import ACO
+    g = np.load(os.path.join(GOLDEN, "g8b_cvrp_ls_many.npz"))
+    pos, dem, paths_in = g[f"n{n}_positions"], g[f"n{n}_demands"], g[f"n{n}_paths_in"]
+    for i in range(pos.shape[0]):
+        p = torch.from_numpy(pos[i])
+        d = torch.norm(p[:, None] - p, dim=2, p=2, dtype=torch.double)      # cvrp_nls/utils.py:32-36
+        d[torch.arange(n + 1), torch.arange(n + 1)] = 1e-10
+        A = paths_in.shape[2]
+        for inference, key in ((False, "costs_nls"), (True, "costs_nls_inf")):
+            aco = ACO(d.to(dev()), torch.from_numpy(dem[i]).to(dev()), n_ants=A, heuristic=(1.0 / d).to(dev()), device="cuda:0",
+                      swapstar=True, positions=p, inference=inference)
+            out = aco.multiple_swap_star(torch.from_numpy(paths_in[i].astype(np.int64)).to(dev()))
+            c = np.array([ols.route_cost(ols.compress(out[:, a].cpu().tolist()), d.numpy()) for a in range(A)])
+            np.testing.assert_allclose(c, g[f"n{n}_{key}"][i], rtol=1e-12, err_msg=f"instance {i} inference {inference}")
+
+
+@pytest.mark.parametrize("n", [20, 50, 100])
 def test_local_search_reaches_the_reference_cost(n):
     """g8 (tests/golden/gen_g8_cvrp_ls.py): solutions sampled by the reference's ACO and improved by the reference's
     neural_swapstar (HGS LocalSearch: search on the distances, 10 loops on the heuristic-derived matrix, search again).
-    The drop-in's multiple_swap_star on the same sampled solutions: every result feasible, none worse than its input, and the
+    The drop-in's multiple_swap_star with local_search="best_improvement" (round 3's kernel, kept as an option) on the same
+    sampled solutions: every result feasible, none worse than its input, and the
     mean cost not more than 0.5 % above the reference's (measured on 24 / 24 / 16 solutions: ratio 0.9857 / 0.9985 / 0.9867 --
     best improvement over moves 1-9 and SWAP* with hard capacity against HGS's penalised first-improvement search; without
     SWAP* it was 0.9989 / 1.0004 / 0.9972; the sampled solutions are 2.5 x as long)."""
@@ -158,7 +213,7 @@ def test_local_search_reaches_the_reference_cost(n):
     A = g["paths_in"].shape[1]
     aco = ACO(torch.from_numpy(dist64).to(dev()), torch.from_numpy(dem).to(dev()), n_ants=A,
               heuristic=torch.from_numpy(g["heuristic"]).to(dev()), device="cuda:0", swapstar=True,
-              positions=torch.from_numpy(g["positions"]))
+              positions=torch.from_numpy(g["positions"]), local_search="best_improvement")
     np.testing.assert_allclose(aco.heuristic_dist.cpu().numpy(), g["heuristic_dist"], rtol=2e-6)
     paths = torch.from_numpy(g["paths_in"]).to(dev())
     out = aco.multiple_swap_star(paths.clone())
@@ -196,7 +251,7 @@ def test_local_search_cost_distribution_on_many_instances(n):
         d[torch.arange(n + 1), torch.arange(n + 1)] = 1e-10
         A = paths_in.shape[2]
         aco = ACO(d.to(dev()), torch.from_numpy(dem[i]).to(dev()), n_ants=A, heuristic=(1.0 / d).to(dev()), device="cuda:0",
-                  swapstar=True, positions=p)
+                  swapstar=True, positions=p, local_search="best_improvement")
         out = aco.multiple_swap_star(torch.from_numpy(paths_in[i].astype(np.int64)).to(dev()))
         for a in range(A):
             s = ols.compress(out[:, a].cpu().tolist())
