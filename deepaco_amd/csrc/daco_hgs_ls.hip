@@ -181,11 +181,12 @@ struct HgsLds {
   int32_t *whenRI;                         // [n]
   int32_t *rowptr;                         // [n]  >= 0: offset in the table's entries, < 0: -(1 + offset) in the wave's scratch
   double *rLoad, *rPen, *rRev;             // [Rmax]
+  uint8_t *e2;                             // [n]  move of a node towards the empty route (valid while no move is applied)
   int32_t *rWhen, *rCnt;                   // [Rmax]
 };
 __host__ __device__ inline size_t hgs_lds_bytes(int n, int Rmax) {
   const size_t N = (size_t)n + 2 * Rmax;
-  return a16(2 * N) * 4 + a16(8 * N) * 2 + a16(4 * (size_t)n) * 2 + a16(8 * (size_t)Rmax) * 3 + a16(4 * (size_t)Rmax) * 2;
+  return a16(2 * N) * 4 + a16(8 * N) * 2 + a16(4 * (size_t)n) * 2 + a16(8 * (size_t)Rmax) * 3 + a16(4 * (size_t)Rmax) * 2 + a16((size_t)n);
 }
 __device__ inline HgsLds hgs_carve(unsigned char *p, int n, int Rmax) {
   const size_t N = (size_t)n + 2 * Rmax;
@@ -202,7 +203,8 @@ __device__ inline HgsLds hgs_carve(unsigned char *p, int n, int Rmax) {
   l.next = (uint16_t *)p; p += a16(2 * N);
   l.prev = (uint16_t *)p; p += a16(2 * N);
   l.route = (uint16_t *)p; p += a16(2 * N);
-  l.pos = (uint16_t *)p;
+  l.pos = (uint16_t *)p; p += a16(2 * N);
+  l.e2 = (uint8_t *)p;
   return l;
 }
 
@@ -273,15 +275,37 @@ struct USide {
   double loadU, loadX, penU, loadRU, cumLoadU, cumRevX, revDistU;
   double dUpU, dUX, dXXn, dUpX, dUpXn, dXU;
 };
+__device__ inline double uni_d(double v) {
+  const uint64_t w = __double_as_longlong(v);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)w), hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+  return __longlong_as_double(((uint64_t)hi << 32) | lo);
+}
+// UNIFORM: U is the same in every lane: the values are moved to scalar registers (40 vector registers less).  Measured at
+// CVRP-100 x 512 x 256: not a gain -- the scalar file overflows into v_readlane / v_writelane traffic (three wavefronts per
+// SIMD: 309 k solutions/s against 379 k with the values in vector registers; four with 49 spilled registers: 374 k) -- so the
+// search loop instantiates <false>
+template <bool UNIFORM>
 __device__ inline void hgs_set_u(const HgsCtx &c, int U, USide &u) {
   u.U = U; u.X = c.l.next[U]; u.prevU = c.l.prev[U]; u.nextX = c.l.next[u.X];
+  u.rU = c.l.route[U]; u.posU = c.l.pos[U];
+  if (UNIFORM) {
+    u.X = __builtin_amdgcn_readfirstlane(u.X); u.prevU = __builtin_amdgcn_readfirstlane(u.prevU);
+    u.nextX = __builtin_amdgcn_readfirstlane(u.nextX); u.rU = __builtin_amdgcn_readfirstlane(u.rU);
+    u.posU = __builtin_amdgcn_readfirstlane(u.posU);
+  }
   u.iU = U; u.iX = c.cour(u.X); u.Up = c.cour(u.prevU); u.Xn = c.cour(u.nextX);
-  u.rU = c.l.route[U]; u.posU = c.l.pos[U]; u.xDep = c.isdep(u.X);
+  u.xDep = c.isdep(u.X);
   u.loadU = c.dem[u.iU]; u.loadX = c.dem[u.iX];
   u.penU = c.l.rPen[u.rU]; u.loadRU = c.l.rLoad[u.rU]; u.revDistU = c.l.rRev[u.rU];
   u.cumLoadU = c.l.cumLoad[U]; u.cumRevX = c.l.cumRev[u.X];
   u.dUpU = c.TC(u.Up, u.iU); u.dUX = c.TC(u.iU, u.iX); u.dXXn = c.TC(u.iX, u.Xn);
   u.dUpX = c.TC(u.Up, u.iX); u.dUpXn = c.TC(u.Up, u.Xn); u.dXU = c.TC(u.iX, u.iU);
+  if (UNIFORM) {
+    u.loadU = uni_d(u.loadU); u.loadX = uni_d(u.loadX); u.penU = uni_d(u.penU); u.loadRU = uni_d(u.loadRU);
+    u.revDistU = uni_d(u.revDistU); u.cumLoadU = uni_d(u.cumLoadU); u.cumRevX = uni_d(u.cumRevX);
+    u.dUpU = uni_d(u.dUpU); u.dUX = uni_d(u.dUX); u.dXXn = uni_d(u.dXXn); u.dUpX = uni_d(u.dUpX); u.dUpXn = uni_d(u.dUpXn);
+    u.dXU = uni_d(u.dXU);
+  }
 }
 
 // First move of the reference's sequence that applies to (U, V), 0 if none.  block 0: LocalSearch.cpp:36-44 (moves 1-9),
@@ -482,8 +506,8 @@ __device__ inline void hgs_apply(HgsCtx &c, int mv, int U, int V) {
   if (!intra) hgs_update_route(c, rV);
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void hgs_ls_kernel(const HgsParams p) {
+template <int WAVES, int WPS>
+__global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams p) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = p.n, nc = n - 1;
@@ -506,7 +530,7 @@ __global__ __launch_bounds__(WAVES * 64) void hgs_ls_kernel(const HgsParams p) {
     c.fail = 0;
 
     // ---- the routes of the input (cvrp_nls/aco.py:12-20 get_subroutes: the non-empty pieces between zeros)
-    int R = 0, status = 0, totalMoves = 0, totalLoops = 0;
+    int R = 0, status = 0, totalMoves = 0, totalLoops = 0, nRounds = 0;
     {   // pass A: entries in range, number of routes, every client exactly once (Individual.cpp:69)
       int last = 0, seen = 0;
       bool bad = false;
@@ -621,35 +645,51 @@ __global__ __launch_bounds__(WAVES * 64) void hgs_ls_kernel(const HgsParams p) {
       __threadfence_block();
 
       bool searchCompleted = false;
-      int loops = 0;
+      int loops = 0, e2stamp = -1, e2er = -1;
       for (int loopID = 0; !searchCompleted && loopID <= sg.count && !c.fail; ++loopID) {
         ++loops;
         if (loopID > 1) searchCompleted = true;
+        // the neighbour list of the next node is fetched while the current one is evaluated (one L2 round trip less per node)
+        int nU = order[0];
+        int nLn = tlen[nU], nRp = c.l.rowptr[nU];
+        int nV = lane < nLn ? (int)(nRp >= 0 ? tent + nRp : scratch + (-(nRp + 1)))[lane] : 0;
         for (int posU = 0; posU < nc && !c.fail; ++posU) {
-          const int U = order[posU];
+          const int U = nU, ln = nLn, rp = nRp;
+          const int firstV = nV;
+          if (posU + 1 < nc) {
+            nU = order[posU + 1];
+            nLn = tlen[nU]; nRp = c.l.rowptr[nU];
+            nV = lane < nLn ? (int)(nRp >= 0 ? tent + nRp : scratch + (-(nRp + 1)))[lane] : 0;
+          }
           const int lastTest = c.l.whenRI[U];
           if (lane == 0) c.l.whenRI[U] = c.nbMoves;
-          const int ln = tlen[U];
-          const int rp = c.l.rowptr[U];
           const uint16_t *list = rp >= 0 ? tent + rp : scratch + (-(rp + 1));
           USide u;
           for (int ch = 0; ch < ln; ch += 64) {
-            const int myV = ch + lane < ln ? (int)list[ch + lane] : 0;
+            const int myV = ch == 0 ? firstV : (ch + lane < ln ? (int)list[ch + lane] : 0);
             int start = 0;
             for (;;) {
               if (c.tick(2)) break;
-              hgs_set_u(c, U, u);
-              int code = 0;
-              if (lane >= start && myV != 0) {
-                const int rV = c.l.route[myV];
-                const int wu = c.l.rWhen[u.rU], wv = c.l.rWhen[rV];
-                if (loopID == 0 || (wu > wv ? wu : wv) > lastTest) {
-                  code = hgs_eval(c, u, myV, 0);
-                  if (code == 0) {
-                    const int pvn = c.l.prev[myV];
-                    if (c.isdep(pvn)) { code = hgs_eval(c, u, pvn, 1); if (code) code += 16; }
-                  }
-                }
+              // who is to be evaluated (LocalSearch.cpp:32): LDS only -- after the first loop most nodes have nobody
+              const int rUn = c.l.route[U];
+              const int wu = c.l.rWhen[rUn];
+              bool act = lane >= start && myV != 0;
+              const int Vs = myV != 0 ? myV : U;                              // lanes without a candidate look at U itself (masked)
+              if (loopID != 0) { const int wv = c.l.rWhen[c.l.route[Vs]]; act = act && (wu > wv ? wu : wv) > lastTest; }
+              if (!__ballot(act)) break;
+              ++nRounds;
+              hgs_set_u<false>(c, U, u);
+              // both blocks for every lane, no branch between them: all matrix gathers of a round are in flight together
+              const int pvn = c.l.prev[Vs];
+              const bool depPrev = c.isdep(pvn);
+              const int c0 = hgs_eval(c, u, Vs, 0);
+              int code = act ? c0 : 0;
+              // "insert after the depot" (LocalSearch.cpp:47-56) for the lanes whose V opens its route and found nothing: only
+              // when such a lane exists (in the late loops few lanes are evaluated at all)
+              const bool need1 = act && c0 == 0 && depPrev;
+              if (__ballot(need1)) {
+                const int c1 = hgs_eval(c, u, depPrev ? pvn : Vs, 1);
+                if (need1 && c1) code = c1 + 16;
               }
               const uint64_t m = __ballot(code != 0);
               if (!m) break;
@@ -670,10 +710,21 @@ __global__ __launch_bounds__(WAVES * 64) void hgs_ls_kernel(const HgsParams p) {
               if (m) er = r0 + __builtin_ctzll(m);
             }
             if (er >= 0) {
-              hgs_set_u(c, U, u);
-              const int V = c.dep(er);
-              const int mv = hgs_eval(c, u, V, 2);
-              if (mv) { hgs_apply(c, mv, U, V); searchCompleted = false; }
+              // moves 1, 2, 3, 9 of U towards the empty route depend on the solution only: evaluated for 64 nodes at a time
+              // (one lane per node) and kept until the next move is applied -- in the late loops that is one evaluation
+              // per 64 nodes instead of one per node
+              if (e2stamp != c.nbMoves || e2er != er) {
+                for (int u0 = 1; u0 <= nc; u0 += 64) {
+                  const int Ul = u0 + lane <= nc ? u0 + lane : 1;
+                  USide ul;
+                  hgs_set_u<false>(c, Ul, ul);
+                  const int mvl = hgs_eval(c, ul, c.dep(er), 2);
+                  if (u0 + lane <= nc) c.l.e2[Ul] = (uint8_t)mvl;
+                }
+                e2stamp = c.nbMoves; e2er = er;
+              }
+              const int mv = c.l.e2[U];
+              if (mv) { hgs_apply(c, mv, U, c.dep(er)); searchCompleted = false; }
             }
           }
         }
@@ -744,7 +795,7 @@ __global__ __launch_bounds__(WAVES * 64) void hgs_ls_kernel(const HgsParams p) {
     }
     if (lane == 0) {
       if (p.status) p.status[item] = status;
-      if (p.stats) { p.stats[(size_t)item * 4] = totalMoves; p.stats[(size_t)item * 4 + 1] = totalLoops; p.stats[(size_t)item * 4 + 2] = c.R; p.stats[(size_t)item * 4 + 3] = c.fail; }
+      if (p.stats) { p.stats[(size_t)item * 4] = totalMoves; p.stats[(size_t)item * 4 + 1] = totalLoops; p.stats[(size_t)item * 4 + 2] = nRounds; p.stats[(size_t)item * 4 + 3] = c.fail; }
     }
   }
 }
@@ -770,6 +821,11 @@ extern "C" int daco_hgs_prepare(void *stream, int B, int n, const double *matrix
   return DACO_OK;
 }
 
+static int hgs_wps() {
+  static const int v = getenv("DACO_HGS_WPS") ? atoi(getenv("DACO_HGS_WPS")) : 0;
+  return v >= 2 && v <= 4 ? v : 3;
+}
+
 static int hgs_grid(int n, int Rmax, int *waves_out, size_t *lds_out) {
   const size_t per_wave = hgs_lds_bytes(n, Rmax);
   int waves = 4;
@@ -784,7 +840,7 @@ static int hgs_grid(int n, int Rmax, int *waves_out, size_t *lds_out) {
   }
   const size_t lds_cu = 160 * 1024;
   int wg_per_cu = (int)(lds_cu / (*lds_out ? *lds_out : 1));
-  const int cap = 16 / waves;                          // up to 16 wavefronts per CU (4 per SIMD: float64 code, ~128 VGPRs)
+  const int cap = 4 * hgs_wps() / waves > 0 ? 4 * hgs_wps() / waves : 1;      // wavefronts per CU the register budget of the kernel allows
   if (wg_per_cu > cap) wg_per_cu = cap;
   if (wg_per_cu < 1) wg_per_cu = 1;
   return cus * wg_per_cu;
@@ -836,15 +892,18 @@ extern "C" int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(workspace, 0, 256, st);
   if (e != hipSuccess) { set_error("daco_hgs_local_search: memset: %s", hipGetErrorString(e)); return DACO_E_HIP; }
-#define DACO_HGS_LAUNCH(W_)                                                                                                       \
+#define DACO_HGS_LAUNCH(W_, S_)                                                                                                   \
   do {                                                                                                                              \
     if (lds > 64 * 1024) {                                                                                                          \
-      e = hipFuncSetAttribute((const void *)hgs_ls_kernel<W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      e = hipFuncSetAttribute((const void *)hgs_ls_kernel<W_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
       if (e != hipSuccess) { set_error("daco_hgs_local_search: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return DACO_E_HIP; } \
     }                                                                                                                               \
-    hipLaunchKernelGGL(hgs_ls_kernel<W_>, dim3(grid), dim3(W_ * 64), lds, st, p);                                                   \
+    hipLaunchKernelGGL((hgs_ls_kernel<W_, S_>), dim3(grid), dim3(W_ * 64), lds, st, p);                                             \
   } while (0)
-  if (waves == 4) DACO_HGS_LAUNCH(4); else if (waves == 2) DACO_HGS_LAUNCH(2); else DACO_HGS_LAUNCH(1);
+  const int wps = hgs_wps();
+  if (waves == 4) { if (wps == 4) DACO_HGS_LAUNCH(4, 4); else if (wps == 2) DACO_HGS_LAUNCH(4, 2); else DACO_HGS_LAUNCH(4, 3); }
+  else if (waves == 2) DACO_HGS_LAUNCH(2, 3);
+  else DACO_HGS_LAUNCH(1, 3);
 #undef DACO_HGS_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("hgs_ls_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }

@@ -683,7 +683,7 @@ def hgs_local_search_(paths, stages, demand, capacity=1000.001, demand_scale=100
     paths [B,Lmax,A] or [Lmax,A] int64, rewritten in place in merge_subroutes' layout; stages: up to three
     (HgsTables, count) pairs run one after the other on each solution (neural_swapstar: (dist, limit), (heuristic_dist, 10),
     (dist, limit)); demand [B,n] or [n] as the colony holds it (scaled by demand_scale = 1000 as swapstar.py:335 does).
-    Returns paths (and status [B,A], stats [B,A,4] = moves, loops, routes, 0)."""
+    Returns paths (and status [B,A], stats [B,A,4] = moves, loops, evaluation rounds, watchdog)."""
     _require_gpu(paths)
     assert paths.dtype == torch.int64 and 1 <= len(stages) <= 3
     p3 = paths if paths.dim() == 3 else paths.unsqueeze(0)

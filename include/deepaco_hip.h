@@ -514,7 +514,8 @@ int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lmax, const fl
  *   status   out [B][A] int32 or NULL: 0 searched; 1 a stage was skipped because HGS throws there (distances or demands
  *            out of scale Params.cpp:106-111, fleet too small :112, infeasible input Individual.cpp:70) -- the reference
  *            then keeps that stage's input (swapstar.py:341-345); 2 the column is not a complete solution (left untouched)
- *   stats    out [B][A][4] int32 or NULL: moves applied, loops run, routes, 0
+ *   stats    out [B][A][4] int32 or NULL: moves applied, loops run, evaluation rounds (one per node and re-evaluation),
+ *            watchdog (0; the per-stage step budget DACO_HGS_BUDGET ran out at: 1 a route walk, 2 an evaluation round)
  *   workspace daco_hgs_workspace_bytes(B, n, A, Lmax, nb_granular) bytes
  */
 size_t daco_hgs_table_bytes(int n, int nb_granular);

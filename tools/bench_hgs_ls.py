@@ -49,7 +49,7 @@ def main():
         dt = time.perf_counter() - t0
         c1 = engine.tour_costs(d.float(), w, closed=False)
         print(f"hgs: {dt * 1e3:.2f} ms = {B * A / dt / 1e3:.1f} k solutions/s; moves/solution {float(stats[..., 0].float().mean()):.1f}, "
-              f"loops {float(stats[..., 1].float().mean()):.2f}, cost {float(c1.mean()):.4f}, status != 0: {int((status != 0).sum())}", flush=True)
+              f"loops {float(stats[..., 1].float().mean()):.2f}, rounds {float(stats[..., 2].float().mean()):.0f}, cost {float(c1.mean()):.4f}, status != 0: {int((status != 0).sum())}", flush=True)
     for cnt in (0, 1):
         w = paths.clone()
         torch.cuda.synchronize()
