@@ -412,6 +412,74 @@ def _cpu_small(job):
             if time.perf_counter() - t0 > budget_s:
                 break
         return done, time.perf_counter() - t0, sweeps
+    if kind == "hgs":
+        # the reference's own compiled local search when oracle/_ref/libhgscvrp.so travelled with the repository (HGS built from
+        # the reference's sources; called as cvrp_nls/swapstar.py:240-271 does, through /tmp route files, with the parameters HGS
+        # reads from the reference's structure: seed 1, no SWAP*), else the C restatement (oracle/hgs_ls.c)
+        import ctypes as C
+        import oracle
+        pos, d, hd, dem, cols, limit, wid = job[3:]
+        ref = os.path.join(ROOT, "oracle", "_ref", "libhgscvrp.so")
+        lib = None
+        if os.path.isfile(ref):
+            try:
+                lib = C.CDLL(ref)
+            except OSError:
+                lib = None
+        done = 0
+        if lib is not None:
+            class AP(C.Structure):      # AlgorithmParameters.h:10-28
+                _fields_ = [("nbGranular", C.c_int), ("mu", C.c_int), ("lambda_", C.c_int), ("nbElite", C.c_int), ("nbClose", C.c_int),
+                            ("nbIterPenaltyManagement", C.c_int), ("targetFeasible", C.c_double), ("penaltyDecrease", C.c_double),
+                            ("penaltyIncrease", C.c_double), ("seed", C.c_int), ("nbIter", C.c_int), ("nbIterTraces", C.c_int),
+                            ("timeLimit", C.c_double), ("useSwapStar", C.c_int)]
+            dp = C.POINTER(C.c_double)
+            lib.local_search.argtypes = [C.c_int, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_char, C.c_int, C.POINTER(AP), C.c_char,
+                                         C.c_int, C.c_int]
+            n = len(dem)
+            x, y = np.ascontiguousarray(pos[:, 0]), np.ascontiguousarray(pos[:, 1])
+            sv, dm = np.zeros(n), np.ascontiguousarray(dem * 1000)
+            ap = AP(20, 25, 40, 4, 5, 100, 0.2, 0.85, 1.2, 1, 20000, 500, 0.0, 0)
+
+            def call(mat, routes, count, cid):
+                with open(f"/tmp/route-{cid}", "w") as f:
+                    for i, r in enumerate(routes):
+                        f.write(f"Route #{i + 1}: " + " ".join(map(str, r)) + "\n")
+                m = np.ascontiguousarray(mat).reshape(-1)
+                lib.local_search(n, x.ctypes.data_as(dp), y.ctypes.data_as(dp), m.ctypes.data_as(dp), sv.ctypes.data_as(dp),
+                                 dm.ctypes.data_as(dp), 1000.001, sys.float_info.max, b'\0', len(routes), C.byref(ap), b'\0', cid, count)
+                out = []
+                with open(f"/tmp/swapstar-result-{cid}") as f:
+                    for line in f:
+                        if line.startswith("Route"):
+                            out.append(list(map(int, line.split(":")[1].split())))
+                os.remove(f"/tmp/swapstar-result-{cid}")
+                os.remove(f"/tmp/route-{cid}")
+                return out
+            for a in range(cols.shape[1]):
+                seq = cols[:, a].tolist()
+                routes, cur = [], []
+                for v in seq:
+                    if v == 0:
+                        if cur:
+                            routes.append(cur)
+                        cur = []
+                    else:
+                        cur.append(v)
+                cid = 1000003 * (wid + 1) + a
+                r = call(d, routes, limit, cid)
+                r = call(hd, r, 10, cid)
+                call(d, r, limit, cid)
+                done += 1
+                if time.perf_counter() - t0 > budget_s:
+                    break
+            return done, time.perf_counter() - t0, "reference"
+        for a in range(cols.shape[1]):
+            oracle.hgs_neural_swapstar(pos, d, hd, dem, cols[:, a], limit)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return done, time.perf_counter() - t0, "port"
     raise ValueError(kind)
 
 
@@ -672,56 +740,72 @@ def extra_configs(dev, headline_colony, cpu=True):
     except Exception as e:
         out["headline_scan_sparse"] = {"error": repr(e)}
 
-    # CVRP local search (cvrp_nls/aco.py:114-126 through csrc/daco_cvrp_ls.hip): CVRP-100, 512 ants, 16 instances, the
-    # schedule of cvrp_nls/aco.py:443-448 (to convergence, 10 moves on the perturbation matrix, to convergence)
+    # CVRP local search (cvrp_nls/aco.py:114-126, 443-448 through csrc/daco_hgs_ls.hip: the reference's routes, entry for entry):
+    # CVRP-100, 512 ants, 64 instances, neural_swapstar's three stages (limit = max(n, 50) loops, 10 on the heuristic-derived
+    # matrix, limit) in one launch
     try:
-        n, A, B = 100, 512, 16
+        n, A, B = 100, 512, 64
         g = torch.Generator().manual_seed(3)
-        loc = torch.cat((torch.full((B, 1, 2), 0.5), torch.rand(B, n, 2, generator=g)), 1)
-        dem = torch.cat((torch.zeros(B, 1), torch.randint(1, 10, (B, n), generator=g).float()), 1).to(dev)
+        loc = torch.cat((torch.full((B, 1, 2), 0.5, dtype=torch.double), torch.rand(B, n, 2, generator=g, dtype=torch.double)), 1)
+        dem = torch.cat((torch.zeros(B, 1, dtype=torch.double), torch.randint(1, 10, (B, n), generator=g).double() / 50.0), 1)
         dls = (loc[:, :, None] - loc[:, None]).norm(dim=-1)
         ii = torch.arange(n + 1)
         dls[:, ii, ii] = 1e-10
-        dls = dls.to(dev)
         heu = 1 / dls
-        hdl = (1 / (heu / heu.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
-        col = engine.BatchedCVRP(dls, dem, n_ants=A, capacity=50, seed=1)
+        hdl = 1 / (heu / heu.amax(dim=-1, keepdim=True) + 1e-5)
+        dls_d, hdl_d, dem_d = dls.to(dev), hdl.to(dev), dem.to(dev)
+        col = engine.BatchedCVRP(dls_d.float(), dem_d, n_ants=A, capacity=1.0, seed=1)
         paths, costs0 = col.step(trim=True)
-        Lm = float(col.last_lens.float().mean())
-
-        def search(pw):
-            tot = 0.0
-            for mtx, cnt in ((dls, 100000), (hdl, 10), (dls, 100000)):
-                _, _, mv = engine.cvrp_local_search_(mtx, dem, 50.0, pw, cnt, want_stats=True)
-                tot += float(mv.float().sum())
-            return tot
-        search(paths.clone())
+        limit = max(n + 1, 50)
+        td, th = engine.HgsTables(dls_d), engine.HgsTables(hdl_d)
+        stages = [(td, limit), (th, 10), (td, limit)]
+        engine.hgs_local_search_(paths.clone(), stages, dem_d)
         torch.cuda.synchronize()
         wk = paths.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        nm = search(wk)
+        e0.record()
+        _, st, stats = engine.hgs_local_search_(wk, stages, dem_d, want_stats=True)
+        e1.record()
         torch.cuda.synchronize()
         dtl = time.perf_counter() - t0
-        c1 = engine.tour_costs(dls, wk, closed=False)
-        pairs = nm * Lm * Lm
-        # a candidate pair costs 6-8 look-ups into the staged matrix (4 bytes each, LDS); ds_read_b32 peak 128 B/clk/CU
-        lds_peak = 128.0 * 256 * 2.4e9 / 1e9
-        ach = pairs * 7 * 4.0 / dtl / 1e9
-        pc = counters.get("cvrp_ls_100_a512_b16")
-        out["cvrp_local_search_100_a512_b16"] = {
-            "workload": f"CVRP-{n} local search (nine move families + SWAP*), {B} x {A} sampled solutions, the schedule of "
-                        f"cvrp_nls/aco.py:443-448", "value": B * A / dtl, "unit": "solutions/s", "seconds": dtl,
-            "moves_per_solution": nm / (B * A), "pairs_evaluated_per_s": pairs / dtl, "mean_sequence_length": Lm,
+        kms = e0.elapsed_time(e1)
+        c1 = engine.tour_costs(dls_d.float(), wk, closed=False)
+        moves, loops, rounds = [float(stats[..., k].float().mean()) for k in range(3)]
+        pc = counters.get("hgs_ls_100_a512_b64")
+        cb = None
+        if cpu:
+            procs = min(16, max(1, ncpu // 2))
+            pn = paths.cpu().numpy()
+            res = _cpu_leg([("hgs", 1, 8.0, loc[r % B].numpy(), dls[r % B].numpy(), hdl[r % B].numpy(), dem[r % B].numpy(),
+                             pn[r % B][:, : 64], limit, r) for r in range(procs)])
+            busy = max(r[1] for r in res)
+            kind = res[0][2]
+            cb = {"value": sum(r[0] for r in res) / busy, "unit": "solutions/s", "cores": procs, "host_cpus": ncpu, "kind": kind,
+                  "sample": f"{sum(r[0] for r in res)} of the same sampled solutions through neural_swapstar's three local_search calls, "
+                            f"{procs} processes (one thread each, the reference runs one task per ant in a thread pool), {busy:.1f} s: "
+                            + ("HGS-CVRP built from the reference's sources (oracle/_ref/libhgscvrp.so), called through the /tmp route "
+                               "files as cvrp_nls/swapstar.py:240-271 does" if kind == "reference" else
+                               "oracle/hgs_ls.c, the C restatement of HGS's LocalSearch (oracle/_ref did not travel)")}
+        # every evaluation round is ~450 wave instructions, most of them float64 (4 cycles on a SIMD): the kernel is bound by
+        # VALU issue and the latency of the dependent L2 gathers between rounds, not by bytes
+        out["cvrp_local_search_100_a512_b64"] = {
+            "workload": f"CVRP-{n} local search, route for route with the reference (HGS moves 1-9, granular 20, first improvement), "
+                        f"{B} x {A} sampled solutions, neural_swapstar's three stages in one launch",
+            "value": B * A / dtl, "unit": "solutions/s", "seconds": dtl, "kernel_ms": kms,
+            "moves_per_solution": moves, "loops_per_solution": loops, "evaluation_rounds_per_solution": rounds,
             "mean_cost_before": float(costs0.mean()), "mean_cost_after": float(c1.mean()),
-            "roofline": {"bound": "lds", "achieved": ach, "peak": lds_peak, "unit": "GB/s", "frac": ach / lds_peak, "traffic": None,
-                         "kernel": "cvrp_ls_kernel<true, 512> (three launches; wall clock around them)", "pipes": pc,
-                         "valu_busy": (pc or {}).get("valu_busy"),
-                         "note": "pair evaluations x 7 matrix look-ups x 4 B against the LDS gather rate (ds_read_b32: 128 B/clk/CU, "
-                                 "MI355X_MICROARCH.md LDS table); the matrix of an instance is staged in LDS, the pair loop is a chain "
-                                 "of dependent look-ups (profiles/r04_pmc_cvrp_ls.txt)"}}
+            "status_nonzero": int((st != 0).sum()),
+            "roofline": {"bound": "valu", "unit": "SIMD-cycles/s", "achieved": None if not pc else pc.get("valu_active_cycles", 0) / (kms * 1e-3),
+                         "peak": 1024 * 2.4e9, "frac": (pc or {}).get("valu_active"), "traffic": (pc or {}).get("hbm_bytes"),
+                         "kernel": "hgs_ls_kernel<4, 3> (HIP events around the launch)", "kernel_ms": kms, "pipes": pc,
+                         "note": "frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x kernel cycles) from the counter pass of this "
+                                 "workload (profiles/r05_pmc_hgs_ls.txt); the wavefronts spend the other half parked on the L2 gathers "
+                                 "of the next round (one wavefront per solution, a chain of ~1 900 dependent rounds)"},
+            "cpu_baseline": cb}
         del col
     except Exception as e:
-        out["cvrp_local_search_100_a512_b16"] = {"error": repr(e)}
+        out["cvrp_local_search_100_a512_b64"] = {"error": repr(e)}
 
     # headline workload with the LEARNED heuristic: Net + the reference's pretrained tsp500 weights
     # (tests/golden/w_tsp_tsp500.npz: the checkpoint as plain arrays), heu + 1e-10, next to the vanilla 1/d on the
