@@ -986,7 +986,15 @@ class StreamedTSP:
             self.streams.append(st)
         self._dev = dev
 
+    def _fork(self):
+        """The part streams wait for what the current stream has queued (a gather of the parts' state that is still
+        pending there must not be overtaken by a step that rewrites that state in place -- ADVICE r4)."""
+        cur = torch.cuda.current_stream(self._dev)
+        for st in self.streams:
+            st.wait_stream(cur)
+
     def sparsify(self, k_sparse):
+        self._fork()
         for col, st in zip(self.cols, self.streams):
             with torch.cuda.stream(st):
                 col.sparsify(k_sparse)
@@ -998,6 +1006,7 @@ class StreamedTSP:
 
     def step(self, events=None):
         """events: one (begin, end) torch.cuda.Event pair PER PART, re-recorded around that part's construction kernel."""
+        self._fork()
         for p, (col, st) in enumerate(zip(self.cols, self.streams)):
             with torch.cuda.stream(st):
                 col.step(events=events[p] if events is not None else None)
@@ -1014,7 +1023,11 @@ class StreamedTSP:
 
     def _gather(self, name):
         self.join()
-        return torch.cat([getattr(c, name) for c in self.cols], dim=0)
+        cur = torch.cuda.current_stream(self._dev)
+        src = [getattr(c, name) for c in self.cols]
+        for t in src:                       # allocated on a part's stream, read on this one
+            t.record_stream(cur)
+        return torch.cat(src, dim=0)
 
     @property
     def lowest_cost(self):

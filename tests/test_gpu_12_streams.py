@@ -49,3 +49,28 @@ def test_streamed_colony_run_and_uneven_split():
     one.sparsify(16)
     assert torch.equal(low, one.run(6)) and low.shape == (7,)
     assert many.shortest_path.sort(dim=1).values.tolist() == [list(range(160))] * 7
+
+
+def test_reading_state_between_steps_without_a_device_sync():
+    """`low = many.lowest_cost; many.step()` -- the gather is queued on the current stream, the next step rewrites
+    the parts' state in place on their own streams.  The parts wait for the current stream at the start of a step, so every
+    gathered copy is the state of ITS iteration (compared with one BatchedTSP read at the same points; no synchronize in between)."""
+    from deepaco_amd import engine
+    d = instances(8, 400, 11)
+    one = engine.BatchedTSP(d, n_ants=128, seed=9)
+    many = engine.StreamedTSP(d, parts=4, n_ants=128, seed=9)
+    one.sparsify(40)
+    many.sparsify(40)
+    got, want = [], []
+    big = torch.rand(4096, 4096, device=dev())
+    for _ in range(6):
+        one.step()
+        want.append((one.lowest_cost.clone(), one.pheromone.clone(), one.shortest_path.clone()))
+    for _ in range(6):
+        many.step()
+        for _ in range(4):
+            big = big @ big * 1e-3                                     # keeps the current stream busy: the gathers below queue up behind it
+        got.append((many.lowest_cost, many.pheromone, many.shortest_path))
+    torch.cuda.synchronize()
+    for (gl, gp, gs), (wl, wp, ws) in zip(got, want):
+        assert torch.equal(gl, wl) and torch.equal(gp, wp) and torch.equal(gs, ws)
