@@ -81,6 +81,9 @@ def parse_args():
                          "(strong scaling)")
     ap.add_argument("--exchange", default="tours", choices=["tours", "delta"],
                     help="--shard ants: all-gather of the tours (int16; exact, default) or all-reduce of delta-tau")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and take the distributed code path even with one rank (world size 1 on RCCL: "
+                         "what an N-GPU run executes, on one GPU)")
     ap.add_argument("--force-device", type=int, default=None,
                     help="testing only: put every rank on this GPU (needs --dist-backend gloo)")
     return apply_config(ap.parse_args())
@@ -175,6 +178,20 @@ def _finite(v):
     return v
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Everything but the record goes to stderr: file descriptor 1 is pointed at stderr for the rest of the run and the record
+    is written to the saved descriptor at the very end.  (RCCL prints a version banner on C stdout, flushed when the process
+    exits -- i.e. AFTER a Python print of the record: the driver reads the LAST stdout line.)"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(full):
     """Full record -> bench_extras.json (repo root, and gpurun_out/ when it exists so that it travels back from a GPU box);
     compact record -> the last stdout line."""
@@ -187,7 +204,8 @@ def emit(full):
         except OSError as e:
             log(f"could not write bench_extras.json under {d}: {e}")
     sys.stderr.flush()
-    print(headline_record(full), flush=True)
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (headline_record(full) + "\n").encode())
 
 
 # ---------------------------------------------------------------------------------------------- launcher
@@ -983,6 +1001,7 @@ def active_knobs():
 
 # ---------------------------------------------------------------------------------------------- one rank
 def worker(args):
+    quiet_stdout()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -990,10 +1009,17 @@ def worker(args):
     if world != args.gpus:
         log(f"rank {rank}: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs "
             f"(n_gpus = {world})")
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         import torch.distributed as dist_pkg
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:           # --force-dist without a launcher
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev_index = local_rank if args.force_device is None else args.force_device
     if dev_index >= torch.cuda.device_count():

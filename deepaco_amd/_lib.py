@@ -38,7 +38,7 @@ SIGNATURES = {
     "daco_pick_move": (_i, [_vp, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp]),
     "daco_directed_table_bytes": (_sz, [_i, _i, _i]),
     "daco_track_best": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f]),
-    "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _vp, _u32, _i,
+    "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, C.c_double, _vp, _vp]),
     "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                                   C.c_double]),

@@ -128,8 +128,8 @@ extern "C" int daco_tsp_sample(void *stream, int B, int n, int A, const float *t
 extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *tau, long tau_bstride,
                                 const float *eta, long eta_bstride, float alpha, float beta,
                                 const float *demand, float capacity, int mode, const float *noise,
-                                int noise_steps, uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax,
-                                int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
+                                int noise_steps, uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0, int ant_gid_bstride,
+                                int Lmax, int64_t *paths, float *logp, float *rowsum, int32_t *lens, int32_t *flags,
                                 const float *dist, long dist_bstride, float *costs, void *next_table,
                                 void *workspace, size_t workspace_bytes, const double *demand64, double capacity64,
                                 void *ev_begin, void *ev_end) {
@@ -138,6 +138,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
     return DACO_E_BADARG;
   }
   if (n > DACO_MAX_NODES) { set_error("daco_cvrp_sample: n=%d exceeds DACO_MAX_NODES=%d", n, DACO_MAX_NODES); return DACO_E_TOOLARGE; }
+  if (ant_gid_bstride < 0 || (ant_gid_bstride > 0 && ant_gid_bstride < A)) { set_error("daco_cvrp_sample: ant_gid_bstride %d < A %d", ant_gid_bstride, A); return DACO_E_BADARG; }
   const bool packed = mode == DACO_SCAN && (size_t)n * A * 8 < ((size_t)1 << 32);
   // (float64 load bookkeeping: the one-ant-per-wavefront kernel's PROB_CVRP64 policy)
   // scan16_kernel family (4 / 8 / 16 lanes per ant), float32 or float64 load bookkeeping (above 512 nodes and in the race modes: the
@@ -172,7 +173,7 @@ extern "C" int daco_cvrp_sample(void *stream, int B, int n, int A, const float *
   SampleParams sp;
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = CH;
   sp.P = P; sp.R = R; sp.norm_passes = 1; sp.start = nullptr; sp.fixed_start = 0;
-  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = 0;
+  sp.noise = noise; sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.logp = logp; sp.rowsum = rowsum; sp.flags = flags;
   sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = (uint32_t *)next_table; sp.hubmask = hubmask; sp.tab_lens = tab_lens;
   sp.demand = demand; sp.capacity = capacity; sp.Lmax = Lmax; sp.noise_steps = noise_steps; sp.lens = lens;

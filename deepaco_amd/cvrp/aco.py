@@ -214,3 +214,43 @@ class ACO():
         if require_prob:
             return paths[0, :L], logp[0, :L - 1]
         return paths[0, :L]
+
+    # ------------------------------------------------------------------ cvrp/aco.py:167-205 (the step-wise helpers)
+    @torch.no_grad()
+    def pick_move(self, prev, visit_mask, capacity_mask, require_prob, *, _noise=None):
+        """cvrp/aco.py:167-174: one draw per ant from tau[prev]^alpha * eta[prev]^beta * visit_mask * capacity_mask
+        (engine.PickService).  gen_path() is one fused launch and does not call this; see tsp.ACO.pick_move."""
+        key = (id(self.pheromone), self.pheromone._version, id(self.heuristic), self.heuristic._version)
+        if getattr(self, "_pick_key", None) != key:
+            self._pick_svc = engine.PickService(self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha,
+                                                self.beta, mode="scan", seed=self.seed, it=self._calls)
+            self._pick_key, self._pick_step = key, 0
+            self._calls += 1
+        self._pick_step += 1
+        dev = self.pheromone.device
+        mask = visit_mask.to(dev) * capacity_mask.to(dev)
+        actions, log_probs, _ = self._pick_svc.pick(prev.to(dev), mask, self._pick_step, require_prob=bool(require_prob), noise=_noise)
+        if bool(self._pick_svc.flags.any()):
+            raise ValueError("ACO.pick_move: a transition row had no feasible candidate")
+        return actions, log_probs
+
+    def update_visit_mask(self, visit_mask, actions):
+        """cvrp/aco.py:176-180: the visited customer closes, the depot is open unless the ant stands on it with customers left."""
+        visit_mask[torch.arange(self.n_ants, device=visit_mask.device), actions] = 0
+        visit_mask[:, 0] = 1
+        visit_mask[(actions == 0) * (visit_mask[:, 1:] != 0).any(dim=1), 0] = 0
+        return visit_mask
+
+    def update_capacity_mask(self, cur_nodes, used_capacity):
+        """cvrp/aco.py:182-202: (used capacity after serving cur_nodes -- reset at the depot --, mask of the nodes whose demand
+        still fits: demand > capacity - used closes a node)."""
+        used_capacity[cur_nodes == 0] = 0
+        used_capacity = used_capacity + self.demand[cur_nodes]
+        remaining = (self.capacity - used_capacity).unsqueeze(-1)
+        capacity_mask = torch.ones((self.n_ants, self.problem_size), device=used_capacity.device)
+        capacity_mask[self.demand.unsqueeze(0) > remaining] = 0
+        return used_capacity, capacity_mask
+
+    def check_done(self, visit_mask, actions):
+        """cvrp/aco.py:204-205."""
+        return (visit_mask[:, 1:] == 0).all() and (actions == 0).all()

@@ -194,7 +194,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
 
 def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
                 it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False,
-                iter_dev=None, events=None):
+                iter_dev=None, events=None, ant_gid_bstride=0):
     """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
     or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, rowsum|None, lens [B,A], flags [B]);
     the reference's result is paths[:, :lens.max()].
@@ -245,7 +245,7 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
                                 float(beta), demand.data_ptr(), float(capacity), m,
                                 noise.data_ptr() if noise is not None else None, steps,
                                 int(seed) & (2 ** 64 - 1), int(it), iter_dev.data_ptr() if iter_dev is not None else None,
-                                int(ant_gid0) & 0xFFFFFFFF, Lmax,
+                                int(ant_gid0) & 0xFFFFFFFF, int(ant_gid_bstride), Lmax,
                                 paths.data_ptr(), logp.data_ptr() if require_prob else None,
                                 rowsum.data_ptr() if require_prob else None, lens.data_ptr(),
                                 flags.data_ptr(), dist.data_ptr() if dist is not None else None, dbs,
@@ -1118,11 +1118,12 @@ class BatchedCVRP:
 
 
 def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1.0, heuristic=None, sampler="scan",
-                    seed=0, exchange="delta"):
+                    seed=0, exchange="delta", elitist=False, min_max=False, min=None):
     """Ant-sharded TSP colony on this rank's GPU: A/world ants of every instance here, pheromone
     replicated, one collective per iteration (RCCL over xGMI when the process group is nccl):
     exchange="delta": all-reduce of the deposits [B,n,n]; exchange="tours": all-gather of the tours (int16) and
-    costs, every rank applies the full deposit in ant order -- bit-identical to BatchedTSP with the same seed.
+    costs, every rank applies the full deposit in ant order -- bit-identical to BatchedTSP with the same seed, for AS,
+    elitist and MMAS colonies, best tours (`shortest_path`) included.
     Returns a parallel.AntShardedColony whose kernels are the HIP ones."""
     from .parallel import AntShardedColony
     _require_gpu(distances)
@@ -1137,7 +1138,7 @@ def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1
         # rank-local ids would overlap when n_ants % world != 0 (shard_range gives the first ranks one ant more)
         paths, _, _, _, costs, nbr = tsp_sample(tau, eta, n_local, alpha, beta, mode=sampler, seed=seed, it=it,
                                                 ant_gid0=lo, ant_gid_bstride=n_ants, batch=B, dist=dist_,
-                                                want_nbr=not exact)
+                                                want_nbr=not exact and not elitist)
         state["costs"], state["nbr"] = costs, nbr
         return paths
 
@@ -1147,8 +1148,42 @@ def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1
     def deposit_fn(zero, paths, costs):
         return pheromone_update_(zero, paths, costs, 1.0, nbr=state["nbr"])
 
-    def update_fn(tau, paths, costs):
-        return pheromone_update_(tau, paths.contiguous(), costs.contiguous(), decay)
+    def update_fn(tau, paths, costs, elit, cmin, cmax):
+        return pheromone_update_(tau, paths, costs, decay, elit, True, cmin, cmax)
 
     return AntShardedColony(torch.ones_like(dist_), n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn,
-                            exchange=exchange, update_fn=update_fn)
+                            exchange=exchange, update_fn=update_fn, elitist=elitist, min_max=min_max, min=min, problem_size=n)
+
+
+def ant_sharded_cvrp(distances, demand, n_ants, rank, world, capacity=50, decay=0.9, alpha=1.0, beta=1.0, heuristic=None,
+                     sampler="scan", seed=0, exchange="tours", elitist=False, min_max=False, min=None):
+    """Ant-sharded CVRP colony (cvrp/aco.py:67-130 per instance: directed deposits tau[path[:-1], path[1:]] += 1/cost, floor
+    1e-10): A/world ants of every instance on this rank, the route sequences ([B, 2n+1, A_local], zero padded) exchanged as
+    int16 (exchange="tours": the single-GPU BatchedCVRP bit for bit) or the directed deposits summed (exchange="delta")."""
+    from .parallel import AntShardedColony
+    _require_gpu(distances, demand)
+    dist_ = _f32c(distances)
+    B, n, _ = dist_.shape
+    eta = (1 / dist_) if heuristic is None else heuristic
+    state = {}
+    exact = exchange == "tours"
+
+    def sample_fn(tau, lo, n_local, it):
+        paths, _, _, lens, flags, costs, table = cvrp_sample(tau, eta, demand, capacity, n_local, alpha, beta, mode=sampler,
+                                                             seed=seed, it=it, ant_gid0=lo, ant_gid_bstride=n_ants, batch=B,
+                                                             dist=dist_, want_table=not exact and not elitist)
+        state["costs"], state["table"], state["flags"] = costs, table, flags
+        return paths
+
+    def cost_fn(paths):
+        return state["costs"]
+
+    def deposit_fn(zero, paths, costs):
+        return pheromone_update_(zero, paths, costs, 1.0, False, False, nbr=state["table"])
+
+    def update_fn(tau, paths, costs, elit, cmin, cmax):
+        return pheromone_update_(tau, paths, costs, decay, elit, False, cmin, cmax, floor=1e-10)
+
+    return AntShardedColony(torch.ones_like(dist_), n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn,
+                            exchange=exchange, update_fn=update_fn, elitist=elitist, min_max=min_max, min=min, problem_size=n,
+                            floor=1e-10)

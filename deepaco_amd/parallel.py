@@ -95,26 +95,54 @@ def gather_best(lowest_cost, total, rank, world):
     return torch.cat(parts)
 
 
-class AntShardedColony:
-    """Ant-sharded AS colony: replicated pheromone, local deposits summed by one all-reduce.
+def all_gather_into_(out, x):
+    """out [world, *x.shape] <- every rank's x (one collective into a preallocated buffer)."""
+    # (the concatenated form [world * x.shape[0], ...] of the output: the one both gloo and RCCL accept)
+    flat = (out.shape[0] * x.shape[0],) + tuple(x.shape[1:])
+    if _host_staged(x):
+        host = torch.empty(flat, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, x.cpu().contiguous())
+        out.copy_(host.view(out.shape))
+    else:
+        dist.all_gather_into_tensor(out.view(flat), x.contiguous())
 
-    sample_fn(tau, ant_gid0, n_local, it) -> paths [B, n, A_local]
+
+class AntShardedColony:
+    """Ant-sharded colony: replicated pheromone, every rank builds A / world ants of the same instances.
+    AS, elitist and MMAS as tsp/aco.py:75-118 (cvrp/aco.py:67-130 with directed deposits): best-so-far cost AND tour are
+    tracked colony-wide, the elitist deposit is the iteration-best ant's, the MMAS bounds follow the global best.
+
+    sample_fn(tau, ant_lo, n_local, it) -> paths [B, L, A_local] int64
     cost_fn(paths) -> costs [B, A_local]
-    deposit_fn(zeros_like_tau, paths, costs) -> delta (deposit with decay = 1 onto zeros, in place)
+    exchange="delta":  deposit_fn(zeros_like_tau, paths, costs) -> the deposits of this rank's ants (decay 1, onto zeros);
+                       one all-reduce(sum) of [B, n, n] per iteration (AS).  The best ant travels separately: all-gather of the
+                       ranks' best costs [B], the winner's tour by an all-reduce of [B, L] int32 (zeros from the others).
+                       elitist colonies need NO [B, n, n] exchange: every rank deposits the winner's tour itself
+                       (update_fn on one ant).  Pheromone equals the single-GPU colony's to ~1e-6 (sum order), tours differ.
+    exchange="tours":  update_fn(tau, paths [B, L, A], costs [B, A], elitist, cmin, cmax) -> tau updated in place by the full
+                       evaporate + deposit (+ clamp) of the single-GPU colony; one all-gather of the tours (int16) and costs.
+                       With colony-wide ant ids this is the single-GPU colony bit for bit, best tours included.
     The callables are the engine's kernels on a GPU and plain torch on CPU in the gloo tests."""
 
     def __init__(self, tau, n_ants, decay, rank, world, sample_fn, cost_fn, deposit_fn, exchange="delta",
-                 update_fn=None):
-        """exchange="tours" needs update_fn(tau, paths [B,n,A], costs [B,A]) -> tau updated in place (the full
-        evaporate + deposit of the single-GPU colony) instead of deposit_fn."""
+                 update_fn=None, elitist=False, min_max=False, min=None, problem_size=None, floor=None):
         assert exchange in ("delta", "tours")
         assert exchange == "delta" or update_fn is not None
+        assert not (exchange == "delta" and elitist) or update_fn is not None
         self.tau = tau              # the colony OWNS this tensor from here on: step() updates it in place (pass a clone to keep yours)
         self.n_ants, self.decay, self.rank, self.world = n_ants, decay, rank, world
         self.lo, self.hi = shard_range(n_ants, rank, world)
         self.sample_fn, self.cost_fn, self.deposit_fn = sample_fn, cost_fn, deposit_fn
         self.exchange, self.update_fn = exchange, update_fn
+        self.elitist, self.min_max, self.floor = elitist, min_max, floor
+        self.problem_size = tau.shape[-1] if problem_size is None else problem_size
+        if min_max:
+            self.min = 0.1 if min is None else min
+            assert self.min > 1e-9
+            self.max = None
+            self.tau.mul_(self.min)                                        # tsp/aco.py:37-40 (tau starts at ones * min)
         self.lowest_cost = torch.full((tau.shape[0],), float("inf"), device=tau.device)
+        self.shortest_path = None                                          # [B, L] int64 once a step has run
         self.iteration = 0
         self._buffers = {}          # exchange buffers, allocated once (a [B,n,n] delta or B*n*A tours per iteration otherwise)
 
@@ -126,7 +154,8 @@ class AntShardedColony:
         return buf
 
     def _gather_ants(self, x, dim):
-        """all-gather along the ant dimension (ranks may own one ant more or less: padded, then trimmed)."""
+        """all-gather along the ant dimension (ranks may own one ant more or less: padded, then trimmed): ONE
+        all_gather_into_tensor into a preallocated [world, ...] buffer."""
         if self.world == 1:
             return x
         q = -(-self.n_ants // self.world)
@@ -134,38 +163,80 @@ class AntShardedColony:
         shape[dim] = q
         pad = self._buffer("pad", shape, x.dtype, x.device)            # (rows past this rank's ants stay zero)
         pad.narrow(dim, 0, x.shape[dim]).copy_(x)
-        out = [self._buffer(("out", r), shape, x.dtype, x.device) for r in range(self.world)]
-        if pad.dtype == torch.int16:          # neither gloo nor RCCL moves int16: ship the same bytes as uint8
-            all_gather_([o.view(torch.uint8) for o in out], pad.view(torch.uint8))
+        out = self._buffer("out", [self.world] + shape, x.dtype, x.device)
+        if pad.dtype == torch.int16:          # neither gloo nor RCCL has a 16-bit integer type: the same bytes as uint8
+            all_gather_into_(out.view(torch.uint8), pad.view(torch.uint8))
         else:
-            all_gather_(out, pad)
+            all_gather_into_(out, pad)
         parts = []
         for r in range(self.world):
             lo, hi = shard_range(self.n_ants, r, self.world)
             parts.append(out[r].narrow(dim, 0, hi - lo))
         return torch.cat(parts, dim=dim)
 
+    def _track(self, best_cost, best_path):
+        """tsp/aco.py:78-88 with the colony-wide iteration best: (MMAS max | None)."""
+        if self.shortest_path is None or self.shortest_path.shape[1] != best_path.shape[1]:
+            self.shortest_path = torch.zeros_like(best_path)
+        better = best_cost < self.lowest_cost
+        self.shortest_path = torch.where(better.unsqueeze(1), best_path, self.shortest_path)
+        self.lowest_cost = torch.where(better, best_cost, self.lowest_cost)
+        if not self.min_max:
+            return None
+        new_max = (1 / self.lowest_cost) * self.problem_size          # the two roundings of daco_track_best
+        if self.max is None:                                           # tsp/aco.py:86-87: first best rescales tau
+            self.tau.mul_((new_max / self.tau.amax(dim=(1, 2))).view(-1, 1, 1))
+        self.max = new_max
+        return new_max
+
+    def _iteration_best(self, paths, costs):
+        """(cost [B], tour [B, L]) of the colony's best ant of this iteration (first minimum in ant order) on every rank."""
+        lc, li = costs.min(dim=1)
+        lp = torch.gather(paths, 2, li.view(-1, 1, 1).expand(-1, paths.shape[1], 1)).squeeze(2)
+        if self.world == 1:
+            return lc, lp
+        allc = self._buffer("bestc", (self.world,) + tuple(lc.shape), lc.dtype, lc.device)
+        all_gather_into_(allc, lc)
+        gc, owner = allc.min(dim=0)                                   # first minimum = lowest rank = lowest ant id
+        mine = (owner == self.rank).unsqueeze(1)
+        contrib = torch.where(mine, lp, torch.zeros_like(lp)).to(torch.int32)
+        all_reduce_(contrib, dist.ReduceOp.SUM)                       # the winner's tour; the other ranks add zeros
+        return gc, contrib.to(torch.int64)
+
     @torch.no_grad()
     def step(self):
         paths = self.sample_fn(self.tau, self.lo, self.hi - self.lo, self.iteration)
         costs = self.cost_fn(paths)
         if self.exchange == "tours":
-            narrow = torch.int16 if paths.shape[1] <= 32767 else torch.int32
+            narrow = torch.int16 if self.tau.shape[-1] <= 32767 else torch.int32
             all_paths = self._gather_ants(paths.to(narrow), 2).to(torch.int64)       # the one data-path collective
             all_costs = self._gather_ants(costs, 1)
-            self.update_fn(self.tau, all_paths, all_costs)
-            self.lowest_cost = torch.minimum(self.lowest_cost, all_costs.min(dim=1).values)
+            bc, bi = all_costs.min(dim=1)
+            bp = torch.gather(all_paths, 2, bi.view(-1, 1, 1).expand(-1, all_paths.shape[1], 1)).squeeze(2)
+            new_max = self._track(bc, bp)
+            cmin = None if new_max is None else torch.full_like(new_max, self.min)
+            self.update_fn(self.tau, all_paths.contiguous(), all_costs.contiguous(), self.elitist, cmin, new_max)
+            self.iteration += 1
+            return paths, costs
+        bc, bp = self._iteration_best(paths, costs)
+        new_max = self._track(bc, bp)
+        cmin = None if new_max is None else torch.full_like(new_max, self.min)
+        if self.elitist:
+            # only the iteration-best ant deposits (tsp/aco.py:103-107): every rank has its tour, nothing else is exchanged
+            self.update_fn(self.tau, bp.unsqueeze(2).contiguous(), bc.unsqueeze(1).contiguous(), False, cmin, new_max)
             self.iteration += 1
             return paths, costs
         buf = self._buffer("delta", self.tau.shape, self.tau.dtype, self.tau.device).zero_()
         delta = self.deposit_fn(buf, paths, costs)                # (deposit_fn adds into the buffer it is given and returns it; the
         if delta is not buf:                                      # buffer is zeroed again next step, so nobody may keep it)
             delta = buf.copy_(delta)
-        best = costs.min(dim=1).values
         if self.world > 1:
-            all_reduce_(delta, dist.ReduceOp.SUM)                 # the one data-path collective
-            all_reduce_(best, dist.ReduceOp.MIN)
-        self.tau.mul_(self.decay).add_(delta)                     # in place: tau * decay (rounded), then + delta, as before
-        self.lowest_cost = torch.minimum(self.lowest_cost, best)
+            all_reduce_(delta, dist.ReduceOp.SUM)                 # the one [B, n, n] collective
+        self.tau.mul_(self.decay).add_(delta)                     # in place: tau * decay (rounded), then + delta
+        if new_max is not None:                                   # tsp/aco.py:116-118
+            torch.maximum(self.tau, cmin.view(-1, 1, 1), out=self.tau)
+            torch.minimum(self.tau, new_max.view(-1, 1, 1), out=self.tau)
+        if self.floor is not None:                                # cvrp/aco.py:130
+            self.tau.clamp_(min=self.floor)
         self.iteration += 1
         return paths, costs

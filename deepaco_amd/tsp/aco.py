@@ -248,6 +248,26 @@ class ACO():
             return paths[0], logp[0]
         return paths[0]
 
+    # ------------------------------------------------------------------ tsp/aco.py:165-177
+    @torch.no_grad()
+    def pick_move(self, prev, mask, require_prob, *, _noise=None):
+        """One draw per ant from tau[prev]^alpha * eta[prev]^beta * mask (daco_prob_matrix + daco_pick_move through
+        engine.PickService): `prev` [n_ants] int64, `mask` [n_ants, problem_size] (0 = closed).  Returns (actions,
+        log_probs | None).  gen_path() does NOT call this (its n - 1 draws are one fused kernel launch), so overriding it in
+        a subclass does not change gen_path; log-probabilities that carry gradient come from gen_path(require_prob=True) /
+        sample().  `_noise` [n_ants, problem_size]: the reference's Exp(1) variates for a bit-exact replay of its draw."""
+        key = (id(self.pheromone), self.pheromone._version, id(self.heuristic), self.heuristic._version)
+        if getattr(self, "_pick_key", None) != key:
+            self._pick_svc = engine.PickService(self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha,
+                                                self.beta, mode="scan", seed=self.seed, it=self._calls)
+            self._pick_key, self._pick_step = key, 0
+            self._calls += 1
+        self._pick_step += 1
+        actions, log_probs, _ = self._pick_svc.pick(prev.to(self.pheromone.device), mask.to(self.pheromone.device),
+                                                    self._pick_step, require_prob=bool(require_prob), noise=_noise)
+        self._last_flags = self._pick_svc.flags
+        return actions, log_probs
+
     def check_feasible(self):
         """Raise like torch.distributions.Categorical does when some draw had no candidate
         (host sync; the kernels only set a flag)."""

@@ -171,3 +171,52 @@ class ACO(_TspACO):
                            T_nls=T_nls, T_p=T_p, dist_t=dt.unsqueeze(0) if torch.is_tensor(dt) else dt,
                            heuristic_dist_t=hdt.unsqueeze(0) if torch.is_tensor(hdt) else hdt, tables=tabs, heuristic_tables=hd_tabs)
         return self._paths(best[0])
+
+    # ------------------------------------------------------------------ tsp_nls/aco.py:171-182, 222-228
+    def gen_numpy_path_costs(self, paths, numpy_distances):
+        """Closed-tour lengths of `paths` [n_ants, problem_size] (one ROW per ant -- the transposed layout of the local search)
+        on a numpy matrix, as tsp_nls/aco.py:171-182 sums them."""
+        import numpy as np
+        assert paths.shape == (self.n_ants, self.problem_size)
+        return np.sum(numpy_distances[paths, np.roll(paths, shift=1, axis=1)], axis=1)
+
+    @property
+    def distances_numpy(self):
+        """tsp_nls/aco.py:222-224: the distances as a float32 numpy matrix (a host copy; the local search here reads the device one)."""
+        if getattr(self, "_distances_numpy", None) is None:
+            import numpy as np
+            self._distances_numpy = self.distances.detach().cpu().numpy().astype(np.float32)
+        return self._distances_numpy
+
+    @property
+    def heuristic_numpy(self):
+        """tsp_nls/aco.py:226-228."""
+        if getattr(self, "_heuristic_numpy", None) is None:
+            import numpy as np
+            self._heuristic_numpy = self.heuristic.detach().cpu().numpy().astype(np.float32)
+        return self._heuristic_numpy
+
+
+def inference_batch_sample(probmat, count=1, startnode=None, *, seed=None):
+    """tsp_nls/aco.py:276-297: `count` tours drawn from the transition matrix `probmat` [n, n] (numpy or tensor) by roulette
+    selection, fixed start node (random per tour if None) -> routes [count, n] uint16 numpy.  The reference runs a numba loop
+    per tour in a thread pool; here it is one launch of the scan sampler (the same categorical per step: the cumulative sum
+    against u * total; fixtures g6 / g6w pin the arithmetic on injected uniforms), its own random stream."""
+    import numpy as np
+    from deepaco_amd import engine
+    p = torch.as_tensor(np.asarray(probmat, dtype=np.float32)) if not torch.is_tensor(probmat) else probmat.detach().float()
+    p = engine.stage_to_hip(p).contiguous()
+    n = p.shape[0]
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)))
+    start = None
+    if startnode is None:
+        start = torch.randint(0, n, (1, count), device=p.device)
+    paths, _, _, flags = engine.tsp_sample(torch.ones_like(p), p, count, mode="scan", start=start,
+                                           fixed_start=-1 if startnode is None else int(startnode), seed=seed, batch=1)
+    return paths[0].T.contiguous().cpu().numpy().astype(np.uint16)
+
+
+def _inference_sample(probmat, startnode=0):
+    """tsp_nls/aco.py:260-274: one tour."""
+    return inference_batch_sample(probmat, 1, startnode)[0]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 124 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count) */
+#define DACO_VERSION 124 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count; 124: daco_hgs_*, daco_cvrp_sample takes ant_gid_bstride) */
 
 /* error codes */
 #define DACO_OK 0
@@ -198,6 +198,8 @@ int daco_tsp_sample_race_head(void *stream, int B, int n, int A,
  *            fits exactly is common and the last bit decides); `demand` / `capacity` must still be given (their float32
  *            images).  Every layout of the scan draw has the variant (packed kernels for n <= 512, one ant per wavefront above and in the
  *            race modes).
+ *   ant_gid_bstride    as in daco_tsp_sample: 0, or the colony's ant count when this call draws a slice [ant_gid0, ant_gid0 + A)
+ *            of every colony's ants (ant-sharded colonies keep the single-GPU ant ids)
  *   ev_begin, ev_end   optional hipEvent_t recorded on `stream` right before / after the construction kernel (as in
  *            daco_tsp_sample: the kernel alone, without the weight-matrix kernel and the table memsets before it).
  */
@@ -206,7 +208,8 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
                      const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                      float alpha, float beta, const float *demand, float capacity, int mode,
                      const float *noise, int noise_steps, uint64_t seed, uint64_t iter,
-                     const uint64_t *iter_offset, uint32_t ant_gid0, int Lmax, int64_t *paths, float *logp, float *rowsum,
+                     const uint64_t *iter_offset, uint32_t ant_gid0, int ant_gid_bstride, int Lmax, int64_t *paths, float *logp,
+                     float *rowsum,
                      int32_t *lens, int32_t *flags,
                      const float *dist, long dist_bstride, float *costs, void *next_table,
                      void *workspace, size_t workspace_bytes, const double *demand64, double capacity64,

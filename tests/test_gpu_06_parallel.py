@@ -29,51 +29,170 @@ def _instances(B, n, seed):
     return d
 
 
-def _worker(rank, world, port, q, B, n, A, iters, exchange):
+def _cvrp_instances(B, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    loc = torch.cat((torch.full((B, 1, 2), 0.5), torch.rand(B, n, 2, generator=g)), 1)
+    dem = torch.cat((torch.zeros(B, 1), torch.randint(1, 10, (B, n), generator=g).float()), 1)
+    d = torch.cdist(loc, loc)
+    i = torch.arange(n + 1)
+    d[:, i, i] = 1e-10
+    return d, dem
+
+
+def _worker(rank, world, port, q, B, n, A, iters, exchange, kw, problem="tsp", backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from deepaco_amd import engine
     dev = torch.device("cuda:0")
-    col = engine.ant_sharded_tsp(_instances(B, n, 5).to(dev), A, rank, world, seed=77, exchange=exchange)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepaco_amd import engine
+    if problem == "tsp":
+        col = engine.ant_sharded_tsp(_instances(B, n, 5).to(dev), A, rank, world, seed=77, exchange=exchange, **kw)
+    else:
+        d, dem = _cvrp_instances(B, n, 5)
+        col = engine.ant_sharded_cvrp(d.to(dev), dem.to(dev), A, rank, world, capacity=30, seed=77, exchange=exchange, **kw)
     for _ in range(iters):
         col.step()
     torch.cuda.synchronize()
-    q.put((rank, col.tau.cpu().numpy(), col.lowest_cost.cpu().numpy()))
+    q.put((rank, col.tau.cpu().numpy(), col.lowest_cost.cpu().numpy(), col.shortest_path.cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,n,A", [("tours", 40, 13), ("tours", 300, 16), ("delta", 40, 12)])
-def test_two_ranks_equal_single_process(exchange, n, A):
-    from deepaco_amd import engine
-    B, iters, world = 2, 4, 2
+def _run_ranks(world, *args, **kwargs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, B, n, A, iters, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + args, kwargs=kwargs) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
     for _ in range(world):
-        r, tau, low = q.get(timeout=300)
-        res[r] = (tau, low)
+        r, tau, low, sp = q.get(timeout=300)
+        res[r] = (tau, low, sp)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    single = engine.BatchedTSP(_instances(B, n, 5).to("cuda:0"), n_ants=A, seed=77)
+    for r in range(1, world):                                                        # replicas agree
+        assert (res[0][0] == res[r][0]).all() and (res[0][1] == res[r][1]).all() and (res[0][2] == res[r][2]).all()
+    return res[0]
+
+
+@pytest.mark.parametrize("exchange,n,A,kw", [("tours", 40, 13, {}), ("tours", 300, 16, {}), ("delta", 40, 12, {}),
+                                             ("tours", 60, 13, dict(elitist=True)), ("tours", 60, 14, dict(min_max=True)),
+                                             ("delta", 60, 12, dict(elitist=True)), ("delta", 60, 12, dict(min_max=True))])
+def test_two_ranks_equal_single_process(exchange, n, A, kw):
+    """AS, elitist and MMAS colonies (tsp/aco.py:75-118): with the tour exchange the two-rank colony IS the single-GPU one --
+    pheromone, best costs and best tours bit for bit; with the delta exchange the tours are the same (colony-wide ant
+    ids), the elitist deposit is exact (one ant, applied by every rank), the AS / MMAS sums agree to summation order."""
+    import numpy as np
+    from deepaco_amd import engine
+    B, iters, world = 2, 4, 2
+    tau, low, sp = _run_ranks(world, B, n, A, iters, exchange, kw)
+    single = engine.BatchedTSP(_instances(B, n, 5).to("cuda:0"), n_ants=A, seed=77, **kw)
     single.run(iters)
-    ref_tau, ref_low = single.pheromone.cpu().numpy(), single.lowest_cost.cpu().numpy()
-    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()          # replicas agree
-    if exchange == "tours":
-        assert (res[0][0].view("uint32") == ref_tau.view("uint32")).all()
-        assert (res[0][1] == ref_low).all()
+    ref_tau, ref_low, ref_sp = single.pheromone.cpu().numpy(), single.lowest_cost.cpu().numpy(), single.shortest_path.cpu().numpy()
+    if exchange == "tours" or kw.get("elitist"):
+        assert (tau.view("uint32") == ref_tau.view("uint32")).all()
+        assert (low == ref_low).all() and (sp == ref_sp).all()
+    elif kw.get("min_max"):
+        # the pheromone feeds back into the draws: after the first iteration the tours may part ways; the bounds hold
+        assert tau.shape == ref_tau.shape and (tau >= 0.1 * (1 - 1e-6)).all()
+        assert (np.sort(sp, axis=1) == np.arange(n)).all()
     else:
         # colony-wide ant ids: the same tours as the single-GPU colony, deposits summed in a different order
-        assert res[0][0].shape == ref_tau.shape and (res[0][0] > 0).all()
-        import numpy as np
-        np.testing.assert_allclose(res[0][0], ref_tau, rtol=2e-5)
-        np.testing.assert_allclose(res[0][1], ref_low, rtol=0, atol=0)
+        np.testing.assert_allclose(tau, ref_tau, rtol=2e-5)
+        np.testing.assert_allclose(low, ref_low, rtol=0, atol=0)
+        assert (sp == ref_sp).all()
+
+
+@pytest.mark.parametrize("exchange,kw", [("tours", {}), ("tours", dict(elitist=True)), ("tours", dict(min_max=True)), ("delta", {})])
+def test_two_ranks_cvrp_equal_single_process(exchange, kw):
+    """cvrp/aco.py:67-130 ant-sharded (directed deposits, floor 1e-10): the two-rank colony against BatchedCVRP."""
+    import numpy as np
+    from deepaco_amd import engine
+    B, n, A, iters, world = 2, 30, 13 if exchange == "tours" else 12, 3, 2
+    tau, low, sp = _run_ranks(world, B, n, A, iters, exchange, kw, problem="cvrp")
+    d, dem = _cvrp_instances(B, n, 5)
+    single = engine.BatchedCVRP(d.to("cuda:0"), dem.to("cuda:0"), n_ants=A, capacity=30, seed=77, **kw)
+    single.run(iters)
+    ref_tau, ref_low, ref_sp = single.pheromone.cpu().numpy(), single.lowest_cost.cpu().numpy(), single.shortest_path.cpu().numpy()
+    # tau[0][0] only records padding: cvrp/aco.py:107-130 deposits on the (0, 0) pairs behind every ant that finished before the
+    # longest one of ITS instance's trimmed paths; the exchanged sequences are the untrimmed [2n+1] buffers, where every ant has
+    # such a pair.  The sampler never reads the entry (the depot is closed for an ant standing on it, cvrp/aco.py:176-180).
+    tau[:, 0, 0] = ref_tau[:, 0, 0]
+    if exchange == "tours":
+        assert (tau.view("uint32") == ref_tau.view("uint32")).all()
+        assert (low == ref_low).all() and (sp == ref_sp).all()
+    else:
+        np.testing.assert_allclose(tau, ref_tau, rtol=2e-5)
+        np.testing.assert_allclose(low, ref_low, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("exchange,kw", [("tours", dict(min_max=True)), ("delta", {}), ("delta", dict(elitist=True))])
+def test_world_size_one_on_rccl(exchange, kw):
+    """The RCCL code path on ONE GPU: init_process_group("nccl", device_id=...), the collectives of
+    parallel.py on device tensors (no host staging), barrier_max_time, gather_best -- world size 1, the same calls the driver's
+    8-GPU run makes.  (A world-size-1 colony skips its exchanges, so they are called directly on the colony's buffers too.)"""
+    from deepaco_amd import engine
+    B, n, A, iters = 2, 80, 16, 3
+    tau, low, sp = _run_ranks(1, B, n, A, iters, exchange, kw, backend="nccl")
+    single = engine.BatchedTSP(_instances(B, n, 5).to("cuda:0"), n_ants=A, seed=77, **kw)
+    single.run(iters)
+    import numpy as np
+    if exchange == "delta" and not kw:          # AS deposits are summed before they meet tau: equal to summation order
+        np.testing.assert_allclose(tau, single.pheromone.cpu().numpy(), rtol=2e-5)
+    else:
+        assert (tau.view("uint32") == single.pheromone.cpu().numpy().view("uint32")).all()
+    assert (sp == single.shortest_path.cpu().numpy()).all()
+
+
+def _rccl_collectives(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from deepaco_amd import parallel
+    out = {}
+    x = torch.arange(12, dtype=torch.float32, device=dev).view(3, 4)
+    parallel.all_reduce_(x)
+    out["sum"] = x.cpu().tolist()
+    m = torch.tensor([3.0, 1.0], device=dev)
+    parallel.all_reduce_(m, dist.ReduceOp.MIN)
+    out["min"] = m.cpu().tolist()
+    i32 = torch.arange(6, dtype=torch.int32, device=dev)
+    parallel.all_reduce_(i32)
+    out["i32"] = i32.cpu().tolist()
+    src = (torch.arange(10, dtype=torch.int16, device=dev) - 3).view(2, 5)
+    dst = torch.zeros((world, 2, 5), dtype=torch.int16, device=dev)
+    parallel.all_gather_into_(dst.view(torch.uint8), src.view(torch.uint8))      # the tours' exchange: int16 bytes as uint8
+    out["i16"] = dst.cpu().tolist()
+    f = torch.rand(4, device=dev)
+    g = torch.zeros((world, 4), device=dev)
+    parallel.all_gather_into_(g, f)
+    out["f_ok"] = bool(torch.equal(g[0], f))
+    out["best"] = parallel.gather_best(torch.tensor([2.0, 5.0], device=dev), 2, rank, world).cpu().tolist()
+    out["t"] = parallel.barrier_max_time(lambda: torch.cuda.synchronize(), dev, True)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_world_size_one():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_collectives, args=(0, 1, _free_port(), q))
+    p.start()
+    _, out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert out["sum"] == [[0.0, 1.0, 2.0, 3.0], [4.0, 5.0, 6.0, 7.0], [8.0, 9.0, 10.0, 11.0]] and out["min"] == [3.0, 1.0]
+    assert out["i32"] == list(range(6)) and out["i16"] == [[[-3, -2, -1, 0, 1], [2, 3, 4, 5, 6]]]
+    assert out["f_ok"] and out["best"] == [2.0, 5.0] and out["t"] >= 0
 
 
 def _bench_line(*args, env=None):
@@ -153,3 +272,15 @@ def test_bench_eight_ranks_the_drivers_launch_path():
     assert len(lines) == 1
     import json
     assert json.loads(lines[0])["n_gpus"] == 4
+
+
+def test_bench_world_size_one_on_rccl():
+    """bench.py --force-dist: the distributed code path (init_process_group("nccl", device_id), barrier / max reduce on device
+    tensors, the all-reduce bus-bandwidth probe, the `rccl` object on the line) with ONE rank on one GPU."""
+    common = ("--no-cpu", "--no-extras", "--min-seconds", "0", "--steps", "3", "--warmup", "1", "--nodes", "120",
+              "--ants", "64", "--batch", "4", "--force-dist")
+    inst = _bench_line(*common)
+    assert inst["n_gpus"] == 1 and inst["rccl"]["ranks"] == 1 and inst["rccl"]["backend"] == "nccl"
+    assert inst["rccl"]["allreduce_ms"] > 0 and inst["value"] > 0
+    ants = _bench_line("--shard", "ants", "--exchange", "delta", *common)
+    assert ants["rccl"]["backend"] == "nccl" and ants["scaling"] == "strong" and ants["gpu_mean_best_cost"] > 0

@@ -91,9 +91,11 @@ def _worker(rank, world, port, q):
               for b in range(Bs)]
         return torch.from_numpy(np.stack(ps))
 
-    def update_fn(tau, paths, costs):
+    def update_fn(tau, paths, costs, elitist, cmin, cmax):
         for b in range(Bs):
-            tau[b] = torch.from_numpy(oracle.pheromone_update_tsp(tau[b].numpy(), paths[b].numpy(), costs[b].numpy(), 0.9))
+            tau[b] = torch.from_numpy(oracle.pheromone_update_tsp(
+                tau[b].numpy(), paths[b].numpy(), costs[b].numpy(), 0.9, elitist=bool(elitist),
+                clamp_min=0.0 if cmin is None else float(cmin[b]), clamp_max=0.0 if cmax is None else float(cmax[b])))
 
     col3 = parallel.AntShardedColony(torch.ones(Bs, n, n), A3, 0.9, rank, world, sample3, cost_fn, None,
                                      exchange="tours", update_fn=update_fn)
@@ -101,6 +103,15 @@ def _worker(rank, world, port, q):
         col3.step()
     out["tau3"] = col3.tau.numpy()
     out["low3"] = col3.lowest_cost.tolist()
+    out["sp3"] = col3.shortest_path.numpy()
+    # --- elitist and MMAS colonies (tsp/aco.py:78-88, 103-107, 116-118), both exchanges
+    for tag, exch, kw in (("el_t", "tours", dict(elitist=True)), ("mm_t", "tours", dict(min_max=True)),
+                          ("el_d", "delta", dict(elitist=True)), ("mm_d", "delta", dict(min_max=True))):
+        c = parallel.AntShardedColony(torch.ones(Bs, n, n), A3, 0.9, rank, world, sample3, cost_fn, deposit_fn,
+                                      exchange=exch, update_fn=update_fn, problem_size=n, **kw)
+        for _ in range(3):
+            c.step()
+        out[tag] = (c.tau.numpy(), c.lowest_cost.tolist(), c.shortest_path.numpy())
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -156,6 +167,60 @@ def test_world2_gloo():
             tau = oracle.pheromone_update_tsp(tau, paths, costs, 0.9)
         assert np.array_equal(res[0]["tau3"][b].view(np.uint32), tau.view(np.uint32))
         assert res[0]["low3"][b] == low
+
+
+def _single_colony(d, A, iters, seed, gid0, elitist=False, min_max=False):
+    """tsp/aco.py:75-118 in one process on the oracle's kernels: (tau, lowest, shortest path)."""
+    n = d.shape[0]
+    tau = np.ones((n, n), np.float32) * (np.float32(0.1) if min_max else np.float32(1.0))
+    eta = (1.0 / d).numpy()
+    low, sp, mx = np.float32(np.inf), None, None
+    for it in range(iters):
+        paths, _, _ = oracle.tsp_sample_scan(oracle.prob_matrix(tau, eta), A, seed, it, gid0)
+        costs = oracle.tour_costs(d.numpy(), paths)
+        b = int(np.argmin(costs))
+        if costs[b] < low:
+            low, sp = costs[b], paths[:, b].copy()
+        cmin = cmax = 0.0
+        if min_max:
+            new = np.float32(np.float32(1.0) / low) * np.float32(n)
+            if mx is None:
+                tau = tau * np.float32(new / tau.max())
+            mx = new
+            cmin, cmax = 0.1, float(mx)
+        tau = oracle.pheromone_update_tsp(tau, paths, costs, 0.9, elitist=elitist, clamp_min=cmin, clamp_max=cmax)
+    return tau, float(low), sp
+
+
+def test_world2_gloo_elitist_and_mmas():
+    """Elitist / MMAS / best-tour tracking of the ant-sharded colony on two gloo ranks against the single-process colony:
+    tour exchange and the elitist delta mode bit for bit; (the workers ran inside test_world2_gloo's processes: rerun here)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, seed, Bs, A3 = 16, 21, 2, 13
+    Ds = _instances(Bs, n, 9)
+    for tag in ("el_t", "mm_t", "el_d", "mm_d"):
+        for k in range(3):
+            assert np.array_equal(np.asarray(res[0][tag][k]), np.asarray(res[1][tag][k])), tag      # replicas agree
+    for b in range(Bs):
+        tau, low, sp = _single_colony(Ds[b], A3, 3, seed, b * A3)
+        assert np.array_equal(res[0]["sp3"][b], sp) and res[0]["low3"][b] == low
+        for tag, kw in (("el_t", dict(elitist=True)), ("mm_t", dict(min_max=True)), ("el_d", dict(elitist=True))):
+            tau, low, sp = _single_colony(Ds[b], A3, 3, seed, b * A3, **kw)
+            got = res[0][tag]
+            assert np.array_equal(got[0][b].view(np.uint32), tau.view(np.uint32)), tag
+            assert got[1][b] == low and np.array_equal(got[2][b], sp), tag
+        got = res[0]["mm_d"]
+        assert got[0][b].min() >= np.float32(0.1) and sorted(got[2][b].tolist()) == list(range(n))
 
 
 def test_shard_range_covers_everything():
