@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations")
     ap.add_argument("--cpu-instances", type=int, default=0,
                     help="colonies of the cpu_baseline leg, side by side (0 = min(instances, host CPUs // 4))")
-    ap.add_argument("--cpu-iters", type=int, default=3,
+    ap.add_argument("--cpu-iters", type=int, default=10,
                     help="colony iterations of every cpu_baseline colony (the best-cost gap is taken at this many iterations)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="safety stop of a cpu_baseline colony")
     ap.add_argument("--config", default="headline", choices=["headline", "c5"],
@@ -139,7 +139,7 @@ def headline_record(full):
         rec["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:400]
     g = full.get("best_cost_gap")
     if g:
-        rec["best_cost_gap"] = {k: g.get(k) for k in ("gap", "ci95", "gpu_mean_best", "cpu_mean_best", "instances", "iterations")
+        rec["best_cost_gap"] = {k: g.get(k) for k in ("gap", "ci95", "equal_or_better", "gpu_mean_best", "cpu_mean_best", "instances", "iterations")
                                 if k in g}
     for k in ("speedup_vs_cpu", "gpu_mean_best_cost"):
         if k in full:
@@ -1185,17 +1185,28 @@ def worker(args):
             ncol = args.cpu_instances or max(1, min(B, 16, (os.cpu_count() or 1) // 2))
             cb, cpu_best, done = cpu_baseline(dist_cpu, k_sparse, A, ncol, args.cpu_iters, budget_s=args.cpu_seconds)
             line["cpu_baseline"] = cb
-            # best-cost gap: the same instances, equal iterations, fresh GPU colonies
+            # best-cost gap: the same instances, equal iterations, fresh GPU colonies; paired per instance, with the 95 % interval
+            # of the mean relative difference (Student t): "equal or better" = the interval contains 0 or lies below it
             ni = len(cpu_best)
             gcol = engine.BatchedTSP(dist_cpu[:ni].to(dev), n_ants=A, sampler=args.sampler, seed=99)
             gcol.sparsify(k_sparse)
             gcol.run(done)
             gb = gcol.lowest_cost.cpu()
             cm = sum(cpu_best) / ni
+            rel = [(float(gb[i]) - cpu_best[i]) / cpu_best[i] for i in range(ni)]
+            mean_rel = sum(rel) / ni
+            sd = (sum((r - mean_rel) ** 2 for r in rel) / max(1, ni - 1)) ** 0.5
+            t975 = {1: 12.706, 2: 4.303, 3: 3.182, 4: 2.776, 5: 2.571, 6: 2.447, 7: 2.365, 8: 2.306, 9: 2.262, 10: 2.228, 11: 2.201,
+                    12: 2.179, 13: 2.160, 14: 2.145, 15: 2.131}.get(ni - 1, 2.0)
+            half = t975 * sd / ni ** 0.5 if ni > 1 else None
             line["best_cost_gap"] = {"gpu_mean_best": float(gb.mean()), "cpu_mean_best": cm,
                                      "gap": (float(gb.mean()) - cm) / cm, "instances": ni, "iterations": done,
+                                     "mean_paired_relative_difference": mean_rel,
+                                     "ci95": None if half is None else [mean_rel - half, mean_rel + half],
+                                     "equal_or_better": None if half is None else bool(mean_rel - half <= 0.0),
                                      "gpu_better_or_equal_on": int(sum(float(gb[i]) <= cpu_best[i] for i in range(ni))),
-                                     "note": "same instances, equal iterations, independent RNG streams"}
+                                     "note": "same instances, equal iterations, independent RNG streams; ci95 = mean +- t(0.975, n-1) s / sqrt(n) "
+                                             "of the per-instance (gpu - cpu) / cpu"}
             line["speedup_vs_cpu"] = value / cb["value"]
         emit(line)
     if distributed:
