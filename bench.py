@@ -54,7 +54,9 @@ def parse_args():
     ap.add_argument("--nodes", type=int, default=500)
     ap.add_argument("--ants", type=int, default=512)
     ap.add_argument("--batch", type=int, default=64, help="instances per GPU")
-    ap.add_argument("--sampler", default="scan", choices=["scan", "scan_wave", "race", "scan_sparse"])
+    ap.add_argument("--sampler", default="auto", choices=["auto", "scan", "scan_wave", "race", "scan_sparse"],
+                    help="auto (the colonies' default): the scan draw, on head / tail rows where they apply -- here they do: the "
+                         "heuristic is 1/d sparsified to k = n // 10 entries per row; scan: the dense scan")
     ap.add_argument("--k-sparse", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations")
@@ -149,6 +151,11 @@ def headline_record(full):
     if full.get("rccl"):
         rec["rccl"] = {k: v for k, v in full["rccl"].items() if not isinstance(v, (dict, list))}
     ex = full.get("extras")
+    if isinstance(ex, dict) and isinstance(ex.get("headline_scan_sparse"), dict) and "scan" in ex["headline_scan_sparse"]:
+        # the same workload on the dense scan (sampler="scan": whole rows), next to the default's head / tail rows
+        d_ = ex["headline_scan_sparse"]["scan"]
+        rec["dense_scan"] = {"value": d_.get("value"), "kernel_ms": d_.get("kernel_ms"),
+                             "roofline_frac": (d_.get("roofline") or {}).get("frac"), "kernel": "tsp_scan32_kernel"}
     if isinstance(ex, dict):
         # one number per extra configuration; the objects are in the file
         rec["extras"] = {k: (_r(v.get("value"), 4) if isinstance(v, dict) and "value" in v else
@@ -751,6 +758,10 @@ def extra_configs(dev, headline_colony, cpu=True):
                             "bound by it but by instruction issue (profiles/r04_scan_sparse_ablation.txt: without any memory "
                             "access the first version still took 0.72 of its time; 93 -> 35 VALU per wave-step bought 0.77 -> "
                             "0.58 ms); profiles/r04_pmc_scan_sparse.txt"}
+            else:
+                tr_, src_ = traffic.get(f"tsp{n}_a{A}_b{B}_scan", (None, None))
+                res[tag]["roofline"] = roofline_rows(n, A, B, "scan", kms, traffic=tr_, traffic_source=src_,
+                                                     pipes=counters.get(f"tsp{n}_a{A}_b{B}_scan"))
             del col
         res["speedup_whole_iteration"] = res["scan_sparse"]["value"] / res["scan"]["value"]
         out["headline_scan_sparse"] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, 1/d sparsified k={k}: sampler "
@@ -847,22 +858,31 @@ def extra_configs(dev, headline_colony, cpu=True):
             torch.cuda.synchronize()
             t_net.append((time.perf_counter() - t0) * 1e3)
         res = {}
-        for tag, kw in (("learned", dict(heuristic=heu)), ("vanilla_1_over_d_sparsified", {})):
+        # learned_on_head_rows: the colony's DEFAULT (sampler="auto": the network's heuristic is k-sparse, so the draws run on head /
+        # tail rows); learned_dense_scan: the same colony forced onto whole rows
+        for tag, kw in (("learned_on_head_rows", dict(heuristic=heu)), ("learned_dense_scan", dict(heuristic=heu, sampler="scan")),
+                        ("vanilla_1_over_d_sparsified_dense_scan", dict(sampler="scan"))):
             col = engine.BatchedTSP(dist, n_ants=A, seed=7, **kw)
-            if not kw:
+            if "heuristic" not in kw:
                 col.sparsify(k)
             col.heuristic = col.heuristic.contiguous()
             warm_colony(col)
-            dtl = time_launches(col.step, 10, warm=0)
+            ev = events(10)
+            t0 = time.perf_counter()
+            for s_ in range(10):
+                col.step(events=ev[s_])
+            torch.cuda.synchronize()
+            dtl = (time.perf_counter() - t0) / 10
+            kms = sum(a.elapsed_time(b) for a, b in ev) / 10
             col2 = engine.BatchedTSP(dist, n_ants=A, seed=7, **kw)
-            if not kw:
+            if "heuristic" not in kw:
                 col2.sparsify(k)
             best = []
             for T in (1, 10, 20):
                 col2.run(T - col2.iteration)
                 best.append(float(col2.lowest_cost.mean()))
-            res[tag] = {"value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3,
-                        "mean_best_cost_after_1_10_20_iterations": best}
+            res[tag] = {"value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3, "kernel_ms": kms,
+                        "sampler": list(col.resolved_sampler()), "mean_best_cost_after_1_10_20_iterations": best}
         out["headline_learned_heuristic"] = {
             "workload": f"TSP-{n}, n_ants={A}, {B} instances, heuristic = Net(pretrained tsp500) + 1e-10 vs 1/d sparsified k={k}",
             "gnn_forward_plus_reshape_ms_for_the_batch": {"first_call": t_net[0], "steady": min(t_net[1:])}, **res}
@@ -888,11 +908,10 @@ def extra_configs(dev, headline_colony, cpu=True):
             heu = lnet.reshape_batch(n, ei, lnet.forward_batch(x, ei, ea, k_sparse=k)) + 1e-10
         res = {}
         # (learned_on_head_rows: the same heuristic through sampler "scan_sparse" -- the k live entries of a row are its head)
-        for tag, kw in (("learned", dict(heuristic=heu)), ("learned_on_head_rows", dict(heuristic=heu, sampler="scan_sparse")),
-                        ("vanilla_1_over_d_sparsified", {})):
+        for tag, kw in (("learned_dense_scan", dict(heuristic=heu, sampler="scan")), ("learned_on_head_rows", dict(heuristic=heu)),
+                        ("vanilla_1_over_d_sparsified_dense_scan", dict(sampler="scan"))):
             col = engine.BatchedTSP(dist, n_ants=A, seed=7, fixed_start=0, **kw)
-            col.head_k = k
-            if not kw:
+            if "heuristic" not in kw:
                 col.sparsify(k)
             col.heuristic = col.heuristic.contiguous()
             col.step()
@@ -900,9 +919,10 @@ def extra_configs(dev, headline_colony, cpu=True):
             col.run(10 - col.iteration)
             res[tag] = {"value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3,
                         "mean_best_cost_after_10_iterations": float(col.lowest_cost.mean())}
-            if kw.get("sampler") == "scan_sparse":
-                st = engine.tsp_sample_sparse(col.pheromone, col.heuristic, A, col._head_table(), seed=1, batch=B, fixed_start=0,
-                                              want_stats=True)[4].tolist()
+            res[tag]["sampler"] = list(col.resolved_sampler())
+            if col.resolved_sampler()[0] == "scan_sparse":
+                st = engine.tsp_sample_sparse(col.pheromone, col.heuristic, A, col._head_table(col.resolved_sampler()[1]), seed=1,
+                                              batch=B, fixed_start=0, want_stats=True)[4].tolist()
                 res[tag]["steps_dense_tailwalk_rejected_of"] = st + [B * A * (n - 1)]
             del col
         out["c5_learned_tsp1000_a2048_b8"] = {
@@ -1045,7 +1065,8 @@ def worker(args):
         sparse = torch.full_like(d_dev, 1e10)
         sparse.scatter_(2, idx, torch.gather(d_dev, 2, idx))
         colony = engine.ant_sharded_tsp(d_dev, A, rank, world, heuristic=(1 / sparse).contiguous(),
-                                        sampler=args.sampler, seed=1234, exchange=args.exchange)
+                                        sampler=args.sampler if args.sampler != "auto" else "scan", seed=1234,
+                                        exchange=args.exchange)
         _step = colony.step
         colony.step = lambda events=None: _step()
     streams = 1 if ant_sharded else max(1, min(args.streams, B))
@@ -1063,7 +1084,11 @@ def worker(args):
     if not ant_sharded:
         colony = make_colony(1234, rank * B * A)
 
-    log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler}")
+    if ant_sharded:
+        resolved = args.sampler if args.sampler != "auto" else "scan"
+    else:
+        resolved = (colony.cols[0] if streams > 1 else colony).resolved_sampler()[0]
+    log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler} -> {resolved}")
     pre_steps = 0
     if args.precondition_seconds > 0 and not ant_sharded:
         # a throw-away colony of the same shape keeps the device busy until its clocks have settled; the measured colony
@@ -1141,7 +1166,7 @@ def worker(args):
             rccl["allreduce_busbw_GBps"] = 2 * (world - 1) / world * nbytes / t_ar / 1e9
 
     if rank == 0:
-        traffic, tsrc = load_traffic().get(f"tsp{n}_a{A}_b{B}_{args.sampler}", (None, None))
+        traffic, tsrc = load_traffic().get(f"tsp{n}_a{A}_b{B}_{resolved}", (None, None))
         line = {
             "metric": "ant-tours/sec, TSP-500 n_ants=512", "value": value, "unit": "ant-tours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1149,8 +1174,9 @@ def worker(args):
             "scaling": "strong" if ant_sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"TSP-{n} random-Euclidean, n_ants={A}, {B} instances per GPU, "
-                                   f"AS update, heuristic 1/d sparsified k={k_sparse}, sampler={args.sampler}",
-                       "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": args.sampler,
+                                   f"AS update, heuristic 1/d sparsified k={k_sparse}, sampler={args.sampler}"
+                                   + (f" -> {resolved}" if resolved != args.sampler else ""),
+                       "nodes": n, "n_ants": A, "instances_per_gpu": B, "sampler": resolved,
                        "parallelism": f"{'ant' if ant_sharded else 'instance'}-sharded x{world}",
                        "streams_per_gpu": streams,
                        "streams": (f"{streams} colonies of {B // streams}-{-(-B // streams)} instances on {streams} HIP streams per GPU "
@@ -1158,11 +1184,11 @@ def worker(args):
                        else "one colony over all instances"},
             # per LAUNCH of the construction kernel: B / streams instances (the counter passes are of one launch over all B
             # instances of the same kernel: their per-launch byte counts are scaled, their occupancies are ratios)
-            "roofline": roofline_rows(n, A, B / streams, args.sampler, kern_ms,
+            "roofline": roofline_rows(n, A, B / streams, resolved, kern_ms,
                                       traffic=traffic / streams if traffic is not None else None,
                                       traffic_source=(tsrc + f"; one launch here covers 1/{streams} of the instances of that pass: scaled"
                                                       if tsrc and streams > 1 else tsrc),
-                                      pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{args.sampler}"), head_k=k_sparse)
+                                      pipes=load_counters().get(f"tsp{n}_a{A}_b{B}_{resolved}"), head_k=k_sparse)
             if kern_ms else None,
             "knobs": active_knobs(),
             "preconditioning": {"steps": pre_steps, "seconds": args.precondition_seconds,

@@ -46,8 +46,8 @@ SIGNATURES = {
     "daco_gnn_workspace_bytes": (_sz, [_i, _i]),
     "daco_gnn_forward": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "daco_gnn_train_workspace_bytes": (_sz, [_i, _i, _i]),
-    "daco_gnn_train_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
-    "daco_gnn_train_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "daco_gnn_train_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "daco_gnn_train_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "daco_cvrp_local_search": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _f, _vp, _i, _vp, _vp]),
     "daco_hgs_table_bytes": (_sz, [_i, _i]),
     "daco_hgs_prepare": (_i, [_vp, _i, _i, _vp, _l, _i, _vp]),

@@ -72,6 +72,15 @@ __global__ void gnn_t_stat_table(int G, int count, const double *sums, float2 *t
   tab[idx] = make_float2((float)m, (float)(1.0 / sqrt(v + (double)BN_EPS)));
 }
 
+// BatchNorm in evaluation mode (running statistics, the same for every graph): (mean, 1 / sqrt(var + eps)) from the caller's
+// [32][2] (mean, var) block into the table of all G graphs
+__global__ void gnn_t_fixed_table(int G, const float *fixed, float2 *tab) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * 32) return;
+  const int c = idx & 31;
+  tab[idx] = make_float2(fixed[c * 2], (float)(1.0 / sqrt((double)fixed[c * 2 + 1] + (double)BN_EPS)));
+}
+
 // ------------------------------------------------------------------ forward
 // ze = w We^T + be + x3[src] + x4[dst] for one 32-edge tile per wave; channel sums of the tile -> f64 atomics
 __global__ void __launch_bounds__(256)
@@ -739,8 +748,8 @@ static int check_train_args(const char *what, int n, int E, int feats, int G) {
 
 extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
                                       const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const float *edge_attr,
-                                      const float *params, float *heu, float *stats_out, void *workspace,
-                                      size_t workspace_bytes) {
+                                      const float *params, float *heu, float *stats_out, const float *fixed_stats,
+                                      void *workspace, size_t workspace_bytes) {
   if (int rc = check_train_args("daco_gnn_train_forward", n, E, feats, G)) return rc;
   if (!x || !src || !dst || !rowptr || !edge_attr || !params || !heu || !workspace) { set_error("daco_gnn_train_forward: null pointer"); return DACO_E_BADARG; }
   if (workspace_bytes < daco_gnn_train_workspace_bytes(n, E, G)) { set_error("daco_gnn_train_forward: workspace too small"); return DACO_E_WORKSPACE; }
@@ -760,8 +769,13 @@ extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int
     const unsigned tb = (unsigned)((G * 32 + 255) / 256);
     hipLaunchKernelGGL(gnn_t_edge_pre, dim3(tile_blocks), dim3(256), 0, s, E, Eg, src, dst, We, be, t.X[l], t.w[l], t.ze[l], fe);
     hipLaunchKernelGGL(gnn_t_node_pre, dim3(node_blocks), dim3(256), 0, s, n, ng, dst, rowptr, perm, t.X[l], t.w[l], t.zv[l], fv);
-    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, fe, fte, 0);
-    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, fv, ftv, 0);
+    if (fixed_stats) {   // evaluation-mode BatchNorm: the caller's running statistics ([12][2 (e, v)][32][2 (mean, var)])
+      hipLaunchKernelGGL(gnn_t_fixed_table, dim3(tb), dim3(256), 0, s, G, fixed_stats + ((size_t)l * 2 + 0) * 64, fte);
+      hipLaunchKernelGGL(gnn_t_fixed_table, dim3(tb), dim3(256), 0, s, G, fixed_stats + ((size_t)l * 2 + 1) * 64, ftv);
+    } else {
+      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, fe, fte, 0);
+      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, fv, ftv, 0);
+    }
     hipLaunchKernelGGL(gnn_t_edge_post, dim3(ew_blocks), dim3(256), 0, s, E, Eg, ge, bee, fte, t.w[l], t.ze[l], t.w[l + 1]);
     const float *WTn = l < 11 ? params + t_off_layer(feats, l + 1) : nullptr;
     hipLaunchKernelGGL(gnn_t_node_post, dim3(node_blocks), dim3(256), 0, s, n, ng, gv, bv_, ftv, t.x[l], t.zv[l], t.x[l + 1], WTn,
@@ -778,7 +792,8 @@ extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int
 extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
                                        const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const int32_t *rowptr_dst,
                                        const int32_t *perm_dst, const float *edge_attr, const float *params, const float *heu,
-                                       const float *grad_heu, float *grad_params, void *workspace, size_t workspace_bytes) {
+                                       const float *grad_heu, float *grad_params, int fixed_stats, void *workspace,
+                                       size_t workspace_bytes) {
   if (int rc = check_train_args("daco_gnn_train_backward", n, E, feats, G)) return rc;
   if (!x || !src || !dst || !rowptr || !edge_attr || !params || !heu || !grad_heu || !grad_params || !workspace) { set_error("daco_gnn_train_backward: null pointer"); return DACO_E_BADARG; }
   if (workspace_bytes < daco_gnn_train_workspace_bytes(n, E, G)) { set_error("daco_gnn_train_backward: workspace too small"); return DACO_E_WORKSPACE; }
@@ -821,8 +836,12 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     const unsigned tb = (unsigned)((G * 32 + 255) / 256);
     hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((E + 255) / 256), dim3(256), 0, s, E, Eg, ge, bee, fte, t.ze[l], t.gw, be_s);
     hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((n + 255) / 256), dim3(256), 0, s, n, ng, gv, bv_, ftv, t.zv[l], t.gx, bv_s);
-    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, be_s, bte, 1);
-    hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, bv_s, btv, 1);
+    if (fixed_stats) {   // the statistics were constants of the forward: g_z = gamma * rstd * g_y, no batch terms
+      if (hipMemsetAsync(t.btab, 0, (size_t)2 * G * 32 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    } else {
+      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, be_s, bte, 1);
+      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, bv_s, btv, 1);
+    }
     hipLaunchKernelGGL(gnn_t_node_bwd_apply, dim3(node_blocks), dim3(256), 0, s, n, ng, rowptr, gv, bv_, ftv, btv, t.zv[l], t.gx,
                        t.gX, t.gmsg);
     hipLaunchKernelGGL(gnn_t_edge_bwd, dim3(egrid), dim3(256), 0, s, E, Eg, src, dst, We, ge, bee, fte, bte, t.X[l], t.w[l], t.ze[l],

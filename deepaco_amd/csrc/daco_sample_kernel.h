@@ -49,7 +49,6 @@ struct SampleParams {
   int Lmax;              // rows of paths (and Lmax-1 rows of logp)
   int noise_steps;       // rows of the noise tensor
   int32_t *lens;         // [B][A] rows used by each ant
-  int knob = 0;          // measurement knob of a kernel (0 in production)
   // head / tail rows (daco_scan_sparse.hip)
   const float *hval = nullptr;       // [B][n] head rows of this iteration: 16 lanes x {SPL f32 values, SPL u16 ids} (sparse_prepass_kernel)
   const uint16_t *hid = nullptr;     // the caller's head table [B][n][slots] (the pre-pass reads it; the scan reads the head rows)

@@ -66,10 +66,12 @@ sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const
   float *pr = P + row * ld;
   const int kh = 16 * spl, ls = sp_lane_bytes(spl);
   const uint16_t *ids = hid + row * kh;
-  const int cnt = ids[kh - 1];
+  // a malformed table (count beyond the slots, ids beyond the row) must not reach past the bitmap or the row:
+  // the count is clamped, an id >= n is an empty slot.  (engine.sparse_head never produces either.)
+  const int cnt = ids[kh - 1] < kh - 1 ? ids[kh - 1] : kh - 1;
   if (lane < 32) bm[wave][lane] = 0u;
   __builtin_amdgcn_wave_barrier();
-  for (int m = lane; m < cnt; m += 64) { const int id = ids[m]; atomicOr(&bm[wave][id >> 5], 1u << (id & 31)); }
+  for (int m = lane; m < cnt; m += 64) { const int id = ids[m]; if (id < n) atomicOr(&bm[wave][id >> 5], 1u << (id & 31)); }
   __builtin_amdgcn_wave_barrier();
   float part = RACE ? __builtin_inff() : 0.0f;
   const int ch = ld >> 8;
@@ -110,8 +112,8 @@ sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const
     T = readlane_f(wave_scan_add(part), 63);
   }
   for (int m = lane; m < kh; m += 64) {                         // slot m: lane m / spl of the row, element m % spl
-    const bool live = m < cnt;
     const int id = ids[m];
+    const bool live = m < cnt && id < n;
     const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
     float val;
     if constexpr (RACE) val = m == kh - 1 ? T : (live ? 1.0f / pid : __builtin_inff());

@@ -137,15 +137,6 @@ tsp_scan32_kernel(const SampleParams p) {
   _Float16 *fl = open_flags[wave * 2 + up];
   uint16_t *tour = tour_s[wave * 2 + up];
 
-  if (p.knob == 1) {
-    // EXPERIMENT: static issue priorities that differ between the waves of a SIMD (do the waves run in convoy?)
-    switch ((w * 2654435761u) >> 30) {
-      case 0: __builtin_amdgcn_s_setprio(0); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: __builtin_amdgcn_s_setprio(3); break;
-    }
-  }
   if (active) {
     const f16x8 ones = {1, 1, 1, 1, 1, 1, 1, 1};
 #pragma unroll
@@ -355,11 +346,8 @@ static hipError_t launch32(const SampleParams &sp, bool logp, hipStream_t s) {
   const int bpi = (sp.A + 7) / 8;
   dim3 grid((unsigned)(sp.B * bpi)), block(256);
   static const int pad = getenv("DACO_SCAN32_LDS_PAD") ? atoi(getenv("DACO_SCAN32_LDS_PAD")) : 0;
-  static const int knob = getenv("DACO_SCAN32_KNOB") ? atoi(getenv("DACO_SCAN32_KNOB")) : 0;
-  SampleParams spk = sp;
-  spk.knob = knob;
-  if (logp) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, true>), grid, block, pad, s, spk);
-  else hipLaunchKernelGGL((tsp_scan32_kernel<CH2, false>), grid, block, pad, s, spk);
+  if (logp) hipLaunchKernelGGL((tsp_scan32_kernel<CH2, true>), grid, block, pad, s, sp);
+  else hipLaunchKernelGGL((tsp_scan32_kernel<CH2, false>), grid, block, pad, s, sp);
   return hipGetLastError();
 }
 

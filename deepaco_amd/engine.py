@@ -134,12 +134,74 @@ def sparse_head(weights, k):
     B, n, _ = w.shape
     assert 1 <= k <= 127 and k <= n
     slots = 64 if k <= 63 else 128
-    # by value descending, then id ascending: a stable sort of the ids by descending value
-    order = torch.sort(w.to(torch.float64), dim=2, descending=True, stable=True).indices[:, :, :k]
+    # the k largest by (value descending, id ascending), without sorting the rows: everything above the k-th value,
+    # and of the entries equal to it the smallest ids; then the chosen ids ascending
+    v = w.detach().to(torch.float32)
+    kth = torch.topk(v, k, dim=2).values[:, :, k - 1:k]
+    greater = v > kth
+    eq = v == kth
+    room = k - greater.sum(dim=2, keepdim=True)
+    chosen = greater | (eq & (torch.cumsum(eq, dim=2) <= room))
+    ar = torch.arange(n, device=w.device, dtype=torch.int32).view(1, 1, n)
+    keys = torch.where(chosen, ar, ar + n)
     ids = torch.zeros((B, n, slots), dtype=torch.int64, device=w.device)
-    ids[:, :, :k] = torch.sort(order, dim=2).values
+    ids[:, :, :k] = torch.topk(keys, k, dim=2, largest=False, sorted=True).values
     ids[:, :, slots - 1] = k
     return ids.to(torch.int16).contiguous()          # (bit pattern of uint16: ids < 32768 here, n <= 1024)
+
+
+SPARSE_MIN_N, SPARSE_MAX_N = 129, 1024        # sizes daco_tsp_sample_sparse / _race_head cover
+
+
+def auto_head_k(heuristic, mass=0.98):
+    """Head size for sampler='auto' on a heuristic nobody sparsified by hand: 63 or 127 if that many largest entries hold at
+    least `mass` of EVERY row (the learned heuristic is k-sparse by construction: tsp/net.py:94-102 scatters k values per row
+    into zeros, + 1e-10), else None.  One reduction and one host read per heuristic object.
+    mass = 0.98: a step that has to leave the head re-reads the whole row for its ants (each such step stops four
+    ants for a row walk); with a fifth of the mass in the tail (plain 1/d at n = 200: 0.85 in the best 127) the head rows lose."""
+    h = heuristic.detach()
+    n = h.shape[-1]
+    if not (SPARSE_MIN_N <= n <= SPARSE_MAX_N):
+        return None
+    h = h.to(torch.float32)
+    top = torch.topk(h, min(127, n - 1), dim=-1).values
+    tot = h.sum(dim=-1)
+    f63 = (top[..., :63].sum(dim=-1) / tot).min()
+    f127 = (top.sum(dim=-1) / tot).min()
+    f63, f127 = float(f63), float(f127)
+    if f63 >= mass:
+        return 63
+    return 127 if f127 >= mass else None
+
+
+_warned_sparse_range = False
+
+
+def resolve_sampler(sampler, n, head_k, heuristic, cache):
+    """('scan' | 'scan_wave' | 'race' | 'scan_sparse', head size) for a colony of n nodes.
+    'auto': head / tail rows (scan_sparse: the same categorical as 'scan', 384 / 768 bytes per step instead of a row) whenever
+    they apply -- after sparsify(k), or when auto_head_k finds the heuristic concentrated -- and 129 <= n <= 1024; else the dense
+    scan.  An explicit 'scan_sparse' outside that range falls back to 'scan' with one warning.
+    cache: a dict of the colony (the concentration test is repeated only when the heuristic object changes)."""
+    global _warned_sparse_range
+    in_range = SPARSE_MIN_N <= n <= SPARSE_MAX_N
+    if sampler == "scan_sparse" and not in_range:
+        if not _warned_sparse_range:
+            _warned_sparse_range = True
+            import warnings
+            warnings.warn(f"sampler='scan_sparse' covers {SPARSE_MIN_N} <= n <= {SPARSE_MAX_N}; n = {n} runs the dense scan "
+                          f"(the same distribution)", RuntimeWarning, stacklevel=3)
+        return "scan", None
+    if sampler != "auto":
+        return sampler, head_k
+    if not in_range:
+        return "scan", None
+    if head_k is not None:
+        return "scan_sparse", head_k
+    hit = cache.get("auto_head")
+    if hit is None or hit[0] is not heuristic:
+        hit = cache["auto_head"] = (heuristic, auto_head_k(heuristic))
+    return ("scan_sparse", hit[1]) if hit[1] else ("scan", None)
 
 
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
@@ -797,8 +859,10 @@ class BatchedTSP:
     tracking is done on the device, so an iteration never synchronises with the host."""
 
     def __init__(self, distances, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
-                 pheromone=None, heuristic=None, min=None, sampler="scan", seed=None, ant_gid0=0,
+                 pheromone=None, heuristic=None, min=None, sampler="auto", seed=None, ant_gid0=0,
                  fixed_start=-1, local_search=None, inference=False):
+        """sampler: 'auto' (default: head / tail rows where they apply -- after sparsify(k) or on a concentrated heuristic,
+        129 <= n <= 1024 -- else the dense scan; resolve_sampler), 'scan', 'scan_wave', 'race', 'scan_sparse'."""
         _require_gpu(distances)
         assert distances.dim() == 3
         self.distances = _f32c(distances)
@@ -851,13 +915,19 @@ class BatchedTSP:
         self.head_k = min(int(k_sparse), 127)
         self._head = None
 
-    def _head_table(self):
+    def resolved_sampler(self):
+        """(kernel family this colony's next step runs, head size): see resolve_sampler."""
+        if getattr(self, "_auto", None) is None:
+            self._auto = {}
+        return resolve_sampler(self.sampler, self.n, self.head_k, self.heuristic, self._auto)
+
+    def _head_table(self, k=None):
         """(heuristic object it was built from, [B,n,64] head ids) for sampler='scan_sparse'."""
-        if self._head is None or self._head[0] is not self.heuristic:
-            k = self.head_k if self.head_k is not None else max(1, min(127, self.n // 10))
+        if self._head is None or self._head[0] is not self.heuristic or (k is not None and self._head[2] != k):
+            k = k if k is not None else (self.head_k if self.head_k is not None else max(1, min(127, self.n // 10)))
             h = self.heuristic.detach()
             h = h if h.dim() == 3 else h.unsqueeze(0).expand(self.B, self.n, self.n)
-            self._head = (self.heuristic, sparse_head(_f32c(h), k))
+            self._head = (self.heuristic, sparse_head(_f32c(h), k), k)
         return self._head[1]
 
     @torch.no_grad()
@@ -866,15 +936,16 @@ class BatchedTSP:
         # events: torch.cuda.Event pair re-recorded around the construction kernel; ls_events: a pair recorded (on the
         # current stream, which is the stream the library launches on) right before / after the local-search launches
         # sampler="race" after sparsify(k): the same tours from the head rows (daco_tsp_sample_race_head), an eighth of the noise
-        race_head = self.sampler == "race" and self.head_k is not None and 128 < self.n <= 1024
-        if self.sampler == "scan_sparse" or race_head:
-            paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, self._head_table(), self.alpha,
+        sampler, hk = self.resolved_sampler()
+        race_head = sampler == "race" and self.head_k is not None and 128 < self.n <= 1024
+        if sampler == "scan_sparse" or race_head:
+            paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, self._head_table(hk), self.alpha,
                                                      self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
                                                      dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head)
         else:
             paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
-                                                    self.beta, mode=self.sampler, seed=self.seed, it=self.iteration,
+                                                    self.beta, mode=sampler, seed=self.seed, it=self.iteration,
                                                     ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
                                                     batch=self.B, events=events, dist=self.distances, want_nbr=True,
                                                     iter_dev=_iter_dev)

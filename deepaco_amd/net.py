@@ -10,12 +10,12 @@ forward(pyg):
   * training mode -> daco_gnn_train_forward / daco_gnn_train_backward behind a torch.autograd.Function
     (csrc/daco_gnn_train.hip: BatchNorm on the statistics of the single graph, as in the reference
     tsp/net.py:21,24,43-44; MFMA linears and weight gradients; no library GEMM).  The BatchNorm running
-    statistics are updated from the statistics the kernels report.  `Net.train_backend = "torch"` (or
-    eval mode with gradients required) runs the same math as torch ops with autograd instead.
+    statistics are updated from the statistics the kernels report (every BatchNorm1d configuration: momentum, cumulative
+    average, no running statistics);
+  * eval mode with a gradient required -> the same kernels, the running statistics as constants (`fixed_stats`).
+There is no torch-op path in forward(): the module tree (EmbNet / ParNet.forward) stays callable for cross-checks only.
 `pyg` only needs `.x`, `.edge_index`, `.edge_attr` (torch_geometric is not required).
 """
-import warnings
-
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -162,7 +162,7 @@ class _GnnTrainFn(torch.autograd.Function):
     """heu = Net(graph) in training mode; the backward returns d loss / d (flat parameter block)."""
 
     @staticmethod
-    def forward(ctx, flat, x, attr, src, dst, rowptr, perm, feats, G):
+    def forward(ctx, flat, x, attr, src, dst, rowptr, perm, feats, G, fixed=None):
         # (perm may be None; the destination CSR is derived here, once per forward, for the backward)
         n, E = x.shape[0], src.numel()
         L = _lib.lib()
@@ -175,10 +175,11 @@ class _GnnTrainFn(torch.autograd.Function):
             flat = flat.detach().contiguous()
             rc = L.daco_gnn_train_forward(engine._stream(dev), n, E, feats, G, x.data_ptr(), src.data_ptr(), dst.data_ptr(),
                                           rowptr.data_ptr(), perm.data_ptr() if perm is not None else None, attr.data_ptr(),
-                                          flat.data_ptr(), heu.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel())
+                                          flat.data_ptr(), heu.data_ptr(), stats.data_ptr(),
+                                          fixed.data_ptr() if fixed is not None else None, ws.data_ptr(), ws.numel())
         _lib.check(rc, "daco_gnn_train_forward")
         ctx.save_for_backward(flat, x, attr, src, dst, rowptr, heu)
-        ctx.ws, ctx.feats, ctx.G, ctx.perm = ws, feats, G, perm
+        ctx.ws, ctx.feats, ctx.G, ctx.perm, ctx.fixed = ws, feats, G, perm, fixed is not None
         ctx.mark_non_differentiable(stats)
         return heu, stats
 
@@ -187,7 +188,7 @@ class _GnnTrainFn(torch.autograd.Function):
         if ctx.ws is None:
             raise RuntimeError("Net (HIP training path): the saved activations of this forward were already consumed by a "
                                "backward pass -- backward through the same forward a second time is not supported "
-                               "(run the forward again, or set Net.train_backend = 'torch')")
+                               "(run the forward again)")
         flat, x, attr, src, dst, rowptr, heu = ctx.saved_tensors
         n, E = x.shape[0], src.numel()
         L = _lib.lib()
@@ -199,11 +200,11 @@ class _GnnTrainFn(torch.autograd.Function):
             rc = L.daco_gnn_train_backward(engine._stream(dev), n, E, ctx.feats, ctx.G, x.data_ptr(), src.data_ptr(),
                                            dst.data_ptr(), rowptr.data_ptr(), perm.data_ptr() if perm is not None else None,
                                            None, None, attr.data_ptr(), flat.data_ptr(),
-                                           heu.data_ptr(), gheu.data_ptr(), gflat.data_ptr(), ctx.ws.data_ptr(),
+                                           heu.data_ptr(), gheu.data_ptr(), gflat.data_ptr(), int(ctx.fixed), ctx.ws.data_ptr(),
                                            ctx.ws.numel())
         _lib.check(rc, "daco_gnn_train_backward")
         ctx.ws = None
-        return (gflat,) + (None,) * 8
+        return (gflat,) + (None,) * 9
 
 
 class Net(nn.Module):
@@ -211,8 +212,6 @@ class Net(nn.Module):
     with_phe: also create the unused par_net_phe head that tsp/ checkpoints contain;
     node_update=False: the sop/ and smtwtp/ variant whose node states are never updated (sop/net.py:43).  The kernels
     run it as the same layer with the node BatchNorm's scale and shift set to zero: x + silu(0) = x exactly."""
-
-    train_backend = "hip"          # "torch": training forward/backward as torch ops + autograd (cross-check)
 
     def __init__(self, feats=2, with_phe=True, node_update=True):
         super().__init__()
@@ -223,33 +222,29 @@ class Net(nn.Module):
         self._packed = None
         self._packed_key = None
 
-    _warned_torch_path = False
-
     # ------------------------------------------------------------------ reference surface
     def forward(self, pyg):
-        x, edge_index, edge_attr = pyg.x, pyg.edge_index, pyg.edge_attr
+        """tsp/net.py:84-88.  Every mode runs on the HIP kernels:
+          training mode                        -> daco_gnn_train_forward / _backward, per-graph batch statistics (+ the running
+                                                  statistics' update, for every BatchNorm1d configuration)
+          eval mode under autograd             -> the same kernels with the running statistics as constants (fixed_stats)
+          eval mode without a gradient         -> daco_gnn_forward (BatchNorm folded into scale / shift)
+        (The module tree itself -- EmbNet / ParNet.forward as torch ops -- stays callable for cross-checks; forward() never is.)"""
+        x = pyg.x
         if not x.is_cuda:
             raise _lib.DacoError("deepaco_amd.Net runs on a HIP device only (got CPU tensors)")
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self.training and self.train_backend == "hip" and self._hip_train_supported():
-            return self.forward_train_hip(pyg)
         if self.training or needs_graph:
-            # the module tree evaluated with torch ops (rocBLAS GEMMs, autograd): a second backend on the product path, taken
-            # only where the HIP kernels have no implementation -- said once, so that nobody measures it by accident
-            if not Net._warned_torch_path and not (self.training and self.train_backend != "hip"):
-                Net._warned_torch_path = True
-                why = ("eval mode with autograd enabled: wrap the call in torch.no_grad() for the HIP inference kernels"
-                       if not self.training else "BatchNorm configured away from its defaults (momentum=None or no running statistics)")
-                warnings.warn(f"deepaco_amd.Net.forward: torch-op path ({why})", RuntimeWarning, stacklevel=2)
-            emb = self.emb_net(x, edge_index, edge_attr)
-            return self.par_net_heu(emb)
+            return self.forward_train_hip(pyg)
         return self.forward_hip(pyg)
 
-    def _hip_train_supported(self):
-        """The training kernels implement BatchNorm1d's default bookkeeping (running statistics tracked, a numeric momentum);
-        other configurations (momentum=None: cumulative average; track_running_stats=False) go through the torch ops."""
-        return all(bn.module.track_running_stats and bn.module.momentum is not None and bn.module.running_mean is not None
-                   for bn in list(self.emb_net.v_bns) + list(self.emb_net.e_bns))
+    def _bn_config(self):
+        """(tracks running statistics, momentum | None) -- one configuration for all BatchNorm modules of the network."""
+        bns = [bn.module for bn in list(self.emb_net.v_bns) + list(self.emb_net.e_bns)]
+        cfg = {(bool(bn.track_running_stats and bn.running_mean is not None), bn.momentum) for bn in bns}
+        if len(cfg) != 1:
+            raise _lib.DacoError("deepaco_amd.Net: the BatchNorm modules of one network must share track_running_stats / momentum")
+        return next(iter(cfg))
 
     def freeze_gnn(self):
         for param in self.emb_net.parameters():
@@ -287,30 +282,53 @@ class Net(nn.Module):
 
     @torch.no_grad()
     def _update_running_stats(self, stats, count_e, count_v):
-        """BatchNorm1d's training-mode side effect, from the statistics the kernels report: for each graph in turn
-        running = (1 - m) * running + m * batch (variance unbiased), as G successive reference forwards would do."""
+        """BatchNorm1d's training-mode side effect, from the statistics the kernels report, as G successive reference forwards
+        (one per graph) would leave it: momentum m: running = (1 - m) * running + m * batch per graph (variance unbiased);
+        momentum None (cumulative average): running = (k * running + sum of the batches) / (k + G), k = num_batches_tracked."""
+        tracks, momentum = self._bn_config()
+        if not tracks:
+            return
         G = stats.shape[2]
         for i in range(DEPTH):
             for which, bn, cnt in ((0, self.emb_net.e_bns[i].module, count_e), (1, self.emb_net.v_bns[i].module, count_v)):
                 if which == 1 and not self.emb_net.node_update:
                     continue                                  # the reference never calls these modules
-                m = bn.momentum if bn.momentum is not None else 0.1
-                decay = (1 - m) ** torch.arange(G - 1, -1, -1, device=stats.device, dtype=torch.float32)     # oldest graph first
                 mean, var = stats[i, which, :, :, 0], stats[i, which, :, :, 1] * (cnt / max(cnt - 1, 1))
-                bn.running_mean.mul_((1 - m) ** G).add_(m * (decay.view(G, 1) * mean).sum(0))
-                bn.running_var.mul_((1 - m) ** G).add_(m * (decay.view(G, 1) * var).sum(0))
+                if momentum is None:
+                    k = bn.num_batches_tracked.to(torch.float32)
+                    bn.running_mean.mul_(k).add_(mean.sum(0)).div_(k + G)
+                    bn.running_var.mul_(k).add_(var.sum(0)).div_(k + G)
+                else:
+                    m = momentum
+                    decay = (1 - m) ** torch.arange(G - 1, -1, -1, device=stats.device, dtype=torch.float32)     # oldest graph first
+                    bn.running_mean.mul_((1 - m) ** G).add_(m * (decay.view(G, 1) * mean).sum(0))
+                    bn.running_var.mul_((1 - m) ** G).add_(m * (decay.view(G, 1) * var).sum(0))
                 bn.num_batches_tracked += G
 
+    def _running_stats_block(self):
+        """[12][2][32][2] (mean, variance) of the edge (0) and node (1) BatchNorm of every layer: fixed_stats of the kernels."""
+        e = self.emb_net
+        rows = []
+        for i in range(DEPTH):
+            for bn in (e.e_bns[i].module, e.v_bns[i].module):
+                rows.append(torch.stack((bn.running_mean.float(), bn.running_var.float()), dim=1))
+        return torch.stack(rows).view(DEPTH, 2, UNITS, 2).contiguous()
+
     def forward_train_hip(self, pyg, graphs=1):
-        """Training-mode forward through the HIP kernels (graphs > 1: that many equal-sized graphs side by side,
-        each normalised with its own statistics).  Differentiable w.r.t. the parameters."""
+        """Differentiable forward through the HIP kernels (graphs > 1: that many equal-sized graphs side by side).  Training
+        mode: every graph is normalised with its own batch statistics; eval mode (a gradient through a module in eval()):
+        with the running statistics, as constants."""
         x = pyg.x.float().contiguous()
         n, feats = x.shape
         src, dst, rowptr, perm = _csr_graph(pyg, n, x.device)
         attr = pyg.edge_attr.float().contiguous().view(-1)
         flat = self.pack_params_train()
-        heu, stats = _GnnTrainFn.apply(flat, x, attr, src, dst, rowptr, perm, feats, graphs)
-        self._update_running_stats(stats, src.numel() // graphs, n // graphs)
+        tracks, _ = self._bn_config()
+        # BatchNorm1d normalises with the batch statistics in training mode -- and in eval mode too when it tracks none
+        fixed = self._running_stats_block() if (not self.training and tracks) else None
+        heu, stats = _GnnTrainFn.apply(flat, x, attr, src, dst, rowptr, perm, feats, graphs, fixed)
+        if self.training:
+            self._update_running_stats(stats, src.numel() // graphs, n // graphs)
         return heu
 
     def forward_batch_train(self, x, edge_index, edge_attr, k_sparse=None):

@@ -8,7 +8,10 @@ return layouts and attributes follow tsp/aco.py:4-177.  What differs is undernea
 construction, costing and the pheromone update are single launches of hand-written HIP
 kernels (libdeepaco_hip.so) instead of ~20 aten ops per step.  Extra keyword-only arguments:
 
-  sampler  'scan' (default): roulette draw by wavefront prefix scan, one Philox uniform per step
+  sampler  'auto' (default): the scan draw (roulette by wavefront prefix scan, one Philox uniform per step) -- on head / tail
+           rows ('scan_sparse': the same categorical from 384 / 768 bytes per step instead of a whole row) wherever they apply:
+           after sparsify(k), or when 63 / 127 entries hold >= 98 % of every heuristic row (the learned heuristic is k-sparse),
+           and 129 <= n <= 1024; 'scan' / 'scan_sparse' force one of them
            'race': the exponential race torch.multinomial runs, noise from Philox in-kernel
   seed     Philox key (default: torch.initial_seed(), so torch.manual_seed() governs the run)
 
@@ -46,7 +49,7 @@ class ACO():
                  min=None,
                  device='cpu',
                  *,
-                 sampler='scan',
+                 sampler='auto',
                  seed=None,
                  ):
         # device='cpu' + host tensors (the reference's test scripts): staged to the HIP device, see engine.stage_to_hip
@@ -98,12 +101,17 @@ class ACO():
         self.heuristic = 1 / sparse_distances
         self._head_k = min(int(k_sparse), 127)              # sampler='scan_sparse': the head of a row = these k entries
 
-    def _head_table(self):
-        """[1, n, 64] head ids for sampler='scan_sparse' (engine.sparse_head), once per heuristic object."""
+    def resolved_sampler(self):
+        """(sampler the next construction runs, head size): engine.resolve_sampler."""
+        cache = self.__dict__.setdefault("_auto", {})
+        return engine.resolve_sampler(self.sampler, self.problem_size, self.__dict__.get("_head_k"), self.heuristic, cache)
+
+    def _head_table(self, k=None):
+        """[1, n, 64 | 128] head ids for sampler='scan_sparse' (engine.sparse_head), once per heuristic object."""
         hit = self.__dict__.get("_head")
-        if hit is None or hit[0] is not self.heuristic:
-            k = self.__dict__.get("_head_k") or max(1, min(127, self.problem_size // 10))
-            hit = (self.heuristic, engine.sparse_head(self.heuristic.detach().float().contiguous(), k))
+        if hit is None or hit[0] is not self.heuristic or (k is not None and hit[2] != k):
+            k = k or self.__dict__.get("_head_k") or max(1, min(127, self.problem_size // 10))
+            hit = (self.heuristic, engine.sparse_head(self.heuristic.detach().float().contiguous(), k), k)
             self._head = hit
         return hit[1]
 
@@ -134,15 +142,16 @@ class ACO():
         tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
         eta = self.heuristic.detach()
         cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
-        sparse = self.sampler == "scan_sparse"              # head / tail rows (inference on a k-sparse heuristic, 129 <= n <= 1024)
+        sampler, hk = self.resolved_sampler()               # head / tail rows where they apply (a k-sparse heuristic, 129 <= n <= 1024)
+        sparse = sampler == "scan_sparse"
         for _ in range(n_iterations):
             if sparse:
                 paths, flags, costs, nbr = engine.tsp_sample_sparse(
-                    tau, eta, self.n_ants, self._head_table(), self.alpha, self.beta, fixed_start=self.FIXED_START,
+                    tau, eta, self.n_ants, self._head_table(hk), self.alpha, self.beta, fixed_start=self.FIXED_START,
                     seed=self.seed, it=self._calls, batch=1, dist=dist, want_nbr=True)
             else:
                 paths, _, _, flags, costs, nbr = engine.tsp_sample(
-                    tau, eta, self.n_ants, self.alpha, self.beta, mode=self.sampler,
+                    tau, eta, self.n_ants, self.alpha, self.beta, mode=sampler,
                     norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
                     dist=dist, want_nbr=True)
             self._calls += 1
@@ -224,6 +233,13 @@ class ACO():
             mode, start = "race_noise", _start
         else:
             mode, start = self.sampler, _start
+        hk = None
+        if mode in ("auto", "scan_sparse"):
+            # head / tail rows draw tours only: with log-probabilities (training) or prescribed start nodes the dense scan --
+            # the same categorical -- builds them
+            mode, hk = self.resolved_sampler()
+            if mode == "scan_sparse" and (require_prob or start is not None):
+                mode = "scan"
         fixed = self.FIXED_START
         if _noise is not None and start is None and fixed < 0:
             raise ValueError("noise injection needs the start nodes too (_start)")
@@ -239,6 +255,12 @@ class ACO():
                                                    self.seed, it)
             self._last_flags = flags
             return paths, logp
+        if mode == "scan_sparse":
+            paths, flags, _, _ = engine.tsp_sample_sparse(self.pheromone.detach(), self.heuristic.detach(), self.n_ants,
+                                                          self._head_table(hk), self.alpha, self.beta, fixed_start=fixed,
+                                                          seed=self.seed, it=it, batch=1)
+            self._last_flags = flags
+            return paths[0]
         paths, logp, rowsum, flags = engine.tsp_sample(
             self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha, self.beta, mode=mode,
             norm_passes=self.NORM_PASSES, start=start, fixed_start=fixed, noise=noise,
@@ -259,7 +281,8 @@ class ACO():
         key = (id(self.pheromone), self.pheromone._version, id(self.heuristic), self.heuristic._version)
         if getattr(self, "_pick_key", None) != key:
             self._pick_svc = engine.PickService(self.pheromone.detach(), self.heuristic.detach(), self.n_ants, self.alpha,
-                                                self.beta, mode="scan", seed=self.seed, it=self._calls)
+                                                self.beta, mode="race" if self.sampler == "race" else "scan", seed=self.seed,
+                                                it=self._calls)
             self._pick_key, self._pick_step = key, 0
             self._calls += 1
         self._pick_step += 1

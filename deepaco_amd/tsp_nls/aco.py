@@ -44,7 +44,7 @@ class ACO(_TspACO):
                  device='cpu',
                  local_search='nls',
                  *,
-                 sampler='scan',
+                 sampler='auto',
                  seed=None,
                  ):
         if not distances.is_cuda and str(device) != 'cpu':
@@ -58,7 +58,7 @@ class ACO(_TspACO):
     # ------------------------------------------------------------------ tsp_nls/aco.py:80-95
     def sample(self, inference=False):
         if inference:
-            paths = self.gen_path(require_prob=False, _sampler='scan')
+            paths = self.gen_path(require_prob=False, _sampler='auto')
             costs = self.gen_path_costs(paths)
             return costs, None, paths
         paths, log_probs = self.gen_path(require_prob=True)
@@ -82,7 +82,7 @@ class ACO(_TspACO):
     def run(self, n_iterations, inference=False):
         for _ in range(n_iterations):
             if inference:
-                paths = self.gen_path(require_prob=False, _sampler='scan')
+                paths = self.gen_path(require_prob=False, _sampler='auto')
             else:
                 paths = self.gen_path(require_prob=False)
 

@@ -450,6 +450,10 @@ int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, cons
  *   heu        out [E]
  *   stats_out  out [12][2][G][32][2] f32 or NULL: (mean, biased variance) of every BatchNorm (index 0 = edge BN,
  *              1 = node BN of the layer), for the caller's running-statistics update
+ *   fixed_stats (forward) NULL, or [12][2][32][2] f32 (mean, variance) per layer and BatchNorm (0 = edge, 1 = node): BatchNorm in
+ *              EVALUATION mode -- these running statistics normalise every graph instead of its own batch statistics (a
+ *              module in eval() whose output still needs a gradient); (backward) the same fact as a flag: the statistics
+ *              were constants, g_z = gamma * rstd * g_y
  *   workspace  daco_gnn_train_workspace_bytes(n, E, G) bytes; the forward leaves the activations the backward needs
  *              there: pass the SAME, untouched block to daco_gnn_train_backward
  *   grad_heu   [E] d loss / d heu;   grad_params out: d loss / d params, same layout as params
@@ -462,11 +466,12 @@ int daco_gnn_forward(void *stream, int n, int E, int feats, const float *x, cons
 size_t daco_gnn_train_workspace_bytes(int n, int E, int G);
 int daco_gnn_train_forward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
                            const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const float *edge_attr,
-                           const float *params, float *heu, float *stats_out, void *workspace, size_t workspace_bytes);
+                           const float *params, float *heu, float *stats_out, const float *fixed_stats, void *workspace,
+                           size_t workspace_bytes);
 int daco_gnn_train_backward(void *stream, int n, int E, int feats, int G, const float *x, const int32_t *src,
                             const int32_t *dst, const int32_t *rowptr, const int32_t *perm, const int32_t *rowptr_dst,
                             const int32_t *perm_dst, const float *edge_attr, const float *params, const float *heu,
-                            const float *grad_heu, float *grad_params, void *workspace, size_t workspace_bytes);
+                            const float *grad_heu, float *grad_params, int fixed_stats, void *workspace, size_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_cvrp_local_search -- replaces ACO.multiple_swap_star's per-ant CPU tasks

@@ -13,6 +13,15 @@ from test_net_host import make_net, load_weights, names
 
 pytestmark = pytest.mark.gpu
 
+
+def forward_as(net, pyg, backend):
+    """backend 'hip': Net.forward (always the HIP kernels).  'torch': the module tree evaluated as torch ops with autograd (EmbNet /
+    ParNet.forward: the op sequence of tsp/net.py:27-75) -- the cross-check these tests hold the kernels to; the product's
+    forward() never takes it."""
+    if backend == "hip":
+        return net(pyg)
+    return net.par_net_heu(net.emb_net(pyg.x, pyg.edge_index, pyg.edge_attr))
+
 ATOL_HEU = 1e-5        # SURVEY.md G5: heu[E] eval-mode, abs tol 1e-5 (the HIP path: fixed arithmetic, same on every box)
 ATOL_TORCH = 1e-4      # the torch-op path (rocBLAS GEMMs; kernel selection differs from box to box)
 
@@ -60,11 +69,9 @@ def test_net_train_mode_matches_reference(name):
     load_weights(net, g)
     net = net.to(dev()).train()
     for backend in ("hip", "torch"):                       # the HIP training kernels and the torch-op cross-check path
-        net.train_backend = backend
         with torch.no_grad():
-            heu = net(graph(g))
+            heu = forward_as(net, graph(g), backend)
         np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=ATOL_TORCH, rtol=5e-4, err_msg=backend)
-    net.train_backend = "hip"
 
 
 def _zero_in_exact_arithmetic(key):
@@ -95,7 +102,6 @@ def test_net_training_step_hip_matches_reference(name, gather, monkeypatch):
     net = make_net(name)
     load_weights(net, g)
     net = net.to(dev()).train()
-    assert net.train_backend == "hip"
     heu = net(graph(g))
     np.testing.assert_allclose(heu.detach().cpu().numpy(), g7["heu_train"], atol=ATOL_TORCH, rtol=5e-4)
     loss = torch.sum(heu * torch.from_numpy(g7["coef"]).to(dev()))
@@ -149,12 +155,10 @@ def test_net_training_hip_equals_torch_autograd_on_random_graph(gather, monkeypa
     coef = torch.randn(E, generator=gen).to(dev())
     grads = {}
     for backend in ("hip", "torch"):
-        net.train_backend = backend
         net.zero_grad()
-        heu = net(pyg)
+        heu = forward_as(net, pyg, backend)
         torch.sum(heu * coef).backward()
         grads[backend] = (heu.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
-    net.train_backend = "hip"
     torch.testing.assert_close(grads["hip"][0], grads["torch"][0], atol=ATOL_TORCH, rtol=5e-4)
     gmax = max(float(v.abs().max()) for v in grads["torch"][1].values())
     for k in grads["hip"][1]:
@@ -312,7 +316,8 @@ def test_batched_forward_equals_per_graph():
     heu = net.forward_batch(coords, ei, ea)
     assert heu.shape == (B, n * k)
     for b in range(B):
-        one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
+        with torch.no_grad():
+            one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
         torch.testing.assert_close(heu[b], one.view(-1), rtol=1e-6, atol=2e-7)     # (tile position moves the last bit)
     mats = Net.reshape_batch(n, ei, heu)
     one = Net.reshape(GraphData(x=coords[2], edge_index=ei[2], edge_attr=ea[2]), heu[2])
@@ -430,13 +435,11 @@ def test_sibling_nets_hip_equals_torch_ops(name):
     state = {k_: v.clone() for k_, v in net.state_dict().items()}
     for backend in ("hip", "torch"):
         net.load_state_dict(state)
-        net.train_backend = backend
         net.zero_grad()
-        heu = net(pyg)
+        heu = forward_as(net, pyg, backend)
         torch.sum(heu * coef).backward()
         grads[backend] = (heu.detach().clone(), {k_: p.grad.clone() for k_, p in net.named_parameters() if p.grad is not None})
         stats[backend] = {k_: v.clone() for k_, v in net.state_dict().items() if "running_" in k_}
-    net.train_backend = "hip"
     torch.testing.assert_close(grads["hip"][0], grads["torch"][0], atol=ATOL_TORCH, rtol=5e-4)
     gmax = max(float(v.abs().max()) for v in grads["torch"][1].values())
     for k_ in grads["torch"][1]:
@@ -474,11 +477,9 @@ def test_sibling_nets_match_the_reference_checkpoints(name):
     np.testing.assert_allclose(mat.cpu().numpy(), g["heu_mat"], atol=ATOL_HEU, rtol=1e-4)
     net.train()
     for backend in ("hip", "torch"):
-        net.train_backend = backend
         with torch.no_grad():
-            ht = net(graph(g))
+            ht = forward_as(net, graph(g), backend)
         np.testing.assert_allclose(ht.cpu().numpy(), g["heu_train"], atol=ATOL_TORCH, rtol=5e-4, err_msg=backend)
-    net.train_backend = "hip"
 
 
 def test_cvrp_nls_train_instance_on_the_drop_in():
@@ -550,3 +551,93 @@ def test_notebook_validation_protocol_reproduces_the_published_costs(n, n_ants, 
             sums += (float(costs.mean()), float(costs.min()), float(aco.lowest_cost))
     got, want = sums / len(coords), g[f"notebook{n}"]
     np.testing.assert_allclose(got, want, rtol=0.015)
+
+
+
+def _small_graph(n=45, E=520, seed=4):
+    from deepaco_amd.net import GraphData
+    gen = torch.Generator().manual_seed(seed)
+    src = torch.sort(torch.randint(0, n, (E,), generator=gen)).values
+    dst = torch.randint(0, n, (E,), generator=gen)
+    pyg = GraphData(x=torch.rand(n, 2, generator=gen), edge_index=torch.stack([src, dst]),
+                    edge_attr=torch.rand(E, 1, generator=gen)).to(dev())
+    return pyg, torch.randn(E, generator=gen).to(dev())
+
+
+def _grads(net):
+    return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def test_eval_mode_under_autograd_runs_on_the_kernels():
+    """A module in eval() whose output needs a gradient (this used to evaluate the module tree as torch
+    ops): the training kernels with the running statistics as constants -- value = the inference kernels', gradient = torch
+    autograd through the eval-mode module tree; the running statistics stay untouched."""
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(5)
+    net = Net().to(dev())
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.3, 0.3)
+            m.running_var.uniform_(0.4, 1.6)
+    net.eval()
+    pyg, coef = _small_graph()
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+    with torch.no_grad():
+        inf = net(pyg)
+    net.zero_grad()
+    heu = net(pyg)
+    assert heu.requires_grad
+    torch.sum(heu * coef).backward()
+    g_hip = _grads(net)
+    net.zero_grad()
+    ref = forward_as(net, pyg, "torch")
+    torch.sum(ref * coef).backward()
+    g_ref = _grads(net)
+    torch.testing.assert_close(heu.detach(), inf, atol=ATOL_HEU, rtol=1e-4)
+    torch.testing.assert_close(heu.detach(), ref.detach(), atol=ATOL_TORCH, rtol=5e-4)
+    gmax = max(float(v.abs().max()) for v in g_ref.values())
+    for k in g_ref:
+        _grad_close(g_hip[k].cpu().numpy(), g_ref[k].cpu().numpy(), k, rel=2e-3, floor=4e-6 * gmax)
+    for k, v in before.items():
+        assert torch.equal(net.state_dict()[k], v), k
+
+
+@pytest.mark.parametrize("config", ["momentum_none", "no_running_stats"])
+def test_batchnorm_configurations_away_from_the_default(config):
+    """BatchNorm1d(momentum=None) (cumulative average of the statistics) and track_running_stats=False (batch statistics in
+    eval mode too): the kernels plus the host-side bookkeeping against the module tree as torch ops."""
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(6)
+    net = Net().to(dev())
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            if config == "momentum_none":
+                m.momentum = None
+            else:
+                m.track_running_stats = False
+                m.running_mean = None
+                m.running_var = None
+                m.num_batches_tracked = None
+    pyg, coef = _small_graph(seed=8)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    out = {}
+    for backend in ("hip", "torch"):
+        net.load_state_dict(state)
+        net.train()
+        res = []
+        for _ in range(3):                                # three training forwards: the cumulative average moves each time
+            net.zero_grad()
+            heu = forward_as(net, pyg, backend)
+            torch.sum(heu * coef).backward()
+            res.append(heu.detach().clone())
+        net.eval()
+        res.append(forward_as(net, pyg, backend).detach().clone())         # eval mode (under autograd)
+        out[backend] = (res, _grads(net), {k: v.clone() for k, v in net.state_dict().items() if "running_" in k})
+    for a, b in zip(out["hip"][0], out["torch"][0]):
+        torch.testing.assert_close(a, b, atol=ATOL_TORCH, rtol=5e-4)
+    for k, v in out["torch"][2].items():
+        torch.testing.assert_close(out["hip"][2][k], v, rtol=1e-4, atol=1e-6)
+    gmax = max(float(v.abs().max()) for v in out["torch"][1].values())
+    for k in out["torch"][1]:
+        if not _zero_in_exact_arithmetic(k):
+            _grad_close(out["hip"][1][k].cpu().numpy(), out["torch"][1][k].cpu().numpy(), k, rel=2e-3, floor=4e-6 * gmax)

@@ -219,3 +219,76 @@ def test_class_surface_runs_on_head_rows():
         best[smp] = float(aco.run(8))
         assert aco.shortest_path.sort().values.tolist() == list(range(n))
     assert abs(best["scan_sparse"] / best["scan"] - 1) < 0.06
+
+
+def test_auto_sampler_picks_head_rows_where_they_apply():
+    """sampler='auto' (the colonies' default): head / tail rows after sparsify(k) and on a k-sparse (learned-like) heuristic,
+    the dense scan on plain 1/d and outside 129 <= n <= 1024; the auto colony IS the explicit scan_sparse colony, bit for bit."""
+    import warnings
+    from deepaco_amd import engine
+    from deepaco_amd.tsp.aco import ACO
+    g = torch.Generator().manual_seed(8)
+    c = torch.rand(3, 300, 2, generator=g)
+    d = (c[:, :, None] - c[:, None]).norm(dim=-1)
+    d[:, torch.arange(300), torch.arange(300)] = 1e9
+    d = d.to(dev())
+    auto = engine.BatchedTSP(d, n_ants=64, seed=3)
+    assert auto.resolved_sampler() == ("scan", None)                       # plain 1/d: a fifth of the mass is in the tail
+    auto.sparsify(30)
+    assert auto.resolved_sampler() == ("scan_sparse", 30)
+    forced = engine.BatchedTSP(d, n_ants=64, seed=3, sampler="scan_sparse")
+    forced.sparsify(30)
+    dense = engine.BatchedTSP(d, n_ants=64, seed=3, sampler="scan")
+    dense.sparsify(30)
+    assert dense.resolved_sampler()[0] == "scan"
+    for _ in range(4):
+        auto.step(); forced.step(); dense.step()
+    assert torch.equal(auto.pheromone, forced.pheromone) and torch.equal(auto.shortest_path, forced.shortest_path)
+    assert not torch.equal(auto.pheromone, dense.pheromone)                # its own uniform stream
+    # a k-sparse heuristic nobody announced (what Net.reshape + 1e-10 hands over): 40 live entries per row
+    _, idx = torch.topk(d, k=40, dim=2, largest=False)
+    heu = torch.full_like(d, 1e-10).scatter_(2, idx, torch.rand(3, 300, 40, device=dev()) + 0.05)
+    learned = engine.BatchedTSP(d, n_ants=64, seed=3, heuristic=heu)
+    assert learned.resolved_sampler() == ("scan_sparse", 63)
+    learned.run(3)
+    assert bool((learned.shortest_path.sort(dim=1).values == torch.arange(300, device=dev())).all())
+    wide = torch.full_like(d, 1e-10).scatter_(2, torch.topk(d, k=100, dim=2, largest=False).indices, 1.0)
+    assert engine.BatchedTSP(d, n_ants=8, heuristic=wide).resolved_sampler() == ("scan_sparse", 127)
+    # sizes the head kernels do not cover: the dense scan, also when scan_sparse was asked for (one warning, no exception)
+    small = d[:, :100, :100].contiguous()
+    col = engine.BatchedTSP(small, n_ants=16, seed=1)
+    col.sparsify(10)
+    assert col.resolved_sampler() == ("scan", None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        engine._warned_sparse_range = False
+        f = engine.BatchedTSP(small, n_ants=16, seed=1, sampler="scan_sparse")
+        f.sparsify(10)
+        f.run(2)
+        col.run(2)
+    assert any("scan_sparse" in str(x.message) for x in w) and torch.equal(f.pheromone, col.pheromone)
+    # the class surface: run() and gen_path() of the drop-in ACO follow the same rule
+    aco = ACO(d[0], n_ants=32, device="cuda:0", seed=5)
+    aco.sparsify(30)
+    assert aco.resolved_sampler() == ("scan_sparse", 30)
+    aco.run(3)
+    p = aco.gen_path(require_prob=False)
+    assert sorted(p[:, 0].tolist()) == list(range(300))
+    p2, lp = aco.gen_path(require_prob=True)                                 # log-probabilities: the dense scan builds them
+    assert lp.shape == (299, 32)
+
+
+def test_sparse_head_equals_the_oracles_rule_with_ties():
+    """engine.sparse_head (top-k selection, no row sort) against oracle.sparse_head_ids: ties at the k-th value go to the
+    smaller ids."""
+    import numpy as np
+    import oracle
+    from deepaco_amd import engine
+    g = torch.Generator().manual_seed(2)
+    w = torch.randint(0, 12, (2, 150, 150), generator=g).float() + 1e-3         # many equal values
+    for k in (1, 17, 63, 64, 127):
+        got = engine.sparse_head(w.to(dev()), k).cpu().numpy().view(np.uint16)
+        for b in range(2):
+            want, _ = oracle.sparse_head_ids(w[b].numpy(), k)
+            np.testing.assert_array_equal(got[b][:, :k], want[:, :k], err_msg=f"k={k}")
+            assert (got[b][:, -1] == k).all()

@@ -45,4 +45,4 @@ for r in range(reps):
 torch.cuda.synchronize()
 t = sorted(a.elapsed_time(b) for a, b in ev[2:])
 print(json.dumps({"n": n, "B": B, "A": A, "reps": reps, "kernel_ms_median": round(t[len(t) // 2], 4), "kernel_ms_min": round(t[0], 4),
-                  "mode": mode, "sparse_stats": stats, "knob": os.environ.get("DACO_SCAN32_KNOB", "0")}))
+                  "mode": mode, "sparse_stats": stats}))
