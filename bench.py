@@ -669,20 +669,25 @@ def extra_configs(dev, headline_colony, cpu=True):
         "local_search": {"kernel_ms": kms, "sweeps_per_iteration": sweeps, "sweeps_per_s": sweeps / (kms * 1e-3),
                          "list_entries_walked_per_sweep": walked / sweeps if sweeps else None,
                          "reference_pair_evaluations_per_s": sweeps * (n - 1) * (n - 2) / 2 / (kms * 1e-3)},
-        "roofline": {"bound": "l2", "achieved": alg / (kms * 1e-3) / 1e9, "peak": PEAK_L2_GBS, "unit": "GB/s",
-                     "frac": alg / (kms * 1e-3) / 1e9 / PEAK_L2_GBS, "traffic": tr, "traffic_source": src,
-                     "kernel": "nls_kernel (daco_tsp_nls; HIP events around the launch)", "kernel_ms": kms,
-                     "pipes": counters.get("nls500_a256_b64"), "valu_busy": (counters.get("nls500_a256_b64") or {}).get("valu_busy"),
-                     "algorithmic_bytes_per_launch": alg,
-                     # what the L2 actually moves for them: every 8-byte table entry / 4-byte gather pulls a 128-byte line
-                     "l2_lines": None if lines_req is None else {
-                         "requests_per_launch": lines_req, "GBps": lines_req * 128 / (kms * 1e-3) / 1e9,
-                         "frac": lines_req * 128 / (kms * 1e-3) / 1e9 / PEAK_L2_GBS,
-                         "source": "TCP_TCC_READ_REQ_sum of the kernel (profiles/r04_pmc_nls.txt; same workload and library "
-                                   "version, not collected in this run) x 128 B / this run's kernel time"},
-                     "note": "algorithmic bytes = 12 B per walked list entry (table entry + matrix gather) + 128 B per sweep for "
-                             "the changed edges, from the in-run counters; the kernel is a chain of dependent L2 round trips and "
-                             "LDS phases per sweep (latency / issue bound, profiles/r03_pmc_nls_*), not bound by this bandwidth"},
+        # the bound this kernel sits on is the L2's LINE rate: every 8-byte table entry / 4-byte matrix gather moves a 128-byte
+        # line (16-32 x inflation, structural: the second access of an entry is a function of the tour, not of the list).  With
+        # the counter pass of this workload at hand, achieved = line requests x 128 B / this run's kernel time; without it, the
+        # bytes the search needs by definition (12 B per walked entry), which no roofline bounds.
+        "roofline": (lambda lines_GBps, alg_GBps: {
+            "bound": "l2", "unit": "GB/s", "peak": PEAK_L2_GBS,
+            "achieved": lines_GBps if lines_GBps is not None else alg_GBps,
+            "frac": (lines_GBps if lines_GBps is not None else alg_GBps) / PEAK_L2_GBS,
+            "basis": "L2 line requests x 128 B (TCP_TCC_READ_REQ_sum of the counter pass of this workload and library version, "
+                     "profiles/r05_pmc_nls.txt) / this run's kernel time" if lines_GBps is not None else
+                     "algorithmic bytes only (no counter pass of this library version in profiles/)",
+            "traffic": tr, "traffic_source": src,
+            "kernel": "nls_kernel (daco_tsp_nls; HIP events around the launch)", "kernel_ms": kms,
+            "pipes": counters.get("nls500_a256_b64"), "valu_busy": (counters.get("nls500_a256_b64") or {}).get("valu_busy"),
+            "algorithmic": {"bytes_per_launch": alg, "GBps": alg_GBps, "frac_of_l2": alg_GBps / PEAK_L2_GBS,
+                            "note": "12 B per walked list entry (table entry + matrix gather) + 128 B per sweep for the changed "
+                                    "edges, from the in-run counters"},
+            "l2_line_requests_per_launch": lines_req,
+        })(None if lines_req is None else lines_req * 128 / (kms * 1e-3) / 1e9, alg / (kms * 1e-3) / 1e9),
         "cpu_baseline": cb}
     del col
 
@@ -807,7 +812,7 @@ def extra_configs(dev, headline_colony, cpu=True):
             procs = min(16, max(1, ncpu // 2))
             pn = paths.cpu().numpy()
             res = _cpu_leg([("hgs", 1, 8.0, loc[r % B].numpy(), dls[r % B].numpy(), hdl[r % B].numpy(), dem[r % B].numpy(),
-                             pn[r % B][:, : 64], limit, r) for r in range(procs)])
+                             pn[r % B], limit, r) for r in range(procs)])
             busy = max(r[1] for r in res)
             kind = res[0][2]
             cb = {"value": sum(r[0] for r in res) / busy, "unit": "solutions/s", "cores": procs, "host_cpus": ncpu, "kind": kind,
@@ -931,6 +936,127 @@ def extra_configs(dev, headline_colony, cpu=True):
         del lnet, heu
     except Exception as e:
         out["c5_learned_tsp1000_a2048_b8"] = {"error": repr(e)}
+
+    # one optimisation step of tsp_nls/train.py:15-44 for the reference's training batch (20 instances of TSP-100, 30 ants,
+    # k = 10: tsp_nls/train.py:95-100), all on the device: pipeline.train_tsp_nls_batch; stages timed with events
+    try:
+        from deepaco_amd.pipeline import train_tsp_nls_batch, W_2OPT, EPS
+        from deepaco_amd.tsp_nls.net import Net as TrainNet
+        from deepaco_amd.autograd import TspBatchSampleFn
+        Bt, nt, At, kt = 20, 100, 30, 10
+        torch.manual_seed(0)
+        tnet = TrainNet().to(dev)
+        opt = torch.optim.AdamW(tnet.parameters(), lr=3e-4)
+        for s_ in range(3):
+            train_tsp_nls_batch(tnet, opt, torch.rand(Bt, nt, 2, device=dev), At, kt, seed=1, it=s_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(10):
+            train_tsp_nls_batch(tnet, opt, torch.rand(Bt, nt, 2, device=dev), At, kt, seed=1, it=3 + s_)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / 10
+        # the same step with an event between its stages (pipeline.train_tsp_nls_batch, unrolled)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        stage_ms = [0.0] * 5
+        for s_ in range(5):
+            coords_t = torch.rand(Bt, nt, 2, device=dev)
+            tnet.train()
+            marks[0].record()
+            dist_t, ei_t, ea_t = engine.tsp_knn_graph(coords_t, kt)
+            xt = torch.zeros((Bt, nt, 1), device=dev)
+            xt[:, 0] = 1.0
+            heu_t = tnet.forward_batch_train(xt, ei_t, ea_t, k_sparse=kt)
+            hm = tnet.reshape_batch(nt, ei_t, heu_t) + EPS
+            marks[1].record()
+            paths_t, logp_t, _ = TspBatchSampleFn.apply(hm, torch.ones((Bt, nt, nt), device=dev), At, 1.0, 1.0, "scan", 2, 0, 1, 20 + s_)
+            marks[2].record()
+            with torch.no_grad():
+                c_t = engine.tour_costs(dist_t, paths_t)
+                tours_t = paths_t.permute(0, 2, 1).to(torch.int16).contiguous()
+                hd_t = (1 / (hm.detach() / hm.detach().amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+                tours_t = engine.nls_(dist_t, hd_t, tours_t, nt // 4, dist_t="symmetric")
+                cl_t = engine.tour_costs(dist_t, tours_t.permute(0, 2, 1).to(torch.int64).contiguous())
+                adv = (cl_t - cl_t.mean(dim=1, keepdim=True)) * W_2OPT + (c_t - c_t.mean(dim=1, keepdim=True)) * (1 - W_2OPT)
+            marks[3].record()
+            loss_t = torch.sum(adv.unsqueeze(1) * logp_t) / At / Bt
+            opt.zero_grad()
+            loss_t.backward()
+            marks[4].record()
+            torch.nn.utils.clip_grad_norm_(parameters=tnet.parameters(), max_norm=3.0, norm_type=2)
+            opt.step()
+            marks[5].record()
+            torch.cuda.synchronize()
+            for j in range(5):
+                stage_ms[j] += marks[j].elapsed_time(marks[j + 1]) / 5
+        cb = None
+        if cpu:
+            # the reference's train_instance on the host: its module tree in training mode + the aten op sequence of the rollout
+            # with log-probabilities + 2-opt / NLS through the C restatement, backward and optimizer step; one instance after the other
+            from oracle import torch_port
+            import oracle
+            cnet = TrainNet()
+            cnet.load_state_dict(tnet.state_dict())
+            cnet.train()
+            copt = torch.optim.AdamW(cnet.parameters(), lr=3e-4)
+            torch.set_num_threads(min(8, ncpu))
+            t0 = time.perf_counter()
+            done_i = 0
+            while time.perf_counter() - t0 < 8.0 and done_i < Bt:
+                cc = torch.rand(nt, 2)
+                dd = (cc[:, None] - cc).norm(dim=-1)
+                dd[torch.arange(nt), torch.arange(nt)] = 1e9
+                tk = torch.topk(dd, k=kt, dim=1, largest=False)
+                eidx = torch.stack((torch.repeat_interleave(torch.arange(nt), kt), tk.indices.flatten()))
+                xx = torch.zeros(nt, 1)
+                xx[0] = 1.0
+                hv = cnet.par_net_heu(cnet.emb_net(xx, eidx, tk.values.reshape(-1, 1)))
+                hmat = torch.zeros(nt, nt)
+                hmat[eidx[0], eidx[1]] = hv
+                hmat = hmat + 1e-10
+                pth, lps = torch_port.rollout(torch.ones(nt, nt), hmat, At, require_prob=True)
+                cst = torch_port.tour_lengths(dd, pth)
+                hdn = (1 / (hmat.detach() / hmat.detach().amax(dim=-1, keepdim=True) + 1e-5)).numpy()
+                tl, _ = oracle.nls_batch(dd.numpy(), hdn, pth.T.numpy().astype(np.uint16), nt // 4)
+                cls_ = torch_port.tour_lengths(dd, torch.from_numpy(tl.T.astype(np.int64)))
+                advc = (cls_ - cls_.mean()) * W_2OPT + (cst - cst.mean()) * (1 - W_2OPT)
+                lossc = torch.sum(advc * lps.sum(dim=0)) / At
+                copt.zero_grad()
+                lossc.backward()
+                torch.nn.utils.clip_grad_norm_(parameters=cnet.parameters(), max_norm=3.0, norm_type=2)
+                copt.step()
+                done_i += 1
+            busy = time.perf_counter() - t0
+            cb = {"value": done_i / busy, "unit": "instances/s", "cores": min(8, ncpu), "host_cpus": ncpu, "kind": "port",
+                  "sample": f"{done_i} instances, one after the other as tsp_nls/train.py:52-60 runs them, {busy:.1f} s: the module tree of "
+                            f"tsp_nls/net.py as torch CPU ops with autograd, oracle/torch_port.rollout with log-probabilities, the NLS through "
+                            f"the C restatement of two_opt.py (the reference: numba), AdamW; {min(8, ncpu)} intra-op threads"}
+        out["train_step_tsp100_b20_a30"] = {
+            "workload": f"one optimisation step of tsp_nls/train.py: {Bt} instances of TSP-{nt}, {At} ants, k = {kt}, NLS, AdamW",
+            "value": Bt / dts, "unit": "instances/s", "ms_per_step": dts * 1e3,
+            "stage_ms": {"graph_and_network_forward": stage_ms[0], "construction_with_log_probs": stage_ms[1],
+                         "costs_and_local_search": stage_ms[2], "loss_and_backward": stage_ms[3], "clip_and_optimizer": stage_ms[4]},
+            "note": "every stage is launch-bound at this size (a TSP-100 graph has 1 000 edges: the twelve layers' kernels take a few "
+                    "microseconds each); profiles/r05_kernel_stats_train.csv lists the kernels of a step",
+            "cpu_baseline": cb}
+        del tnet, opt
+    except Exception as e:
+        out["train_step_tsp100_b20_a30"] = {"error": repr(e)}
+
+    # the six sibling problems (op, pctsp, sop, smtwtp, bpp, mkp: */aco.py gen_sol / gen_path), 512 ants, n = 100: one fused launch
+    # per construction against the draw-by-draw service (torch mask bookkeeping + daco_pick_move, the reference's own structure)
+    try:
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "measure_siblings.py")], capture_output=True, text=True, timeout=300)
+        rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out["siblings_n100_a512"] = {
+            "workload": "solution construction of the sibling problems, n = 100, 512 ants, one instance (tools/measure_siblings.py)",
+            "unit": "solutions/s", "problems": {x["problem"]: {"fused_solutions_per_s": x["fused_solutions_per_s"], "fused_ms": x["fused_ms"],
+                                                              "stepwise_ms": x["stepwise_ms"]} for x in rows},
+            "value": sum(x["fused_solutions_per_s"] for x in rows) / max(1, len(rows)),
+            "note": "no CPU leg: the oracle restates the siblings' draws (fixtures s_*), not their Python drivers; the step-wise column is "
+                    "the reference's call structure (one pick_move per step, masks as torch ops) on this GPU"}
+    except Exception as e:
+        out["siblings_n100_a512"] = {"error": repr(e)}
 
     # GNN forward (eval), 64 graphs of TSP-500 k=50 side by side
     from deepaco_amd.tsp.net import Net
