@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--cap", type=float, default=50.0)
     ap.add_argument("--limit", type=int, default=100)
     ap.add_argument("--old", action="store_true")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-short", action="store_true", help="only the three-stage launches (counter passes: one kernel shape)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     n, A, B = args.n, args.ants, args.batch
@@ -40,7 +42,7 @@ def main():
     torch.cuda.synchronize()
     print(f"tables: {(time.perf_counter() - t0) * 1e3:.2f} ms (two matrices x {B} instances)")
     stages = [(td, args.limit), (th, 10), (td, args.limit)]
-    for rep in range(3):
+    for rep in range(args.reps):
         w = paths.clone()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -50,7 +52,7 @@ def main():
         c1 = engine.tour_costs(d.float(), w, closed=False)
         print(f"hgs: {dt * 1e3:.2f} ms = {B * A / dt / 1e3:.1f} k solutions/s; moves/solution {float(stats[..., 0].float().mean()):.1f}, "
               f"loops {float(stats[..., 1].float().mean()):.2f}, rounds {float(stats[..., 2].float().mean()):.0f}, cost {float(c1.mean()):.4f}, status != 0: {int((status != 0).sum())}", flush=True)
-    for cnt in (0, 1):
+    for cnt in (() if args.no_short else (0, 1)):
         w = paths.clone()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

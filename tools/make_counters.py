@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/counters.json and profiles/hbm_traffic.json from the counter passes of tools/profile_r4.sh.
+"""profiles/counters.json and profiles/hbm_traffic.json from the counter passes of tools/profile_r5.sh.
 
 usage: tools/make_counters.py gpurun_out/<tag>   (reads <tag>/pmc_<workload>/pmc_*/p_counter_collection.csv)
 Per workload the dominant kernel's mean counters per launch become:
@@ -34,6 +34,7 @@ WORKLOADS = {
     "nls": ("nls_kernel", "nls500_a256_b64"),
     "gnn": ("gnn_fused2_layer_kernel<false>", "gnn_fused2_layer_tsp500_k50_b64"),
     "cvrp_ls": ("cvrp_ls_kernel", "cvrp_ls_100_a512_b16"),
+    "hgs_ls": ("hgs_ls_kernel", "hgs_ls_100_a512_b64"),
 }
 
 
@@ -51,11 +52,10 @@ def main():
     from deepaco_amd import _lib
     version = _lib.ABI_VERSION
     counters = {"daco_version": version,
-                "source": "profiles/r04_pmc_*.txt (tools/profile_r4.sh + tools/make_counters.py: rocprofv3 --pmc, one pass per counter "
-                          "group, mean per launch of the workload's dominant kernel; the head / tail kernels' passes are of this library "
-                          "version, the other kernels are unchanged since their passes under version 120)"}
+                "source": "profiles/r05_pmc_*.txt (tools/profile_r5.sh + tools/make_counters.py: rocprofv3 --pmc, one pass per counter "
+                          "group, mean per launch of the workload's dominant kernel, all of this library version)"}
     traffic = {"daco_version": version,
-               "source": "profiles/r04_pmc_*.txt (tools/profile_r4.sh: FETCH_SIZE KiB x 1024 x 2 [gfx950 correction] + WRITE_SIZE KiB x "
+               "source": "profiles/r05_pmc_*.txt (tools/profile_r5.sh: FETCH_SIZE KiB x 1024 x 2 [gfx950 correction] + WRITE_SIZE KiB x "
                          "1024, mean per launch of the dominant kernel)"}
     for wl, (needle, key) in WORKLOADS.items():
         m = kernel_means(os.path.join(out_dir, "pmc_" + wl), needle)
@@ -68,6 +68,11 @@ def main():
             c["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
             c["valu_busy"] = m["SQ_INSTS_VALU"] * 2 / (1024 * cyc)
             c["salu_insts_per_launch"] = m.get("SQ_INSTS_SALU")
+        if "SQ_ACTIVE_INST_VALU" in m:
+            # cycles the SIMDs spent executing VALU instructions (the counter ticks every four cycles, like SQ_WAVE_CYCLES): the
+            # measure for float64-heavy kernels, whose instructions take four cycles and not the two assumed above
+            c["valu_active_cycles"] = m["SQ_ACTIVE_INST_VALU"] * 4
+            c["valu_active"] = m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)
         if "TA_TA_BUSY_sum" in m:
             c["ta_busy"] = m["TA_TA_BUSY_sum"] / (256 * cyc)
             c["td_busy"] = m["TD_TD_BUSY_sum"] / (256 * cyc)

@@ -38,7 +38,7 @@ def timeit(fn, steps, warm=2):
 def run(cfg):
     if cfg in ("headline", "c2", "c5shard"):
         n, A, B, k = {"headline": (500, 512, 64, 50), "c2": (100, 512, 256, 20), "c5shard": (1000, 2048, 64, 100)}[cfg]
-        col = engine.BatchedTSP(tsp_instances(B, n, 1), n_ants=A, seed=1)
+        col = engine.BatchedTSP(tsp_instances(B, n, 1), n_ants=A, seed=1, sampler="scan")   # (the dense scan: these passes are of tsp_scan32 / scan16)
         col.sparsify(k)
         dt = timeit(col.step, 3 if n >= 1000 else 10)
         return dict(config=cfg, desc=f"TSP-{n}, {A} ants, {B} instances, AS iteration", ms_per_iteration=dt * 1e3,
