@@ -52,7 +52,7 @@ SIGNATURES = {
     "daco_hgs_table_bytes": (_sz, [_i, _i]),
     "daco_hgs_prepare": (_i, [_vp, _i, _i, _vp, _l, _i, _vp]),
     "daco_hgs_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "daco_hgs_local_search": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp, _vp, _sz]),
+    "daco_hgs_local_search": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _i, _vp, _vp, _vp, _vp, _sz]),
     "daco_sibling_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_sibling_sample": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _l, _f, _vp, _i, _i, _vp, _vp,
                                  _i, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),

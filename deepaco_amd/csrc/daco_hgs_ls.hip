@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void hgs_prepare_kernel(int n, int g_req, cons
 }
 
 // ---------------------------------------------------------------------------------------------- the search
-struct HgsStage { const double *tc; long bstride; const unsigned char *tables; size_t table_bytes; int count; };
+struct HgsStage { const double *tc, *tct; long bstride; const unsigned char *tables; size_t table_bytes; int count; };
 struct HgsParams {
   int B, n, A, Lmax, Rmax, g, nstages, budget;
   HgsStage st[HGS_MAX_STAGES];
@@ -178,6 +178,7 @@ struct HgsParams {
 struct HgsLds {
   uint16_t *next, *prev, *route, *pos;     // [N]   N = nc + 1 + 2 Rmax; nodes: 1..nc clients, nc+1+r / nc+1+R+r depots of route r
   double *cumLoad, *cumRev;                // [N]
+  double *dNext;                           // [N]  timeCost[node][next(node)]: the edges of the routes, refreshed by the route update
   int32_t *whenRI;                         // [n]
   int32_t *rowptr;                         // [n]  >= 0: offset in the table's entries, < 0: -(1 + offset) in the wave's scratch
   double *rLoad, *rPen, *rRev;             // [Rmax]
@@ -186,13 +187,14 @@ struct HgsLds {
 };
 __host__ __device__ inline size_t hgs_lds_bytes(int n, int Rmax) {
   const size_t N = (size_t)n + 2 * Rmax;
-  return a16(2 * N) * 4 + a16(8 * N) * 2 + a16(4 * (size_t)n) * 2 + a16(8 * (size_t)Rmax) * 3 + a16(4 * (size_t)Rmax) * 2 + a16((size_t)n);
+  return a16(2 * N) * 4 + a16(8 * N) * 3 + a16(4 * (size_t)n) * 2 + a16(8 * (size_t)Rmax) * 3 + a16(4 * (size_t)Rmax) * 2 + a16((size_t)n);
 }
 __device__ inline HgsLds hgs_carve(unsigned char *p, int n, int Rmax) {
   const size_t N = (size_t)n + 2 * Rmax;
   HgsLds l;
   l.cumLoad = (double *)p; p += a16(8 * N);
   l.cumRev = (double *)p; p += a16(8 * N);
+  l.dNext = (double *)p; p += a16(8 * N);
   l.rLoad = (double *)p; p += a16(8 * (size_t)Rmax);
   l.rPen = (double *)p; p += a16(8 * (size_t)Rmax);
   l.rRev = (double *)p; p += a16(8 * (size_t)Rmax);
@@ -216,7 +218,7 @@ __device__ inline double rl_d(double v, int lane) {
 
 struct HgsCtx {
   HgsLds l;
-  const double *tc, *dem;
+  const double *tc, *tct, *dem;         // tct: the transposed matrix (tc itself when symmetric)
   int n, nc, R, lane;
   double cap, penCap;
   int nbMoves;
@@ -226,6 +228,8 @@ struct HgsCtx {
   __device__ inline bool isdep(int v) const { return v > nc; }
   __device__ inline int dep(int r) const { return nc + 1 + r; }
   __device__ inline double TC(int a, int b) const { return tc[(size_t)a * n + b]; }
+  // timeCost[b][a] read from row a of the transposed copy: with a wave-uniform `a` the lanes' entries share a few lines
+  __device__ inline double TT(int a, int b) const { return tct[(size_t)a * n + b]; }
   __device__ inline double pen(double load) const { const double e = load - cap; return (e > 0. ? e : 0.) * penCap; }   // LocalSearch.h:140
 };
 
@@ -251,7 +255,9 @@ __device__ inline void hgs_update_route(HgsCtx &c, int r) {
     if (lane < cnt) {
       const int cc = c.cour(mine), pc = c.cour(mprev);
       dl = c.dem[cc];
-      dr = c.TC(cc, pc) - c.TC(pc, cc);
+      const double fwd = c.TC(pc, cc);
+      dr = c.TC(cc, pc) - fwd;
+      c.l.dNext[mprev] = fwd;
     }
     double myl = 0., myr = 0.;
     for (int k = 0; k < cnt; ++k) {
@@ -263,6 +269,7 @@ __device__ inline void hgs_update_route(HgsCtx &c, int r) {
     place += cnt;
   }
   if (lane == 0) {
+    c.l.dNext[node] = c.TC(0, 0);                      // the closing depot's own successor is the route's first depot
     c.l.rLoad[r] = load; c.l.rPen[r] = c.pen(load); c.l.rRev[r] = rev;
     c.l.rCnt[r] = place - 1; c.l.rWhen[r] = c.nbMoves;
   }
@@ -298,7 +305,7 @@ __device__ inline void hgs_set_u(const HgsCtx &c, int U, USide &u) {
   u.loadU = c.dem[u.iU]; u.loadX = c.dem[u.iX];
   u.penU = c.l.rPen[u.rU]; u.loadRU = c.l.rLoad[u.rU]; u.revDistU = c.l.rRev[u.rU];
   u.cumLoadU = c.l.cumLoad[U]; u.cumRevX = c.l.cumRev[u.X];
-  u.dUpU = c.TC(u.Up, u.iU); u.dUX = c.TC(u.iU, u.iX); u.dXXn = c.TC(u.iX, u.Xn);
+  u.dUpU = c.l.dNext[u.prevU]; u.dUX = c.l.dNext[U]; u.dXXn = c.l.dNext[u.X];       // edges of the route: kept in LDS
   u.dUpX = c.TC(u.Up, u.iX); u.dUpXn = c.TC(u.Up, u.Xn); u.dXU = c.TC(u.iX, u.iU);
   if (UNIFORM) {
     u.loadU = uni_d(u.loadU); u.loadX = uni_d(u.loadX); u.penU = uni_d(u.penU); u.loadRU = uni_d(u.loadRU);
@@ -317,7 +324,9 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
   const bool intra = (u.rU == rV), yDep = c.isdep(Y);
   const double loadV = c.dem[iV], loadY = c.dem[iY];
   const double penV = c.l.rPen[rV], loadRV = c.l.rLoad[rV];
-  const double dVY = c.TC(iV, iY), dVU = c.TC(iV, u.iU), dUY = c.TC(u.iU, iY), dXY = c.TC(u.iX, iY);
+  // matrix entries: the routes' own edges from LDS; everything else has one index on the U side -- read from that node's row
+  // of the matrix or of its transpose, so that the 64 lanes' gathers fall on the few lines of (at most six) wave-uniform rows
+  const double dVY = c.l.dNext[V], dVU = c.TT(u.iU, iV), dUY = c.TC(u.iU, iY), dXY = c.TC(u.iX, iY);
   const double sumPen = u.penU + penV;
   {   // move1 (LocalSearch.cpp:134-162)
     double cU = u.dUpX - u.dUpU - u.dUX;
@@ -341,7 +350,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
     }
     if (ok && !(cU + cV > -HGS_EPS) && !(u.U == Y || V == u.X || u.xDep)) return 2;
   }
-  const double dVX = c.TC(iV, u.iX);
+  const double dVX = c.TT(u.iX, iV);
   {   // move3 (:195-224)
     double cU = u.dUpXn - u.dUpU - u.dUX - u.dXXn;
     double cV = dVX + u.dXU + dUY - dVY;
@@ -354,7 +363,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
     if (ok && !(cU + cV > -HGS_EPS) && !(u.U == Y || u.X == V || u.xDep)) return 3;
   }
   if (block == 0) {
-    const double dUpV = c.TC(u.Up, iV), dVpU = c.TC(Vp, u.iU), dVpV = c.TC(Vp, iV);
+    const double dUpV = c.TC(u.Up, iV), dVpU = c.TT(u.iU, Vp), dVpV = c.l.dNext[prevV];
     if (u.iU <= iV) {   // move4 (:226-254)
       double cU = dUpV + dVX - u.dUpU - u.dUX;
       double cV = dVpU + dUY - dVpV - dVY;
@@ -367,7 +376,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
       if (ok && !(cU + cV > -HGS_EPS) && !(u.iU == Vp || u.iU == iY)) return 4;
     }
     {   // move5 (:256-285)
-      double cU = dUpV + c.TC(iV, u.Xn) - u.dUpU - u.dXXn;
+      double cU = dUpV + c.TT(u.Xn, iV) - u.dUpU - u.dXXn;
       double cV = dVpU + dXY - dVpV - dVY;
       bool ok = true;
       if (!intra) {
@@ -378,8 +387,8 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
       if (ok && !(cU + cV > -HGS_EPS) && !(u.U == prevV || u.X == prevV || u.U == Y || u.xDep)) return 5;
     }
     if (u.iU <= iV) {   // move6 (:287-316)
-      double cU = dUpV + c.TC(iY, u.Xn) - u.dUpU - u.dXXn;
-      double cV = dVpU + c.TC(u.iX, Yn) - dVpV - c.TC(iY, Yn);
+      double cU = dUpV + c.TT(u.Xn, iY) - u.dUpU - u.dXXn;
+      double cV = dVpU + c.TC(u.iX, Yn) - dVpV - c.l.dNext[Y];
       bool ok = true;
       if (!intra) {
         if (cU + cV >= sumPen) ok = false;
@@ -601,6 +610,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
       const uint32_t *toff = reinterpret_cast<const uint32_t *>(tab + lay.off);
       const uint16_t *tent = reinterpret_cast<const uint16_t *>(tab + lay.ent);
       c.tc = sg.tc + (size_t)b * sg.bstride;
+      c.tct = sg.tct + (size_t)b * sg.bstride;
       R = c.R;
       // Params: scale checks, penalty (Params.cpp:106-118)
       const double maxDist = hdr->maxDist;
@@ -679,16 +689,19 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
               if (!__ballot(act)) break;
               ++nRounds;
               hgs_set_u<false>(c, U, u);
-              // both blocks for every lane, no branch between them: all matrix gathers of a round are in flight together
-              const int pvn = c.l.prev[Vs];
+              // the lanes that are not evaluated look at U itself: their matrix gathers fall on the lines the U side reads
+              // anyway (a gated-off lane that gathered ITS V's entries cost the data-return unit as much as a live one: the
+              // kernel sits on that unit, TD busy 0.92 in profiles/r05_pmc_hgs_ls.txt)
+              const int Ve = act ? Vs : U;
+              const int pvn = c.l.prev[Ve];
               const bool depPrev = c.isdep(pvn);
-              const int c0 = hgs_eval(c, u, Vs, 0);
+              const int c0 = hgs_eval(c, u, Ve, 0);
               int code = act ? c0 : 0;
               // "insert after the depot" (LocalSearch.cpp:47-56) for the lanes whose V opens its route and found nothing: only
               // when such a lane exists (in the late loops few lanes are evaluated at all)
               const bool need1 = act && c0 == 0 && depPrev;
               if (__ballot(need1)) {
-                const int c1 = hgs_eval(c, u, depPrev ? pvn : Vs, 1);
+                const int c1 = hgs_eval(c, u, need1 ? pvn : U, 1);
                 if (need1 && c1) code = c1 + 16;
               }
               const uint64_t m = __ballot(code != 0);
@@ -856,7 +869,7 @@ extern "C" size_t daco_hgs_workspace_bytes(int B, int n, int A, int Lmax, int nb
 }
 
 extern "C" int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax, int nstages, const double *const *matrices,
-                                     const long *bstrides, const void *const *tables, const int *counts, const double *demand,
+                                     const double *const *matrices_t, const long *bstrides, const void *const *tables, const int *counts, const double *demand,
                                      double capacity, int nb_granular, int64_t *paths, int32_t *status, int32_t *stats,
                                      void *workspace, size_t workspace_bytes) {
   if (B <= 0 || n < 2 || A <= 0 || Lmax < 3 || nstages < 1 || nstages > HGS_MAX_STAGES || !matrices || !bstrides || !tables ||
@@ -879,7 +892,7 @@ extern "C" int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax
   if (n + 2 * Rmax > 65535) { set_error("daco_hgs_local_search: n + 2 routes = %d does not fit 16-bit node ids", n + 2 * Rmax); return DACO_E_TOOLARGE; }
   for (int s = 0; s < nstages; ++s) {
     if (!matrices[s] || !tables[s] || counts[s] < 0) { set_error("daco_hgs_local_search: stage %d: null matrix / table or negative count", s); return DACO_E_BADARG; }
-    p.st[s].tc = matrices[s]; p.st[s].bstride = bstrides[s]; p.st[s].tables = (const unsigned char *)tables[s];
+    p.st[s].tc = matrices[s]; p.st[s].tct = (matrices_t && matrices_t[s]) ? matrices_t[s] : matrices[s]; p.st[s].bstride = bstrides[s]; p.st[s].tables = (const unsigned char *)tables[s];
     p.st[s].table_bytes = HgsLayout(n, nb_granular).total; p.st[s].count = counts[s];
   }
   p.demand = demand; p.cap = capacity; p.paths = paths; p.status = status; p.stats = stats;

@@ -730,6 +730,9 @@ class HgsTables:
         m = matrix if matrix.dim() == 3 else matrix.unsqueeze(0)
         self.matrix = m if (m.dtype == torch.float64 and m.is_contiguous()) else m.contiguous().double()
         self.B, self.n = self.matrix.shape[0], self.matrix.shape[-1]
+        # the transposed copy the search reads "column" entries from (None for a symmetric matrix: one device comparison)
+        mt = self.matrix.transpose(-1, -2)
+        self.matrix_t = None if bool(torch.equal(self.matrix, mt)) else mt.contiguous()
         self.nb_granular = int(nb_granular)
         L = _lib.lib()
         self.table_bytes = L.daco_hgs_table_bytes(self.n, self.nb_granular)
@@ -762,6 +765,7 @@ def hgs_local_search_(paths, stages, demand, capacity=1000.001, demand_scale=100
     dem = (dem * demand_scale).contiguous()
     S = len(stages)
     mats = (C.c_void_p * S)(*[st[0].matrix.data_ptr() for st in stages])
+    mats_t = (C.c_void_p * S)(*[(st[0].matrix_t.data_ptr() if st[0].matrix_t is not None else None) for st in stages])
     strides = (C.c_long * S)(*[(0 if st[0].B == 1 and B > 1 else n * n) for st in stages])
     tabs = (C.c_void_p * S)(*[st[0].tables.data_ptr() for st in stages])
     counts = (C.c_int * S)(*[int(st[1]) for st in stages])
@@ -775,7 +779,7 @@ def hgs_local_search_(paths, stages, demand, capacity=1000.001, demand_scale=100
         ws = _workspace(dev, wsb, "hgs_ls")
         status = torch.empty((B, A), dtype=torch.int32, device=dev)
         stats = torch.empty((B, A, 4), dtype=torch.int32, device=dev) if want_stats else None
-        rc = L.daco_hgs_local_search(_stream(dev), B, n, A, Lmax, S, mats, strides, tabs, counts, dem.data_ptr(), float(capacity), g,
+        rc = L.daco_hgs_local_search(_stream(dev), B, n, A, Lmax, S, mats, mats_t, strides, tabs, counts, dem.data_ptr(), float(capacity), g,
                                      p3.data_ptr(), status.data_ptr(), stats.data_ptr() if want_stats else None,
                                      ws.data_ptr(), ws.numel())
     _lib.check(rc, "daco_hgs_local_search")

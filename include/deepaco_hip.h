@@ -515,6 +515,9 @@ int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lmax, const fl
  *   handed to the next as the reference's files do (non-empty routes, in export order).
  *   matrices[s], bstrides[s], tables[s], counts[s]   stage s: its matrix [B][n][n] f64, the tables daco_hgs_prepare made
  *            of it, and `count` (the loop bound of LocalSearch.cpp:17)
+ *   matrices_t[s]   the transposed copy of matrices[s] (same stride), or NULL (the array itself may be NULL) for a symmetric
+ *            matrix: timeCost[v][u] with u the node being improved is read as row u of the transpose, so that a wavefront's 64
+ *            gathers fall on a few cache lines instead of 64 (the same numbers either way)
  *   demand   [B][n] f64 AS HGS GETS THEM (the caller multiplies by 1000, swapstar.py:335), demand[.][0] = 0
  *   capacity 1000.001 in the reference (swapstar.py:337)
  *   paths    in/out [B][Lmax][A] int64: column (b, a) is a zero-separated route sequence (cvrp/aco.py:138-165); rewritten
@@ -530,7 +533,7 @@ size_t daco_hgs_table_bytes(int n, int nb_granular);
 int daco_hgs_prepare(void *stream, int B, int n, const double *matrix, long bstride, int nb_granular, void *tables);
 size_t daco_hgs_workspace_bytes(int B, int n, int A, int Lmax, int nb_granular);
 int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax, int nstages, const double *const *matrices,
-                          const long *bstrides, const void *const *tables, const int *counts, const double *demand,
+                          const double *const *matrices_t, const long *bstrides, const void *const *tables, const int *counts, const double *demand,
                           double capacity, int nb_granular, int64_t *paths, int32_t *status, int32_t *stats,
                           void *workspace, size_t workspace_bytes);
 
