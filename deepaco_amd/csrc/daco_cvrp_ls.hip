@@ -410,7 +410,8 @@ extern "C" int daco_cvrp_local_search(void *stream, int B, int n, int A, int Lma
     return DACO_E_BADARG;
   }
   // (a column without a closing depot gets one appended: one entry of head room)
-  if (Lmax >= LS_MAXL || n > 16383) { set_error("daco_cvrp_local_search: Lmax=%d must stay below %d", Lmax, LS_MAXL); return DACO_E_TOOLARGE; }
+  if (Lmax >= LS_MAXL) { set_error("daco_cvrp_local_search: Lmax=%d must stay below %d", Lmax, LS_MAXL); return DACO_E_TOOLARGE; }
+  if (n > 16383) { set_error("daco_cvrp_local_search: n=%d is above 16383 (positions travel in 14-bit fields)", n); return DACO_E_TOOLARGE; }
   const bool stage = n <= LS_STAGE_MAX_N;
   const size_t lds = ls_fixed_bytes(Lmax, n) + (stage ? (size_t)n * n * 4 : 0);
   hipStream_t s = (hipStream_t)stream;

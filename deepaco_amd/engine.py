@@ -1195,32 +1195,69 @@ class BatchedCVRP:
 
 
 def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1.0, heuristic=None, sampler="scan",
-                    seed=0, exchange="delta", elitist=False, min_max=False, min=None):
+                    seed=0, exchange="delta", elitist=False, min_max=False, min=None, head_k=None, local_search=None,
+                    inference=False, fixed_start=-1):
     """Ant-sharded TSP colony on this rank's GPU: A/world ants of every instance here, pheromone
     replicated, one collective per iteration (RCCL over xGMI when the process group is nccl):
     exchange="delta": all-reduce of the deposits [B,n,n]; exchange="tours": all-gather of the tours (int16) and
     costs, every rank applies the full deposit in ant order -- bit-identical to BatchedTSP with the same seed, for AS,
     elitist and MMAS colonies, best tours (`shortest_path`) included.
+    sampler: as BatchedTSP ("auto" / "scan_sparse": head / tail rows, head_k entries per row as after sparsify(head_k));
+    local_search "2opt" | "nls" (tsp_nls/aco.py:105-129): every rank improves ITS ants' tours before the exchange (the search
+    of a tour depends on that tour only, so the colony stays the single-GPU one).
     Returns a parallel.AntShardedColony whose kernels are the HIP ones."""
     from .parallel import AntShardedColony
     _require_gpu(distances)
     dist_ = _f32c(distances)
     B, n, _ = dist_.shape
     eta = (1 / dist_) if heuristic is None else heuristic
-    state = {}
+    state, cache = {}, {}
     exact = exchange == "tours"
+    assert local_search in (None, "2opt", "nls")
 
     def sample_fn(tau, lo, n_local, it):
         # colony-wide ant ids in both modes (ant lo + a of instance b is ant b*A + lo + a of the single-GPU colony):
         # rank-local ids would overlap when n_ants % world != 0 (shard_range gives the first ranks one ant more)
-        paths, _, _, _, costs, nbr = tsp_sample(tau, eta, n_local, alpha, beta, mode=sampler, seed=seed, it=it,
-                                                ant_gid0=lo, ant_gid_bstride=n_ants, batch=B, dist=dist_,
-                                                want_nbr=not exact and not elitist)
+        want_nbr = not exact and not elitist and local_search is None
+        mode, hk = resolve_sampler(sampler, n, head_k, eta, cache)
+        if mode == "scan_sparse":
+            if cache.get("head") is None or cache["head"][0] != hk:
+                h = eta.detach()
+                h = h if h.dim() == 3 else h.unsqueeze(0).expand(B, n, n)
+                cache["head"] = (hk, sparse_head(_f32c(h), hk))
+            paths, _, costs, nbr = tsp_sample_sparse(tau, eta, n_local, cache["head"][1], alpha, beta, seed=seed, it=it, ant_gid0=lo,
+                                                     ant_gid_bstride=n_ants, fixed_start=fixed_start, batch=B, dist=dist_,
+                                                     want_nbr=want_nbr)
+        else:
+            paths, _, _, _, costs, nbr = tsp_sample(tau, eta, n_local, alpha, beta, mode=mode, seed=seed, it=it,
+                                                    ant_gid0=lo, ant_gid_bstride=n_ants, fixed_start=fixed_start, batch=B,
+                                                    dist=dist_, want_nbr=want_nbr)
+        if local_search is not None:
+            tours = paths.permute(0, 2, 1).to(torch.int16).contiguous()
+            maxt = 10000 if inference else n // 4
+            if "dist_t" not in cache:
+                cache["dist_t"] = transposed_for_two_opt(dist_)
+                cache["tables"] = two_opt_tables(dist_, cache["dist_t"])
+            if local_search == "2opt":
+                two_opt_(dist_, tours, maxt, dist_t=cache["dist_t"], tables=cache["tables"])
+                costs = None
+            else:
+                if "hd" not in cache:
+                    h = eta.detach().float()
+                    cache["hd"] = (1 / (h / h.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
+                    cache["hd_t"] = transposed_for_two_opt(cache["hd"])
+                    cache["htables"] = two_opt_tables(cache["hd"], cache["hd_t"])
+                tours, costs = nls_(dist_, cache["hd"], tours, maxt, dist_t=cache["dist_t"], heuristic_dist_t=cache["hd_t"],
+                                    tables=cache["tables"], heuristic_tables=cache["htables"], want_costs=True)
+            paths = tours.permute(0, 2, 1).to(torch.int64).contiguous()
+            if costs is None:
+                costs = tour_costs(dist_, paths)
+            nbr = None
         state["costs"], state["nbr"] = costs, nbr
         return paths
 
     def cost_fn(paths):
-        return state["costs"]                     # fused into the sampler
+        return state["costs"]                     # fused into the sampler (or the local search)
 
     def deposit_fn(zero, paths, costs):
         return pheromone_update_(zero, paths, costs, 1.0, nbr=state["nbr"])

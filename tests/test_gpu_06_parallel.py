@@ -50,7 +50,14 @@ def _worker(rank, world, port, q, B, n, A, iters, exchange, kw, problem="tsp", b
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from deepaco_amd import engine
     if problem == "tsp":
-        col = engine.ant_sharded_tsp(_instances(B, n, 5).to(dev), A, rank, world, seed=77, exchange=exchange, **kw)
+        kw = dict(kw)
+        k_sparse = kw.pop("k_sparse", None)
+        d = _instances(B, n, 5).to(dev)
+        if k_sparse:                                             # what BatchedTSP.sparsify(k) makes of the heuristic
+            _, idx = torch.topk(d, k=k_sparse, dim=2, largest=False)
+            kw["heuristic"] = 1 / torch.full_like(d, 1e10).scatter_(2, idx, torch.gather(d, 2, idx))
+            kw["head_k"] = k_sparse
+        col = engine.ant_sharded_tsp(d, A, rank, world, seed=77, exchange=exchange, **kw)
     else:
         d, dem = _cvrp_instances(B, n, 5)
         col = engine.ant_sharded_cvrp(d.to(dev), dem.to(dev), A, rank, world, capacity=30, seed=77, exchange=exchange, **kw)
@@ -107,6 +114,24 @@ def test_two_ranks_equal_single_process(exchange, n, A, kw):
         np.testing.assert_allclose(tau, ref_tau, rtol=2e-5)
         np.testing.assert_allclose(low, ref_low, rtol=0, atol=0)
         assert (sp == ref_sp).all()
+
+
+@pytest.mark.parametrize("kw,n", [(dict(sampler="auto", k_sparse=20), 200), (dict(local_search="2opt", fixed_start=0), 120),
+                                  (dict(local_search="nls", fixed_start=0, sampler="auto", k_sparse=15), 150)])
+def test_two_ranks_with_head_rows_and_local_search(kw, n):
+    """The ant-sharded colony on head / tail rows (sampler 'auto' after sparsify) and with the local search of tsp_nls
+    (tsp_nls/aco.py:105-129: every rank improves its own ants' tours before the exchange): two ranks, tour exchange ==
+    BatchedTSP bit for bit (pheromone, best costs, best tours)."""
+    from deepaco_amd import engine
+    B, A, iters, world = 2, 13, 3, 2
+    tau, low, sp = _run_ranks(world, B, n, A, iters, "tours", kw)
+    skw = {k: v for k, v in kw.items() if k != "k_sparse"}
+    single = engine.BatchedTSP(_instances(B, n, 5).to("cuda:0"), n_ants=A, seed=77, **skw)
+    if kw.get("k_sparse"):
+        single.sparsify(kw["k_sparse"])
+    single.run(iters)
+    assert (tau.view("uint32") == single.pheromone.cpu().numpy().view("uint32")).all()
+    assert (low == single.lowest_cost.cpu().numpy()).all() and (sp == single.shortest_path.cpu().numpy()).all()
 
 
 @pytest.mark.parametrize("exchange,kw", [("tours", {}), ("tours", dict(elitist=True)), ("tours", dict(min_max=True)), ("delta", {})])
