@@ -78,6 +78,7 @@ class ACO(_CvrpACO):
         self._heu_src = None if heuristic is None else engine.stage_to_hip(heuristic.detach(), like=self.distances)
         self._demand_src = engine.stage_to_hip(demand.detach(), like=self.distances)
         self._hgs = None
+        self._heu_at_init = self.heuristic               # (a heuristic assigned later replaces the constructor's in the local search too)
 
     def sample(self, inference=False):
         paths, log_probs = self.gen_path(require_prob=True)
@@ -105,7 +106,10 @@ class ACO(_CvrpACO):
         colony.  The perturbation matrix is cvrp_nls/aco.py:128-132 in the heuristic's own dtype (numpy there, torch here:
         the same IEEE divisions), the default heuristic 1 / distances (cvrp_nls/aco.py:92)."""
         if self._hgs is None:
-            heu = self._heu_src if self._heu_src is not None else 1 / self._dist_src
+            if self.heuristic is not self._heu_at_init:      # assigned after construction (the reference reads self.heuristic at first use)
+                heu = self.heuristic.detach()
+            else:
+                heu = self._heu_src if self._heu_src is not None else 1 / self._dist_src
             hd = 1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)
             self._hgs = (engine.HgsTables(self._dist_src), engine.HgsTables(hd))
         return self._hgs
