@@ -130,6 +130,10 @@ def headline_record(full):
     if rf:
         rec["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms")}
         rec["roofline"]["valu_busy"] = rf.get("valu_busy")
+        pp = rf.get("pipes") or {}
+        # what the counter pass of this kernel says about the CU's units (the head-row kernel is bound by instruction issue and the
+        # vector-memory return path, not by the byte rate `frac` is taken against)
+        rec["roofline"]["units"] = {k: pp.get(k) for k in ("valu_active", "td_busy", "ta_busy", "lds_busy", "l2_hit_rate") if k in pp} or None
         alg, hbm = rf.get("algorithmic") or {}, rf.get("hbm") or {}
         rec["roofline"]["algorithmic"] = {"GBps": alg.get("GBps"), "over_hbm_peak": alg.get("over_hbm_peak")}
         rec["roofline"]["hbm"] = {"ratio": hbm.get("ratio"), "GBps": hbm.get("GBps"), "peak": hbm.get("peak")}

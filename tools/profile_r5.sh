@@ -34,6 +34,13 @@ stats() {
   find $OUT/stats_$tag -name "*.db" -delete 2>/dev/null
   rm -rf $OUT/stats_$tag
 }
+if [ "$WHAT" = "hgs" ]; then      # the local-search kernel alone (after a change to it)
+  stats hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short
+  pmc hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short --reps 2
+  stats train python tools/run_train_step.py 5
+  ls $OUT
+  exit 0
+fi
 if [ "$WHAT" != "pmc" ]; then
   stats headline python bench.py --no-cpu --no-extras --min-seconds 0
   stats headline_dense python bench.py --no-cpu --no-extras --min-seconds 0 --sampler scan
