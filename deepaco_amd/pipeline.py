@@ -14,11 +14,12 @@ EPS = 1e-10        # added to the learned heuristic (tsp/train.ipynb:35, tsp_nls
 
 @torch.no_grad()
 def infer_tsp_batch(coords, n_ants, t_aco, k_sparse, net=None, node_feature="coords", local_search=None,
-                    sampler="scan", seed=0, **aco_kw):
+                    sampler="auto", seed=0, **aco_kw):
     """coords [B,n,2] on a HIP device; t_aco: iteration checkpoints, e.g. [1, 10, 20] (the reference's schedule
     `t_aco_diff`); net: a deepaco_amd Net in eval mode or None for the vanilla heuristic 1/d on the kNN edges
     (ACO.sparsify, tsp/aco.py:52-67); node_feature: 'coords' (tsp/) or 'onehot0' (tsp_nls/utils.py:38-44: a
-    one-hot of the start node).  Returns (best costs [len(t_aco), B], colony)."""
+    one-hot of the start node); sampler: BatchedTSP's ("auto": the network's k-sparse heuristic and the sparsified 1/d both
+    run on head / tail rows for 129 <= n <= 1024).  Returns (best costs [len(t_aco), B], colony)."""
     B, n, _ = coords.shape
     dist, ei, ea = engine.tsp_knn_graph(coords, k_sparse)
     heuristic = None
