@@ -845,6 +845,33 @@ def extra_configs(dev, headline_colony, cpu=True):
     except Exception as e:
         out["cvrp_local_search_100_a512_b64"] = {"error": repr(e)}
 
+    # configuration 4's colonies with cvrp_nls's local search in the loop (cvrp_nls/aco.py:134-171: the 8 cheapest ants of every
+    # instance through neural_swapstar each iteration): engine.BatchedCVRP(local_search="hgs")
+    try:
+        n, A, B = 100, 512, 256
+        g = torch.Generator().manual_seed(3)
+        loc = torch.cat((torch.full((B, 1, 2), 0.5, dtype=torch.double), torch.rand(B, n, 2, generator=g, dtype=torch.double)), 1)
+        dem = torch.cat((torch.zeros(B, 1, dtype=torch.double), torch.randint(1, 10, (B, n), generator=g).double()), 1)
+        dl = (loc[:, :, None] - loc[:, None]).norm(dim=-1)
+        dl[:, torch.arange(n + 1), torch.arange(n + 1)] = 1e-10
+        col = engine.BatchedCVRP(dl.to(dev), dem.to(dev), n_ants=A, capacity=50, seed=1, local_search="hgs")
+        plain = engine.BatchedCVRP(dl.to(dev), dem.to(dev), n_ants=A, capacity=50, seed=1)
+        col.step()
+        plain.step()
+        dtl = time_launches(col.step, 5, warm=1)
+        plain.run(6)
+        out["c4_cvrp100_nls_a512_b256"] = {
+            "workload": f"CVRP-{n}, n_ants={A}, {B} instances, the 8 cheapest ants of every instance through neural_swapstar each iteration "
+                        f"(cvrp_nls/aco.py:134-171), AS iteration", "value": B * A / dtl, "unit": "ant-tours/s", "ms_per_step": dtl * 1e3,
+            "local_search_solutions_per_iteration": 8 * B,
+            "mean_best_cost_after_7_iterations": float(col.lowest_cost.mean()),
+            "without_local_search_mean_best_cost_after_7_iterations": float(plain.lowest_cost.mean()),
+            "note": "the local search of an iteration is 2 048 solutions = one round of wavefronts: its time is a single solution's chain "
+                    "(DESIGN 3.8b: 3.7 us per round), not the kernel's throughput"}
+        del col, plain
+    except Exception as e:
+        out["c4_cvrp100_nls_a512_b256"] = {"error": repr(e)}
+
     # headline workload with the LEARNED heuristic: Net + the reference's pretrained tsp500 weights
     # (tests/golden/w_tsp_tsp500.npz: the checkpoint as plain arrays), heu + 1e-10, next to the vanilla 1/d on the
     # same instances and seeds

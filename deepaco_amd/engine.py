@@ -1132,8 +1132,17 @@ class BatchedCVRP:
     elitist / MMAS); an iteration is sampler (+ fused costs and successor table) -> deposit, no host sync."""
 
     def __init__(self, distances, demand, n_ants=20, decay=0.9, alpha=1, beta=1, elitist=False, min_max=False,
-                 pheromone=None, heuristic=None, min=None, capacity=50, sampler="scan", seed=None, ant_gid0=0):
+                 pheromone=None, heuristic=None, min=None, capacity=50, sampler="scan", seed=None, ant_gid0=0,
+                 local_search=None, ls_ants=8, inference=False):
+        """local_search="hgs": the colony iteration of cvrp_nls/aco.py:134-171 (swapstar=True) for every instance -- the `ls_ants`
+        cheapest ants of each instance go through neural_swapstar (cvrp_nls/aco.py:143-146, 443-448; daco_hgs_local_search, the
+        reference's routes) before best tracking and the deposit.  The local search reads `distances` and the heuristic in the
+        dtype they are passed in (float64 instance data as cvrp_nls/utils.py builds it) and the demands as demand / capacity."""
         _require_gpu(distances, demand)
+        assert local_search in (None, "hgs")
+        self.local_search, self.ls_ants, self.inference = local_search, int(ls_ants), inference
+        self._ls_src = (distances.detach(), None if heuristic is None else heuristic.detach(), demand.detach())
+        self._hgs = None
         self.distances = _f32c(distances)
         self.demand = _f32c(demand)
         self.B, self.n = distances.shape[0], distances.shape[1]
@@ -1163,6 +1172,22 @@ class BatchedCVRP:
             dist=self.distances, want_table=True, events=events)
         self.iteration += 1
         self.last_lens, self.last_flags = lens, flags
+        if self.local_search == "hgs":
+            if self._hgs is None:
+                d_src, h_src, dem_src = self._ls_src
+                heu = h_src if h_src is not None else 1 / d_src
+                hd = 1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)                    # cvrp_nls/aco.py:128-132
+                self._hgs = (HgsTables(d_src), HgsTables(hd), dem_src.double() / float(self.capacity))
+            td, th, dem_n = self._hgs
+            k = min(self.ls_ants, self.n_ants)
+            idx = costs.topk(k, dim=1, largest=False).indices                               # [B, k]
+            gi = idx.unsqueeze(1).expand(self.B, paths.shape[1], k)
+            work = paths.gather(2, gi).contiguous()
+            limit = 100000 if self.inference else max(self.n, 50)
+            hgs_local_search_(work, [(td, limit), (th, 10), (td, limit)], dem_n)
+            paths.scatter_(2, gi, work)
+            costs.scatter_(1, idx, tour_costs(self.distances, work, closed=False))
+            table = None                                                                    # (the deposit rebuilds it from the paths)
         if self.shortest_path is None or self.shortest_path.shape[1] != paths.shape[1]:
             self.shortest_path = torch.zeros((self.B, paths.shape[1]), dtype=torch.int64, device=paths.device)
         new_max = track_best_(costs, paths, self.lowest_cost, self.shortest_path,

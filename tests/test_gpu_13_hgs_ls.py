@@ -191,3 +191,35 @@ def test_incomplete_column_is_left_untouched():
     out, status, _ = run(bad, [(td, 10)], dem, want_stats=True)
     assert status[0].tolist() == [0, 0, 0, 2, 0, 0, 0, 0]
     np.testing.assert_array_equal(out[0, :bad.shape[0], 3].cpu().numpy(), bad[:, 3])
+
+
+def test_batched_cvrp_colony_with_the_local_search():
+    """engine.BatchedCVRP(local_search="hgs"): the iteration of cvrp_nls/aco.py:134-171 for B instances -- the eight cheapest ants
+    of every instance go through neural_swapstar before best tracking and the deposit.  First iteration against a twin colony
+    without the local search (same seed: the same sampled routes) and the oracle on the selected ants; best costs improve."""
+    from deepaco_amd import engine
+    B, n, A = 3, 60, 24
+    g = torch.Generator().manual_seed(9)
+    loc = torch.cat((torch.full((B, 1, 2), 0.5, dtype=torch.double), torch.rand(B, n, 2, generator=g, dtype=torch.double)), 1)
+    dem = torch.cat((torch.zeros(B, 1, dtype=torch.double), torch.randint(1, 10, (B, n), generator=g).double()), 1)
+    d = (loc[:, :, None] - loc[:, None]).norm(dim=-1)
+    d[:, torch.arange(n + 1), torch.arange(n + 1)] = 1e-10
+    plain = engine.BatchedCVRP(d.to(dev()), dem.to(dev()), n_ants=A, capacity=30, seed=4)
+    ls = engine.BatchedCVRP(d.to(dev()), dem.to(dev()), n_ants=A, capacity=30, seed=4, local_search="hgs")
+    p0, c0 = plain.step()
+    p1, c1 = ls.step()
+    idx = c0.topk(8, dim=1, largest=False).indices
+    hd = (1 / ((1 / d) / (1 / d).max(-1, keepdim=True).values + 1e-5)).numpy()
+    L = p0.shape[1]
+    touched = torch.zeros(B, A, dtype=torch.bool, device=dev())
+    touched.scatter_(1, idx, True)
+    assert torch.equal(p1.permute(0, 2, 1)[~touched], p0.permute(0, 2, 1)[~touched])          # the other ants keep their routes
+    for b in range(B):
+        for a in idx[b].tolist()[:3]:
+            want = oracle.hgs_neural_swapstar(loc[b].numpy(), d[b].numpy(), hd[b], (dem[b] / 30).numpy(), p0[b, :, a].cpu().numpy(),
+                                              max(n + 1, 50))
+            np.testing.assert_array_equal(p1[b, :, a].cpu().numpy(), want[:L], err_msg=f"instance {b} ant {a}")
+            assert not want[L:].any()
+    assert bool((c1 <= c0 + 1e-5).all()) and bool((ls.lowest_cost < plain.lowest_cost).all())
+    ls.run(3)
+    assert bool((ls.lowest_cost <= c1.min(dim=1).values + 1e-6).all())
