@@ -1,0 +1,52 @@
+"""Host logic of sampler='auto' (engine.resolve_sampler / auto_head_k): which kernel family a colony's next construction runs.
+No GPU: the rule reads the heuristic's rows only."""
+import warnings
+
+import torch
+
+from deepaco_amd import engine
+
+
+def _ksparse(n, k, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand(n, 2, generator=g)
+    d = (c[:, None] - c).norm(dim=-1)
+    d[torch.arange(n), torch.arange(n)] = 1e9
+    _, idx = torch.topk(d, k=k, dim=1, largest=False)
+    return d, torch.full_like(d, 1e-10).scatter_(1, idx, torch.rand(n, k, generator=g) + 0.05)
+
+
+def test_head_size_from_the_heuristics_rows():
+    d, h40 = _ksparse(300, 40)
+    assert engine.auto_head_k(h40) == 63                      # the network's k-sparse output: 40 live entries per row
+    _, h100 = _ksparse(300, 100)
+    assert engine.auto_head_k(h100) == 127
+    assert engine.auto_head_k(1 / d) is None                  # plain 1/d: a fifth of a row's mass is in the tail
+    _, h200 = _ksparse(300, 200)
+    assert engine.auto_head_k(h200) is None
+    assert engine.auto_head_k(_ksparse(100, 10)[1]) is None   # sizes the head kernels do not cover
+    flat = h40.clone()
+    flat[:10] = 1e-10                                         # a few flat rows (all live entries below the floor) do not veto
+    assert engine.auto_head_k(flat) == 63
+    flat[:40] = 1e-10                                         # more than one row in twenty does
+    assert engine.auto_head_k(flat) is None
+
+
+def test_resolution_rules():
+    d, h = _ksparse(300, 40)
+    cache = {}
+    assert engine.resolve_sampler("scan", 300, 30, h, cache) == ("scan", 30)          # explicit choices pass through
+    assert engine.resolve_sampler("race", 300, None, h, cache) == ("race", None)
+    assert engine.resolve_sampler("auto", 300, 30, 1 / d, cache) == ("scan_sparse", 30)      # after sparsify(k): its k
+    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 63)
+    assert cache["auto_head"][0] is h                                                  # (tested once per heuristic object)
+    assert engine.resolve_sampler("auto", 300, None, 1 / d, cache) == ("scan", None)
+    assert engine.resolve_sampler("auto", 100, 10, h[:100, :100], {}) == ("scan", None)
+    assert engine.resolve_sampler("auto", 2000, 100, h, {}) == ("scan", None)
+    engine._warned_sparse_range = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert engine.resolve_sampler("scan_sparse", 100, 10, h, {}) == ("scan", None)
+        assert engine.resolve_sampler("scan_sparse", 100, 10, h, {}) == ("scan", None)
+    assert len([x for x in w if "scan_sparse" in str(x.message)]) == 1                # said once
+    assert engine.resolve_sampler("scan_sparse", 300, 20, h, {}) == ("scan_sparse", 20)
