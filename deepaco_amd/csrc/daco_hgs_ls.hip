@@ -834,10 +834,9 @@ extern "C" int daco_hgs_prepare(void *stream, int B, int n, const double *matrix
   return DACO_OK;
 }
 
-static int hgs_wps() {
-  static const int v = getenv("DACO_HGS_WPS") ? atoi(getenv("DACO_HGS_WPS")) : 0;
-  return v >= 2 && v <= 4 ? v : 3;
-}
+// wavefronts per SIMD the kernel is compiled for: 168 registers.  Measured at CVRP-100 x 512 ants: two (198 registers) 232 k, three
+// 309 k, four (128 registers, 49 of them spilled) 283 k solutions/s at 16 instances, 374 k against 384 k at 256.
+constexpr int HGS_WPS = 3;
 
 static int hgs_grid(int n, int Rmax, int *waves_out, size_t *lds_out) {
   const size_t per_wave = hgs_lds_bytes(n, Rmax);
@@ -853,7 +852,7 @@ static int hgs_grid(int n, int Rmax, int *waves_out, size_t *lds_out) {
   }
   const size_t lds_cu = 160 * 1024;
   int wg_per_cu = (int)(lds_cu / (*lds_out ? *lds_out : 1));
-  const int cap = 4 * hgs_wps() / waves > 0 ? 4 * hgs_wps() / waves : 1;      // wavefronts per CU the register budget of the kernel allows
+  const int cap = 4 * HGS_WPS / waves > 0 ? 4 * HGS_WPS / waves : 1;      // wavefronts per CU the register budget of the kernel allows
   if (wg_per_cu > cap) wg_per_cu = cap;
   if (wg_per_cu < 1) wg_per_cu = 1;
   return cus * wg_per_cu;
@@ -913,10 +912,9 @@ extern "C" int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax
     }                                                                                                                               \
     hipLaunchKernelGGL((hgs_ls_kernel<W_, S_>), dim3(grid), dim3(W_ * 64), lds, st, p);                                             \
   } while (0)
-  const int wps = hgs_wps();
-  if (waves == 4) { if (wps == 4) DACO_HGS_LAUNCH(4, 4); else if (wps == 2) DACO_HGS_LAUNCH(4, 2); else DACO_HGS_LAUNCH(4, 3); }
-  else if (waves == 2) DACO_HGS_LAUNCH(2, 3);
-  else DACO_HGS_LAUNCH(1, 3);
+  if (waves == 4) DACO_HGS_LAUNCH(4, HGS_WPS);
+  else if (waves == 2) DACO_HGS_LAUNCH(2, HGS_WPS);
+  else DACO_HGS_LAUNCH(1, HGS_WPS);
 #undef DACO_HGS_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) { set_error("hgs_ls_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
