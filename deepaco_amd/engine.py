@@ -1144,7 +1144,8 @@ class BatchedCVRP:
         self._ls_src = (distances.detach(), None if heuristic is None else heuristic.detach(), demand.detach())
         self._hgs = None
         self.distances = _f32c(distances)
-        self.demand = _f32c(demand)
+        # float64 demands (cvrp_nls/utils.py:12-26) keep the load bookkeeping of the construction in double, as cvrp_sample does
+        self.demand = demand.contiguous() if demand.dtype == torch.float64 else _f32c(demand)
         self.B, self.n = distances.shape[0], distances.shape[1]
         self.n_ants, self.decay, self.alpha, self.beta, self.capacity = n_ants, decay, alpha, beta, capacity
         self.elitist, self.min_max = elitist, min_max

@@ -84,3 +84,48 @@ def train_tsp_nls_batch(net, optimizer, coords, n_ants, k_sparse, seed=0, it=0, 
     torch.nn.utils.clip_grad_norm_(parameters=net.parameters(), max_norm=max_norm, norm_type=2)
     optimizer.step()
     return loss.detach(), costs.mean(), costs_ls.mean()
+
+
+@torch.no_grad()
+def cvrp_nls_graph_batch(demands, distances, k_sparse):
+    """cvrp_nls/utils.py:34-60 (gen_pyg_data) for B instances at once: every customer's k nearest customers (customer order,
+    nearest first), then depot -> customer and customer -> depot; node feature = demand.  demands [B,n+1], distances
+    [B,n+1,n+1] -> (x [B,n+1,1] f32, edge_index [B,2,E] int64 with ids local to each graph, edge_attr [B,E,1] f32)."""
+    B, n1 = demands.shape
+    dev = demands.device
+    near_d, near_i = torch.topk(distances[:, 1:, 1:], k=k_sparse, dim=2, largest=False)
+    src = torch.repeat_interleave(torch.arange(1, n1, device=dev), repeats=k_sparse).unsqueeze(0).expand(B, -1)
+    knn = torch.stack((src, near_i.reshape(B, -1) + 1), dim=1)                                  # [B, 2, n k]
+    customers = torch.arange(1, n1, device=dev).unsqueeze(0).expand(B, -1)
+    depot = torch.zeros_like(customers)
+    edge_index = torch.cat((knn, torch.stack((depot, customers), dim=1), torch.stack((customers, depot), dim=1)), dim=2)
+    to_depot = distances[:, 1:, 0]
+    edge_attr = torch.cat((near_d.reshape(B, -1), to_depot, to_depot), dim=1).unsqueeze(2)
+    return demands.unsqueeze(2).float(), edge_index.contiguous(), edge_attr.float().contiguous()
+
+
+@torch.no_grad()
+def infer_cvrp_nls_batch(locations, demands, n_ants, t_aco, k_sparse, net=None, seed=0, ls_ants=8, **aco_kw):
+    """The batched counterpart of cvrp_nls/test.py:40-60 (`infer_instance`): locations [B,n+1,2] (node 0 = depot) and
+    demands [B,n+1] normalised to capacity 1, float64 as cvrp_nls/utils.py:12-26 builds them -> distances -> sparse graph ->
+    heuristic (the network in eval mode, + 1e-10; None: 1 / distance) -> B colonies whose `ls_ants` cheapest ants go through the
+    reference's local search every iteration (engine.BatchedCVRP(local_search="hgs", inference=True)).
+    Returns (best costs [len(t_aco), B], colony); colony.shortest_path holds the best route sequences."""
+    B, n1, _ = locations.shape
+    loc = locations.double()
+    dist = torch.norm(loc[:, :, None] - loc[:, None], dim=3, p=2)
+    ar = torch.arange(n1, device=loc.device)
+    dist[:, ar, ar] = 1e-10                                                                         # cvrp_nls/utils.py:28-32
+    heuristic = None
+    if net is not None:
+        x, ei, ea = cvrp_nls_graph_batch(demands, dist, k_sparse)
+        heu = net.forward_batch(x, ei, ea)
+        heuristic = net.reshape_batch(n1, ei, heu) + EPS
+    colony = engine.BatchedCVRP(dist, demands.double(), n_ants=n_ants, capacity=1.0, heuristic=heuristic, seed=seed,
+                                local_search="hgs", ls_ants=ls_ants, inference=True, **aco_kw)
+    out, done = [], 0
+    for t in t_aco:
+        colony.run(t - done)
+        done = t
+        out.append(colony.lowest_cost.clone())
+    return torch.stack(out), colony

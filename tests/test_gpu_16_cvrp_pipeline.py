@@ -1,0 +1,107 @@
+"""pipeline.infer_cvrp_nls_batch: the batched counterpart of cvrp_nls/test.py:40-60 (infer_instance).  The batched graph
+and heuristic are checked against the per-instance class path (cvrp_nls/utils.py:34-60 + Net + reshape), the colonies'
+results through the properties every CVRP solution has (each customer once, route loads within the capacity, the cost of
+the stored routes), determinism, and the gain over plain construction."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _instances(B, n, seed):
+    sys.path.insert(0, os.path.join(ROOT, "deepaco_amd", "cvrp_nls"))
+    from deepaco_amd.cvrp_nls.utils import gen_instance
+    torch.manual_seed(seed)
+    rows = [gen_instance(n, dev(), position=True) for _ in range(B)]
+    demands = torch.stack([r[0] for r in rows])
+    distances = torch.stack([r[1] for r in rows])
+    locations = torch.stack([r[2] for r in rows])
+    return demands, distances, locations
+
+
+def _net(seed=3):
+    from deepaco_amd.cvrp_nls.net import Net
+    torch.manual_seed(seed)
+    return Net().to(dev()).eval()
+
+
+@pytest.mark.parametrize("n,k", [(20, 4), (100, 20)])
+def test_batched_graph_and_heuristic_match_the_class_path(n, k):
+    from deepaco_amd import pipeline
+    from deepaco_amd.cvrp_nls.utils import gen_pyg_data
+    B = 5
+    demands, distances, _ = _instances(B, n, seed=n)
+    x, ei, ea = pipeline.cvrp_nls_graph_batch(demands, distances, k)
+    net = _net()
+    heu = net.forward_batch(x, ei, ea)
+    mats = net.reshape_batch(n + 1, ei, heu)
+    for b in range(B):
+        g = gen_pyg_data(demands[b], distances[b], dev(), k_sparse=k)
+        assert torch.equal(g.edge_index, ei[b])
+        assert torch.equal(g.edge_attr, ea[b])
+        assert torch.equal(g.x, x[b])
+        with torch.no_grad():
+            one = net(g)
+        torch.testing.assert_close(heu[b], one.view(-1), atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(mats[b], net.reshape(g, one), atol=1e-6, rtol=1e-5)
+
+
+def _check_solution(route, demand, dist, cost):
+    """route: zero-padded node sequence of one instance; demand normalised to capacity 1."""
+    r = route.tolist()
+    n1 = demand.shape[0]
+    visited = [v for v in r if v != 0]
+    assert sorted(visited) == list(range(1, n1)), "every customer exactly once"
+    load, total = 0.0, 0.0
+    for a, b in zip(r[:-1], r[1:]):
+        if a != b:
+            total += float(dist[a, b])
+        load = 0.0 if b == 0 else load + float(demand[b])
+        assert load <= 1.0 + 1e-9, "route load within the capacity"
+    assert abs(total - float(cost)) <= 1e-4 * max(1.0, total)
+
+
+@pytest.mark.parametrize("with_net", [False, True])
+def test_batched_inference_returns_feasible_improving_solutions(with_net):
+    from deepaco_amd import pipeline
+    B, n = 6, 50
+    demands, distances, locations = _instances(B, n, seed=11)
+    net = _net() if with_net else None
+    costs, colony = pipeline.infer_cvrp_nls_batch(locations, demands, n_ants=20, t_aco=[1, 3, 6], k_sparse=10, net=net, seed=5)
+    assert costs.shape == (3, B)
+    assert bool(torch.isfinite(costs).all())
+    assert bool((costs[1:] <= costs[:-1] + 1e-6).all()), "the best cost never gets worse"
+    colony.check_feasible()
+    for b in range(B):
+        _check_solution(colony.shortest_path[b].cpu(), demands[b].cpu(), distances[b].cpu(), costs[-1, b])
+
+
+def test_batched_inference_is_deterministic():
+    """Same seed, same instances: the same best costs and routes."""
+    from deepaco_amd import pipeline
+    B, n = 4, 30
+    demands, distances, locations = _instances(B, n, seed=23)
+    net = _net()
+    a, ca = pipeline.infer_cvrp_nls_batch(locations, demands, n_ants=16, t_aco=[2, 4], k_sparse=6, net=net, seed=9)
+    b, cb = pipeline.infer_cvrp_nls_batch(locations, demands, n_ants=16, t_aco=[2, 4], k_sparse=6, net=net, seed=9)
+    assert torch.equal(a, b) and torch.equal(ca.shortest_path, cb.shortest_path)
+
+
+def test_local_search_lowers_the_batch_mean_against_plain_construction():
+    """What the local search is for (cvrp_nls/test.py's 'swapstar' rows against cvrp/'s): same instances, same seed."""
+    from deepaco_amd import engine, pipeline
+    B, n = 8, 50
+    demands, distances, locations = _instances(B, n, seed=31)
+    with_ls, _ = pipeline.infer_cvrp_nls_batch(locations, demands, n_ants=20, t_aco=[5], k_sparse=10, seed=2)
+    plain = engine.BatchedCVRP(distances, demands, n_ants=20, capacity=1.0, seed=2)
+    plain.run(5)
+    assert float(with_ls[-1].mean()) < float(plain.lowest_cost.mean())
