@@ -489,19 +489,29 @@ gnn_fused_layer_kernel(int n, int E, int feats, int layer, int npw, const int *s
 //     product stays finite; sigmoid(-44) = 8e-20 is zero at the network's 1e-5 tolerance either way);
 //   * the accumulator starts from zero (inline constant) and the bias is folded into the BatchNorm shift; every address is
 //     a uniform base plus a 32-bit byte offset (host guarantees E * 128 < 4 GB).
+// Round 5, after an ablation of this kernel (profiles/r05_gnn_layer_ablation.txt: memory alone and compute alone ~85 us each,
+// together 114; no single part is the bound) -- 120 -> 113 us per launch in alternating profiler runs:
+//   * the aggregate is S x P on the matrix unit (S[node][edge] = 1 where the edge leaves the node), accumulated over the
+//     wave's tiles in two 16x16x4 blocks: the products are read back once, nothing is cut by scalar compares and branches;
+//   * the node phase has all of a wavefront's loads in flight at once (it waited once per node and per input channel, and
+//     every wavefront of the one-round launch is in that phase at the same time: 15 us of the launch);
+//   * e^-x without the residual term of exp_neg (see one_plus_exp_neg2).
+// NOTE: a register spilled INSIDE the tile loop is reloaded behind `s_waitcnt vmcnt(0)`, i.e. behind the next tile's row
+// prefetch (loads return in order) -- that serialises the loop (measured: +5 us with two such reloads).  Check the .s.
 constexpr int F2_MAX_NPW = 16;
 __device__ inline f32x2 one_plus_exp_neg2(f32x2 x) {       // 1 + e^-x, x clamped at -44
   // -min(-x, 44) = max(x, -44): one v_max with a literal each (fminf would add a second instruction that quiets NaNs)
   f32x2 m;
   asm("v_max_f32 %0, 0xc2300000, %1" : "=v"(m.x) : "v"(x.x));
   asm("v_max_f32 %0, 0xc2300000, %1" : "=v"(m.y) : "v"(x.y));
-  const f32x2 nx = -m;
-  const f32x2 hi = {L2E_HI, L2E_HI}, lw = {L2E_LO, L2E_LO}, ln2 = {LN2F, LN2F}, one = {1.0f, 1.0f};
-  const f32x2 t = nx * hi;
-  const f32x2 lo = __builtin_elementwise_fma(nx, lw, __builtin_elementwise_fma(nx, hi, -t));
+  // 2^(-x log2 e) on the rounded product alone (no residual term, unlike exp_neg above): the argument's rounding moves
+  // sigmoid(x) by at most s (1 - s) |x| 2^-24 <= 1.4e-8 and silu(x) by at most 2.7e-8 -- below half an ulp of either wherever
+  // they are not themselves below 1e-7 -- and takes four of ten instructions off each of the 2 * 32 * E evaluations of a layer
+  const f32x2 nl2e = {-L2E_HI, -L2E_HI}, one = {1.0f, 1.0f};
+  const f32x2 t = m * nl2e;
   f32x2 e;
   e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
-  return one + __builtin_elementwise_fma(e, lo * ln2, e);
+  return one + e;
 }
 // INIT (layer 0 only): the old edge state is not read but made on the fly, w0 = silu(e_lin0(edge_attr)) (tsp/net.py:31) --
 // 4 bytes per edge instead of 128, and no separate launch that writes E * 128 bytes first.
@@ -511,7 +521,7 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
                         const float *params, const float *x0, const float *X, const float *w0, float *x1out, float *Xnext,
                         float *w1out, const float *attr, int nt) {
   __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];            // A rows -> MFMA result (edge-major) -> products (channel-major)
-  __shared__ float agg_s[4][F2_MAX_NPW][U];
+  __shared__ __attribute__((aligned(16))) float agg_s[4][F2_MAX_NPW][U];      // per node: the aggregate, then x' (node phase)
   __shared__ __attribute__((aligned(16))) float x3_s[4][F2_MAX_NPW][U];       // x3 rows of the wave's own nodes
   __shared__ __attribute__((aligned(16))) float we_s[32][36];                 // We
   const float *lp = params + off_layer(feats, layer);
@@ -540,8 +550,6 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
       const int j = k * 8 + g8, jn = min(i0 + min(j, cnt - 1), n - 1);
       *reinterpret_cast<float4 *>(&x3_s[wave][j][c0]) = *reinterpret_cast<const float4 *>(Xb + (uint32_t)jn * 512u + 256u + (uint32_t)c0 * 4u);
     }
-#pragma unroll
-    for (int j = 0; j < F2_MAX_NPW; ++j) agg_s[wave][j][o] = 0.0f;             // nodes without out-edges aggregate 0
   }
   const float4 sc = *reinterpret_cast<const float4 *>(se + c0);
   float4 sh = *reinterpret_cast<const float4 *>(te + c0);
@@ -549,9 +557,15 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
     const float4 bb = *reinterpret_cast<const float4 *>(be + c0);             // (g + b + a3 + a4) s + t = (g + a3 + a4) s + (b s + t)
     sh.x = fmaf(bb.x, sc.x, sh.x); sh.y = fmaf(bb.y, sc.y, sh.y); sh.z = fmaf(bb.z, sc.z, sh.z); sh.w = fmaf(bb.w, sc.w, sh.w);
   }
-  int cur = 0, seg_end = row_at(1);
-  while (cur < cnt && seg_end <= ebeg) { ++cur; seg_end = cur < cnt ? row_at(cur + 1) : 0x7fffffff; }
-  float run = 0.0f;
+  // the aggregate: agg[node][channel] = sum over the node's edges of the products, as S x P on the matrix unit -- S[node][edge]
+  // = 1 where the edge leaves the node -- accumulated over all tiles in two 16 x 16 blocks (channels 0-15, 16-31; four
+  // registers each), so a tile's 32 x 32 products are read back once (four 16-byte reads per lane) and nothing is carried
+  // through scalar compares.  Lane (r = lane / 16, i = lane % 16): node i's edge range [elo, elo + edeg), K-slot r.
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v aggA = {0, 0, 0, 0}, aggB = {0, 0, 0, 0};
+  const int r16 = lane >> 4, i16 = lane & 15;
+  const int elo = rowptr[i0 + min(i16, cnt)];
+  const uint32_t edeg = (uint32_t)(rowptr[i0 + min(i16 + 1, cnt)] - elo);
   const int elast = eend - 1;
   float4 res[4];
   // INIT: e_lin0's weight and bias of this lane's four channels; a row is silu(attr * W + b)
@@ -678,55 +692,94 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
       pr[24] = live ? gate23.y * x2[q].w : 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
-    // lane = channel: the tile's 32 products in edge order, cut at the CSR boundaries
-#pragma unroll 1
-    for (int j = 0; j < 8; ++j) {
-      const float4 v4 = *reinterpret_cast<const float4 *>(&tile[(j >> 1) * 8 + (o >> 2)][(o & 3) * 8 + (j & 1) * 4]);
-      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    // S x P: K-slot r of step kk is the edge 8r + kk of the tile (pass r's eight edges: the lane's products of a channel are
+    // eight consecutive floats of one row)
+    {
+      const uint32_t eb = (uint32_t)(e0 + 8 * r16 - elo);                       // (an edge before the node's range wraps to a large number)
+      const float *pb = &tile[8 * r16 + (i16 >> 2)][(i16 & 3) * 8];
+      const float4 p0 = *reinterpret_cast<const float4 *>(pb), p1 = *reinterpret_cast<const float4 *>(pb + 4);
+      const float4 p2 = *reinterpret_cast<const float4 *>(pb + 4 * 36), p3 = *reinterpret_cast<const float4 *>(pb + 4 * 36 + 4);
+      const float pa[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+      const float pc[8] = {p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        run += v[k];
-        const int enext = e0 + j * 4 + k + 1;
-        if (enext == seg_end) {
-          agg_s[wave][cur][o] = run;
-          run = 0.0f;
-          do { ++cur; seg_end = cur < cnt ? row_at(cur + 1) : 0x7fffffff; } while (cur < cnt && seg_end <= enext);
-        }
+      for (int kk = 0; kk < 8; ++kk) {
+        const float sel = eb + (uint32_t)kk < edeg ? 1.0f : 0.0f;
+        aggA = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, pa[kk], aggA, 0, 0, 0);
+        aggB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel, pc[kk], aggB, 0, 0, 0);
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // the wave's nodes, four at a time (as in the first version)
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {                                              // (D: lane holds nodes 4 r + rr, channel i / 16 + i)
+    agg_s[wave][4 * r16 + rr][i16] = aggA[rr];
+    agg_s[wave][4 * r16 + rr][16 + i16] = aggB[rr];
+  }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  // the wave's nodes.  Every wavefront of the launch reaches this point at about the same time (one round of workgroups), so
+  // nothing hides a load's latency here but the wavefront's own other loads: (1) x' = x0 + silu(bn_v(x1 + mean)) for ALL of
+  // the wave's nodes with their rows in flight together (lane = channel, half-wave h takes the nodes 2t + h; x' replaces the
+  // aggregate in LDS); (2) the next layer's node linears for eight nodes at a time, the weights sixteen loads per batch and
+  // x' read back from LDS as broadcasts -- the same fma order per output as the first version's four-at-a-time loop, which
+  // waited for memory once per node and once per input channel (15 us of a layer's 109).
   const float *WT = params + off_layer(feats, layer + 1), *bv = WT + 32 * 128;
-  for (int j0 = 0; j0 < cnt; j0 += 4) {
-    float xn[4];
+  {
+    constexpr int T = F2_MAX_NPW / 2;
+    float xv[T], x0v[T];
+    const float svo = sv[o], tvo = tv[o];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xn[j] = 0.0f;
-      if (j0 + j < cnt) {
-        const int i = i0 + j0 + j;
-        const int deg = row_at(j0 + j + 1) - row_at(j0 + j);
-        const float agg = agg_s[wave][j0 + j][o] / (float)max(deg, 1);
-        const float y = fmaf(X[(size_t)i * 128 + o] + agg, sv[o], tv[o]);
-        xn[j] = x0[(size_t)i * U + o] + silu(y);
-        if (h == 0) x1out[(size_t)i * U + o] = xn[j];
-      }
-    }
-    if (layer == 11) continue;
-    float y0[4], y1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { y0[j] = bv[lane]; y1[j] = bv[64 + lane]; }
-    for (int c = 0; c < U; ++c) {
-      const float wa = WT[c * 128 + lane], wb = WT[c * 128 + 64 + lane];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xc = __shfl(xn[j], c, 64);
-        y0[j] = fmaf(xc, wa, y0[j]);
-        y1[j] = fmaf(xc, wb, y1[j]);
+    for (int t = 0; t < T; ++t) {
+      xv[t] = x0v[t] = 0.0f;
+      if (2 * t < cnt) {
+        const int i = i0 + min(2 * t + h, cnt - 1);
+        xv[t] = X[(size_t)i * 128 + o];
+        x0v[t] = x0[(size_t)i * U + o];
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int t = 0; t < T; ++t) {
+      if (2 * t < cnt) {
+        const int d0 = row_at(2 * t + 1) - row_at(2 * t), d1 = row_at(2 * t + 2) - row_at(2 * t + 1);
+        const int jn = 2 * t + h;
+        if (jn < cnt) {
+          const float agg = agg_s[wave][jn][o] / (float)max(h ? d1 : d0, 1);
+          const float y = fmaf(xv[t] + agg, svo, tvo);
+          const float xn = x0v[t] + silu(y);
+          x1out[(size_t)(i0 + jn) * U + o] = xn;
+          agg_s[wave][jn][o] = xn;
+        }
+      }
+    }
+  }
+  if (layer == 11) return;
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  for (int j0 = 0; j0 < cnt; j0 += 8) {
+    float y0[8], y1[8];
+    {
+      const float b0 = bv[lane], b1 = bv[64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { y0[j] = b0; y1[j] = b1; }
+    }
+#pragma unroll 2
+    for (int c4 = 0; c4 < U; c4 += 4) {
+      float wa[4], wb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { wa[k] = WT[(c4 + k) * 128 + lane]; wb[k] = WT[(c4 + k) * 128 + 64 + lane]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 xq = *reinterpret_cast<const float4 *>(&agg_s[wave][j0 + j][c4]);     // (rows past cnt: zeros, not stored)
+        const float xc[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          y0[j] = fmaf(xc[k], wa[k], y0[j]);
+          y1[j] = fmaf(xc[k], wb[k], y1[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
       if (j0 + j < cnt) {
         Xnext[(size_t)(i0 + j0 + j) * 128 + lane] = y0[j];
         Xnext[(size_t)(i0 + j0 + j) * 128 + 64 + lane] = y1[j];

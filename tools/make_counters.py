@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/counters.json and profiles/hbm_traffic.json from the counter passes of tools/profile_r5.sh.
 
-usage: tools/make_counters.py gpurun_out/<tag>   (reads <tag>/pmc_<workload>/pmc_*/p_counter_collection.csv)
+usage: tools/make_counters.py gpurun_out/<tag> [--merge]   (reads <tag>/pmc_<workload>/pmc_*/p_counter_collection.csv;
+       --merge: keep the entries of the existing files (same library version) for workloads <tag> has no passes of)
 Per workload the dominant kernel's mean counters per launch become:
   cycles            GRBM_GUI_ACTIVE / 8 XCDs (the launch's duration in shader clocks)
   valu_busy         SQ_INSTS_VALU x 2 / (1024 SIMDs x cycles): a wave64 VALU instruction issues over two cycles on gfx950's SIMD-32
@@ -57,6 +58,11 @@ def main():
     traffic = {"daco_version": version,
                "source": "profiles/r05_pmc_*.txt (tools/profile_r5.sh: FETCH_SIZE KiB x 1024 x 2 [gfx950 correction] + WRITE_SIZE KiB x "
                          "1024, mean per launch of the dominant kernel)"}
+    if "--merge" in sys.argv[2:]:
+        for name, cur in (("counters.json", counters), ("hbm_traffic.json", traffic)):
+            old = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if old.get("daco_version") == version:
+                cur.update({k: v for k, v in old.items() if k not in ("daco_version", "source")})
     for wl, (needle, key) in WORKLOADS.items():
         m = kernel_means(os.path.join(out_dir, "pmc_" + wl), needle)
         if "GRBM_GUI_ACTIVE" not in m:

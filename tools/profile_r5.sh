@@ -3,7 +3,7 @@
 # a training step and the siblings; counter passes (rocprofv3 --pmc, kernel trace only, one pass per counter group) of the
 # dominant kernels.  Copy what should be judged from gpurun_out/<tag>/ into profiles/; tools/make_counters.py turns the counter
 # passes into profiles/counters.json and profiles/hbm_traffic.json.
-# usage (on the GPU box, from the repo root):  bash tools/profile_r5.sh r05 [pmc|stats|all]
+# usage (on the GPU box, from the repo root):  bash tools/profile_r5.sh r05 [pmc|stats|hgs|gnn|all]
 set -u
 TAG=${1:-r05}
 WHAT=${2:-all}
@@ -38,6 +38,12 @@ if [ "$WHAT" = "hgs" ]; then      # the local-search kernel alone (after a chang
   stats hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short
   pmc hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short --reps 2
   stats train python tools/run_train_step.py 5
+  ls $OUT
+  exit 0
+fi
+if [ "$WHAT" = "gnn" ]; then      # the network's forward alone (after a change to its kernels)
+  stats gnn python tools/time_gnn_batch.py
+  pmc gnn python tools/run_gnn_batch.py 500 50 64 3
   ls $OUT
   exit 0
 fi
