@@ -15,7 +15,7 @@ namespace daco {
 template <int CPL>   // columns per lane
 __global__ void __launch_bounds__(256)
 knn_graph_kernel(int B, int n, int k, const float *coords, float diag, float *dist, int64_t *edge_src,
-                 int64_t *edge_dst, float *edge_attr) {
+                 int64_t *edge_dst, float *edge_attr, int32_t *src32, int32_t *dst32) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;          // b*n + i
   if (row >= (long)B * n) return;
@@ -34,6 +34,9 @@ knn_graph_kernel(int B, int n, int k, const float *coords, float diag, float *di
     }
     dv[q] = v;
   }
+  // round r's winner is kept by lane r % 64; every 64 rounds (and at the end) the lanes store their edges side by side
+  float rkey = 0.0f;
+  int ridx = 0;
   for (int r = 0; r < k; ++r) {
     float bk = __builtin_inff();
     int bj = 0x7fffffff;
@@ -44,11 +47,16 @@ knn_graph_kernel(int B, int n, int k, const float *coords, float diag, float *di
 #pragma unroll
     for (int q = 0; q < CPL; ++q)
       if (lane + 64 * q == w.idx) dv[q] = __builtin_inff();          // taken
-    if (lane == 0) {
-      const size_t e = (size_t)row * k + r;
-      edge_src[e] = i;
-      edge_dst[e] = w.idx;
-      edge_attr[e] = w.key;
+    if (lane == (r & 63)) { rkey = w.key; ridx = w.idx; }
+    if ((r & 63) == 63 || r == k - 1) {
+      const int r0 = r & ~63;
+      if (lane <= r - r0) {
+        const size_t e = (size_t)row * k + r0 + lane;
+        edge_src[e] = i;
+        edge_dst[e] = ridx;
+        edge_attr[e] = rkey;
+        if (src32) { src32[e] = b * n + i; dst32[e] = b * n + ridx; }
+      }
     }
   }
 }
@@ -57,17 +65,18 @@ knn_graph_kernel(int B, int n, int k, const float *coords, float diag, float *di
 
 using namespace daco;
 
-extern "C" int daco_tsp_knn_graph(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
-                                  int64_t *edge_src, int64_t *edge_dst, float *edge_attr) {
-  if (B <= 0 || n < 2 || k < 1 || k > n || !coords || !edge_src || !edge_dst || !edge_attr) {
-    set_error("daco_tsp_knn_graph: bad argument (B=%d n=%d k=%d)", B, n, k);
+static int knn_graph_launch(const char *what, void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
+                            int64_t *edge_src, int64_t *edge_dst, float *edge_attr, int32_t *src32, int32_t *dst32) {
+  if (B <= 0 || n < 2 || k < 1 || k > n || !coords || !edge_src || !edge_dst || !edge_attr || (src32 == nullptr) != (dst32 == nullptr)) {
+    set_error("%s: bad argument (B=%d n=%d k=%d)", what, B, n, k);
     return DACO_E_BADARG;
   }
-  if (n > DACO_MAX_NODES) { set_error("daco_tsp_knn_graph: n=%d exceeds DACO_MAX_NODES", n); return DACO_E_TOOLARGE; }
+  if (n > DACO_MAX_NODES) { set_error("%s: n=%d exceeds DACO_MAX_NODES", what, n); return DACO_E_TOOLARGE; }
+  if (src32 && (long)B * n > 0x7fffffffL) { set_error("%s: B * n = %ld node ids do not fit 32 bits", what, (long)B * n); return DACO_E_TOOLARGE; }
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)(((long)B * n + 3) / 4)), block(256);
   const int cpl = (n + 63) / 64;
-#define DACO_KNN(C) hipLaunchKernelGGL(knn_graph_kernel<C>, grid, block, 0, s, B, n, k, coords, diag, dist, edge_src, edge_dst, edge_attr)
+#define DACO_KNN(C) hipLaunchKernelGGL(knn_graph_kernel<C>, grid, block, 0, s, B, n, k, coords, diag, dist, edge_src, edge_dst, edge_attr, src32, dst32)
   if (cpl <= 2) DACO_KNN(2);
   else if (cpl <= 4) DACO_KNN(4);
   else if (cpl <= 8) DACO_KNN(8);
@@ -78,4 +87,15 @@ extern "C" int daco_tsp_knn_graph(void *stream, int B, int n, int k, const float
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("knn_graph_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
+}
+
+extern "C" int daco_tsp_knn_graph(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
+                                  int64_t *edge_src, int64_t *edge_dst, float *edge_attr) {
+  return knn_graph_launch("daco_tsp_knn_graph", stream, B, n, k, coords, diag, dist, edge_src, edge_dst, edge_attr, nullptr, nullptr);
+}
+
+extern "C" int daco_tsp_knn_graph_csr(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
+                                      int64_t *edge_src, int64_t *edge_dst, float *edge_attr, int32_t *src32, int32_t *dst32) {
+  if (!src32 || !dst32) { set_error("daco_tsp_knn_graph_csr: src32 / dst32 missing"); return DACO_E_BADARG; }
+  return knn_graph_launch("daco_tsp_knn_graph_csr", stream, B, n, k, coords, diag, dist, edge_src, edge_dst, edge_attr, src32, dst32);
 }

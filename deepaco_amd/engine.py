@@ -504,29 +504,35 @@ class PickService:
 
 def tsp_knn_graph(coords, k_sparse, diag=1e9, want_dist=True):
     """Batched gen_pyg_data (tsp/utils.py:16-36): coords [B,n,2] -> (dist [B,n,n] | None, edge_index [B,2,n*k],
-    edge_attr [B,n*k,1]) in one launch."""
+    edge_attr [B,n*k,1]) in one launch.  The same launch writes the batch as one block-diagonal int32 graph (the form the
+    network's kernels take); it rides on the returned edge_index as `_daco_csr`, and Net.forward_batch(..., k_sparse=k) uses it
+    instead of deriving it again (valid as long as that tensor object is not written to: its version counter is checked)."""
     _require_gpu(coords)
     coords = _f32c(coords)
     B, n, _ = coords.shape
     dev = coords.device
+    E = n * int(k_sparse)
     with torch.cuda.device(dev):
         dist = torch.empty((B, n, n), dtype=torch.float32, device=dev) if want_dist else None
-        ei = torch.empty((B, 2, n * k_sparse), dtype=torch.int64, device=dev)
-        ea = torch.empty((B, n * k_sparse, 1), dtype=torch.float32, device=dev)
+        ei = torch.empty((B, 2, E), dtype=torch.int64, device=dev)
+        ea = torch.empty((B, E, 1), dtype=torch.float32, device=dev)
+        src32 = torch.empty((B * E,), dtype=torch.int32, device=dev)
+        dst32 = torch.empty((B * E,), dtype=torch.int32, device=dev)
         # src / dst rows of one instance are the two halves of its [2, E] block
         src = ei[:, 0]
         dst = ei[:, 1]
         if B > 1:                       # the kernel writes [B][E] arrays: use separate contiguous buffers
-            src_c = torch.empty((B, n * k_sparse), dtype=torch.int64, device=dev)
-            dst_c = torch.empty((B, n * k_sparse), dtype=torch.int64, device=dev)
+            src_c = torch.empty((B, E), dtype=torch.int64, device=dev)
+            dst_c = torch.empty((B, E), dtype=torch.int64, device=dev)
         else:
             src_c, dst_c = src, dst
-        rc = _lib.lib().daco_tsp_knn_graph(_stream(dev), B, n, int(k_sparse), coords.data_ptr(), float(diag),
-                                           dist.data_ptr() if want_dist else None, src_c.data_ptr(), dst_c.data_ptr(),
-                                           ea.data_ptr())
+        rc = _lib.lib().daco_tsp_knn_graph_csr(_stream(dev), B, n, int(k_sparse), coords.data_ptr(), float(diag),
+                                               dist.data_ptr() if want_dist else None, src_c.data_ptr(), dst_c.data_ptr(),
+                                               ea.data_ptr(), src32.data_ptr(), dst32.data_ptr())
         if B > 1:
             ei[:, 0], ei[:, 1] = src_c, dst_c
-    _lib.check(rc, "daco_tsp_knn_graph")
+    _lib.check(rc, "daco_tsp_knn_graph_csr")
+    ei._daco_csr = (src32, dst32, n, int(k_sparse), ei._version)
     return dist, ei, ea
 
 

@@ -141,20 +141,42 @@ def _csr_graph(pyg, n, device):
     return graph
 
 
+_ROWPTR_CACHE = {}
+
+
+def _regular_rowptr(nodes, k, device):
+    """arange(nodes + 1) * k as int32: the CSR row pointer of a graph whose every node has k out-edges (read-only, cached)."""
+    key = (int(nodes), int(k), str(device))
+    rp = _ROWPTR_CACHE.get(key)
+    if rp is None:
+        if len(_ROWPTR_CACHE) > 64:
+            _ROWPTR_CACHE.clear()
+        rp = _ROWPTR_CACHE[key] = torch.arange(0, nodes + 1, device=device, dtype=torch.int32) * int(k)
+    return rp
+
+
 def _merge_graphs(x, edge_index, edge_attr, k_sparse=None):
     """B equal-sized graphs as one block-diagonal GraphData.  k_sparse: the caller's promise that every graph is the regular
     k-nearest-neighbour layout engine.tsp_knn_graph / gen_pyg_data build (edge j*k + t leaves node j): the CSR arrays are then
-    written down directly instead of being derived (sortedness check, bincount, cumsum and a host sync per call)."""
+    written down directly instead of being derived (sortedness check, bincount, cumsum and a host sync per call) -- and if the
+    edge_index is the very tensor engine.tsp_knn_graph returned, untouched since, the merged int32 arrays that launch wrote are
+    taken as they are (no elementwise launch at all; the merged graph then has no int64 `edge_index` of its own)."""
     B, n, feats = x.shape
     E = edge_index.shape[2]
+    if k_sparse is not None and E != n * int(k_sparse):
+        raise _lib.DacoError(f"k_sparse = {k_sparse} does not describe graphs of {n} nodes and {E} edges")
+    csr = getattr(edge_index, "_daco_csr", None)
+    if (k_sparse is not None and csr is not None and csr[2] == n and csr[3] == int(k_sparse) and csr[4] == edge_index._version
+            and csr[0].numel() == B * E and csr[0].device == x.device):
+        merged = GraphData(x=x.reshape(B * n, feats), edge_index=None, edge_attr=edge_attr.reshape(B * E, 1))
+        merged._daco_graph = (csr[0], csr[1], _regular_rowptr(B * n, k_sparse, x.device), None)
+        return merged
     off = (torch.arange(B, device=x.device, dtype=edge_index.dtype) * n).view(B, 1, 1)
     ei = (edge_index + off).permute(1, 0, 2).reshape(2, B * E)
     merged = GraphData(x=x.reshape(B * n, feats), edge_index=ei, edge_attr=edge_attr.reshape(B * E, 1))
     if k_sparse is not None:
-        if E != n * int(k_sparse):
-            raise _lib.DacoError(f"k_sparse = {k_sparse} does not describe graphs of {n} nodes and {E} edges")
-        rowptr = torch.arange(0, B * n + 1, device=x.device, dtype=torch.int32) * int(k_sparse)
-        merged._daco_graph = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous(), rowptr, None)
+        merged._daco_graph = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous(),
+                              _regular_rowptr(B * n, k_sparse, x.device), None)
     return merged
 
 

@@ -546,6 +546,11 @@ int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax, int nstag
  */
 int daco_tsp_knn_graph(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
                        int64_t *edge_src, int64_t *edge_dst, float *edge_attr);
+/* The same launch, which also writes the batch as ONE block-diagonal graph in the form daco_gnn_forward takes
+ * (src32 / dst32 [B*n*k] int32, node ids b*n + i; the CSR row pointer of it is arange(B*n + 1) * k): what the caller
+ * would otherwise derive from edge_src / edge_dst with a handful of elementwise launches per forward. */
+int daco_tsp_knn_graph_csr(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
+                           int64_t *edge_src, int64_t *edge_dst, float *edge_attr, int32_t *src32, int32_t *dst32);
 
 #ifdef __cplusplus
 }

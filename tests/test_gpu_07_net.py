@@ -298,6 +298,40 @@ def test_batched_graph_construction_matches_reference(name):
         torch.testing.assert_close(out[b][0].edge_attr, ref.edge_attr, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("B,n,k", [(5, 60, 7), (3, 200, 100), (1, 130, 64), (2, 150, 65)])
+def test_knn_graph_merged_int32_form_and_the_forward_that_uses_it(B, n, k):
+    """engine.tsp_knn_graph also writes the batch as one block-diagonal int32 graph (daco_tsp_knn_graph_csr); Net.forward_batch
+    takes it as it is.  Held against (a) torch.topk per instance (k > 64: the kernel stores its edges 64 rounds at a time),
+    (b) the merged arrays derived from the int64 edge_index, (c) the forward on a copy of edge_index that carries nothing."""
+    from deepaco_amd import engine
+    from deepaco_amd.net import _merge_graphs
+    from deepaco_amd.tsp.net import Net
+    torch.manual_seed(B * 1000 + n)
+    coords = torch.rand(B, n, 2, device=dev())
+    dist, ei, ea = engine.tsp_knn_graph(coords, k)
+    ref_d, ref_i = torch.topk(dist, k=k, dim=2, largest=False)
+    assert torch.equal(ei[:, 1].reshape(B, n, k), ref_i)
+    assert torch.equal(ea.reshape(B, n, k), ref_d)
+    assert torch.equal(ei[:, 0].reshape(B, n, k), torch.arange(n, device=dev()).view(1, n, 1).expand(B, n, k))
+    src32, dst32, n_, k_, version = ei._daco_csr
+    off = (torch.arange(B, device=dev()) * n).view(B, 1)
+    assert (n_, k_, version) == (n, k, ei._version)
+    assert torch.equal(src32.long(), (ei[:, 0] + off).reshape(-1)) and torch.equal(dst32.long(), (ei[:, 1] + off).reshape(-1))
+    fast = _merge_graphs(coords, ei, ea, k_sparse=k)
+    assert fast.edge_index is None and fast._daco_graph[0] is src32
+    plain = ei.clone()
+    slow = _merge_graphs(coords, plain, ea, k_sparse=k)
+    assert slow.edge_index is not None
+    for a, b in zip(fast._daco_graph[:3], slow._daco_graph[:3]):
+        assert torch.equal(a, b)
+    torch.manual_seed(2)
+    net = Net().to(dev()).eval()
+    assert torch.equal(net.forward_batch(coords, ei, ea, k_sparse=k), net.forward_batch(coords, plain, ea, k_sparse=k))
+    # a write to the tensor makes the attached arrays stale: the version counter sends the call down the derived path
+    ei[0, 1, 0] = ei[0, 1, 1]
+    assert _merge_graphs(coords, ei, ea, k_sparse=k).edge_index is not None
+
+
 def test_batched_forward_equals_per_graph():
     """B graphs side by side in one pass == B separate forwards (eval mode), and the batched reshape."""
     from deepaco_amd import engine
