@@ -890,7 +890,7 @@ def extra_configs(dev, headline_colony, cpu=True):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             with torch.no_grad():
-                heu = lnet.reshape_batch(n, ei, lnet.forward_batch(coords, ei, ea, k_sparse=k)) + 1e-10
+                heu = lnet.reshape_batch(n, ei, lnet.forward_batch(coords, ei, ea, k_sparse=k), eps=1e-10)
             torch.cuda.synchronize()
             t_net.append((time.perf_counter() - t0) * 1e3)
         res = {}
@@ -941,7 +941,7 @@ def extra_configs(dev, headline_colony, cpu=True):
         x = torch.zeros((B, n, 1), device=dev)
         x[:, 0, 0] = 1.0                                       # tsp_nls/utils.py:30-33: the start node's one-hot
         with torch.no_grad():
-            heu = lnet.reshape_batch(n, ei, lnet.forward_batch(x, ei, ea, k_sparse=k)) + 1e-10
+            heu = lnet.reshape_batch(n, ei, lnet.forward_batch(x, ei, ea, k_sparse=k), eps=1e-10)
         res = {}
         # (learned_on_head_rows: the same heuristic through sampler "scan_sparse" -- the k live entries of a row are its head)
         for tag, kw in (("learned_dense_scan", dict(heuristic=heu, sampler="scan")), ("learned_on_head_rows", dict(heuristic=heu)),

@@ -60,6 +60,7 @@ SIGNATURES = {
                                    _vp, _vp, _vp]),
     "daco_tsp_knn_graph": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp]),
     "daco_tsp_knn_graph_csr": (_i, [_vp, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "daco_heu_matrix": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp]),
     "daco_two_opt": (_i, [_vp, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp]),
     "daco_two_opt_tables_bytes": (_sz, [_i, _i]),
     "daco_two_opt_prepare": (_i, [_vp, _i, _i, _vp, _l, _vp, _sz]),

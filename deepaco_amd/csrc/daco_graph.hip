@@ -61,6 +61,26 @@ knn_graph_kernel(int B, int n, int k, const float *coords, float diag, float *di
   }
 }
 
+// ---- Net.reshape for a batch (tsp/net.py:94-102) with the "+ eps" of its callers (tsp/train.ipynb:35, tsp_nls/test.py:28):
+// out[b] = fill everywhere, heu[b][e] + add at [src_e][dst_e].  Two launches on one stream: the fill, then one thread per edge.
+__global__ void __launch_bounds__(256)
+heu_fill_kernel(size_t total, float fill, float *out) {
+  const size_t quads = total / 4;
+  const float4 v = make_float4(fill, fill, fill, fill);
+  float4 *out4 = reinterpret_cast<float4 *>(out);
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) out4[q] = v;
+  if (blockIdx.x == 0 && quads * 4 + threadIdx.x < total) out[quads * 4 + threadIdx.x] = fill;     // (past the last whole float4)
+}
+__global__ void __launch_bounds__(256)
+heu_scatter_kernel(int B, int n, int E, const int64_t *edge_index, const float *heu, float add, float *out, int32_t *bad) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)B * E) return;
+  const int b = (int)(idx / E), e = (int)(idx - (size_t)b * E);
+  const int64_t sidx = edge_index[((size_t)b * 2) * E + e], didx = edge_index[((size_t)b * 2 + 1) * E + e];
+  if (sidx < 0 || sidx >= n || didx < 0 || didx >= n) { if (bad) atomicAdd(bad, 1); return; }
+  out[((size_t)b * n + (size_t)sidx) * n + (size_t)didx] = heu[idx] + add;
+}
+
 }  // namespace daco
 
 using namespace daco;
@@ -98,4 +118,25 @@ extern "C" int daco_tsp_knn_graph_csr(void *stream, int B, int n, int k, const f
                                       int64_t *edge_src, int64_t *edge_dst, float *edge_attr, int32_t *src32, int32_t *dst32) {
   if (!src32 || !dst32) { set_error("daco_tsp_knn_graph_csr: src32 / dst32 missing"); return DACO_E_BADARG; }
   return knn_graph_launch("daco_tsp_knn_graph_csr", stream, B, n, k, coords, diag, dist, edge_src, edge_dst, edge_attr, src32, dst32);
+}
+
+extern "C" int daco_heu_matrix(void *stream, int B, int n, int E, const int64_t *edge_index, const float *heu, float fill, float add,
+                               float *out, int32_t *bad) {
+  if (B <= 0 || n < 1 || E < 0 || !edge_index || !heu || !out) {
+    set_error("daco_heu_matrix: bad argument (B=%d n=%d E=%d)", B, n, E);
+    return DACO_E_BADARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)B * n * n, quads = total / 4;
+  if (((uintptr_t)out & 15) != 0) { set_error("daco_heu_matrix: out must be 16-byte aligned"); return DACO_E_BADARG; }
+  {
+    const size_t want = (quads + 255) / 256;
+    hipLaunchKernelGGL(heu_fill_kernel, dim3((unsigned)(want < 1 ? 1 : (want < 8192 ? want : 8192))), dim3(256), 0, s, total, fill, out);
+  }
+  if (E > 0)                                                // (the scatter follows the fill on the same stream)
+    hipLaunchKernelGGL(heu_scatter_kernel, dim3((unsigned)(((size_t)B * E + 255) / 256)), dim3(256), 0, s, B, n, E, edge_index, heu, add,
+                       out, bad);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("daco_heu_matrix launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
 }

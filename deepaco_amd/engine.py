@@ -536,6 +536,27 @@ def tsp_knn_graph(coords, k_sparse, diag=1e9, want_dist=True):
     return dist, ei, ea
 
 
+def heu_matrix(n, edge_index, heu, fill=0.0, add=0.0, check=False):
+    """Net.reshape for a batch (tsp/net.py:94-102) with its callers' `+ eps`: edge_index [B,2,E] int64 (graph-local ids),
+    heu [B,E] f32 -> [B,n,n] f32 = `fill` everywhere, heu + add at [src, dst].  check=True: raise if an id lies outside
+    [0, n) (the reference's indexed assignment would; this syncs) -- otherwise such edges are skipped."""
+    _require_gpu(edge_index, heu)
+    B, E = heu.shape
+    assert edge_index.shape == (B, 2, E) and edge_index.dtype == torch.int64
+    ei = edge_index.contiguous()
+    heu = _f32c(heu.detach())
+    dev = heu.device
+    with torch.cuda.device(dev):
+        out = torch.empty((B, n, n), dtype=torch.float32, device=dev)
+        bad = torch.zeros((1,), dtype=torch.int32, device=dev) if check else None
+        rc = _lib.lib().daco_heu_matrix(_stream(dev), B, n, E, ei.data_ptr(), heu.data_ptr(), float(fill), float(add),
+                                        out.data_ptr(), bad.data_ptr() if check else None)
+    _lib.check(rc, "daco_heu_matrix")
+    if check and int(bad.item()):
+        raise IndexError(f"heu_matrix: {int(bad.item())} edge(s) with a node id outside [0, {n})")
+    return out
+
+
 def tour_costs(dist, paths, closed=True):
     """ACO.gen_path_costs for a batch (tsp/aco.py:121-132; closed=False: cvrp/aco.py:133-136)."""
     _require_gpu(dist, paths)

@@ -406,13 +406,17 @@ class Net(nn.Module):
         return self.forward_hip(_merge_graphs(x, edge_index, edge_attr, k_sparse)).view(B, E)
 
     @staticmethod
-    def reshape_batch(n_nodes, edge_index, heu):
-        """Batched Net.reshape (tsp/net.py:94-102): heu [B,E] -> [B,n,n] with zeros off the graph."""
+    def reshape_batch(n_nodes, edge_index, heu, eps=0.0):
+        """Batched Net.reshape (tsp/net.py:94-102): heu [B,E] -> [B,n,n] with zeros off the graph, `+ eps` included (what every
+        caller adds: tsp/train.ipynb:35, tsp_nls/test.py:28).  Outside autograd on the device: one fill and one scatter launch
+        (daco_heu_matrix), the values of zeros / indexed assignment / add bit for bit; under autograd the torch ops themselves."""
         B, E = heu.shape
+        if heu.is_cuda and heu.dtype == torch.float32 and not (heu.requires_grad and torch.is_grad_enabled()):
+            return engine.heu_matrix(n_nodes, edge_index, heu, fill=eps, add=eps)
         out = torch.zeros((B, n_nodes, n_nodes), dtype=heu.dtype, device=heu.device)
         bidx = torch.arange(B, device=heu.device).view(B, 1).expand(B, E)
         out[bidx, edge_index[:, 0], edge_index[:, 1]] = heu
-        return out
+        return out + eps if eps else out
 
     @torch.no_grad()
     def forward_hip(self, pyg, return_embedding=False):

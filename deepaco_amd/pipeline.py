@@ -30,7 +30,7 @@ def infer_tsp_batch(coords, n_ants, t_aco, k_sparse, net=None, node_feature="coo
             x = torch.zeros((B, n, 1), device=coords.device)
             x[:, 0] = 1.0
         heu = net.forward_batch(x, ei, ea, k_sparse=k_sparse)
-        heuristic = net.reshape_batch(n, ei, heu) + EPS
+        heuristic = net.reshape_batch(n, ei, heu, eps=EPS)
     colony = engine.BatchedTSP(dist, n_ants=n_ants, heuristic=heuristic, sampler=sampler, seed=seed,
                                local_search=local_search, fixed_start=0 if local_search else -1,
                                inference=True,      # tsp_nls/test.py:30 aco.run(t, inference=True): 2-opt to convergence
@@ -120,7 +120,7 @@ def infer_cvrp_nls_batch(locations, demands, n_ants, t_aco, k_sparse, net=None, 
     if net is not None:
         x, ei, ea = cvrp_nls_graph_batch(demands, dist, k_sparse)
         heu = net.forward_batch(x, ei, ea)
-        heuristic = net.reshape_batch(n1, ei, heu) + EPS
+        heuristic = net.reshape_batch(n1, ei, heu, eps=EPS)
     colony = engine.BatchedCVRP(dist, demands.double(), n_ants=n_ants, capacity=1.0, heuristic=heuristic, seed=seed,
                                 local_search="hgs", ls_ants=ls_ants, inference=True, **aco_kw)
     out, done = [], 0

@@ -552,6 +552,16 @@ int daco_tsp_knn_graph(void *stream, int B, int n, int k, const float *coords, f
 int daco_tsp_knn_graph_csr(void *stream, int B, int n, int k, const float *coords, float diag, float *dist,
                            int64_t *edge_src, int64_t *edge_dst, float *edge_attr, int32_t *src32, int32_t *dst32);
 
+/* ---------------------------------------------------------------------------------------------
+ * daco_heu_matrix -- replaces Net.reshape for a batch, with the "+ eps" its callers add
+ *   tsp/net.py:94-102 (matrix = zeros; matrix[edge_index[0], edge_index[1]] = vector), tsp/train.ipynb:35, tsp_nls/test.py:28
+ * edge_index [B][2][E] int64 (graph-local ids), heu [B][E] f32 -> out [B][n][n] f32 (16-byte aligned): `fill` everywhere,
+ * heu + add at [src][dst] (fill = add = eps gives reshape(...) + eps bit for bit; an edge listed twice: one of its values,
+ * as with the reference's indexed assignment).  Ids outside [0, n) are skipped and counted in *bad (may be NULL).
+ */
+int daco_heu_matrix(void *stream, int B, int n, int E, const int64_t *edge_index, const float *heu, float fill, float add,
+                    float *out, int32_t *bad);
+
 #ifdef __cplusplus
 }
 #endif

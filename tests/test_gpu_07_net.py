@@ -332,6 +332,36 @@ def test_knn_graph_merged_int32_form_and_the_forward_that_uses_it(B, n, k):
     assert _merge_graphs(coords, ei, ea, k_sparse=k).edge_index is not None
 
 
+@pytest.mark.parametrize("B,n,k,eps", [(4, 60, 7, 1e-10), (1, 45, 5, 1e-10), (3, 131, 20, 0.0), (2, 33, 32, 1e-10)])
+def test_reshape_batch_on_the_device_equals_the_indexed_assignment(B, n, k, eps):
+    """Net.reshape_batch(..., eps) outside autograd = daco_heu_matrix: zeros / matrix[src, dst] = heu / + eps (tsp/net.py:94-102
+    and the callers' `+ 1e-10`), bit for bit, including sizes whose element count is not a multiple of four."""
+    from deepaco_amd import engine
+    from deepaco_amd.net import Net
+    torch.manual_seed(n)
+    coords = torch.rand(B, n, 2, device=dev())
+    _, ei, _ = engine.tsp_knn_graph(coords, k, want_dist=False)
+    heu = torch.rand(B, n * k, device=dev())
+    ref = torch.zeros((B, n, n), device=dev())
+    bidx = torch.arange(B, device=dev()).view(B, 1).expand(B, n * k)
+    ref[bidx, ei[:, 0], ei[:, 1]] = heu
+    ref = ref + eps
+    got = Net.reshape_batch(n, ei, heu, eps=eps)
+    assert torch.equal(got, ref)
+    # under autograd the torch ops run (the gradient flows back through the indexed assignment)
+    h2 = heu.clone().requires_grad_(True)
+    m2 = Net.reshape_batch(n, ei, h2, eps=eps)
+    assert torch.equal(m2.detach(), ref)
+    m2.sum().backward()
+    assert torch.equal(h2.grad, torch.ones_like(heu))
+    bad = ei.clone()
+    bad[0, 1, 3] = n
+    with pytest.raises(IndexError):
+        engine.heu_matrix(n, bad, heu, check=True)
+    skipped = engine.heu_matrix(n, bad, heu)                      # (unchecked: the edge is left out)
+    assert float(skipped[0, int(ei[0, 0, 3]), int(ei[0, 1, 3])]) == 0.0
+
+
 def test_batched_forward_equals_per_graph():
     """B graphs side by side in one pass == B separate forwards (eval mode), and the batched reshape."""
     from deepaco_amd import engine
