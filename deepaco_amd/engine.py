@@ -124,45 +124,52 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
     return paths, logp, rowsum, flags
 
 
-def sparse_head(weights, k):
+def sparse_head(weights, k, top=None):
     """Head table of scan_sparse for `weights` [B,n,n] or [n,n] (the colony passes its heuristic): per row the k (<= 127)
     largest entries, ids ascending (ties at the k-th value: the smaller id) -- [B,n,S] int16 holding uint16 ids with S = 64
     slots for k <= 63, else 128; the unused slots 0, the last slot = k (include/deepaco_hip.h daco_tsp_sample_sparse;
-    oracle.sparse_head_ids is the same rule)."""
+    oracle.sparse_head_ids is the same rule).
+    top: the rows' largest values in descending order, at least k of them ([.., m >= k], e.g. what auto_head_k computed for the
+    same matrix): the one torch.topk this function needs is then skipped."""
     _require_gpu(weights)
     w = weights if weights.dim() == 3 else weights.unsqueeze(0)
     B, n, _ = w.shape
     assert 1 <= k <= 127 and k <= n
     slots = 64 if k <= 63 else 128
     # the k largest by (value descending, id ascending), without sorting the rows (ADVICE r4): everything above the k-th value,
-    # and of the entries equal to it the smallest ids; then the chosen ids ascending
+    # and of the entries equal to it the smallest ids.  The chosen ids ascending = the chosen columns in column order: their
+    # running count is the slot (the others go to a spare slot that is cut off).
     v = w.detach().to(torch.float32)
-    kth = torch.topk(v, k, dim=2).values[:, :, k - 1:k]
+    if top is not None and top.shape[-1] >= k:
+        kth = (top if top.dim() == 3 else top.unsqueeze(0))[:, :, k - 1:k].to(torch.float32)     # ([1,n,1] broadcasts over B)
+    else:
+        kth = torch.topk(v, k, dim=2).values[:, :, k - 1:k]
     greater = v > kth
     eq = v == kth
     room = k - greater.sum(dim=2, keepdim=True)
-    chosen = greater | (eq & (torch.cumsum(eq, dim=2) <= room))
-    ar = torch.arange(n, device=w.device, dtype=torch.int32).view(1, 1, n)
-    keys = torch.where(chosen, ar, ar + n)
-    ids = torch.zeros((B, n, slots), dtype=torch.int64, device=w.device)
-    ids[:, :, :k] = torch.topk(keys, k, dim=2, largest=False, sorted=True).values
+    chosen = greater | (eq & (torch.cumsum(eq, dim=2, dtype=torch.int32) <= room))
+    slot = torch.where(chosen, torch.cumsum(chosen, dim=2, dtype=torch.int32) - 1, slots).to(torch.int64)
+    ids = torch.zeros((B, n, slots + 1), dtype=torch.int16, device=w.device)
+    ids.scatter_(2, slot, torch.arange(n, device=w.device, dtype=torch.int16).view(1, 1, n).expand(B, n, n))
+    ids = ids[:, :, :slots].contiguous()                 # (bit pattern of uint16: ids < 32768 here, n <= 1024)
     ids[:, :, slots - 1] = k
-    return ids.to(torch.int16).contiguous()          # (bit pattern of uint16: ids < 32768 here, n <= 1024)
+    return ids
 
 
 SPARSE_MIN_N, SPARSE_MAX_N = 129, 1024        # sizes daco_tsp_sample_sparse / _race_head cover
 
 
-def auto_head_k(heuristic, mass=0.98):
+def auto_head_k(heuristic, mass=0.98, want_top=False):
     """Head size for sampler='auto' on a heuristic nobody sparsified by hand: 63 or 127 if that many largest entries hold at
     least `mass` of (nearly) every row (the learned heuristic is k-sparse by construction: tsp/net.py:94-102 scatters k values per row
     into zeros, + 1e-10), else None.  One reduction and one host read per heuristic object.
     mass = 0.98: a step that has to leave the head re-reads the whole row for its ants (each such step stops four
-    ants for a row walk); with a fifth of the mass in the tail (plain 1/d at n = 200: 0.85 in the best 127) the head rows lose."""
+    ants for a row walk); with a fifth of the mass in the tail (plain 1/d at n = 200: 0.85 in the best 127) the head rows lose.
+    want_top: also return the rows' 127 largest values (descending), which sparse_head takes instead of its own torch.topk."""
     h = heuristic.detach()
     n = h.shape[-1]
     if not (SPARSE_MIN_N <= n <= SPARSE_MAX_N):
-        return None
+        return (None, None) if want_top else None
     h = h.to(torch.float32)
     top = torch.topk(h, min(127, n - 1), dim=-1).values
     tot = h.sum(dim=-1)
@@ -170,10 +177,9 @@ def auto_head_k(heuristic, mass=0.98):
     # 1e-10 floor); those rows cost a dense step when an ant stands on them, the colony still gains on the others
     ok63 = ((top[..., :63].sum(dim=-1) / tot) >= mass).float().mean()
     ok127 = ((top.sum(dim=-1) / tot) >= mass).float().mean()
-    f63, f127 = (mass if float(ok63) >= 0.95 else 0.0), (mass if float(ok127) >= 0.95 else 0.0)
-    if f63 >= mass:
-        return 63
-    return 127 if f127 >= mass else None
+    ok63, ok127 = (float(x) for x in torch.stack((ok63, ok127)).tolist())          # (one host read)
+    k = 63 if ok63 >= 0.95 else (127 if ok127 >= 0.95 else None)
+    return (k, top if k else None) if want_top else k
 
 
 _warned_sparse_range = False
@@ -202,8 +208,17 @@ def resolve_sampler(sampler, n, head_k, heuristic, cache):
         return "scan_sparse", head_k
     hit = cache.get("auto_head")
     if hit is None or hit[0] is not heuristic:
-        hit = cache["auto_head"] = (heuristic, auto_head_k(heuristic))
+        k, top = auto_head_k(heuristic, want_top=True)
+        hit = cache["auto_head"] = (heuristic, k)
+        cache["auto_top"] = (heuristic, top)            # (taken -- and dropped -- by the colony's next head table)
     return ("scan_sparse", hit[1]) if hit[1] else ("scan", None)
+
+
+def take_auto_top(cache, heuristic):
+    """The sorted top values resolve_sampler left in a colony's cache for this heuristic object (None if there are none); they
+    are handed over once: 16 MB per 64 x 500 rows that nothing needs after the head table is built."""
+    hit = cache.pop("auto_top", None) if cache else None
+    return hit[1] if hit is not None and hit[0] is heuristic else None
 
 
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
@@ -960,7 +975,7 @@ class BatchedTSP:
             k = k if k is not None else (self.head_k if self.head_k is not None else max(1, min(127, self.n // 10)))
             h = self.heuristic.detach()
             h = h if h.dim() == 3 else h.unsqueeze(0).expand(self.B, self.n, self.n)
-            self._head = (self.heuristic, sparse_head(_f32c(h), k), k)
+            self._head = (self.heuristic, sparse_head(_f32c(h), k, top=take_auto_top(getattr(self, "_auto", None), self.heuristic)), k)
         return self._head[1]
 
     @torch.no_grad()

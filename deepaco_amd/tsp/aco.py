@@ -111,7 +111,8 @@ class ACO():
         hit = self.__dict__.get("_head")
         if hit is None or hit[0] is not self.heuristic or (k is not None and hit[2] != k):
             k = k or self.__dict__.get("_head_k") or max(1, min(127, self.problem_size // 10))
-            hit = (self.heuristic, engine.sparse_head(self.heuristic.detach().float().contiguous(), k), k)
+            top = engine.take_auto_top(self.__dict__.get("_auto"), self.heuristic)
+            hit = (self.heuristic, engine.sparse_head(self.heuristic.detach().float().contiguous(), k, top=top), k)
             self._head = hit
         return hit[1]
 

@@ -292,3 +292,8 @@ def test_sparse_head_equals_the_oracles_rule_with_ties():
             want, _ = oracle.sparse_head_ids(w[b].numpy(), k)
             np.testing.assert_array_equal(got[b][:, :k], want[:, :k], err_msg=f"k={k}")
             assert (got[b][:, -1] == k).all()
+        # the same table from the sorted top values sampler='auto' already has (no torch.topk of its own), batched and [n, m]
+        top = torch.topk(w.to(dev()), 127, dim=-1).values
+        assert torch.equal(engine.sparse_head(w.to(dev()), k, top=top).cpu().view(torch.int16), torch.from_numpy(got.view(np.int16)))
+        one = engine.sparse_head(w[0].to(dev()), k, top=top[0])
+        assert torch.equal(one[0].cpu(), torch.from_numpy(got[0].view(np.int16)))
