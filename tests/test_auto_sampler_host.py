@@ -50,3 +50,25 @@ def test_resolution_rules():
         assert engine.resolve_sampler("scan_sparse", 100, 10, h, {}) == ("scan", None)
     assert len([x for x in w if "scan_sparse" in str(x.message)]) == 1                # said once
     assert engine.resolve_sampler("scan_sparse", 300, 20, h, {}) == ("scan_sparse", 20)
+
+
+def test_the_sorted_top_values_are_handed_to_the_head_table_once():
+    """resolve_sampler leaves the rows' 127 largest values (which its concentration test sorted) in the colony's cache;
+    the head table takes them instead of a torch.topk of its own, and they are dropped after that."""
+    d, h = _ksparse(300, 40)
+    k, top = engine.auto_head_k(h, want_top=True)
+    assert k == 63 and top.shape == (300, 127)
+    assert torch.equal(top, torch.topk(h, 127, dim=-1).values) and bool((top[:, 1:] <= top[:, :-1]).all())
+    assert engine.auto_head_k(1 / d, want_top=True) == (None, None)
+    assert engine.auto_head_k(h[:100, :100], want_top=True) == (None, None)
+    cache = {}
+    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 63)
+    assert engine.take_auto_top(cache, 1 / d) is None          # another heuristic object: nothing to take (and nothing kept)
+    assert "auto_top" not in cache
+    cache = {}
+    engine.resolve_sampler("auto", 300, None, h, cache)
+    got = engine.take_auto_top(cache, h)
+    assert torch.equal(got, top)
+    assert engine.take_auto_top(cache, h) is None and engine.take_auto_top(None, h) is None
+    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 63)      # (cached verdict: no second test)
+    assert "auto_top" not in cache
