@@ -513,6 +513,12 @@ __device__ inline f32x2 one_plus_exp_neg2(f32x2 x) {       // 1 + e^-x, x clampe
   e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
   return one + e;
 }
+__device__ inline f32x2 silu2_fast(f32x2 x) {             // x sigmoid(x) on the same exponential (silu(-44) = -3e-18 either way)
+  const f32x2 d = one_plus_exp_neg2(x);
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return x * r;
+}
 // INIT (layer 0 only): the old edge state is not read but made on the fly, w0 = silu(e_lin0(edge_attr)) (tsp/net.py:31) --
 // 4 bytes per edge instead of 128, and no separate launch that writes E * 128 bytes first.
 template <bool INIT>
@@ -530,6 +536,10 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   *reinterpret_cast<float4 *>(&we_s[threadIdx.x >> 3][(threadIdx.x & 7) * 4]) = *reinterpret_cast<const float4 *>(We + threadIdx.x * 4);
+  // INIT: e_lin0's weight and bias (a row is silu(attr * W + b)) are read from LDS when a tile starts: kept in registers they
+  // were eight more than the loop has (reloads inside the loop wait behind the row prefetch, see the note above)
+  __shared__ __attribute__((aligned(16))) float init_s[INIT ? 2 : 1][INIT ? 32 : 4];
+  if (INIT && threadIdx.x < 64) init_s[threadIdx.x >> 5][threadIdx.x & 31] = params[32 * feats + 32 + threadIdx.x];
   __syncthreads();                                                            // the only workgroup barrier
   const int per_xcd = (int)gridDim.x >> 3;                                    // XCD x owns one contiguous eighth of the nodes
   const int block = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -568,11 +578,11 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
   const uint32_t edeg = (uint32_t)(rowptr[i0 + min(i16 + 1, cnt)] - elo);
   const int elast = eend - 1;
   float4 res[4];
-  // INIT: e_lin0's weight and bias of this lane's four channels; a row is silu(attr * W + b)
-  const float4 iw = INIT ? *reinterpret_cast<const float4 *>(params + 32 * feats + 32 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 ib = INIT ? *reinterpret_cast<const float4 *>(params + 32 * feats + 64 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_row = [&](int e) -> float4 {
-    if constexpr (INIT) { const float av = attr[e]; return make_float4(av, av, av, av); }   // (expanded when the tile starts)
+    if constexpr (INIT) {                                                              // (expanded when the tile starts)
+      const float av = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(attr) + (uint32_t)e * 4u);
+      return make_float4(av, av, av, av);
+    }
     else {
       // the edge rows are a stream (each read once per layer, by one lane): with the non-temporal policy (DACO_GNN_NT=0 turns
       // it off) they do not push the node rows -- which every edge of a node gathers again -- out of the L2
@@ -587,8 +597,9 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
   };
   auto made_row = [&](float4 r) -> float4 {
     if constexpr (INIT) {
+      const float4 iw = *reinterpret_cast<const float4 *>(&init_s[0][c0]), ib = *reinterpret_cast<const float4 *>(&init_s[INIT ? 1 : 0][c0]);
       const f32x2 p01 = {fmaf(r.x, iw.x, ib.x), fmaf(r.y, iw.y, ib.y)}, p23 = {fmaf(r.z, iw.z, ib.z), fmaf(r.w, iw.w, ib.w)};
-      const f32x2 s01 = silu2(p01), s23 = silu2(p23);
+      const f32x2 s01 = silu2_fast(p01), s23 = silu2_fast(p23);
       return make_float4(s01.x, s01.y, s23.x, s23.y);
     } else return r;
   };
@@ -810,14 +821,28 @@ gnn_head_kernel(int E, int feats, const float *params, const float *w, float *he
   __builtin_amdgcn_s_waitcnt(0xc07f);
   f32x16 acc = tile_gemm(&t[o][0], W1, lane);
   __builtin_amdgcn_wave_barrier();
+  {
+    const float bo = b1[o];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[drow(r, lane)][o] = silu(acc[r] + b1[o]);
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 v = {acc[r] + bo, acc[r + 1] + bo};
+      const f32x2 a = silu2_fast(v);
+      t[drow(r, lane)][o] = a.x; t[drow(r + 1, lane)][o] = a.y;
+    }
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): LDS writes of this wave landed
   acc = tile_gemm(&t[o][0], W2, lane);
   __builtin_amdgcn_wave_barrier();
+  {
+    const float bo = b2[o], wo = W3[o];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[drow(r, lane)][o] = silu(acc[r] + b2[o]) * W3[o];
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 v = {acc[r] + bo, acc[r + 1] + bo};
+      const f32x2 a = silu2_fast(v);
+      t[drow(r, lane)][o] = a.x * wo; t[drow(r + 1, lane)][o] = a.y * wo;
+    }
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
   // final 32 -> 1: row sums of the tile, one edge per lane (lanes 0..31), fixed channel order
