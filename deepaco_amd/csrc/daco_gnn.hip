@@ -85,12 +85,18 @@ gnn_node_init_kernel(int n, int feats, const float *xin, const float *params, fl
   __syncthreads();
   if (i >= n) return;
   const float *WT = params + off_layer(feats, 0), *bv = WT + 32 * 128;
+  // the four linears side by side, eight input channels' weights in flight at a time (one output's fmas stay in channel order)
+  float acc[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float acc = bv[q * 32 + o];
-    for (int c = 0; c < U; ++c) acc = fmaf(xs[il][c], WT[c * 128 + q * 32 + o], acc);
-    X[(size_t)i * 128 + q * 32 + o] = acc;
+  for (int q = 0; q < 4; ++q) acc[q] = bv[q * 32 + o];
+#pragma unroll 8
+  for (int c = 0; c < U; ++c) {
+    const float xc = xs[il][c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = fmaf(xc, WT[c * 128 + q * 32 + o], acc[q]);
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) X[(size_t)i * 128 + q * 32 + o] = acc[q];
 }
 
 // w = silu(e_lin0(edge_attr)); four channels per thread (16-byte stores)
