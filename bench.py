@@ -1127,7 +1127,7 @@ def extra_configs(dev, headline_colony, cpu=True):
                                  "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": PEAK_HBM_GBS,
                                               "unit": "GB/s", "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "traffic": tr,
                                               "traffic_source": src,
-                                              "kernel": "gnn_fused2_layer_kernel x 12 layers (layer 0 makes the edge state, edge state in place) + node init + head (whole forward)",
+                                              "kernel": "gnn_fused2_layer_kernel x 12 layers (layer 0 makes the edge state) + node init + head (whole forward)",
                                               "mfma_tflops": flops / dt / 1e12,
                                               "pipes": counters.get("gnn_fused2_layer_tsp500_k50_b64"),
                                               "valu_busy": (counters.get("gnn_fused2_layer_tsp500_k50_b64") or {}).get("valu_busy")},
