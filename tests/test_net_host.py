@@ -101,3 +101,32 @@ def test_regular_knn_csr_shortcut_equals_derived_csr():
         assert torch.equal(hinted.edge_index, plain.edge_index) and torch.equal(hinted.x, plain.x)
     with pytest.raises(_lib.DacoError):
         _merge_graphs(torch.rand(2, 5, 2), torch.zeros(2, 2, 12, dtype=torch.long), torch.rand(2, 12, 1), k_sparse=3)
+
+
+def test_attached_merged_graph_is_taken_only_while_it_describes_the_tensor():
+    """engine.tsp_knn_graph leaves the batch's merged int32 graph on the edge_index it returns (`_daco_csr`); _merge_graphs
+    takes it only if it is of the same shape parameters and the tensor has not been written to since (version counter).
+    Host logic: checked here with the attribute put on a CPU tensor by hand."""
+    from deepaco_amd.net import _merge_graphs, _regular_rowptr
+    g = torch.Generator().manual_seed(5)
+    B, n, k = 3, 12, 4
+    src = torch.arange(n).repeat_interleave(k)
+    ei = torch.stack([torch.stack([src, torch.randint(0, n, (n * k,), generator=g)]) for _ in range(B)])
+    x, ea = torch.rand(B, n, 2, generator=g), torch.rand(B, n * k, 1, generator=g)
+    derived = _merge_graphs(x, ei, ea, k_sparse=k)
+    off = (torch.arange(B) * n).view(B, 1)
+    src32, dst32 = (ei[:, 0] + off).reshape(-1).int(), (ei[:, 1] + off).reshape(-1).int()
+    ei._daco_csr = (src32, dst32, n, k, ei._version)
+    fast = _merge_graphs(x, ei, ea, k_sparse=k)
+    assert fast.edge_index is None and fast._daco_graph[0] is src32 and fast._daco_graph[1] is dst32
+    for a, b in zip(fast._daco_graph[:3], derived._daco_graph[:3]):
+        assert torch.equal(a, b)
+    assert fast._daco_graph[2] is _regular_rowptr(B * n, k, x.device)           # (the row pointer is shared, read-only)
+    assert _merge_graphs(x, ei, ea).edge_index is not None                      # no k_sparse promise: derived
+    ei._daco_csr = (src32, dst32, n, k + 1, ei._version)                        # other shape parameters: derived
+    assert _merge_graphs(x, ei, ea, k_sparse=k).edge_index is not None
+    ei._daco_csr = (src32, dst32, n, k, ei._version)
+    ei[0, 1, 0] = (ei[0, 1, 0] + 1) % n                                         # written to: derived (and correct)
+    after = _merge_graphs(x, ei, ea, k_sparse=k)
+    assert after.edge_index is not None and int(after._daco_graph[1][0]) == int(ei[0, 1, 0])
+    assert getattr(ei[:2], "_daco_csr", None) is None                           # (a slice is a new tensor object: nothing rides on it)
