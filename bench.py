@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations")
     ap.add_argument("--cpu-instances", type=int, default=0,
                     help="colonies of the cpu_baseline leg, side by side (0 = min(instances, host CPUs // 4))")
-    ap.add_argument("--cpu-iters", type=int, default=10,
+    ap.add_argument("--cpu-iters", type=int, default=20,
                     help="colony iterations of every cpu_baseline colony (the best-cost gap is taken at this many iterations)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="safety stop of a cpu_baseline colony")
     ap.add_argument("--config", default="headline", choices=["headline", "c5"],
@@ -145,8 +145,12 @@ def headline_record(full):
         rec["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:400]
     g = full.get("best_cost_gap")
     if g:
-        rec["best_cost_gap"] = {k: g.get(k) for k in ("gap", "ci95", "equal_or_better", "gpu_mean_best", "cpu_mean_best", "instances", "iterations")
-                                if k in g}
+        rec["best_cost_gap"] = {k: g.get(k) for k in ("gap", "ci95", "equal_or_better", "gpu_better_or_equal_on", "gpu_mean_best",
+                                                      "cpu_mean_best", "instances", "iterations", "gpu_seeds", "sampler") if k in g}
+        if isinstance(g.get("samplers"), dict):          # scan_sparse / scan / race: [gap, ci low, ci high, equal_or_better, wins]
+            rec["best_cost_gap"]["samplers"] = {k: [v.get("gap")] + list(v.get("ci95") or [None, None]) + [v.get("equal_or_better"),
+                                                                                                         v.get("gpu_better_or_equal_on")]
+                                                for k, v in g["samplers"].items()}
     for k in ("speedup_vs_cpu", "gpu_mean_best_cost"):
         if k in full:
             rec[k] = full[k]
@@ -349,19 +353,21 @@ def _cpu_colony(job):
     heu = 1 / sparse
     tau = torch.ones_like(d)
     lowest, done = float("inf"), 0
+    trace = []                                   # best cost after 1, 2, ... iterations (the gap is taken where every colony got to)
     t0 = time.perf_counter()
     for _ in range(iters):
         paths = torch_port.rollout(tau, heu, n_ants)
         costs = torch_port.tour_lengths(d, paths)
         lowest = min(lowest, float(costs.min()))
+        trace.append(lowest)
         tau = torch_port.deposit(tau, paths, costs, 0.9)
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    return lowest, done, time.perf_counter() - t0
+    return trace, done, time.perf_counter() - t0
 
 
-def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0):
+def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0, seed0=4321, threads=None):
     """Reference CPU path (torch port): `instances` colonies of the same workload, `iters` iterations each, as
     parallel processes with a few intra-op threads each (torch's default of one thread per logical CPU is far from
     optimal for [512 x 500] tensors on a many-core host).
@@ -373,10 +379,10 @@ def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0):
     # intra-op threads per colony process: the [512 x 500] elementwise ops of a rollout step stop scaling beyond a few
     # threads (one process alone on the 256-CPU box: 2 -> 3.75, 4 -> 3.53, 8 -> 3.48, 16 -> 4.03 ms per step), and with 16
     # colonies side by side fewer threads each is faster still (20 iterations: 88 s at 2 threads, 150 s at 4, > 300 s at 8)
-    threads = max(1, min(2, ncpu // max(1, min(instances, dist_cpu.shape[0]))))
+    threads = threads or max(1, min(2, ncpu // max(1, min(instances, dist_cpu.shape[0]))))
     instances = min(instances, dist_cpu.shape[0])
     procs = max(1, min(instances, ncpu // threads))
-    jobs = [(dist_cpu[b].clone(), k_sparse, n_ants, iters, threads, 4321 + b, budget_s) for b in range(instances)]
+    jobs = [(dist_cpu[b].clone(), k_sparse, n_ants, iters, threads, seed0 + b, budget_s) for b in range(instances)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(procs) as pool:
         res = pool.map(_cpu_colony, jobs, chunksize=1)
@@ -391,7 +397,7 @@ def cpu_baseline(dist_cpu, k_sparse, n_ants, instances, iters, budget_s=110.0):
                      f"(oracle/torch_port.py: the reference's aten op sequence, torch {torch.__version__} CPU), "
                      f"{procs} processes x {threads} intra-op threads = {procs * threads} of the host's {ncpu} CPUs, {busy:.1f} s",
            "one_process_value": n_ants * res[0][1] / res[0][2]}
-    return out, [r[0] for r in res], done
+    return out, [r[0][done - 1] for r in res], done
 
 
 # ---------------------------------------------------------------------------------------------- extras
@@ -1177,6 +1183,97 @@ def active_knobs():
 
 
 # ---------------------------------------------------------------------------------------------- one rank
+# ---------------------------------------------------------------------------------------------- best-cost gap
+T975 = {1: 12.706, 2: 4.303, 3: 3.182, 4: 2.776, 5: 2.571, 6: 2.447, 7: 2.365, 8: 2.306, 9: 2.262, 10: 2.228, 11: 2.201, 12: 2.179,
+        13: 2.160, 14: 2.145, 15: 2.131, 16: 2.120, 17: 2.110, 18: 2.101, 19: 2.093, 20: 2.086, 21: 2.080, 22: 2.074, 23: 2.069,
+        24: 2.064, 25: 2.060, 26: 2.056, 27: 2.052, 28: 2.048, 29: 2.045, 30: 2.042, 40: 2.021, 60: 2.000, 120: 1.980}
+GAP_UPPER_BOUND = 0.0025        # "equal or better": the 95 % interval of the paired relative difference ends at or below +0.25 %
+
+
+def t975(dof):
+    if dof in T975:
+        return T975[dof]
+    if dof < 1:
+        return float("nan")
+    below = max(k for k in T975 if k <= dof)            # (conservative: the quantile of the next smaller tabulated dof)
+    return T975[below] if dof < 120 else 1.960 + (1.980 - 1.960) * 120 / dof
+
+
+def gap_samplers(resolved):
+    """The default sampler of the workload first, then the two samplers the reference fixtures pin bit for bit."""
+    out = [resolved]
+    for s_ in ("scan", "race"):
+        if s_ not in out:
+            out.append(s_)
+    return out
+
+
+def gap_statistics(gpu_best, cpu_best):
+    """gpu_best [seeds][instances], cpu_best [seeds][instances] best costs after the same number of iterations: the paired
+    per-instance relative difference of the seed means, its Student-t 95 % interval, and the verdict."""
+    ni = len(cpu_best[0])
+    g = [sum(run[i] for run in gpu_best) / len(gpu_best) for i in range(ni)]
+    c = [sum(run[i] for run in cpu_best) / len(cpu_best) for i in range(ni)]
+    rel = [(g[i] - c[i]) / c[i] for i in range(ni)]
+    mean_rel = sum(rel) / ni
+    sd = (sum((r - mean_rel) ** 2 for r in rel) / max(1, ni - 1)) ** 0.5
+    half = t975(ni - 1) * sd / ni ** 0.5 if ni > 1 else None
+    gm, cm = sum(g) / ni, sum(c) / ni
+    return {"gap": (gm - cm) / cm, "gpu_mean_best": gm, "cpu_mean_best": cm,
+            "mean_paired_relative_difference": mean_rel,
+            "ci95": None if half is None else [mean_rel - half, mean_rel + half],
+            "ci95_half_width": half,
+            "equal_or_better": None if half is None else bool(mean_rel + half <= GAP_UPPER_BOUND),
+            "gpu_better_or_equal_on": int(sum(g[i] <= c[i] for i in range(ni)))}
+
+
+def best_cost_gap(dist_cpu, k_sparse, A, cpu_best, iters, dev, samplers, default, gpu_seeds=(99, 199, 299)):
+    """(mean best cost of the GPU colonies - the CPU reference path's) / the CPU's, on the same instances after the same number
+    of colony iterations, independent RNG streams, per sampler.  cpu_best: [cpu seeds][instances] best costs of the torch port
+    (the reference's op sequence).  Every GPU colony is fresh (tau = 1), `gpu_seeds` runs per sampler; an instance's cost is the
+    mean over the seeds on either side.  equal_or_better = the 95 % interval of the paired relative difference ends at or
+    below +0.25 % (an interval that merely touches zero is not evidence of equality)."""
+    from deepaco_amd import engine
+    ni = len(cpu_best[0])
+    d_dev = dist_cpu[:ni].to(dev)
+    rows = {}
+    for smp in samplers:
+        runs = []
+        for sd_ in gpu_seeds:
+            col = engine.BatchedTSP(d_dev, n_ants=A, sampler=smp, seed=sd_)
+            col.sparsify(k_sparse)
+            col.run(iters)
+            runs.append([float(x) for x in col.lowest_cost.cpu()])
+        rows[smp] = gap_statistics(runs, cpu_best)
+    out = dict(rows[default])
+    out.update({"instances": ni, "iterations": iters, "gpu_seeds": len(gpu_seeds), "cpu_seeds": len(cpu_best), "sampler": default,
+                "upper_bound_for_equal": GAP_UPPER_BOUND,
+                "samplers": {k: {kk: v[kk] for kk in ("gap", "ci95", "equal_or_better", "gpu_better_or_equal_on")} for k, v in rows.items()},
+                "note": "same instances, equal iterations, independent RNG streams; per instance the mean over the seeds on either side; "
+                        "ci95 = mean +- t(0.975, n-1) s / sqrt(n) of the per-instance (gpu - cpu) / cpu; equal_or_better = the "
+                        "interval's upper end <= +0.25 %"})
+    return out
+
+
+def gpu_topology():
+    """Link types between the node's GPUs as rocm-smi reports them (best effort; one string for the record):
+    e.g. "8 GPUs: 28 XGMI pairs" on an MI355X node, "1 GPU" on a single-GPU box."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showtopotype", "--json"], capture_output=True, text=True, timeout=20).stdout
+        j = json.loads(out[out.index("{"):])
+        kinds = {}
+        for sect in j.values():
+            if isinstance(sect, dict):
+                for k_, v in sect.items():
+                    if "type" in k_.lower() and isinstance(v, str):
+                        kinds[v] = kinds.get(v, 0) + 1
+        import torch
+        ng = torch.cuda.device_count()
+        return f"{ng} GPU{'s' if ng != 1 else ''}" + (": " + ", ".join(f"{c} {t} pairs" for t, c in sorted(kinds.items())) if kinds else "")
+    except Exception as e:
+        return f"unavailable ({type(e).__name__})"
+
+
 def worker(args):
     quiet_stdout()
     import torch
@@ -1221,8 +1318,10 @@ def worker(args):
         _, idx = torch.topk(d_dev, k=k_sparse, dim=2, largest=False)
         sparse = torch.full_like(d_dev, 1e10)
         sparse.scatter_(2, idx, torch.gather(d_dev, 2, idx))
+        # the SAME sampler as the N = 1 line: "auto" resolves to the head / tail rows with the k of the
+        # sparsified heuristic, exactly as BatchedTSP.sparsify(k) leaves it
         colony = engine.ant_sharded_tsp(d_dev, A, rank, world, heuristic=(1 / sparse).contiguous(),
-                                        sampler=args.sampler if args.sampler != "auto" else "scan", seed=1234,
+                                        sampler=args.sampler, head_k=min(k_sparse, 127), seed=1234,
                                         exchange=args.exchange)
         _step = colony.step
         colony.step = lambda events=None: _step()
@@ -1242,7 +1341,7 @@ def worker(args):
         colony = make_colony(1234, rank * B * A)
 
     if ant_sharded:
-        resolved = args.sampler if args.sampler != "auto" else "scan"
+        resolved = engine.resolve_sampler(args.sampler, n, min(k_sparse, 127), None, {})[0]
     else:
         resolved = (colony.cols[0] if streams > 1 else colony).resolved_sampler()[0]
     log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler} -> {resolved}")
@@ -1311,7 +1410,13 @@ def worker(args):
                 "data_path_collective": "none (instance-sharded)" if not ant_sharded else
                 ("all-gather of int16 tours + f32 costs per iteration" if args.exchange == "tours"
                  else "all-reduce of delta-tau [B,n,n] f32 per iteration")}
+        rccl["visible_gpus"] = torch.cuda.device_count()
+        rccl["topology"] = gpu_topology()
         if args.dist_backend == "nccl":
+            try:
+                rccl["version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                rccl["version"] = None
             buf = torch.ones((B, n, n), device=dev)
             for _ in range(2):
                 dist_pkg.all_reduce(buf)
@@ -1365,31 +1470,14 @@ def worker(args):
         if world == 1 and not args.no_cpu and not ant_sharded:
             # 16 colonies x 2 threads: the best aggregate found on this host class (round 2: 2 103 ant-tours/s; 64 x 2 on the
             # same 128 cores gave 1 594 -- the op sequence is memory-bound and slows down as colonies are added)
-            ncol = args.cpu_instances or max(1, min(B, 16, (os.cpu_count() or 1) // 2))
+            # (round 6: 32 colonies x 20 iterations -- the gap's interval needs the instances; the aggregate rate is the same)
+            ncol = args.cpu_instances or max(1, min(B, 32, (os.cpu_count() or 1) // 4))
             cb, cpu_best, done = cpu_baseline(dist_cpu, k_sparse, A, ncol, args.cpu_iters, budget_s=args.cpu_seconds)
             line["cpu_baseline"] = cb
-            # best-cost gap: the same instances, equal iterations, fresh GPU colonies; paired per instance, with the 95 % interval
-            # of the mean relative difference (Student t): "equal or better" = the interval contains 0 or lies below it
-            ni = len(cpu_best)
-            gcol = engine.BatchedTSP(dist_cpu[:ni].to(dev), n_ants=A, sampler=args.sampler, seed=99)
-            gcol.sparsify(k_sparse)
-            gcol.run(done)
-            gb = gcol.lowest_cost.cpu()
-            cm = sum(cpu_best) / ni
-            rel = [(float(gb[i]) - cpu_best[i]) / cpu_best[i] for i in range(ni)]
-            mean_rel = sum(rel) / ni
-            sd = (sum((r - mean_rel) ** 2 for r in rel) / max(1, ni - 1)) ** 0.5
-            t975 = {1: 12.706, 2: 4.303, 3: 3.182, 4: 2.776, 5: 2.571, 6: 2.447, 7: 2.365, 8: 2.306, 9: 2.262, 10: 2.228, 11: 2.201,
-                    12: 2.179, 13: 2.160, 14: 2.145, 15: 2.131}.get(ni - 1, 2.0)
-            half = t975 * sd / ni ** 0.5 if ni > 1 else None
-            line["best_cost_gap"] = {"gpu_mean_best": float(gb.mean()), "cpu_mean_best": cm,
-                                     "gap": (float(gb.mean()) - cm) / cm, "instances": ni, "iterations": done,
-                                     "mean_paired_relative_difference": mean_rel,
-                                     "ci95": None if half is None else [mean_rel - half, mean_rel + half],
-                                     "equal_or_better": None if half is None else bool(mean_rel - half <= 0.0),
-                                     "gpu_better_or_equal_on": int(sum(float(gb[i]) <= cpu_best[i] for i in range(ni))),
-                                     "note": "same instances, equal iterations, independent RNG streams; ci95 = mean +- t(0.975, n-1) s / sqrt(n) "
-                                             "of the per-instance (gpu - cpu) / cpu"}
+            # best-cost gap (BASELINE.json: "at equal or better best-cost gap"): the same instances, equal iterations, fresh GPU
+            # colonies of the default sampler AND of the two reference-pinned ones, three seeds each
+            line["best_cost_gap"] = best_cost_gap(dist_cpu[:len(cpu_best)], k_sparse, A, [cpu_best], done, dev,
+                                                  samplers=gap_samplers(resolved), default=resolved)
             line["speedup_vs_cpu"] = value / cb["value"]
         emit(line)
     if distributed:

@@ -529,9 +529,14 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
   const HgsLayout lay(n, p.g);
 
   for (;;) {
-    // every lane adds one: the compiler folds the 64 adds into one atomic of 64, the wave's item is the old value / 64.
-    // (A lane-0-only fetch broadcast with readfirstlane was compiled into a divergent loop that re-ran item 0 for ever.)
-    const int item = (int)(__builtin_amdgcn_readfirstlane(atomicAdd(p.queue, 1u)) >> 6);
+    // one lane takes the next item, the wave reads it back: a single returning atomic written out as such (the form
+    // "every lane adds one, item = old / 64" was right only while the compiler folded the 64 adds into one; and a lane-0-only
+    // atomicAdd broadcast with readfirstlane was compiled into a divergent loop that re-ran item 0 for ever -- the instruction
+    // itself is not something an optimisation level can reshape)
+    uint32_t fetched = 0;
+    if (lane == 0)
+      asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(fetched) : "v"(p.queue), "v"(1u) : "memory");
+    const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
     if (item >= nitems) break;
     const int b = item / p.A, a = item - b * p.A;
     int64_t *col = p.paths + (size_t)b * p.Lmax * p.A + a;

@@ -1183,7 +1183,7 @@ class BatchedCVRP:
         _require_gpu(distances, demand)
         assert local_search in (None, "hgs")
         self.local_search, self.ls_ants, self.inference = local_search, int(ls_ants), inference
-        self._ls_src = (distances.detach(), None if heuristic is None else heuristic.detach(), demand.detach())
+        self._ls_src = (distances.detach(), demand.detach())
         self._hgs = None
         self.distances = _f32c(distances)
         # float64 demands (cvrp_nls/utils.py:12-26) keep the load bookkeeping of the construction in double, as cvrp_sample does
@@ -1198,6 +1198,7 @@ class BatchedCVRP:
         if min_max and pheromone is None:
             self.pheromone = self.pheromone * self.min
         self.heuristic = (1 / self.distances) if heuristic is None else heuristic
+        self._own_heuristic = self.heuristic if heuristic is None else None        # (derived here from the f32 distances)
         self.lowest_cost = torch.full((self.B,), float("inf"), device=distances.device)
         self.shortest_path = None               # [B, Lmax] int64 once a step has run (zero-padded routes)
         self.sampler, self.iteration, self.ant_gid0 = sampler, 0, ant_gid0
@@ -1216,12 +1217,16 @@ class BatchedCVRP:
         self.iteration += 1
         self.last_lens, self.last_flags = lens, flags
         if self.local_search == "hgs":
-            if self._hgs is None:
-                d_src, h_src, dem_src = self._ls_src
-                heu = h_src if h_src is not None else 1 / d_src
-                hd = 1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)                    # cvrp_nls/aco.py:128-132
-                self._hgs = (HgsTables(d_src), HgsTables(hd), dem_src.double() / float(self.capacity))
-            td, th, dem_n = self._hgs
+            if self._hgs is None or self._hgs[3] is not self.heuristic:
+                # the heuristic the colony holds NOW (cvrp_nls/aco.py:128-132 reads self.heuristic at first use; an assignment
+                # after construction counts, and a later one rebuilds the perturbation tables -- ADVICE r5).  The colony's own
+                # 1 / distances is taken from the distances in the dtype they were passed in (float64 instance data).
+                d_src, dem_src = self._ls_src
+                heu = (1 / d_src) if self.heuristic is self._own_heuristic else self.heuristic.detach()
+                hd = 1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)
+                td = self._hgs[0] if self._hgs is not None else HgsTables(d_src)
+                self._hgs = (td, HgsTables(hd), dem_src.double() / float(self.capacity), self.heuristic)
+            td, th, dem_n, _ = self._hgs
             k = min(self.ls_ants, self.n_ants)
             idx = costs.topk(k, dim=1, largest=False).indices                               # [B, k]
             gi = idx.unsqueeze(1).expand(self.B, paths.shape[1], k)
@@ -1230,6 +1235,9 @@ class BatchedCVRP:
             hgs_local_search_(work, [(td, limit), (th, 10), (td, limit)], dem_n)
             paths.scatter_(2, gi, work)
             costs.scatter_(1, idx, tour_costs(self.distances, work, closed=False))
+            # the rewritten columns' used rows: up to and including the depot after their last client
+            rows = torch.arange(1, work.shape[1] + 1, device=work.device, dtype=lens.dtype).view(1, -1, 1)
+            lens.scatter_(1, idx, ((work != 0) * rows).amax(dim=1) + 1)
             table = None                                                                    # (the deposit rebuilds it from the paths)
         if self.shortest_path is None or self.shortest_path.shape[1] != paths.shape[1]:
             self.shortest_path = torch.zeros((self.B, paths.shape[1]), dtype=torch.int64, device=paths.device)
@@ -1292,7 +1300,7 @@ def ant_sharded_tsp(distances, n_ants, rank, world, decay=0.9, alpha=1.0, beta=1
             if cache.get("head") is None or cache["head"][0] != hk:
                 h = eta.detach()
                 h = h if h.dim() == 3 else h.unsqueeze(0).expand(B, n, n)
-                cache["head"] = (hk, sparse_head(_f32c(h), hk))
+                cache["head"] = (hk, sparse_head(_f32c(h), hk, top=take_auto_top(cache, eta)))     # (the top values are handed over once)
             paths, _, costs, nbr = tsp_sample_sparse(tau, eta, n_local, cache["head"][1], alpha, beta, seed=seed, it=it, ant_gid0=lo,
                                                      ant_gid_bstride=n_ants, fixed_start=fixed_start, batch=B, dist=dist_,
                                                      want_nbr=want_nbr)

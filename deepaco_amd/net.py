@@ -256,7 +256,9 @@ class Net(nn.Module):
         if not x.is_cuda:
             raise _lib.DacoError("deepaco_amd.Net runs on a HIP device only (got CPU tensors)")
         needs_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if self.training or needs_graph:
+        # BatchNorm1d(track_running_stats=False) normalises with the batch statistics in eval mode too: there is nothing to fold
+        # into scale / shift, the statistics kernels run (without a graph under no_grad) -- ADVICE r5
+        if self.training or needs_graph or not self._bn_config()[0]:
             return self.forward_train_hip(pyg)
         return self.forward_hip(pyg)
 
@@ -376,6 +378,9 @@ class Net(nn.Module):
         e = self.emb_net
         with torch.no_grad():
             parts = [e.v_lin0.weight.reshape(-1), e.v_lin0.bias, e.e_lin0.weight.reshape(-1), e.e_lin0.bias]
+            if not self._bn_config()[0]:
+                raise _lib.DacoError("Net.pack_params folds the BatchNorm running statistics; this network tracks none "
+                                     "(track_running_stats=False): forward() / forward_batch() run the statistics kernels instead")
             for i in range(DEPTH):
                 Wv = torch.cat([m[i].weight for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)   # [128, 32]
                 bv = torch.cat([m[i].bias for m in (e.v_lins1, e.v_lins2, e.v_lins3, e.v_lins4)], 0)
@@ -403,6 +408,8 @@ class Net(nn.Module):
         if self.training:
             raise _lib.DacoError("Net.forward_batch is an inference path (BatchNorm running statistics): call .eval()")
         B, E = x.shape[0], edge_index.shape[2]
+        if not self._bn_config()[0]:             # no running statistics: every graph is normalised with its own batch statistics
+            return self.forward_train_hip(_merge_graphs(x, edge_index, edge_attr, k_sparse), graphs=B).view(B, E)
         return self.forward_hip(_merge_graphs(x, edge_index, edge_attr, k_sparse)).view(B, E)
 
     @staticmethod
@@ -412,6 +419,17 @@ class Net(nn.Module):
         (daco_heu_matrix), the values of zeros / indexed assignment / add bit for bit; under autograd the torch ops themselves."""
         B, E = heu.shape
         if heu.is_cuda and heu.dtype == torch.float32 and not (heu.requires_grad and torch.is_grad_enabled()):
+            # the scatter kernel skips an edge whose node id lies outside [0, n) where the indexed assignment below (and the
+            # reference's) raises: the ids are validated once per edge_index tensor (ADVICE r5) -- a graph built by
+            # engine.tsp_knn_graph is in range by construction, anything else costs one aminmax and one host read, cached on
+            # the tensor like `_daco_csr`
+            if getattr(edge_index, "_daco_ids_ok", None) != (n_nodes, edge_index._version):
+                csr = getattr(edge_index, "_daco_csr", None)
+                if not (csr is not None and csr[2] == n_nodes and csr[4] == edge_index._version):
+                    lo, hi = (int(v) for v in torch.stack(torch.aminmax(edge_index)).tolist())
+                    if lo < 0 or hi >= n_nodes:
+                        raise IndexError(f"Net.reshape_batch: edge_index holds node ids in [{lo}, {hi}], outside [0, {n_nodes})")
+                edge_index._daco_ids_ok = (n_nodes, edge_index._version)
             return engine.heu_matrix(n_nodes, edge_index, heu, fill=eps, add=eps)
         out = torch.zeros((B, n_nodes, n_nodes), dtype=heu.dtype, device=heu.device)
         bidx = torch.arange(B, device=heu.device).view(B, 1).expand(B, E)

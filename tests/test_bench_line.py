@@ -52,3 +52,30 @@ def test_roofline_counts_true_row_bytes():
     rf = bench.roofline_rows(500, 512, 64, "scan", 1.2)
     assert rf["row_bytes_per_launch"] == 64 * 512 * 499 * 4.0 * 500
     assert rf["padded_row_floats"] == 512
+
+
+def test_gap_statistics_and_the_equal_or_better_rule():
+    """equal_or_better only when the interval's upper end is at or below +0.25 %; wins are counted."""
+    import random
+    rnd = random.Random(3)
+    cpu = [[20.0 + rnd.gauss(0, 0.2) for _ in range(64)] for _ in range(3)]
+    same = [[c + rnd.gauss(0, 0.05) for c in cpu[0]] for _ in range(3)]
+    g = bench.gap_statistics(same, cpu)
+    assert g["equal_or_better"] is True and abs(g["gap"]) < 0.002 and g["ci95"][0] < g["mean_paired_relative_difference"] < g["ci95"][1]
+    assert 0 <= g["gpu_better_or_equal_on"] <= 64
+    worse = [[c * 1.005 for c in run] for run in same]                      # +0.5 %: not equal, however tight the interval
+    assert bench.gap_statistics(worse, cpu)["equal_or_better"] is False
+    wide = bench.gap_statistics([[c + rnd.gauss(0, 1.0) for c in cpu[0]][:4]], [cpu[0][:4]])   # four noisy instances: no verdict of equality
+    assert wide["equal_or_better"] is False
+    assert bench.t975(63) == bench.T975[60] and bench.t975(15) == 2.131 and 1.96 < bench.t975(500) < 1.98
+
+
+def test_headline_record_carries_the_three_gaps():
+    full = _full()
+    row = {"gap": 0.001, "ci95": [-0.001, 0.003], "equal_or_better": False, "gpu_better_or_equal_on": 14}
+    full["best_cost_gap"] = dict(row, instances=32, iterations=20, gpu_seeds=3, sampler="scan_sparse", gpu_mean_best=17.0, cpu_mean_best=17.0,
+                                 samplers={"scan_sparse": row, "scan": row, "race": row}, note="x" * 500)
+    rec = json.loads(bench.headline_record(bench._finite(full)))
+    assert set(rec["best_cost_gap"]["samplers"]) == {"scan_sparse", "scan", "race"}
+    assert rec["best_cost_gap"]["samplers"]["race"] == [0.001, -0.001, 0.003, False, 14]
+    assert bench.gap_samplers("scan_sparse") == ["scan_sparse", "scan", "race"] and bench.gap_samplers("scan") == ["scan", "race"]

@@ -360,6 +360,15 @@ def test_reshape_batch_on_the_device_equals_the_indexed_assignment(B, n, k, eps)
         engine.heu_matrix(n, bad, heu, check=True)
     skipped = engine.heu_matrix(n, bad, heu)                      # (unchecked: the edge is left out)
     assert float(skipped[0, int(ei[0, 0, 3]), int(ei[0, 1, 3])]) == 0.0
+    # the class surface validates a foreign edge_index once and raises like the indexed assignment, negative ids too
+    with pytest.raises(IndexError):
+        Net.reshape_batch(n, bad, heu, eps=eps)
+    neg = ei.clone()
+    neg[B - 1, 0, 0] = -1
+    with pytest.raises(IndexError):
+        Net.reshape_batch(n, neg, heu, eps=eps)
+    good = ei.clone()                                             # (no attached CSR: validated by aminmax, then cached)
+    assert torch.equal(Net.reshape_batch(n, good, heu, eps=eps), ref) and good._daco_ids_ok == (n, good._version)
 
 
 def test_batched_forward_equals_per_graph():
@@ -696,6 +705,8 @@ def test_batchnorm_configurations_away_from_the_default(config):
             res.append(heu.detach().clone())
         net.eval()
         res.append(forward_as(net, pyg, backend).detach().clone())         # eval mode (under autograd)
+        with torch.no_grad():                                              # eval mode without a gradient: the inference path (ADVICE r5:
+            res.append(forward_as(net, pyg, backend).clone())              # without running statistics there is nothing to fold)
         out[backend] = (res, _grads(net), {k: v.clone() for k, v in net.state_dict().items() if "running_" in k})
     for a, b in zip(out["hip"][0], out["torch"][0]):
         torch.testing.assert_close(a, b, atol=ATOL_TORCH, rtol=5e-4)

@@ -297,3 +297,50 @@ def test_sparse_head_equals_the_oracles_rule_with_ties():
         assert torch.equal(engine.sparse_head(w.to(dev()), k, top=top).cpu().view(torch.int16), torch.from_numpy(got.view(np.int16)))
         one = engine.sparse_head(w[0].to(dev()), k, top=top[0])
         assert torch.equal(one[0].cpu(), torch.from_numpy(got[0].view(np.int16)))
+
+
+def _import_cpu_chi2():
+    import importlib
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    return importlib.import_module("test_scan_sparse_oracle")
+
+
+@pytest.mark.parametrize("kind", ["dense_random_head", "ksparse", "tiny_head", "dense_wide_head", "ksparse_wide"])
+def test_hip_draws_follow_the_reference_categorical(kind):
+    """the HIP kernel's OWN draws against the reference's distribution, not only against the restatement.
+    30 000 ants from a fixed start on the five head kinds of tests/test_scan_sparse_oracle.py (arbitrary heads of a dense
+    heuristic: tail walks and rejections; the k-sparse heuristic of tsp/aco.py:52-67; an exhausted head: dense steps; both head
+    widths): chi-square of the first step and of the conditioned second step against Categorical(P[cur] * mask)
+    (tsp/aco.py:165-177), with a seed the CPU suite does not use; and the same launch ant for ant against the restatement."""
+    from deepaco_amd import engine
+    cpu = _import_cpu_chi2()
+    n, A, seed = 160, 30000, 20261
+    tau, eta, (hid, cnt) = cpu._instance_parts(n, 5, kind)
+    P = oracle.prob_matrix(tau, eta)
+    head = pack([(hid, cnt)])
+    paths, flags, _, _, stats = engine.tsp_sample_sparse(torch.from_numpy(tau)[None].to(dev()), torch.from_numpy(eta)[None].to(dev()), A,
+                                                        head, seed=seed, fixed_start=0, want_stats=True)
+    assert int(flags.sum()) == 0
+    got = paths[0].cpu().numpy()
+    cpu.check_first_two_steps(kind, P, got, stats.cpu().numpy())
+    ref, rc, st = oracle.tsp_sample_scan_sparse(P, hid, cnt, A, seed=seed, fixed_start=0)
+    assert rc == 0 and np.array_equal(got, ref) and np.array_equal(stats.cpu().numpy(), st)
+
+
+@pytest.mark.parametrize("mode", ["scan", "race"])
+def test_dense_samplers_follow_the_reference_categorical(mode):
+    """The same chi-square for the two dense samplers the reference fixtures pin (scan: the roulette arithmetic of
+    tsp_nls/aco.py:266-274; race: torch.multinomial's, tsp/aco.py:174-175) with in-kernel Philox noise."""
+    from deepaco_amd import engine
+    cpu = _import_cpu_chi2()
+    n, A = 160, 30000
+    tau, eta, _ = cpu._instance_parts(n, 5, "dense_random_head")
+    P = oracle.prob_matrix(tau, eta)
+    paths, _, _, flags = engine.tsp_sample(torch.from_numpy(tau)[None].to(dev()), torch.from_numpy(eta)[None].to(dev()), A, mode=mode,
+                                           seed=31337, fixed_start=0)
+    assert int(flags.sum()) == 0
+    cpu.check_first_two_steps("dense", P, paths[0].cpu().numpy(), np.zeros(3, dtype=np.int64))

@@ -6,7 +6,11 @@
   config 3   TSP-500 + NLS, 256 ants, 64 instances       nls_kernel (a slice of the ants through the oracle's schedule)
   config 4   CVRP-100, 512 ants, 256 instances           scan16_kernel<CVRP> + the route-exact local search on top
   config 5   TSP-1000, 2048 ants, 64 instances per GPU   tsp_scan32_kernel
+  headline / config 5 on the head rows (sampler "auto" after sparsify(k): what bench.py times)   scan_sparse_kernel, EVERY ant
 The whole colony iteration (costs, deposit in ant order) is compared for the checked instances, bit for bit."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import pytest
 import torch
@@ -58,6 +62,57 @@ def test_tsp_colony_iteration_at_the_configurations_batch(n, A, B, k):
         assert np.array_equal(t2[b].cpu().numpy().view(np.uint32), rt.view(np.uint32)), b
     # every tour of every instance is a permutation
     assert bool((paths.sort(dim=1).values == torch.arange(n, device=dev()).view(1, n, 1)).all())
+
+
+@pytest.mark.parametrize("n,A,B,k", [(500, 512, 64, 50), (1000, 2048, 64, 100)])
+def test_head_row_sampler_at_the_bench_shape_every_ant(n, A, B, k):
+    """The kernel the headline times: BatchedTSP(sampler="auto") after sparsify(k) resolves to the head / tail
+    rows (scan_sparse_kernel<2,false,4> at TSP-500 x 512 x 64, k = 50; <4,false,8> at config 5's per-GPU share) -- one colony
+    iteration at the bench's grid, EVERY ant of EVERY instance against oracle.tsp_sample_scan_sparse (the restatement the CPU
+    suite holds against the categorical of tsp/aco.py:165-177), the three step counters, the fused tour lengths and the deposit
+    in ant order (tsp/aco.py:95-118) bit for bit."""
+    from deepaco_amd import engine
+    d = tsp_instances(B, n, 31 * n + 1)
+    g = torch.Generator().manual_seed(n + 7)
+    tau = torch.rand(B, n, n, generator=g) * 0.5 + 0.75
+    D = d.to(dev())
+    col = engine.BatchedTSP(D, n_ants=A, seed=5, sampler="auto", pheromone=tau.to(dev()))
+    col.sparsify(k)
+    col.heuristic = col.heuristic.contiguous()
+    assert col.resolved_sampler() == ("scan_sparse", k)
+    head = col._head_table(k)
+    assert head.shape[2] == (64 if k <= 63 else 128)
+    # the launch by itself (step counters), then the colony's step: the same tours, then costs / bookkeeping / deposit
+    paths, flags, costs, nbr, stats = engine.tsp_sample_sparse(col.pheromone, col.heuristic, A, head, seed=5, it=0, batch=B, dist=D,
+                                                               want_nbr=True, want_stats=True)
+    assert int(flags.sum()) == 0
+    p2, c2 = col.step()
+    assert torch.equal(p2, paths) and torch.equal(c2.view(torch.int32), costs.view(torch.int32))
+    eta = col.heuristic.cpu().numpy()
+    hid = head.cpu().numpy().view(np.uint16)
+    got_p, got_c, got_t = paths.cpu().numpy(), costs.cpu().numpy(), col.pheromone.cpu().numpy()
+    low = col.lowest_cost.cpu().numpy()
+
+    def check(b):
+        ids = hid[b].copy()
+        cnt = ids[:, -1].astype(np.uint8)
+        ids[:, -1] = 0
+        ref, rc, st = oracle.tsp_sample_scan_sparse(oracle.prob_matrix(tau[b].numpy(), eta[b]), ids, cnt, A, seed=5, it=0, ant_gid0=b * A)
+        bad = int((got_p[b] != ref).any(axis=0).sum()) + (rc != 0)
+        rc_ = oracle.tour_costs(d[b].numpy(), ref)
+        bad_c = int((got_c[b].view(np.uint32) != rc_.view(np.uint32)).sum())
+        rt = oracle.pheromone_update_tsp(tau[b].numpy(), ref, rc_, 0.9)
+        bad_t = int((got_t[b].view(np.uint32) != rt.view(np.uint32)).sum())
+        return bad, bad_c, bad_t, st, float(rc_.min()) == float(low[b])
+
+    with ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1))) as ex:     # (the C oracle releases the GIL)
+        res = list(ex.map(check, range(B)))
+    assert sum(r[0] for r in res) == 0, ("ants that differ", [(b, r[0]) for b, r in enumerate(res) if r[0]][:8])
+    assert sum(r[1] for r in res) == 0 and sum(r[2] for r in res) == 0, ("costs / pheromone entries that differ", [(b, r[1], r[2]) for b, r in enumerate(res) if r[1] or r[2]][:8])
+    assert all(r[4] for r in res)
+    ref_stats = np.sum([r[3] for r in res], axis=0)
+    assert np.array_equal(stats.cpu().numpy(), ref_stats), (stats.cpu().numpy(), ref_stats)
+    assert ref_stats[1] == 0 and ref_stats[2] == 0 and 0 < ref_stats[0] < 0.05 * B * A * n        # k-sparse: never past the head, few dense steps
 
 
 def test_config3_nls_at_its_batch():

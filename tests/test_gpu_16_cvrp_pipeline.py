@@ -105,3 +105,38 @@ def test_local_search_lowers_the_batch_mean_against_plain_construction():
     plain = engine.BatchedCVRP(distances, demands, n_ants=20, capacity=1.0, seed=2)
     plain.run(5)
     assert float(with_ls[-1].mean()) < float(plain.lowest_cost.mean())
+
+
+def test_colony_local_search_reads_the_heuristic_it_holds_now_and_keeps_lens_current():
+    """BatchedCVRP(local_search='hgs') builds the perturbation tables from the heuristic the colony holds at the first
+    step (cvrp_nls/aco.py:128-132 reads self.heuristic at first use), rebuilds them when another heuristic is assigned, and
+    last_lens describes the routes AFTER the local search for the columns it rewrote."""
+    from deepaco_amd import engine
+    B, n, A = 3, 30, 12
+    demands, distances, _ = _instances(B, n, seed=41)
+    g = torch.Generator().manual_seed(1)
+    other = (1 / distances) * (0.2 + torch.rand(distances.shape, generator=g, dtype=distances.dtype).to(dev()))
+
+    def colony(heuristic_at_construction, assign_later):
+        col = engine.BatchedCVRP(distances, demands, n_ants=A, capacity=1.0, seed=4, local_search="hgs", ls_ants=4,
+                                 heuristic=heuristic_at_construction)
+        if assign_later is not None:
+            col.heuristic = assign_later
+        paths, costs = col.step()
+        return col, paths, costs
+
+    a, pa, ca = colony(other, None)
+    b, pb, cb = colony(None, other)                    # assigned after construction: the same colony
+    assert torch.equal(pa, pb) and torch.equal(ca, cb)
+    assert b._hgs[3] is other
+    tables = b._hgs[1]
+    b.heuristic = (1 / distances)
+    b.step()
+    kept = b._hgs[0]
+    assert b._hgs[1] is not tables and b._hgs[3] is b.heuristic                     # rebuilt for the new heuristic
+    b.step()
+    assert b._hgs[0] is kept                                                          # (the distance tables are built once)
+    # lens: the used rows of every column, rewritten ones included
+    rows = torch.arange(1, pa.shape[1] + 1, device=pa.device).view(1, -1, 1)
+    want = ((pa != 0) * rows).amax(dim=1) + 1
+    assert torch.equal(a.last_lens.to(want.dtype), want)

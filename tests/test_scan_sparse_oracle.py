@@ -12,6 +12,12 @@ import oracle
 
 
 def _instance(n, seed, kind):
+    tau, eta, head = _instance_parts(n, seed, kind)
+    return oracle.prob_matrix(tau, eta), head
+
+
+def _instance_parts(n, seed, kind):
+    """(tau, eta, (head ids, live counts)): the GPU suite draws from the same instances through the C ABI."""
     rng = np.random.default_rng(seed)
     c = rng.random((n, 2))
     d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1)).astype(np.float32)
@@ -44,7 +50,7 @@ def _instance(n, seed, kind):
         eta = (1 / d).astype(np.float32)
         head = oracle.sparse_head_ids(eta, 3)
     tau = (0.5 + rng.random((n, n))).astype(np.float32)
-    return oracle.prob_matrix(tau, eta), head
+    return tau, eta, head
 
 
 def _chi2(counts, probs):
@@ -53,12 +59,23 @@ def _chi2(counts, probs):
     return float(((counts[keep] - exp) ** 2 / exp).sum()), int(keep.sum()) - 1, int(counts[~keep].sum())
 
 
-@pytest.mark.parametrize("kind", ["dense_random_head", "ksparse", "tiny_head", "dense_wide_head", "ksparse_wide"])
+KINDS = ["dense_random_head", "ksparse", "tiny_head", "dense_wide_head", "ksparse_wide"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_scan_sparse_draws_the_categorical(kind):
     n, A = 160, 30000
     P, (hid, cnt) = _instance(n, 5, kind)
     paths, rc, stats = oracle.tsp_sample_scan_sparse(P, hid, cnt, A, seed=11, fixed_start=0)
     assert rc == 0
+    check_first_two_steps(kind, P, paths, stats)
+
+
+def check_first_two_steps(kind, P, paths, stats):
+    """paths [n, A] from fixed start 0, stats = (dense steps, tail walks, rejections): chi-square of the first step and of the
+    conditioned second step against Categorical(P[cur] * mask) (tsp/aco.py:165-177).  Shared with the GPU suite, which holds the
+    HIP kernel's draws to the same bound (tests/test_gpu_11_scan_sparse.py)."""
+    n, A = paths.shape
     assert (np.sort(paths, axis=0) == np.arange(n)[:, None]).all()                     # every column a permutation
     # first step: Categorical(P[0][k], k != 0)
     p1 = P[0].astype(np.float64).copy(); p1[0] = 0; p1 /= p1.sum()
