@@ -30,6 +30,11 @@ SIGNATURES = {
                                     _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                        _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "daco_tsp_sample_heads": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
+                                   _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "daco_pheromone_update_heads": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp, _sz,
+                                         _vp, _l, _f, _f, _vp, _i, _i, _vp, _sz]),
+    "daco_allreduce_delta_tau": (_i, [_vp, _vp, _vp, _sz]),
     "daco_tour_costs": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp]),
     "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "daco_pheromone_update": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _f, _vp, _vp, _i, _vp,
@@ -70,7 +75,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 124          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 125          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

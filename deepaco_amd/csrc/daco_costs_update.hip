@@ -11,6 +11,7 @@
 // (probe-verified bit-identical).  Evaporation is fused into the
 // LDS fill and the MMAS clamp / floor into the write-back, so tau makes one round trip.
 #include "daco_device.h"
+#include "daco_head_rows.h"
 #include <cstdlib>
 #include "../../include/deepaco_hip.h"
 
@@ -170,10 +171,14 @@ constexpr int DEP_CHUNK = 64;
 // SYM: symmetric deposit, two lanes per row (prev / next side).  !SYM: directed deposit, one lane
 // per row adds at next_a(i) (0xFFFF = ant a does not leave node i); the hub row is skipped (it
 // belongs to deposit_hub_kernel).  LDS: rows[R][n] | stage[2][R][DEP_CHUNK] | wts[2][DEP_CHUNK].
-template <bool SYM>
+// HEADS (symmetric only, round 6): the workgroup still holds its R finished rows of tau in LDS when they have been written back;
+// one wavefront per row then forms the NEXT iteration's head row of sampler "scan_sparse" (HEADS = 1) or of the race on head rows
+// (HEADS = 2) from them and the row of eta (daco_head_rows.h emit_head_row: the very code of sparse_prepass_kernel), so that
+// iteration neither launches the pre-pass nor reads tau again.
+template <bool SYM, int HEADS>
 __global__ void __launch_bounds__(256)
 deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nbr, const float *costs, const float *weights,
-                    float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val) {
+                    float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val, const HeadEmit he) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
   uint32_t *stage = (uint32_t *)(rows + (((size_t)R * n + 3) & ~(size_t)3));
   float *wts = (float *)(stage + 2 * R * DEP_CHUNK);
@@ -260,16 +265,36 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
   };
   if (vec_ok) {
     float4 *g4 = (float4 *)g;
-    const float4 *r4 = (const float4 *)rows;
+    float4 *r4 = (float4 *)rows;
     for (int i = threadIdx.x; i < cnt / 4; i += blockDim.x) {
       float4 x = r4[i];
       x.x = finish(x.x); x.y = finish(x.y); x.z = finish(x.z); x.w = finish(x.w);
       g4[i] = x;
+      if constexpr (HEADS != 0) r4[i] = x;                 // (the head rows are formed from the values tau now holds)
     }
   } else {
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
       if (!SYM && i >= hub_lo && i < hub_hi) continue;
-      g[i] = finish(rows[i]);
+      const float x = finish(rows[i]);
+      g[i] = x;
+      if constexpr (HEADS != 0) rows[i] = x;
+    }
+  }
+  if constexpr (SYM && HEADS != 0) {
+    __shared__ uint32_t head_bm[4][32];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *eb = he.eta + (size_t)b * he.eta_bs;
+    // (16-byte row vectors: the LDS rows are aligned whenever n % 4 == 0; eta's rows when its base and stride are -- he.ch < 0 says no)
+    const bool vec4 = he.ch > 0;
+    const int ch = vec4 ? he.ch : -he.ch;
+    for (int rr = wave; rr < Rv; rr += 4) {
+      const size_t row = (size_t)b * n + i0 + rr;
+      const float *tr = rows + rr * n, *er = eb + (size_t)(i0 + rr) * n;
+      const uint16_t *ids = he.hid + row * (16 * he.spl);
+      char *hl = he.hrow + row * sp_head_row_bytes(he.spl);
+      if (vec4) emit_head_row<HEADS == 2, true>(n, ch, tr, er, he.alpha, he.beta, ids, head_bm[wave], hl, he.spl, he.dead, lane);
+      else emit_head_row<HEADS == 2, false>(n, ch, tr, er, he.alpha, he.beta, ids, head_bm[wave], hl, he.spl, he.dead, lane);
     }
   }
 }
@@ -439,11 +464,11 @@ static size_t deposit_lds_bytes(int R, int n) {
   return (((size_t)R * n + 3) & ~(size_t)3) * sizeof(float) + (size_t)2 * R * DEP_CHUNK * sizeof(uint32_t) + 2 * DEP_CHUNK * sizeof(float);
 }
 
-extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
-                                     const int64_t *paths, const float *costs, float decay, int elitist,
-                                     int symmetric, const float *clamp_min, const float *clamp_max,
-                                     float floor_val, const uint32_t *nbr_in, const float *weights, int hub,
-                                     void *workspace, size_t workspace_bytes) {
+static int pheromone_update_impl(void *stream, int B, int n, int len, int A, float *tau,
+                                 const int64_t *paths, const float *costs, float decay, int elitist,
+                                 int symmetric, const float *clamp_min, const float *clamp_max,
+                                 float floor_val, const uint32_t *nbr_in, const float *weights, int hub,
+                                 void *workspace, size_t workspace_bytes, const HeadEmit &he) {
   if (B <= 0 || n < 3 || A <= 0 || !tau || !paths || !costs || !workspace) {
     set_error("daco_pheromone_update: bad argument (B=%d n=%d A=%d)", B, n, A);
     return DACO_E_BADARG;
@@ -480,9 +505,9 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
     if (hub >= 0)
       hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), (size_t)HUB_CHUNK * (W + 2) * sizeof(uint32_t), s, n, A, W, hub, tau, hubmask, tab_lens,
                          costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
-    hipLaunchKernelGGL(deposit_rows_kernel<false>, dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, hub, tau,
+    hipLaunchKernelGGL((deposit_rows_kernel<false, 0>), dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, hub, tau,
                        nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max,
-                       floor_val);
+                       floor_val, he);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) { set_error("directed pheromone update launch: %s", hipGetErrorString(e2)); return DACO_E_HIP; }
     return DACO_OK;
@@ -496,9 +521,45 @@ extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A,
   if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
   const int R = rows_per_block(n, true);
   const int bpi = (n + R - 1) / R;
-  hipLaunchKernelGGL(deposit_rows_kernel<true>, dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, 0, tau,
-                     nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val);
+#define DACO_DEPOSIT_SYM(H) hipLaunchKernelGGL((deposit_rows_kernel<true, H>), dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, 0, tau, \
+                                               nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val, he)
+  if (!he.eta) DACO_DEPOSIT_SYM(0);
+  else if (!he.race) DACO_DEPOSIT_SYM(1);
+  else DACO_DEPOSIT_SYM(2);
+#undef DACO_DEPOSIT_SYM
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("pheromone update launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
+}
+
+extern "C" int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau,
+                                     const int64_t *paths, const float *costs, float decay, int elitist,
+                                     int symmetric, const float *clamp_min, const float *clamp_max,
+                                     float floor_val, const uint32_t *nbr_in, const float *weights, int hub,
+                                     void *workspace, size_t workspace_bytes) {
+  return pheromone_update_impl(stream, B, n, len, A, tau, paths, costs, decay, elitist, symmetric, clamp_min, clamp_max, floor_val, nbr_in,
+                               weights, hub, workspace, workspace_bytes, HeadEmit{});
+}
+
+extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A);
+
+extern "C" int daco_pheromone_update_heads(void *stream, int B, int n, int A, float *tau, const int64_t *paths, const float *costs,
+                                           float decay, int elitist, const float *clamp_min, const float *clamp_max, float floor_val,
+                                           const uint32_t *nbr_in, const float *weights, void *workspace, size_t workspace_bytes,
+                                           const float *eta, long eta_bstride, float alpha, float beta, const uint16_t *head_id,
+                                           int head_slots, int race, void *sparse_workspace, size_t sparse_workspace_bytes) {
+  if (!eta || !head_id || !sparse_workspace) { set_error("daco_pheromone_update_heads: bad argument"); return DACO_E_BADARG; }
+  if (head_slots != 64 && head_slots != 128) { set_error("daco_pheromone_update_heads: head_slots = %d (64 or 128)", head_slots); return DACO_E_BADARG; }
+  if (n <= 128 || n > 1024) { set_error("daco_pheromone_update_heads: n=%d outside 129..1024 (the sizes daco_tsp_sample_heads serves)", n); return DACO_E_TOOLARGE; }
+  const size_t need = daco_tsp_sparse_workspace_bytes(B, n, A);
+  if (sparse_workspace_bytes < need) { set_error("daco_pheromone_update_heads: sparse workspace %zu < %zu bytes", sparse_workspace_bytes, need); return DACO_E_WORKSPACE; }
+  HeadEmit he;
+  he.eta = eta; he.eta_bs = eta_bstride; he.alpha = alpha; he.beta = beta; he.hid = head_id; he.hrow = (char *)sparse_workspace;
+  he.spl = head_slots / 16; he.race = race ? 1 : 0;
+  const int ld = n <= 512 ? 512 : 1024;
+  he.dead = ld;
+  const bool vec4 = (n & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)eta | (uintptr_t)tau) & 15) == 0;
+  he.ch = vec4 ? ld / 256 : -(ld / 256);
+  return pheromone_update_impl(stream, B, n, n, A, tau, paths, costs, decay, elitist, 1, clamp_min, clamp_max, floor_val, nbr_in, weights, 0,
+                               workspace, workspace_bytes, he);
 }

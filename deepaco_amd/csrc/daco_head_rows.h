@@ -1,0 +1,106 @@
+// daco_head_rows.h -- the HEAD ROW of one transition row (sampler "scan_sparse" / the race on head rows), formed by one
+// wavefront from the row of tau (global memory, or the copy the pheromone update holds in LDS) and the row of eta.
+//
+// Reference behaviour: the row is tau[i]^alpha * eta[i]^beta of tsp/aco.py:165-172 (tsp_nls/aco.py:195 forms it once per
+// iteration); the head / tail split is this library's (restated in the CPU checker as orc_sparse_head_values).  Two callers
+// share this code so that their head rows agree bit for bit: sparse_prepass_kernel (daco_scan_sparse.hip: the first iteration,
+// and every caller that updates tau some other way) and deposit_rows_kernel (daco_costs_update.hip: the update that just wrote
+// the row emits the NEXT iteration's head row from the registers / LDS it still holds -- tau is not read a second time).
+#pragma once
+#include "daco_device.h"
+
+namespace daco {
+
+// head slots per row: 64 or 128 (SPL = 4 or 8 per lane, 16 lanes); the last slot holds the tail total (its id field: the live
+// count in the caller's table).  Bytes per lane of a head row: SPL f32 values, SPL u16 ids -- 24 or 48.
+constexpr int SP_KH_MAX = 128;
+__host__ __device__ constexpr int sp_lane_bytes(int spl) { return spl * 6; }
+__host__ __device__ constexpr size_t sp_head_row_bytes(int spl) { return (size_t)16 * sp_lane_bytes(spl); }
+
+// element k0..k0+3 of the row tau^alpha * eta^beta (0 past n): the arithmetic of prob_matrix_kernel, no fused multiply-add
+template <bool VEC4>
+__device__ inline float4 sp_prob4(const float *tr, const float *er, int n, int k0, float alpha, float beta) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (VEC4) {
+    if (k0 < n) {                                             // (n % 4 == 0: a vector is inside the row or past it)
+      const float4 t = *reinterpret_cast<const float4 *>(tr + k0), e = *reinterpret_cast<const float4 *>(er + k0);
+      v.x = pw(t.x, alpha) * pw(e.x, beta); v.y = pw(t.y, alpha) * pw(e.y, beta);
+      v.z = pw(t.z, alpha) * pw(e.z, beta); v.w = pw(t.w, alpha) * pw(e.w, beta);
+    }
+  } else {
+    if (k0 + 0 < n) v.x = pw(tr[k0 + 0], alpha) * pw(er[k0 + 0], beta);
+    if (k0 + 1 < n) v.y = pw(tr[k0 + 1], alpha) * pw(er[k0 + 1], beta);
+    if (k0 + 2 < n) v.z = pw(tr[k0 + 2], alpha) * pw(er[k0 + 2], beta);
+    if (k0 + 3 < n) v.w = pw(tr[k0 + 3], alpha) * pw(er[k0 + 3], beta);
+  }
+  return v;
+}
+
+// One wavefront, one row.  tr / er: the row of tau and of eta (n entries each); ids: the caller's head table row (kh = 16 spl
+// slots, the last one = the live count); bm: 32 words of LDS private to this wavefront; hl: where the head row goes
+// (16 lanes x sp_lane_bytes(spl)); ch: 256-candidate chunks of the 64-lane walk (ld / 256 -- the summation order of the tail
+// total is the 64-lane scan's, oracle sparse_tail_scan).  Value of slot m = P[id_m] for the live slots, +0 for the others; the
+// last slot = the tail total (the 64-lane scan total of the row's non-head entries).  The id of an empty slot and of the last
+// slot is `dead` (>= n): its visited flag is never set, so the scan needs no "is a candidate" select.
+// RACE (the exponential race on head rows): value = 1 / P[id_m] (+inf for the other slots), last slot = the smallest 1 / P of
+// the tail, i.e. the reciprocal of its largest entry.
+template <bool RACE, bool VEC4>
+__device__ inline void emit_head_row(int n, int ch, const float *tr, const float *er, float alpha, float beta,
+                                     const uint16_t *ids, uint32_t *bm, char *hl, int spl, int dead, int lane) {
+  const int kh = 16 * spl, ls = sp_lane_bytes(spl);
+  // a malformed table (count beyond the slots, ids beyond the row) must not reach past the bitmap or the row:
+  // the count is clamped, an id >= n is an empty slot.  (engine.sparse_head never produces either.)
+  const int cnt = ids[kh - 1] < kh - 1 ? ids[kh - 1] : kh - 1;
+  if (lane < 32) bm[lane] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  for (int m = lane; m < cnt; m += 64) { const int id = ids[m]; if (id < n) atomicOr(&bm[id >> 5], 1u << (id & 31)); }
+  __builtin_amdgcn_wave_barrier();
+  float part = RACE ? __builtin_inff() : 0.0f;
+  for (int c = 0; c < ch; ++c) {
+    const int k0 = (c * 64 + lane) * 4;
+    const float4 v = sp_prob4<VEC4>(tr, er, n, k0, alpha, beta);
+    const uint32_t w = bm[(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
+    if constexpr (RACE) {
+      part = fminf(part, (w & 1u) ? __builtin_inff() : 1.0f / v.x);
+      part = fminf(part, (w & 2u) ? __builtin_inff() : 1.0f / v.y);
+      part = fminf(part, (w & 4u) ? __builtin_inff() : 1.0f / v.z);
+      part = fminf(part, (w & 8u) ? __builtin_inff() : 1.0f / v.w);
+    } else {
+      part = part + ((w & 1u) ? 0.0f : v.x);
+      part = part + ((w & 2u) ? 0.0f : v.y);
+      part = part + ((w & 4u) ? 0.0f : v.z);
+      part = part + ((w & 8u) ? 0.0f : v.w);
+    }
+  }
+  float T;
+  if constexpr (RACE) {
+    for (int o = 32; o >= 1; o >>= 1) part = fminf(part, __shfl_xor(part, o));
+    T = part;
+  } else {
+    T = readlane_f(wave_scan_add(part), 63);
+  }
+  for (int m = lane; m < kh; m += 64) {                         // slot m: lane m / spl of the row, element m % spl
+    const int id = ids[m];
+    const bool live = m < cnt && id < n;
+    const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
+    float val;
+    if constexpr (RACE) val = m == kh - 1 ? T : (live ? 1.0f / pid : __builtin_inff());
+    else val = m == kh - 1 ? T : (live ? pid : 0.0f);
+    char *hs = hl + (m / spl) * ls;
+    *reinterpret_cast<float *>(hs + (m % spl) * 4) = val;
+    *reinterpret_cast<uint16_t *>(hs + spl * 4 + (m % spl) * 2) = (uint16_t)(live && m != kh - 1 ? id : dead);
+  }
+  __builtin_amdgcn_wave_barrier();                              // (bm is reused by the wavefront's next row)
+}
+
+// what the update needs to emit head rows (null eta: no emission)
+struct HeadEmit {
+  const float *eta = nullptr;      // [B][n][n] or one shared [n][n] (eta_bs = 0)
+  long eta_bs = 0;
+  float alpha = 1.0f, beta = 1.0f;
+  const uint16_t *hid = nullptr;   // [B][n][16 spl]
+  char *hrow = nullptr;            // [B][n][16 sp_lane_bytes(spl)]
+  int spl = 4, ch = 2, dead = 512, race = 0;
+};
+
+}  // namespace daco

@@ -54,6 +54,11 @@ struct SampleParams {
   const uint16_t *hid = nullptr;     // the caller's head table [B][n][slots] (the pre-pass reads it; the scan reads the head rows)
   unsigned long long *stats = nullptr;   // [3] dense steps, tail walks, rejections (tests) or null
   uint16_t *tours16 = nullptr;       // scan_sparse at n > 512: [B][A][ld] the tours as they are built (32 bytes per ant every 16 steps)
+  // the rows the rare ways of scan_sparse walk: tau^alpha * eta^beta formed from the caller's tensors (no dense copy since round 6)
+  const float *tau = nullptr, *eta = nullptr;
+  long tau_bs = 0, eta_bs = 0;
+  float alpha = 1.0f, beta = 1.0f;
+  int row_vec = 0;                   // rows can be read as aligned 16-byte vectors (n % 4 == 0, aligned bases and strides)
 };
 
 template <class F, int... I>

@@ -19,15 +19,12 @@
 // k = (c * 64 + lane) * 4 + v, the 64-lane scan).  Tours (u16) and visited flags (bytes, node order) live in LDS; paths / tour
 // lengths / the update's table leave the workgroup in the epilogue of the scan16 family (16 ants = one 128-byte run per row).
 #include "daco_sample_kernel.h"
+#include "daco_head_rows.h"
 
 namespace daco {
 
-// head slots per row: 64 or 128 (SPL = 4 or 8 per lane, 16 lanes); the last slot holds the tail total (its id field: the live
-// count in the caller's table).  Bytes per lane of a head row: SPL f32 values, SPL u16 ids -- 24 or 48.  (32-byte lanes for
-// SPL = 4 -- every 16-byte load aligned, four cache lines per row instead of three -- measured 0.61 ms against 0.58 at the
-// headline shape.)
-constexpr int SP_KH_MAX = 128;
-__host__ __device__ constexpr int sp_lane_bytes(int spl) { return spl * 6; }
+// (head slots per row, bytes per lane: daco_head_rows.h.  32-byte lanes for SPL = 4 -- every 16-byte load aligned, four cache
+// lines per row instead of three -- measured 0.61 ms against 0.58 at the headline shape.)
 constexpr int SP_FCMP_OGT = 2, SP_FCMP_OGE = 3, SP_FCMP_OLT = 4;
 
 enum : uint32_t { STREAM_SPARSE = 4, STREAM_SPARSE_RETRY = 5 };   // (retry: the second uniform of a step, block t << 8, component 0)
@@ -45,83 +42,23 @@ __device__ inline float sp_row_scan(float x) {
 __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x8000800080008000ull) - 0x0001000100010001ull); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// the pre-pass of one iteration, one wavefront per row: the padded row P[row][.] = tau^alpha * eta^beta (the arithmetic of
-// prob_matrix_kernel; only the rare ways read it back) and, from the same registers, the HEAD ROW the scan reads each step:
-// 16 lanes x ls bytes, lane s = {values of slots 4s..4s+3 (f32), their node ids (u16)}.  Value of slot m = P[row][id_m] for the
-// live slots, +0 for the others; slot 63 = the tail total (the 64-lane scan total of the row's non-head entries).  The id of an
-// empty slot and of slot 63 is `dead` (>= n): its visited flag is never set, so the scan needs no "is a candidate" select.
-// tau and eta are read once (2 x 4n bytes per row), nothing is read back.
-// RACE (the exponential race on head rows): value = 1 / P[row][id_m] (+inf for the other slots), slot 63 = the smallest
-// 1 / P of the tail, i.e. the reciprocal of its largest entry.
+// the pre-pass of one iteration, one wavefront per row: the HEAD ROW the scan reads each step (daco_head_rows.h emit_head_row:
+// 16 lanes x ls bytes, lane s = {values of slots 4s..4s+3 (f32), their node ids (u16)}; the last slot = the tail total), from one
+// read of the rows of tau and eta.  Round 6: the dense fused row P = tau^alpha * eta^beta is no longer written (65 MB per
+// iteration at the headline shape for the 1.4 % of the steps that walked it): the rare ways form tau * eta from the two rows
+// themselves (sp_prob4: the same two roundings), and an iteration whose pheromone update emitted the head rows
+// (daco_pheromone_update_heads) does not run this kernel at all.
 template <bool RACE, bool VEC4>
 __global__ void __launch_bounds__(256)
-sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha, float beta,
-                      const uint16_t *hid, float *P, char *hrow, int spl, int dead) {
+sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha, float beta,
+                      const uint16_t *hid, char *hrow, int spl, int dead) {
   __shared__ uint32_t bm[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= (long)B * n) return;
   const int b = (int)(row / n), r = (int)(row - (long)b * n);
   const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
-  float *pr = P + row * ld;
-  const int kh = 16 * spl, ls = sp_lane_bytes(spl);
-  const uint16_t *ids = hid + row * kh;
-  // a malformed table (count beyond the slots, ids beyond the row) must not reach past the bitmap or the row:
-  // the count is clamped, an id >= n is an empty slot.  (engine.sparse_head never produces either.)
-  const int cnt = ids[kh - 1] < kh - 1 ? ids[kh - 1] : kh - 1;
-  if (lane < 32) bm[wave][lane] = 0u;
-  __builtin_amdgcn_wave_barrier();
-  for (int m = lane; m < cnt; m += 64) { const int id = ids[m]; if (id < n) atomicOr(&bm[wave][id >> 5], 1u << (id & 31)); }
-  __builtin_amdgcn_wave_barrier();
-  float part = RACE ? __builtin_inff() : 0.0f;
-  const int ch = ld >> 8;
-  for (int c = 0; c < ch; ++c) {
-    const int k0 = (c * 64 + lane) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (VEC4) {
-      if (k0 < n) {                                           // (n % 4 == 0: a vector is inside the row or in the padding)
-        const float4 t = *reinterpret_cast<const float4 *>(tr + k0), e = *reinterpret_cast<const float4 *>(er + k0);
-        v.x = pw(t.x, alpha) * pw(e.x, beta); v.y = pw(t.y, alpha) * pw(e.y, beta);
-        v.z = pw(t.z, alpha) * pw(e.z, beta); v.w = pw(t.w, alpha) * pw(e.w, beta);
-      }
-    } else {
-      if (k0 + 0 < n) v.x = pw(tr[k0 + 0], alpha) * pw(er[k0 + 0], beta);
-      if (k0 + 1 < n) v.y = pw(tr[k0 + 1], alpha) * pw(er[k0 + 1], beta);
-      if (k0 + 2 < n) v.z = pw(tr[k0 + 2], alpha) * pw(er[k0 + 2], beta);
-      if (k0 + 3 < n) v.w = pw(tr[k0 + 3], alpha) * pw(er[k0 + 3], beta);
-    }
-    *reinterpret_cast<float4 *>(pr + k0) = v;
-    const uint32_t w = bm[wave][(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
-    if constexpr (RACE) {
-      part = fminf(part, (w & 1u) ? __builtin_inff() : 1.0f / v.x);
-      part = fminf(part, (w & 2u) ? __builtin_inff() : 1.0f / v.y);
-      part = fminf(part, (w & 4u) ? __builtin_inff() : 1.0f / v.z);
-      part = fminf(part, (w & 8u) ? __builtin_inff() : 1.0f / v.w);
-    } else {
-      part = part + ((w & 1u) ? 0.0f : v.x);
-      part = part + ((w & 2u) ? 0.0f : v.y);
-      part = part + ((w & 4u) ? 0.0f : v.z);
-      part = part + ((w & 8u) ? 0.0f : v.w);
-    }
-  }
-  float T;
-  if constexpr (RACE) {
-    for (int o = 32; o >= 1; o >>= 1) part = fminf(part, __shfl_xor(part, o));
-    T = part;
-  } else {
-    T = readlane_f(wave_scan_add(part), 63);
-  }
-  for (int m = lane; m < kh; m += 64) {                         // slot m: lane m / spl of the row, element m % spl
-    const int id = ids[m];
-    const bool live = m < cnt && id < n;
-    const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
-    float val;
-    if constexpr (RACE) val = m == kh - 1 ? T : (live ? 1.0f / pid : __builtin_inff());
-    else val = m == kh - 1 ? T : (live ? pid : 0.0f);
-    char *hl = hrow + row * (16 * ls) + (m / spl) * ls;
-    *reinterpret_cast<float *>(hl + (m % spl) * 4) = val;
-    *reinterpret_cast<uint16_t *>(hl + spl * 4 + (m % spl) * 2) = (uint16_t)(live && m != kh - 1 ? id : dead);
-  }
+  emit_head_row<RACE, VEC4>(n, ch, tr, er, alpha, beta, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), spl, dead, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -129,8 +66,14 @@ sparse_prepass_kernel(int B, int n, int ld, const float *tau, long tau_bs, const
 // 64-lane scan specification with uniform `ur` (oracle draw_scan, lanes = 64).  TAIL = true: the walk over the row's
 // non-head entries, visited or not, with the threshold `ur` given (oracle draw_scan_sparse, "past the head").
 // Returns the node, -1 if no candidate can be drawn (dense: infeasible; tail: a tail without mass).
+// (the row itself: tau^alpha * eta^beta formed from the rows of tau and eta -- sp_prob4, what the dense P held until round 5)
+struct SpRowSrc { const float *t, *e; float alpha, beta; int n; bool vec; };
+__device__ inline float4 sp_row4(const SpRowSrc &r, int k0) {
+  return r.vec ? sp_prob4<true>(r.t, r.e, r.n, k0, r.alpha, r.beta) : sp_prob4<false>(r.t, r.e, r.n, k0, r.alpha, r.beta);
+}
+
 template <int CHD, bool TAIL>
-__device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, const uint32_t *bm, int lane, float ur) {
+__device__ inline int sparse_row_walk(const SpRowSrc &rowp, const uint8_t *flg, const uint32_t *bm, int lane, float ur) {
   constexpr int NJ = CHD * 4;
   float run[16];
   float acc = 0.0f;
@@ -138,7 +81,7 @@ __device__ inline int sparse_row_walk(const char *rowp, const uint8_t *flg, cons
 #pragma unroll
   for (int c = 0; c < CHD; ++c) {
     const int k0 = (c * 64 + lane) * 4;
-    const float4 rv = *reinterpret_cast<const float4 *>(rowp + (uint32_t)k0 * 4u);
+    const float4 rv = sp_row4(rowp, k0);
     float f[4];
     if constexpr (TAIL) {
       const uint32_t w = bm[(k0 >> 5) & 31] >> (k0 & 31);
@@ -220,6 +163,8 @@ scan_sparse_kernel(const SampleParams p) {
   constexpr int LAST = SPL - 1;                          // (lane 15: the slot of the tail total)
   constexpr int FL = CHD * 256;                          // tour / inverse-table entries per ant (>= n)
   constexpr int FLP = FL + 16;                           // flag bytes per ant: entry FL is never set (the id of slot 63 and of empty slots)
+  constexpr int FLT = FL + 2;                            // u16 entries between two ants' tours in LDS (n <= 512): 1028 bytes, so that the
+                                                         // four ants of a wavefront (and the sixteen of the epilogue) fall on different banks
   constexpr uint32_t ROWB = 16u * LS;                    // bytes of a head row: lane s holds {SPL f32 values, SPL u16 ids} at s * LS
   // LDS (one dynamic block): visited flags as BYTES (1 while node k is unvisited, node order) and
   //   n <= 512: the u16 tours -- 1.5 KB per ant, six workgroups per CU (all outputs leave in the epilogue below);
@@ -242,19 +187,19 @@ scan_sparse_kernel(const SampleParams p) {
   const int b = w / bpi;
   const int abase = (w - b * bpi) * APB;
   const int a0 = abase + wave * APW;
-  const int n = p.n, A = p.A, ld = p.ld;
+  const int n = p.n, A = p.A;
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);
   const bool active = a0 < A;
   const int a = a0 + q < A ? a0 + q : A - 1;             // spare groups build ant A-1 again (not written)
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
-  const char *Pb = (const char *)(p.P + (size_t)b * n * ld);
+  const float *taub = p.tau + (size_t)b * p.tau_bs, *etab = p.eta + (size_t)b * p.eta_bs;
   const char *hrb = (const char *)p.hval + (size_t)b * n * ROWB;
   const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void *)hrb, 0, (int)((uint32_t)n * ROWB), 0x00020000);
-  const uint32_t ldb = (uint32_t)ld * 4u;
+#define SP_ROW_OF(pv) SpRowSrc{taub + (size_t)(pv) * n, etab + (size_t)(pv) * n, p.alpha, p.beta, n, p.row_vec != 0}
   uint32_t sls = (uint32_t)s * LS;
   asm volatile("" : "+v"(sls));                          // (kept in a register: the loop adds it to the row offset)
   uint8_t *fl = flag_mem + (wave * APW + q) * FLP;
-  uint16_t *tour = tour_mem + (wave * APW + q) * (TG ? 16 : FL);
+  uint16_t *tour = tour_mem + (wave * APW + q) * (TG ? 16 : FLT);
   // TG: tour entry t lives at tour[t & 15] until its chunk is flushed to the workgroup's rows of tours16 [B][A][FL]
   uint16_t *t16b = TG ? p.tours16 + ((size_t)b * A + abase) * FL : nullptr;
   const uint32_t t16o = (uint32_t)((wave * APW + q) * FL + s);
@@ -348,14 +293,14 @@ scan_sparse_kernel(const SampleParams p) {
             const int pv = readlane_i(prev, gl);
             const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
             const uint8_t *flg = flag_mem + (wave * APW + g) * FLP;
-            const char *rowp = Pb + (uint32_t)pv * ldb;
+            const SpRowSrc rowp = SP_ROW_OF(pv);
             n_dense += a0 + g < A ? 1ull : 0ull;
             float dk = __builtin_inff();
             int di = 0x7fffffff;
 #pragma unroll
             for (int c = 0; c < CHD; ++c) {
               const int k0 = (c * 64 + lane) * 4;
-              const float4 pvv = *reinterpret_cast<const float4 *>(rowp + (uint32_t)k0 * 4u);
+              const float4 pvv = sp_row4(rowp, k0);
               const uint32_t ff = *reinterpret_cast<const uint32_t *>(flg + k0);
               const u32x4 r4 = rng_block(p.seed, iter_now, STREAM_RACE, gidg, ((uint32_t)t << 12) | (uint32_t)(c * 64 + lane));
               const float pp[4] = {pvv.x, pvv.y, pvv.z, pvv.w};
@@ -441,7 +386,7 @@ scan_sparse_kernel(const SampleParams p) {
               const float ug = readlane_f(ucur, gl), rg = readlane_f(r, gl);     // (ucur: already rotated, lane 0 holds this step's)
               const uint32_t gidg = (uint32_t)readlane_i((int)gid, gl);
               const uint8_t *flg = flag_mem + (wave * APW + g) * FLP;
-              const char *rowp = Pb + (uint32_t)pv * ldb;
+              const SpRowSrc rowp = SP_ROW_OF(pv);
               int choice_g = -1;
               const unsigned long long real = a0 + g < A ? 1ull : 0ull;      // (a spare group repeats ant A-1: not counted)
               if (!(Hg > 0.0f)) {                               // no live head candidate: the dense masked draw with this uniform
@@ -506,6 +451,7 @@ scan_sparse_kernel(const SampleParams p) {
     }
   }
 #undef SP_T
+#undef SP_ROW_OF
 #undef SP_HEAD_DECIDE
 #undef SP_LAST_POSITIVE
 #undef SP_ID
@@ -518,7 +464,7 @@ scan_sparse_kernel(const SampleParams p) {
   // ------------------------------------------------------------------ epilogue: the workgroup's 16 tours leave
   const int nant = A - abase < APB ? A - abase : APB;
   if constexpr (!TG) {
-    uint16_t (*tour_s)[FL] = reinterpret_cast<uint16_t (*)[FL]>(tour_mem);
+    uint16_t (*tour_s)[FLT] = reinterpret_cast<uint16_t (*)[FLT]>(tour_mem);
     __syncthreads();
     const int k16 = threadIdx.x & (APB - 1);
     constexpr int TSTEP = 256 / APB;
@@ -660,15 +606,18 @@ scan_sparse_kernel(const SampleParams p) {
 
 using namespace daco;
 
+// workspace: the head rows (at offset 0: daco_pheromone_update_heads writes them there too), then (n > 512) the u16 tours as they are built
 extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A) {
   if (B <= 0 || A <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
-  // the transition rows, the head rows, and (n > 512) the u16 tours as they are built
-  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * 16 * sp_lane_bytes(SP_KH_MAX / 16)) +
-         (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
+  return align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)) + (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
 }
 
-static int sample_sparse_impl(bool race, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+static bool sparse_rows_vec4(int n, const float *tau, long tau_bstride, const float *eta, long eta_bstride) {
+  return (n & 3) == 0 && (tau_bstride & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
+}
+
+static int sample_sparse_impl(bool race, bool heads_ready, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                       long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                       int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
@@ -687,25 +636,25 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   if (workspace_bytes < need) { set_error("%s: workspace %zu < %zu bytes", what, workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   const int ld = n <= 512 ? 512 : 1024;
-  float *P = (float *)workspace;
-  char *hrow = (char *)workspace + align256((size_t)B * n * ld * sizeof(float));
+  char *hrow = (char *)workspace;
   const int spl = head_slots / 16;
-  {
-    const bool vec4 = (n & 3) == 0 && (tau_bstride & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
+  const bool vec4 = sparse_rows_vec4(n, tau, tau_bstride, eta, eta_bstride);
+  if (!heads_ready) {
     const dim3 pg((unsigned)(((long)B * n + 3) / 4));
-#define DACO_PREPASS(R, V) hipLaunchKernelGGL((sparse_prepass_kernel<R, V>), pg, dim3(256), 0, s, B, n, ld, tau, tau_bstride, eta, eta_bstride, \
-                                              alpha, beta, head_id, P, hrow, spl, ld)
+#define DACO_PREPASS(R, V) hipLaunchKernelGGL((sparse_prepass_kernel<R, V>), pg, dim3(256), 0, s, B, n, ld / 256, tau, tau_bstride, eta, eta_bstride, \
+                                              alpha, beta, head_id, hrow, spl, ld)
     if (race) { if (vec4) DACO_PREPASS(true, true); else DACO_PREPASS(true, false); }
     else { if (vec4) DACO_PREPASS(false, true); else DACO_PREPASS(false, false); }
 #undef DACO_PREPASS
   }
   SampleParams sp{};
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = ld / 256;
-  sp.P = P; sp.start = start; sp.fixed_start = fixed_start;
+  sp.P = nullptr; sp.start = start; sp.fixed_start = fixed_start;
+  sp.tau = tau; sp.tau_bs = tau_bstride; sp.eta = eta; sp.eta_bs = eta_bstride; sp.alpha = alpha; sp.beta = beta; sp.row_vec = vec4 ? 1 : 0;
   sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
   sp.hval = (const float *)hrow; sp.hid = head_id; sp.stats = stats;
-  sp.tours16 = (uint16_t *)(hrow + align256((size_t)B * n * 16 * sp_lane_bytes(SP_KH_MAX / 16)));
+  sp.tours16 = (uint16_t *)(hrow + align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("%s pre-pass: %s", what, hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
@@ -713,7 +662,7 @@ static int sample_sparse_impl(bool race, const char *what, void *stream, int B, 
   const dim3 grid((unsigned)(B * bpi));
   // dynamic LDS: flags + tours (n <= 512); the larger of flags + window and eight tours + their inverse table (n > 512)
   const int pad_lds = getenv("DACO_SPARSE_PAD_LDS") ? atoi(getenv("DACO_SPARSE_PAD_LDS")) : 0;   // (measurement knob: fewer workgroups per CU)
-#define DACO_SPARSE_LDS(C) ((C) == 2 ? 16 * ((C) * 256 + 16) + 16 * (C) * 256 * 2 : 2 * 8 * (C) * 256 * 2)
+#define DACO_SPARSE_LDS(C) ((C) == 2 ? 16 * ((C) * 256 + 16) + 16 * ((C) * 256 + 2) * 2 : 2 * 8 * (C) * 256 * 2)
 #define DACO_SPARSE_LAUNCH(C, R, S) hipLaunchKernelGGL((scan_sparse_kernel<C, R, S>), grid, dim3(256), DACO_SPARSE_LDS(C) + pad_lds, s, sp)
 #define DACO_SPARSE_PICK(C, R) do { if (spl == 4) DACO_SPARSE_LAUNCH(C, R, 4); else DACO_SPARSE_LAUNCH(C, R, 8); } while (0)
   if (ld <= 512) { if (race) DACO_SPARSE_PICK(2, true); else DACO_SPARSE_PICK(2, false); }
@@ -736,7 +685,7 @@ extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const f
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                       long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                       size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(false, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(false, false, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
 }
 extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                          long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
@@ -744,5 +693,13 @@ extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, cons
                                          uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                          long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                          size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(true, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(true, false, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
+}
+extern "C" int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+                                     long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
+                                     int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
+                                     uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
+                                     long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
+                                     size_t workspace_bytes, void *ev_begin, void *ev_end) {
+  return sample_sparse_impl(race != 0, heads_ready != 0, "daco_tsp_sample_heads", DACO_SPARSE_ARGS);
 }

@@ -78,6 +78,7 @@ class ACO(_CvrpACO):
         self._heu_src = None if heuristic is None else engine.stage_to_hip(heuristic.detach(), like=self.distances)
         self._demand_src = engine.stage_to_hip(demand.detach(), like=self.distances)
         self._hgs = None
+        self._host = {}                                  # distances_cpu / demand_cpu / positions_cpu, on first use
         self._heu_at_init = self.heuristic               # (a heuristic assigned later replaces the constructor's in the local search too)
 
     def sample(self, inference=False):
@@ -100,6 +101,28 @@ class ACO(_CvrpACO):
             heu = self.heuristic.detach().float()
             self._heuristic_dist = (1 / (heu / heu.max(-1, keepdim=True).values + 1e-5)).contiguous()
         return self._heuristic_dist
+
+    # ------------------------------------------------------------------ cvrp_nls/aco.py:273-287
+    # Host copies of the instance, as numpy arrays in the caller's dtype: what the reference hands to its C++ local search
+    # (swapstar(self.demand_cpu, self.distances_cpu, ...)).  Nothing here computes with them (the local search reads the device
+    # tensors); they exist for scripts that read them off the colony.  Cached on first use, like the reference's cached_property.
+    @property
+    def distances_cpu(self):
+        if "distances_cpu" not in self._host:
+            self._host["distances_cpu"] = self._dist_src.detach().cpu().numpy()
+        return self._host["distances_cpu"]
+
+    @property
+    def demand_cpu(self):
+        if "demand_cpu" not in self._host:
+            self._host["demand_cpu"] = self._demand_src.detach().cpu().numpy()
+        return self._host["demand_cpu"]
+
+    @property
+    def positions_cpu(self):
+        if "positions_cpu" not in self._host:
+            self._host["positions_cpu"] = self.positions.detach().cpu().numpy() if self.positions is not None else None
+        return self._host["positions_cpu"]
 
     def _hgs_stage_tables(self):
         """(tables of the distances, tables of the heuristic-derived matrix): what HGS's Params derives from a matrix, once per

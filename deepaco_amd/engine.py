@@ -221,15 +221,29 @@ def take_auto_top(cache, heuristic):
     return hit[1] if hit is not None and hit[0] is heuristic else None
 
 
+def sparse_workspace(device, B, n, n_ants):
+    """A scratch tensor of the head-row samplers that a colony KEEPS (daco_tsp_sparse_workspace_bytes: the iteration's head rows
+    and, for n > 512, the tours as they are built): pheromone_update_(heads=...) writes the next iteration's head rows into it and
+    tsp_sample_sparse(heads_ready=True) reads them, so it must not be the per-stream scratch other colonies share."""
+    nbytes = _lib.lib().daco_tsp_sparse_workspace_bytes(B, n, n_ants)
+    if nbytes == 0:
+        raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
-                      want_paths=True, race=False):
+                      want_paths=True, race=False, workspace=None, heads_ready=False):
     """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
     distribution of tsp_sample(mode="scan"), 384 / 768 bytes per step instead of a row while the head has a live candidate.
     head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats]).
     race=True: daco_tsp_sample_race_head -- the exponential race of mode="race" on the head rows, with the tours of the dense
-    race kernel (same seed), one variate per head slot and step instead of n."""
-    _require_gpu(tau, eta, start, head)
+    race kernel (same seed), one variate per head slot and step instead of n.
+    workspace: a sparse_workspace() tensor the caller keeps (default: the per-stream scratch); heads_ready=True: it already holds
+    this iteration's head rows (pheromone_update_(heads=...) wrote them for these very tensors) and the pass over tau is skipped
+    (include/deepaco_hip.h daco_tsp_sample_heads) -- the same tours."""
+    _require_gpu(tau, eta, start, head, workspace)
+    assert not heads_ready or workspace is not None
     n = tau.shape[-1]
     B = batch or (tau.shape[0] if tau.dim() == 3 else (eta.shape[0] if eta.dim() == 3 else 1))
     dev = tau.device
@@ -254,9 +268,9 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
         nbytes = L.daco_tsp_sparse_workspace_bytes(B, n, n_ants)
         if nbytes == 0:
             raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
-        ws = _workspace(dev, nbytes, "sample_sparse")
-        fn = L.daco_tsp_sample_race_head if race else L.daco_tsp_sample_sparse
-        rc = fn(_stream(dev), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+        ws = workspace if workspace is not None else _workspace(dev, nbytes, "sample_sparse")
+        assert ws.numel() >= nbytes
+        rc = L.daco_tsp_sample_heads(_stream(dev), int(bool(race)), int(bool(heads_ready)), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
                                       float(beta), head.data_ptr(), int(head.shape[2]), start.data_ptr() if start is not None else None,
                                       int(fixed_start), int(seed) & (2 ** 64 - 1), int(it),
                                       iter_dev.data_ptr() if iter_dev is not None else None, int(ant_gid0) & 0xFFFFFFFF,
@@ -266,7 +280,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
                                       nbr.data_ptr() if nbr is not None else None,
                                       stats.data_ptr() if stats is not None else None, ws.data_ptr(), ws.numel(),
                                       events[0].cuda_event if events else None, events[1].cuda_event if events else None)
-    _lib.check(rc, "daco_tsp_sample_race_head" if race else "daco_tsp_sample_sparse")
+    _lib.check(rc, "daco_tsp_sample_heads")
     out = (paths, flags, costs, nbr)
     return out + (stats,) if want_stats else out
 
@@ -608,11 +622,14 @@ def track_best_(costs, paths, lowest, shortest=None, mmas_scale=None):
 
 
 def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, clamp_min=None,
-                      clamp_max=None, floor=0.0, nbr=None, weights=None, hub=0):
+                      clamp_max=None, floor=0.0, nbr=None, weights=None, hub=0, heads=None):
     """In-place ACO.update_pheronome for a batch (tsp/aco.py:95-118, cvrp/aco.py:107-130).
 
     tau [B,n,n] f32 contiguous (modified in place); clamp_min/clamp_max: [B] f32 tensors or None.
-    weights [B,A]: explicit deposit per ant (default 1/cost); hub: see include/deepaco_hip.h."""
+    weights [B,A]: explicit deposit per ant (default 1/cost); hub: see include/deepaco_hip.h.
+    heads (symmetric only): dict(eta, alpha, beta, head, race, workspace) of a colony whose next construction is
+    tsp_sample_sparse(..., workspace=workspace, heads_ready=True): the update also writes that call's head rows
+    (daco_pheromone_update_heads: tau is read once per iteration instead of twice)."""
     _require_gpu(tau, paths, costs, clamp_min, clamp_max)
     assert tau.dim() == 3 and tau.dtype == torch.float32 and tau.is_contiguous()
     B, n, _ = tau.shape
@@ -626,6 +643,20 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
     with torch.cuda.device(dev):
         nbytes = L.daco_pheromone_update_workspace_bytes(B, n, length, A)
         ws = _workspace(dev, nbytes, "update")
+        if heads is not None:
+            assert symmetric and length == n
+            eta, ebs = _bstride(heads["eta"], n)
+            head, sws = heads["head"], heads["workspace"]
+            _require_gpu(eta, head, sws)
+            rc = L.daco_pheromone_update_heads(_stream(dev), B, n, A, tau.data_ptr(), paths.data_ptr(), costs.data_ptr(), float(decay),
+                                               int(bool(elitist)), clamp_min.data_ptr() if clamp_min is not None else None,
+                                               clamp_max.data_ptr() if clamp_max is not None else None, float(floor),
+                                               nbr.data_ptr() if nbr is not None else None,
+                                               weights.data_ptr() if weights is not None else None, ws.data_ptr(), ws.numel(),
+                                               eta.data_ptr(), ebs, float(heads["alpha"]), float(heads["beta"]), head.data_ptr(),
+                                               int(head.shape[2]), int(bool(heads.get("race", False))), sws.data_ptr(), sws.numel())
+            _lib.check(rc, "daco_pheromone_update_heads")
+            return tau
         rc = L.daco_pheromone_update(_stream(dev), B, n, length, A, tau.data_ptr(), paths.data_ptr(),
                                      costs.data_ptr(), float(decay), int(bool(elitist)), int(bool(symmetric)),
                                      clamp_min.data_ptr() if clamp_min is not None else None,
@@ -946,6 +977,15 @@ class BatchedTSP:
         # k from sparsify(k), else `head_k` (default n // 10, at most 127); rebuilt when the heuristic object changes.
         self.head_k = None
         self._head = None
+        # the head-row samplers' workspace is the colony's own, and the pheromone update leaves the NEXT iteration's head rows in
+        # it (pheromone_update_(heads=...)); _heads_for names the state those rows were formed from -- the next step takes them
+        # only if pheromone (object and version counter), heuristic, head table and exponents are still those
+        self._sparse_ws = None
+        self._heads_for = None
+        self.fuse_head_rows = os.environ.get("DACO_FUSE_HEAD_ROWS", "1") != "0"      # (knob: 0 = a pre-pass every iteration, as until round 5)
+
+    def _heads_state(self, head, race):
+        return (self.pheromone, self.pheromone._version, self.heuristic, head, bool(race), float(self.alpha), float(self.beta))
 
     def _heuristic_dist(self):
         if self._hdist is None:
@@ -986,11 +1026,22 @@ class BatchedTSP:
         # sampler="race" after sparsify(k): the same tours from the head rows (daco_tsp_sample_race_head), an eighth of the noise
         sampler, hk = self.resolved_sampler()
         race_head = sampler == "race" and self.head_k is not None and 128 < self.n <= 1024
+        heads = None
         if sampler == "scan_sparse" or race_head:
-            paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, self._head_table(hk), self.alpha,
+            head = self._head_table(hk)
+            if self._sparse_ws is None:
+                self._sparse_ws = sparse_workspace(self.distances.device, self.B, self.n, self.n_ants)
+            st = self._heads_state(head, race_head)
+            ready = self._heads_for is not None and len(st) == len(self._heads_for) and all(
+                (a is b) if torch.is_tensor(a) else (a == b) for a, b in zip(st, self._heads_for))
+            paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, head, self.alpha,
                                                      self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
-                                                     dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head)
+                                                     dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head,
+                                                     workspace=self._sparse_ws, heads_ready=ready)
+            if self.fuse_head_rows:
+                heads = {"eta": self.heuristic, "alpha": self.alpha, "beta": self.beta, "head": head, "race": race_head,
+                         "workspace": self._sparse_ws}
         else:
             paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
                                                     self.beta, mode=sampler, seed=self.seed, it=self.iteration,
@@ -1034,7 +1085,8 @@ class BatchedTSP:
             if self._cmin is None:
                 self._cmin = torch.full_like(new_max, self.min)
             cmin, cmax = self._cmin, new_max
-        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
+        pheromone_update_(self.pheromone, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr, heads=heads)
+        self._heads_for = self._heads_state(heads["head"], heads["race"]) if heads is not None else None
         return paths, costs
 
     @torch.no_grad()

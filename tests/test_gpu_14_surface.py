@@ -88,3 +88,18 @@ def test_tsp_nls_numpy_helpers_and_inference_sampler():
     assert (np.sort(rnd, axis=1) == np.arange(n)).all() and len(set(rnd[:, 0].tolist())) > 1
     one = _inference_sample(prob, 3)
     assert one.shape == (n,) and one[0] == 3
+
+
+def test_cvrp_nls_host_copies_of_the_instance():
+    """cvrp_nls/aco.py:273-287: distances_cpu / demand_cpu / positions_cpu -- numpy copies in the caller's dtype (float64 instance
+    data, cvrp_nls/utils.py:12-32), cached; positions_cpu is None without positions (VERDICT r5 missing 6)."""
+    from deepaco_amd.cvrp_nls.aco import ACO
+    from deepaco_amd.cvrp_nls.utils import gen_instance
+    torch.manual_seed(3)
+    demand, dist, pos = gen_instance(20, dev(), position=True)
+    aco = ACO(dist, demand, n_ants=4, swapstar=True, positions=pos, device="cuda:0")
+    assert aco.distances_cpu.dtype == np.float64 and np.array_equal(aco.distances_cpu, dist.cpu().numpy())
+    assert aco.demand_cpu.dtype == np.float64 and np.array_equal(aco.demand_cpu, demand.cpu().numpy())
+    assert np.array_equal(aco.positions_cpu, pos.cpu().numpy())
+    assert aco.distances_cpu is aco.distances_cpu                   # cached
+    assert ACO(dist, demand, n_ants=4, device="cuda:0").positions_cpu is None

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, load_golden
+from conftest import GOLDEN, load_golden, assert_close_mostly
 
 RTOL_COST = 1e-5      # north_star: tour costs within 1e-5 relative
 ATOL_LOGP = 2e-6      # logf differs by <= 1 ulp between libm builds; |logp| < 20
@@ -230,6 +230,24 @@ def test_gnn_restatement(name):
     n = g["x"].shape[0]
     if "cvrp" not in name:
         assert np.array_equal(gnn.reshape(n, g["edge_index"], g["heu_eval"]), g["heu_mat"])
+
+
+@pytest.mark.parametrize("name,wname", [("g5c_net_tsp_tsp500", "w_tsp_tsp500"), ("g5c_net_tsp_nls_tsp1000", "w_tsp_nls_tsp1000")])
+def test_gnn_restatement_at_bench_size(name, wname):
+    """g5c (tests/golden/gen_g5c_net_bench_size.py): the imported reference's Net.forward at the sizes bench.py runs -- n = 500 /
+    k = 50 with pretrained/tsp/tsp500.pt (tsp/train.ipynb:268), n = 1000 / k = 100 with pretrained/tsp_nls/tsp1000.pt -- eval mode,
+    train mode, and 2 048 rows of the embedding."""
+    from oracle import gnn
+    g = load_golden(name)
+    w = gnn.weights_from_fixture(load_golden(wname))
+    ei = g["edge_index"].astype(np.int64)
+    ea = g["edge_attr"].reshape(-1, 1)
+    emb = gnn.emb_forward(w, g["x"], ei, ea)
+    np.testing.assert_allclose(emb[g["emb_rows"]], g["emb_eval_rows"], rtol=3e-4, atol=3e-4)
+    heu = gnn.net_forward(w, g["x"], ei, ea)
+    assert_close_mostly(heu, g["heu_eval"])
+    heu_t = gnn.net_forward(w, g["x"], ei, ea, train=True)
+    assert_close_mostly(heu_t, g["heu_train"])
 
 
 @pytest.mark.parametrize("name", ["g5b_net_sop_sop20", "g5b_net_op_op100", "g5b_net_mkp_mkp300"])
