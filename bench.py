@@ -1257,21 +1257,24 @@ def best_cost_gap(dist_cpu, k_sparse, A, cpu_best, iters, dev, samplers, default
 
 def gpu_topology():
     """Link types between the node's GPUs as rocm-smi reports them (best effort; one string for the record):
-    e.g. "8 GPUs: 28 XGMI pairs" on an MI355X node, "1 GPU" on a single-GPU box."""
+    e.g. "8 GPUs: 56 XGMI links" on an MI355X node, "1 GPU" on a single-GPU box."""
+    import torch
+    ng = torch.cuda.device_count()
+    base = f"{ng} GPU{'s' if ng != 1 else ''}"
+    if ng < 2:
+        return base
     try:
-        out = subprocess.run(["rocm-smi", "--showtopotype", "--json"], capture_output=True, text=True, timeout=20).stdout
-        j = json.loads(out[out.index("{"):])
+        out = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20).stdout
         kinds = {}
-        for sect in j.values():
-            if isinstance(sect, dict):
-                for k_, v in sect.items():
-                    if "type" in k_.lower() and isinstance(v, str):
-                        kinds[v] = kinds.get(v, 0) + 1
-        import torch
-        ng = torch.cuda.device_count()
-        return f"{ng} GPU{'s' if ng != 1 else ''}" + (": " + ", ".join(f"{c} {t} pairs" for t, c in sorted(kinds.items())) if kinds else "")
+        for line in out.splitlines():
+            toks = line.split()
+            if toks and toks[0].startswith("GPU") and len(toks) > 1:          # a row of the link-type matrix
+                for t in toks[1:]:
+                    if t.upper() in ("XGMI", "PCIE"):
+                        kinds[t.upper()] = kinds.get(t.upper(), 0) + 1
+        return base + (": " + ", ".join(f"{c} {t} links" for t, c in sorted(kinds.items())) if kinds else " (link types not reported)")
     except Exception as e:
-        return f"unavailable ({type(e).__name__})"
+        return base + f" (rocm-smi unavailable: {type(e).__name__})"
 
 
 def worker(args):

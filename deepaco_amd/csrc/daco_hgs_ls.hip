@@ -529,13 +529,17 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
   const HgsLayout lay(n, p.g);
 
   for (;;) {
-    // one lane takes the next item, the wave reads it back: a single returning atomic written out as such (the form
-    // "every lane adds one, item = old / 64" was right only while the compiler folded the 64 adds into one; and a lane-0-only
-    // atomicAdd broadcast with readfirstlane was compiled into a divergent loop that re-ran item 0 for ever -- the instruction
-    // itself is not something an optimisation level can reshape)
-    uint32_t fetched = 0;
-    if (lane == 0)
-      asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(fetched) : "v"(p.queue), "v"(1u) : "memory");
+    // one lane takes the next item and the wave reads it back: a single returning atomic, written out as such (the
+    // form "every lane adds one, item = old / 64" was right only while the compiler folded the 64 adds into one).  The lane is
+    // selected INSIDE the asm statement (exec = 1 around the instruction): an `if (lane == 0)` around the atomic -- as an
+    // intrinsic or as inline asm, both were tried -- makes the compiler treat everything derived from `item` as divergent and
+    // wrap the item's processing in a loop over exec subsets in which the other lanes' zero re-runs item 0 for ever.
+    uint32_t fetched;
+    {
+      unsigned long long exec_save;
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_waitcnt vmcnt(0)\n\ts_mov_b64 exec, %1"
+                   : "=&v"(fetched), "=&s"(exec_save) : "v"(p.queue), "v"(1u) : "memory");
+    }
     const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
     if (item >= nitems) break;
     const int b = item / p.A, a = item - b * p.A;

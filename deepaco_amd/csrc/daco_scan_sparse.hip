@@ -155,10 +155,20 @@ __device__ inline float sp_at_least_denorm(float x) {     // max(x, denorm_min) 
   return y;
 }
 
-template <int CHD, bool RACE, int SPL>
-__global__ void __launch_bounds__(256, CHD == 2 ? (RACE ? 4 : 6) : 5)
+// LH (round 6, "LDS heads"; CHD = 2, scan draw, four slots per lane): the launch for FEW ants -- one instance, a few hundred ants:
+// the reference's own calling pattern (tsp/test.ipynb:66-68 loops the instances, one colony each).  Such a launch has fewer
+// wavefronts than the chip has SIMDs, so a step is a bare latency chain, and a third of it is the L2 round trip of the head row
+// (0.41 us per step, 203 us per launch at TSP-500 x 512 ants x 1 instance, profiles/r06_kernel_stats_b1_before.csv).  Here a
+// workgroup is ONE wavefront of four ants (three more wavefronts help with the copy and the epilogue) and keeps the instance's
+// whole head table in LDS: the rows without their empty lanes (lanes 0 .. kl-1 of 16, kl = ceil((kmax + 1) / 4) for at most kmax
+// live slots per row) with the tail total moved into the first slot no row uses (slot kmax, whose id stays `dead`: its term is
+// T x 0 = 0 as before) -- 500 rows x 312 bytes at k = 50.  The step then reads its head row from LDS; values, order of the
+// additions, uniforms and decisions are those of the kernel above, so the tours are the same bit for bit.
+template <int CHD, bool RACE, int SPL, bool LH = false>
+__global__ void __launch_bounds__(256, LH ? 1 : (CHD == 2 ? (RACE ? 4 : 6) : 5))
 scan_sparse_kernel(const SampleParams p) {
-  constexpr int APW = 4, APB = 16;
+  static_assert(!LH || (CHD == 2 && !RACE && SPL == 4), "the LDS-heads variant: n <= 512, scan draw, 64-slot heads");
+  constexpr int APW = 4, APB = LH ? 4 : 16;
   constexpr int LS = sp_lane_bytes(SPL);                 // bytes per lane of a head row
   constexpr int LAST = SPL - 1;                          // (lane 15: the slot of the tail total)
   constexpr int FL = CHD * 256;                          // tour / inverse-table entries per ant (>= n)
@@ -178,8 +188,11 @@ scan_sparse_kernel(const SampleParams p) {
   uint16_t *tour_mem = reinterpret_cast<uint16_t *>(sparse_dyn + APB * FLP);      // !TG: [APB][FL]; TG: [APB][16], the window
   // tail walk: the head of the row as a bitmap over the nodes, one per wavefront (inside the block at n > 512, so that five
   // workgroups of 32 KB fill a CU's LDS)
-  __shared__ uint32_t bm_static[TG ? 1 : 4][32];
+  __shared__ uint32_t bm_static[TG ? 1 : (LH ? 1 : 4)][32];
   uint32_t (*bm_s)[32] = TG ? reinterpret_cast<uint32_t (*)[32]>(sparse_dyn + APB * FLP + APB * 32) : bm_static;
+  // LH: the head table behind the flags and the tours: [n][kl] lane records of LS bytes, then one empty record
+  unsigned char *lh_tab = sparse_dyn + APB * FLP + APB * FLT * 2;
+  static_assert(!LH || ((APB * FLP + APB * FLT * 2) % 16 == 0), "LH: table aligned");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, s = lane & 15;
   const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -189,7 +202,7 @@ scan_sparse_kernel(const SampleParams p) {
   const int a0 = abase + wave * APW;
   const int n = p.n, A = p.A;
   const uint64_t iter_now = p.iter + (p.iter_dev ? *p.iter_dev : 0ull);
-  const bool active = a0 < A;
+  const bool active = a0 < A && (!LH || wave == 0);
   const int a = a0 + q < A ? a0 + q : A - 1;             // spare groups build ant A-1 again (not written)
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
   const float *taub = p.tau + (size_t)b * p.tau_bs, *etab = p.eta + (size_t)b * p.eta_bs;
@@ -206,6 +219,38 @@ scan_sparse_kernel(const SampleParams p) {
 #define SP_T(t) ((t) & (TG ? 15 : 0xFFFF))
   bool infeasible = false;
   unsigned long long n_dense = 0, n_tail = 0, n_rej = 0;
+  // LH: per-lane constants of the LDS row read (lanes past the live records read the empty record), the tail total's place
+  uint32_t lh_rb = 0, lh_rbsel = 0, lh_loff = 0, lh_toff = 0;
+  if constexpr (LH) {
+    const int kl = p.lh_kl, kmax = p.lh_kmax;
+    lh_rb = (uint32_t)kl * LS;
+    lh_toff = (uint32_t)(kmax / SPL) * LS + (uint32_t)(kmax % SPL) * 4u;
+    lh_rbsel = s < kl ? lh_rb : 0u;
+    lh_loff = s < kl ? (uint32_t)s * LS : (uint32_t)n * lh_rb;
+    // the copy: sixteen threads per row, 8 bytes at a time; then the tail totals (slot 63 of the full row -> slot kmax)
+    const char *src = hrb;
+    const int l16 = threadIdx.x & 15;
+    for (int row = threadIdx.x >> 4; row < n; row += 16)
+      if (l16 < kl) {
+        const uint2 *g = reinterpret_cast<const uint2 *>(src + (size_t)row * ROWB + l16 * LS);
+        uint2 *d = reinterpret_cast<uint2 *>(lh_tab + (uint32_t)row * lh_rb + l16 * LS);
+        const uint2 x0 = g[0], x1 = g[1], x2 = g[2];
+        d[0] = x0; d[1] = x1; d[2] = x2;
+      }
+    if (threadIdx.x < 4) reinterpret_cast<float *>(lh_tab + (uint32_t)n * lh_rb)[threadIdx.x] = 0.0f;
+    if (threadIdx.x >= 4 && threadIdx.x < 6) reinterpret_cast<uint32_t *>(lh_tab + (uint32_t)n * lh_rb)[threadIdx.x] = (uint32_t)p.ld * 0x00010001u;
+    __syncthreads();
+    bool too_many = false;
+    for (int row = threadIdx.x; row < n; row += 256) {
+      const char *gr = src + (size_t)row * ROWB;
+      // (slot kmax must be empty in every row: its id is `dead`; a table with more live slots than the caller said is an error)
+      const uint16_t idk = *reinterpret_cast<const uint16_t *>(gr + (kmax / SPL) * LS + SPL * 4 + (kmax % SPL) * 2);
+      too_many |= idk != (uint16_t)p.ld;
+      *reinterpret_cast<float *>(lh_tab + (uint32_t)row * lh_rb + lh_toff) = *reinterpret_cast<const float *>(gr + 15 * LS + LAST * 4);
+    }
+    if (too_many && p.flags) atomicOr(p.flags + b, 4);
+    __syncthreads();
+  }
 
   if (active) {
     {
@@ -242,12 +287,19 @@ scan_sparse_kernel(const SampleParams p) {
 #pragma unroll 1
       for (; t < te; ++t) {
         // ---- the head of row `prev`: SPL values and SPL ids per lane
-        const uint32_t off = __umul24((uint32_t)prev, ROWB) + sls;
+        const uint32_t off = LH ? __umul24((uint32_t)prev, lh_rbsel) + lh_loff : __umul24((uint32_t)prev, ROWB) + sls;
         // (the id words stay named scalars, never an array: a select between array elements is turned into an indexed load
         // and the array then lives in scratch memory)
         float h[SPL];
         uint32_t w0, w1, w2 = 0, w3 = 0;                    // the ids, two per word
-        if constexpr (SPL == 4) {
+        if constexpr (LH) {
+          const uint2 ra = *reinterpret_cast<const uint2 *>(lh_tab + off), rb_ = *reinterpret_cast<const uint2 *>(lh_tab + off + 8),
+                      rc = *reinterpret_cast<const uint2 *>(lh_tab + off + 16);
+          const float tv = *reinterpret_cast<const float *>(lh_tab + __umul24((uint32_t)prev, lh_rb) + lh_toff);
+          h[0] = __uint_as_float(ra.x); h[1] = __uint_as_float(ra.y); h[2] = __uint_as_float(rb_.x);
+          h[3] = s == 15 ? tv : __uint_as_float(rb_.y);      // (lane 15's last slot: the tail total)
+          w0 = rc.x; w1 = rc.y;
+        } else if constexpr (SPL == 4) {
           const sp_u32x4 hvr = __builtin_amdgcn_raw_buffer_load_b128(hres, off, 0, 0);
           const sp_u32x2 hi2 = __builtin_amdgcn_raw_buffer_load_b64(hres, off + 16u, 0, 0);
           h[0] = __uint_as_float(hvr.x); h[1] = __uint_as_float(hvr.y); h[2] = __uint_as_float(hvr.z); h[3] = __uint_as_float(hvr.w);
@@ -477,7 +529,8 @@ scan_sparse_kernel(const SampleParams p) {
       // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
       __syncthreads();
       const float *dist_b = p.dist + (size_t)b * p.dist_bs;
-      float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(flag_mem);
+      // (LH: the flag array is four ants' worth; the head table is dead by now and holds the staging rows and the inverse table)
+      float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(LH ? lh_tab : flag_mem);
       if (active) {
         float cost = 0.0f;
         const float *mine_d = dstage[wave][q];
@@ -507,8 +560,8 @@ scan_sparse_kernel(const SampleParams p) {
     }
     if (p.nbr) {
       // the update's table through an inverse-permutation table in the (dead) flag array, eight ants at a time
-      uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(flag_mem);
-      static_assert(APB * FLP >= 8 * FL * (int)sizeof(uint16_t), "inverse table of eight ants inside the flag array");
+      uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(LH ? lh_tab + 4096 : flag_mem);
+      static_assert(LH || APB * FLP >= 8 * FL * (int)sizeof(uint16_t), "inverse table of eight ants inside the flag array");
       const int k8 = threadIdx.x & 7;
       for (int half = 0; half < 2; ++half) {
         const int nh = nant - half * 8 < 8 ? nant - half * 8 : 8;
@@ -617,7 +670,7 @@ static bool sparse_rows_vec4(int n, const float *tau, long tau_bstride, const fl
   return (n & 3) == 0 && (tau_bstride & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
 }
 
-static int sample_sparse_impl(bool race, bool heads_ready, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                       long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                       int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
@@ -658,14 +711,33 @@ static int sample_sparse_impl(bool race, bool heads_ready, const char *what, voi
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("%s pre-pass: %s", what, hipGetErrorString(e)); return DACO_E_HIP; }
   if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, s) != hipSuccess) { set_error("hipEventRecord(ev_begin) failed"); return DACO_E_HIP; }
-  const int bpi = (A + 15) / 16;
+  // few ants (no more workgroups of four than the chip has CUs) and a head table that fits a CU's LDS: the LDS-heads variant
+  static const int lh_knob = getenv("DACO_SPARSE_LDS_HEADS") ? atoi(getenv("DACO_SPARSE_LDS_HEADS")) : 1;   // (0: never; measurement knob)
+  bool lh = false;
+  size_t lh_lds = 0;
+  if (lh_knob && !race && spl == 4 && ld == 512 && head_live_max > 0 && head_live_max <= 62 && (long)B * ((A + 3) / 4) <= 256) {
+    const int kl = (head_live_max + 1 + 3) / 4;
+    const size_t table = (size_t)n * kl * sp_lane_bytes(4) + 32;
+    lh_lds = (size_t)4 * (512 + 16) + (size_t)4 * (512 + 2) * 2 + (table > 12288 + 1024 ? table : 12288 + 1024);
+    lh = lh_lds + 128 <= 160 * 1024;                     // (+ the kernel's static words)
+    sp.lh_kl = kl; sp.lh_kmax = head_live_max;
+  }
+  const int bpi = lh ? (A + 3) / 4 : (A + 15) / 16;
   const dim3 grid((unsigned)(B * bpi));
   // dynamic LDS: flags + tours (n <= 512); the larger of flags + window and eight tours + their inverse table (n > 512)
   const int pad_lds = getenv("DACO_SPARSE_PAD_LDS") ? atoi(getenv("DACO_SPARSE_PAD_LDS")) : 0;   // (measurement knob: fewer workgroups per CU)
 #define DACO_SPARSE_LDS(C) ((C) == 2 ? 16 * ((C) * 256 + 16) + 16 * ((C) * 256 + 2) * 2 : 2 * 8 * (C) * 256 * 2)
 #define DACO_SPARSE_LAUNCH(C, R, S) hipLaunchKernelGGL((scan_sparse_kernel<C, R, S>), grid, dim3(256), DACO_SPARSE_LDS(C) + pad_lds, s, sp)
 #define DACO_SPARSE_PICK(C, R) do { if (spl == 4) DACO_SPARSE_LAUNCH(C, R, 4); else DACO_SPARSE_LAUNCH(C, R, 8); } while (0)
-  if (ld <= 512) { if (race) DACO_SPARSE_PICK(2, true); else DACO_SPARSE_PICK(2, false); }
+  if (lh) {
+    static bool attr_set = false;                        // (more than 64 KB of dynamic LDS has to be asked for once)
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_sparse_kernel<2, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 128) != hipSuccess) { set_error("%s: hipFuncSetAttribute(dynamic LDS) failed", what); return DACO_E_HIP; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((scan_sparse_kernel<2, false, 4, true>), grid, dim3(256), lh_lds, s, sp);
+  } else if (ld <= 512) { if (race) DACO_SPARSE_PICK(2, true); else DACO_SPARSE_PICK(2, false); }
   else { if (race) DACO_SPARSE_PICK(4, true); else DACO_SPARSE_PICK(4, false); }
 #undef DACO_SPARSE_PICK
 #undef DACO_SPARSE_LDS
@@ -685,7 +757,7 @@ extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const f
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                       long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                       size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(false, false, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(false, false, 0, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
 }
 extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                          long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
@@ -693,13 +765,13 @@ extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, cons
                                          uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                          long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                          size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(true, false, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(true, false, 0, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
 }
-extern "C" int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+extern "C" int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int head_live_max, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                      int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                      uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                      long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                      size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(race != 0, heads_ready != 0, "daco_tsp_sample_heads", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(race != 0, heads_ready != 0, head_live_max, "daco_tsp_sample_heads", DACO_SPARSE_ARGS);
 }

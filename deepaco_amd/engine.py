@@ -233,7 +233,7 @@ def sparse_workspace(device, B, n, n_ants):
 
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
-                      want_paths=True, race=False, workspace=None, heads_ready=False):
+                      want_paths=True, race=False, workspace=None, heads_ready=False, head_live_max=0):
     """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
     distribution of tsp_sample(mode="scan"), 384 / 768 bytes per step instead of a row while the head has a live candidate.
     head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats]).
@@ -241,7 +241,9 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
     race kernel (same seed), one variate per head slot and step instead of n.
     workspace: a sparse_workspace() tensor the caller keeps (default: the per-stream scratch); heads_ready=True: it already holds
     this iteration's head rows (pheromone_update_(heads=...) wrote them for these very tensors) and the pass over tau is skipped
-    (include/deepaco_hip.h daco_tsp_sample_heads) -- the same tours."""
+    (include/deepaco_hip.h daco_tsp_sample_heads) -- the same tours.
+    head_live_max: the k the head table was built with (sparse_head(.., k)), or 0: lets a launch of few ants (one instance, a few
+    hundred ants) keep the head rows in LDS -- the same tours, about half the time at TSP-500 x 512 ants x 1 instance."""
     _require_gpu(tau, eta, start, head, workspace)
     assert not heads_ready or workspace is not None
     n = tau.shape[-1]
@@ -270,7 +272,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
             raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
         ws = workspace if workspace is not None else _workspace(dev, nbytes, "sample_sparse")
         assert ws.numel() >= nbytes
-        rc = L.daco_tsp_sample_heads(_stream(dev), int(bool(race)), int(bool(heads_ready)), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+        rc = L.daco_tsp_sample_heads(_stream(dev), int(bool(race)), int(bool(heads_ready)), int(head_live_max), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
                                       float(beta), head.data_ptr(), int(head.shape[2]), start.data_ptr() if start is not None else None,
                                       int(fixed_start), int(seed) & (2 ** 64 - 1), int(it),
                                       iter_dev.data_ptr() if iter_dev is not None else None, int(ant_gid0) & 0xFFFFFFFF,
@@ -1038,7 +1040,7 @@ class BatchedTSP:
                                                      self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
                                                      dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head,
-                                                     workspace=self._sparse_ws, heads_ready=ready)
+                                                     workspace=self._sparse_ws, heads_ready=ready, head_live_max=self._head[2])
             if self.fuse_head_rows:
                 heads = {"eta": self.heuristic, "alpha": self.alpha, "beta": self.beta, "head": head, "race": race_head,
                          "workspace": self._sparse_ws}

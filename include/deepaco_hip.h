@@ -173,8 +173,14 @@ int daco_tsp_sample_race_head(void *stream, int B, int n, int A,
  *   heads_ready  0: the head rows are formed first (one pass over tau and eta, as the two calls above do);
  *                1: `workspace` already holds this iteration's head rows -- daco_pheromone_update_heads wrote them when it
  *                   finished the rows of tau, for the same tau / eta / alpha / beta / head_id / head_slots / race -- and no
- *                   pass over tau runs.  The caller vouches that tau has not changed since.  Same tours either way. */
-int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int B, int n, int A,
+ *                   pass over tau runs.  The caller vouches that tau has not changed since.  Same tours either way.
+ *   head_live_max   0, or an upper bound of the live counts in head_id (the k of the colony's head table, <= 62): a launch of
+ *                FEW ants (B * ceil(A / 4) <= 256 -- one instance with a few hundred ants, the reference's own call pattern,
+ *                tsp/test.ipynb:66-68) then keeps the instance's head rows in LDS when they fit (n <= 512, 64-slot heads,
+ *                n * ceil((k + 1) / 4) * 24 bytes <= ~150 KB: TSP-500 with k = 50 does), one wavefront of four ants per
+ *                workgroup: the same tours, the per-step L2 round trip gone.  A row with more live slots than the bound sets
+ *                bit 2 of flags[b]. */
+int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int head_live_max, int B, int n, int A,
                           const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                           float alpha, float beta, const uint16_t *head_id, int head_slots,
                           const int64_t *start, int fixed_start,

@@ -384,3 +384,52 @@ def test_head_rows_from_the_pheromone_update_equal_the_pre_pass(n, A, B, k, kw):
     cols[0].pheromone = cols[0].pheromone.clone()                      # another tensor object: likewise
     (pa, _), (pb, _) = cols[0].step(), cols[1].step()
     assert torch.equal(pa, pb) and torch.equal(cols[0].pheromone.view(torch.int32), cols[1].pheromone.view(torch.int32))
+
+
+@pytest.mark.parametrize("n,A,B,kind,fixed", [(500, 512, 1, "ksparse", -1), (200, 40, 2, "ksparse", -1), (333, 21, 1, "ksparse", 0),
+                                            (160, 24, 1, "random_head", 0), (512, 16, 1, "random_head", -1), (300, 21, 1, "tiny_head", 3),
+                                            (129, 33, 1, "tiny_head", -1), (400, 100, 2, "random_head", 5)])
+def test_few_ants_keep_the_head_rows_in_lds_same_tours(n, A, B, kind, fixed):
+    """Round 6: a launch of few ants -- the reference's own call pattern, one instance per colony
+    (tsp/test.ipynb:66-68) -- takes the LDS-heads variant of scan_sparse_kernel when the caller names the head's live bound
+    (head_live_max): one wavefront of four ants per workgroup, the instance's head rows compressed into LDS.  Tours, step
+    counters, fused costs and the update's table must be the oracle's AND those of the launch without the bound (the kernel
+    that reads its head rows through L2), bit for bit."""
+    from deepaco_amd import engine
+    d, tau, eta, heads = instance(n, 300 + n, kind, B)
+    live = int(max(int(h[1].max()) for h in heads))
+    assert live <= 62
+    T, E, D, H = tau.to(dev()), eta.to(dev()), d.to(dev()), pack(heads)
+    paths, flags, costs, nbr, stats = engine.tsp_sample_sparse(T, E, A, H, seed=91, it=2, fixed_start=fixed, dist=D, want_nbr=True,
+                                                               want_stats=True, head_live_max=live)
+    assert int(flags.sum()) == 0
+    p0, f0, c0, n0, s0 = engine.tsp_sample_sparse(T, E, A, H, seed=91, it=2, fixed_start=fixed, dist=D, want_nbr=True, want_stats=True)
+    assert torch.equal(paths, p0) and torch.equal(costs.view(torch.int32), c0.view(torch.int32)) and torch.equal(nbr, n0) and torch.equal(stats, s0)
+    ref_stats = np.zeros(3, dtype=np.int64)
+    for b in range(B):
+        P = oracle.prob_matrix(tau[b].numpy(), eta[b].numpy())
+        ref, rc, st = oracle.tsp_sample_scan_sparse(P, heads[b][0], heads[b][1], A, seed=91, it=2, ant_gid0=b * A, fixed_start=fixed)
+        assert rc == 0 and np.array_equal(paths[b].cpu().numpy(), ref), (n, kind, b)
+        ref_stats += st
+        assert np.array_equal(costs[b].cpu().numpy().view(np.int32), np.asarray(oracle.tour_costs(d[b].numpy(), ref), dtype=np.float32).view(np.int32))
+    assert np.array_equal(stats.cpu().numpy(), ref_stats)
+    # a bound below the table's live counts is reported (bit 2 of the flags), not silently wrong
+    if live > 4:
+        _, fl_bad, _, _ = engine.tsp_sample_sparse(T, E, A, H, seed=91, it=2, fixed_start=fixed, head_live_max=live - 1)
+        assert int(fl_bad[0]) & 4
+
+
+def test_single_instance_colony_takes_the_lds_heads_and_matches_the_batched_one():
+    """BatchedTSP at B = 1 (what ACO(...).run does per instance) passes the head bound: the colony's iterations equal instance 0 of
+    a B = 3 colony of the same seed (which is too large for the variant) -- tours, costs and pheromone, three iterations."""
+    from deepaco_amd import engine
+    n, A, k = 500, 512, 50
+    d = instance(n, 77, "ksparse", 3)[0].to(dev())
+    one = engine.BatchedTSP(d[:1].contiguous(), n_ants=A, seed=6)
+    many = engine.BatchedTSP(d, n_ants=A, seed=6)
+    one.sparsify(k)
+    many.sparsify(k)
+    for _ in range(3):
+        (p1, c1), (p3, c3) = one.step(), many.step()
+        assert torch.equal(p1[0], p3[0]) and torch.equal(c1[0], c3[0])
+    assert torch.equal(one.pheromone[0], many.pheromone[0])
