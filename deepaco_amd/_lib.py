@@ -26,6 +26,7 @@ SIGNATURES = {
     "daco_tsp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _i, _i, _vp, _i, _vp, _u64, _u64, _vp,
                              _u32, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sparse_workspace_bytes": (_sz, [_i, _i, _i]),
+    "daco_tsp_sparse_workspace_bytes_general": (_sz, [_i, _i, _i]),
     "daco_tsp_sample_sparse": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                     _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,

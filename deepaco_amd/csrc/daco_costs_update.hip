@@ -293,8 +293,8 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
       const float *tr = rows + rr * n, *er = eb + (size_t)(i0 + rr) * n;
       const uint16_t *ids = he.hid + row * (16 * he.spl);
       char *hl = he.hrow + row * sp_head_row_bytes(he.spl);
-      if (vec4) emit_head_row<HEADS == 2, true>(n, ch, tr, er, he.alpha, he.beta, ids, head_bm[wave], hl, he.spl, he.dead, lane);
-      else emit_head_row<HEADS == 2, false>(n, ch, tr, er, he.alpha, he.beta, ids, head_bm[wave], hl, he.spl, he.dead, lane);
+      if (vec4) emit_head_row<HEADS == 2, true>(n, ch, tr, er, ids, head_bm[wave], hl, he.spl, he.dead, lane);
+      else emit_head_row<HEADS == 2, false>(n, ch, tr, er, ids, head_bm[wave], hl, he.spl, he.dead, lane);
     }
   }
 }
@@ -551,10 +551,11 @@ extern "C" int daco_pheromone_update_heads(void *stream, int B, int n, int A, fl
   if (!eta || !head_id || !sparse_workspace) { set_error("daco_pheromone_update_heads: bad argument"); return DACO_E_BADARG; }
   if (head_slots != 64 && head_slots != 128) { set_error("daco_pheromone_update_heads: head_slots = %d (64 or 128)", head_slots); return DACO_E_BADARG; }
   if (n <= 128 || n > 1024) { set_error("daco_pheromone_update_heads: n=%d outside 129..1024 (the sizes daco_tsp_sample_heads serves)", n); return DACO_E_TOOLARGE; }
+  if (alpha != 1.0f || beta != 1.0f) { set_error("daco_pheromone_update_heads: alpha = beta = 1 only (the rows of tau are formed here; other exponents take the sampler's own pass)"); return DACO_E_BADARG; }
   const size_t need = daco_tsp_sparse_workspace_bytes(B, n, A);
   if (sparse_workspace_bytes < need) { set_error("daco_pheromone_update_heads: sparse workspace %zu < %zu bytes", sparse_workspace_bytes, need); return DACO_E_WORKSPACE; }
   HeadEmit he;
-  he.eta = eta; he.eta_bs = eta_bstride; he.alpha = alpha; he.beta = beta; he.hid = head_id; he.hrow = (char *)sparse_workspace;
+  he.eta = eta; he.eta_bs = eta_bstride; he.hid = head_id; he.hrow = (char *)sparse_workspace;
   he.spl = head_slots / 16; he.race = race ? 1 : 0;
   const int ld = n <= 512 ? 512 : 1024;
   he.dead = ld;

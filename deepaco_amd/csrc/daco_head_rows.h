@@ -1,7 +1,7 @@
 // daco_head_rows.h -- the HEAD ROW of one transition row (sampler "scan_sparse" / the race on head rows), formed by one
 // wavefront from the row of tau (global memory, or the copy the pheromone update holds in LDS) and the row of eta.
 //
-// Reference behaviour: the row is tau[i]^alpha * eta[i]^beta of tsp/aco.py:165-172 (tsp_nls/aco.py:195 forms it once per
+// Reference behaviour: the row is tau[i]^alpha * eta[i]^beta of tsp/aco.py:165-172, alpha = beta = 1 here (tsp_nls/aco.py:195 forms it once per
 // iteration); the head / tail split is this library's (restated in the CPU checker as orc_sparse_head_values).  Two callers
 // share this code so that their head rows agree bit for bit: sparse_prepass_kernel (daco_scan_sparse.hip: the first iteration,
 // and every caller that updates tau some other way) and deposit_rows_kernel (daco_costs_update.hip: the update that just wrote
@@ -17,21 +17,25 @@ constexpr int SP_KH_MAX = 128;
 __host__ __device__ constexpr int sp_lane_bytes(int spl) { return spl * 6; }
 __host__ __device__ constexpr size_t sp_head_row_bytes(int spl) { return (size_t)16 * sp_lane_bytes(spl); }
 
-// element k0..k0+3 of the row tau^alpha * eta^beta (0 past n): the arithmetic of prob_matrix_kernel, no fused multiply-add
+// element k0..k0+3 of the row tau * eta (0 past n), no fused multiply-add.  The head-row kernels take alpha = beta = 1 -- every
+// script of the reference (tsp/aco.py:10-11) -- and nothing else: other exponents are applied to the two matrices BEFORE these
+// kernels run (pow_pair_kernel, daco_scan_sparse.hip: tau^alpha and eta^beta into the workspace), the products are the same.
+// (Round 6 first formed tau^alpha * eta^beta here with pw(): sixteen powf bodies per vector kept the inliner from inlining this
+// function at all, and the rare ways of scan_sparse_kernel and every row of emit_head_row made real calls -- +65 us on the
+// headline launch, and the update's head rows cost 64 us instead of ~10; profiles/r06_fused_head_rows.txt.)
 template <bool VEC4>
-__device__ inline float4 sp_prob4(const float *tr, const float *er, int n, int k0, float alpha, float beta) {
+__device__ __forceinline__ float4 sp_prob4(const float *tr, const float *er, int n, int k0) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (VEC4) {
     if (k0 < n) {                                             // (n % 4 == 0: a vector is inside the row or past it)
       const float4 t = *reinterpret_cast<const float4 *>(tr + k0), e = *reinterpret_cast<const float4 *>(er + k0);
-      v.x = pw(t.x, alpha) * pw(e.x, beta); v.y = pw(t.y, alpha) * pw(e.y, beta);
-      v.z = pw(t.z, alpha) * pw(e.z, beta); v.w = pw(t.w, alpha) * pw(e.w, beta);
+      v.x = t.x * e.x; v.y = t.y * e.y; v.z = t.z * e.z; v.w = t.w * e.w;
     }
   } else {
-    if (k0 + 0 < n) v.x = pw(tr[k0 + 0], alpha) * pw(er[k0 + 0], beta);
-    if (k0 + 1 < n) v.y = pw(tr[k0 + 1], alpha) * pw(er[k0 + 1], beta);
-    if (k0 + 2 < n) v.z = pw(tr[k0 + 2], alpha) * pw(er[k0 + 2], beta);
-    if (k0 + 3 < n) v.w = pw(tr[k0 + 3], alpha) * pw(er[k0 + 3], beta);
+    if (k0 + 0 < n) v.x = tr[k0 + 0] * er[k0 + 0];
+    if (k0 + 1 < n) v.y = tr[k0 + 1] * er[k0 + 1];
+    if (k0 + 2 < n) v.z = tr[k0 + 2] * er[k0 + 2];
+    if (k0 + 3 < n) v.w = tr[k0 + 3] * er[k0 + 3];
   }
   return v;
 }
@@ -45,8 +49,8 @@ __device__ inline float4 sp_prob4(const float *tr, const float *er, int n, int k
 // RACE (the exponential race on head rows): value = 1 / P[id_m] (+inf for the other slots), last slot = the smallest 1 / P of
 // the tail, i.e. the reciprocal of its largest entry.
 template <bool RACE, bool VEC4>
-__device__ inline void emit_head_row(int n, int ch, const float *tr, const float *er, float alpha, float beta,
-                                     const uint16_t *ids, uint32_t *bm, char *hl, int spl, int dead, int lane) {
+__device__ __forceinline__ void emit_head_row(int n, int ch, const float *tr, const float *er,
+                                              const uint16_t *ids, uint32_t *bm, char *hl, int spl, int dead, int lane) {
   const int kh = 16 * spl, ls = sp_lane_bytes(spl);
   // a malformed table (count beyond the slots, ids beyond the row) must not reach past the bitmap or the row:
   // the count is clamped, an id >= n is an empty slot.  (engine.sparse_head never produces either.)
@@ -58,7 +62,7 @@ __device__ inline void emit_head_row(int n, int ch, const float *tr, const float
   float part = RACE ? __builtin_inff() : 0.0f;
   for (int c = 0; c < ch; ++c) {
     const int k0 = (c * 64 + lane) * 4;
-    const float4 v = sp_prob4<VEC4>(tr, er, n, k0, alpha, beta);
+    const float4 v = sp_prob4<VEC4>(tr, er, n, k0);
     const uint32_t w = bm[(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
     if constexpr (RACE) {
       part = fminf(part, (w & 1u) ? __builtin_inff() : 1.0f / v.x);
@@ -82,7 +86,7 @@ __device__ inline void emit_head_row(int n, int ch, const float *tr, const float
   for (int m = lane; m < kh; m += 64) {                         // slot m: lane m / spl of the row, element m % spl
     const int id = ids[m];
     const bool live = m < cnt && id < n;
-    const float pid = live ? pw(tr[id], alpha) * pw(er[id], beta) : 0.0f;
+    const float pid = live ? tr[id] * er[id] : 0.0f;
     float val;
     if constexpr (RACE) val = m == kh - 1 ? T : (live ? 1.0f / pid : __builtin_inff());
     else val = m == kh - 1 ? T : (live ? pid : 0.0f);
@@ -97,7 +101,6 @@ __device__ inline void emit_head_row(int n, int ch, const float *tr, const float
 struct HeadEmit {
   const float *eta = nullptr;      // [B][n][n] or one shared [n][n] (eta_bs = 0)
   long eta_bs = 0;
-  float alpha = 1.0f, beta = 1.0f;
   const uint16_t *hid = nullptr;   // [B][n][16 spl]
   char *hrow = nullptr;            // [B][n][16 sp_lane_bytes(spl)]
   int spl = 4, ch = 2, dead = 512, race = 0;

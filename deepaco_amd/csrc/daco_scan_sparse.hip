@@ -46,11 +46,11 @@ __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x800080
 // 16 lanes x ls bytes, lane s = {values of slots 4s..4s+3 (f32), their node ids (u16)}; the last slot = the tail total), from one
 // read of the rows of tau and eta.  Round 6: the dense fused row P = tau^alpha * eta^beta is no longer written (65 MB per
 // iteration at the headline shape for the 1.4 % of the steps that walked it): the rare ways form tau * eta from the two rows
-// themselves (sp_prob4: the same two roundings), and an iteration whose pheromone update emitted the head rows
+// themselves (sp_prob4: the same product), and an iteration whose pheromone update emitted the head rows
 // (daco_pheromone_update_heads) does not run this kernel at all.
 template <bool RACE, bool VEC4>
 __global__ void __launch_bounds__(256)
-sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const float *eta, long eta_bs, float alpha, float beta,
+sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const float *eta, long eta_bs,
                       const uint16_t *hid, char *hrow, int spl, int dead) {
   __shared__ uint32_t bm[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -58,7 +58,7 @@ sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const
   if (row >= (long)B * n) return;
   const int b = (int)(row / n), r = (int)(row - (long)b * n);
   const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
-  emit_head_row<RACE, VEC4>(n, ch, tr, er, alpha, beta, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), spl, dead, lane);
+  emit_head_row<RACE, VEC4>(n, ch, tr, er, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), spl, dead, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -67,13 +67,13 @@ sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const
 // non-head entries, visited or not, with the threshold `ur` given (oracle draw_scan_sparse, "past the head").
 // Returns the node, -1 if no candidate can be drawn (dense: infeasible; tail: a tail without mass).
 // (the row itself: tau^alpha * eta^beta formed from the rows of tau and eta -- sp_prob4, what the dense P held until round 5)
-struct SpRowSrc { const float *t, *e; float alpha, beta; int n; bool vec; };
-__device__ inline float4 sp_row4(const SpRowSrc &r, int k0) {
-  return r.vec ? sp_prob4<true>(r.t, r.e, r.n, k0, r.alpha, r.beta) : sp_prob4<false>(r.t, r.e, r.n, k0, r.alpha, r.beta);
+struct SpRowSrc { const float *t, *e; int n; bool vec; };
+__device__ __forceinline__ float4 sp_row4(const SpRowSrc &r, int k0) {
+  return r.vec ? sp_prob4<true>(r.t, r.e, r.n, k0) : sp_prob4<false>(r.t, r.e, r.n, k0);
 }
 
 template <int CHD, bool TAIL>
-__device__ inline int sparse_row_walk(const SpRowSrc &rowp, const uint8_t *flg, const uint32_t *bm, int lane, float ur) {
+__device__ __forceinline__ int sparse_row_walk(const SpRowSrc &rowp, const uint8_t *flg, const uint32_t *bm, int lane, float ur) {
   constexpr int NJ = CHD * 4;
   float run[16];
   float acc = 0.0f;
@@ -208,7 +208,7 @@ scan_sparse_kernel(const SampleParams p) {
   const float *taub = p.tau + (size_t)b * p.tau_bs, *etab = p.eta + (size_t)b * p.eta_bs;
   const char *hrb = (const char *)p.hval + (size_t)b * n * ROWB;
   const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void *)hrb, 0, (int)((uint32_t)n * ROWB), 0x00020000);
-#define SP_ROW_OF(pv) SpRowSrc{taub + (size_t)(pv) * n, etab + (size_t)(pv) * n, p.alpha, p.beta, n, p.row_vec != 0}
+#define SP_ROW_OF(pv) SpRowSrc{taub + (size_t)(pv) * n, etab + (size_t)(pv) * n, n, p.row_vec != 0}
   uint32_t sls = (uint32_t)s * LS;
   asm volatile("" : "+v"(sls));                          // (kept in a register: the loop adds it to the row offset)
   uint8_t *fl = flag_mem + (wave * APW + q) * FLP;
@@ -659,11 +659,26 @@ scan_sparse_kernel(const SampleParams p) {
 
 using namespace daco;
 
+// tau^alpha and eta^beta for exponents other than 1 (x^2 = x x and x^0 = 1 exactly, as torch computes them; powf otherwise):
+// the head-row kernels then run on these two matrices with unit exponents -- the same products tau^alpha * eta^beta
+__global__ void __launch_bounds__(256)
+pow_pair_kernel(long count_t, const float *tau, float alpha, float *tau_out, long count_e, const float *eta, float beta, float *eta_out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count_t) tau_out[i] = pw(tau[i], alpha);
+  if (i < count_e) eta_out[i] = pw(eta[i], beta);
+}
+
 // workspace: the head rows (at offset 0: daco_pheromone_update_heads writes them there too), then (n > 512) the u16 tours as they are built
 extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A) {
   if (B <= 0 || A <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
   return align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)) + (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
+}
+
+// ... and, for exponents other than 1, tau^alpha [B][n][n] and eta^beta [B or 1][n][n] behind it
+extern "C" size_t daco_tsp_sparse_workspace_bytes_general(int B, int n, int A) {
+  const size_t base = daco_tsp_sparse_workspace_bytes(B, n, A);
+  return base ? base + 2 * align256((size_t)B * n * n * sizeof(float)) : 0;
 }
 
 static bool sparse_rows_vec4(int n, const float *tau, long tau_bstride, const float *eta, long eta_bstride) {
@@ -691,11 +706,30 @@ static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, co
   const int ld = n <= 512 ? 512 : 1024;
   char *hrow = (char *)workspace;
   const int spl = head_slots / 16;
+  if (alpha != 1.0f || beta != 1.0f) {
+    // the kernels take unit exponents: the powers are applied to the matrices first, into the tail of a `general` workspace
+    const size_t need_g = daco_tsp_sparse_workspace_bytes_general(B, n, A);
+    if (workspace_bytes < need_g) {
+      set_error("%s: alpha = %g, beta = %g need daco_tsp_sparse_workspace_bytes_general() = %zu bytes of workspace (got %zu)", what, alpha, beta, need_g, workspace_bytes);
+      return DACO_E_WORKSPACE;
+    }
+    if (heads_ready) { set_error("%s: heads_ready needs alpha = beta = 1 (daco_pheromone_update_heads forms the rows of tau itself)", what); return DACO_E_BADARG; }
+    float *tp = (float *)((char *)workspace + need), *ep = tp + align256((size_t)B * n * n * sizeof(float)) / sizeof(float);
+    if ((tau_bstride != 0 && tau_bstride != (long)n * n) || (eta_bstride != 0 && eta_bstride != (long)n * n)) {
+      set_error("%s: exponents other than 1 need dense matrices (stride n * n between instances, or 0 for a shared one)", what);
+      return DACO_E_BADARG;
+    }
+    const long ct = (tau_bstride ? (long)B : 1L) * n * n, ce = (eta_bstride ? (long)B : 1L) * n * n;
+    const long cm = ct > ce ? ct : ce;
+    hipLaunchKernelGGL(pow_pair_kernel, dim3((unsigned)((cm + 255) / 256)), dim3(256), 0, s, ct, tau, alpha, tp, ce, eta, beta, ep);
+    tau = tp; eta = ep;
+    alpha = beta = 1.0f;
+  }
   const bool vec4 = sparse_rows_vec4(n, tau, tau_bstride, eta, eta_bstride);
   if (!heads_ready) {
     const dim3 pg((unsigned)(((long)B * n + 3) / 4));
 #define DACO_PREPASS(R, V) hipLaunchKernelGGL((sparse_prepass_kernel<R, V>), pg, dim3(256), 0, s, B, n, ld / 256, tau, tau_bstride, eta, eta_bstride, \
-                                              alpha, beta, head_id, hrow, spl, ld)
+                                              head_id, hrow, spl, ld)
     if (race) { if (vec4) DACO_PREPASS(true, true); else DACO_PREPASS(true, false); }
     else { if (vec4) DACO_PREPASS(false, true); else DACO_PREPASS(false, false); }
 #undef DACO_PREPASS

@@ -221,11 +221,12 @@ def take_auto_top(cache, heuristic):
     return hit[1] if hit is not None and hit[0] is heuristic else None
 
 
-def sparse_workspace(device, B, n, n_ants):
+def sparse_workspace(device, B, n, n_ants, unit_exponents=True):
     """A scratch tensor of the head-row samplers that a colony KEEPS (daco_tsp_sparse_workspace_bytes: the iteration's head rows
     and, for n > 512, the tours as they are built): pheromone_update_(heads=...) writes the next iteration's head rows into it and
     tsp_sample_sparse(heads_ready=True) reads them, so it must not be the per-stream scratch other colonies share."""
-    nbytes = _lib.lib().daco_tsp_sparse_workspace_bytes(B, n, n_ants)
+    L = _lib.lib()
+    nbytes = (L.daco_tsp_sparse_workspace_bytes if unit_exponents else L.daco_tsp_sparse_workspace_bytes_general)(B, n, n_ants)
     if nbytes == 0:
         raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -267,7 +268,8 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
         if want_nbr:
             nbr = torch.empty((B, n, n_ants), dtype=torch.int32, device=dev)
         stats = torch.zeros(3, dtype=torch.int64, device=dev) if want_stats else None
-        nbytes = L.daco_tsp_sparse_workspace_bytes(B, n, n_ants)
+        unit = float(alpha) == 1.0 and float(beta) == 1.0       # (other exponents: tau^alpha, eta^beta are formed in the workspace first)
+        nbytes = (L.daco_tsp_sparse_workspace_bytes if unit else L.daco_tsp_sparse_workspace_bytes_general)(B, n, n_ants)
         if nbytes == 0:
             raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
         ws = workspace if workspace is not None else _workspace(dev, nbytes, "sample_sparse")
@@ -1031,8 +1033,9 @@ class BatchedTSP:
         heads = None
         if sampler == "scan_sparse" or race_head:
             head = self._head_table(hk)
+            unit = float(self.alpha) == 1.0 and float(self.beta) == 1.0
             if self._sparse_ws is None:
-                self._sparse_ws = sparse_workspace(self.distances.device, self.B, self.n, self.n_ants)
+                self._sparse_ws = sparse_workspace(self.distances.device, self.B, self.n, self.n_ants, unit_exponents=unit)
             st = self._heads_state(head, race_head)
             ready = self._heads_for is not None and len(st) == len(self._heads_for) and all(
                 (a is b) if torch.is_tensor(a) else (a == b) for a, b in zip(st, self._heads_for))
@@ -1041,7 +1044,7 @@ class BatchedTSP:
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
                                                      dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head,
                                                      workspace=self._sparse_ws, heads_ready=ready, head_live_max=self._head[2])
-            if self.fuse_head_rows:
+            if self.fuse_head_rows and unit:                 # (the update forms the rows of tau itself: unit exponents only)
                 heads = {"eta": self.heuristic, "alpha": self.alpha, "beta": self.beta, "head": head, "race": race_head,
                          "workspace": self._sparse_ws}
         else:

@@ -138,8 +138,12 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  *              {4 or 8 f32 values, as many u16 ids} per row of tau, at offset 0) and, for n > 512, the tours as they are built.
  *              The steps that leave the head walk tau^alpha * eta^beta formed from the rows of `tau` and `eta` themselves
  *              (until version 124 a dense copy of that matrix lived here: 65 MB written per call at TSP-500 x 64).
+ *              alpha, beta other than 1: the kernels themselves take unit exponents; tau^alpha and eta^beta are formed first (one
+ *              elementwise launch; x^2 = x x and x^0 = 1 exactly) into a workspace of daco_tsp_sparse_workspace_bytes_general(B, n, A)
+ *              bytes (= the above + two [B][n][n] f32 matrices), which such a call needs (DACO_E_WORKSPACE otherwise).
  */
 size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A);
+size_t daco_tsp_sparse_workspace_bytes_general(int B, int n, int A);
 int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
                            const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                            float alpha, float beta, const uint16_t *head_id, int head_slots,
@@ -384,7 +388,8 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
  * (tsp/aco.py:95-118 followed by the next iteration's tsp/aco.py:165-172): the workgroup that has just finished rows of tau
  * (evaporation, deposits in ant order, clamp, floor -- bit for bit the update above) also forms their head rows for
  * daco_tsp_sample_heads(heads_ready = 1) from the copy it still holds on chip, so tau is read once per iteration instead of twice.
- *   eta, eta_bstride, alpha, beta, head_id, head_slots, race   as the sampler will be called
+ *   eta, eta_bstride, alpha, beta, head_id, head_slots, race   as the sampler will be called; alpha = beta = 1 only (other
+ *                exponents take the sampler's own pass: DACO_E_BADARG here)
  *   sparse_workspace   the sampler's workspace (daco_tsp_sparse_workspace_bytes(B, n, A)); its head rows are (re)written
  *   129 <= n <= 1024; the other arguments as daco_pheromone_update (len = n, hub unused) */
 int daco_pheromone_update_heads(void *stream, int B, int n, int A, float *tau,

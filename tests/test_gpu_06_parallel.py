@@ -334,6 +334,7 @@ def test_c_abi_allreduce_of_delta_tau_on_a_one_rank_rccl_communicator():
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     torch.cuda.set_device(0)
+    dev = lambda: torch.device("cuda:0")
     assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
     try:
         n, A, B = 60, 16, 2
