@@ -31,10 +31,10 @@ SIGNATURES = {
                                     _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                        _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "daco_tsp_sample_heads": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
+    "daco_tsp_sample_heads": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                    _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_pheromone_update_heads": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _i, _vp, _vp, _f, _vp, _vp, _vp, _sz,
-                                         _vp, _l, _f, _f, _vp, _i, _i, _vp, _sz]),
+                                         _vp, _l, _f, _f, _vp, _i, _i, _i, _vp, _sz]),
     "daco_allreduce_delta_tau": (_i, [_vp, _vp, _vp, _sz]),
     "daco_tour_costs": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _i, _vp]),
     "daco_pheromone_update_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -168,6 +168,37 @@ track_best_kernel(int len, int A, const float *costs, const int64_t *paths, floa
 // meet the next side of ant a) and bought 82 -> 74 us without them: the chain is not what the launch waits for.)
 constexpr int DEP_CHUNK = 64;
 
+// The head rows of a workgroup's finished rows (HEADS): wavefront w takes the rows w, w + 4, ...  What a row needs from global
+// memory -- its row of eta, eta at the head's ids, the ids -- is fetched for up to PF rows at once, so the wavefront waits for
+// memory once and then forms the rows out of LDS and registers (one row at a time the fetches were four round trips in a row on
+// a kernel that is a chain of latencies already: 64 us on top of the update's 80 at the headline shape).
+template <bool RACE, int CH, bool VEC4>
+__device__ __forceinline__ void emit_rows_of_wave(int n, int b, int i0, int Rv, const float *rows, const HeadEmit &he, uint32_t *bm,
+                                                  int lane, int wave) {
+  constexpr int PF = VEC4 ? 2 : 1;     // (unaligned rows: sixteen scalar loads per row, one row at a time)
+  const float *eb = he.eta + (size_t)b * he.eta_bs;
+  const int ch = he.ch > 0 ? he.ch : -he.ch;
+  for (int r0 = wave; r0 < Rv; r0 += 4 * PF) {
+    HeadEta<CH> pre[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int rr = r0 + 4 * j;
+      if (rr < Rv) {
+        const size_t row = (size_t)b * n + i0 + rr;
+        head_eta_fetch<CH, VEC4>(pre[j], n, ch, eb + (size_t)(i0 + rr) * n, he.hid + row * (16 * he.spl), he.spl, lane);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int rr = r0 + 4 * j;
+      if (rr < Rv) {
+        const size_t row = (size_t)b * n + i0 + rr;
+        emit_head_row_pre<RACE, CH, VEC4>(n, ch, rows + rr * n, pre[j], bm, he.hrow + row * sp_head_row_bytes(he.spl), he.spl, he.dead, lane);
+      }
+    }
+  }
+}
+
 // SYM: symmetric deposit, two lanes per row (prev / next side).  !SYM: directed deposit, one lane
 // per row adds at next_a(i) (0xFFFF = ant a does not leave node i); the hub row is skipped (it
 // belongs to deposit_hub_kernel).  LDS: rows[R][n] | stage[2][R][DEP_CHUNK] | wts[2][DEP_CHUNK].
@@ -175,8 +206,10 @@ constexpr int DEP_CHUNK = 64;
 // one wavefront per row then forms the NEXT iteration's head row of sampler "scan_sparse" (HEADS = 1) or of the race on head rows
 // (HEADS = 2) from them and the row of eta (daco_head_rows.h emit_head_row: the very code of sparse_prepass_kernel), so that
 // iteration neither launches the pre-pass nor reads tau again.
-template <bool SYM, int HEADS>
-__global__ void __launch_bounds__(256)
+// GT (symmetric only): the table in the grouped layout [B][ceil(A/8)][n][8] (daco_tsp_sample_heads(nbr_grouped = 1)): the
+// entries of a workgroup's R rows and eight ants are one run of R x 32 bytes.
+template <bool SYM, int HEADS, bool GT = false>
+__global__ void __launch_bounds__(256, 4)
 deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nbr, const float *costs, const float *weights,
                     float decay, const int *best, const float *clamp_min, const float *clamp_max, float floor_val, const HeadEmit he) {
   extern __shared__ __attribute__((aligned(16))) float rows[];
@@ -191,15 +224,29 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
   const int hub_lo = SYM ? -1 : (hub - i0) * n, hub_hi = SYM ? -1 : hub_lo + n;
   int alo = 0, ahi = A;
   if (best) { alo = best[b]; ahi = alo + 1; }
-  const uint32_t *tab = nbr + ((size_t)b * n + i0) * A;            // rows i0.. of this instance's [n][A] table
+  const uint32_t *tab = GT ? nbr + (size_t)b * ((A + 7) >> 3) * n * 8 + (size_t)i0 * 8     // group g, row r, ant a8 at ((g n) + r) 8 + a8
+                           : nbr + ((size_t)b * n + i0) * A;        // rows i0.. of this instance's [n][A] table
   const float *cs = costs + (size_t)b * A, *wt = weights ? weights + (size_t)b * A : nullptr;
   // chunk loader: consecutive threads on consecutive ants of one row (256-byte segments).  Wave 0 runs
   // the chains, so after the first chunk only waves 1..3 fetch: a chain never waits for a prefetch.
   auto load_chunk = [&](int c0, int buf, int t0, int nt) {
     const int m = min(DEP_CHUNK, ahi - c0);
-    for (int i = t0; i < Rv * DEP_CHUNK; i += nt) {
-      const int r = i / DEP_CHUNK, j = i - r * DEP_CHUNK;
-      stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[(size_t)r * A + c0 + j] : 0xFFFFFFFFu;
+    if constexpr (GT) {
+      // consecutive threads on the eight ants of a row, then on the rows, then on the chunk's groups: runs of Rv x 32 bytes
+      const int per_g = Rv * 8;
+      for (int i = t0; i < per_g * (DEP_CHUNK / 8); i += nt) {
+        const int gq = i / per_g, rem = i - gq * per_g;
+        const int r = rem >> 3, a8 = rem & 7;
+        const int ant = c0 + gq * 8 + a8;                   // (c0: a multiple of 8 except for the elitist's single ant)
+        const int j = ant - c0;
+        if (j < DEP_CHUNK)
+          stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[((size_t)(ant >> 3) * n + r) * 8 + (ant & 7)] : 0xFFFFFFFFu;
+      }
+    } else {
+      for (int i = t0; i < Rv * DEP_CHUNK; i += nt) {
+        const int r = i / DEP_CHUNK, j = i - r * DEP_CHUNK;
+        stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[(size_t)r * A + c0 + j] : 0xFFFFFFFFu;
+      }
     }
     if (t0 < DEP_CHUNK)
       wts[buf * DEP_CHUNK + t0] = t0 < m ? (wt ? wt[c0 + t0] : 1.0f / cs[c0 + t0]) : 0.0f;
@@ -284,18 +331,13 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
     __shared__ uint32_t head_bm[4][32];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float *eb = he.eta + (size_t)b * he.eta_bs;
     // (16-byte row vectors: the LDS rows are aligned whenever n % 4 == 0; eta's rows when its base and stride are -- he.ch < 0 says no)
     const bool vec4 = he.ch > 0;
     const int ch = vec4 ? he.ch : -he.ch;
-    for (int rr = wave; rr < Rv; rr += 4) {
-      const size_t row = (size_t)b * n + i0 + rr;
-      const float *tr = rows + rr * n, *er = eb + (size_t)(i0 + rr) * n;
-      const uint16_t *ids = he.hid + row * (16 * he.spl);
-      char *hl = he.hrow + row * sp_head_row_bytes(he.spl);
-      if (vec4) emit_head_row<HEADS == 2, true>(n, ch, tr, er, ids, head_bm[wave], hl, he.spl, he.dead, lane);
-      else emit_head_row<HEADS == 2, false>(n, ch, tr, er, ids, head_bm[wave], hl, he.spl, he.dead, lane);
-    }
+    if (ch <= 2) { if (vec4) emit_rows_of_wave<HEADS == 2, 2, true>(n, b, i0, Rv, rows, he, head_bm[wave], lane, wave);
+                   else emit_rows_of_wave<HEADS == 2, 2, false>(n, b, i0, Rv, rows, he, head_bm[wave], lane, wave); }
+    else { if (vec4) emit_rows_of_wave<HEADS == 2, 4, true>(n, b, i0, Rv, rows, he, head_bm[wave], lane, wave);
+           else emit_rows_of_wave<HEADS == 2, 4, false>(n, b, i0, Rv, rows, he, head_bm[wave], lane, wave); }
   }
 }
 
@@ -521,12 +563,15 @@ static int pheromone_update_impl(void *stream, int B, int n, int len, int A, flo
   if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
   const int R = rows_per_block(n, true);
   const int bpi = (n + R - 1) / R;
-#define DACO_DEPOSIT_SYM(H) hipLaunchKernelGGL((deposit_rows_kernel<true, H>), dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, 0, tau, \
-                                               nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val, he)
+#define DACO_DEPOSIT_SYM_G(H, G) hipLaunchKernelGGL((deposit_rows_kernel<true, H, G>), dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, 0, tau, \
+                                                    nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val, he)
+#define DACO_DEPOSIT_SYM(H) do { if (grouped) DACO_DEPOSIT_SYM_G(H, true); else DACO_DEPOSIT_SYM_G(H, false); } while (0)
+  const bool grouped = nbr_in != nullptr && he.nbr_grouped != 0;        // (a table rebuilt here from `paths` is [n][A])
   if (!he.eta) DACO_DEPOSIT_SYM(0);
   else if (!he.race) DACO_DEPOSIT_SYM(1);
   else DACO_DEPOSIT_SYM(2);
 #undef DACO_DEPOSIT_SYM
+#undef DACO_DEPOSIT_SYM_G
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("pheromone update launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;
@@ -547,7 +592,7 @@ extern "C" int daco_pheromone_update_heads(void *stream, int B, int n, int A, fl
                                            float decay, int elitist, const float *clamp_min, const float *clamp_max, float floor_val,
                                            const uint32_t *nbr_in, const float *weights, void *workspace, size_t workspace_bytes,
                                            const float *eta, long eta_bstride, float alpha, float beta, const uint16_t *head_id,
-                                           int head_slots, int race, void *sparse_workspace, size_t sparse_workspace_bytes) {
+                                           int head_slots, int race, int nbr_grouped, void *sparse_workspace, size_t sparse_workspace_bytes) {
   if (!eta || !head_id || !sparse_workspace) { set_error("daco_pheromone_update_heads: bad argument"); return DACO_E_BADARG; }
   if (head_slots != 64 && head_slots != 128) { set_error("daco_pheromone_update_heads: head_slots = %d (64 or 128)", head_slots); return DACO_E_BADARG; }
   if (n <= 128 || n > 1024) { set_error("daco_pheromone_update_heads: n=%d outside 129..1024 (the sizes daco_tsp_sample_heads serves)", n); return DACO_E_TOOLARGE; }
@@ -556,7 +601,7 @@ extern "C" int daco_pheromone_update_heads(void *stream, int B, int n, int A, fl
   if (sparse_workspace_bytes < need) { set_error("daco_pheromone_update_heads: sparse workspace %zu < %zu bytes", sparse_workspace_bytes, need); return DACO_E_WORKSPACE; }
   HeadEmit he;
   he.eta = eta; he.eta_bs = eta_bstride; he.hid = head_id; he.hrow = (char *)sparse_workspace;
-  he.spl = head_slots / 16; he.race = race ? 1 : 0;
+  he.spl = head_slots / 16; he.race = race ? 1 : 0; he.nbr_grouped = nbr_grouped ? 1 : 0;
   const int ld = n <= 512 ? 512 : 1024;
   he.dead = ld;
   const bool vec4 = (n & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)eta | (uintptr_t)tau) & 15) == 0;

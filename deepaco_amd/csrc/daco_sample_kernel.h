@@ -59,6 +59,7 @@ struct SampleParams {
   long tau_bs = 0, eta_bs = 0;
   float alpha = 1.0f, beta = 1.0f;
   int row_vec = 0;                   // rows can be read as aligned 16-byte vectors (n % 4 == 0, aligned bases and strides)
+  int nbr_grouped = 0;               // scan_sparse: nbr as [B][ceil(A/8)][n][8] (eight ants' entries of a node together) instead of [B][n][A]
   int lh_kl = 0, lh_kmax = 0;        // scan_sparse, LDS-heads variant: lane records per row kept in LDS, the caller's bound of live slots per row
 };
 

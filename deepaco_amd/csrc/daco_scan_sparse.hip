@@ -48,7 +48,7 @@ __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x800080
 // iteration at the headline shape for the 1.4 % of the steps that walked it): the rare ways form tau * eta from the two rows
 // themselves (sp_prob4: the same product), and an iteration whose pheromone update emitted the head rows
 // (daco_pheromone_update_heads) does not run this kernel at all.
-template <bool RACE, bool VEC4>
+template <bool RACE, bool VEC4, int CH>
 __global__ void __launch_bounds__(256)
 sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const float *eta, long eta_bs,
                       const uint16_t *hid, char *hrow, int spl, int dead) {
@@ -58,7 +58,7 @@ sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const
   if (row >= (long)B * n) return;
   const int b = (int)(row / n), r = (int)(row - (long)b * n);
   const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
-  emit_head_row<RACE, VEC4>(n, ch, tr, er, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), spl, dead, lane);
+  emit_head_row<RACE, CH, VEC4>(n, ch, tr, er, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), spl, dead, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -272,6 +272,15 @@ scan_sparse_kernel(const SampleParams p) {
     __builtin_amdgcn_wave_barrier();
     u32x4 ublk = {0, 0, 0, 0};
     float ucur = 0.0f;
+    // tour lengths while the tour is built (round 6; the epilogue's gather-and-sum phase was 65 us of the headline launch,
+    // tools/ablate_epilogue.py): when a chunk of sixteen steps is done, lane s of the ant gathers the length of the edge of step
+    // t0 + s (one load per wavefront and chunk, in flight over the next chunk's steps) and the sixteen lengths of the PREVIOUS
+    // chunk are added to the ant's sum one after the other (row_newbcast: every lane of the ant carries the same sum) -- the
+    // order of tsp/aco.py:121-132 as daco_tour_costs fixes it: edges t = 1 .. n-1 in turn, the closing edge last.
+    float cacc = 0.0f, dpend = 0.0f;
+    int carry_e = prev;                                    // the node before the chunk's first entry
+    const int first_node = prev;
+    const float *dist_c = p.costs ? p.dist + (size_t)b * p.dist_bs : nullptr;
 
     for (int t0 = 0; t0 < n; t0 += 16) {
       int t = t0;
@@ -493,6 +502,20 @@ scan_sparse_kernel(const SampleParams p) {
           asm volatile("" ::: "memory");
         }
       }
+      if (dist_c) {
+        asm volatile("" ::: "memory");
+        const int e = (int)tour[SP_T(t0 + s)];              // the node of step t0 + s (past n - 1: not used)
+        const int eb = __float_as_int(dpp_f<DPP_ROW_SHR(1), 0xF, false>(__int_as_float(carry_e), __int_as_float(e)));
+        const int ep = s ? eb : carry_e;
+        carry_e = __float_as_int(sp_row_bcast<15>(__int_as_float(e)));
+        const int tt = t0 + s;
+        // the previous chunk's lengths, in step order (+0 for the slots that are no edge: x + 0 = x)
+#define SP_COST_ADD(j) cacc = cacc + sp_row_bcast<j>(dpend)
+        SP_COST_ADD(0); SP_COST_ADD(1); SP_COST_ADD(2); SP_COST_ADD(3); SP_COST_ADD(4); SP_COST_ADD(5); SP_COST_ADD(6); SP_COST_ADD(7);
+        SP_COST_ADD(8); SP_COST_ADD(9); SP_COST_ADD(10); SP_COST_ADD(11); SP_COST_ADD(12); SP_COST_ADD(13); SP_COST_ADD(14); SP_COST_ADD(15);
+#undef SP_COST_ADD
+        dpend = (tt >= 1 && tt < n) ? dist_c[(uint32_t)e * (uint32_t)n + (uint32_t)ep] : 0.0f;
+      }
       if constexpr (TG) {
         // the chunk's sixteen entries leave the window: 32 contiguous bytes per ant (entries past n - 1: never read)
         asm volatile("" ::: "memory");
@@ -500,6 +523,17 @@ scan_sparse_kernel(const SampleParams p) {
         if (a0 + q < A) t16b[t16o + (uint32_t)t0] = wv;
         asm volatile("" ::: "memory");
       }
+    }
+    if (dist_c) {
+      // the last chunk's lengths, then the closing edge (carry_e: the tour's last node -- entry n - 1 sits in the last chunk,
+      // whose lane 15 holds a later, unused slot unless n is a multiple of 16)
+#define SP_COST_ADD(j) cacc = cacc + sp_row_bcast<j>(dpend)
+      SP_COST_ADD(0); SP_COST_ADD(1); SP_COST_ADD(2); SP_COST_ADD(3); SP_COST_ADD(4); SP_COST_ADD(5); SP_COST_ADD(6); SP_COST_ADD(7);
+      SP_COST_ADD(8); SP_COST_ADD(9); SP_COST_ADD(10); SP_COST_ADD(11); SP_COST_ADD(12); SP_COST_ADD(13); SP_COST_ADD(14); SP_COST_ADD(15);
+#undef SP_COST_ADD
+      const int last_node = prev;                           // (the node the last step chose)
+      cacc = cacc + dist_c[(uint32_t)first_node * (uint32_t)n + (uint32_t)last_node];
+      if (s == 0 && a0 + q < A) p.costs[(size_t)b * A + a0 + q] = cacc;
     }
   }
 #undef SP_T
@@ -524,40 +558,7 @@ scan_sparse_kernel(const SampleParams p) {
       int64_t *pb = p.paths + (size_t)b * n * A + abase;
       for (int t = threadIdx.x / APB; t < n; t += TSTEP) pb[(size_t)t * A + k16] = (int64_t)tour_s[k16][t];
     }
-    if (p.costs) {
-      // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of each
-      // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
-      __syncthreads();
-      const float *dist_b = p.dist + (size_t)b * p.dist_bs;
-      // (LH: the flag array is four ants' worth; the head table is dead by now and holds the staging rows and the inverse table)
-      float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(LH ? lh_tab : flag_mem);
-      if (active) {
-        float cost = 0.0f;
-        const float *mine_d = dstage[wave][q];
-        for (int base = 1; base < n; base += 64) {
-          const int t = base + lane;
-#pragma unroll
-          for (int r4 = 0; r4 < APW; ++r4) {
-            const uint16_t *tr = tour_s[wave * APW + r4];
-            dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (s == 0) {
-#pragma unroll
-            for (int v4 = 0; v4 < 16; ++v4) {
-              const float4 v = *(const float4 *)(mine_d + 4 * v4);
-              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (s == 0 && a0 + q < A) {
-          const uint16_t *tm = tour_s[wave * APW + q];
-          cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
-          p.costs[(size_t)b * A + a0 + q] = cost;
-        }
-      }
-    }
+    // (the tour lengths were summed while the tours were built: see the chunk loop)
     if (p.nbr) {
       // the update's table through an inverse-permutation table in the (dead) flag array, eight ants at a time
       uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(LH ? lh_tab + 4096 : flag_mem);
@@ -573,12 +574,16 @@ scan_sparse_kernel(const SampleParams p) {
         if (k8 < nh)
           for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k8][tk[t]] = (uint16_t)t;
         __syncthreads();
-        uint32_t *nb = p.nbr + (size_t)b * n * A + abase + half * 8;
+        // classic layout [B][n][A]: one 32-byte run per node; grouped (nbr_grouped: [B][ceil(A/8)][n][8]): the eight ants' entries
+        // of consecutive nodes are consecutive -- the 256 threads of a pass write 1 KB in one piece
+        const int a8 = abase + half * 8;
+        uint32_t *nb = p.nbr_grouped ? p.nbr + (((size_t)b * ((A + 7) >> 3) + (a8 >> 3)) * n) * 8 + (a8 & 7) : p.nbr + (size_t)b * n * A + a8;
+        const size_t nstride = p.nbr_grouped ? 8 : (size_t)A;
         if (k8 < nh)
           for (int node = threadIdx.x >> 3; node < n; node += 32) {
             const int t = inv[k8][node];
             const uint32_t pv = tk[t == 0 ? n - 1 : t - 1], nx = tk[t == n - 1 ? 0 : t + 1];
-            nb[(size_t)node * A + k8] = pv | (nx << 16);
+            nb[(size_t)node * nstride + k8] = pv | (nx << 16);
           }
       }
     }
@@ -603,38 +608,6 @@ scan_sparse_kernel(const SampleParams p) {
         int64_t *pb = p.paths + (size_t)b * n * A + abase + half * 8;
         for (int t = threadIdx.x >> 3; t < n; t += 32) pb[(size_t)t * A + k8] = (int64_t)tl[k8][t];
       }
-      if (p.costs) {
-        // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of
-        // each of the wave's two ants are gathered with every lane active and staged in LDS.
-        const float *dist_b = p.dist + (size_t)b * p.dist_bs;
-        float (*dstage)[2][64] = reinterpret_cast<float (*)[2][64]>(&inv[0][0]);
-        const int hh = lane >> 5;                             // lanes 0 and 32 sum the wave's two ants
-        const int mine = wave * 2 + hh;
-        float cost = 0.0f;
-        for (int base = 1; base < n; base += 64) {
-          const int t = base + lane;
-#pragma unroll
-          for (int r2 = 0; r2 < 2; ++r2) {
-            const uint16_t *tr = tl[wave * 2 + r2];
-            dstage[wave][r2][lane] = t < n && wave * 2 + r2 < nh ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if ((lane & 31) == 0) {
-            const float *md = dstage[wave][hh];
-#pragma unroll
-            for (int v4 = 0; v4 < 16; ++v4) {
-              const float4 v = *(const float4 *)(md + 4 * v4);
-              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
-        if ((lane & 31) == 0 && mine < nh) {
-          const uint16_t *tm = tl[mine];
-          cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
-          p.costs[(size_t)b * A + abase + half * 8 + mine] = cost;
-        }
-      }
       if (p.nbr) {
         __syncthreads();
         for (int e = threadIdx.x; e < 8 * FL / 8; e += 256) ((uint4 *)&inv[0][0])[e] = make_uint4(0, 0, 0, 0);
@@ -643,12 +616,16 @@ scan_sparse_kernel(const SampleParams p) {
         if (k8 < nh)
           for (int t = threadIdx.x >> 3; t < n; t += 32) inv[k8][tk[t]] = (uint16_t)t;
         __syncthreads();
-        uint32_t *nb = p.nbr + (size_t)b * n * A + abase + half * 8;
+        // classic layout [B][n][A]: one 32-byte run per node; grouped (nbr_grouped: [B][ceil(A/8)][n][8]): the eight ants' entries
+        // of consecutive nodes are consecutive -- the 256 threads of a pass write 1 KB in one piece
+        const int a8 = abase + half * 8;
+        uint32_t *nb = p.nbr_grouped ? p.nbr + (((size_t)b * ((A + 7) >> 3) + (a8 >> 3)) * n) * 8 + (a8 & 7) : p.nbr + (size_t)b * n * A + a8;
+        const size_t nstride = p.nbr_grouped ? 8 : (size_t)A;
         if (k8 < nh)
           for (int node = threadIdx.x >> 3; node < n; node += 32) {
             const int t = inv[k8][node];
             const uint32_t pv = tk[t == 0 ? n - 1 : t - 1], nx = tk[t == n - 1 ? 0 : t + 1];
-            nb[(size_t)node * A + k8] = pv | (nx << 16);
+            nb[(size_t)node * nstride + k8] = pv | (nx << 16);
           }
       }
     }
@@ -685,7 +662,7 @@ static bool sparse_rows_vec4(int n, const float *tau, long tau_bstride, const fl
   return (n & 3) == 0 && (tau_bstride & 3) == 0 && (eta_bstride & 3) == 0 && (((uintptr_t)tau | (uintptr_t)eta) & 15) == 0;
 }
 
-static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, int nbr_grouped, const char *what, void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                       long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                       int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
@@ -728,18 +705,20 @@ static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, co
   const bool vec4 = sparse_rows_vec4(n, tau, tau_bstride, eta, eta_bstride);
   if (!heads_ready) {
     const dim3 pg((unsigned)(((long)B * n + 3) / 4));
-#define DACO_PREPASS(R, V) hipLaunchKernelGGL((sparse_prepass_kernel<R, V>), pg, dim3(256), 0, s, B, n, ld / 256, tau, tau_bstride, eta, eta_bstride, \
-                                              head_id, hrow, spl, ld)
+#define DACO_PREPASS_C(R, V, C) hipLaunchKernelGGL((sparse_prepass_kernel<R, V, C>), pg, dim3(256), 0, s, B, n, ld / 256, tau, tau_bstride, eta, eta_bstride, \
+                                                   head_id, hrow, spl, ld)
+#define DACO_PREPASS(R, V) do { if (ld <= 512) DACO_PREPASS_C(R, V, 2); else DACO_PREPASS_C(R, V, 4); } while (0)
     if (race) { if (vec4) DACO_PREPASS(true, true); else DACO_PREPASS(true, false); }
     else { if (vec4) DACO_PREPASS(false, true); else DACO_PREPASS(false, false); }
 #undef DACO_PREPASS
+#undef DACO_PREPASS_C
   }
   SampleParams sp{};
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = ld / 256;
   sp.P = nullptr; sp.start = start; sp.fixed_start = fixed_start;
   sp.tau = tau; sp.tau_bs = tau_bstride; sp.eta = eta; sp.eta_bs = eta_bstride; sp.alpha = alpha; sp.beta = beta; sp.row_vec = vec4 ? 1 : 0;
   sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
-  sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr;
+  sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr; sp.nbr_grouped = nbr_grouped ? 1 : 0;
   sp.hval = (const float *)hrow; sp.hid = head_id; sp.stats = stats;
   sp.tours16 = (uint16_t *)(hrow + align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)));
   hipError_t e = hipGetLastError();
@@ -791,7 +770,7 @@ extern "C" int daco_tsp_sample_sparse(void *stream, int B, int n, int A, const f
                                       uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                       long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                       size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(false, false, 0, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(false, false, 0, 0, "daco_tsp_sample_sparse", DACO_SPARSE_ARGS);
 }
 extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                          long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
@@ -799,13 +778,13 @@ extern "C" int daco_tsp_sample_race_head(void *stream, int B, int n, int A, cons
                                          uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                          long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                          size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(true, false, 0, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(true, false, 0, 0, "daco_tsp_sample_race_head", DACO_SPARSE_ARGS);
 }
-extern "C" int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int head_live_max, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
+extern "C" int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int head_live_max, int nbr_grouped, int B, int n, int A, const float *tau, long tau_bstride, const float *eta,
                                      long eta_bstride, float alpha, float beta, const uint16_t *head_id, int head_slots, const int64_t *start,
                                      int fixed_start, uint64_t seed, uint64_t iter, const uint64_t *iter_offset,
                                      uint32_t ant_gid0, int ant_gid_bstride, int64_t *paths, int32_t *flags, const float *dist,
                                      long dist_bstride, float *costs, uint32_t *nbr, unsigned long long *stats, void *workspace,
                                      size_t workspace_bytes, void *ev_begin, void *ev_end) {
-  return sample_sparse_impl(race != 0, heads_ready != 0, head_live_max, "daco_tsp_sample_heads", DACO_SPARSE_ARGS);
+  return sample_sparse_impl(race != 0, heads_ready != 0, head_live_max, nbr_grouped, "daco_tsp_sample_heads", DACO_SPARSE_ARGS);
 }

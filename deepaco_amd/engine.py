@@ -234,7 +234,7 @@ def sparse_workspace(device, B, n, n_ants, unit_exponents=True):
 
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
-                      want_paths=True, race=False, workspace=None, heads_ready=False, head_live_max=0):
+                      want_paths=True, race=False, workspace=None, heads_ready=False, head_live_max=0, nbr_grouped=False):
     """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
     distribution of tsp_sample(mode="scan"), 384 / 768 bytes per step instead of a row while the head has a live candidate.
     head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats]).
@@ -244,7 +244,9 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
     this iteration's head rows (pheromone_update_(heads=...) wrote them for these very tensors) and the pass over tau is skipped
     (include/deepaco_hip.h daco_tsp_sample_heads) -- the same tours.
     head_live_max: the k the head table was built with (sparse_head(.., k)), or 0: lets a launch of few ants (one instance, a few
-    hundred ants) keep the head rows in LDS -- the same tours, about half the time at TSP-500 x 512 ants x 1 instance."""
+    hundred ants) keep the head rows in LDS -- the same tours, about half the time at TSP-500 x 512 ants x 1 instance.
+    nbr_grouped: the update's table as [B, ceil(A/8), n, 8] (written in 1 KB pieces; pheromone_update_(heads={..., "nbr_grouped": True})
+    takes it) instead of [B, n, A]; the returned tensor keeps the shape [B, n, A] either way (same bytes, opaque to the caller)."""
     _require_gpu(tau, eta, start, head, workspace)
     assert not heads_ready or workspace is not None
     n = tau.shape[-1]
@@ -266,6 +268,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
             dist, dbs = _bstride(dist, n)
             costs = torch.empty((B, n_ants), dtype=torch.float32, device=dev)
         if want_nbr:
+            assert not nbr_grouped or n_ants % 8 == 0, "the grouped table wants a multiple of eight ants"
             nbr = torch.empty((B, n, n_ants), dtype=torch.int32, device=dev)
         stats = torch.zeros(3, dtype=torch.int64, device=dev) if want_stats else None
         unit = float(alpha) == 1.0 and float(beta) == 1.0       # (other exponents: tau^alpha, eta^beta are formed in the workspace first)
@@ -274,7 +277,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
             raise ValueError(f"scan_sparse serves 129 <= n <= 1024 (n = {n})")
         ws = workspace if workspace is not None else _workspace(dev, nbytes, "sample_sparse")
         assert ws.numel() >= nbytes
-        rc = L.daco_tsp_sample_heads(_stream(dev), int(bool(race)), int(bool(heads_ready)), int(head_live_max), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
+        rc = L.daco_tsp_sample_heads(_stream(dev), int(bool(race)), int(bool(heads_ready)), int(head_live_max), int(bool(nbr_grouped)), B, n, n_ants, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
                                       float(beta), head.data_ptr(), int(head.shape[2]), start.data_ptr() if start is not None else None,
                                       int(fixed_start), int(seed) & (2 ** 64 - 1), int(it),
                                       iter_dev.data_ptr() if iter_dev is not None else None, int(ant_gid0) & 0xFFFFFFFF,
@@ -658,7 +661,8 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
                                                nbr.data_ptr() if nbr is not None else None,
                                                weights.data_ptr() if weights is not None else None, ws.data_ptr(), ws.numel(),
                                                eta.data_ptr(), ebs, float(heads["alpha"]), float(heads["beta"]), head.data_ptr(),
-                                               int(head.shape[2]), int(bool(heads.get("race", False))), sws.data_ptr(), sws.numel())
+                                               int(head.shape[2]), int(bool(heads.get("race", False))),
+                                               int(bool(heads.get("nbr_grouped", False))) if nbr is not None else 0, sws.data_ptr(), sws.numel())
             _lib.check(rc, "daco_pheromone_update_heads")
             return tau
         rc = L.daco_pheromone_update(_stream(dev), B, n, length, A, tau.data_ptr(), paths.data_ptr(),
@@ -1036,6 +1040,8 @@ class BatchedTSP:
             unit = float(self.alpha) == 1.0 and float(self.beta) == 1.0
             if self._sparse_ws is None:
                 self._sparse_ws = sparse_workspace(self.distances.device, self.B, self.n, self.n_ants, unit_exponents=unit)
+            fused = self.fuse_head_rows and unit                 # (the update forms the rows of tau itself: unit exponents only)
+            grouped = fused and self.n_ants % 8 == 0 and self.local_search is None
             st = self._heads_state(head, race_head)
             ready = self._heads_for is not None and len(st) == len(self._heads_for) and all(
                 (a is b) if torch.is_tensor(a) else (a == b) for a, b in zip(st, self._heads_for))
@@ -1043,10 +1049,11 @@ class BatchedTSP:
                                                      self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
                                                      dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head,
-                                                     workspace=self._sparse_ws, heads_ready=ready, head_live_max=self._head[2])
-            if self.fuse_head_rows and unit:                 # (the update forms the rows of tau itself: unit exponents only)
+                                                     workspace=self._sparse_ws, heads_ready=ready, head_live_max=self._head[2],
+                                                     nbr_grouped=grouped)
+            if fused:
                 heads = {"eta": self.heuristic, "alpha": self.alpha, "beta": self.beta, "head": head, "race": race_head,
-                         "workspace": self._sparse_ws}
+                         "workspace": self._sparse_ws, "nbr_grouped": grouped}
         else:
             paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
                                                     self.beta, mode=sampler, seed=self.seed, it=self.iteration,

@@ -183,8 +183,11 @@ int daco_tsp_sample_race_head(void *stream, int B, int n, int A,
  *                tsp/test.ipynb:66-68) then keeps the instance's head rows in LDS when they fit (n <= 512, 64-slot heads,
  *                n * ceil((k + 1) / 4) * 24 bytes <= ~150 KB: TSP-500 with k = 50 does), one wavefront of four ants per
  *                workgroup: the same tours, the per-step L2 round trip gone.  A row with more live slots than the bound sets
- *                bit 2 of flags[b]. */
-int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int head_live_max, int B, int n, int A,
+ *                bit 2 of flags[b].
+ *   nbr_grouped  0: nbr as [B][n][A] (what daco_pheromone_update takes); 1: nbr as [B][ceil(A/8)][n][8] -- the eight ants' entries
+ *                of a node together, so that the sampler writes the table in 1 KB pieces instead of 32-byte runs and the update
+ *                reads it in runs of R x 32 bytes (daco_pheromone_update_heads(nbr_grouped = 1) takes this form). */
+int daco_tsp_sample_heads(void *stream, int race, int heads_ready, int head_live_max, int nbr_grouped, int B, int n, int A,
                           const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                           float alpha, float beta, const uint16_t *head_id, int head_slots,
                           const int64_t *start, int fixed_start,
@@ -390,6 +393,7 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
  * daco_tsp_sample_heads(heads_ready = 1) from the copy it still holds on chip, so tau is read once per iteration instead of twice.
  *   eta, eta_bstride, alpha, beta, head_id, head_slots, race   as the sampler will be called; alpha = beta = 1 only (other
  *                exponents take the sampler's own pass: DACO_E_BADARG here)
+ *   nbr_grouped        the layout of `nbr` (see daco_tsp_sample_heads); a NULL nbr is rebuilt from `paths` either way
  *   sparse_workspace   the sampler's workspace (daco_tsp_sparse_workspace_bytes(B, n, A)); its head rows are (re)written
  *   129 <= n <= 1024; the other arguments as daco_pheromone_update (len = n, hub unused) */
 int daco_pheromone_update_heads(void *stream, int B, int n, int A, float *tau,
@@ -397,7 +401,7 @@ int daco_pheromone_update_heads(void *stream, int B, int n, int A, float *tau,
                                 const float *clamp_min, const float *clamp_max, float floor_val,
                                 const uint32_t *nbr, const float *weights, void *workspace, size_t workspace_bytes,
                                 const float *eta, long eta_bstride, float alpha, float beta,
-                                const uint16_t *head_id, int head_slots, int race,
+                                const uint16_t *head_id, int head_slots, int race, int nbr_grouped,
                                 void *sparse_workspace, size_t sparse_workspace_bytes);
 
 /* daco_allreduce_delta_tau -- the ant-sharded colony's one data-path collective (every rank builds the deposits

@@ -347,6 +347,7 @@ def test_dense_samplers_follow_the_reference_categorical(mode):
 
 
 @pytest.mark.parametrize("n,A,B,k,kw", [(500, 48, 3, 50, {}), (333, 20, 2, 30, {"min_max": True}), (640, 17, 2, 100, {"elitist": True}),
+                                        (300, 24, 2, 30, {"elitist": True}), (1000, 72, 1, 100, {}),
                                         (200, 33, 1, 20, {"sampler": "race"}), (513, 16, 2, 51, {"alpha": 2, "beta": 2})])
 def test_head_rows_from_the_pheromone_update_equal_the_pre_pass(n, A, B, k, kw):
     """Round 6: daco_pheromone_update_heads leaves the NEXT iteration's head rows in the colony's workspace
@@ -368,8 +369,8 @@ def test_head_rows_from_the_pheromone_update_equal_the_pre_pass(n, A, B, k, kw):
         (pa, ca), (pb, cb) = cols[0].step(), cols[1].step()
         assert torch.equal(pa, pb) and torch.equal(ca.view(torch.int32), cb.view(torch.int32)), it
         assert torch.equal(cols[0].pheromone.view(torch.int32), cols[1].pheromone.view(torch.int32)), it
-        if it:
-            assert cols[0]._heads_for is not None and cols[1]._heads_for is None
+        if it:                                             # (exponents other than 1: the update does not form the rows, both colonies pre-pass)
+            assert (cols[0]._heads_for is not None) == (kw.get("alpha", 1) == 1) and cols[1]._heads_for is None
     # the rows the update left = the rows a pre-pass forms from the same pheromone (compared as bytes; every slot is written)
     rows = n * 16 * (24 if k <= 63 else 48)
     fused_rows = cols[0]._sparse_ws[:B * rows].clone()
@@ -433,3 +434,17 @@ def test_single_instance_colony_takes_the_lds_heads_and_matches_the_batched_one(
         (p1, c1), (p3, c3) = one.step(), many.step()
         assert torch.equal(p1[0], p3[0]) and torch.equal(c1[0], c3[0])
     assert torch.equal(one.pheromone[0], many.pheromone[0])
+
+
+@pytest.mark.parametrize("n,A,B", [(500, 48, 2), (200, 8, 1), (700, 40, 2)])
+def test_grouped_table_is_the_classic_table_rearranged(n, A, B):
+    """nbr_grouped=True (include/deepaco_hip.h daco_tsp_sample_heads): the update's table as [B][A/8][n][8] -- the same entries as
+    the classic [B][n][A] table of the same launch."""
+    from deepaco_amd import engine
+    d, tau, eta, heads = instance(n, 500 + n, "ksparse", B)
+    T, E, D, H = tau.to(dev()), eta.to(dev()), d.to(dev()), pack(heads)
+    p0, _, c0, n0 = engine.tsp_sample_sparse(T, E, A, H, seed=4, it=1, dist=D, want_nbr=True)
+    p1, _, c1, n1 = engine.tsp_sample_sparse(T, E, A, H, seed=4, it=1, dist=D, want_nbr=True, nbr_grouped=True)
+    assert torch.equal(p0, p1) and torch.equal(c0, c1)
+    regrouped = n1.reshape(B, A // 8, n, 8).permute(0, 2, 1, 3).reshape(B, n, A)
+    assert torch.equal(regrouped, n0)
