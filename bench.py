@@ -599,6 +599,32 @@ def extra_configs(dev, headline_colony, cpu=True):
     tsp("c2_tsp100_a512_b256", 100, 512, 256, 20, 10, 6.0)
     tsp("c5_share_tsp1000_a2048_b64", 1000, 2048, 64, 100, 5, 20.0, head_rows=True)
 
+    def headline_small(tag, B, steps=200):
+        """the headline workload (TSP-500, 512 ants, k = 50) at B = 1 -- the reference's own call pattern, one colony
+        per instance, tsp/test.ipynb:66-68 -- and B = 8: the colony's default sampler (auto -> head rows; B = 1 keeps them in LDS)."""
+        n, A, k = 500, 512, 50
+        try:
+            col = engine.BatchedTSP(make_instances(B, n, 1234).to(dev), n_ants=A, seed=5, sampler="auto")
+            col.sparsify(k)
+            col.heuristic = col.heuristic.contiguous()
+            warm_colony(col)
+            ev = events(steps)
+            t0 = time.perf_counter()
+            for s_ in range(steps):
+                col.step(events=ev[s_])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            kms = sum(a.elapsed_time(b) for a, b in ev) / steps
+            out[tag] = {"workload": f"TSP-{n}, n_ants={A}, {B} instance{'s' if B > 1 else ''}, 1/d sparsified k={k}, sampler auto -> "
+                                    f"{col.resolved_sampler()[0]}", "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3,
+                        "steps": steps, "kernel_ms": kms,
+                        "roofline": roofline_rows(n, A, B, "scan_sparse", kms, head_k=k)}
+        except Exception as e:
+            out[tag] = {"error": repr(e)}
+
+    headline_small("headline_b1", 1)
+    headline_small("headline_b8", 8)
+
     # config 4: CVRP-100, capacity mask in the sampling kernel
     n, A, B = 100, 512, 256
     g = torch.Generator().manual_seed(3)
@@ -1160,6 +1186,42 @@ def load_traffic():
         return {}
 
 
+def live_traffic(needle, cmd, timeout=150):
+    """HBM-side bytes per launch of the kernel whose name contains `needle`, collected NOW: two rocprofv3 counter passes (FETCH_SIZE,
+    then WRITE_SIZE: they do not fit one pass, and counters are collected with the kernel trace only -- MI355X_MICROARCH.md) of the
+    command `cmd`, which launches that kernel at this workload a few times.  bytes = FETCH_SIZE KiB x 1024 x 2 (the guide's gfx950
+    correction for wide coalesced reads) + WRITE_SIZE KiB x 1024, mean per launch.  None if rocprofv3 is not there or a pass fails
+    (the stored figure of profiles/hbm_traffic.json is used then, and says so)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="daco_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--"] + cmd,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            got = []
+            for f in glob.glob(os.path.join(tmp, "**", "p_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if needle in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                log(f"live counter pass {ctr}: no rows for {needle!r} (rc {r.returncode})")
+                return None
+            vals[ctr] = sum(got) / len(got)
+        except Exception as e:
+            log(f"live counter pass {ctr} failed: {e!r}")
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return vals["FETCH_SIZE"] * 1024.0 * 2.0 + vals["WRITE_SIZE"] * 1024.0
+
+
 def load_counters():
     """profiles/counters.json: what the kernels' hardware counters said (rocprofv3 --pmc passes of the workloads below,
     tools/profile_r4.sh), stamped with the library version like hbm_traffic.json and dropped when it differs.  Pipe
@@ -1432,6 +1494,14 @@ def worker(args):
 
     if rank == 0:
         traffic, tsrc = load_traffic().get(f"tsp{n}_a{A}_b{B}_{resolved}", (None, None))
+        if world == 1 and not args.no_extras and not ant_sharded and streams == 1 and resolved in ("scan_sparse", "scan"):
+            # the HBM-side bytes of the dominant kernel, collected in THIS run (a stored figure cannot show a
+            # regression): two counter passes of the kernel alone at this workload, in subprocesses
+            needle = "scan_sparse_kernel" if resolved == "scan_sparse" else "tsp_scan32_kernel"
+            live = live_traffic(needle, [sys.executable, os.path.join(ROOT, "tools", "run_headline_kernel.py"), "5", str(B), str(A), str(n), resolved])
+            if live is not None:
+                traffic, tsrc = live, ("collected in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (kernel trace only) of "
+                                       "tools/run_headline_kernel.py at this workload; FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, per launch")
         line = {
             "metric": "ant-tours/sec, TSP-500 n_ants=512", "value": value, "unit": "ant-tours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

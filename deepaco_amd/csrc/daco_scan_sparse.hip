@@ -272,16 +272,10 @@ scan_sparse_kernel(const SampleParams p) {
     __builtin_amdgcn_wave_barrier();
     u32x4 ublk = {0, 0, 0, 0};
     float ucur = 0.0f;
-    // tour lengths while the tour is built (round 6; the epilogue's gather-and-sum phase was 65 us of the headline launch,
-    // tools/ablate_epilogue.py): when a chunk of sixteen steps is done, lane s of the ant gathers the length of the edge of step
-    // t0 + s (one load per wavefront and chunk, in flight over the next chunk's steps) and the sixteen lengths of the PREVIOUS
-    // chunk are added to the ant's sum one after the other (row_newbcast: every lane of the ant carries the same sum) -- the
-    // order of tsp/aco.py:121-132 as daco_tour_costs fixes it: edges t = 1 .. n-1 in turn, the closing edge last.
-    float cacc = 0.0f, dpend = 0.0f;
-    int carry_e = prev;                                    // the node before the chunk's first entry
-    const int first_node = prev;
-    const float *dist_c = p.costs ? p.dist + (size_t)b * p.dist_bs : nullptr;
-
+    // (Round 6 tried to sum the tour lengths while the tours are built -- one 64-lane gather of edge lengths per chunk of sixteen
+    // steps, added in step order by row_newbcast: bit-identical, and 150 us SLOWER at the headline shape than the epilogue's
+    // 65 us: loads return in order, so every chunk's first head-row load waited behind a gather of 64 different cache lines.
+    // profiles/r06_fused_head_rows.txt.)
     for (int t0 = 0; t0 < n; t0 += 16) {
       int t = t0;
       if constexpr (!RACE) {
@@ -496,25 +490,21 @@ scan_sparse_kernel(const SampleParams p) {
             }
           }
           // the winning lane of every ant marks the node and appends it; the ant's lanes read it back as the next row
-          if (__builtin_amdgcn_inverse_ballot_w64(first)) { fl[sel] = 0; tour[SP_T(t)] = (uint16_t)sel; }
+          const bool winner = __builtin_amdgcn_inverse_ballot_w64(first);
+          if (winner) { fl[sel] = 0; tour[SP_T(t)] = (uint16_t)sel; }
           asm volatile("" ::: "memory");                    // (same wavefront: the LDS executes these in program order)
-          prev = tour[SP_T(t)];
+          if (LH && __builtin_popcountll(first) == APW) {
+            // LH runs one wavefront per CU: a step is a bare chain of latencies and instructions are free, so the next row index
+            // travels through the ant's sixteen lanes by four DPP rotations instead of an LDS store and load (the other kernels
+            // are bound by instruction issue and keep the read-back: one instruction)
+            int x = winner ? sel : 0;
+            x |= sp_row_ror<1>(x); x |= sp_row_ror<2>(x); x |= sp_row_ror<4>(x); x |= sp_row_ror<8>(x);
+            prev = x;
+          } else {
+            prev = tour[SP_T(t)];
+          }
           asm volatile("" ::: "memory");
         }
-      }
-      if (dist_c) {
-        asm volatile("" ::: "memory");
-        const int e = (int)tour[SP_T(t0 + s)];              // the node of step t0 + s (past n - 1: not used)
-        const int eb = __float_as_int(dpp_f<DPP_ROW_SHR(1), 0xF, false>(__int_as_float(carry_e), __int_as_float(e)));
-        const int ep = s ? eb : carry_e;
-        carry_e = __float_as_int(sp_row_bcast<15>(__int_as_float(e)));
-        const int tt = t0 + s;
-        // the previous chunk's lengths, in step order (+0 for the slots that are no edge: x + 0 = x)
-#define SP_COST_ADD(j) cacc = cacc + sp_row_bcast<j>(dpend)
-        SP_COST_ADD(0); SP_COST_ADD(1); SP_COST_ADD(2); SP_COST_ADD(3); SP_COST_ADD(4); SP_COST_ADD(5); SP_COST_ADD(6); SP_COST_ADD(7);
-        SP_COST_ADD(8); SP_COST_ADD(9); SP_COST_ADD(10); SP_COST_ADD(11); SP_COST_ADD(12); SP_COST_ADD(13); SP_COST_ADD(14); SP_COST_ADD(15);
-#undef SP_COST_ADD
-        dpend = (tt >= 1 && tt < n) ? dist_c[(uint32_t)e * (uint32_t)n + (uint32_t)ep] : 0.0f;
       }
       if constexpr (TG) {
         // the chunk's sixteen entries leave the window: 32 contiguous bytes per ant (entries past n - 1: never read)
@@ -523,17 +513,6 @@ scan_sparse_kernel(const SampleParams p) {
         if (a0 + q < A) t16b[t16o + (uint32_t)t0] = wv;
         asm volatile("" ::: "memory");
       }
-    }
-    if (dist_c) {
-      // the last chunk's lengths, then the closing edge (carry_e: the tour's last node -- entry n - 1 sits in the last chunk,
-      // whose lane 15 holds a later, unused slot unless n is a multiple of 16)
-#define SP_COST_ADD(j) cacc = cacc + sp_row_bcast<j>(dpend)
-      SP_COST_ADD(0); SP_COST_ADD(1); SP_COST_ADD(2); SP_COST_ADD(3); SP_COST_ADD(4); SP_COST_ADD(5); SP_COST_ADD(6); SP_COST_ADD(7);
-      SP_COST_ADD(8); SP_COST_ADD(9); SP_COST_ADD(10); SP_COST_ADD(11); SP_COST_ADD(12); SP_COST_ADD(13); SP_COST_ADD(14); SP_COST_ADD(15);
-#undef SP_COST_ADD
-      const int last_node = prev;                           // (the node the last step chose)
-      cacc = cacc + dist_c[(uint32_t)first_node * (uint32_t)n + (uint32_t)last_node];
-      if (s == 0 && a0 + q < A) p.costs[(size_t)b * A + a0 + q] = cacc;
     }
   }
 #undef SP_T
@@ -558,7 +537,40 @@ scan_sparse_kernel(const SampleParams p) {
       int64_t *pb = p.paths + (size_t)b * n * A + abase;
       for (int t = threadIdx.x / APB; t < n; t += TSTEP) pb[(size_t)t * A + k16] = (int64_t)tour_s[k16][t];
     }
-    // (the tour lengths were summed while the tours were built: see the chunk loop)
+    if (p.costs) {
+      // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of each
+      // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
+      __syncthreads();
+      const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+      // (LH: the flag array is four ants' worth; the head table is dead by now and holds the staging rows and the inverse table)
+      float (*dstage)[APW][64] = reinterpret_cast<float (*)[APW][64]>(LH ? lh_tab : flag_mem);
+      if (active) {
+        float cost = 0.0f;
+        const float *mine_d = dstage[wave][q];
+        for (int base = 1; base < n; base += 64) {
+          const int t = base + lane;
+#pragma unroll
+          for (int r4 = 0; r4 < APW; ++r4) {
+            const uint16_t *tr = tour_s[wave * APW + r4];
+            dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (s == 0) {
+#pragma unroll
+            for (int v4 = 0; v4 < 16; ++v4) {
+              const float4 v = *(const float4 *)(mine_d + 4 * v4);
+              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (s == 0 && a0 + q < A) {
+          const uint16_t *tm = tour_s[wave * APW + q];
+          cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+          p.costs[(size_t)b * A + a0 + q] = cost;
+        }
+      }
+    }
     if (p.nbr) {
       // the update's table through an inverse-permutation table in the (dead) flag array, eight ants at a time
       uint16_t (*inv)[FL] = reinterpret_cast<uint16_t (*)[FL]>(LH ? lh_tab + 4096 : flag_mem);
@@ -607,6 +619,38 @@ scan_sparse_kernel(const SampleParams p) {
       if (p.paths && k8 < nh) {
         int64_t *pb = p.paths + (size_t)b * n * A + abase + half * 8;
         for (int t = threadIdx.x >> 3; t < n; t += 32) pb[(size_t)t * A + k8] = (int64_t)tl[k8][t];
+      }
+      if (p.costs) {
+        // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of
+        // each of the wave's two ants are gathered with every lane active and staged in LDS.
+        const float *dist_b = p.dist + (size_t)b * p.dist_bs;
+        float (*dstage)[2][64] = reinterpret_cast<float (*)[2][64]>(&inv[0][0]);
+        const int hh = lane >> 5;                             // lanes 0 and 32 sum the wave's two ants
+        const int mine = wave * 2 + hh;
+        float cost = 0.0f;
+        for (int base = 1; base < n; base += 64) {
+          const int t = base + lane;
+#pragma unroll
+          for (int r2 = 0; r2 < 2; ++r2) {
+            const uint16_t *tr = tl[wave * 2 + r2];
+            dstage[wave][r2][lane] = t < n && wave * 2 + r2 < nh ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if ((lane & 31) == 0) {
+            const float *md = dstage[wave][hh];
+#pragma unroll
+            for (int v4 = 0; v4 < 16; ++v4) {
+              const float4 v = *(const float4 *)(md + 4 * v4);
+              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if ((lane & 31) == 0 && mine < nh) {
+          const uint16_t *tm = tl[mine];
+          cost = cost + dist_b[(uint32_t)tm[0] * (uint32_t)n + tm[n - 1]];
+          p.costs[(size_t)b * A + abase + half * 8 + mine] = cost;
+        }
       }
       if (p.nbr) {
         __syncthreads();
