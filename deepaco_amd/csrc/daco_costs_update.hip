@@ -193,7 +193,8 @@ __device__ __forceinline__ void emit_rows_of_wave(int n, int b, int i0, int Rv, 
       const int rr = r0 + 4 * j;
       if (rr < Rv) {
         const size_t row = (size_t)b * n + i0 + rr;
-        emit_head_row_pre<RACE, CH, VEC4>(n, ch, rows + rr * n, pre[j], bm, he.hrow + row * sp_head_row_bytes(he.spl), he.spl, he.dead, lane);
+        emit_head_row_pre<RACE, CH, VEC4>(n, ch, rows + rr * n, pre[j], bm, he.hrow + row * sp_head_row_bytes(he.spl), he.P + row * (256 * ch),
+                                          he.spl, he.dead, lane);
       }
     }
   }
@@ -328,7 +329,9 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
     }
   }
   if constexpr (SYM && HEADS != 0) {
-    __shared__ uint32_t head_bm[4][32];
+    // (the wavefronts' bitmaps live in the staging area, which the chains no longer need: 512 bytes of static LDS on top of the
+    // 40 KB slab were the difference between four and three workgroups per CU -- the update took 143 us instead of ~90)
+    uint32_t (*head_bm)[32] = reinterpret_cast<uint32_t (*)[32]>(stage);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // (16-byte row vectors: the LDS rows are aligned whenever n % 4 == 0; eta's rows when its base and stride are -- he.ch < 0 says no)
@@ -600,7 +603,9 @@ extern "C" int daco_pheromone_update_heads(void *stream, int B, int n, int A, fl
   const size_t need = daco_tsp_sparse_workspace_bytes(B, n, A);
   if (sparse_workspace_bytes < need) { set_error("daco_pheromone_update_heads: sparse workspace %zu < %zu bytes", sparse_workspace_bytes, need); return DACO_E_WORKSPACE; }
   HeadEmit he;
-  he.eta = eta; he.eta_bs = eta_bstride; he.hid = head_id; he.hrow = (char *)sparse_workspace;
+  he.eta = eta; he.eta_bs = eta_bstride; he.hid = head_id;
+  he.P = (float *)sparse_workspace;                                     // (the sampler's layout: dense rows, then head rows)
+  he.hrow = (char *)sparse_workspace + align256((size_t)B * n * (n <= 512 ? 512 : 1024) * sizeof(float));
   he.spl = head_slots / 16; he.race = race ? 1 : 0; he.nbr_grouped = nbr_grouped ? 1 : 0;
   const int ld = n <= 512 ? 512 : 1024;
   he.dead = ld;

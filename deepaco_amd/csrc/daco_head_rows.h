@@ -82,9 +82,14 @@ __device__ __forceinline__ void head_eta_fetch(HeadEta<CH> &h, int n, int ch, co
 // "is a candidate" select.
 // RACE (the exponential race on head rows): value = 1 / P[id_m] (+inf for the other slots), last slot = the smallest 1 / P of
 // the tail, i.e. the reciprocal of its largest entry.
+// pr: the row of the dense matrix P = tau * eta (ld = 256 ch floats, zeros past n) that the rare ways of the scan walk, written
+// from the same registers.  (Round 6 tried to do without P -- 65 MB written per iteration at the headline shape -- and let the
+// rare ways read tau and eta instead: the headline launch got 70 us SLOWER on the same box.  A wavefront stops for a row walk
+// some thirty times per tour, the walk is a bare memory round trip, and a row written a moment ago is found in the L2 / Infinity
+// Cache where the two rows of tau and eta are not.  profiles/r06_fused_head_rows.txt.)
 template <bool RACE, int CH, bool VEC4>
 __device__ __forceinline__ void emit_head_row_pre(int n, int ch, const float *tr, const HeadEta<CH> &h, uint32_t *bm, char *hl,
-                                                  int spl, int dead, int lane) {
+                                                  float *pr, int spl, int dead, int lane) {
   const int kh = 16 * spl, ls = sp_lane_bytes(spl);
   const int cnt = h.cnt;
   if (lane < 32) bm[lane] = 0u;
@@ -100,6 +105,7 @@ __device__ __forceinline__ void emit_head_row_pre(int n, int ch, const float *tr
       float4 t;
       sp_load4<VEC4>(tr, n, k0, t);
       const float4 v = sp_mul4_masked(t, h.e[c], n, k0);
+      *reinterpret_cast<float4 *>(pr + k0) = v;
       const uint32_t w = bm[(k0 >> 5) & 31] >> (k0 & 31);          // the four candidates share a word
       if constexpr (RACE) {
         part = fminf(part, (w & 1u) ? __builtin_inff() : 1.0f / v.x);
@@ -141,10 +147,10 @@ __device__ __forceinline__ void emit_head_row_pre(int n, int ch, const float *tr
 
 template <bool RACE, int CH, bool VEC4>
 __device__ __forceinline__ void emit_head_row(int n, int ch, const float *tr, const float *er,
-                                              const uint16_t *ids, uint32_t *bm, char *hl, int spl, int dead, int lane) {
+                                              const uint16_t *ids, uint32_t *bm, char *hl, float *pr, int spl, int dead, int lane) {
   HeadEta<CH> h;
   head_eta_fetch<CH, VEC4>(h, n, ch, er, ids, spl, lane);
-  emit_head_row_pre<RACE, CH, VEC4>(n, ch, tr, h, bm, hl, spl, dead, lane);
+  emit_head_row_pre<RACE, CH, VEC4>(n, ch, tr, h, bm, hl, pr, spl, dead, lane);
 }
 
 // what the update needs to emit head rows (null eta: no emission)
@@ -153,6 +159,7 @@ struct HeadEmit {
   long eta_bs = 0;
   const uint16_t *hid = nullptr;   // [B][n][16 spl]
   char *hrow = nullptr;            // [B][n][16 sp_lane_bytes(spl)]
+  float *P = nullptr;              // [B][n][256 ch]: the dense rows the scan's rare ways walk
   int spl = 4, ch = 2, dead = 512, race = 0;
   int nbr_grouped = 0;             // the update's table arrives as [B][ceil(A/8)][n][8] (written by daco_tsp_sample_heads(nbr_grouped = 1))
 };

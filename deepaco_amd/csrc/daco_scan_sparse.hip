@@ -51,14 +51,14 @@ __device__ inline uint64_t sp_row_first(uint64_t m) { return m & ~((m | 0x800080
 template <bool RACE, bool VEC4, int CH>
 __global__ void __launch_bounds__(256)
 sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const float *eta, long eta_bs,
-                      const uint16_t *hid, char *hrow, int spl, int dead) {
+                      const uint16_t *hid, float *P, char *hrow, int spl, int dead) {
   __shared__ uint32_t bm[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= (long)B * n) return;
   const int b = (int)(row / n), r = (int)(row - (long)b * n);
   const float *tr = tau + b * tau_bs + (long)r * n, *er = eta + b * eta_bs + (long)r * n;
-  emit_head_row<RACE, CH, VEC4>(n, ch, tr, er, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), spl, dead, lane);
+  emit_head_row<RACE, CH, VEC4>(n, ch, tr, er, hid + row * (16 * spl), bm[wave], hrow + row * sp_head_row_bytes(spl), P + row * (256 * ch), spl, dead, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -66,11 +66,9 @@ sparse_prepass_kernel(int B, int n, int ch, const float *tau, long tau_bs, const
 // 64-lane scan specification with uniform `ur` (oracle draw_scan, lanes = 64).  TAIL = true: the walk over the row's
 // non-head entries, visited or not, with the threshold `ur` given (oracle draw_scan_sparse, "past the head").
 // Returns the node, -1 if no candidate can be drawn (dense: infeasible; tail: a tail without mass).
-// (the row itself: tau^alpha * eta^beta formed from the rows of tau and eta -- sp_prob4, what the dense P held until round 5)
-struct SpRowSrc { const float *t, *e; int n; bool vec; };
-__device__ __forceinline__ float4 sp_row4(const SpRowSrc &r, int k0) {
-  return r.vec ? sp_prob4<true>(r.t, r.e, r.n, k0) : sp_prob4<false>(r.t, r.e, r.n, k0);
-}
+// (the row itself: the padded dense row of P the pre-pass / the update wrote next to the head row)
+struct SpRowSrc { const float *p; };
+__device__ __forceinline__ float4 sp_row4(const SpRowSrc &r, int k0) { return *reinterpret_cast<const float4 *>(r.p + k0); }
 
 template <int CHD, bool TAIL>
 __device__ __forceinline__ int sparse_row_walk(const SpRowSrc &rowp, const uint8_t *flg, const uint32_t *bm, int lane, float ur) {
@@ -205,10 +203,10 @@ scan_sparse_kernel(const SampleParams p) {
   const bool active = a0 < A && (!LH || wave == 0);
   const int a = a0 + q < A ? a0 + q : A - 1;             // spare groups build ant A-1 again (not written)
   const uint32_t gid = p.ant_gid0 + (uint32_t)(b * (p.gid_bstride ? p.gid_bstride : A) + a);
-  const float *taub = p.tau + (size_t)b * p.tau_bs, *etab = p.eta + (size_t)b * p.eta_bs;
+  const float *Pb = p.P + (size_t)b * n * p.ld;
   const char *hrb = (const char *)p.hval + (size_t)b * n * ROWB;
   const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void *)hrb, 0, (int)((uint32_t)n * ROWB), 0x00020000);
-#define SP_ROW_OF(pv) SpRowSrc{taub + (size_t)(pv) * n, etab + (size_t)(pv) * n, n, p.row_vec != 0}
+#define SP_ROW_OF(pv) SpRowSrc{Pb + (size_t)(pv) * p.ld}
   uint32_t sls = (uint32_t)s * LS;
   asm volatile("" : "+v"(sls));                          // (kept in a register: the loop adds it to the row offset)
   uint8_t *fl = flag_mem + (wave * APW + q) * FLP;
@@ -689,11 +687,12 @@ pow_pair_kernel(long count_t, const float *tau, float alpha, float *tau_out, lon
   if (i < count_e) eta_out[i] = pw(eta[i], beta);
 }
 
-// workspace: the head rows (at offset 0: daco_pheromone_update_heads writes them there too), then (n > 512) the u16 tours as they are built
+// workspace: the dense rows P [B][n][ld], the head rows (daco_pheromone_update_heads writes both), then (n > 512) the u16 tours as they are built
 extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A) {
   if (B <= 0 || A <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
-  return align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)) + (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
+  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)) +
+         (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
 }
 
 // ... and, for exponents other than 1, tau^alpha [B][n][n] and eta^beta [B or 1][n][n] behind it
@@ -725,7 +724,8 @@ static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, in
   if (workspace_bytes < need) { set_error("%s: workspace %zu < %zu bytes", what, workspace_bytes, need); return DACO_E_WORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   const int ld = n <= 512 ? 512 : 1024;
-  char *hrow = (char *)workspace;
+  float *P = (float *)workspace;
+  char *hrow = (char *)workspace + align256((size_t)B * n * ld * sizeof(float));
   const int spl = head_slots / 16;
   if (alpha != 1.0f || beta != 1.0f) {
     // the kernels take unit exponents: the powers are applied to the matrices first, into the tail of a `general` workspace
@@ -750,7 +750,7 @@ static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, in
   if (!heads_ready) {
     const dim3 pg((unsigned)(((long)B * n + 3) / 4));
 #define DACO_PREPASS_C(R, V, C) hipLaunchKernelGGL((sparse_prepass_kernel<R, V, C>), pg, dim3(256), 0, s, B, n, ld / 256, tau, tau_bstride, eta, eta_bstride, \
-                                                   head_id, hrow, spl, ld)
+                                                   head_id, P, hrow, spl, ld)
 #define DACO_PREPASS(R, V) do { if (ld <= 512) DACO_PREPASS_C(R, V, 2); else DACO_PREPASS_C(R, V, 4); } while (0)
     if (race) { if (vec4) DACO_PREPASS(true, true); else DACO_PREPASS(true, false); }
     else { if (vec4) DACO_PREPASS(false, true); else DACO_PREPASS(false, false); }
@@ -759,7 +759,7 @@ static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, in
   }
   SampleParams sp{};
   sp.B = B; sp.n = n; sp.A = A; sp.ld = ld; sp.CH = ld / 256;
-  sp.P = nullptr; sp.start = start; sp.fixed_start = fixed_start;
+  sp.P = P; sp.start = start; sp.fixed_start = fixed_start;
   sp.tau = tau; sp.tau_bs = tau_bstride; sp.eta = eta; sp.eta_bs = eta_bstride; sp.alpha = alpha; sp.beta = beta; sp.row_vec = vec4 ? 1 : 0;
   sp.seed = seed; sp.iter = iter; sp.iter_dev = iter_offset; sp.ant_gid0 = ant_gid0; sp.gid_bstride = ant_gid_bstride;
   sp.paths = paths; sp.flags = flags; sp.dist = dist; sp.dist_bs = dist_bstride; sp.costs = costs; sp.nbr = nbr; sp.nbr_grouped = nbr_grouped ? 1 : 0;
