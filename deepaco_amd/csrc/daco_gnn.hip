@@ -527,11 +527,17 @@ __device__ inline f32x2 silu2_fast(f32x2 x) {             // x sigmoid(x) on the
 }
 // INIT (layer 0 only): the old edge state is not read but made on the fly, w0 = silu(e_lin0(edge_attr)) (tsp/net.py:31) --
 // 4 bytes per edge instead of 128, and no separate launch that writes E * 128 bytes first.
-template <bool INIT>
+// HEAD (round 6): the LAST layer with the output head in it (tsp/net.py:59-66 on top of :27-45).  The head only takes the edge
+// state, and layer 12's node state feeds nothing, so this variant runs the edge update of a tile, keeps the new rows in the
+// wavefront's LDS tile and sends them through the head's two 32x32 linears and the 32 -> 1 row sum right there (the tile code
+// of gnn_head_kernel, the same MFMA order per row: the same bits): it writes heu[E] -- 4 bytes per edge -- and neither the edge
+// state (128 bytes per edge written here and read again by the head launch) nor the node state; no x2 gathers, no aggregate, no
+// node phase.  Used when the caller does not ask for the embedding.
+template <bool INIT, bool HEAD = false>
 __global__ void __launch_bounds__(256, 4)
 gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *src, const int *dst, const int *rowptr,
                         const float *params, const float *x0, const float *X, const float *w0, float *x1out, float *Xnext,
-                        float *w1out, const float *attr, int nt) {
+                        float *w1out, const float *attr, int nt, float *heu = nullptr) {
   __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];            // A rows -> MFMA result (edge-major) -> products (channel-major)
   __shared__ __attribute__((aligned(16))) float agg_s[4][F2_MAX_NPW][U];      // per node: the aggregate, then x' (node phase)
   __shared__ __attribute__((aligned(16))) float x3_s[4][F2_MAX_NPW][U];       // x3 rows of the wave's own nodes
@@ -630,7 +636,7 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
       *reinterpret_cast<float4 *>(&tile[q * 8 + g8][c0]) = old[q];
       const uint32_t drow_off = (uint32_t)dn[q] * 512u + (uint32_t)c0 * 4u;
       a4[q] = *reinterpret_cast<const float4 *>(Xb + drow_off + 384u);
-      x2[q] = *reinterpret_cast<const float4 *>(Xb + drow_off + 128u);
+      if constexpr (!HEAD) x2[q] = *reinterpret_cast<const float4 *>(Xb + drow_off + 128u);
       sl |= (uint32_t)min(max(sn[q] - i0, 0), F2_MAX_NPW - 1) << (4 * q);
     }
     __builtin_amdgcn_wave_barrier();
@@ -690,6 +696,14 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
       r23.x = __builtin_amdgcn_rcpf(p23.x); r23.y = __builtin_amdgcn_rcpf(p23.y);
       const f32x2 gate01 = r01 * sd01, gate23 = r23 * sd23;                           // sigmoid(w0)
       const f32x2 s01 = y01 * (r01 * gd01), s23 = y23 * (r23 * gd23);               // silu(y)
+      if constexpr (HEAD) {
+        // the new row stays in the tile (row = edge, as the head's first linear reads it); rows past the wave's edges: zeros
+        float4 out;
+        out.x = old[q].x + s01.x; out.y = old[q].y + s01.y; out.z = old[q].z + s23.x; out.w = old[q].w + s23.y;
+        asm volatile("" ::: "memory");                                       // (this pass's row reads stay above the write)
+        *reinterpret_cast<float4 *>(&tile[el][c0]) = live ? out : make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
       if (live) {
         float4 out;
         out.x = old[q].x + s01.x; out.y = old[q].y + s01.y; out.z = old[q].z + s23.x; out.w = old[q].w + s23.y;
@@ -709,6 +723,47 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
       pr[24] = live ? gate23.y * x2[q].w : 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
+    if constexpr (HEAD) {
+      // the head on this tile: heu = sigmoid(W3 silu(W2 silu(W1 w + b1) + b2) + b3)
+      const float *hp = params + off_head(feats);
+      const float *W1 = hp, *b1 = W1 + 1024, *W2 = b1 + 32, *b2 = W2 + 1024, *W3 = b2 + 32, *b3 = W3 + 32;
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                      // lgkmcnt(0): the rows are in the tile
+      f32x16 hacc = tile_gemm(&tile[o][0], W1, lane);
+      __builtin_amdgcn_wave_barrier();
+      {
+        const float bo = b1[o];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = {hacc[r] + bo, hacc[r + 1] + bo};
+          const f32x2 a = silu2_fast(v);
+          tile[drow(r, lane)][o] = a.x; tile[drow(r + 1, lane)][o] = a.y;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      hacc = tile_gemm(&tile[o][0], W2, lane);
+      __builtin_amdgcn_wave_barrier();
+      {
+        const float bo = b2[o], wo = W3[o];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = {hacc[r] + bo, hacc[r + 1] + bo};
+          const f32x2 a = silu2_fast(v);
+          tile[drow(r, lane)][o] = a.x * wo; tile[drow(r + 1, lane)][o] = a.y * wo;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (lane < 32) {                                                         // 32 -> 1: row sums, fixed channel order
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < U; ++c) sum = sum + tile[lane][c];
+        const int e = e0 + lane;
+        if (e < eend) heu[e] = sigmoidf(sum + b3[0]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     // S x P: K-slot r of step kk is the edge 8r + kk of the tile (pass r's eight edges: the lane's products of a channel are
     // eight consecutive floats of one row)
     {
@@ -727,6 +782,7 @@ gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (HEAD) return;                                                   // (layer 12's node state feeds nothing)
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {                                              // (D: lane holds nodes 4 r + rr, channel i / 16 + i)
     agg_s[wave][4 * r16 + rr][i16] = aggA[rr];
@@ -921,16 +977,20 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
   const bool fused2 = E >= split_min && !perm && fused_npw != 0 && fused_v == 2;
   // (the second fused kernel makes layer 0's edge state itself; every other path reads it from the init launch)
   if (!fused2) hipLaunchKernelGGL(gnn_edge_init_kernel, dim3((unsigned)(((long)E * 8 + 255) / 256)), dim3(256), 0, s, E, feats, edge_attr, params, wb[0]);
+  // the output head inside the last layer's launch (no embedding asked for; DACO_GNN_HEAD_FUSED=0: the separate head launch)
+  const bool head_fused = fused2 && !emb && !(getenv("DACO_GNN_HEAD_FUSED") && atoi(getenv("DACO_GNN_HEAD_FUSED")) == 0);
   const bool inplace = getenv("DACO_GNN_INPLACE") && atoi(getenv("DACO_GNN_INPLACE")) == 1 && E >= split_min && !perm && fused_npw != 0;
   int wcur = 0;
   for (int l = 0; l < 12; ++l) {
     float *wout = (l == 11 && emb) ? emb : wb[inplace ? wcur : (wcur ^ 1)];
     if (fused2) {
       const dim3 grid((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8));
-      if (l == 0) hipLaunchKernelGGL(gnn_fused2_layer_kernel<true>, grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
-                                     Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows);
-      else hipLaunchKernelGGL(gnn_fused2_layer_kernel<false>, grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
-                              Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows);
+      if (l == 0) hipLaunchKernelGGL((gnn_fused2_layer_kernel<true, false>), grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
+                                     Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows, nullptr);
+      else if (l == 11 && head_fused) hipLaunchKernelGGL((gnn_fused2_layer_kernel<false, true>), grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr,
+                                                         params, xb[cur], Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows, heu);
+      else hipLaunchKernelGGL((gnn_fused2_layer_kernel<false, false>), grid, dim3(256), 0, s, n, E, feats, l, npw, src, dst, rowptr, params, xb[cur],
+                              Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout, edge_attr, nt_rows, nullptr);
     } else if (E >= split_min && !perm && fused_npw != 0) {
       hipLaunchKernelGGL(gnn_fused_layer_kernel, dim3((unsigned)(((n + 4 * npw - 1) / (4 * npw) + 7) / 8 * 8)), dim3(256), 0, s, n, E, feats, l,
                          npw, src, dst, rowptr, params, xb[cur], Xb[cur], wb[wcur], xb[cur ^ 1], Xb[cur ^ 1], wout);
@@ -949,7 +1009,7 @@ extern "C" int daco_gnn_forward(void *stream, int n, int E, int feats, const flo
   }
   // (a head that walks several tiles per wave with the next rows in flight, W1 / W2 in LDS, was measured: 139 us against
   // this kernel's 131 at 64 x TSP-500 -- not kept)
-  hipLaunchKernelGGL(gnn_head_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, params, wb[wcur], heu);
+  if (!head_fused) hipLaunchKernelGGL(gnn_head_kernel, dim3(edge_blocks), dim3(256), 0, s, E, feats, params, wb[wcur], heu);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("gnn kernels launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
   return DACO_OK;

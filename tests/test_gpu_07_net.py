@@ -455,9 +455,10 @@ def test_fused_layer_kernel_vs_oracle_on_ragged_sorted_graph(npw, monkeypatch):
     torch.testing.assert_close(heu, heu_split, rtol=1e-5, atol=2e-6)
 
 
-def test_fused_layer_kernel_at_bench_size_equals_per_graph():
+def test_fused_layer_kernel_at_bench_size_equals_per_graph(monkeypatch):
     """9 graphs of TSP-500 (k = 50) side by side take the fused layer kernel (E >= 200 000); each graph alone takes the
-    single-launch layer kernel: same heuristic up to the aggregation's summation order."""
+    single-launch layer kernel: same heuristic up to the aggregation's summation order.  The output head inside the last
+    layer's launch (round 6) against the separate head launch: the same bits."""
     from deepaco_amd import engine
     from deepaco_amd.net import GraphData
     from deepaco_amd.tsp.net import Net
@@ -469,6 +470,9 @@ def test_fused_layer_kernel_at_bench_size_equals_per_graph():
     _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
     heu = net.forward_batch(coords, ei, ea, k_sparse=k)
     assert torch.equal(heu, net.forward_batch(coords, ei, ea))          # the CSR shortcut describes the same graph
+    monkeypatch.setenv("DACO_GNN_HEAD_FUSED", "0")
+    assert torch.equal(heu, net.forward_batch(coords, ei, ea, k_sparse=k))      # head as its own launch over the stored edge state
+    monkeypatch.delenv("DACO_GNN_HEAD_FUSED")
     for b in (0, 4, 8):
         one = net(GraphData(x=coords[b], edge_index=ei[b], edge_attr=ea[b]))
         torch.testing.assert_close(heu[b], one.view(-1), rtol=1e-5, atol=2e-6)
