@@ -151,6 +151,13 @@ def headline_record(full):
             rec["best_cost_gap"]["samplers"] = {k: [v.get("gap")] + list(v.get("ci95") or [None, None]) + [v.get("equal_or_better"),
                                                                                                          v.get("gpu_better_or_equal_on")]
                                                 for k, v in g["samplers"].items()}
+        if isinstance(g.get("study"), dict) and isinstance(g["study"].get("samplers"), dict):
+            # the committed full-power study (64 instances x 3 seeds x 20 iterations), same five numbers per sampler
+            st = g["study"]
+            rec["best_cost_gap"]["study"] = {"n": [st.get("instances"), st.get("cpu_seeds"), st.get("iterations")], "stored": True,
+                                             **{k: [v.get("gap")] + list(v.get("ci95") or [None, None]) + [v.get("equal_or_better"),
+                                                                                                       v.get("gpu_better_or_equal_on")]
+                                                for k, v in st["samplers"].items()}}
     for k in ("speedup_vs_cpu", "gpu_mean_best_cost"):
         if k in full:
             rec[k] = full[k]
@@ -1551,6 +1558,16 @@ def worker(args):
             # colonies of the default sampler AND of the two reference-pinned ones, three seeds each
             line["best_cost_gap"] = best_cost_gap(dist_cpu[:len(cpu_best)], k_sparse, A, [cpu_best], done, dev,
                                                   samplers=gap_samplers(resolved), default=resolved)
+            # ... and the full-power form of the same statistic (tools/best_cost_gap.py: 64 instances x 3 seeds on both sides, 20
+            # iterations, ~22 minutes of CPU), from the committed record: the live sample above is what a few minutes allow
+            try:
+                st = json.load(open(os.path.join(ROOT, "profiles", "r06_best_cost_gap.json")))
+                line["best_cost_gap"]["study"] = {
+                    "source": "profiles/r06_best_cost_gap.json (tools/best_cost_gap.py on the GPU box, this round; not collected in this run)",
+                    "instances": st["instances"], "iterations": st["iterations"], "cpu_seeds": st["cpu_seeds"], "gpu_seeds": st["gpu_seeds"],
+                    "samplers": st["samplers"]}
+            except Exception:
+                pass
             line["speedup_vs_cpu"] = value / cb["value"]
         emit(line)
     if distributed:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/counters.json and profiles/hbm_traffic.json from the counter passes of tools/profile_r5.sh.
+"""profiles/counters.json and profiles/hbm_traffic.json from the counter passes of tools/profile_r6.sh.
 
 usage: tools/make_counters.py gpurun_out/<tag> [--merge]   (reads <tag>/pmc_<workload>/pmc_*/p_counter_collection.csv;
        --merge: keep the entries of the existing files (same library version) for workloads <tag> has no passes of)
@@ -25,15 +25,17 @@ sys.path.insert(0, ROOT)
 # workload directory -> (kernel substring, key in counters.json / hbm_traffic.json)
 WORKLOADS = {
     "headline": ("tsp_scan32_kernel", "tsp500_a512_b64_scan"),
-    "scan_sparse": ("scan_sparse_kernel<2, false, 4>", "tsp500_a512_b64_scan_sparse"),
-    "c5_sparse": ("scan_sparse_kernel<4, false, 8>", "tsp1000_a2048_b64_scan_sparse"),
+    "scan_sparse": ("scan_sparse_kernel<2, false, 4, false>", "tsp500_a512_b64_scan_sparse"),
+    "c5_sparse": ("scan_sparse_kernel<4, false, 8, false>", "tsp1000_a2048_b64_scan_sparse"),
+    "b1_lds_heads": ("scan_sparse_kernel<2, false, 4, true>", "tsp500_a512_b1_scan_sparse"),
+    "deposit_heads": ("deposit_rows_kernel<true, 1, true>", "tsp500_a512_b64_update_heads"),
     "race": ("tsp_sample_kernel", "tsp500_a512_b64_race"),
-    "race_head": ("scan_sparse_kernel<2, true, 4>", "tsp500_a512_b64_race_head"),
+    "race_head": ("scan_sparse_kernel<2, true, 4, false>", "tsp500_a512_b64_race_head"),
     "c2": ("scan16_kernel", "tsp100_a512_b256_scan"),
     "c4": ("scan16_kernel", "cvrp100_a512_b256_scan"),
     "c5": ("tsp_scan32_kernel", "tsp1000_a2048_b64_scan"),
     "nls": ("nls_kernel", "nls500_a256_b64"),
-    "gnn": ("gnn_fused2_layer_kernel<false>", "gnn_fused2_layer_tsp500_k50_b64"),
+    "gnn": ("gnn_fused2_layer_kernel<false, false>", "gnn_fused2_layer_tsp500_k50_b64"),
     "cvrp_ls": ("cvrp_ls_kernel", "cvrp_ls_100_a512_b16"),
     "hgs_ls": ("hgs_ls_kernel", "hgs_ls_100_a512_b64"),
 }
@@ -53,10 +55,10 @@ def main():
     from deepaco_amd import _lib
     version = _lib.ABI_VERSION
     counters = {"daco_version": version,
-                "source": "profiles/r05_pmc_*.txt (tools/profile_r5.sh + tools/make_counters.py: rocprofv3 --pmc, one pass per counter "
+                "source": "profiles/r06_pmc_*.txt (tools/profile_r6.sh + tools/make_counters.py: rocprofv3 --pmc, one pass per counter "
                           "group, mean per launch of the workload's dominant kernel, all of this library version)"}
     traffic = {"daco_version": version,
-               "source": "profiles/r05_pmc_*.txt (tools/profile_r5.sh: FETCH_SIZE KiB x 1024 x 2 [gfx950 correction] + WRITE_SIZE KiB x "
+               "source": "profiles/r06_pmc_*.txt (tools/profile_r6.sh: FETCH_SIZE KiB x 1024 x 2 [gfx950 correction] + WRITE_SIZE KiB x "
                          "1024, mean per launch of the dominant kernel)"}
     if "--merge" in sys.argv[2:]:
         for name, cur in (("counters.json", counters), ("hbm_traffic.json", traffic)):
@@ -96,6 +98,10 @@ def main():
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             c["hbm_bytes"] = m["FETCH_SIZE"] * 1024 * 2 + m["WRITE_SIZE"] * 1024
             traffic[key] = c["hbm_bytes"]
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in m and m["TCP_TOTAL_CACHE_ACCESSES_sum"] and "TCP_TCC_READ_REQ_sum" in m:
+            # the CU's vector L1: the share of its accesses that did not go on to the L2 as read requests
+            c["l1_accesses"] = m["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            c["l1_hit_rate"] = max(0.0, 1.0 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"])
         if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
             c["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
         counters[key] = c
