@@ -632,6 +632,28 @@ def extra_configs(dev, headline_colony, cpu=True):
     headline_small("headline_b1", 1)
     headline_small("headline_b8", 8)
 
+    # the headline's 64 instances as TWO colonies of 32 on two HIP streams (engine.StreamedTSP: the same tours, costs and pheromone
+    # as one colony over all instances, tests/test_gpu_12_streams.py): one colony's update and the tail of its construction launch
+    # (2 048 workgroups on 1 536 resident: a third of a round at two per CU) run under the other's construction.  Not the default:
+    # `roofline` is defined per launch, and two launches sharing the chip each look slower than they are together.
+    try:
+        n, A, B, k = 500, 512, 64, 50
+        col = engine.StreamedTSP(make_instances(B, n, 1234).to(dev), parts=2, n_ants=A, sampler="auto", seed=1234)
+        col.sparsify(k)
+        for _ in range(8):
+            col.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            col.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 40
+        out["headline_two_streams"] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances as two colonies on two HIP streams, 1/d sparsified k={k}, sampler auto",
+                                       "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "steps": 40}
+        del col
+    except Exception as e:
+        out["headline_two_streams"] = {"error": repr(e)}
+
     # config 4: CVRP-100, capacity mask in the sampling kernel
     n, A, B = 100, 512, 256
     g = torch.Generator().manual_seed(3)

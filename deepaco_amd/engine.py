@@ -234,7 +234,7 @@ def sparse_workspace(device, B, n, n_ants, unit_exponents=True):
 
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
-                      want_paths=True, race=False, workspace=None, heads_ready=False, head_live_max=0, nbr_grouped=False):
+                      want_paths=True, race=False, workspace=None, heads_ready=False, head_live_max=0, nbr_grouped=False, flags=None):
     """ACO.gen_path on head / tail rows (sampler "scan_sparse", include/deepaco_hip.h daco_tsp_sample_sparse): the
     distribution of tsp_sample(mode="scan"), 384 / 768 bytes per step instead of a row while the head has a live candidate.
     head: sparse_head(heuristic, k).  Returns (paths, flags, costs|None, nbr|None[, stats]).
@@ -258,7 +258,8 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
     L = _lib.lib()
     with torch.cuda.device(dev):
         paths = torch.empty((B, n, n_ants), dtype=torch.int64, device=dev) if want_paths else None
-        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if flags is None:                                    # (a caller that keeps its flag words -- they are OR-ed into -- saves a fill launch per call)
+            flags = torch.zeros((B,), dtype=torch.int32, device=dev)
         if start is not None:
             start = start.to(torch.int64).contiguous().view(B, n_ants)
         costs = nbr = None
@@ -990,7 +991,17 @@ class BatchedTSP:
         # only if pheromone (object and version counter), heuristic, head table and exponents are still those
         self._sparse_ws = None
         self._heads_for = None
+        self._flags = torch.zeros((self.B,), dtype=torch.int32, device=dev)      # sticky: bit 0 a draw without a candidate, bit 2 see daco_tsp_sample_heads
         self.fuse_head_rows = os.environ.get("DACO_FUSE_HEAD_ROWS", "1") != "0"      # (knob: 0 = a pre-pass every iteration, as until round 5)
+
+    def check_feasible(self):
+        """Raise like the reference's Categorical if any head-row draw so far had no candidate (bit 0), or the head table holds more
+        live entries than the colony said (bit 2: daco_tsp_sample_heads); syncs.  The flag words are sticky."""
+        fl = int(self._flags.max())
+        if fl & 1:
+            raise ValueError("BatchedTSP: a transition row had no feasible candidate")
+        if fl & 4:
+            raise RuntimeError("BatchedTSP: the head table has more live entries per row than head_live_max")
 
     def _heads_state(self, head, race):
         return (self.pheromone, self.pheromone._version, self.heuristic, head, bool(race), float(self.alpha), float(self.beta))
@@ -1050,7 +1061,7 @@ class BatchedTSP:
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
                                                      dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head,
                                                      workspace=self._sparse_ws, heads_ready=ready, head_live_max=self._head[2],
-                                                     nbr_grouped=grouped)
+                                                     nbr_grouped=grouped, flags=self._flags)
             if fused:
                 heads = {"eta": self.heuristic, "alpha": self.alpha, "beta": self.beta, "head": head, "race": race_head,
                          "workspace": self._sparse_ws, "nbr_grouped": grouped}
