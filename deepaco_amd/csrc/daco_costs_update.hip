@@ -496,13 +496,17 @@ extern "C" size_t daco_pheromone_update_workspace_bytes(int B, int n, int len, i
 // rows per workgroup from an LDS budget: smaller slabs mean more workgroups per CU moving tau while others run
 // their add chains.  Measured (DACO_DEPOSIT_LDS_KB sweep, TSP-500 x 512 x 64 / CVRP-100 x 512 x 256): symmetric
 // 80 / 53 / 40 / 32 KiB -> 119 / 91 / 84 / 105 us; directed 80 / 40 / 26 / 20 KiB -> 92 / 70 / 54 / 53 us.
-static int rows_per_block(int n, bool symmetric) {
+static int rows_per_block(int n, bool symmetric, int B = 1 << 20) {
   static const int override_kb = getenv("DACO_DEPOSIT_LDS_KB") ? atoi(getenv("DACO_DEPOSIT_LDS_KB")) : 0;
   const int budget_kb = override_kb ? override_kb : (symmetric ? 40 : 24);
   int R = (budget_kb * 1024 - 2 * DEP_CHUNK * 4 - 16) / (4 * n + 2 * DEP_CHUNK * 4);
   const int cap = symmetric ? 32 : 64;
   if (R > cap) R = cap;
   if (R < 1) R = 1;
+  // few instances (round 6: one colony per instance is the reference's call pattern): the slab size above would leave most CUs
+  // without a workgroup, and a workgroup's load / store / head-row phases are serial per wavefront -- fewer rows per workgroup
+  // until the launch has two workgroups per CU (the chains are as long either way: one per row)
+  while (R > 1 && (long)B * ((n + R - 1) / R) < 512) R = (R + 1) / 2;
   return R;
 }
 static size_t deposit_lds_bytes(int R, int n) {
@@ -545,7 +549,7 @@ static int pheromone_update_impl(void *stream, int B, int n, int len, int A, flo
       hipLaunchKernelGGL(build_next_kernel, dim3(blocks), dim3(256), 0, s, B, n, len, A, hub, W, paths, (uint32_t *)workspace, (uint32_t *)hubmask);
     }
     if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
-    const int R = rows_per_block(n, false);
+    const int R = rows_per_block(n, false, B);
     const int bpi = (n + R - 1) / R;
     if (hub >= 0)
       hipLaunchKernelGGL(deposit_hub_kernel, dim3(B), dim3(256), (size_t)HUB_CHUNK * (W + 2) * sizeof(uint32_t), s, n, A, W, hub, tau, hubmask, tab_lens,
@@ -564,7 +568,7 @@ static int pheromone_update_impl(void *stream, int B, int n, int len, int A, flo
     hipLaunchKernelGGL(build_nbr_kernel, dim3(blocks), dim3(256), 0, s, B, n, A, paths, (uint32_t *)workspace);
   }
   if (elitist) hipLaunchKernelGGL(argmin_cost_kernel, dim3(B), dim3(64), 0, s, A, costs, best);
-  const int R = rows_per_block(n, true);
+  const int R = rows_per_block(n, true, B);
   const int bpi = (n + R - 1) / R;
 #define DACO_DEPOSIT_SYM_G(H, G) hipLaunchKernelGGL((deposit_rows_kernel<true, H, G>), dim3(B * bpi), dim3(256), deposit_lds_bytes(R, n), s, n, A, R, 0, tau, \
                                                     nbr, costs, weights, decay, elitist ? best : nullptr, clamp_min, clamp_max, floor_val, he)

@@ -491,16 +491,10 @@ scan_sparse_kernel(const SampleParams p) {
           const bool winner = __builtin_amdgcn_inverse_ballot_w64(first);
           if (winner) { fl[sel] = 0; tour[SP_T(t)] = (uint16_t)sel; }
           asm volatile("" ::: "memory");                    // (same wavefront: the LDS executes these in program order)
-          if (LH && __builtin_popcountll(first) == APW) {
-            // LH runs one wavefront per CU: a step is a bare chain of latencies and instructions are free, so the next row index
-            // travels through the ant's sixteen lanes by four DPP rotations instead of an LDS store and load (the other kernels
-            // are bound by instruction issue and keep the read-back: one instruction)
-            int x = winner ? sel : 0;
-            x |= sp_row_ror<1>(x); x |= sp_row_ror<2>(x); x |= sp_row_ror<4>(x); x |= sp_row_ror<8>(x);
-            prev = x;
-          } else {
-            prev = tour[SP_T(t)];
-          }
+          // (LH, measured and not kept: the next row index through the ant's sixteen lanes by four DPP rotations instead of this LDS
+          // store and load -- 0.2278 against 0.2161 ms per colony iteration at TSP-500 x 512 x 1: the extra branch and five
+          // dependent VALU instructions cost more than the LDS round trip they replace)
+          prev = tour[SP_T(t)];
           asm volatile("" ::: "memory");
         }
       }

@@ -48,6 +48,15 @@ if [ "$WHAT" = "gnn" ]; then      # the network's forward alone (after a change 
   ls $OUT
   exit 0
 fi
+if [ "$WHAT" = "rest" ]; then    # the counter passes `headline` leaves out (make_counters.py --merge puts the two together)
+  pmc headline python tools/run_headline_kernel.py 5 64 512 500 scan
+  pmc c2 python tools/measure_configs.py c2
+  pmc c4 python tools/measure_configs.py c4
+  pmc c5 python tools/measure_configs.py c5shard
+  pmc hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short --reps 2
+  ls $OUT
+  exit 0
+fi
 if [ "$WHAT" = "headline" ]; then # the headline's kernels only: the construction kernel, the update with the head rows, one instance
   stats headline python bench.py --no-cpu --no-extras --min-seconds 0
   stats b1 python tools/b1_modes.py 100
