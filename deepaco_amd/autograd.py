@@ -36,12 +36,13 @@ class TspBatchSampleFn(torch.autograd.Function):
     forward, one daco_sample_backward launch backward (the batched tsp_nls/train.py step)."""
 
     @staticmethod
-    def forward(ctx, heuristic, pheromone, n_ants, alpha, beta, mode, norm_passes, fixed_start, seed, it):
+    def forward(ctx, heuristic, pheromone, n_ants, alpha, beta, mode, norm_passes, fixed_start, seed, it, iter_dev=None):
+        # (iter_dev: int64 device scalar added to `it` by the kernel -- a captured training step advances it)
         eta = heuristic.detach().contiguous()
         B = eta.shape[0]
         paths, logp, rowsum, flags = engine.tsp_sample(
             pheromone, eta, n_ants, alpha, beta, mode=mode, norm_passes=norm_passes, fixed_start=fixed_start,
-            seed=seed, it=it, require_prob=True, batch=B)
+            seed=seed, it=it, require_prob=True, batch=B, iter_dev=iter_dev)
         ctx.save_for_backward(pheromone, eta, paths, rowsum)
         ctx.ab = (alpha, beta)
         ctx.mark_non_differentiable(paths, flags)
@@ -51,7 +52,7 @@ class TspBatchSampleFn(torch.autograd.Function):
     def backward(ctx, _gp, glogp, _gf):
         tau, eta, paths, rowsum = ctx.saved_tensors
         grad = engine.sample_backward(tau, eta, ctx.ab[0], ctx.ab[1], paths, rowsum, glogp.contiguous())
-        return (grad,) + (None,) * 9
+        return (grad,) + (None,) * 10
 
 
 class CvrpSampleFn(torch.autograd.Function):

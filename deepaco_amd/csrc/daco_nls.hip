@@ -436,7 +436,9 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
                      max_iterations, T_nls, T_p, sweeps, costs, counters, prof)
   int group = 3;                                            // (measured on config 3: 1 / 2 / 3 / 4 entries -> 58.9 / 48.4 / 45.8 / 50.8 ms)
   if (const char *ev = getenv("DACO_NLS_GROUP")) group = atoi(ev);
-  if (nt >= 1024) DACO_NLS_LAUNCH(1024, 2, 2);
+  if (nt == 64 && n + 1 <= 128) DACO_NLS_LAUNCH(64, 2, 2);            // one wavefront per tour: the barriers of a sweep cost nothing
+  else if (nt == 128 && n + 1 <= 256) DACO_NLS_LAUNCH(128, 2, 2);
+  else if (nt >= 1024) DACO_NLS_LAUNCH(1024, 2, 2);
   else if (nt >= 512) DACO_NLS_LAUNCH(512, 3, 2);
   else if (nt == 192 && n + 1 <= 576) DACO_NLS_LAUNCH(192, 3, 3);
   else if (n + 1 > 512) DACO_NLS_LAUNCH(256, 5, 2);

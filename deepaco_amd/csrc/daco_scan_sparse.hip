@@ -781,12 +781,10 @@ static int sample_sparse_impl(bool race, bool heads_ready, int head_live_max, in
 #define DACO_SPARSE_LAUNCH(C, R, S) hipLaunchKernelGGL((scan_sparse_kernel<C, R, S>), grid, dim3(256), DACO_SPARSE_LDS(C) + pad_lds, s, sp)
 #define DACO_SPARSE_PICK(C, R) do { if (spl == 4) DACO_SPARSE_LAUNCH(C, R, 4); else DACO_SPARSE_LAUNCH(C, R, 8); } while (0)
   if (lh) {
-    static bool attr_set = false;                        // (more than 64 KB of dynamic LDS has to be asked for once)
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_sparse_kernel<2, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024 - 128) != hipSuccess) { set_error("%s: hipFuncSetAttribute(dynamic LDS) failed", what); return DACO_E_HIP; }
-      attr_set = true;
-    }
+    // (more than 64 KB of dynamic LDS has to be asked for; per call: the attribute belongs to the current device's copy of the
+    // kernel and a process may drive several devices)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_sparse_kernel<2, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 128) != hipSuccess) { set_error("%s: hipFuncSetAttribute(dynamic LDS) failed", what); return DACO_E_HIP; }
     hipLaunchKernelGGL((scan_sparse_kernel<2, false, 4, true>), grid, dim3(256), lh_lds, s, sp);
   } else if (ld <= 512) { if (race) DACO_SPARSE_PICK(2, true); else DACO_SPARSE_PICK(2, false); }
   else { if (race) DACO_SPARSE_PICK(4, true); else DACO_SPARSE_PICK(4, false); }

@@ -304,6 +304,112 @@ class Net(nn.Module):
         parts += [h[0].weight.reshape(-1), h[0].bias, h[1].weight.reshape(-1), h[1].bias, h[2].weight.reshape(-1), h[2].bias]
         return torch.cat([p.float().reshape(-1) for p in parts])
 
+    # ------------------------------------------------------------------ one flat parameter block (round 6)
+    def _flat_specs(self):
+        """(parameter, offset, shape, stride) of every parameter the kernels read inside the training block (the layout
+        pack_params_train writes; csrc/daco_gnn.hip).  The four node linears of a layer are one [32 in][128 out] matrix there:
+        linear q's weight [out][in] is the strided view (1, 128) at column 32 q."""
+        e = self.emb_net
+        specs, off = [], 0
+
+        def put(p, shape, stride):
+            nonlocal off
+            specs.append((p, off, shape, stride))
+            off += p.numel()
+
+        put(e.v_lin0.weight, (UNITS, e.feats), (e.feats, 1))
+        put(e.v_lin0.bias, (UNITS,), (1,))
+        put(e.e_lin0.weight, (UNITS, 1), (1, 1))
+        put(e.e_lin0.bias, (UNITS,), (1,))
+        for i in range(DEPTH):
+            lins = (e.v_lins1[i], e.v_lins2[i], e.v_lins3[i], e.v_lins4[i])
+            for q, lin in enumerate(lins):
+                specs.append((lin.weight, off + UNITS * q, (UNITS, UNITS), (1, 4 * UNITS)))
+            off += 4 * UNITS * UNITS
+            for q, lin in enumerate(lins):
+                specs.append((lin.bias, off + UNITS * q, (UNITS,), (1,)))
+            off += 4 * UNITS
+            put(e.e_lins0[i].weight, (UNITS, UNITS), (UNITS, 1))
+            put(e.e_lins0[i].bias, (UNITS,), (1,))
+            for bn in (e.v_bns[i].module, e.e_bns[i].module):
+                put(bn.weight, (UNITS,), (1,))
+                put(bn.bias, (UNITS,), (1,))
+        for lin in self.par_net_heu.lins:
+            put(lin.weight, tuple(lin.weight.shape), (lin.weight.shape[1], 1))
+            put(lin.bias, tuple(lin.bias.shape), (1,))
+        return specs, off
+
+    def flatten_parameters(self):
+        """Re-seat every parameter the kernels read as a VIEW of one flat f32 block in the training kernels' layout and return
+        that block as a single leaf nn.Parameter (the training step re-packed ~100 tensors with torch.cat every
+        step and autograd split the flat gradient back into ~100 pieces -- two hundred launches of a few microseconds each).
+        After this call
+          * the training forward hands the block to daco_gnn_train_forward as it is (no pack), the backward's flat gradient IS
+            the block's .grad, and every parameter's .grad is a view of it (set when the gradient arrives);
+          * an elementwise optimizer may be built on [block] alone -- `torch.optim.AdamW(net.train_parameters(), ...)` -- and is
+            then one fused update of one tensor: AdamW's update and decoupled weight decay are elementwise, so this is the
+            update `AdamW(net.parameters())` makes, element for element; clip_grad_norm_ over [block] is the same norm;
+          * state_dict / load_state_dict / eval-mode inference see the same module tree (load copies into the views).
+        Moving or casting the module afterwards (.to / .double / .cuda) gives the parameters storages of their own again: the
+        next training forward notices and raises; call flatten_parameters() again (and rebuild the optimizer).
+        Only for networks whose every covered parameter is trained (node_update=True, nothing frozen): AdamW leaves a parameter
+        without a gradient alone, a flat block cannot."""
+        e = self.emb_net
+        specs, total = self._flat_specs()
+        if not e.node_update or any(not p.requires_grad for p, _, _, _ in specs):
+            raise _lib.DacoError("Net.flatten_parameters: every parameter of the block must be trained (node_update=True, none "
+                                 "frozen): the optimizer's weight decay would move the ones the reference never touches")
+        if any(p.dtype != torch.float32 for p, _, _, _ in specs):
+            raise _lib.DacoError("Net.flatten_parameters: float32 parameters only")
+        with torch.no_grad():
+            flat = self.pack_params_train().detach().clone().contiguous()
+        assert flat.numel() == total, (flat.numel(), total)
+        for p, off, shape, stride in specs:
+            view = flat.as_strided(shape, stride, off)
+            assert torch.equal(view, p.data), "flat layout does not match the parameter"
+            p.data = view
+        block = nn.Parameter(flat)
+        self._flat_holder = [block, specs]          # (a list: not registered -- parameters() keeps listing the module tree only)
+
+        def spread(param):                          # the pieces of the flat gradient, where torch utilities look for them
+            g = param.grad
+            if g is not None:
+                for p, off, shape, stride in specs:
+                    p.grad = g.as_strided(shape, stride, off)
+        block.register_post_accumulate_grad_hook(spread)
+        self._packed = None
+        return block
+
+    def __deepcopy__(self, memo):
+        # (a copy's parameters get storages of their own: a flattened network is flattened again, on its own block)
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_flat_holder":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        if getattr(self, "_flat_holder", None) is not None:
+            new.flatten_parameters()
+        return new
+
+    def _flat_block(self):
+        """The flat block if flatten_parameters() was called and the parameters still are its views, else None."""
+        holder = getattr(self, "_flat_holder", None)
+        if holder is None:
+            return None
+        block, specs = holder
+        esz = block.element_size()
+        for p, off, _, _ in (specs[0], specs[len(specs) // 2], specs[-1]):
+            if p.data_ptr() != block.data_ptr() + off * esz or p.device != block.device:
+                raise _lib.DacoError("Net: the parameters no longer alias the block flatten_parameters() made (the module was "
+                                     "moved or cast afterwards): call flatten_parameters() again and rebuild the optimizer")
+        return block
+
+    def train_parameters(self):
+        """What to hand the optimizer: [the flat block] after flatten_parameters(), else the parameters that receive a gradient."""
+        block = self._flat_block()
+        return [block] if block is not None else [p for p in self.parameters() if p.requires_grad]
+
     @torch.no_grad()
     def _update_running_stats(self, stats, count_e, count_v):
         """BatchNorm1d's training-mode side effect, from the statistics the kernels report, as G successive reference forwards
@@ -353,7 +459,9 @@ class Net(nn.Module):
         n, feats = x.shape
         src, dst, rowptr, perm = _csr_graph(pyg, n, x.device)
         attr = pyg.edge_attr.float().contiguous().view(-1)
-        flat = self.pack_params_train()
+        flat = self._flat_block()
+        if flat is None or not torch.is_grad_enabled():
+            flat = self.pack_params_train() if flat is None else flat.detach()
         tracks, _ = self._bn_config()
         # BatchNorm1d normalises with the batch statistics in training mode -- and in eval mode too when it tracks none
         fixed = self._running_stats_block() if (not self.training and tracks) else None

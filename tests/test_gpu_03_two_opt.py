@@ -333,7 +333,9 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
 
 
 # ------------------------------------------------------------------ daco_tsp_nls: dirty-list sweeps, the whole NLS in one launch
-NLS_SHAPES = (("192", "3"), ("256", "3"), ("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"))     # threads per tour, entries per thread and round
+# threads per tour, entries per thread and round ("64" / "128": one / two wavefronts per tour, n <= 127 / 255 -- the training
+# step's tours; larger n falls through to the default choice)
+NLS_SHAPES = (("192", "3"), ("256", "3"), ("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"), ("64", "2"), ("128", "2"))
 
 
 @pytest.mark.parametrize("n,Tn,B,maxit", [(4, 3, 1, 50), (5, 4, 2, 50), (33, 6, 1, 1000), (129, 5, 2, 1000), (257, 4, 1, 30),
@@ -385,7 +387,8 @@ def _nls_case(B, n, A, seed, kind):
 
 @pytest.mark.parametrize("kind,B,n,A,maxt", [("dense", 2, 300, 24, 75), ("sparse", 2, 500, 16, 125), ("sparse", 1, 200, 40, 10000),
                                               ("learned", 2, 150, 32, 37), ("asym_dist", 2, 120, 24, 30), ("sym_hd", 1, 257, 12, 64),
-                                              ("dense", 3, 40, 20, 10), ("sparse", 1, 1000, 3, 250)])
+                                              ("dense", 3, 40, 20, 10), ("sparse", 1, 1000, 3, 250), ("learned", 4, 100, 30, 25),
+                                              ("sparse", 2, 127, 16, 31)])
 def test_fused_nls_equals_pass_by_pass_driver(kind, B, n, A, maxt, monkeypatch):
     """engine.nls_ fused (one launch of daco_tsp_nls per colony iteration) against the pass-by-pass driver over the
     round-2 kernels -- which test_nls_driver_matches_reference pins on the reference's output and the tests above on

@@ -275,6 +275,119 @@ def test_batched_training_step_on_device():
     assert float(c) < first               # the policy improved on the instances it trains on
 
 
+def test_flat_block_training_equals_the_parameter_list():
+    """Net.flatten_parameters on the device: the training forward takes the block as it is, the backward's flat gradient is the
+    block's .grad and every parameter's .grad a view of it -- the same heuristic and the same gradients as the network whose
+    parameters are packed with torch.cat every step (bit for bit: the same kernels on the same values)."""
+    import copy
+    from deepaco_amd import engine
+    from deepaco_amd.tsp_nls.net import Net
+    torch.manual_seed(21)
+    B, n, k = 3, 40, 8
+    net = Net().to(dev()).train()
+    ref = copy.deepcopy(net)
+    block = net.flatten_parameters()
+    coords = torch.rand(B, n, 2, device=dev())
+    _, ei, ea = engine.tsp_knn_graph(coords, k, want_dist=False)
+    x = torch.zeros(B, n, 1, device=dev())
+    x[:, 0] = 1.0
+    coef = torch.randn(B, n * k, device=dev())
+    monkey_env = os.environ.get("DACO_GNN_TRAIN_GATHER")
+    os.environ["DACO_GNN_TRAIN_GATHER"] = "1"                  # (CSR row sums: no f32 atomics, the backward is deterministic)
+    try:
+        heu = net.forward_batch_train(x, ei, ea, k_sparse=k)
+        torch.sum(heu * coef).backward()
+        heu_r = ref.forward_batch_train(x, ei, ea, k_sparse=k)
+        torch.sum(heu_r * coef).backward()
+    finally:
+        if monkey_env is None:
+            del os.environ["DACO_GNN_TRAIN_GATHER"]
+        else:
+            os.environ["DACO_GNN_TRAIN_GATHER"] = monkey_env
+    assert torch.equal(heu.detach(), heu_r.detach())
+    assert block.grad is not None and block.grad.shape == block.shape
+    gmax = max(float(q.grad.abs().max()) for q in ref.parameters() if q.grad is not None)
+    for (k1, p), (k2, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            continue
+        assert p.grad is not None, k1
+        assert block.grad.data_ptr() <= p.grad.data_ptr() < block.grad.data_ptr() + block.numel() * 4, k1
+        # (the weight gradients are sums of MFMA tiles flushed with f32 atomics: equal up to the order of a few additions)
+        torch.testing.assert_close(p.grad, q.grad, rtol=2e-5, atol=2e-6 * gmax, msg=k1)
+    for (k1, v), (k2, w) in zip(net.state_dict().items(), ref.state_dict().items()):
+        if "running_" in k1:
+            assert torch.equal(v, w), k1
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_trainer_draws_what_the_eager_step_draws(graph):
+    """pipeline.TspNlsTrainer (the step as one captured HIP graph; graph=False: the same step eagerly on the flat block) against
+    pipeline.train_tsp_nls_batch(..., seed, it = s) step by step.  With a learning rate of zero AdamW leaves the parameters where
+    they are, so every step is a function of (parameters, coordinates, seed, s) alone: the captured step s -- whose Philox
+    iteration counter lives in device memory and is advanced inside the graph -- must sample the tours of the eager step s:
+    the same mean costs, the same loss."""
+    import copy
+    from deepaco_amd.pipeline import TspNlsTrainer, train_tsp_nls_batch
+    from deepaco_amd.tsp_nls.net import Net
+    torch.manual_seed(31)
+    B, n, A, k = 4, 30, 12, 8
+    net = Net().to(dev())
+    eager_net = copy.deepcopy(net)
+    opt = torch.optim.AdamW(eager_net.parameters(), lr=0.0)
+    trainer = TspNlsTrainer(net, B, n, A, k, lr=0.0, seed=9, graph=graph)
+    gen = torch.Generator().manual_seed(4)
+    seen = []
+    for s in range(6):
+        coords = torch.rand(B, n, 2, generator=gen).to(dev())
+        loss_g, c_g, cls_g = (float(v) for v in trainer.step(coords))
+        loss_e, c_e, cls_e = (float(v) for v in train_tsp_nls_batch(eager_net, opt, coords, A, k, seed=9, it=s))
+        assert abs(c_g - c_e) <= 1e-6 * abs(c_e) and abs(cls_g - cls_e) <= 1e-6 * abs(cls_e), (s, c_g, c_e, cls_g, cls_e)
+        assert abs(loss_g - loss_e) <= 2e-4 * max(abs(loss_e), 1e-3), (s, loss_g, loss_e)
+        seen.append(c_g)
+    assert (trainer._graph is not None) == graph
+    assert int(trainer.it_dev) == 6
+    assert len(set(seen)) == 6                                         # (fresh instances and fresh draws every step)
+    # the same coordinates twice: the counter advanced, the tours differ
+    again = [float(trainer.step(coords)[1]) for _ in range(2)]
+    assert again[0] != again[1]
+    for p, q in zip(net.parameters(), eager_net.parameters()):         # lr = 0: nobody moved
+        assert torch.equal(p.detach(), q.detach())
+
+
+def test_trainer_captured_steps_train():
+    """The captured step with a real learning rate: parameters move (through the block: the module tree's views follow), the
+    running statistics advance, local search only lowers costs, and a dozen steps on the same instances lower their sampled
+    cost -- what test_batched_training_step_on_device asks of the eager step."""
+    from deepaco_amd.pipeline import TspNlsTrainer
+    from deepaco_amd.tsp_nls.net import Net
+    torch.manual_seed(11)
+    net = Net().to(dev())
+    before = [p.detach().clone() for p in net.parameters()]
+    rm_before = net.emb_net.e_bns[3].module.running_mean.clone()
+    trainer = TspNlsTrainer(net, 6, 30, 16, 8, lr=1e-3, seed=5, graph=True)
+    coords = torch.rand(6, 30, 2, device=dev())
+    first = None
+    for step in range(12):
+        loss, c, c_ls = trainer.step(coords)
+        assert torch.isfinite(loss) and float(c_ls) <= float(c) + 1e-5
+        first = float(c) if first is None else first
+    assert trainer._graph is not None
+    changed = sum(int(not torch.equal(a, b.detach())) for a, b in zip(before, net.parameters()))
+    assert changed > 100
+    assert not torch.equal(rm_before, net.emb_net.e_bns[3].module.running_mean)
+    assert int(net.emb_net.e_bns[3].module.num_batches_tracked) == 12 * 6
+    assert float(c) < first
+    assert torch.equal(net.pack_params_train().detach(), trainer.block.detach())
+    # eval-mode inference sees the trained values (the folded block is rebuilt from the views' version counter)
+    net.eval()
+    from deepaco_amd import engine
+    _, ei, ea = engine.tsp_knn_graph(coords, 8, want_dist=False)
+    x = torch.zeros(6, 30, 1, device=dev())
+    x[:, 0] = 1.0
+    h1 = net.forward_batch(x, ei, ea, k_sparse=8)
+    assert torch.isfinite(h1).all()
+
+
 @pytest.mark.parametrize("name", ["g5_net_tsp_tsp100", "g5_net_tsp_tsp20", "g5_net_tsp_nls_tsp100"])
 def test_batched_graph_construction_matches_reference(name):
     """daco_tsp_knn_graph (one launch for a batch) == the reference's gen_pyg_data on captured instances."""

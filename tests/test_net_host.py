@@ -130,3 +130,72 @@ def test_attached_merged_graph_is_taken_only_while_it_describes_the_tensor():
     after = _merge_graphs(x, ei, ea, k_sparse=k)
     assert after.edge_index is not None and int(after._daco_graph[1][0]) == int(ei[0, 1, 0])
     assert getattr(ei[:2], "_daco_csr", None) is None                           # (a slice is a new tensor object: nothing rides on it)
+
+
+def _tree_forward(net, x, ei, ea):
+    return net.par_net_heu(net.emb_net(x, ei, ea))
+
+
+def test_flatten_parameters_views_of_one_block():
+    """Net.flatten_parameters (round 6): every parameter the kernels read becomes a view of ONE flat block in the training
+    kernels' layout.  Held here on the CPU (the method is torch only): the values and the module tree's output do not move, the
+    block equals what pack_params_train packs, an optimizer on the block alone updates the module's parameters -- AdamW is
+    elementwise, so exactly as AdamW over the parameter list does --, a checkpoint loads INTO the views, and a cast afterwards is
+    noticed."""
+    import copy
+    from deepaco_amd import _lib
+    from deepaco_amd.tsp_nls.net import Net
+    torch.manual_seed(5)
+    net = Net()
+    ref = copy.deepcopy(net)
+    n, k = 12, 4
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand(n, 1, generator=gen)
+    src = torch.repeat_interleave(torch.arange(n), k)
+    dst = torch.randint(0, n, (n * k,), generator=gen)
+    ei, ea = torch.stack([src, dst]), torch.rand(n * k, 1, generator=gen)
+    before = _tree_forward(net.train(), x, ei, ea).detach().clone()
+    packed = net.pack_params_train().detach().clone()
+    sd_before = {k_: v.clone() for k_, v in net.state_dict().items()}
+    block = net.flatten_parameters()
+    assert block.is_leaf and block.requires_grad and torch.equal(block.detach(), packed)
+    assert net.train_parameters() == [block] or (len(net.train_parameters()) == 1 and net.train_parameters()[0] is block)
+    assert all(torch.equal(v, sd_before[k_]) for k_, v in net.state_dict().items())
+    assert len(list(net.parameters())) == len(list(ref.parameters()))          # the block is not listed twice
+    covered = sum(p.numel() for p, _, _, _ in net._flat_specs()[0])
+    assert covered == block.numel()
+    lo, hi = block.data_ptr(), block.data_ptr() + block.numel() * 4
+    inside = [lo <= p.data_ptr() < hi for p in net.parameters() if p.numel()]
+    assert sum(inside) == len(net._flat_specs()[0])                             # (par_net_phe: none in tsp_nls)
+    torch.testing.assert_close(_tree_forward(net, x, ei, ea), before, rtol=0, atol=0)
+    assert torch.equal(net.pack_params_train().detach(), block.detach())
+
+    # one AdamW step on the block == one AdamW step on the parameter list, element for element
+    coef = torch.randn(n * k, generator=gen)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    torch.sum(_tree_forward(ref.train(), x, ei, ea) * coef).backward()
+    opt_ref.step()
+    opt = torch.optim.AdamW(net.train_parameters(), lr=1e-2)
+    # (on the CPU the gradient of the block comes from the reference net's parameter gradients, packed the same way)
+    gparts = copy.deepcopy(ref)
+    for p, q in zip(gparts.parameters(), ref.parameters()):
+        p.data = q.grad.clone() if q.grad is not None else torch.zeros_like(q)
+    block.grad = gparts.pack_params_train().detach().clone()
+    opt.step()
+    for (k1, p), (k2, q) in zip(net.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=1e-6, atol=1e-7, msg=k1)
+    assert torch.equal(net.pack_params_train().detach(), block.detach())        # the views moved with the block
+
+    # a checkpoint loads into the views; the block follows
+    net.load_state_dict(sd_before)
+    assert torch.equal(block.detach(), packed)
+    assert net._flat_block() is block
+    # frozen parameters / the variant without node updates cannot be flattened; a cast breaks the aliasing and is noticed
+    net.double()
+    with pytest.raises(_lib.DacoError):
+        net._flat_block()
+    frozen = Net()
+    frozen.freeze_gnn()
+    with pytest.raises(_lib.DacoError):
+        frozen.flatten_parameters()
