@@ -1122,15 +1122,50 @@ def extra_configs(dev, headline_colony, cpu=True):
                   "sample": f"{done_i} instances, one after the other as tsp_nls/train.py:52-60 runs them, {busy:.1f} s: the module tree of "
                             f"tsp_nls/net.py as torch CPU ops with autograd, oracle/torch_port.rollout with log-probabilities, the NLS through "
                             f"the C restatement of two_opt.py (the reference: numba), AdamW; {min(8, ncpu)} intra-op threads"}
+        # round 6: the same step on the flat parameter block (Net.flatten_parameters: no torch.cat of ~100 tensors and no split of
+        # the flat gradient per step) eagerly, and as ONE captured HIP graph (pipeline.TspNlsTrainer) -- the value of this entry
+        from deepaco_amd.pipeline import TspNlsTrainer
+
+        def time_trainer(Bq, nq, Aq, kq, graph, steps_q):
+            torch.manual_seed(0)
+            tr = TspNlsTrainer(TrainNet().to(dev), Bq, nq, Aq, kq, lr=3e-4, seed=1, graph=graph)
+            cs = [torch.rand(Bq, nq, 2, device=dev) for _ in range(4)]
+            for s_ in range(4):
+                tr.step(cs[s_])
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for s_ in range(steps_q):
+                last = tr.step(cs[s_ % 4])
+            torch.cuda.synchronize()
+            dt_ = (time.perf_counter() - t0_) / steps_q
+            ok = bool(all(torch.isfinite(p_).all() for p_ in tr.net.parameters()))
+            return {"ms_per_step": dt_ * 1e3, "instances_per_s": Bq / dt_, "loss": float(last[0]), "mean_cost": float(last[1]),
+                    "mean_cost_after_nls": float(last[2]), "parameters_finite": ok}
+        flat_e = time_trainer(Bt, nt, At, kt, False, 20)
+        flat_g = time_trainer(Bt, nt, At, kt, True, 40)
         out["train_step_tsp100_b20_a30"] = {
             "workload": f"one optimisation step of tsp_nls/train.py: {Bt} instances of TSP-{nt}, {At} ants, k = {kt}, NLS, AdamW",
-            "value": Bt / dts, "unit": "instances/s", "ms_per_step": dts * 1e3,
-            "stage_ms": {"graph_and_network_forward": stage_ms[0], "construction_with_log_probs": stage_ms[1],
-                         "costs_and_local_search": stage_ms[2], "loss_and_backward": stage_ms[3], "clip_and_optimizer": stage_ms[4]},
-            "note": "every stage is launch-bound at this size (a TSP-100 graph has 1 000 edges: the twelve layers' kernels take a few "
-                    "microseconds each); profiles/r05_kernel_stats_train.csv lists the kernels of a step",
+            "value": flat_g["instances_per_s"], "unit": "instances/s", "ms_per_step": flat_g["ms_per_step"],
+            "captured_hip_graph": flat_g, "eager_flat_block": flat_e,
+            "eager_parameter_list": {"ms_per_step": dts * 1e3, "instances_per_s": Bt / dts},
+            "stage_ms_eager_parameter_list": {"graph_and_network_forward": stage_ms[0], "construction_with_log_probs": stage_ms[1],
+                                              "costs_and_local_search": stage_ms[2], "loss_and_backward": stage_ms[3],
+                                              "clip_and_optimizer": stage_ms[4]},
+            "note": "value = the step as one captured HIP graph on the flat parameter block (pipeline.TspNlsTrainer); the eager step on "
+                    "the parameter list is what round 5 measured.  profiles/r06_kernel_stats_train_graph_tsp100.csv lists a step's kernels "
+                    "(~330 launches: the NLS kernel a third of the time, the twelve layers' backward kernels most of the rest)",
             "cpu_baseline": cb}
         del tnet, opt
+        # tsp/train.ipynb's size (TSP-500, 50 ants, k = 50) with the NLS as local search, 8 instances per step
+        try:
+            out["train_step_tsp500_b8_a50"] = {
+                "workload": "one optimisation step: 8 instances of TSP-500, 50 ants, k = 50 (tsp/train.ipynb:245-251's size), NLS, AdamW",
+                "unit": "instances/s", "captured_hip_graph": time_trainer(8, 500, 50, 50, True, 10),
+                "eager_flat_block": time_trainer(8, 500, 50, 50, False, 10)}
+            out["train_step_tsp500_b8_a50"]["value"] = out["train_step_tsp500_b8_a50"]["captured_hip_graph"]["instances_per_s"]
+            out["train_step_tsp500_b8_a50"]["ms_per_step"] = out["train_step_tsp500_b8_a50"]["captured_hip_graph"]["ms_per_step"]
+        except Exception as e:
+            out["train_step_tsp500_b8_a50"] = {"error": repr(e)}
     except Exception as e:
         out["train_step_tsp100_b20_a30"] = {"error": repr(e)}
 

@@ -47,6 +47,25 @@ __device__ inline const uint16_t *nbr_rk(const unsigned char *tab, int n) {
 }
 
 
+// ------------------------------------------------------------------ zero fill as a kernel
+// (instead of hipMemsetAsync: a captured HIP graph then consists of kernel nodes only -- the training step captured by
+// pipeline.TspNlsTrainer came back with NaN gradients while its accumulators were cleared by memset nodes -- and dozens of
+// per-instance memsets become one launch.)  `count` blocks of `bytes` bytes (a multiple of 4, the blocks 4-byte aligned),
+// `stride` bytes apart.
+template <int UNUSED = 0>
+__global__ void __launch_bounds__(256) zero_blocks_kernel(unsigned char *base, size_t stride, size_t bytes) {
+  uint32_t *p = reinterpret_cast<uint32_t *>(base + (size_t)blockIdx.y * stride);
+  const size_t words = bytes >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+inline hipError_t zero_async(void *ptr, size_t bytes, hipStream_t s, int count = 1, size_t stride = 0) {
+  if (bytes == 0 || count <= 0) return hipSuccess;
+  size_t blocks = ((bytes >> 2) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((zero_blocks_kernel<0>), dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, s, (unsigned char *)ptr, stride, bytes);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ DPP helpers
 template <int CTRL, int ROW_MASK, bool BOUND>
 __device__ inline float dpp_f(float old, float src) {

@@ -61,9 +61,12 @@ __device__ inline Stat load_stat(const float2 *tab, int g, int c, int /*count*/)
   return Stat{t.x, t.y};
 }
 // forward table: (mean, rstd); backward table: (sum(g_y) / count, sum(g_y * zhat) / count)
-__global__ void gnn_t_stat_table(int G, int count, const double *sums, float2 *tab, int backward) {
+// (the edge and the node BatchNorm of a layer in one launch: their sums and their tables are neighbours in memory; the first
+// G * 32 entries count `count_e` rows each, the next G * 32 `count_v`)
+__global__ void gnn_t_stat_table(int G, int count_e, int count_v, const double *sums, float2 *tab, int backward) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G * 32) return;
+  if (idx >= 2 * G * 32) return;
+  const int count = idx < G * 32 ? count_e : count_v;
   const double s = sums[(size_t)idx * 2], q = sums[(size_t)idx * 2 + 1];
   if (backward) { tab[idx] = make_float2((float)(s / count), (float)(q / count)); return; }
   const double m = s / count;
@@ -74,10 +77,11 @@ __global__ void gnn_t_stat_table(int G, int count, const double *sums, float2 *t
 
 // BatchNorm in evaluation mode (running statistics, the same for every graph): (mean, 1 / sqrt(var + eps)) from the caller's
 // [32][2] (mean, var) block into the table of all G graphs
+// (both BatchNorms of a layer: fixed = [2 (e, v)][32][2])
 __global__ void gnn_t_fixed_table(int G, const float *fixed, float2 *tab) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G * 32) return;
-  const int c = idx & 31;
+  if (idx >= 2 * G * 32) return;
+  const int c = (idx & 31) + (idx >= G * 32 ? 32 : 0);
   tab[idx] = make_float2(fixed[c * 2], (float)(1.0 / sqrt((double)fixed[c * 2 + 1] + (double)BN_EPS)));
 }
 
@@ -396,7 +400,7 @@ __device__ inline float bn_bwd(float gout, float z, const Stat &st, float gamma,
 // node side: g_zv -> gX[:, 0:32] (x1 block) and g_msg = g_zv / degree; BatchNorm parameter gradients
 __global__ void __launch_bounds__(256)
 gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const float *beta, const float2 *fsums,
-                     const float2 *bsums, const float *zv, const float *gx, float *gX, float *gmsg) {
+                     const float2 *bsums, const float *zv, const float *gx, float *gX, float *gmsg, int clear_rest) {
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
   const int i = blockIdx.x * 8 + il;
   if (i >= n) return;
@@ -404,6 +408,7 @@ gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const
   const Stat st = load_stat(fsums, g, o, ng);
   const float gz = bn_bwd(gx[(size_t)i * TU + o], zv[(size_t)i * TU + o], st, gamma[o], beta[o], bsums, g, o, ng);
   gX[(size_t)i * 128 + o] = gz;
+  if (clear_rest) { gX[(size_t)i * 128 + 32 + o] = 0.0f; gX[(size_t)i * 128 + 64 + o] = 0.0f; gX[(size_t)i * 128 + 96 + o] = 0.0f; }
   gmsg[(size_t)i * TU + o] = gz / (float)max(rowptr[i + 1] - rowptr[i], 1);
 }
 
@@ -622,9 +627,12 @@ gnn_t_node_lin_bwd(int n, const float *WT, const float *x0, const float *gX, flo
 }
 
 // BatchNorm parameter gradients from the backward sums: d/dgamma = sum(g_y * zhat), d/dbeta = sum(g_y), over graphs
-__global__ void gnn_t_bn_param_grad(int G, const double *bsums, float *ggamma, float *gbeta) {
+// (block 0: the edge BatchNorm, block 1: the node BatchNorm, whose sums follow the edge's)
+__global__ void gnn_t_bn_param_grad(int G, const double *bsums_e, float *ggamma_e, float *gbeta_e, float *ggamma_v, float *gbeta_v) {
   const int c = threadIdx.x;
   if (c >= 32) return;
+  const double *bsums = bsums_e + (blockIdx.x ? (size_t)G * 64 : 0);
+  float *ggamma = blockIdx.x ? ggamma_v : ggamma_e, *gbeta = blockIdx.x ? gbeta_v : gbeta_e;
   double a = 0.0, b = 0.0;
   for (int g = 0; g < G; ++g) { b += bsums[((size_t)g * 32 + c) * 2]; a += bsums[((size_t)g * 32 + c) * 2 + 1]; }
   ggamma[c] = (float)a; gbeta[c] = (float)b;
@@ -699,7 +707,7 @@ struct TrainWs {
   float *gx, *gw, *gX, *gmsg;
   float *c2buf, *gzbuf;   // [E][32] per-edge contributions of the layer being differentiated (gather path)
   int *csr_rowptr, *csr_perm, *csr_cursor;   // destination CSR built by the backward when the caller passes none
-  double *bsums;   // [2][G][32][2]
+  double *bsums;   // [12][2][G][32][2]
   size_t total;
 };
 static TrainWs carve(void *base, int n, int E, int G) {
@@ -724,7 +732,7 @@ static TrainWs carve(void *base, int n, int E, int G) {
   t.csr_rowptr = (int *)take((size_t)(n + 1) * 4);
   t.csr_perm = (int *)take((size_t)E * 4);
   t.csr_cursor = (int *)take((size_t)n * 4);
-  t.bsums = (double *)take((size_t)2 * G * 32 * 2 * 8);
+  t.bsums = (double *)take((size_t)12 * 2 * G * 32 * 2 * 8);   // per layer (cleared once per backward)
   t.total = (size_t)(p - (char *)base);
   return t;
 }
@@ -758,7 +766,7 @@ extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int
   const int ng = n / G, Eg = E / G;
   const int node_blocks = (n + 7) / 8, tile_blocks = (E + 127) / 128;
   const unsigned ew_blocks = (unsigned)(((long)E * 32 + 255) / 256);
-  if (hipMemsetAsync(t.fsums, 0, (size_t)12 * 2 * G * 32 * 2 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+  if (zero_async(t.fsums, (size_t)12 * 2 * G * 32 * 2 * 8, s) != hipSuccess) { set_error("zero fill failed"); return DACO_E_HIP; }
   hipLaunchKernelGGL(gnn_t_node_init, dim3(node_blocks), dim3(256), 0, s, n, feats, x, params, t.a0, t.x[0], t.X[0]);
   hipLaunchKernelGGL(gnn_t_edge_init, dim3(ew_blocks), dim3(256), 0, s, E, feats, edge_attr, params, t.w[0]);
   for (int l = 0; l < 12; ++l) {
@@ -766,15 +774,13 @@ extern "C" int daco_gnn_train_forward(void *stream, int n, int E, int feats, int
     const float *We = lp + 32 * 128 + 128, *be = We + 1024, *gv = be + 32, *bv_ = gv + 32, *ge = bv_ + 32, *bee = ge + 32;
     double *fe = t.fsums + ((size_t)l * 2 + 0) * G * 64, *fv = t.fsums + ((size_t)l * 2 + 1) * G * 64;
     float2 *fte = t.ftab + ((size_t)l * 2 + 0) * G * 32, *ftv = t.ftab + ((size_t)l * 2 + 1) * G * 32;
-    const unsigned tb = (unsigned)((G * 32 + 255) / 256);
+    const unsigned tb = (unsigned)((2 * G * 32 + 255) / 256);
     hipLaunchKernelGGL(gnn_t_edge_pre, dim3(tile_blocks), dim3(256), 0, s, E, Eg, src, dst, We, be, t.X[l], t.w[l], t.ze[l], fe);
     hipLaunchKernelGGL(gnn_t_node_pre, dim3(node_blocks), dim3(256), 0, s, n, ng, dst, rowptr, perm, t.X[l], t.w[l], t.zv[l], fv);
     if (fixed_stats) {   // evaluation-mode BatchNorm: the caller's running statistics ([12][2 (e, v)][32][2 (mean, var)])
-      hipLaunchKernelGGL(gnn_t_fixed_table, dim3(tb), dim3(256), 0, s, G, fixed_stats + ((size_t)l * 2 + 0) * 64, fte);
-      hipLaunchKernelGGL(gnn_t_fixed_table, dim3(tb), dim3(256), 0, s, G, fixed_stats + ((size_t)l * 2 + 1) * 64, ftv);
+      hipLaunchKernelGGL(gnn_t_fixed_table, dim3(tb), dim3(256), 0, s, G, fixed_stats + (size_t)l * 2 * 64, fte);
     } else {
-      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, fe, fte, 0);
-      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, fv, ftv, 0);
+      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, ng, fe, fte, 0);      // (fv / ftv follow fe / fte)
     }
     hipLaunchKernelGGL(gnn_t_edge_post, dim3(ew_blocks), dim3(256), 0, s, E, Eg, ge, bee, fte, t.w[l], t.ze[l], t.w[l + 1]);
     const float *WTn = l < 11 ? params + t_off_layer(feats, l + 1) : nullptr;
@@ -804,13 +810,14 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
   const int etiles = (E + 31) / 32, ntiles = (n + 31) / 32;
   const int egrid = etiles / 4 + 1 < 1024 ? etiles / 4 + 1 : 1024, ngrid = ntiles / 4 + 1 < 512 ? ntiles / 4 + 1 : 512;
   const size_t pfloats = t_off_head(feats) + 2 * (1024 + 32) + 32 + 1;
-  if (hipMemsetAsync(grad_params, 0, pfloats * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
-  if (hipMemsetAsync(t.gx, 0, (size_t)n * 32 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+  // (kernels, not memset nodes: daco_device.h zero_async)
+  if (zero_async(grad_params, pfloats * 4, s) != hipSuccess || zero_async(t.gx, (size_t)n * 32 * 4, s) != hipSuccess ||
+      zero_async(t.bsums, (size_t)12 * 2 * G * 64 * 8, s) != hipSuccess) { set_error("zero fill failed"); return DACO_E_HIP; }
   const bool caller_csr = rowptr_dst && perm_dst;
   const int force_gather = getenv("DACO_GNN_TRAIN_GATHER") ? atoi(getenv("DACO_GNN_TRAIN_GATHER")) : -1;   // read per call
   const bool use_gather = force_gather >= 0 ? force_gather != 0 : (E >= 100000 || caller_csr);
   if (use_gather && !caller_csr) {
-    if (hipMemsetAsync(t.csr_cursor, 0, (size_t)n * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    if (zero_async(t.csr_cursor, (size_t)n * 4, s) != hipSuccess) { set_error("zero fill failed"); return DACO_E_HIP; }
     hipLaunchKernelGGL(csr_count_kernel, dim3((E + 255) / 256), dim3(256), 0, s, E, dst, t.csr_cursor);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, n, t.csr_cursor, t.csr_rowptr, t.csr_cursor);
     hipLaunchKernelGGL(csr_fill_kernel, dim3((E + 255) / 256), dim3(256), 0, s, E, dst, t.csr_cursor, t.csr_perm);
@@ -825,33 +832,30 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
     const float *WT = lp, *We = lp + 32 * 128 + 128, *gv = We + 1024 + 32, *bv_ = gv + 32, *ge = bv_ + 32, *bee = ge + 32;
     float *glp = grad_params + t_off_layer(feats, l);
     float *gWT = glp, *gbv = glp + 32 * 128, *gWe = gbv + 128, *gbe = gWe + 1024, *ggv = gbe + 32, *gbv_ = ggv + 32, *gge = gbv_ + 32, *gbee = gge + 32;
-    double *be_s = t.bsums, *bv_s = t.bsums + (size_t)G * 64;
-    if (hipMemsetAsync(t.bsums, 0, (size_t)2 * G * 64 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    double *be_s = t.bsums + (size_t)l * 2 * G * 64, *bv_s = be_s + (size_t)G * 64;
     // the gather path pays four small CSR kernels per call and one gather launch per layer: it wins from ~100 k edges
     // (8 x TSP-500: edge_bwd 508 -> 303 + 47 us per layer); below, the f32 atomics are cheaper.  DACO_GNN_TRAIN_GATHER=0/1 forces.
     const bool gather = use_gather;
-    if (!gather && hipMemsetAsync(t.gX, 0, (size_t)n * 128 * 4, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+    // (atomics path: node_bwd_apply writes the x1 block of every row of gX and clears the three blocks the edges add into)
     const float2 *fte = t.ftab + ((size_t)l * 2 + 0) * G * 32, *ftv = t.ftab + ((size_t)l * 2 + 1) * G * 32;
     float2 *bte = t.btab, *btv = t.btab + (size_t)G * 32;
-    const unsigned tb = (unsigned)((G * 32 + 255) / 256);
+    const unsigned tb = (unsigned)((2 * G * 32 + 255) / 256);
     hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((E + 255) / 256), dim3(256), 0, s, E, Eg, ge, bee, fte, t.ze[l], t.gw, be_s);
     hipLaunchKernelGGL(gnn_t_bwd_stats, dim3((n + 255) / 256), dim3(256), 0, s, n, ng, gv, bv_, ftv, t.zv[l], t.gx, bv_s);
     if (fixed_stats) {   // the statistics were constants of the forward: g_z = gamma * rstd * g_y, no batch terms
-      if (hipMemsetAsync(t.btab, 0, (size_t)2 * G * 32 * 8, s) != hipSuccess) { set_error("memset failed"); return DACO_E_HIP; }
+      if (l == 11 && zero_async(t.btab, (size_t)2 * G * 32 * 8, s) != hipSuccess) { set_error("zero fill failed"); return DACO_E_HIP; }   // (nobody writes it in this mode)
     } else {
-      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, be_s, bte, 1);
-      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, ng, bv_s, btv, 1);
+      hipLaunchKernelGGL(gnn_t_stat_table, dim3(tb), dim3(256), 0, s, G, Eg, ng, be_s, bte, 1);    // (bv_s / btv follow be_s / bte)
     }
     hipLaunchKernelGGL(gnn_t_node_bwd_apply, dim3(node_blocks), dim3(256), 0, s, n, ng, rowptr, gv, bv_, ftv, btv, t.zv[l], t.gx,
-                       t.gX, t.gmsg);
+                       t.gX, t.gmsg, gather ? 0 : 1);
     hipLaunchKernelGGL(gnn_t_edge_bwd, dim3(egrid), dim3(256), 0, s, E, Eg, src, dst, We, ge, bee, fte, bte, t.X[l], t.w[l], t.ze[l],
                        t.gmsg, t.gw, t.gX, gWe, gbe, gather ? t.c2buf : nullptr, gather ? t.gzbuf : nullptr);
     if (gather)
       hipLaunchKernelGGL(gnn_t_gather_bwd, dim3(node_blocks), dim3(256), 0, s, n, rowptr, perm, rowptr_dst, perm_dst, t.c2buf,
                          t.gzbuf, t.gX);
     hipLaunchKernelGGL(gnn_t_node_lin_bwd, dim3(ngrid), dim3(256), 0, s, n, WT, t.x[l], t.gX, t.gx, gWT, gbv);
-    hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, be_s, gge, gbee);
-    hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(1), dim3(64), 0, s, G, bv_s, ggv, gbv_);
+    hipLaunchKernelGGL(gnn_t_bn_param_grad, dim3(2), dim3(64), 0, s, G, be_s, gge, gbee, ggv, gbv_);
   }
   hipLaunchKernelGGL(gnn_t_node_init_bwd, dim3(node_blocks < 128 ? node_blocks : 128), dim3(256), 0, s, n, feats, x, t.a0, t.gx,
                      grad_params, grad_params + 32 * feats);

@@ -418,7 +418,15 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   // (the sweeps are bound by instruction issue once the device is full: three wavefronts per tour walk a sweep's ~850 entries in
   // two rounds like four do, with a quarter less of the per-wave work -- scans, reductions, the dirty tests' set-up; measured on
   // config 3: 128 / 192 / 256 / 320 / 384 threads -> 48.1 / 42.1 / 45.8 / 70.0 / 76.8 ms)
-  int nt = (long)B * T <= 512 ? 1024 : ((long)B * T <= 1536 ? 512 : (n + 1 <= 576 ? 192 : 256));
+  // Round 6 (tools/sweep_nls_threads.py, profiles/r06_sweep_nls_threads.txt): as many threads as a sweep has lists to walk -- about
+  // n -- while the launch's threads fit the device (256 CUs x 1024), else fewer: 48 tours of TSP-200 / 500 / 1000 -> 256 / 512 /
+  // 1024 threads (1.70 / 4.33 / 16.0 ms; the old rule's 1024 everywhere: 2.21 / 4.56 / 16.0), 400 tours of TSP-500 -> 512 (5.45 ms
+  // against 8.95 with 1024), 600 tours of TSP-100 -> 256 (1.45 against 1.55 with 512), 1 024 tours of TSP-500 -> 256 (6.98 against
+  // 10.2 with 512); from a few thousand tours on 192 / 256 as before.
+  const long ntours = (long)B * T, cap = 262144 / ntours;
+  int nt = n <= 256 ? 256 : (n <= 512 ? 512 : 1024);
+  while (nt > 256 && nt > cap) nt >>= 1;
+  if (nt == 256 && cap < 128 && n + 1 <= 576) nt = 192;
   if (const char *ev = getenv("DACO_NLS_THREADS")) nt = atoi(ev);
   const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)np2 * 8 * 2 + 24 * 8 + (size_t)(np2 + 2) * 4 + 32 * 4 + (size_t)np2 * 2 + 16;
   // threads per tour: 256 when there are tours to fill the device several times over (a CU then interleaves six of them),

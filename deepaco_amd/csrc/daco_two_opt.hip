@@ -643,7 +643,7 @@ extern "C" int daco_two_opt_auto(void *stream, int B, int T, int n, const float 
   if (n > 1024) { set_error("daco_two_opt_auto: n=%d above 1024", n); return DACO_E_TOOLARGE; }
   if (max_iterations >= TWO_OPT_DONE) max_iterations = TWO_OPT_DONE - 1;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sweeps, 0, (size_t)B * T * sizeof(int32_t), s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+  if (zero_async(sweeps, (size_t)B * T * sizeof(int32_t), s) != hipSuccess) { set_error("clearing the sweep counts failed"); return DACO_E_HIP; }
   // measured crossovers at n = 500 (tools/bench_two_opt_nbr.py, profiles/r02_two_opt_nbr.txt): the dense kernel's cost grows with
   // the length of the reversed segment, the candidate kernel's with the list entries it walks.  Symmetric matrix (every
   // entry is one candidate; repairs reverse long segments): the dense kernel wins from ~40 k entries per sweep; the 20

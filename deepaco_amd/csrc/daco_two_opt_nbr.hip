@@ -381,8 +381,7 @@ extern "C" int daco_two_opt_prepare(void *stream, int B, int n, const float *dis
   hipStream_t s = (hipStream_t)stream;
   const size_t stride = nbr_instance_bytes(n);
   unsigned char *tabs = (unsigned char *)tables;
-  for (int b = 0; b < B; ++b)
-    if (hipMemsetAsync(tabs + (size_t)b * stride, 0, NBR_HEADER, s) != hipSuccess) { set_error("hipMemsetAsync failed"); return DACO_E_HIP; }
+  if (zero_async(tabs, NBR_HEADER, s, B, stride) != hipSuccess) { set_error("daco_two_opt_prepare: clearing the headers failed"); return DACO_E_HIP; }
   int P2 = 4;
   while (P2 < n) P2 <<= 1;
   hipLaunchKernelGGL(nbr_maxabs_kernel, dim3(16, B), dim3(256), 0, s, n, dist, dist_bstride, tabs, stride);

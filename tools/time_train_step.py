@@ -24,7 +24,8 @@ for key, (B, n, A, k) in shapes.items():
         continue
     res = {"workload": f"tsp_nls training step, {B} instances x TSP-{n} x {A} ants (k = {k}), NLS"}
     batches = [torch.rand(B, n, 2, device=dev) for _ in range(4)]
-    for mode in ("eager_list", "eager_flat", "graph"):
+    modes = tuple(os.environ.get("TRAIN_MODES", "eager_list,eager_flat,graph").split(","))
+    for mode in modes:
         torch.manual_seed(0)
         net = Net().to(dev)
         if mode == "eager_list":
@@ -42,7 +43,8 @@ for key, (B, n, A, k) in shapes.items():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         res[mode] = {"ms_per_step": round(dt * 1e3, 4), "instances_per_s": round(B / dt, 1), "loss": float(loss),
-                     "mean_cost": float(c), "mean_cost_nls": float(c_ls)}
+                     "mean_cost": float(c), "mean_cost_nls": float(c_ls),
+                     "parameters_finite": bool(all(torch.isfinite(p).all() for p in net.parameters()))}
     out[f"tsp{n}"] = res
     print(json.dumps(res), flush=True)
 if os.environ.get("DACO_NLS_THREADS"):
