@@ -515,12 +515,22 @@ __device__ inline void hgs_apply(HgsCtx &c, int mv, int U, int V) {
   if (!intra) hgs_update_route(c, rV);
 }
 
-template <int WAVES, int WPS>
+// LM (round 6, "latency mode"): a launch of FEW solutions -- the reference's own calling pattern hands the local search the 8
+// best ants of ONE instance per iteration (cvrp_nls/aco.py:143-146) -- has one wavefront alone on its SIMD and nothing to overlap:
+// a round is a chain of instruction latency and four or five dependent trips to the L2 for matrix entries (3.7 us per round, 7.2 ms
+// for eight solutions of CVRP-100 against ~3 ms for the reference's eight thread-pool tasks).  Here a workgroup is one
+// wavefront that keeps the stage's float64 matrix (n^2 x 8 bytes: 82 KB at n = 101) and the demands in LDS next to its state, so
+// those trips are LDS gathers; an asymmetric matrix keeps its transpose in global memory (the two do not fit together).  The
+// arithmetic, the order of evaluation and every decision are the kernel's above: the routes are the same.
+template <int WAVES, int WPS, bool LM = false>
 __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams p) {
+  static_assert(!LM || WAVES == 1, "latency mode: one wavefront per workgroup");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = p.n, nc = n - 1;
   const size_t per_wave = hgs_lds_bytes(n, p.Rmax);
+  double *mat_lds = reinterpret_cast<double *>(lds_raw + per_wave);          // LM: [n][n], then the demands [n]
+  double *dem_lds = mat_lds + (size_t)n * n;
   HgsCtx c;
   c.l = hgs_carve(lds_raw + (size_t)wave * per_wave, n, p.Rmax);
   c.n = n; c.nc = nc; c.lane = lane; c.cap = p.cap;
@@ -545,6 +555,10 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
     const int b = item / p.A, a = item - b * p.A;
     int64_t *col = p.paths + (size_t)b * p.Lmax * p.A + a;
     c.dem = p.demand + (size_t)b * n;
+    if constexpr (LM) {
+      for (int i = lane; i < n; i += 64) dem_lds[i] = c.dem[i];
+      c.dem = dem_lds;
+    }
     c.fail = 0;
 
     // ---- the routes of the input (cvrp_nls/aco.py:12-20 get_subroutes: the non-empty pieces between zeros)
@@ -620,6 +634,14 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
       const uint16_t *tent = reinterpret_cast<const uint16_t *>(tab + lay.ent);
       c.tc = sg.tc + (size_t)b * sg.bstride;
       c.tct = sg.tct + (size_t)b * sg.bstride;
+      if constexpr (LM) {
+        const double *src = c.tc;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n * n; i += 64) mat_lds[i] = src[i];
+        __threadfence_block();
+        if (sg.tct == sg.tc) c.tct = mat_lds;
+        c.tc = mat_lds;
+      }
       R = c.R;
       // Params: scale checks, penalty (Params.cpp:106-118)
       const double maxDist = hdr->maxDist;
@@ -908,11 +930,29 @@ extern "C" int daco_hgs_local_search(void *stream, int B, int n, int A, int Lmax
   p.scratch = (uint16_t *)((unsigned char *)workspace + 256);
   p.scratch_stride = a16(2 * (size_t)2 * nb_granular * (n - 1)) / 2;
   int waves; size_t lds;
-  const int grid = hgs_grid(n, Rmax, &waves, &lds);
+  int grid = hgs_grid(n, Rmax, &waves, &lds);
   if (lds > 160 * 1024) { set_error("daco_hgs_local_search: %zu bytes of LDS per solution (n=%d, up to %d routes)", lds, n, Rmax); return DACO_E_TOOLARGE; }
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(workspace, 0, 256, st);
-  if (e != hipSuccess) { set_error("daco_hgs_local_search: memset: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  hipError_t e = zero_async(workspace, 256, st);
+  if (e != hipSuccess) { set_error("daco_hgs_local_search: clearing the queue: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  // latency mode (hgs_ls_kernel<1, .., true>): no more solutions than a quarter of the CUs (each then has a CU's LDS to itself and
+  // nothing would have overlapped anyway) and the matrix fits.  DACO_HGS_LATENCY=0 / 1 forces (1: whenever it fits).
+  {
+    const size_t lm_lds = hgs_lds_bytes(n, Rmax) + ((size_t)n * n + n) * sizeof(double);
+    const char *ev = getenv("DACO_HGS_LATENCY");
+    const int force = ev ? atoi(ev) : -1;
+    const long items = (long)B * A;
+    if (lm_lds <= 160 * 1024 - 256 && force != 0 && (force == 1 || items <= 64)) {
+      e = hipFuncSetAttribute((const void *)hgs_ls_kernel<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds);
+      if (e != hipSuccess) { set_error("daco_hgs_local_search: cannot reserve %zu bytes of LDS: %s", lm_lds, hipGetErrorString(e)); return DACO_E_HIP; }
+      // (the scratch stride was sized for hgs_grid's wavefronts: one wavefront per workgroup here, never more workgroups than that)
+      const long lm_grid = items < (long)grid * waves ? items : (long)grid * waves;
+      hipLaunchKernelGGL((hgs_ls_kernel<1, 1, true>), dim3((unsigned)lm_grid), dim3(64), lm_lds, st, p);
+      e = hipGetLastError();
+      if (e != hipSuccess) { set_error("hgs_ls_kernel (latency mode) launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+      return DACO_OK;
+    }
+  }
 #define DACO_HGS_LAUNCH(W_, S_)                                                                                                   \
   do {                                                                                                                              \
     if (lds > 64 * 1024) {                                                                                                          \

@@ -23,6 +23,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["0", "1"], ids=["throughput", "latency"], autouse=True)
+def hgs_mode(request, monkeypatch):
+    """Every test of this module runs on both forms of the kernel: the persistent wavefronts of the batched colonies
+    (DACO_HGS_LATENCY=0) and the latency mode -- one wavefront per workgroup with the stage's matrix in LDS, what a call with a
+    handful of solutions takes by itself -- forced wherever the matrix fits (=1; larger instances fall back)."""
+    monkeypatch.setenv("DACO_HGS_LATENCY", request.param)
+    return request.param
+
+
 def run(paths_in, stages, demands, Lpad=2, want_stats=False):
     from deepaco_amd import engine
     pin = torch.as_tensor(np.asarray(paths_in, dtype=np.int64))
