@@ -654,6 +654,33 @@ def extra_configs(dev, headline_colony, cpu=True):
     except Exception as e:
         out["headline_two_streams"] = {"error": repr(e)}
 
+    # the headline iteration as BatchedTSP.run() executes it: the tours stay compact (u16 rows in the sampler's workspace, the best
+    # one copied from there: step(want_paths=False)) instead of leaving as the int64 [B, n, A] tensor step() returns -- the
+    # reference's loop keeps `paths` to itself too (tsp/aco.py:75-92).  Not the metric's default: the line above is the iteration
+    # that also hands out the reference's paths tensor.  Same costs, records and pheromone (tests/test_gpu_11_scan_sparse.py).
+    try:
+        n, A, B, k = 500, 512, 64, 50
+        col = engine.BatchedTSP(make_instances(B, n, 1234).to(dev), n_ants=A, seed=1234, sampler="auto")
+        col.sparsify(k)
+        col.heuristic = col.heuristic.contiguous()
+        for _ in range(8):
+            col.step(want_paths=False)
+        ev = events(40)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(40):
+            col.step(events=ev[s_], want_paths=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 40
+        kms = sum(a.elapsed_time(b) for a, b in ev) / 40
+        out["headline_compact_tours"] = {"workload": f"TSP-{n}, n_ants={A}, {B} instances, 1/d sparsified k={k}, sampler auto, the iteration of "
+                                                     "run(): tours as u16 rows, no int64 paths tensor",
+                                         "value": B * A / dt, "unit": "ant-tours/s", "ms_per_step": dt * 1e3, "steps": 40, "kernel_ms": kms,
+                                         "roofline": roofline_rows(n, A, B, "scan_sparse", kms, head_k=k)}
+        del col
+    except Exception as e:
+        out["headline_compact_tours"] = {"error": repr(e)}
+
     # config 4: CVRP-100, capacity mask in the sampling kernel
     n, A, B = 100, 512, 256
     g = torch.Generator().manual_seed(3)

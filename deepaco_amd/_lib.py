@@ -27,6 +27,7 @@ SIGNATURES = {
                              _u32, _i, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sparse_workspace_bytes": (_sz, [_i, _i, _i]),
     "daco_tsp_sparse_workspace_bytes_general": (_sz, [_i, _i, _i]),
+    "daco_tsp_sparse_tours_offset": (_sz, [_i, _i, _i]),
     "daco_tsp_sample_sparse": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
                                     _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "daco_tsp_sample_race_head": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _vp, _vp,
@@ -44,6 +45,7 @@ SIGNATURES = {
     "daco_pick_move": (_i, [_vp, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp, _u64, _u64, _u32, _i, _vp, _vp, _vp, _vp]),
     "daco_directed_table_bytes": (_sz, [_i, _i, _i]),
     "daco_track_best": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f]),
+    "daco_track_best_tours16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f]),
     "daco_cvrp_sample": (_i, [_vp, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _f, _i, _vp, _i, _u64, _u64, _vp, _u32, _i, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _sz, _vp, C.c_double, _vp, _vp]),
     "daco_sample_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _l, _vp, _l, _f, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,

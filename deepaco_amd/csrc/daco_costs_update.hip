@@ -119,9 +119,10 @@ __global__ void __launch_bounds__(64) argmin_cost_kernel(int A, const float *cos
 
 // best-so-far bookkeeping of ACO.run (tsp/aco.py:78-88): first minimum of the costs, and if it
 // beats the colony's record, the record and its tour are replaced (device-side: no host branch)
+// (tours16 != null: the tours as u16 rows [B][A][ld] -- daco_tsp_sparse_tours_offset -- instead of int64 paths [B][len][A])
 __global__ void __launch_bounds__(256)
 track_best_kernel(int len, int A, const float *costs, const int64_t *paths, float *lowest, int64_t *shortest,
-                  int32_t *best_idx, float *mmas_max, float mmas_scale) {
+                  int32_t *best_idx, float *mmas_max, float mmas_scale, const uint16_t *tours16 = nullptr, int ld = 0) {
   __shared__ float rk[4];
   __shared__ int ri[4];
   __shared__ int take;
@@ -150,8 +151,10 @@ track_best_kernel(int len, int A, const float *costs, const int64_t *paths, floa
   }
   __syncthreads();
   const int t = take;
-  if (t >= 0 && shortest)
-    for (int k = tid; k < len; k += 256) shortest[(size_t)b * len + k] = paths[((size_t)b * len + k) * A + t];
+  if (t >= 0 && shortest) {
+    if (tours16) { for (int k = tid; k < len; k += 256) shortest[(size_t)b * len + k] = (int64_t)tours16[((size_t)b * A + t) * ld + k]; }
+    else for (int k = tid; k < len; k += 256) shortest[(size_t)b * len + k] = paths[((size_t)b * len + k) * A + t];
+  }
 }
 
 // Row owners: a workgroup keeps R rows of tau in LDS.  Row i receives, per ant and in ant order,
@@ -479,6 +482,19 @@ extern "C" int daco_track_best(void *stream, int B, int len, int A, const float 
   return DACO_OK;
 }
 
+extern "C" int daco_track_best_tours16(void *stream, int B, int len, int A, int ld, const float *costs, const uint16_t *tours16,
+                                       float *lowest, int64_t *shortest, int32_t *best_idx, float *mmas_max, float mmas_scale) {
+  if (B <= 0 || len <= 0 || A <= 0 || ld < len || !costs || !lowest || !tours16) {
+    set_error("daco_track_best_tours16: bad argument (B=%d len=%d A=%d ld=%d)", B, len, A, ld);
+    return DACO_E_BADARG;
+  }
+  hipLaunchKernelGGL(track_best_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, len, A, costs, (const int64_t *)nullptr, lowest, shortest,
+                     best_idx, mmas_max, mmas_scale, tours16, ld);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("track_best_kernel launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
+  return DACO_OK;
+}
+
 extern "C" size_t daco_directed_table_bytes(int B, int n, int A) {
   if (B <= 0 || n <= 0 || A <= 0) return 0;
   // successor per (node, ant) | per-ant set of depot successors | per-ant route length
@@ -518,7 +534,7 @@ static int pheromone_update_impl(void *stream, int B, int n, int len, int A, flo
                                  int symmetric, const float *clamp_min, const float *clamp_max,
                                  float floor_val, const uint32_t *nbr_in, const float *weights, int hub,
                                  void *workspace, size_t workspace_bytes, const HeadEmit &he) {
-  if (B <= 0 || n < 3 || A <= 0 || !tau || !paths || !costs || !workspace) {
+  if (B <= 0 || n < 3 || A <= 0 || !tau || (!paths && !nbr_in) || !costs || !workspace) {     // (the table replaces the paths)
     set_error("daco_pheromone_update: bad argument (B=%d n=%d A=%d)", B, n, A);
     return DACO_E_BADARG;
   }

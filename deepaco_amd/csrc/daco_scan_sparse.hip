@@ -529,6 +529,15 @@ scan_sparse_kernel(const SampleParams p) {
       int64_t *pb = p.paths + (size_t)b * n * A + abase;
       for (int t = threadIdx.x / APB; t < n; t += TSTEP) pb[(size_t)t * A + k16] = (int64_t)tour_s[k16][t];
     }
+    if (!p.paths && p.tours16) {
+      // no int64 paths asked for: the tours leave as they are, u16 rows of FL entries per ant in the workspace (a quarter of
+      // the bytes: 32 MB instead of 131 at the headline shape; daco_track_best_tours16 reads the best one)
+      uint32_t *tb = reinterpret_cast<uint32_t *>(p.tours16 + ((size_t)b * A + abase) * FL);
+      for (int e = threadIdx.x; e < nant * (FL / 2); e += 256) {
+        const int k = e / (FL / 2), j = e - k * (FL / 2);
+        tb[(size_t)k * (FL / 2) + j] = reinterpret_cast<const uint32_t *>(tour_s[k])[j];
+      }
+    }
     if (p.costs) {
       // tour lengths (tsp/aco.py:121-132): sum_k d[u_k][u_{k-1}], then the closing edge -- f32, that order.  64 edges of each
       // of the wave's four ants are gathered with every lane active and staged in the (dead) flag array.
@@ -681,12 +690,17 @@ pow_pair_kernel(long count_t, const float *tau, float alpha, float *tau_out, lon
   if (i < count_e) eta_out[i] = pw(eta[i], beta);
 }
 
-// workspace: the dense rows P [B][n][ld], the head rows (daco_pheromone_update_heads writes both), then (n > 512) the u16 tours as they are built
-extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A) {
+// workspace: the dense rows P [B][n][ld], the head rows (daco_pheromone_update_heads writes both), then the u16 tours [B][A][ld]
+// (n > 512: as they are built; n <= 512: written by a call that asks for no int64 paths)
+extern "C" size_t daco_tsp_sparse_tours_offset(int B, int n, int A) {
   if (B <= 0 || A <= 0 || n <= 128 || n > 1024) return 0;
   const int ld = n <= 512 ? 512 : 1024;                  // (the row walks of the kernel's two instantiations read 512 / 1024 candidates)
-  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16)) +
-         (ld > 512 ? align256(((size_t)B * A + 16) * ld * sizeof(uint16_t)) : 0);
+  return align256((size_t)B * n * ld * sizeof(float)) + align256((size_t)B * n * sp_head_row_bytes(SP_KH_MAX / 16));
+}
+extern "C" size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A) {
+  if (B <= 0 || A <= 0 || n <= 128 || n > 1024) return 0;
+  const int ld = n <= 512 ? 512 : 1024;
+  return daco_tsp_sparse_tours_offset(B, n, A) + align256(((size_t)B * A + 16) * ld * sizeof(uint16_t));
 }
 
 // ... and, for exponents other than 1, tau^alpha [B][n][n] and eta^beta [B or 1][n][n] behind it

@@ -232,6 +232,16 @@ def sparse_workspace(device, B, n, n_ants, unit_exponents=True):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
+def sparse_tours16(workspace, B, n, n_ants):
+    """The tours of the last tsp_sample_sparse call on `workspace` in their compact form: an int16-typed view [B, A, ld] of the
+    workspace (ld = 512 for n <= 512, else 1024; entry t of ant a = the node visited at step t, entries >= n undefined; node ids are
+    below 32768, so the sign bit is never set).  Written by calls with n > 512 and by calls with want_paths=False
+    (include/deepaco_hip.h daco_tsp_sparse_tours_offset)."""
+    off = int(_lib.lib().daco_tsp_sparse_tours_offset(B, n, n_ants))
+    ld = 512 if n <= 512 else 1024
+    return workspace[off:off + B * n_ants * ld * 2].view(torch.int16).view(B, n_ants, ld)
+
+
 def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, fixed_start=-1, seed=0, it=0, ant_gid0=0,
                       batch=None, events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, want_stats=False,
                       want_paths=True, race=False, workspace=None, heads_ready=False, head_live_max=0, nbr_grouped=False, flags=None):
@@ -610,17 +620,29 @@ def tour_costs(dist, paths, closed=True):
     return costs
 
 
-def track_best_(costs, paths, lowest, shortest=None, mmas_scale=None):
+def track_best_(costs, paths, lowest, shortest=None, mmas_scale=None, tours16=None):
     """Best-so-far bookkeeping of ACO.run on the device (tsp/aco.py:78-88): updates lowest [B] and shortest
     [B,len] in place where this iteration's first-minimum cost beats the record.  mmas_scale (= problem size):
-    also returns the MMAS upper bound n / lowest_cost [B] (computed like the reference's rtruediv)."""
-    _require_gpu(costs, paths, lowest, shortest)
-    B, length, A = paths.shape
-    assert costs.dtype == torch.float32 and costs.is_contiguous() and paths.is_contiguous()
+    also returns the MMAS upper bound n / lowest_cost [B] (computed like the reference's rtruediv).
+    tours16 (with paths=None): the tours as sparse_tours16() rows [B, A, ld] instead of int64 paths [B, len, A]; len = shortest's."""
+    _require_gpu(costs, paths, lowest, shortest, tours16)
+    assert costs.dtype == torch.float32 and costs.is_contiguous()
+    B, A = costs.shape
     assert lowest.dtype == torch.float32 and lowest.is_contiguous() and lowest.numel() == B
     dev = costs.device
     with torch.cuda.device(dev):
         mx = torch.empty((B,), dtype=torch.float32, device=dev) if mmas_scale is not None else None
+        if paths is None:
+            assert tours16 is not None and tours16.dtype == torch.int16 and tours16.is_contiguous() and shortest is not None
+            assert tuple(tours16.shape[:2]) == (B, A)
+            rc = _lib.lib().daco_track_best_tours16(_stream(dev), B, int(shortest.shape[1]), A, int(tours16.shape[2]), costs.data_ptr(),
+                                                    tours16.data_ptr(), lowest.data_ptr(), shortest.data_ptr(), None,
+                                                    mx.data_ptr() if mx is not None else None,
+                                                    float(mmas_scale) if mmas_scale is not None else 0.0)
+            _lib.check(rc, "daco_track_best_tours16")
+            return mx
+        length = paths.shape[1]
+        assert paths.is_contiguous() and tuple(paths.shape) == (B, length, A)
         rc = _lib.lib().daco_track_best(_stream(dev), B, length, A, costs.data_ptr(), paths.data_ptr(), lowest.data_ptr(),
                                         shortest.data_ptr() if shortest is not None else None, None,
                                         mx.data_ptr() if mx is not None else None,
@@ -641,8 +663,13 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
     _require_gpu(tau, paths, costs, clamp_min, clamp_max)
     assert tau.dim() == 3 and tau.dtype == torch.float32 and tau.is_contiguous()
     B, n, _ = tau.shape
-    _, length, A = paths.shape
-    paths = paths.contiguous()
+    if paths is None:                                        # (the table is all the deposit reads)
+        assert nbr is not None and symmetric
+        length, A = n, costs.shape[-1]
+    else:
+        _, length, A = paths.shape
+        paths = paths.contiguous()
+    pptr = paths.data_ptr() if paths is not None else None
     costs = _f32c(costs)
     if weights is not None:
         weights = _f32c(weights)
@@ -656,7 +683,7 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
             eta, ebs = _bstride(heads["eta"], n)
             head, sws = heads["head"], heads["workspace"]
             _require_gpu(eta, head, sws)
-            rc = L.daco_pheromone_update_heads(_stream(dev), B, n, A, tau.data_ptr(), paths.data_ptr(), costs.data_ptr(), float(decay),
+            rc = L.daco_pheromone_update_heads(_stream(dev), B, n, A, tau.data_ptr(), pptr, costs.data_ptr(), float(decay),
                                                int(bool(elitist)), clamp_min.data_ptr() if clamp_min is not None else None,
                                                clamp_max.data_ptr() if clamp_max is not None else None, float(floor),
                                                nbr.data_ptr() if nbr is not None else None,
@@ -666,7 +693,7 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
                                                int(bool(heads.get("nbr_grouped", False))) if nbr is not None else 0, sws.data_ptr(), sws.numel())
             _lib.check(rc, "daco_pheromone_update_heads")
             return tau
-        rc = L.daco_pheromone_update(_stream(dev), B, n, length, A, tau.data_ptr(), paths.data_ptr(),
+        rc = L.daco_pheromone_update(_stream(dev), B, n, length, A, tau.data_ptr(), pptr,
                                      costs.data_ptr(), float(decay), int(bool(elitist)), int(bool(symmetric)),
                                      clamp_min.data_ptr() if clamp_min is not None else None,
                                      clamp_max.data_ptr() if clamp_max is not None else None,
@@ -1038,7 +1065,11 @@ class BatchedTSP:
         return self._head[1]
 
     @torch.no_grad()
-    def step(self, events=None, _iter_dev=None, ls_events=None):
+    def step(self, events=None, _iter_dev=None, ls_events=None, want_paths=True):
+        # want_paths=False (head-row samplers without local search; what run() passes): the iteration keeps its tours to itself, as
+        # ACO.run does (tsp/aco.py:75-92: `paths` is a local of the loop) -- the construction kernel writes them as compact u16 rows
+        # in its workspace (32 MB instead of 131 MB of int64 [B, n, A] per iteration at TSP-500 x 512 x 64), the best one is copied
+        # from there, the deposit takes the table: returns (None, costs); sparse_tours16(self._sparse_ws, ...) holds the tours.
         # (_iter_dev: device-side iteration counter of a captured graph; self.iteration then stays frozen)
         # events: torch.cuda.Event pair re-recorded around the construction kernel; ls_events: a pair recorded (on the
         # current stream, which is the stream the library launches on) right before / after the local-search launches
@@ -1056,16 +1087,19 @@ class BatchedTSP:
             st = self._heads_state(head, race_head)
             ready = self._heads_for is not None and len(st) == len(self._heads_for) and all(
                 (a is b) if torch.is_tensor(a) else (a == b) for a, b in zip(st, self._heads_for))
+            compact = not want_paths and self.local_search is None
             paths, _, costs, nbr = tsp_sample_sparse(self.pheromone, self.heuristic, self.n_ants, head, self.alpha,
                                                      self.beta, seed=self.seed, it=self.iteration, ant_gid0=self.ant_gid0,
                                                      fixed_start=self.fixed_start, batch=self.B, events=events,
                                                      dist=self.distances, want_nbr=True, iter_dev=_iter_dev, race=race_head,
                                                      workspace=self._sparse_ws, heads_ready=ready, head_live_max=self._head[2],
-                                                     nbr_grouped=grouped, flags=self._flags)
+                                                     nbr_grouped=grouped, flags=self._flags, want_paths=not compact)
+            tours16 = sparse_tours16(self._sparse_ws, self.B, self.n, self.n_ants) if compact else None
             if fused:
                 heads = {"eta": self.heuristic, "alpha": self.alpha, "beta": self.beta, "head": head, "race": race_head,
                          "workspace": self._sparse_ws, "nbr_grouped": grouped}
         else:
+            tours16 = None
             paths, _, _, _, costs, nbr = tsp_sample(self.pheromone, self.heuristic, self.n_ants, self.alpha,
                                                     self.beta, mode=sampler, seed=self.seed, it=self.iteration,
                                                     ant_gid0=self.ant_gid0, fixed_start=self.fixed_start,
@@ -1099,7 +1133,7 @@ class BatchedTSP:
             costs, nbr = (tour_costs(self.distances, paths) if ls_costs is None else ls_costs), None
         # in place: the best-so-far state lives at fixed addresses (a captured graph replays these very writes)
         new_max = track_best_(costs, paths, self.lowest_cost, self.shortest_path,
-                              mmas_scale=self.n if self.min_max else None)
+                              mmas_scale=self.n if self.min_max else None, tours16=tours16)
         cmin = cmax = None
         if self.min_max:
             if self.max is None:
@@ -1120,21 +1154,21 @@ class BatchedTSP:
         the graph."""
         if not graph or n_iterations < 3:
             for _ in range(n_iterations):
-                self.step()
+                self.step(want_paths=False)
             return self.lowest_cost
-        self.step()                                        # eager: workspaces, first-iteration MMAS rescale
+        self.step(want_paths=False)                        # eager: workspaces, first-iteration MMAS rescale
         dev = self.distances.device
         it_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                      # one un-captured pass on the capture stream (allocator warm-up)
-            self.step(_iter_dev=it_dev)
+            self.step(_iter_dev=it_dev, want_paths=False)
             it_dev += 1
         torch.cuda.current_stream(dev).wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
-            self.step(_iter_dev=it_dev)
+            self.step(_iter_dev=it_dev, want_paths=False)
             it_dev += 1
         for _ in range(n_iterations - 2):
             g.replay()

@@ -144,6 +144,13 @@ int daco_tsp_sample(void *stream, int B, int n, int A,
  */
 size_t daco_tsp_sparse_workspace_bytes(int B, int n, int A);
 size_t daco_tsp_sparse_workspace_bytes_general(int B, int n, int A);
+/* daco_tsp_sparse_tours_offset -- where the workspace keeps the tours in their compact form: uint16 [B][A][ld], ld = 512 (n <= 512) or
+ * 1024, entry t of ant a = the node visited at step t (entries >= n: undefined).  Valid after a call of daco_tsp_sample_sparse /
+ * _race_head / _heads with n > 512 (the tours are built there), and for n <= 512 after a call with paths = NULL (nbr given): the
+ * colony loop of ACO.run (tsp/aco.py:75-92) keeps `paths` to itself -- costs, best tour and deposit are all it takes from them -- so
+ * its iteration asks for no int64 [B][n][A] tensor (131 MB per iteration at TSP-500 x 512 x 64) and hands these rows to
+ * daco_track_best_tours16. */
+size_t daco_tsp_sparse_tours_offset(int B, int n, int A);
 int daco_tsp_sample_sparse(void *stream, int B, int n, int A,
                            const float *tau, long tau_bstride, const float *eta, long eta_bstride,
                            float alpha, float beta, const uint16_t *head_id, int head_slots,
@@ -260,6 +267,9 @@ int daco_cvrp_sample(void *stream, int B, int n, int A,
  */
 int daco_track_best(void *stream, int B, int len, int A, const float *costs, const int64_t *paths,
                     float *lowest, int64_t *shortest, int32_t *best_idx, float *mmas_max, float mmas_scale);
+/* the same bookkeeping on the compact tours of daco_tsp_sparse_tours_offset: tours16 [B][A][ld] uint16; shortest stays int64 [B][len] */
+int daco_track_best_tours16(void *stream, int B, int len, int A, int ld, const float *costs, const uint16_t *tours16,
+                            float *lowest, int64_t *shortest, int32_t *best_idx, float *mmas_max, float mmas_scale);
 
 /* ---------------------------------------------------------------------------------------------
  * daco_prob_matrix + daco_pick_move -- ACO.pick_move as a step-wise service
@@ -393,7 +403,8 @@ int daco_pheromone_update(void *stream, int B, int n, int len, int A, float *tau
  * daco_tsp_sample_heads(heads_ready = 1) from the copy it still holds on chip, so tau is read once per iteration instead of twice.
  *   eta, eta_bstride, alpha, beta, head_id, head_slots, race   as the sampler will be called; alpha = beta = 1 only (other
  *                exponents take the sampler's own pass: DACO_E_BADARG here)
- *   nbr_grouped        the layout of `nbr` (see daco_tsp_sample_heads); a NULL nbr is rebuilt from `paths` either way
+ *   nbr_grouped        the layout of `nbr` (see daco_tsp_sample_heads); a NULL nbr is rebuilt from `paths` either way (paths may be
+ *                      NULL when nbr is given: the table is all the deposit reads)
  *   sparse_workspace   the sampler's workspace (daco_tsp_sparse_workspace_bytes(B, n, A)); its head rows are (re)written
  *   129 <= n <= 1024; the other arguments as daco_pheromone_update (len = n, hub unused) */
 int daco_pheromone_update_heads(void *stream, int B, int n, int A, float *tau,

@@ -449,3 +449,37 @@ def test_grouped_table_is_the_classic_table_rearranged(n, A, B):
     assert torch.equal(p0, p1) and torch.equal(c0, c1)
     regrouped = n1.reshape(B, A // 8, n, 8).permute(0, 2, 1, 3).reshape(B, n, A)
     assert torch.equal(regrouped, n0)
+
+
+@pytest.mark.parametrize("n,A,B,k,kw", [(500, 64, 3, 50, {}), (200, 24, 2, 20, {"elitist": True}), (300, 40, 2, 30, {"min_max": True}),
+                                         (700, 32, 2, 70, {}), (500, 20, 1, 50, {})])
+def test_colony_iteration_without_int64_paths(n, A, B, k, kw):
+    """BatchedTSP.step(want_paths=False) -- what run() passes: the construction kernel leaves the tours as compact u16 rows in its
+    workspace (daco_tsp_sparse_tours_offset) instead of the int64 [B, n, A] tensor, the best tour is copied from those rows
+    (daco_track_best_tours16), the deposit takes the table.  Against the colony that materialises the paths every step: the same
+    costs, records, best tours and pheromone, iteration by iteration; the compact rows are the paths."""
+    from deepaco_amd import engine
+    d = instance(n, 7 + n, "ksparse", B)[0].to(dev())
+    cols = []
+    for _ in range(2):
+        c = engine.BatchedTSP(d, n_ants=A, seed=13, sampler="scan_sparse", **kw)
+        c.sparsify(k)
+        cols.append(c)
+    for it in range(5):
+        paths, costs = cols[0].step()
+        none, costs_c = cols[1].step(want_paths=False)
+        assert none is None and torch.equal(costs, costs_c), it
+        rows = engine.sparse_tours16(cols[1]._sparse_ws, B, n, A)
+        assert torch.equal(rows[:, :, :n].permute(0, 2, 1).to(torch.int64), paths), it
+        assert torch.equal(cols[0].lowest_cost, cols[1].lowest_cost) and torch.equal(cols[0].shortest_path, cols[1].shortest_path), it
+        assert torch.equal(cols[0].pheromone, cols[1].pheromone), it
+    # run() keeps the tours compact; a captured graph replays the same iteration
+    a, b = cols
+    a.run(4)
+    for _ in range(4):
+        b.step()
+    assert torch.equal(a.lowest_cost, b.lowest_cost) and torch.equal(a.shortest_path, b.shortest_path) and torch.equal(a.pheromone, b.pheromone)
+    a.run(5, graph=True)
+    for _ in range(5):
+        b.step()
+    assert torch.equal(a.lowest_cost, b.lowest_cost) and torch.equal(a.shortest_path, b.shortest_path) and torch.equal(a.pheromone, b.pheromone)
