@@ -6,7 +6,8 @@ import torch  # noqa: F401  -- must be loaded first: libdeepaco_hip.so then bind
 #                              (libamdhip64.so.7) torch already mapped, so streams/pointers are shared
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdeepaco_hip.so")
+# (DACO_LIB_PATH: another build of the same library -- the A/B sessions under tools/ measure two builds in one process tree)
+LIB_PATH = os.environ.get("DACO_LIB_PATH") or os.path.join(_HERE, "lib", "libdeepaco_hip.so")
 
 RACE_NOISE, RACE_PHILOX, SCAN, SCAN_WAVE = 0, 1, 2, 3
 MAX_NODES = 4096
@@ -78,7 +79,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 125          # include/deepaco_hip.h DACO_VERSION this table was written against
+ABI_VERSION = 126          # include/deepaco_hip.h DACO_VERSION this table was written against
 
 
 class DacoError(RuntimeError):

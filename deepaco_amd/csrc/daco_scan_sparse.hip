@@ -214,7 +214,7 @@ scan_sparse_kernel(const SampleParams p) {
   // TG: tour entry t lives at tour[t & 15] until its chunk is flushed to the workgroup's rows of tours16 [B][A][FL]
   uint16_t *t16b = TG ? p.tours16 + ((size_t)b * A + abase) * FL : nullptr;
   const uint32_t t16o = (uint32_t)((wave * APW + q) * FL + s);
-#define SP_T(t) ((t) & (TG ? 15 : 0xFFFF))
+#define SP_T(t) (TG ? ((t) & 15) : (t))
   bool infeasible = false;
   unsigned long long n_dense = 0, n_tail = 0, n_rej = 0;
   // LH: per-lane constants of the LDS row read (lanes past the live records read the empty record), the tail total's place
@@ -285,7 +285,10 @@ scan_sparse_kernel(const SampleParams p) {
       }
       if (t0 == 0) t = 1;
       const int te = t0 + 16 < n ? t0 + 16 : n;
-#pragma unroll 1
+#ifndef DACO_SPARSE_UNROLL
+#define DACO_SPARSE_UNROLL 1
+#endif
+#pragma unroll DACO_SPARSE_UNROLL
       for (; t < te; ++t) {
         // ---- the head of row `prev`: SPL values and SPL ids per lane
         const uint32_t off = LH ? __umul24((uint32_t)prev, lh_rbsel) + lh_loff : __umul24((uint32_t)prev, ROWB) + sls;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DACO_VERSION 125 /* 0.1.20: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count; 124: daco_hgs_*, daco_cvrp_sample takes ant_gid_bstride; 125: daco_tsp_sample_heads / daco_pheromone_update_heads, the sparse workspace no longer holds dense rows) */
+#define DACO_VERSION 126 /* 0.1.21: bumped whenever an entry point's signature or the draw stream of a mode changes (120: daco_tsp_sample_sparse; 121: head_slots; 122: scan_sparse draws once after a rejection; 123: its workspace takes the ant count; 124: daco_hgs_*, daco_cvrp_sample takes ant_gid_bstride; 125: daco_tsp_sample_heads / daco_pheromone_update_heads, the sparse workspace no longer holds dense rows; 126: daco_tsp_sparse_tours_offset / daco_track_best_tours16, the sparse workspace holds the u16 tours at every n) */
 
 /* error codes */
 #define DACO_OK 0
