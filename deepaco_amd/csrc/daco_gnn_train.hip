@@ -269,8 +269,15 @@ gnn_t_head_fwd(int E, const float *hp, const float *w, float *heu) {
 // flush a wave's 32x32 accumulator (MFMA output layout) and a per-channel vector into global memory
 __device__ inline void flush_acc(float *dstM, const f32x16 &acc, int lane) {
   const int j = lane & 31;
+#ifdef DACO_ABLATE_FLUSH   // (measurement build: one atomic per lane instead of sixteen -- what the contended flush costs)
+  float t = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t += acc[r];
+  unsafeAtomicAdd(dstM + t_drow(0, lane) * TU + j, t);
+#else
 #pragma unroll
   for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dstM + t_drow(r, lane) * TU + j, acc[r]);
+#endif
 }
 
 // head backward: waves walk tiles (grid-stride), recompute a1, a2, accumulate gW1/gW2/gW3/gb in registers
