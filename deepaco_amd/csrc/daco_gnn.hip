@@ -533,8 +533,11 @@ __device__ inline f32x2 silu2_fast(f32x2 x) {             // x sigmoid(x) on the
 // of gnn_head_kernel, the same MFMA order per row: the same bits): it writes heu[E] -- 4 bytes per edge -- and neither the edge
 // state (128 bytes per edge written here and read again by the head launch) nor the node state; no x2 gathers, no aggregate, no
 // node phase.  Used when the caller does not ask for the embedding.
+#ifndef DACO_GNN_F2_OCC
+#define DACO_GNN_F2_OCC 4                 // workgroups per CU the kernel is compiled for (39 KB of LDS each: four fit)
+#endif
 template <bool INIT, bool HEAD = false>
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, DACO_GNN_F2_OCC)
 gnn_fused2_layer_kernel(int n, int E, int feats, int layer, int npw, const int *src, const int *dst, const int *rowptr,
                         const float *params, const float *x0, const float *X, const float *w0, float *x1out, float *Xnext,
                         float *w1out, const float *attr, int nt, float *heu = nullptr) {
