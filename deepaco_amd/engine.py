@@ -1232,12 +1232,13 @@ class StreamedTSP:
     def iteration(self):
         return self.cols[0].iteration
 
-    def step(self, events=None):
-        """events: one (begin, end) torch.cuda.Event pair PER PART, re-recorded around that part's construction kernel."""
+    def step(self, events=None, want_paths=True):
+        """events: one (begin, end) torch.cuda.Event pair PER PART, re-recorded around that part's construction kernel.
+        want_paths=False: the parts keep their tours compact (BatchedTSP.step; the parts' paths are discarded here either way)."""
         self._fork()
         for p, (col, st) in enumerate(zip(self.cols, self.streams)):
             with torch.cuda.stream(st):
-                col.step(events=events[p] if events is not None else None)
+                col.step(events=events[p] if events is not None else None, want_paths=want_paths)
 
     def join(self):
         cur = torch.cuda.current_stream(self._dev)
@@ -1246,7 +1247,7 @@ class StreamedTSP:
 
     def run(self, n_iterations):
         for _ in range(n_iterations):
-            self.step()
+            self.step(want_paths=False)
         return self.lowest_cost
 
     def _gather(self, name):

@@ -199,3 +199,14 @@ def test_flatten_parameters_views_of_one_block():
     frozen.freeze_gnn()
     with pytest.raises(_lib.DacoError):
         frozen.flatten_parameters()
+
+
+def test_trainer_has_no_cpu_path():
+    """pipeline.TspNlsTrainer is a device object: on a host without a HIP device it says so (no silent CPU training loop)."""
+    from deepaco_amd import _lib
+    from deepaco_amd.pipeline import TspNlsTrainer
+    from deepaco_amd.tsp_nls.net import Net
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible: the trainer runs (tests/test_gpu_07_net.py)")
+    with pytest.raises(_lib.DacoError):
+        TspNlsTrainer(Net(), 2, 20, 4, 5)
