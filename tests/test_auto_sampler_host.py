@@ -18,16 +18,22 @@ def _ksparse(n, k, seed=0):
 
 def test_head_size_from_the_heuristics_rows():
     d, h40 = _ksparse(300, 40)
-    assert engine.auto_head_k(h40) == 63                      # the network's k-sparse output: 40 live entries per row
+    assert engine.auto_head_k(h40) == 62                      # the network's k-sparse output: 40 live entries per row -> the largest
+    #                                                           head that leaves a slot free (a few ants then keep the rows in LDS)
     _, h100 = _ksparse(300, 100)
     assert engine.auto_head_k(h100) == 127
     assert engine.auto_head_k(1 / d) is None                  # plain 1/d: a fifth of a row's mass is in the tail
     _, h200 = _ksparse(300, 200)
     assert engine.auto_head_k(h200) is None
+    _, h50 = _ksparse(500, 50)                                # TSP-500, k = 50: 13 lanes of 24 bytes x 500 rows fit a CU's LDS -> 51
+    assert engine.auto_head_k(h50) == 51
+    heavy = h40.clone()
+    heavy[:, :] = torch.where(heavy > 1e-9, heavy, torch.full_like(heavy, 2e-4))   # 1 % of a row's mass outside its 40 live entries:
+    assert engine.auto_head_k(heavy) == 63                    # not "practically all" in 62 -> the 0.98 rule's 63
     assert engine.auto_head_k(_ksparse(100, 10)[1]) is None   # sizes the head kernels do not cover
     flat = h40.clone()
     flat[:10] = 1e-10                                         # a few flat rows (all live entries below the floor) do not veto
-    assert engine.auto_head_k(flat) == 63
+    assert engine.auto_head_k(flat) == 62
     flat[:40] = 1e-10                                         # more than one row in twenty does
     assert engine.auto_head_k(flat) is None
 
@@ -38,7 +44,7 @@ def test_resolution_rules():
     assert engine.resolve_sampler("scan", 300, 30, h, cache) == ("scan", 30)          # explicit choices pass through
     assert engine.resolve_sampler("race", 300, None, h, cache) == ("race", None)
     assert engine.resolve_sampler("auto", 300, 30, 1 / d, cache) == ("scan_sparse", 30)      # after sparsify(k): its k
-    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 63)
+    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 62)
     assert cache["auto_head"][0] is h                                                  # (tested once per heuristic object)
     assert engine.resolve_sampler("auto", 300, None, 1 / d, cache) == ("scan", None)
     assert engine.resolve_sampler("auto", 100, 10, h[:100, :100], {}) == ("scan", None)
@@ -57,12 +63,12 @@ def test_the_sorted_top_values_are_handed_to_the_head_table_once():
     the head table takes them instead of a torch.topk of its own, and they are dropped after that."""
     d, h = _ksparse(300, 40)
     k, top = engine.auto_head_k(h, want_top=True)
-    assert k == 63 and top.shape == (300, 127)
+    assert k == 62 and top.shape == (300, 127)
     assert torch.equal(top, torch.topk(h, 127, dim=-1).values) and bool((top[:, 1:] <= top[:, :-1]).all())
     assert engine.auto_head_k(1 / d, want_top=True) == (None, None)
     assert engine.auto_head_k(h[:100, :100], want_top=True) == (None, None)
     cache = {}
-    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 63)
+    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 62)
     assert engine.take_auto_top(cache, 1 / d) is None          # another heuristic object: nothing to take (and nothing kept)
     assert "auto_top" not in cache
     cache = {}
@@ -70,5 +76,5 @@ def test_the_sorted_top_values_are_handed_to_the_head_table_once():
     got = engine.take_auto_top(cache, h)
     assert torch.equal(got, top)
     assert engine.take_auto_top(cache, h) is None and engine.take_auto_top(None, h) is None
-    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 63)      # (cached verdict: no second test)
+    assert engine.resolve_sampler("auto", 300, None, h, cache) == ("scan_sparse", 62)      # (cached verdict: no second test)
     assert "auto_top" not in cache

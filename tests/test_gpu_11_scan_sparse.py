@@ -249,7 +249,7 @@ def test_auto_sampler_picks_head_rows_where_they_apply():
     _, idx = torch.topk(d, k=40, dim=2, largest=False)
     heu = torch.full_like(d, 1e-10).scatter_(2, idx, torch.rand(3, 300, 40, device=dev()) + 0.05)
     learned = engine.BatchedTSP(d, n_ants=64, seed=3, heuristic=heu)
-    assert learned.resolved_sampler() == ("scan_sparse", 63)
+    assert learned.resolved_sampler() == ("scan_sparse", 62)       # (the largest head that leaves a slot free: engine.auto_head_k)
     learned.run(3)
     assert bool((learned.shortest_path.sort(dim=1).values == torch.arange(300, device=dev())).all())
     wide = torch.full_like(d, 1e-10).scatter_(2, torch.topk(d, k=100, dim=2, largest=False).indices, 1.0)
@@ -449,6 +449,26 @@ def test_grouped_table_is_the_classic_table_rearranged(n, A, B):
     assert torch.equal(p0, p1) and torch.equal(c0, c1)
     regrouped = n1.reshape(B, A // 8, n, 8).permute(0, 2, 1, 3).reshape(B, n, A)
     assert torch.equal(regrouped, n0)
+
+
+def test_learned_heuristic_of_one_instance_takes_the_lds_heads():
+    """The reference's own inference call (tsp/test.ipynb:31-70: one instance, the network's heuristic + 1e-10, 20-50 ants): sampler
+    'auto' now picks the largest head that leaves a slot free and fits a CU's LDS (51 at TSP-500 for the graph's k = 50 live entries
+    per row, engine.auto_head_k), so the single-instance colony runs the LDS-heads variant; its iterations equal instance 0 of a
+    three-instance colony with the same seed (too many ants for the variant: head rows through L2) -- same tours, costs, pheromone."""
+    from deepaco_amd import engine
+    n, A, k = 500, 50, 50
+    d = instance(n, 55, "ksparse", 3)[0].to(dev())
+    _, idx = torch.topk(d, k=k, dim=2, largest=False)
+    heu = torch.full_like(d, 1e-10).scatter_(2, idx, torch.rand(3, n, k, device=dev()) + 0.05)
+    one = engine.BatchedTSP(d[:1].contiguous(), n_ants=A, seed=8, heuristic=heu[:1].contiguous())
+    many = engine.BatchedTSP(d, n_ants=A, seed=8, heuristic=heu)
+    assert one.resolved_sampler() == ("scan_sparse", 51) and many.resolved_sampler() == ("scan_sparse", 51)
+    for _ in range(3):
+        (p1, c1), (p3, c3) = one.step(), many.step()
+        assert torch.equal(p1[0], p3[0]) and torch.equal(c1[0], c3[0])
+    assert torch.equal(one.pheromone[0], many.pheromone[0])
+    assert bool((one.shortest_path.sort(dim=1).values == torch.arange(n, device=dev())).all())
 
 
 @pytest.mark.parametrize("n,A,B,k,kw", [(500, 64, 3, 50, {}), (200, 24, 2, 20, {"elitist": True}), (300, 40, 2, 30, {"min_max": True}),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where the time of pipeline.infer_tsp_batch goes (64 x TSP-500, k = 50, 512 ants, the pretrained tsp500 network):
-each stage timed with a device sync after it (ms; steady state = third call)."""
+"""Where the time of pipeline.infer_tsp_batch goes (default 64 x TSP-500, k = 50, 512 ants, the pretrained tsp500 network):
+each stage timed with a device sync after it (ms; steady state = third call).  usage: time_infer_pipeline.py [B=64] [ants=512]
+(1 50: one instance with the ant count of the reference's own harness, tsp/test.ipynb)"""
 import os
 import sys
 import time
@@ -18,7 +19,9 @@ wz = np.load(os.path.join(ROOT, "tests", "golden", "w_tsp_tsp500.npz"))
 net = Net()
 net.load_state_dict({k[3:]: torch.from_numpy(wz[k]) for k in wz.files}, strict=False)
 net = net.to(dev).eval()
-n, A, B, k = 500, 512, 64, 50
+n, k = 500, 50
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+A = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 
 
 def stage(label, fn, acc):
@@ -42,4 +45,4 @@ for rep in range(3):
         stage("19 more iterations", lambda: col.run(19), acc)
 for kx, v in acc.items():
     print(f"{kx:50s} first {v[0]:9.3f}   steady {v[-1]:9.3f}")
-print("sampler:", col.resolved_sampler())
+print("sampler:", col.resolved_sampler(), f"B = {B}, ants = {A}")
