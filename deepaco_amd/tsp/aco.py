@@ -133,6 +133,9 @@ class ACO():
         if "gen_path" in self.__dict__ or type(self).gen_path_costs is not ACO.gen_path_costs \
                 or getattr(self, "local_search_type", None) is not None:
             return self._run_plain(n_iterations)
+        sampler, hk = self.resolved_sampler()               # head / tail rows where they apply (a k-sparse heuristic, 129 <= n <= 1024)
+        if sampler == "scan_sparse":
+            return self._run_colony(n_iterations, hk)
         dev = self.distances.device
         dist = self.distances.detach().float().contiguous()
         lowest = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(1).clone()
@@ -143,18 +146,11 @@ class ACO():
         tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
         eta = self.heuristic.detach()
         cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
-        sampler, hk = self.resolved_sampler()               # head / tail rows where they apply (a k-sparse heuristic, 129 <= n <= 1024)
-        sparse = sampler == "scan_sparse"
         for _ in range(n_iterations):
-            if sparse:
-                paths, flags, costs, nbr = engine.tsp_sample_sparse(
-                    tau, eta, self.n_ants, self._head_table(hk), self.alpha, self.beta, fixed_start=self.FIXED_START,
-                    seed=self.seed, it=self._calls, batch=1, dist=dist, want_nbr=True)
-            else:
-                paths, _, _, flags, costs, nbr = engine.tsp_sample(
-                    tau, eta, self.n_ants, self.alpha, self.beta, mode=sampler,
-                    norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
-                    dist=dist, want_nbr=True)
+            paths, _, _, flags, costs, nbr = engine.tsp_sample(
+                tau, eta, self.n_ants, self.alpha, self.beta, mode=sampler,
+                norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
+                dist=dist, want_nbr=True)
             self._calls += 1
             self._last_flags = flags
             # `if best_cost < self.lowest_cost: ...` (tsp/aco.py:78-88) on the device
@@ -169,6 +165,48 @@ class ACO():
             engine.pheromone_update_(tau, paths, costs, self.decay, self.elitist, True, cmin, cmax, nbr=nbr)
         self.pheromone = tau[0]
         self.lowest_cost, self.shortest_path = lowest[0], shortest[0]
+        return self.lowest_cost
+
+    @torch.no_grad()
+    def _run_colony(self, n_iterations, hk):
+        """run() on head / tail rows = a one-instance engine.BatchedTSP kept with this object (round 6): the colony owns the
+        sampler's workspace, so the pheromone update leaves the next iteration's head rows there (no pre-pass launch, tau read once
+        per iteration), a launch of few ants keeps the instance's head rows in LDS (this IS the reference's call
+        pattern -- one instance, 20-50 ants, tsp/test.ipynb:31-70) and the tours stay compact.  Same seed and iteration counter as
+        the loop above: the same tours, costs, records and pheromone (tests/test_gpu_00_tsp.py)."""
+        dev = self.distances.device
+        key = (self.distances, self.heuristic, hk, self.n_ants, self.decay, self.alpha, self.beta, bool(self.elitist), bool(self.min_max), self.seed)
+        hit = self.__dict__.get("_colony")
+        if hit is None or any((a is not b) if torch.is_tensor(a) else (a != b) for a, b in zip(hit[0], key)):
+            eta = self.heuristic.detach().to(torch.float32).contiguous().unsqueeze(0)
+            col = engine.BatchedTSP(self.distances.detach().float().contiguous().unsqueeze(0), n_ants=self.n_ants, decay=self.decay,
+                                    alpha=self.alpha, beta=self.beta, elitist=self.elitist, min_max=self.min_max, heuristic=eta,
+                                    min=self.min if self.min_max else None, sampler="scan_sparse", seed=self.seed,
+                                    fixed_start=self.FIXED_START)
+            col.head_k = hk
+            col._head = (eta, self._head_table(hk), hk)         # (this object's table: built once, from the sorted top values if 'auto' left them)
+            hit = self._colony = (key, col)
+        col = hit[1]
+        # one private copy for the whole loop, rebound at the end (the reference rebinds self.pheromone every iteration,
+        # tsp/aco.py:101: a tensor the caller still holds is never modified)
+        col.pheromone = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
+        col.lowest_cost = torch.as_tensor(self.lowest_cost, dtype=torch.float32, device=dev).reshape(1).clone()
+        col.shortest_path = (self.shortest_path.clone() if self.shortest_path is not None else
+                             torch.zeros(self.problem_size, dtype=torch.int64, device=dev)).reshape(1, -1).contiguous()
+        col.iteration = self._calls
+        if self.min_max:
+            col.min = self.min
+            col._cmin = None
+            col.max = None if self.max is None else torch.as_tensor(self.max, dtype=torch.float32, device=dev).reshape(1).clone()
+        col._flags.zero_()
+        for _ in range(n_iterations):
+            col.step(want_paths=False)
+        self._calls = col.iteration
+        self._last_flags = col._flags
+        if self.min_max and col.max is not None:
+            self.max = col.max[0]
+        self.pheromone = col.pheromone[0]
+        self.lowest_cost, self.shortest_path = col.lowest_cost[0], col.shortest_path[0]
         return self.lowest_cost
 
     @torch.no_grad()

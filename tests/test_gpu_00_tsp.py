@@ -543,3 +543,42 @@ def test_sync_free_run_equals_plain_sequence(kw):
     assert float(r1) == float(r2) and torch.equal(a1.shortest_path, a2.shortest_path)
     r1b = a1.run(3)                                     # continues from tensor state
     assert float(r1b) <= float(r1)
+
+
+@pytest.mark.parametrize("kw", [{}, {"elitist": True}, {"min_max": True}, {"min_max": True, "min": 0.05}])
+@pytest.mark.parametrize("n,A,k,learned", [(300, 24, 30, False), (500, 50, 50, True), (700, 20, 70, False)])
+def test_run_on_head_rows_is_a_one_instance_colony_with_the_plain_loops_results(n, A, k, learned, kw):
+    """ACO.run on head / tail rows keeps a one-instance engine.BatchedTSP (round 6: the update's head rows, the LDS-heads variant for
+    the reference's own ant counts, compact tours).  Against the plain call sequence of tsp/aco.py:75-92 on the same object state
+    (gen_path -> gen_path_costs -> best-so-far -> update_pheronome, `_run_plain`): the same record, best tour and pheromone after
+    two run() calls (the second continues the first: iteration counter, MMAS bound), AS / elitist / MMAS; `learned`: a k-sparse
+    heuristic nobody announced (sampler auto picks the head)."""
+    from deepaco_amd.tsp.aco import ACO
+    g = torch.Generator().manual_seed(n + A)
+    c = torch.rand(n, 2, generator=g)
+    d = (c[:, None] - c).norm(dim=-1)
+    d[torch.arange(n), torch.arange(n)] = 1e9
+    d = d.to(dev())
+    heu = None
+    if learned:
+        _, idx = torch.topk(d, k=k, dim=1, largest=False)
+        heu = torch.full_like(d, 1e-10).scatter_(1, idx, torch.rand(n, k, device=dev()) + 0.05)
+    objs = []
+    for _ in range(2):
+        a = ACO(d, n_ants=A, heuristic=heu, device="cuda:0", seed=77, **kw)
+        if not learned:
+            a.sparsify(k)
+        objs.append(a)
+    fast, plain = objs
+    assert fast.resolved_sampler()[0] == "scan_sparse"
+    held = fast.pheromone
+    before = held.clone()
+    for iters in (4, 3):
+        fast.run(iters)
+        plain._run_plain(iters)
+        assert float(fast.lowest_cost) == float(plain.lowest_cost)
+        assert torch.equal(fast.shortest_path, plain.shortest_path)
+        assert torch.equal(fast.pheromone, plain.pheromone.to(torch.float32))
+    assert torch.equal(held, before)                        # a tensor the caller still holds is never modified
+    assert fast._calls == plain._calls == 7
+    fast.check_feasible()
