@@ -317,6 +317,11 @@ __device__ inline void hgs_set_u(const HgsCtx &c, int U, USide &u) {
 
 // First move of the reference's sequence that applies to (U, V), 0 if none.  block 0: LocalSearch.cpp:36-44 (moves 1-9),
 // block 1: :47-56 (V = the depot in front of the route: 1, 2, 3, 8, 9), block 2: :62-71 (V = the depot of an empty route: 1, 2, 3, 9).
+// HOIST (the latency mode): every entry the nine moves can ask for is fetched before the first of them is evaluated.  The moves
+// return as they apply, so the compiler keeps each move's loads behind the previous move's branch: nine dependent waits per
+// evaluation where one wavefront is alone on its SIMD.  Most (U, V) pairs walk all nine moves and need every entry anyway; with
+// the loads up front the wavefront waits for memory once (LDS in this mode).  Same values, same arithmetic, same order of tests.
+template <bool HOIST>
 __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block) {
   const int Y = c.l.next[V], prevV = c.l.prev[V], nextY = c.l.next[Y];
   const int iV = c.cour(V), iY = c.cour(Y), Vp = c.cour(prevV), Yn = c.cour(nextY);
@@ -327,6 +332,19 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
   // matrix entries: the routes' own edges from LDS; everything else has one index on the U side -- read from that node's row
   // of the matrix or of its transpose, so that the 64 lanes' gathers fall on the few lines of (at most six) wave-uniform rows
   const double dVY = c.l.dNext[V], dVU = c.TT(u.iU, iV), dUY = c.TC(u.iU, iY), dXY = c.TC(u.iX, iY);
+  double h_dVX = 0., h_dUpV = 0., h_dVpU = 0., h_dVpV = 0., h_tXnV = 0., h_tXnY = 0., h_tXYn = 0., h_dNY = 0., h_tUV = 0., h_cumRevV = 0.,
+         h_cumLoadV = 0.;
+  int h_posV = 0, h_nextU = 0;
+  if constexpr (HOIST) {
+    h_dVX = c.TT(u.iX, iV);
+    h_tUV = c.TC(u.iU, iV); h_cumRevV = c.l.cumRev[V]; h_cumLoadV = c.l.cumLoad[V];
+    if (block == 0) {
+      h_dUpV = c.TC(u.Up, iV); h_dVpU = c.TT(u.iU, Vp); h_dVpV = c.l.dNext[prevV];
+      h_tXnV = c.TT(u.Xn, iV); h_tXnY = c.TT(u.Xn, iY); h_tXYn = c.TC(u.iX, Yn); h_dNY = c.l.dNext[Y];
+      h_posV = (int)c.l.pos[V]; h_nextU = (int)c.l.next[u.U];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   const double sumPen = u.penU + penV;
   {   // move1 (LocalSearch.cpp:134-162)
     double cU = u.dUpX - u.dUpU - u.dUX;
@@ -350,7 +368,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
     }
     if (ok && !(cU + cV > -HGS_EPS) && !(u.U == Y || V == u.X || u.xDep)) return 2;
   }
-  const double dVX = c.TT(u.iX, iV);
+  const double dVX = HOIST ? h_dVX : c.TT(u.iX, iV);
   {   // move3 (:195-224)
     double cU = u.dUpXn - u.dUpU - u.dUX - u.dXXn;
     double cV = dVX + u.dXU + dUY - dVY;
@@ -363,7 +381,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
     if (ok && !(cU + cV > -HGS_EPS) && !(u.U == Y || u.X == V || u.xDep)) return 3;
   }
   if (block == 0) {
-    const double dUpV = c.TC(u.Up, iV), dVpU = c.TT(u.iU, Vp), dVpV = c.l.dNext[prevV];
+    const double dUpV = HOIST ? h_dUpV : c.TC(u.Up, iV), dVpU = HOIST ? h_dVpU : c.TT(u.iU, Vp), dVpV = HOIST ? h_dVpV : c.l.dNext[prevV];
     if (u.iU <= iV) {   // move4 (:226-254)
       double cU = dUpV + dVX - u.dUpU - u.dUX;
       double cV = dVpU + dUY - dVpV - dVY;
@@ -376,7 +394,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
       if (ok && !(cU + cV > -HGS_EPS) && !(u.iU == Vp || u.iU == iY)) return 4;
     }
     {   // move5 (:256-285)
-      double cU = dUpV + c.TT(u.Xn, iV) - u.dUpU - u.dXXn;
+      double cU = dUpV + (HOIST ? h_tXnV : c.TT(u.Xn, iV)) - u.dUpU - u.dXXn;
       double cV = dVpU + dXY - dVpV - dVY;
       bool ok = true;
       if (!intra) {
@@ -387,8 +405,8 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
       if (ok && !(cU + cV > -HGS_EPS) && !(u.U == prevV || u.X == prevV || u.U == Y || u.xDep)) return 5;
     }
     if (u.iU <= iV) {   // move6 (:287-316)
-      double cU = dUpV + c.TT(u.Xn, iY) - u.dUpU - u.dXXn;
-      double cV = dVpU + c.TC(u.iX, Yn) - dVpV - c.l.dNext[Y];
+      double cU = dUpV + (HOIST ? h_tXnY : c.TT(u.Xn, iY)) - u.dUpU - u.dXXn;
+      double cV = dVpU + (HOIST ? h_tXYn : c.TC(u.iX, Yn)) - dVpV - (HOIST ? h_dNY : c.l.dNext[Y]);
       bool ok = true;
       if (!intra) {
         if (cU + cV >= sumPen) ok = false;
@@ -399,16 +417,16 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
           !(u.xDep || yDep || Y == u.prevU || u.U == Y || u.X == V || V == u.nextX)) return 6;
     }
     if (intra) {        // move7 (:318-352)
-      if (!(u.posU > (int)c.l.pos[V])) {
-        const double cost = c.TC(u.iU, iV) + dXY - u.dUX - dVY + c.l.cumRev[V] - u.cumRevX;
-        if (!(cost > -HGS_EPS) && c.l.next[u.U] != V) return 7;
+      if (!(u.posU > (HOIST ? h_posV : (int)c.l.pos[V]))) {
+        const double cost = (HOIST ? h_tUV : c.TC(u.iU, iV)) + dXY - u.dUX - dVY + (HOIST ? h_cumRevV : c.l.cumRev[V]) - u.cumRevX;
+        if (!(cost > -HGS_EPS) && (HOIST ? h_nextU : (int)c.l.next[u.U]) != V) return 7;
       }
     }
   }
   if ((block == 0 && !intra) || block == 1) {
     if (!intra) {       // move8 (:354-425)
-      const double cumLoadV = c.l.cumLoad[V];
-      double cost = c.TC(u.iU, iV) + dXY - u.dUX - dVY + c.l.cumRev[V] + u.revDistU - u.cumRevX - u.penU - penV;
+      const double cumLoadV = HOIST ? h_cumLoadV : c.l.cumLoad[V];
+      double cost = (HOIST ? h_tUV : c.TC(u.iU, iV)) + dXY - u.dUX - dVY + (HOIST ? h_cumRevV : c.l.cumRev[V]) + u.revDistU - u.cumRevX - u.penU - penV;
       if (!(cost >= 0)) {
         cost += c.pen(u.cumLoadU + cumLoadV) + c.pen(u.loadRU + loadRV - u.cumLoadU - cumLoadV);
         if (!(cost > -HGS_EPS)) return 8;
@@ -416,7 +434,7 @@ __device__ inline int hgs_eval(const HgsCtx &c, const USide &u, int V, int block
     }
   }
   if (!intra || block == 2) {   // move9 (:427-484)
-    const double cumLoadV = c.l.cumLoad[V];
+    const double cumLoadV = HOIST ? h_cumLoadV : c.l.cumLoad[V];
     double cost = dUY + dVX - u.dUX - dVY - u.penU - penV;
     if (!(cost >= 0)) {
       cost += c.pen(u.cumLoadU + loadRV - cumLoadV) + c.pen(cumLoadV + u.loadRU - u.cumLoadU);
@@ -563,6 +581,15 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
 
     // ---- the routes of the input (cvrp_nls/aco.py:12-20 get_subroutes: the non-empty pieces between zeros)
     int R = 0, status = 0, totalMoves = 0, totalLoops = 0, nRounds = 0;
+#ifdef DACO_HGS_PROFILE   // (measurement build: shader-clock cycles per phase instead of loops / rounds / watchdog in the stats)
+    unsigned long long pf_eval = 0, pf_apply = 0, pf_other = 0, pf_t0 = 0;
+    const unsigned long long pf_begin = __builtin_readcyclecounter();
+#define PF_START() (pf_t0 = __builtin_readcyclecounter())
+#define PF_ADD(acc) ((acc) += __builtin_readcyclecounter() - pf_t0)
+#else
+#define PF_START() ((void)0)
+#define PF_ADD(acc) ((void)0)
+#endif
     {   // pass A: entries in range, number of routes, every client exactly once (Individual.cpp:69)
       int last = 0, seen = 0;
       bool bad = false;
@@ -719,6 +746,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
               if (loopID != 0) { const int wv = c.l.rWhen[c.l.route[Vs]]; act = act && (wu > wv ? wu : wv) > lastTest; }
               if (!__ballot(act)) break;
               ++nRounds;
+              PF_START();
               hgs_set_u<false>(c, U, u);
               // the lanes that are not evaluated look at U itself: their matrix gathers fall on the lines the U side reads
               // anyway (a gated-off lane that gathered ITS V's entries cost the data-return unit as much as a live one: the
@@ -726,28 +754,32 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
               const int Ve = act ? Vs : U;
               const int pvn = c.l.prev[Ve];
               const bool depPrev = c.isdep(pvn);
-              const int c0 = hgs_eval(c, u, Ve, 0);
+              const int c0 = hgs_eval<LM>(c, u, Ve, 0);
               int code = act ? c0 : 0;
               // "insert after the depot" (LocalSearch.cpp:47-56) for the lanes whose V opens its route and found nothing: only
               // when such a lane exists (in the late loops few lanes are evaluated at all)
               const bool need1 = act && c0 == 0 && depPrev;
               if (__ballot(need1)) {
-                const int c1 = hgs_eval(c, u, need1 ? pvn : U, 1);
+                const int c1 = hgs_eval<LM>(c, u, need1 ? pvn : U, 1);
                 if (need1 && c1) code = c1 + 16;
               }
               const uint64_t m = __ballot(code != 0);
+              PF_ADD(pf_eval);
               if (!m) break;
               const int pl = __builtin_ctzll(m);
+              PF_START();
               const int mv = __builtin_amdgcn_readlane(code, pl);
               int V = __builtin_amdgcn_readlane(myV, pl);
               if (mv & 16) V = c.l.prev[V];
               hgs_apply(c, mv & 15, U, V);
+              PF_ADD(pf_apply);
               searchCompleted = false;
               start = pl + 1;
               if (start >= 64) break;
             }
           }
           if (loopID > 0) {                                                   // LocalSearch.cpp:60-71: an empty route
+            PF_START();
             int er = -1;
             for (int r0 = 0; r0 < R && er < 0; r0 += 64) {
               const uint64_t m = __ballot(r0 + lane < R && c.l.rCnt[r0 + lane] == 0);
@@ -762,7 +794,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
                   const int Ul = u0 + lane <= nc ? u0 + lane : 1;
                   USide ul;
                   hgs_set_u<false>(c, Ul, ul);
-                  const int mvl = hgs_eval(c, ul, c.dep(er), 2);
+                  const int mvl = hgs_eval<LM>(c, ul, c.dep(er), 2);
                   if (u0 + lane <= nc) c.l.e2[Ul] = (uint8_t)mvl;
                 }
                 e2stamp = c.nbMoves; e2er = er;
@@ -770,6 +802,7 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
               const int mv = c.l.e2[U];
               if (mv) { hgs_apply(c, mv, U, c.dep(er)); searchCompleted = false; }
             }
+            PF_ADD(pf_other);
           }
         }
       }
@@ -840,6 +873,12 @@ __global__ __launch_bounds__(WAVES * 64, WPS) void hgs_ls_kernel(const HgsParams
     if (lane == 0) {
       if (p.status) p.status[item] = status;
       if (p.stats) { p.stats[(size_t)item * 4] = totalMoves; p.stats[(size_t)item * 4 + 1] = totalLoops; p.stats[(size_t)item * 4 + 2] = nRounds; p.stats[(size_t)item * 4 + 3] = c.fail; }
+#ifdef DACO_HGS_PROFILE
+      if (p.stats) {
+        p.stats[(size_t)item * 4 + 0] = (int)((__builtin_readcyclecounter() - pf_begin) >> 10);
+        p.stats[(size_t)item * 4 + 1] = (int)(pf_eval >> 10); p.stats[(size_t)item * 4 + 2] = (int)(pf_apply >> 10); p.stats[(size_t)item * 4 + 3] = (int)(pf_other >> 10);
+      }
+#endif
     }
   }
 }
