@@ -1216,6 +1216,19 @@ def extra_configs(dev, headline_colony, cpu=True):
     except Exception as e:
         out["siblings_n100_a512"] = {"error": repr(e)}
 
+    # the reference's own call patterns through the drop-in classes (one instance per colony, its harness' ant counts: tsp/test.ipynb,
+    # tsp_nls/test.py, cvrp/test.py), ms per ACO iteration -- tools/time_reference_calls.py
+    try:
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "time_reference_calls.py"), "50"], capture_output=True, text=True, timeout=300)
+        rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        out["reference_call_patterns"] = {
+            "workload": "ACO.run through the drop-in classes, ONE instance per colony with the ant counts of the reference's harnesses "
+                        "(tools/time_reference_calls.py: heuristic = sparsified 1/d; tsp_nls with its inference NLS)",
+            "unit": "ms per ACO iteration", "rows": rows}
+    except Exception as e:
+        out["reference_call_patterns"] = {"error": repr(e)}
+
     # GNN forward (eval), 64 graphs of TSP-500 k=50 side by side
     from deepaco_amd.tsp.net import Net
     torch.manual_seed(0)
