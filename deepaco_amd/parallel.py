@@ -63,12 +63,20 @@ def barrier_max_time(fn, device, distributed):
             dist.barrier()
         if device.type == "cuda":
             torch.cuda.synchronize(device)
+    import gc
+    gc.collect()                 # (the timed region makes no cyclic garbage worth a pass: a collector pause inside a region of a
+    was_on = gc.isenabled()      # dozen milliseconds would be measured as device time)
+    gc.disable()
     fence()
     t0 = time.perf_counter()
-    fn()
-    if device.type == "cuda":
-        torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
+    try:
+        fn()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+    finally:
+        if was_on:
+            gc.enable()
     if distributed:
         # gloo reduces host tensors, nccl (= RCCL) device tensors
         tdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
