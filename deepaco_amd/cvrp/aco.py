@@ -117,12 +117,16 @@ class ACO():
         tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
         eta = self.heuristic.detach()
         cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
+        # (loop invariants formed once: at CVRP-20 / 100 with 20 ants an iteration is three library calls whose HOST time is the
+        # iteration time -- tools/host_overhead_small.py -- so the demands are laid out [1, n] here, not copied per call, and the
+        # flag words are the loop's own, OR-ed into by every construction)
+        dem = self.demand.detach()
+        dem = (dem if dem.dtype == torch.float64 else dem.to(torch.float32)).reshape(1, -1).contiguous()
         for _ in range(n_iterations):
-            paths, _, _, lens, flags, costs, table = engine.cvrp_sample(
-                tau, eta, self.demand, self.capacity, self.n_ants, self.alpha,
-                self.beta, mode=self.sampler, seed=self.seed, it=self._calls, batch=1, dist=dist, want_table=True)
+            paths, _, _, lens, _, costs, table = engine.cvrp_sample(
+                tau, eta, dem, self.capacity, self.n_ants, self.alpha,
+                self.beta, mode=self.sampler, seed=self.seed, it=self._calls, batch=1, dist=dist, want_table=True, flags=flags_seen)
             self._calls += 1
-            flags_seen |= flags
             new_max = engine.track_best_(costs, paths, lowest, shortest,
                                          mmas_scale=self.problem_size if self.min_max else None)
             cmin = cmax = None

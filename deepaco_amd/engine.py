@@ -56,6 +56,25 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+def _on(device):
+    """`with torch.cuda.device(device)` only when that device is not the current one already: the context manager costs ~10 us per
+    use, and at the reference's small sizes (TSP-20 / CVRP-100 with 20 ants: tools/host_overhead_small.py) an ACO iteration is three
+    library calls whose host time IS the iteration time."""
+    return _NULL_CTX if torch.cuda.current_device() == (device.index if device.index is not None else torch.cuda.current_device()) \
+        else torch.cuda.device(device)
+
+
 def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
 
@@ -68,7 +87,7 @@ def _bstride(t, n):
 
 def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1, start=None,
                fixed_start=-1, noise=None, seed=0, it=0, ant_gid0=0, require_prob=False, batch=None,
-               events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0):
+               events=None, dist=None, want_nbr=False, iter_dev=None, ant_gid_bstride=0, flags=None):
     """ACO.gen_path for a batch (tsp/aco.py:134-177, tsp_nls/aco.py:184-220).
 
     tau, eta: [B,n,n] or [n,n] (shared).  Returns (paths, log_probs|None, rowsum|None, flags).
@@ -85,11 +104,12 @@ def tsp_sample(tau, eta, n_ants, alpha=1.0, beta=1.0, mode="scan", norm_passes=1
     eta, ebs = _bstride(eta, n)
     m = MODES[mode] if isinstance(mode, str) else int(mode)
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         paths = torch.empty((B, n, n_ants), dtype=torch.int64, device=dev)
         logp = torch.empty((B, n - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
         rowsum = torch.empty((B, n - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
-        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if flags is None:                                    # (a caller's own flag words are OR-ed into: no fill launch per call)
+            flags = torch.zeros((B,), dtype=torch.int32, device=dev)
         if start is not None:
             start = start.to(torch.int64).contiguous().view(B, n_ants)
         if noise is not None:      # race_noise: the reference's q tensors; scan modes: injected uniforms [B, n-1, A]
@@ -273,7 +293,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
     eta, ebs = _bstride(eta, n)
     assert head.dtype == torch.int16 and head.is_contiguous() and tuple(head.shape) in ((B, n, 64), (B, n, 128))
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         paths = torch.empty((B, n, n_ants), dtype=torch.int64, device=dev) if want_paths else None
         if flags is None:                                    # (a caller that keeps its flag words -- they are OR-ed into -- saves a fill launch per call)
             flags = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -312,7 +332,7 @@ def tsp_sample_sparse(tau, eta, n_ants, head, alpha=1.0, beta=1.0, start=None, f
 
 def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="scan", noise=None, seed=0,
                 it=0, ant_gid0=0, require_prob=False, Lmax=None, batch=None, dist=None, want_table=False,
-                iter_dev=None, events=None, ant_gid_bstride=0):
+                iter_dev=None, events=None, ant_gid_bstride=0, flags=None):
     """CVRP ACO.gen_path for a batch (cvrp/aco.py:138-205).  tau, eta [B,n,n] or [n,n]; demand [B,n]
     or [n] (demand[0] = 0).  Returns (paths [B,Lmax,A], log_probs|None, rowsum|None, lens [B,A], flags [B]);
     the reference's result is paths[:, :lens.max()].
@@ -338,12 +358,13 @@ def cvrp_sample(tau, eta, demand, capacity, n_ants, alpha=1.0, beta=1.0, mode="s
     m = MODES[mode] if isinstance(mode, str) else int(mode)
     Lmax = Lmax or 2 * n + 1
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         paths = torch.empty((B, Lmax, n_ants), dtype=torch.int64, device=dev)
         logp = torch.empty((B, Lmax - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
         rowsum = torch.ones((B, Lmax - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
         lens = torch.empty((B, n_ants), dtype=torch.int32, device=dev)
-        flags = torch.zeros((B,), dtype=torch.int32, device=dev)
+        if flags is None:                                    # (a caller that keeps its flag words -- they are OR-ed into -- saves a fill launch per call)
+            flags = torch.zeros((B,), dtype=torch.int32, device=dev)
         steps = 0
         if noise is not None:
             noise = _f32c(noise)
@@ -398,7 +419,7 @@ def sample_backward(tau, eta, alpha, beta, paths, rowsum, grad_logp, lens=None, 
         if demand.dim() == 1:
             demand = demand.unsqueeze(0).expand(B, n).contiguous()
         lens = lens.contiguous()
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad = torch.zeros((B, n, n), dtype=torch.float32, device=dev)
         rc = _lib.lib().daco_sample_backward(_stream(dev), B, n, A, rows, tau.data_ptr(), tbs, eta.data_ptr(), ebs,
                                              float(alpha), float(beta), paths.data_ptr(), rowsum.data_ptr(),
@@ -443,7 +464,7 @@ def sibling_sample(kind, tau, eta, n_ants, alpha=1.0, beta=1.0, aux_vec=None, au
         if item_weights.dim() == 2:
             item_weights = item_weights.unsqueeze(0).expand(B, n, mdim).contiguous()
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         paths = torch.empty((B, rows, n_ants), dtype=torch.int64, device=dev)
         logp = torch.empty((B, rows - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
         rowsum = torch.ones((B, rows - 1, n_ants), dtype=torch.float32, device=dev) if require_prob else None
@@ -497,7 +518,7 @@ def sibling_backward(kind, tau, eta, alpha, beta, paths, rowsum, grad_logp, lens
         if item_weights.dim() == 2:
             item_weights = item_weights.unsqueeze(0).expand(B, n, mdim).contiguous()
     dev = paths.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         grad = torch.zeros((B, n, n), dtype=torch.float32, device=dev)
         rc = _lib.lib().daco_sibling_backward(
             _stream(dev), SIB_KINDS[kind], B, n, A, rows, tau.data_ptr(), tbs, eta.data_ptr(), ebs, float(alpha),
@@ -566,7 +587,7 @@ def tsp_knn_graph(coords, k_sparse, diag=1e9, want_dist=True):
     B, n, _ = coords.shape
     dev = coords.device
     E = n * int(k_sparse)
-    with torch.cuda.device(dev):
+    with _on(dev):
         dist = torch.empty((B, n, n), dtype=torch.float32, device=dev) if want_dist else None
         ei = torch.empty((B, 2, E), dtype=torch.int64, device=dev)
         ea = torch.empty((B, E, 1), dtype=torch.float32, device=dev)
@@ -600,7 +621,7 @@ def heu_matrix(n, edge_index, heu, fill=0.0, add=0.0, check=False):
     ei = edge_index.contiguous()
     heu = _f32c(heu.detach())
     dev = heu.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((B, n, n), dtype=torch.float32, device=dev)
         bad = torch.zeros((1,), dtype=torch.int32, device=dev) if check else None
         rc = _lib.lib().daco_heu_matrix(_stream(dev), B, n, E, ei.data_ptr(), heu.data_ptr(), float(fill), float(add),
@@ -619,7 +640,7 @@ def tour_costs(dist, paths, closed=True):
     dist, dbs = _bstride(dist, n)
     paths = paths.contiguous()
     dev = paths.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         costs = torch.empty((B, A), dtype=torch.float32, device=dev)
         rc = _lib.lib().daco_tour_costs(_stream(dev), B, n, length, A, dist.data_ptr(), dbs, paths.data_ptr(),
                                         int(closed), costs.data_ptr())
@@ -637,7 +658,7 @@ def track_best_(costs, paths, lowest, shortest=None, mmas_scale=None, tours16=No
     B, A = costs.shape
     assert lowest.dtype == torch.float32 and lowest.is_contiguous() and lowest.numel() == B
     dev = costs.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         mx = torch.empty((B,), dtype=torch.float32, device=dev) if mmas_scale is not None else None
         if paths is None:
             assert tours16 is not None and tours16.dtype == torch.int16 and tours16.is_contiguous() and shortest is not None
@@ -682,7 +703,7 @@ def pheromone_update_(tau, paths, costs, decay, elitist=False, symmetric=True, c
         weights = _f32c(weights)
     dev = tau.device
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = L.daco_pheromone_update_workspace_bytes(B, n, length, A)
         ws = _workspace(dev, nbytes, "update")
         if heads is not None:
@@ -736,7 +757,7 @@ class TwoOptTables:
         B = 1 if m.dim() == 2 else m.shape[0]
         L = _lib.lib()
         dev = m.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             nbytes = L.daco_two_opt_tables_bytes(B, n)
             buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             rc = L.daco_two_opt_prepare(_stream(dev), B, n, m.data_ptr(), dbs, buf.data_ptr(), nbytes)
@@ -764,7 +785,7 @@ def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None, t
         B, T, _ = t3.shape
         assert tables.B == B, f"two_opt_: tables built for {tables.B} instances, launch has {B}"
         dev = tours.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             if kernel == "cached":                  # one launch of the NLS kernel without rounds: dirty-list sweeps
                 sweeps = torch.empty(tuple(shape), dtype=torch.int32, device=dev) if want_sweeps else None
                 rc = _lib.lib().daco_tsp_nls(_stream(dev), B, T, n, dist.data_ptr(), dbs, tables.tables.data_ptr(),
@@ -799,7 +820,7 @@ def two_opt_(dist, tours, max_iterations=1000, want_sweeps=False, dist_t=None, t
         dist_t = dist if same else _bstride(dist_t, n)[0]
         assert dist_t.shape == dist.shape
     dev = tours.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         sweeps = torch.empty((B, T), dtype=torch.int32, device=dev) if want_sweeps else None
         rc = _lib.lib().daco_two_opt(_stream(dev), B, T, n, dist.data_ptr(),
                                      dist_t.data_ptr() if dist_t is not None else None, dbs, t3.data_ptr(),
@@ -825,7 +846,7 @@ def cvrp_local_search_(dist, demand, capacity, paths, max_moves, want_stats=Fals
     if demand.dim() == 1:
         demand = demand.unsqueeze(0).expand(B, n).contiguous()
     dev = paths.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         lens = torch.empty((B, A), dtype=torch.int32, device=dev) if want_stats else None
         moves = torch.empty((B, A), dtype=torch.int32, device=dev) if want_stats else None
         rc = _lib.lib().daco_cvrp_local_search(_stream(dev), B, n, A, Lmax, dist.data_ptr(), dbs, demand.data_ptr(),
@@ -853,7 +874,7 @@ class HgsTables:
         L = _lib.lib()
         self.table_bytes = L.daco_hgs_table_bytes(self.n, self.nb_granular)
         dev = self.matrix.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             self.tables = torch.empty(self.B * self.table_bytes, dtype=torch.uint8, device=dev)
             rc = L.daco_hgs_prepare(_stream(dev), self.B, self.n, self.matrix.data_ptr(), self.n * self.n, self.nb_granular,
                                     self.tables.data_ptr())
@@ -890,7 +911,7 @@ def hgs_local_search_(paths, stages, demand, capacity=1000.001, demand_scale=100
         if st[0].B == 1 and B > 1:
             raise ValueError("hgs_local_search_: one table set per instance is needed (B tables)")
     L = _lib.lib()
-    with torch.cuda.device(dev):
+    with _on(dev):
         wsb = L.daco_hgs_workspace_bytes(B, n, A, Lmax, g)
         ws = _workspace(dev, wsb, "hgs_ls")
         status = torch.empty((B, A), dtype=torch.int32, device=dev)
@@ -947,7 +968,7 @@ def nls_(dist, heuristic_dist, tours, maxt, T_nls=10, T_p=20, dist_t=None, heuri
         d, dbs = _bstride(dist, n)
         h, hbs = _bstride(heuristic_dist, n)
         dev = tours.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             costs = torch.empty((B, T), dtype=torch.float32, device=dev) if want_costs else None
             rc = _lib.lib().daco_tsp_nls(_stream(dev), B, T, n, d.data_ptr(), dbs, tables.tables.data_ptr(),
                                          tables.tables_t.data_ptr(), h.data_ptr(), hbs,

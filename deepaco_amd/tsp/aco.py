@@ -146,11 +146,12 @@ class ACO():
         tau = self.pheromone.detach().to(torch.float32).clone().contiguous().unsqueeze(0)
         eta = self.heuristic.detach()
         cmin_t = torch.full((1,), float(self.min), device=dev) if self.min_max else None
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)        # the loop's own flag words (OR-ed into by every construction)
         for _ in range(n_iterations):
-            paths, _, _, flags, costs, nbr = engine.tsp_sample(
+            paths, _, _, _, costs, nbr = engine.tsp_sample(
                 tau, eta, self.n_ants, self.alpha, self.beta, mode=sampler,
                 norm_passes=self.NORM_PASSES, fixed_start=self.FIXED_START, seed=self.seed, it=self._calls, batch=1,
-                dist=dist, want_nbr=True)
+                dist=dist, want_nbr=True, flags=flags)
             self._calls += 1
             self._last_flags = flags
             # `if best_cost < self.lowest_cost: ...` (tsp/aco.py:78-88) on the device
