@@ -1518,6 +1518,8 @@ def worker(args):
     else:
         resolved = (colony.cols[0] if streams > 1 else colony).resolved_sampler()[0]
     log(f"rank {rank}/{world}: TSP-{n} x {A} ants x {B} instances, sampler={args.sampler} -> {resolved}")
+    import gc
+    gc.collect()                  # (before the warm-up, not between it and the timed region: see parallel.barrier_max_time)
     pre_steps = 0
     if args.precondition_seconds > 0 and not ant_sharded:
         # a throw-away colony of the same shape keeps the device busy until its clocks have settled; the measured colony

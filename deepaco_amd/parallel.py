@@ -64,8 +64,11 @@ def barrier_max_time(fn, device, distributed):
         if device.type == "cuda":
             torch.cuda.synchronize(device)
     import gc
-    gc.collect()                 # (the timed region makes no cyclic garbage worth a pass: a collector pause inside a region of a
-    was_on = gc.isenabled()      # dozen milliseconds would be measured as device time)
+    # the collector is off inside the region (a pause inside a dozen milliseconds would be measured as device time) -- and NOT run
+    # here: a full collection is tens of milliseconds of host work during which the device idles and its clocks fall back, which
+    # the first steps of the region then pay for (measured: 47.8 M instead of 51.2 M ant-tours/s with a gc.collect() at this point;
+    # callers that want one run it before their warm-up steps)
+    was_on = gc.isenabled()
     gc.disable()
     fence()
     t0 = time.perf_counter()
