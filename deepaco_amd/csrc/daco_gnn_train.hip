@@ -280,6 +280,34 @@ __device__ inline void flush_acc(float *dstM, const f32x16 &acc, int lane) {
 #endif
 }
 
+// Round 6: one flush per WORKGROUP.  Every wave used to add its 32x32 accumulator to the same 1 024 words of the flat gradient: an
+// address's atomic adds execute one after the other in the L2 (~75 ns apiece), so a launch of W wavefronts took W x 75 ns whatever
+// else it did -- gnn_t_edge_bwd 300 us at 200 k edges (4 096 wavefronts), 70 us at 20 k (625), gnn_t_head_bwd 329 us; making the
+// flush sixteen times smaller changed nothing (profiles/r06_gnn_train_flush_ablation.txt: it is the number of adds PER ADDRESS).
+// The four waves of a workgroup now add their accumulators in LDS first (ds_add_f32: four adds per word), a launch has at most one
+// workgroup per CU (waves walk more tiles), and the workgroup's 256 threads flush four words each.
+// `red`: >= 1 024 floats of LDS no wave uses any more (callers put a barrier before; all 256 threads call this).
+__device__ inline void flush_acc_wg(float *dstM, const f32x16 &acc, float *red) {
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31;
+  for (int i = tid; i < 1024; i += 256) red[i] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) atomicAdd(&red[t_drow(r, lane) * TU + j], acc[r]);
+  __syncthreads();
+  for (int i = tid; i < 1024; i += 256) unsafeAtomicAdd(dstM + i, red[i]);
+  __syncthreads();
+}
+// the same for per-channel vectors: every lane holds a partial sum for channel `o` (two lanes per wave and channel)
+__device__ inline void flush_vec_wg(float *dst, float v, int o, float *red /* >= 32 floats */, int words = 32) {
+  const int tid = threadIdx.x;
+  if (tid < 32) red[tid] = 0.0f;
+  __syncthreads();
+  atomicAdd(&red[o], v);
+  __syncthreads();
+  if (tid < words) unsafeAtomicAdd(dst + tid, red[tid]);
+  __syncthreads();
+}
+
 // head backward: waves walk tiles (grid-stride), recompute a1, a2, accumulate gW1/gW2/gW3/gb in registers
 __global__ void __launch_bounds__(256)
 gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const float *gheu, float *gw, float *ghp) {
@@ -362,13 +390,15 @@ gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const f
     }
     __builtin_amdgcn_wave_barrier();
   }
-  flush_acc(gW1, aW1, lane);
-  flush_acc(gW2, aW2, lane);
+  __syncthreads();                                         // (the tiles in LDS are dead: the reduction area)
+  float *red = &tin_s[0][0][0];
+  flush_acc_wg(gW1, aW1, red);
+  flush_acc_wg(gW2, aW2, red);
   // per-channel vectors: both halves hold partial sums for channel o
-  unsafeAtomicAdd(gW3 + o, aW3);
-  unsafeAtomicAdd(gb1 + o, ab1);
-  unsafeAtomicAdd(gb2 + o, ab2);
-  if (o == 0) unsafeAtomicAdd(gb3, ab3);
+  flush_vec_wg(gW3, aW3, o, red);
+  flush_vec_wg(gb1, ab1, o, red);
+  flush_vec_wg(gb2, ab2, o, red);
+  flush_vec_wg(gb3, o == 0 ? ab3 : 0.0f, 0, red, 1);       // (a scalar: the lanes of channel 0 hold its partial sums)
 }
 
 // sum(g_y), sum(g_y * zhat) per channel and graph for an [R,32] tensor (edges or nodes); g_y = gout * dsilu(y)
@@ -404,6 +434,13 @@ __device__ inline float bn_bwd(float gout, float z, const Stat &st, float gamma,
   return gamma * st.rstd * (gy - m.x - zh * m.y);
 }
 
+// (the same with the backward table's entry already in hand)
+__device__ inline float bn_bwd_m(float gout, float z, const Stat &st, float gamma, float beta, const float2 m) {
+  const float zh = (z - st.mean) * st.rstd;
+  const float gy = gout * t_dsilu(fmaf(zh, gamma, beta));
+  return gamma * st.rstd * (gy - m.x - zh * m.y);
+}
+
 // node side: g_zv -> gX[:, 0:32] (x1 block) and g_msg = g_zv / degree; BatchNorm parameter gradients
 __global__ void __launch_bounds__(256)
 gnn_t_node_bwd_apply(int n, int ng, const int *rowptr, const float *gamma, const float *beta, const float2 *fsums,
@@ -432,8 +469,22 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
   f32x16 aW = ZERO16;
   float ab = 0.0f;
   const int ntiles = (E + 31) / 32;
+  // (a lane serves the same four channels c0 .. c0 + 3 of every edge it touches: their BatchNorm scale / shift are read once)
+  float gam[4], bet[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k]; }
   for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
     const int e0 = tix * 32;
+    // the statistics of the lane's four channels, once per tile when the tile lies inside one graph (32 edges, graphs of Eg edges:
+    // almost always) instead of once per element: sixteen 8-byte loads per lane and tile instead of thirty-two per pass
+    const int g_first = e0 / Eg, g_last = (min(e0 + 31, E - 1)) / Eg;
+    const bool one_graph = g_first == g_last;
+    Stat st_t[4];
+    float2 bs_t[4];
+    if (one_graph) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { st_t[k] = load_stat(fsums, g_first, c0 + k, Eg); bs_t[k] = bsums[(size_t)g_first * 32 + c0 + k]; }
+    }
     // edge-major pass: g_ze per element, scatter-adds, gate path; tiles tw = w, tg = g_ze
     float4 gres[4], gate_term[4];
 #pragma unroll
@@ -454,8 +505,9 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
         const float gmc[4] = {gm.x, gm.y, gm.z, gm.w}, x2c[4] = {x2.x, x2.y, x2.z, x2.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const Stat st = load_stat(fsums, g, c0 + k, Eg);
-          gzc[k] = bn_bwd(gc[k], zc[k], st, gamma[c0 + k], beta[c0 + k], bsums, g, c0 + k, Eg);
+          const Stat st = one_graph ? st_t[k] : load_stat(fsums, g, c0 + k, Eg);
+          const float2 bm = one_graph ? bs_t[k] : bsums[(size_t)g * 32 + c0 + k];
+          gzc[k] = bn_bwd_m(gc[k], zc[k], st, gam[k], bet[k], bm);
           const float gate = t_sigmoid(wc[k]);
           gt[k] = gmc[k] * x2c[k] * gate * (1.0f - gate);                   // d msg / d w through the gate
           c2c[k] = gmc[k] * gate;                                           // d / d x2[dst]
@@ -501,8 +553,10 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
     }
     __builtin_amdgcn_wave_barrier();
   }
-  flush_acc(gWe, aW, lane);
-  unsafeAtomicAdd(gbe + o, ab);
+  __syncthreads();
+  float *red = &tw_s[0][0][0];
+  flush_acc_wg(gWe, aW, red);
+  flush_vec_wg(gbe, ab, o, red);
 }
 
 // gX[:, x2 | x3 | x4 blocks] as sums over CSR rows of the per-edge contributions edge_bwd stored (no atomics, fixed order):
@@ -624,6 +678,9 @@ gnn_t_node_lin_bwd(int n, const float *WT, const float *x0, const float *gX, flo
     }
     __builtin_amdgcn_wave_barrier();
   }
+  // (per wave, as before round 6: this launch has a few dozen to ~125 wavefronts -- n / 32 tiles -- so a word of gWT sees that
+  // many adds, a few microseconds; combining the waves through LDS first -- flush_acc_wg, four column blocks -- cost more in
+  // barriers than it saved: 38.7 -> 57 us at n = 2 000)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int j = lane & 31;
@@ -815,7 +872,8 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
   const int ng = n / G, Eg = E / G;
   const int node_blocks = (n + 7) / 8;
   const int etiles = (E + 31) / 32, ntiles = (n + 31) / 32;
-  const int egrid = etiles / 4 + 1 < 1024 ? etiles / 4 + 1 : 1024, ngrid = ntiles / 4 + 1 < 512 ? ntiles / 4 + 1 : 512;
+  // (at most one workgroup per CU: the waves walk more tiles, and fewer workgroups add into the same words of the gradient)
+  const int egrid = etiles / 4 + 1 < 256 ? etiles / 4 + 1 : 256, ngrid = ntiles / 4 + 1 < 512 ? ntiles / 4 + 1 : 512;
   const size_t pfloats = t_off_head(feats) + 2 * (1024 + 32) + 32 + 1;
   // (kernels, not memset nodes: daco_device.h zero_async)
   if (zero_async(grad_params, pfloats * 4, s) != hipSuccess || zero_async(t.gx, (size_t)n * 32 * 4, s) != hipSuccess ||
