@@ -93,9 +93,16 @@ gnn_t_edge_pre(int E, int Eg, const int *src, const int *dst, const float *We, c
   __shared__ __attribute__((aligned(16))) float tile_s[4][32][36];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float (*tile)[36] = tile_s[wave];
+  __shared__ double red[4][64];                             // (one add per channel, statistic and workgroup: see gnn_t_bwd_stats)
   const int e0 = (blockIdx.x * 4 + wave) * 32;
-  if (e0 >= E) return;
   const int o = lane & 31, h = lane >> 5, c0 = (lane & 7) * 4;
+  // the workgroup's 128 edges in one graph (uniform): the four waves' sums are added in LDS and flushed once
+  const int wg0 = blockIdx.x * 128, wg1 = min(wg0 + 127, E - 1);
+  const bool one_graph = wg0 / Eg == wg1 / Eg;
+  if (e0 >= E) {                                            // (a wave past the end: nothing to do but the workgroup's barrier)
+    if (one_graph) { red[wave][lane] = 0.0; __syncthreads(); }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
@@ -133,28 +140,49 @@ gnn_t_edge_pre(int E, int Eg, const int *src, const int *dst, const float *We, c
     const float v = tile[el][o];
     accd += h ? (double)v * (double)v : (double)v;
   }
-  unsafeAtomicAdd(sums + ((size_t)gcur * 32 + o) * 2 + h, accd);
+  if (one_graph) {
+    red[wave][lane] = accd;
+    __syncthreads();
+    if (wave == 0) unsafeAtomicAdd(sums + ((size_t)gcur * 32 + o) * 2 + h, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  } else unsafeAtomicAdd(sums + ((size_t)gcur * 32 + o) * 2 + h, accd);
 }
 
 // zv = x1 + mean over out-edges of sigmoid(w) * x2[dst]; 8 nodes per workgroup, 32 lanes per node
 __global__ void __launch_bounds__(256)
 gnn_t_node_pre(int n, int ng, const int *dst, const int *rowptr, const int *perm, const float *X, const float *w0,
                float *zv, double *sums) {
+  __shared__ double red[8][32][2];                          // (one add per channel and workgroup: see gnn_t_bwd_stats)
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
   const int i = blockIdx.x * 8 + il;
-  if (i >= n) return;
-  const int lo = rowptr[i], hi = rowptr[i + 1];
-  float agg = 0.0f;
-  for (int q = lo; q < hi; ++q) {
-    const int e = perm ? perm[q] : q;
-    agg = fmaf(t_sigmoid(w0[(size_t)e * TU + o]), X[(size_t)dst[e] * 128 + 32 + o], agg);
+  const bool live = i < n;
+  float z = 0.0f;
+  if (live) {
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    float agg = 0.0f;
+    for (int q = lo; q < hi; ++q) {
+      const int e = perm ? perm[q] : q;
+      agg = fmaf(t_sigmoid(w0[(size_t)e * TU + o]), X[(size_t)dst[e] * 128 + 32 + o], agg);
+    }
+    agg = agg / (float)max(hi - lo, 1);
+    z = X[(size_t)i * 128 + o] + agg;
+    zv[(size_t)i * TU + o] = z;
   }
-  agg = agg / (float)max(hi - lo, 1);
-  const float z = X[(size_t)i * 128 + o] + agg;
-  zv[(size_t)i * TU + o] = z;
-  const int g = i / ng;
-  unsafeAtomicAdd(sums + ((size_t)g * 32 + o) * 2, (double)z);
-  unsafeAtomicAdd(sums + ((size_t)g * 32 + o) * 2 + 1, (double)z * (double)z);
+  const int i0 = blockIdx.x * 8, i1 = min(i0 + 7, n - 1);
+  if (i0 / ng == i1 / ng) {                                 // the workgroup's nodes lie in one graph (uniform)
+    red[il][o][0] = live ? (double)z : 0.0; red[il][o][1] = live ? (double)z * (double)z : 0.0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int oo = threadIdx.x >> 1, k = threadIdx.x & 1;
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += red[j][oo][k];
+      unsafeAtomicAdd(sums + ((size_t)(i0 / ng) * 32 + oo) * 2 + k, t);
+    }
+  } else if (live) {
+    const int g = i / ng;
+    unsafeAtomicAdd(sums + ((size_t)g * 32 + o) * 2, (double)z);
+    unsafeAtomicAdd(sums + ((size_t)g * 32 + o) * 2 + 1, (double)z * (double)z);
+  }
 }
 
 // w' = w + silu(gamma * (ze - mean) * rstd + beta)
@@ -406,12 +434,17 @@ __global__ void __launch_bounds__(256)
 gnn_t_bwd_stats(int R, int Rg, const float *gamma, const float *beta, const float2 *fsums, const float *z, const float *gout,
                 double *bsums) {
   // 8 rows per pass and workgroup-pass; thread = (row slot, channel); rows of one workgroup: a contiguous chunk
+  // (round 6: the adds to one word of `bsums` execute one after the other in the L2 -- ~75 ns apiece -- and every thread used to
+  // add its own partial sums: 8 x (workgroups per graph) adds per word, 43 us per launch at 200 k edges.  A workgroup whose rows
+  // lie in one graph now sums its eight row slots in LDS first and adds once per channel.)
+  __shared__ double red[8][32][2];
   const int il = threadIdx.x >> 5, o = threadIdx.x & 31;
   const int rows_per_wg = 256;
-  const int r0 = blockIdx.x * rows_per_wg;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(R, r0 + rows_per_wg);
+  const bool one_graph = r0 < r1 && r0 / Rg == (r1 - 1) / Rg;           // uniform
   double s1 = 0.0, s2 = 0.0;
   int gcur = -1;
-  for (int r = r0 + il; r < min(R, r0 + rows_per_wg); r += 8) {
+  for (int r = r0 + il; r < r1; r += 8) {
     const int g = r / Rg;
     if (g != gcur) {
       if (gcur >= 0) { unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2, s1); unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2 + 1, s2); }
@@ -422,7 +455,17 @@ gnn_t_bwd_stats(int R, int Rg, const float *gamma, const float *beta, const floa
     const float gy = gout[(size_t)r * TU + o] * t_dsilu(fmaf(zh, gamma[o], beta[o]));
     s1 += (double)gy; s2 += (double)gy * (double)zh;
   }
-  if (gcur >= 0) { unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2, s1); unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2 + 1, s2); }
+  if (one_graph) {
+    red[il][o][0] = s1; red[il][o][1] = s2;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int oo = threadIdx.x >> 1, k = threadIdx.x & 1;
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += red[j][oo][k];
+      unsafeAtomicAdd(bsums + ((size_t)(r0 / Rg) * 32 + oo) * 2 + k, t);
+    }
+  } else if (gcur >= 0) { unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2, s1); unsafeAtomicAdd(bsums + ((size_t)gcur * 32 + o) * 2 + 1, s2); }
 }
 
 // g_z of a BatchNorm'd row element: (gamma * rstd) * (g_y - mean(g_y) - zhat * mean(g_y * zhat))
