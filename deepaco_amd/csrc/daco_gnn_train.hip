@@ -968,7 +968,8 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
   hipLaunchKernelGGL(gnn_t_node_init_bwd, dim3(node_blocks < 128 ? node_blocks : 128), dim3(256), 0, s, n, feats, x, t.a0, t.gx,
                      grad_params, grad_params + 32 * feats);
   const float *W0e = params + 32 * feats + 32;
-  hipLaunchKernelGGL(gnn_t_edge_init_bwd, dim3(E / 64 + 1 < 512 ? E / 64 + 1 : 512), dim3(256), 0, s, E, edge_attr, W0e, W0e + 32, t.gw,
+  // (at most 128 workgroups: each adds once into the same 64 words, and the adds to one word are serial)
+  hipLaunchKernelGGL(gnn_t_edge_init_bwd, dim3(E / 64 + 1 < 128 ? E / 64 + 1 : 128), dim3(256), 0, s, E, edge_attr, W0e, W0e + 32, t.gw,
                      grad_params + 32 * feats + 32, grad_params + 32 * feats + 64);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("gnn train backward launch: %s", hipGetErrorString(e)); return DACO_E_HIP; }
