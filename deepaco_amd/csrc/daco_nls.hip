@@ -84,6 +84,9 @@ __device__ inline T nls_ld(const T *base, uint32_t idx) {
 }
 
 constexpr uint64_t NLS_NONE = ~(uint64_t)0;
+// the owner of a flat entry without a search: the compacted lists' first entries as a bitmap of 64 words, one word and its
+// prefix count per lane (a sweep near a local optimum walks a few hundred entries; above NLS_OB_MAX the binary search stays)
+constexpr uint32_t NLS_OB_WORDS = 64, NLS_OB_MAX = NLS_OB_WORDS * 32;
 #ifndef NLS_WAVES_256
 #define NLS_WAVES_256 6                       // waves per SIMD the 256-thread variant is compiled for (80 VGPRs)
 #endif
@@ -103,6 +106,7 @@ struct NlsLds {
   uint64_t *ckey, *sig;                       // per list: minimum key of its candidates, position buckets of its walked entries
   uint64_t *red;
   uint32_t *wsum;
+  uint32_t *obits;                            // NLS_OB_WORDS words: bit w set = a compacted dirty list starts at flat entry w (sweeps of <= NLS_OB_MAX entries)
   float *scal;                                // [0] tour length broadcast
   unsigned long long *lap;                    // profile: cycles per phase of this tour (thread 0)
 };
@@ -115,7 +119,7 @@ struct NlsLds {
 // B entries (from nbT[t[m+1]]).
 template <bool SYM, int NT, int MAXIPT, int NLS_G>
 __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int n, const long max_it, const int sh,
-                                 unsigned long long &walked, unsigned long long *prof) {
+                                 unsigned long long &walked, unsigned long long *prof, const bool owner_bits) {
   constexpr int NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t un = (uint32_t)n;
@@ -158,6 +162,7 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
     const int i0 = tid * ipt;
     uint32_t cq[MAXIPT];
     uint32_t local = 0;                                       // entries of my dirty lists | (non-empty dirty lists) << 22
+    if (tid < (int)NLS_OB_WORDS) L.obits[tid] = 0;            // (last read right after the previous sweep's compaction barrier)
 #pragma unroll
     for (int q = 0; q < MAXIPT; ++q) {
       cq[q] = 0;
@@ -178,7 +183,11 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
     uint32_t at = base & 0x3fffff, j = base >> 22;
 #pragma unroll
     for (int q = 0; q < MAXIPT; ++q) {
-      if (cq[q]) { L.pre[j] = at; L.ditem[j] = (uint16_t)(i0 + q); at += cq[q]; ++j; }
+      if (cq[q]) {
+        L.pre[j] = at; L.ditem[j] = (uint16_t)(i0 + q);
+        if (at < NLS_OB_MAX) atomicOr(&L.obits[at >> 5], 1u << (at & 31));
+        at += cq[q]; ++j;
+      }
     }
     if (tid == NT - 1) { L.pre[j] = at; L.wsum[NW] = j; }
     __syncthreads();
@@ -194,23 +203,41 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
       // (A thread's NLS_G entries are neighbours in the flat order: one binary search over the compacted lists finds the first
       // one's list, each following entry is in the same list or the next -- every compacted list has at least one entry.)
       const int steps = D > 1 ? 32 - __builtin_clz(D - 1) : 0;            // ceil(log2 D), uniform
-      for (uint32_t w0 = tid * NLS_G; w0 < cnt; w0 += NT * NLS_G) {
+      // Round 6: the list of a thread's first entry from the bitmap of list starts -- lane l keeps the number of
+      // starts before it; entry w belongs to list (starts up to and including w) - 1: one cross-lane read, one LDS read and a population
+      // count instead of ceil(log2 D) dependent LDS reads (eight at the ~150 dirty lists of a steady-state sweep, per round).
+      const bool by_bits = owner_bits && cnt <= NLS_OB_MAX;               // uniform
+      uint32_t obp = 0;                                                   // lane l: list starts before word l
+      if (by_bits) { const uint32_t pc = (uint32_t)__popc(L.obits[lane]); obp = nls_wave_scan_u32(pc) - pc; }
+      // (the trip count is the wavefront's: every lane of a wavefront that has an entry in this round takes part in the
+      // cross-lane reads; a lane past the end evaluates the last entry's list's first entry and drops it)
+      for (uint32_t r0 = (uint32_t)(__builtin_amdgcn_readfirstlane(wave) * 64 * NLS_G); r0 < cnt; r0 += NT * NLS_G) {
         if (prof && tid == 0) L.lap[7] += 1;
+        const uint32_t w0r = r0 + (uint32_t)lane * NLS_G;
+        const bool ok0 = w0r < cnt;
+        const uint32_t w0 = ok0 ? w0r : cnt - 1;
         uint32_t mm[NLS_G], lo[NLS_G], ga[NLS_G], ww[NLS_G];
         bool ok[NLS_G];
         {
-          uint32_t a = 0, b = D;                              // pre[a] <= w0 < pre[b]
-          for (int st = 0; st < steps; ++st) {
-            const uint32_t mid = (a + b) >> 1;
-            const bool ge = L.pre[mid] <= w0;
-            a = ge ? mid : a;
-            b = ge ? b : mid;
+          uint32_t a = 0;
+          if (by_bits) {
+            const int wi = (int)(w0 >> 5);
+            const uint32_t bw = L.obits[wi], bp = (uint32_t)__shfl((int)obp, wi);      // (independent: one LDS round trip)
+            a = bp + (uint32_t)__popc(bw & ((2u << (w0 & 31)) - 1u)) - 1u;
+          } else {
+            uint32_t b = D;                                   // pre[a] <= w0 < pre[b]
+            for (int st = 0; st < steps; ++st) {
+              const uint32_t mid = (a + b) >> 1;
+              const bool ge = L.pre[mid] <= w0;
+              a = ge ? mid : a;
+              b = ge ? b : mid;
+            }
           }
           uint32_t start = L.pre[a], next = L.pre[a + 1];
 #pragma unroll
           for (int j = 0; j < NLS_G; ++j) {
             const uint32_t w = w0 + j;
-            ok[j] = w < cnt;
+            ok[j] = ok0 && w < cnt;
             if (j > 0 && ok[j] && w >= next) { ++a; start = next; next = L.pre[a + 1]; }
             lo[j] = L.ditem[a];
             ww[j] = ok[j] ? w - start : 0;                    // (entries past the end read their list's first entry and drop it)
@@ -315,11 +342,11 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
 // MAXIPT: lists per thread the prefix phase is unrolled for (ceil((n + 1) / NT) must not exceed it)
 // NLS_G: list entries a thread evaluates together (their loads in flight at once)
 template <int NT, int MAXIPT, int NLS_G>
-__global__ void __launch_bounds__(NT, 4)
+__global__ void __launch_bounds__(NT, NT == 192 ? 6 : 4)     // (second argument: wavefronts per SIMD -- eight 192-thread tours per CU are six, i.e. at most 80 registers)
 nls_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *tabs, const unsigned char *tabsT,
            const float *hdist, long hdist_bs, const unsigned char *htabs, const unsigned char *htabsT, size_t tab_stride,
            uint16_t *tours, long maxt, int T_nls, long T_p, int32_t *sweeps_out, float *costs_out,
-           unsigned long long *counters, unsigned long long *prof) {
+           unsigned long long *counters, unsigned long long *prof, int owner_bits) {
   const int blk = xcd_remap(blockIdx.x, gridDim.x);           // an XCD walks consecutive tours: few instances in its L2 at a time
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int np2 = (n + 2) & ~1;
@@ -337,6 +364,7 @@ nls_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *t
   L.wsum = L.pre + np2 + 2;
   L.ditem = reinterpret_cast<uint16_t *>(L.wsum + 32);
   L.scal = reinterpret_cast<float *>(L.ditem + np2);
+  L.obits = reinterpret_cast<uint32_t *>(L.scal + 4);
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = blk / T;
   uint16_t *tour = tours + (size_t)blk * n;
@@ -365,8 +393,8 @@ nls_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *t
     M.nb = nbr_nb(tb); M.nbT = nbr_nb(tbT);
     M.rk = nbr_rk(tb, n); M.rkT = nbr_rk(tbT, n);
     const long cap = pert ? T_p : maxt;
-    if (pert ? hsym : dsym) sweeps += nls_search<true, NT, MAXIPT, NLS_G>(L, M, n, cap, sh, walked, prof);
-    else sweeps += nls_search<false, NT, MAXIPT, NLS_G>(L, M, n, cap, sh, walked, prof);
+    if (pert ? hsym : dsym) sweeps += nls_search<true, NT, MAXIPT, NLS_G>(L, M, n, cap, sh, walked, prof, owner_bits != 0);
+    else sweeps += nls_search<false, NT, MAXIPT, NLS_G>(L, M, n, cap, sh, walked, prof, owner_bits != 0);
     if (pert || (T_nls == 0 && !costs_out)) continue;
     // tour length in daco_tour_costs' order: edges (t[k-1], t[k]) read as d[t[k]][t[k-1]], k = 1 .. n-1, closing edge last
     for (int k = tid; k < n; k += NT) {
@@ -428,7 +456,7 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   while (nt > 256 && nt > cap) nt >>= 1;
   if (nt == 256 && cap < 128 && n + 1 <= 576) nt = 192;
   if (const char *ev = getenv("DACO_NLS_THREADS")) nt = atoi(ev);
-  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)np2 * 8 * 2 + 24 * 8 + (size_t)(np2 + 2) * 4 + 32 * 4 + (size_t)np2 * 2 + 16;
+  const size_t lds = (size_t)np2 * 8 + (size_t)np2 * 2 * 4 + (size_t)np2 * 8 * 2 + 24 * 8 + (size_t)(np2 + 2) * 4 + 32 * 4 + (size_t)np2 * 2 + 16 + NLS_OB_WORDS * 4;
   // threads per tour: 256 when there are tours to fill the device several times over (a CU then interleaves six of them),
   // more when there are fewer tours than the device holds (a sweep is a latency chain: more threads shorten its evaluation)
   hipStream_t s = (hipStream_t)stream;
@@ -441,7 +469,9 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   hipLaunchKernelGGL((nls_kernel<NT_, IPT_, G_>)    , dim3((unsigned)B * T), dim3(NT_), lds, s, n, T, dist, dist_bstride,     \
                      (const unsigned char *)tables, (const unsigned char *)tables_T, hdist, hdist_bstride,                     \
                      (const unsigned char *)htables, (const unsigned char *)htables_T, nbr_instance_bytes(n), tours,          \
-                     max_iterations, T_nls, T_p, sweeps, costs, counters, prof)
+                     max_iterations, T_nls, T_p, sweeps, costs, counters, prof, owner_bits)
+  int owner_bits = 1;                                       // (DACO_NLS_OWNER_BITS=0: the binary search over the compacted lists, round 3's form)
+  if (const char *ev = getenv("DACO_NLS_OWNER_BITS")) owner_bits = atoi(ev) != 0;
   int group = 3;                                            // (measured on config 3: 1 / 2 / 3 / 4 entries -> 58.9 / 48.4 / 45.8 / 50.8 ms)
   if (const char *ev = getenv("DACO_NLS_GROUP")) group = atoi(ev);
   if (nt == 64 && n + 1 <= 128) DACO_NLS_LAUNCH(64, 2, 2);            // one wavefront per tour: the barriers of a sweep cost nothing

@@ -22,7 +22,7 @@ d[:, i, i] = 1e9
 
 
 def run(tag, env):
-    for k in ("DACO_NLS_FUSED", "DACO_NLS_THREADS", "DACO_NLS_QUEUE", "DACO_NLS_GROUP", "DACO_NLS_PROFILE"):
+    for k in ("DACO_NLS_FUSED", "DACO_NLS_THREADS", "DACO_NLS_QUEUE", "DACO_NLS_GROUP", "DACO_NLS_PROFILE", "DACO_NLS_OWNER_BITS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     col = engine.BatchedTSP(d.to(dev), n_ants=A, seed=1, local_search="nls", fixed_start=0)
@@ -48,6 +48,7 @@ VARIANTS = {
     "g2": ("fused 256 threads, 2 entries per thread and round", {"DACO_NLS_THREADS": "256", "DACO_NLS_GROUP": "2"}),
     "g4": ("fused 256 threads, 4 entries per thread and round", {"DACO_NLS_THREADS": "256", "DACO_NLS_GROUP": "4"}),
     "g3": ("fused 192 threads, 3 entries per thread and round (default)", {}),
+    "g3s": ("fused 192 threads, 3 entries, binary search for the entry's list (round 3's form)", {"DACO_NLS_OWNER_BITS": "0"}),
     "t256": ("fused 256 threads, 3 entries per thread and round", {"DACO_NLS_THREADS": "256"}),
     "t512": ("fused 512 threads", {"DACO_NLS_THREADS": "512"}),
     "t1024": ("fused 1024 threads", {"DACO_NLS_THREADS": "1024"}),
