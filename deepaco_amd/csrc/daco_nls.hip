@@ -243,7 +243,7 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
             ww[j] = ok[j] ? w - start : 0;                    // (entries past the end read their list's first entry and drop it)
           }
         }
-        float c[NLS_G], ej[NLS_G], g[NLS_G];
+        float g[NLS_G];
         NbrEntry en[NLS_G];
 #pragma unroll
         for (int j = 0; j < NLS_G; ++j) {
@@ -274,22 +274,18 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
             const bool take = side_a ? (m + 3 <= un && k < rA[m]) : (side_b && k < rB[m - 1]);
             ok[j] = ok[j] && take;
             const uint32_t e1 = side_a ? m : (side_b ? pw - 1 : 0), e2 = side_a ? pw : (side_b ? m - 1 : 0);
-            const int2 r1 = rec[e1], r2 = rec[e2];
-            c[j] = __int_as_float(r1.y); ej[j] = __int_as_float(r2.y);
-            ga[j] = nls_idx(side_a ? (uint32_t)r1.x >> 16 : (uint32_t)(r1.x & 0xffff), un,
-                            side_a ? (uint32_t)r2.x >> 16 : (uint32_t)(r2.x & 0xffff));
-            lo[j] = side_a ? (((m + 1) << 16) | pw) : ((pw << 16) | (m - 1));
+            const uint32_t x1 = (uint32_t)rec[e1].x, x2 = (uint32_t)rec[e2].x;
+            ga[j] = nls_idx(side_a ? x1 >> 16 : (x1 & 0xffff), un, side_a ? x2 >> 16 : (x2 & 0xffff));
+            lo[j] = ((e1 + 1) << 16) | e2;                    // = (i << 16) | j of the pair: (m + 1, pw) on side A, (pw, m - 1) on side B
           } else {
             const bool side_a = lo[j] != 0;
             // side A: i = m + 1, j = pos[v]: a = d[t[m]][v] from the table, b = d[t[i]][t[j+1]] gathered
             // side B: j = m, i = pos[u]: b = d[u][t[m+1]] from the transposed table, a = d[t[i-1]][t[j]] gathered
             ok[j] = ok[j] && (side_a ? pw > m + 1 : (pw >= 1 && pw < m));
             const uint32_t e1 = side_a ? m : (pw >= 1 ? pw - 1 : 0), e2 = side_a ? pw : m;
-            const int2 r1 = rec[e1], r2 = rec[e2];
-            c[j] = __int_as_float(r1.y); ej[j] = __int_as_float(r2.y);
-            ga[j] = nls_idx(side_a ? (uint32_t)r1.x >> 16 : (uint32_t)(r1.x & 0xffff), un,
-                            side_a ? (uint32_t)r2.x >> 16 : (uint32_t)(r2.x & 0xffff));
-            lo[j] = side_a ? (((m + 1) << 16) | pw) : ((pw << 16) | m);
+            const uint32_t x1 = (uint32_t)rec[e1].x, x2 = (uint32_t)rec[e2].x;
+            ga[j] = nls_idx(side_a ? x1 >> 16 : (x1 & 0xffff), un, side_a ? x2 >> 16 : (x2 & 0xffff));
+            lo[j] = ((e1 + 1) << 16) | e2;                    // = (i << 16) | j: (m + 1, pw) on side A, (pw, m) on side B
           }
         }
         // (vmcnt counts in order: a gather issued between two table entries' uses would have to return before the next one
@@ -300,7 +296,10 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NLS_G; ++j) {
-          const uint32_t oc = nls_ord_f32(((en[j].d + g[j]) - c[j]) - ej[j]);
+          // c = e[i - 1], e = e[j]: the two edge lengths are read when the gather is back (the key's low word names the edges), so
+          // that a thread holds four words per entry across the second trip to memory
+          const float cj = __int_as_float(rec[(lo[j] >> 16) - 1].y), ejj = __int_as_float(rec[lo[j] & 0xffff].y);
+          const uint32_t oc = nls_ord_f32(((en[j].d + g[j]) - cj) - ejj);
           if (ok[j] && oc < 0x80000000u) atomicMin((unsigned long long *)&L.ckey[mm[j]], ((uint64_t)oc << 32) | lo[j]);
         }
       }
@@ -472,13 +471,20 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
                      max_iterations, T_nls, T_p, sweeps, costs, counters, prof, owner_bits)
   int owner_bits = 1;                                       // (DACO_NLS_OWNER_BITS=0: the binary search over the compacted lists, round 3's form)
   if (const char *ev = getenv("DACO_NLS_OWNER_BITS")) owner_bits = atoi(ev) != 0;
-  int group = 3;                                            // (measured on config 3: 1 / 2 / 3 / 4 entries -> 58.9 / 48.4 / 45.8 / 50.8 ms)
+  // entries per thread and round (round 3, 256 threads: 1 / 2 / 3 / 4 -> 58.9 / 48.4 / 45.8 / 50.8 ms on config 3, four entries needing
+  // 96 registers; round 6: the two edge lengths of an entry are read after its gather, so four entries fit the 80 registers of six
+  // wavefronts per SIMD).  Four when the launch fills the device (the sweeps are issue-bound: fewer rounds), three when it does
+  // not (a sweep is a latency chain: more lanes per round).  profiles/r06_nls_owner_bits.txt: config 3 42.8 -> 42.2 ms,
+  // 1 024 tours of TSP-1000 53.5 -> 47.4 (from two), 600 tours of TSP-100 1.43 -> 1.57 (hence three there).
+  int group = ntours * nt >= 262144 ? 4 : 3;
   if (const char *ev = getenv("DACO_NLS_GROUP")) group = atoi(ev);
   if (nt == 64 && n + 1 <= 128) DACO_NLS_LAUNCH(64, 2, 2);            // one wavefront per tour: the barriers of a sweep cost nothing
   else if (nt == 128 && n + 1 <= 256) DACO_NLS_LAUNCH(128, 2, 2);
   else if (nt >= 1024) DACO_NLS_LAUNCH(1024, 2, 2);
   else if (nt >= 512) DACO_NLS_LAUNCH(512, 3, 2);
+  else if (nt == 192 && n + 1 <= 576 && group >= 4) DACO_NLS_LAUNCH(192, 3, 4);
   else if (nt == 192 && n + 1 <= 576) DACO_NLS_LAUNCH(192, 3, 3);
+  else if (n + 1 > 512 && group >= 4) DACO_NLS_LAUNCH(256, 5, 4);
   else if (n + 1 > 512) DACO_NLS_LAUNCH(256, 5, 2);
   else if (group <= 1) DACO_NLS_LAUNCH(256, 2, 1);
   else if (group >= 4) DACO_NLS_LAUNCH(256, 2, 4);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""daco_tsp_nls with the owner of a flat entry from the bitmap of list starts (default) against the binary search over the
-compacted lists (DACO_NLS_OWNER_BITS=0), alternating in one process at the shapes the callers form (tools/sweep_nls_threads.py);
-the two must return the same tours.  Prints ms per call (HIP events, median of `reps`)."""
+"""daco_tsp_nls under two settings of one knob, alternating in one process at the shapes the callers form
+(tools/sweep_nls_threads.py); both must return the same tours.  Default knob: DACO_NLS_OWNER_BITS = 1 (the list of a flat entry
+from the bitmap of list starts) against 0 (the binary search over the compacted lists).  Usage: ab_nls_owner_bits.py [reps [VAR
+a,b]], e.g. `7 DACO_NLS_GROUP 4,3`.  Prints ms per call (HIP events, median of `reps`)."""
 import json
 import os
 import sys
@@ -13,6 +14,8 @@ from deepaco_amd import engine  # noqa: E402
 
 dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+VAR = sys.argv[2] if len(sys.argv) > 2 else "DACO_NLS_OWNER_BITS"      # the knob that alternates, and its two settings
+MODES = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("1", "0")
 SHAPES = [(100, 30, 20, 25), (500, 50, 8, 125), (200, 48, 1, 200), (500, 48, 1, 500), (1000, 48, 1, 1000), (500, 256, 16, 125),
           (500, 256, 64, 125), (1000, 64, 16, 250)]
 for n, A, B, maxt in SHAPES:
@@ -30,11 +33,11 @@ for n, A, B, maxt in SHAPES:
     hd = (1 / (eta / eta.amax(dim=-1, keepdim=True) + 1e-5)).contiguous()
     td, th = engine.TwoOptTables(d), engine.TwoOptTables(hd)
     row = {"n": n, "tours_per_instance": A, "instances": B, "maxt": maxt}
-    ts = {"1": [], "0": []}
+    ts = {m: [] for m in MODES}
     ref = None
     for r in range(reps + 1):
-        for mode in ("1", "0"):
-            os.environ["DACO_NLS_OWNER_BITS"] = mode
+        for mode in MODES:
+            os.environ[VAR] = mode
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = engine.nls_(d, hd, tours, maxt, tables=td, heuristic_tables=th)
@@ -45,7 +48,7 @@ for n, A, B, maxt in SHAPES:
             assert torch.equal(out, ref), (n, A, B, mode)
             if r:
                 ts[mode].append(e0.elapsed_time(e1))
-    row["bitmap_ms"] = round(sorted(ts["1"])[reps // 2], 3)
-    row["search_ms"] = round(sorted(ts["0"])[reps // 2], 3)
+    for m in MODES:
+        row[f"{VAR}={m}"] = round(sorted(ts[m])[reps // 2], 3)
     print(json.dumps(row), flush=True)
-os.environ.pop("DACO_NLS_OWNER_BITS", None)
+os.environ.pop(VAR, None)

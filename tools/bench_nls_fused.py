@@ -47,9 +47,10 @@ VARIANTS = {
     "g1": ("fused 256 threads, 1 entry per thread and round", {"DACO_NLS_THREADS": "256", "DACO_NLS_GROUP": "1"}),
     "g2": ("fused 256 threads, 2 entries per thread and round", {"DACO_NLS_THREADS": "256", "DACO_NLS_GROUP": "2"}),
     "g4": ("fused 256 threads, 4 entries per thread and round", {"DACO_NLS_THREADS": "256", "DACO_NLS_GROUP": "4"}),
-    "g3": ("fused 192 threads, 3 entries per thread and round (default)", {}),
-    "g3s": ("fused 192 threads, 3 entries, binary search for the entry's list (round 3's form)", {"DACO_NLS_OWNER_BITS": "0"}),
-    "t256": ("fused 256 threads, 3 entries per thread and round", {"DACO_NLS_THREADS": "256"}),
+    "g3": ("fused 192 threads, 3 entries per thread and round", {"DACO_NLS_GROUP": "3"}),
+    "g3s": ("fused 192 threads, 3 entries, binary search for the entry's list (round 3's form)", {"DACO_NLS_OWNER_BITS": "0", "DACO_NLS_GROUP": "3"}),
+    "g4_192": ("fused 192 threads, 4 entries per thread and round (default)", {}),
+    "t256": ("fused 256 threads, 3 entries per thread and round", {"DACO_NLS_THREADS": "256", "DACO_NLS_GROUP": "3"}),
     "t512": ("fused 512 threads", {"DACO_NLS_THREADS": "512"}),
     "t1024": ("fused 1024 threads", {"DACO_NLS_THREADS": "1024"}),
     "prof": ("fused, profiled", {"DACO_NLS_PROFILE": "1"}),
