@@ -71,7 +71,12 @@ def test_net_train_mode_matches_reference(name):
     for backend in ("hip", "torch"):                       # the HIP training kernels and the torch-op cross-check path
         with torch.no_grad():
             heu = forward_as(net, graph(g), backend)
-        np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=ATOL_TORCH, rtol=5e-4, err_msg=backend)
+        # the HIP kernels at the eval-mode tolerance (measured: largest error 2.9e-5 at |ref| ~ 1, no element beyond
+        # 1e-5 + 1e-4 |ref|; tools/net_train_mode_error.py, profiles/r06_net_train_mode_error.txt); the torch-op path at its own
+        if backend == "hip":
+            np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=ATOL_HEU, rtol=1e-4, err_msg=backend)
+        else:
+            np.testing.assert_allclose(heu.cpu().numpy(), g["heu_train"], atol=ATOL_TORCH, rtol=5e-4, err_msg=backend)
 
 
 def _zero_in_exact_arithmetic(key):
