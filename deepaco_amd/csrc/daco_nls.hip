@@ -84,6 +84,7 @@ __device__ inline T nls_ld(const T *base, uint32_t idx) {
 }
 
 constexpr uint64_t NLS_NONE = ~(uint64_t)0;
+typedef short nls_s2 __attribute__((ext_vector_type(2)));
 // the owner of a flat entry without a search: the compacted lists' first entries as a bitmap of 64 words, one word and its
 // prefix count per lane (a sweep near a local optimum walks a few hundred entries; above NLS_OB_MAX the binary search stays)
 constexpr uint32_t NLS_OB_WORDS = 64, NLS_OB_MAX = NLS_OB_WORDS * 32;
@@ -124,7 +125,12 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t un = (uint32_t)n;
   int2 *rec = L.rec;
-  uint16_t *t = L.t, *pos = L.pos, *rA = L.rA, *rB = L.rB;
+  uint16_t *t = L.t, *pos = L.pos;
+  // the two list lengths of the edges, interleaved: rAB[2 m] = side A of edge m, rAB[2 m + 3] = side B of edge m -- so that the word
+  // at 2 m holds what item m of a symmetric search walks: side A of edge m | side B of edge m - 1 << 16
+  uint16_t *rAB = L.rA;
+#define NLS_RA(m) rAB[2 * (m)]
+#define NLS_RB(m) rAB[2 * (m) + 3]
   auto refresh_edge = [&](int m) {
     const int x = t[m], y = t[m + 1];
     const uint32_t xy = nls_idx((uint32_t)x, un, (uint32_t)y), yx = nls_idx((uint32_t)y, un, (uint32_t)x);
@@ -132,8 +138,8 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
     const uint16_t ra = nls_ld(M.rk, xy), rb = nls_ld(M.rkT, yx);
     __builtin_amdgcn_sched_barrier(0);
     rec[m] = make_int2(x | (y << 16), __float_as_int(e));
-    rA[m] = ra;
-    rB[m] = rb;
+    NLS_RA(m) = ra;
+    NLS_RB(m) = rb;
   };
   // prof (DACO_NLS_PROFILE=1, a debugging aid): shader-clock cycles per phase as thread 0 sees them, summed over the launch
   unsigned long long tmark = prof ? clock64() : 0;
@@ -144,13 +150,14 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
   __syncthreads();
   lap(0);
   const int items = SYM ? n + 1 : n, ipt = (items + NT - 1) / NT;
-  auto count_a = [&](int m) -> uint32_t { return m <= n - 3 ? rA[m] : 0; };
+  auto count_a = [&](int m) -> uint32_t { return m <= n - 3 ? NLS_RA(m) : 0; };
   auto count_of = [&](int item) -> uint32_t {
     if (SYM) {
-      const uint32_t ca = count_a(item), cb = item >= 3 ? rB[item - 1] : 0;
+      const uint32_t pk = *reinterpret_cast<const uint32_t *>(&rAB[2 * item]);      // side A of edge item | side B of edge item - 1
+      const uint32_t ca = item <= n - 3 ? pk & 0xffffu : 0, cb = item >= 3 ? pk >> 16 : 0;
       return ca > cb ? ca : cb;
     }
-    return count_a(item) + (item >= 2 ? rB[item] : 0);
+    return count_a(item) + (item >= 2 ? NLS_RB(item) : 0);
   };
   int dlo = 0, dhi = n;                                       // positions whose lists are dirty: everything at first
   int it = 0;
@@ -251,10 +258,16 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
           mm[j] = m;
           if (SYM) {
             en[j] = nls_ld(M.nb, nls_idx((uint32_t)t[m], un, k));
-            lo[j] = k;
+            // whether entry k is inside the item's two lists (side A of edge m, side B of edge m - 1) is known from m and k alone:
+            // the two lengths are one LDS word, read here while the table entry is on its way, and what stays is the pair of
+            // 16-bit differences length - k (v_pk_sub_i16; ranks and k are below 2^11).  (A rank read under the side's branch was
+            // a third dependent LDS round trip per entry, and the branches kept the entries' round trips from overlapping.)
+            const nls_s2 lens = __builtin_bit_cast(nls_s2, *reinterpret_cast<const uint32_t *>(&rAB[2 * m]));
+            const nls_s2 kk = {(short)k, (short)k};
+            lo[j] = __builtin_bit_cast(uint32_t, (nls_s2)(lens - kk));
           } else {
             const int2 r1 = rec[m];
-            const uint32_t ca = m + 3 <= un ? rA[m] : 0;
+            const uint32_t ca = m + 3 <= un ? NLS_RA(m) : 0;
             const bool side_a = k < ca;
             // (one multiply: the row is selected first, then row * n + entry)
             en[j] = nls_ld(side_a ? M.nb : M.nbT, nls_idx(side_a ? (uint32_t)(r1.x & 0xffff) : (uint32_t)r1.x >> 16, un, side_a ? k : k - ca));
@@ -267,11 +280,11 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
           const uint32_t m = mm[j], pw = pos[en[j].id];
           if (ok[j]) atomicOr((unsigned long long *)&L.sig[m], (unsigned long long)1 << (pw >> sh));
           if (SYM) {
-            const uint32_t k = lo[j];
+            const nls_s2 room = __builtin_bit_cast(nls_s2, lo[j]);      // (list length - k) of side A, of side B
             const bool side_a = pw > m + 1, side_b = pw >= 1 && pw + 1 < m;
             // side A of edge m: i = m + 1, j = pw: a = table, b = d[t[i]][t[j+1]] gathered
             // side B of edge m - 1: i = pw, j = m - 1: b = table (by symmetry), a = d[t[i-1]][t[j]] gathered
-            const bool take = side_a ? (m + 3 <= un && k < rA[m]) : (side_b && k < rB[m - 1]);
+            const bool take = side_a ? (m + 3 <= un && room.x > 0) : (side_b && room.y > 0);
             ok[j] = ok[j] && take;
             const uint32_t e1 = side_a ? m : (side_b ? pw - 1 : 0), e2 = side_a ? pw : (side_b ? m - 1 : 0);
             const uint32_t x1 = (uint32_t)rec[e1].x, x2 = (uint32_t)rec[e2].x;
@@ -334,6 +347,8 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
     lap(6);
   }
   return it;
+#undef NLS_RA
+#undef NLS_RB
 }
 
 // NT threads per tour.  tours [B][T][n] u16 in/out; sweeps_out / costs_out [B][T] or null; counters: [0] sweeps, [1] list
@@ -341,14 +356,14 @@ __device__ inline int nls_search(const NlsLds &L, const NlsMatrix &M, const int 
 // MAXIPT: lists per thread the prefix phase is unrolled for (ceil((n + 1) / NT) must not exceed it)
 // NLS_G: list entries a thread evaluates together (their loads in flight at once)
 template <int NT, int MAXIPT, int NLS_G>
-__global__ void __launch_bounds__(NT, NT == 192 ? 6 : 4)     // (second argument: wavefronts per SIMD -- eight 192-thread tours per CU are six, i.e. at most 80 registers)
+__global__ void __launch_bounds__(NT, (NT == 192 || (NT == 256 && MAXIPT == 2)) ? 6 : 4)     // (second argument: wavefronts per SIMD -- eight 192-thread or six 256-thread tours of n <= 512 per CU are six, i.e. at most 80 registers)
 nls_kernel(int n, int T, const float *dist, long dist_bs, const unsigned char *tabs, const unsigned char *tabsT,
            const float *hdist, long hdist_bs, const unsigned char *htabs, const unsigned char *htabsT, size_t tab_stride,
            uint16_t *tours, long maxt, int T_nls, long T_p, int32_t *sweeps_out, float *costs_out,
            unsigned long long *counters, unsigned long long *prof, int owner_bits) {
   const int blk = xcd_remap(blockIdx.x, gridDim.x);           // an XCD walks consecutive tours: few instances in its L2 at a time
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int np2 = (n + 2) & ~1;
+  const int np2 = (n + 3) & ~1;                               // >= n + 2, even (the interleaved list lengths reach 2 n + 3)
   NlsLds L;
   L.rec = reinterpret_cast<int2 *>(smem);
   L.t = reinterpret_cast<uint16_t *>(L.rec + np2);
@@ -439,7 +454,7 @@ extern "C" int daco_tsp_nls(void *stream, int B, int T, int n, const float *dist
   if (n > 1024) { set_error("daco_tsp_nls: n=%d above 1024", n); return DACO_E_TOOLARGE; }
   if (max_iterations > 0x3fffffff) max_iterations = 0x3fffffff;
   if (T_p > 0x3fffffff) T_p = 0x3fffffff;
-  const int np2 = (n + 2) & ~1;
+  const int np2 = (n + 3) & ~1;                               // >= n + 2, even (the interleaved list lengths reach 2 n + 3)
   // threads per tour: 256 when there are tours to fill the device several times over (a CU then interleaves several of
   // them), more when there are fewer tours than the device holds (a sweep is a latency chain: more threads shorten it)
   // (the sweeps are bound by instruction issue once the device is full: three wavefronts per tour walk a sweep's ~850 entries in
