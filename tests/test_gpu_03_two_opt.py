@@ -335,7 +335,7 @@ def test_candidate_list_kernel_many_small_cases_with_ties():
 # ------------------------------------------------------------------ daco_tsp_nls: dirty-list sweeps, the whole NLS in one launch
 # threads per tour, entries per thread and round ("64" / "128": one / two wavefronts per tour, n <= 127 / 255 -- the training
 # step's tours; larger n falls through to the default choice)
-NLS_SHAPES = (("192", "3"), ("256", "3"), ("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"), ("64", "2"), ("128", "2"))
+NLS_SHAPES = (("192", "3"), ("192", "4"), ("256", "3"), ("256", "2"), ("256", "4"), ("512", "2"), ("1024", "2"), ("256", "1"), ("64", "2"), ("128", "2"))   # ("192", "4"): config 3's default since round 6; above n = 575 it is the 256 x 4 launch of n > 512
 
 
 @pytest.mark.parametrize("n,Tn,B,maxit", [(4, 3, 1, 50), (5, 4, 2, 50), (33, 6, 1, 1000), (129, 5, 2, 1000), (257, 4, 1, 30),
