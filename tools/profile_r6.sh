@@ -3,7 +3,7 @@
 # a training step and the siblings; counter passes (rocprofv3 --pmc, kernel trace only, one pass per counter group) of the
 # dominant kernels.  Copy what should be judged from gpurun_out/<tag>/ into profiles/; tools/make_counters.py turns the counter
 # passes into profiles/counters.json and profiles/hbm_traffic.json.
-# usage (on the GPU box, from the repo root):  bash tools/profile_r6.sh r06 [pmc|stats|hgs|gnn|headline|all]
+# usage (on the GPU box, from the repo root):  bash tools/profile_r6.sh r06 [pmc|stats|hgs|gnn|nls|headline|all]
 set -u
 TAG=${1:-r06}
 WHAT=${2:-all}
@@ -39,6 +39,12 @@ if [ "$WHAT" = "hgs" ]; then      # the local-search kernel alone (after a chang
   stats hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short
   pmc hgs_ls python tools/bench_hgs_ls.py --batch 64 --no-short --reps 2
   stats train python tools/run_train_step.py 5
+  ls $OUT
+  exit 0
+fi
+if [ "$WHAT" = "nls" ]; then      # the fused NLS kernel alone at config 3 (after a change to it)
+  stats nls python tools/run_nls_c3.py 64
+  pmc nls python tools/run_nls_c3.py 64
   ls $OUT
   exit 0
 fi
