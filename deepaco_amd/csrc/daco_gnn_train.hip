@@ -103,28 +103,41 @@ gnn_t_edge_pre(int E, int Eg, const int *src, const int *dst, const float *We, c
     if (one_graph) { red[wave][lane] = 0.0; __syncthreads(); }
     return;
   }
+  // (Round 6, last session: the tile's rows, the edge ids, the lane's sixteen entries of We and -- once the ids are back -- the
+  // eight gathered node rows are all in flight before the matrix product; the gathers used to sit in each pass's `if (e < E)`
+  // block behind its own id loads: eight dependent memory round trips per tile after the product.)
+  float4 wrow[4], wev[4], a3q[4], a4q[4];
+  int sq[4], dq[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
-    *reinterpret_cast<float4 *>(&tile[el][c0]) = *reinterpret_cast<const float4 *>(w0 + (size_t)e * TU + c0);
+    wrow[q] = *reinterpret_cast<const float4 *>(w0 + (size_t)e * TU + c0);
+    sq[q] = src[e]; dq[q] = dst[e];
   }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) wev[v] = *reinterpret_cast<const float4 *>(We + o * TU + h * 16 + 4 * v);
+  const float4 bb = *reinterpret_cast<const float4 *>(be + c0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a3q[q] = *reinterpret_cast<const float4 *>(X + (size_t)sq[q] * 128 + 64 + c0);
+    a4q[q] = *reinterpret_cast<const float4 *>(X + (size_t)dq[q] * 128 + 96 + c0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&tile[q * 8 + (lane >> 3)][c0]) = wrow[q];
   __builtin_amdgcn_wave_barrier();
   const f32x16 acc = mfma32(ZERO16, [&](int kk) { return tile[o][h * 16 + kk]; },
-                            [&](int kk) { return We[o * TU + h * 16 + kk]; });
+                            [&](int kk) { const float4 w4 = wev[kk >> 2]; return (kk & 3) == 0 ? w4.x : (kk & 3) == 1 ? w4.y : (kk & 3) == 2 ? w4.z : w4.w; });
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int r = 0; r < 16; ++r) tile[t_drow(r, lane)][o] = acc[r];
   __builtin_amdgcn_wave_barrier();
-  const float4 bb = *reinterpret_cast<const float4 *>(be + c0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int el = q * 8 + (lane >> 3), e = e0 + el;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < E) {
-      const int s = src[e], d = dst[e];
       const float4 g = *reinterpret_cast<const float4 *>(&tile[el][c0]);
-      const float4 a3 = *reinterpret_cast<const float4 *>(X + (size_t)s * 128 + 64 + c0);
-      const float4 a4 = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 96 + c0);
+      const float4 a3 = a3q[q], a4 = a4q[q];
       z = make_float4(g.x + bb.x + a3.x + a4.x, g.y + bb.y + a3.y + a4.y, g.z + bb.z + a3.z + a4.z, g.w + bb.w + a3.w + a4.w);
       *reinterpret_cast<float4 *>(ze + (size_t)e * TU + c0) = z;
     }
@@ -159,9 +172,21 @@ gnn_t_node_pre(int n, int ng, const int *dst, const int *rowptr, const int *perm
   if (live) {
     const int lo = rowptr[i], hi = rowptr[i + 1];
     float agg = 0.0f;
-    for (int q = lo; q < hi; ++q) {
-      const int e = perm ? perm[q] : q;
-      agg = fmaf(t_sigmoid(w0[(size_t)e * TU + o]), X[(size_t)dst[e] * 128 + 32 + o], agg);
+    // (four incident edges at a time: their ids, then their rows and endpoints, then the endpoints' rows are each in flight
+    // together -- one edge at a time the loop was perm -> dst -> X, three dependent memory round trips per edge; the sum keeps
+    // its order)
+    for (int q0 = lo; q0 < hi; q0 += 4) {
+      int ee[4], dd[4];
+      float ww[4], xx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int qq = min(q0 + j, hi - 1); ee[j] = perm ? perm[qq] : qq; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dd[j] = dst[ee[j]]; ww[j] = w0[(size_t)ee[j] * TU + o]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xx[j] = X[(size_t)dd[j] * 128 + 32 + o];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (q0 + j < hi) agg = fmaf(t_sigmoid(ww[j]), xx[j], agg);
     }
     agg = agg / (float)max(hi - lo, 1);
     z = X[(size_t)i * 128 + o] + agg;
@@ -348,36 +373,52 @@ gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const f
   f32x16 aW1 = ZERO16, aW2 = ZERO16;
   float aW3 = 0.f, ab1 = 0.f, ab2 = 0.f, ab3 = 0.f;
   const int ntiles = (E + 31) / 32;
+  // (Round 6, last session: the lane's entries of W1 / W2 -- rows for the forward products, columns for the backward ones -- and
+  // b1, b2, W3 are read once, and a tile's rows and its 16 + 16 per-edge scalars are in flight together; read where they are used
+  // they were some eighty dependent memory round trips per tile.)
+  float w1r[16], w2r[16], w1c[16], w2c[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    w1r[kk] = W1[o * TU + h * 16 + kk]; w2r[kk] = W2[o * TU + h * 16 + kk];
+    w1c[kk] = W1[(h * 16 + kk) * TU + o]; w2c[kk] = W2[(h * 16 + kk) * TU + o];
+  }
+  const float b1o = b1[o], b2o = b2[o], w3o = W3[o];
   for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
     const int e0 = tix * 32;
+    float4 win[4];
+    float hvr[16], ghr[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int el = q * 8 + (lane >> 3), e = min(e0 + el, E - 1);
-      *reinterpret_cast<float4 *>(&tin[el][c0]) = *reinterpret_cast<const float4 *>(w + (size_t)e * TU + c0);
+      win[q] = *reinterpret_cast<const float4 *>(w + (size_t)e * TU + c0);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int e = min(e0 + t_drow(r, lane), E - 1); hvr[r] = heu[e]; ghr[r] = gheu[e]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&tin[q * 8 + (lane >> 3)][c0]) = win[q];
     __builtin_amdgcn_wave_barrier();
     // a1 = w W1^T + b1 -> ta (pre-activation), h1 = silu(a1) -> tg (temporarily)
-    f32x16 acc = mfma32(ZERO16, [&](int kk) { return tin[o][h * 16 + kk]; }, [&](int kk) { return W1[o * TU + h * 16 + kk]; });
+    f32x16 acc = mfma32(ZERO16, [&](int kk) { return tin[o][h * 16 + kk]; }, [&](int kk) { return w1r[kk]; });
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { const float a = acc[r] + b1[o]; ta[t_drow(r, lane)][o] = a; tg[t_drow(r, lane)][o] = t_silu(a); }
+    for (int r = 0; r < 16; ++r) { const float a = acc[r] + b1o; ta[t_drow(r, lane)][o] = a; tg[t_drow(r, lane)][o] = t_silu(a); }
     __builtin_amdgcn_wave_barrier();
     // a2 = h1 W2^T + b2; h2 = silu(a2); gs = gheu * heu * (1 - heu) per edge
-    acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return W2[o * TU + h * 16 + kk]; });
+    acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return w2r[kk]; });
     // per-edge scalar gs for the 16 rows this lane holds
     float a2r[16], gsr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int e = e0 + t_drow(r, lane);
       float gs = 0.0f;
-      if (e < E) { const float hv = heu[e]; gs = gheu[e] * hv * (1.0f - hv); }
-      a2r[r] = acc[r] + b2[o]; gsr[r] = gs;
+      if (e < E) { const float hv = hvr[r]; gs = ghr[r] * hv * (1.0f - hv); }
+      a2r[r] = acc[r] + b2o; gsr[r] = gs;
     }
     // gW3[o] += sum_e gs * h2[e][o]; gb3 += sum_e gs (lane o = 0 of half 0 only, below); g_a2 = gs * W3[o] * dsilu(a2)
     float ga2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       aW3 += gsr[r] * t_silu(a2r[r]);
-      ga2[r] = gsr[r] * W3[o] * t_dsilu(a2r[r]);
+      ga2[r] = gsr[r] * w3o * t_dsilu(a2r[r]);
       ab2 += ga2[r];
       if (o == 0) ab3 += gsr[r];
     }
@@ -395,7 +436,7 @@ gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const f
     __builtin_amdgcn_wave_barrier();
     aW2 = mfma32(aW2, [&](int kk) { return tin[h * 16 + kk][o]; }, [&](int kk) { return tg[h * 16 + kk][o]; });
     // g_h1 = g_a2 W2 : D[e][c] = sum_o g_a2[e][o] W2[o][c]
-    acc = mfma32(ZERO16, [&](int kk) { return tin[o][h * 16 + kk]; }, [&](int kk) { return W2[(h * 16 + kk) * TU + o]; });
+    acc = mfma32(ZERO16, [&](int kk) { return tin[o][h * 16 + kk]; }, [&](int kk) { return w2c[kk]; });
     __builtin_amdgcn_wave_barrier();
     // g_a1 = g_h1 * dsilu(a1) -> tg
 #pragma unroll
@@ -406,7 +447,7 @@ gnn_t_head_bwd(int E, const float *hp, const float *w, const float *heu, const f
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&tin[q * 8 + (lane >> 3)][c0]) = wsave[q];
     __builtin_amdgcn_wave_barrier();
     aW1 = mfma32(aW1, [&](int kk) { return tg[h * 16 + kk][o]; }, [&](int kk) { return tin[h * 16 + kk][o]; });
-    acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return W1[(h * 16 + kk) * TU + o]; });
+    acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return w1c[kk]; });
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) ta[t_drow(r, lane)][o] = acc[r];
@@ -516,6 +557,9 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
   float gam[4], bet[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { gam[k] = gamma[c0 + k]; bet[k] = beta[c0 + k]; }
+  float wecol[16];                                            // We[h * 16 + kk][o]: the B operand of g_w = g_ze We, the same for every tile
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) wecol[kk] = We[(h * 16 + kk) * TU + o];
   for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
     const int e0 = tix * 32;
     // the statistics of the lane's four channels, once per tile when the tile lies inside one graph (32 edges, graphs of Eg edges:
@@ -529,22 +573,39 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
       for (int k = 0; k < 4; ++k) { st_t[k] = load_stat(fsums, g_first, c0 + k, Eg); bs_t[k] = bsums[(size_t)g_first * 32 + c0 + k]; }
     }
     // edge-major pass: g_ze per element, scatter-adds, gate path; tiles tw = w, tg = g_ze
+    // (Round 6, last session: the four passes' loads are issued together -- ids and rows first, then the two gathers that need the
+    // ids -- instead of inside each pass's `if (e < E)` block, where every pass waited for its own two memory round trips: eight
+    // dependent trips per tile; a pass past the end reads edge E - 1 and drops it.)
     float4 gres[4], gate_term[4];
+    int sq[4], dq[4];
+    float4 wvq[4], zzq[4], gmq[4], x2q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * 8 + (lane >> 3), ec = e < E ? e : E - 1;
+      sq[q] = src[ec]; dq[q] = dst[ec];
+      wvq[q] = *reinterpret_cast<const float4 *>(w0 + (size_t)ec * TU + c0);
+      zzq[q] = *reinterpret_cast<const float4 *>(ze + (size_t)ec * TU + c0);
+      gres[q] = *reinterpret_cast<const float4 *>(gw + (size_t)ec * TU + c0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      gmq[q] = *reinterpret_cast<const float4 *>(gmsg + (size_t)sq[q] * TU + c0);
+      x2q[q] = *reinterpret_cast<const float4 *>(X + (size_t)dq[q] * 128 + 32 + c0);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int el = q * 8 + (lane >> 3), e = e0 + el;
       float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), gz = wv;
-      gres[q] = wv; gate_term[q] = wv;
+      gate_term[q] = wv;
       if (e < E) {
-        const int g = e / Eg, s = src[e], d = dst[e];
-        wv = *reinterpret_cast<const float4 *>(w0 + (size_t)e * TU + c0);
-        const float4 zz = *reinterpret_cast<const float4 *>(ze + (size_t)e * TU + c0);
-        const float4 go = *reinterpret_cast<const float4 *>(gw + (size_t)e * TU + c0);
-        gres[q] = go;
+        const int g = e / Eg, s = sq[q], d = dq[q];
+        wv = wvq[q];
+        const float4 zz = zzq[q];
+        const float4 go = gres[q];
         const float zc[4] = {zz.x, zz.y, zz.z, zz.w}, gc[4] = {go.x, go.y, go.z, go.w}, wc[4] = {wv.x, wv.y, wv.z, wv.w};
         float gzc[4], gt[4], c2c[4];
-        const float4 gm = *reinterpret_cast<const float4 *>(gmsg + (size_t)s * TU + c0);
-        const float4 x2 = *reinterpret_cast<const float4 *>(X + (size_t)d * 128 + 32 + c0);
+        const float4 gm = gmq[q];
+        const float4 x2 = x2q[q];
         const float gmc[4] = {gm.x, gm.y, gm.z, gm.w}, x2c[4] = {x2.x, x2.y, x2.z, x2.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -568,6 +629,8 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
           *reinterpret_cast<float4 *>(gzbuf + (size_t)e * TU + c0) = gz;
         }
         gate_term[q] = make_float4(gt[0], gt[1], gt[2], gt[3]);
+      } else {
+        gres[q] = wv;
       }
       *reinterpret_cast<float4 *>(&tw[el][c0]) = wv;
       *reinterpret_cast<float4 *>(&tg[el][c0]) = gz;
@@ -578,7 +641,7 @@ gnn_t_edge_bwd(int E, int Eg, const int *src, const int *dst, const float *We, c
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) ab += tg[h * 16 + kk][o];
     // g_w (through the edge linear) = g_ze We : D[e][c] = sum_o g_ze[e][o] We[o][c]
-    const f32x16 acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return We[(h * 16 + kk) * TU + o]; });
+    const f32x16 acc = mfma32(ZERO16, [&](int kk) { return tg[o][h * 16 + kk]; }, [&](int kk) { return wecol[kk]; });
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) tw[t_drow(r, lane)][o] = acc[r];
@@ -697,10 +760,43 @@ gnn_t_node_lin_bwd(int n, const float *WT, const float *x0, const float *gX, flo
   f32x16 aW[4] = {ZERO16, ZERO16, ZERO16, ZERO16};
   float ab[4] = {0.f, 0.f, 0.f, 0.f};
   const int ntiles = (n + 31) / 32;
+  // Round 6 (last session): every global access of a tile is issued before the first one is waited for.  The compiled loops
+  // were load -> s_waitcnt vmcnt(0) -> LDS store, one element at a time: 80 dependent memory round trips per tile for the two
+  // operand tiles, sixteen more for the rows of WT (re-read per tile) and sixteen for gx's read-modify-write -- 38.7 us per launch
+  // at n = 2 000 for 1.3 MB of traffic.  Now: the lane's 64 entries of WT are read once (registers), a tile's rows arrive as
+  // 20 independent 16-byte loads per lane, gx's old values are in flight under the matrix products.  Same products, same sums.
+  float4 wv[4][4];                                            // WT[o][q * 32 + h * 16 + 4 v ..]: the B operand of the second product
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) wv[q][v] = *reinterpret_cast<const float4 *>(WT + o * 128 + q * 32 + h * 16 + 4 * v);
   for (int tix = blockIdx.x * 4 + wave; tix < ntiles; tix += gridDim.x * 4) {
     const int i0 = tix * 32;
-    for (int k = lane; k < 32 * 32; k += 64) { const int r = k >> 5, c = k & 31; tx[r][c] = i0 + r < n ? x0[(size_t)(i0 + r) * TU + c] : 0.0f; }
-    for (int k = lane; k < 32 * 128; k += 64) { const int r = k >> 7, c = k & 127; tG[r][c] = i0 + r < n ? gX[(size_t)(i0 + r) * 128 + c] : 0.0f; }
+    float4 vx[4], vg[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                             // x0 tile: 32 rows x 8 vectors
+      const int f = lane + 64 * j, r = f >> 3;
+      vx[j] = *reinterpret_cast<const float4 *>(x0 + (size_t)(i0 + r < n ? i0 + r : n - 1) * TU + 4 * (f & 7));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                            // gX tile: 32 rows x 32 vectors
+      const int f = lane + 64 * j, r = f >> 5;
+      vg[j] = *reinterpret_cast<const float4 *>(gX + (size_t)(i0 + r < n ? i0 + r : n - 1) * 128 + 4 * (f & 31));
+    }
+    float gold[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int i = i0 + t_drow(r, lane); gold[r] = gx[(size_t)(i < n ? i : n - 1) * TU + o]; }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = lane + 64 * j, r = f >> 3;
+      *reinterpret_cast<float4 *>(&tx[r][4 * (f & 7)]) = i0 + r < n ? vx[j] : z4;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int f = lane + 64 * j, r = f >> 5;
+      *reinterpret_cast<float4 *>(&tG[r][4 * (f & 31)]) = i0 + r < n ? vg[j] : z4;
+    }
     __builtin_amdgcn_wave_barrier();
     // gWT[c][32q + c'] : D_q[c][c'] = sum_i x[i][c] * gX[i][32q + c']
 #pragma unroll
@@ -713,11 +809,12 @@ gnn_t_node_lin_bwd(int n, const float *WT, const float *x0, const float *gX, flo
     f32x16 acc = ZERO16;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      acc = mfma32(acc, [&](int kk) { return tG[o][q * 32 + h * 16 + kk]; }, [&](int kk) { return WT[o * 128 + q * 32 + h * 16 + kk]; });
+      acc = mfma32(acc, [&](int kk) { return tG[o][q * 32 + h * 16 + kk]; },
+                   [&](int kk) { const float4 w4 = wv[q][kk >> 2]; return (kk & 3) == 0 ? w4.x : (kk & 3) == 1 ? w4.y : (kk & 3) == 2 ? w4.z : w4.w; });
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = i0 + t_drow(r, lane);
-      if (i < n) gx[(size_t)i * TU + o] += acc[r];
+      if (i < n) gx[(size_t)i * TU + o] = gold[r] + acc[r];
     }
     __builtin_amdgcn_wave_barrier();
   }
