@@ -69,34 +69,68 @@ sample_backward_kernel(const BackwardParams p) {
   int remaining = n - 1;
   float used = CVRP ? demand[0] : 0.0f;
   double used64 = demand64 ? 0.0 + demand64[0] : 0.0;
+  // Round 6, last session: a step used to be three dependent memory round trips (its path entry, gradient and row sum; then the
+  // chosen candidate's tau / eta; then the lanes' candidates, one chunk of 64 after the other).  Now the NEXT step's three scalars
+  // are fetched while this one is worked on, and the chosen candidate's pair goes out together with the first four chunks of
+  // candidates (and their demands): one round trip per step up to n = 256, one more per 256 candidates beyond.  Same arithmetic.
+  int j = len > 1 ? (int)path[(size_t)A] : 0;
+  float g = len > 1 ? gl[0] : 0.0f, S = len > 1 ? rs[0] : 1.0f;
   for (int t = 1; t < len; ++t) {
-    const int j = (int)path[(size_t)t * A];
-    const float g = gl[(size_t)(t - 1) * A];
-    const float S = rs[(size_t)(t - 1) * A];
+    const int tn = t + 1 < len ? t + 1 : t;                   // (the last step fetches itself again)
+    const int jn = (int)path[(size_t)tn * A];
+    const float gn = gl[(size_t)(tn - 1) * A], Sn = rs[(size_t)(tn - 1) * A];
     const float *trow = tau + (size_t)prev * n, *erow = eta + (size_t)prev * n;
     if (t >= t_lo && g != 0.0f) {
-      const float pj = pw(trow[j], p.alpha) * pw(erow[j], p.beta);
+      float e4[4], t4[4], d4[4] = {0.f, 0.f, 0.f, 0.f};
+      double dd4[4] = {0., 0., 0., 0.};
+      const float tj = trow[j], ej = erow[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = lane + 64 * u, kc = k < n ? k : 0;
+        e4[u] = erow[kc]; t4[u] = trow[kc];
+        if (CVRP) d4[u] = demand[kc];
+      }
+      if (CVRP && demand64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = lane + 64 * u; dd4[u] = demand64[k < n ? k : 0]; }
+      }
+      const float pj = pw(tj, p.alpha) * pw(ej, p.beta);
       const float pr = pj / S;
       if (pr > DACO_EPS_F32 && pr < 1.0f - DACO_EPS_F32) {      // inside the clamp: gradient flows
         const float rem = CVRP ? p.capacity - used : 0.0f;
         const double rem64 = p.capacity64 - used64;
         const float c = g / S;
         float *grow = grad + (size_t)prev * n;
-        for (int ch = 0; ch < chunks; ++ch) {
-          const int k = lane + 64 * ch;
-          if (k >= n) break;
-          bool open = !((vis >> ch) & 1);
-          if (CVRP) {
-            if (k == 0) open = !(prev == 0 && remaining > 0);
-            open = open && !(demand64 ? demand64[k] > rem64 : demand[k] > rem);
+        for (int c0 = 0; c0 < chunks; c0 += 4) {
+          if (c0 > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int k = lane + 64 * (c0 + u), kc = k < n ? k : 0;
+              e4[u] = erow[kc]; t4[u] = trow[kc];
+              if (CVRP) d4[u] = demand[kc];
+            }
+            if (CVRP && demand64) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { const int k = lane + 64 * (c0 + u); dd4[u] = demand64[k < n ? k : 0]; }
+            }
           }
-          if (!open) continue;
-          const float e = erow[k];
-          const float tk = trow[k];
-          const float pk = pw(tk, p.alpha) * pw(e, p.beta);
-          float val = -c * dprob_deta(pk, tk, e, p.alpha, p.beta);
-          if (k == j) val += g * p.beta / e;
-          unsafeAtomicAdd(grow + k, val);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ch = c0 + u, k = lane + 64 * ch;
+            if (ch >= chunks || k >= n) continue;
+            bool open = !((vis >> ch) & 1);
+            if (CVRP) {
+              if (k == 0) open = !(prev == 0 && remaining > 0);
+              open = open && !(demand64 ? dd4[u] > rem64 : d4[u] > rem);
+            }
+            if (!open) continue;
+            const float e = e4[u];
+            const float tk = t4[u];
+            const float pk = pw(tk, p.alpha) * pw(e, p.beta);
+            float val = -c * dprob_deta(pk, tk, e, p.alpha, p.beta);
+            if (k == j) val += g * p.beta / e;
+            unsafeAtomicAdd(grow + k, val);
+          }
         }
       }
     }
@@ -109,6 +143,7 @@ sample_backward_kernel(const BackwardParams p) {
       if ((j & 63) == lane) vis |= 1ull << (j >> 6);
     }
     prev = j;
+    j = jn; g = gn; S = Sn;
   }
 }
 
