@@ -1038,7 +1038,9 @@ extern "C" int daco_gnn_train_backward(void *stream, int n, int E, int feats, in
       zero_async(t.bsums, (size_t)12 * 2 * G * 64 * 8, s) != hipSuccess) { set_error("zero fill failed"); return DACO_E_HIP; }
   const bool caller_csr = rowptr_dst && perm_dst;
   const int force_gather = getenv("DACO_GNN_TRAIN_GATHER") ? atoi(getenv("DACO_GNN_TRAIN_GATHER")) : -1;   // read per call
-  const bool use_gather = force_gather >= 0 ? force_gather != 0 : (E >= 100000 || caller_csr);
+  // (the threshold was 100 k edges before the kernels' loads were batched; measured again at the end of round 6: 20 k edges -- the
+  // TSP-100 training step -- 3.37 ms with atomics, 3.30 with the gather, profiles/r06_train_step_load_batching.txt)
+  const bool use_gather = force_gather >= 0 ? force_gather != 0 : (E >= 16000 || caller_csr);
   if (use_gather && !caller_csr) {
     if (zero_async(t.csr_cursor, (size_t)n * 4, s) != hipSuccess) { set_error("zero fill failed"); return DACO_E_HIP; }
     hipLaunchKernelGGL(csr_count_kernel, dim3((E + 255) / 256), dim3(256), 0, s, E, dst, t.csr_cursor);
