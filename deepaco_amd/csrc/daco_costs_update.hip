@@ -233,23 +233,49 @@ deposit_rows_kernel(int n, int A, int R, int hub, float *tau, const uint32_t *nb
   const float *cs = costs + (size_t)b * A, *wt = weights ? weights + (size_t)b * A : nullptr;
   // chunk loader: consecutive threads on consecutive ants of one row (256-byte segments).  Wave 0 runs
   // the chains, so after the first chunk only waves 1..3 fetch: a chain never waits for a prefetch.
+  // (Round 6, last session: a loader thread's entries of a chunk are all in flight before the first is waited for.  The loop used
+  // to be load -> s_waitcnt vmcnt(0) -> LDS store per entry -- five or six dependent memory round trips per chunk for each of the
+  // 192 loader threads, more than the 2.9 us the chain spends on a chunk: the chain wave stood at the chunk barrier waiting for
+  // its loaders, and the launch was bound by their latency, not by the chain.)
+  constexpr int LDU = 6;                                     // entries per loader thread in flight (6 x 192 >= 16 rows x 64 ants)
   auto load_chunk = [&](int c0, int buf, int t0, int nt) {
     const int m = min(DEP_CHUNK, ahi - c0);
     if constexpr (GT) {
       // consecutive threads on the eight ants of a row, then on the rows, then on the chunk's groups: runs of Rv x 32 bytes
-      const int per_g = Rv * 8;
-      for (int i = t0; i < per_g * (DEP_CHUNK / 8); i += nt) {
-        const int gq = i / per_g, rem = i - gq * per_g;
-        const int r = rem >> 3, a8 = rem & 7;
-        const int ant = c0 + gq * 8 + a8;                   // (c0: a multiple of 8 except for the elitist's single ant)
-        const int j = ant - c0;
-        if (j < DEP_CHUNK)
-          stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[((size_t)(ant >> 3) * n + r) * 8 + (ant & 7)] : 0xFFFFFFFFu;
+      const int per_g = Rv * 8, total = per_g * (DEP_CHUNK / 8);
+      for (int ib = t0; ib < total; ib += nt * LDU) {
+        uint32_t v[LDU];
+        int dstx[LDU];
+#pragma unroll
+        for (int u = 0; u < LDU; ++u) {
+          const int i = ib + u * nt, ic = i < total ? i : t0;
+          const int gq = ic / per_g, rem = ic - gq * per_g;
+          const int r = rem >> 3, a8 = rem & 7;
+          const int ant = c0 + gq * 8 + a8;                 // (c0: a multiple of 8 except for the elitist's single ant)
+          const int j = ant - c0;
+          const int antc = j < m ? ant : c0;                  // (an ant past the chunk's end: reads the first one's entry, stores ~0)
+          v[u] = tab[((size_t)(antc >> 3) * n + r) * 8 + (antc & 7)];
+          dstx[u] = (i < total && j < DEP_CHUNK) ? ((buf * R + r) * DEP_CHUNK + j) | (j < m ? 0 : (int)0x80000000) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < LDU; ++u)
+          if (dstx[u] != -1) stage[dstx[u] & 0x7fffffff] = dstx[u] < 0 ? 0xFFFFFFFFu : v[u];
       }
     } else {
-      for (int i = t0; i < Rv * DEP_CHUNK; i += nt) {
-        const int r = i / DEP_CHUNK, j = i - r * DEP_CHUNK;
-        stage[(buf * R + r) * DEP_CHUNK + j] = j < m ? tab[(size_t)r * A + c0 + j] : 0xFFFFFFFFu;
+      const int total = Rv * DEP_CHUNK;
+      for (int ib = t0; ib < total; ib += nt * LDU) {
+        uint32_t v[LDU];
+        int dstx[LDU];
+#pragma unroll
+        for (int u = 0; u < LDU; ++u) {
+          const int i = ib + u * nt, ic = i < total ? i : t0;
+          const int r = ic / DEP_CHUNK, j = ic - r * DEP_CHUNK;
+          v[u] = tab[(size_t)r * A + c0 + (j < m ? j : 0)];
+          dstx[u] = i < total ? ((buf * R + r) * DEP_CHUNK + j) | (j < m ? 0 : (int)0x80000000) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < LDU; ++u)
+          if (dstx[u] != -1) stage[dstx[u] & 0x7fffffff] = dstx[u] < 0 ? 0xFFFFFFFFu : v[u];
       }
     }
     if (t0 < DEP_CHUNK)

@@ -228,12 +228,25 @@ scan_sparse_kernel(const SampleParams p) {
     // the copy: sixteen threads per row, 8 bytes at a time; then the tail totals (slot 63 of the full row -> slot kmax)
     const char *src = hrb;
     const int l16 = threadIdx.x & 15;
-    for (int row = threadIdx.x >> 4; row < n; row += 16)
-      if (l16 < kl) {
-        const uint2 *g = reinterpret_cast<const uint2 *>(src + (size_t)row * ROWB + l16 * LS);
-        uint2 *d = reinterpret_cast<uint2 *>(lh_tab + (uint32_t)row * lh_rb + l16 * LS);
-        const uint2 x0 = g[0], x1 = g[1], x2 = g[2];
-        d[0] = x0; d[1] = x1; d[2] = x2;
+    // (eight rows per thread in flight: one row per iteration the copy was 31 dependent memory round trips -- load, wait, LDS
+    // store -- in front of a launch that is a latency chain anyway)
+    if (l16 < kl)
+      for (int row0 = threadIdx.x >> 4; row0 < n; row0 += 16 * 8) {
+        uint2 x[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = row0 + 16 * u;
+          const uint2 *g = reinterpret_cast<const uint2 *>(src + (size_t)(row < n ? row : row0) * ROWB + l16 * LS);
+          x[u][0] = g[0]; x[u][1] = g[1]; x[u][2] = g[2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = row0 + 16 * u;
+          if (row < n) {
+            uint2 *d = reinterpret_cast<uint2 *>(lh_tab + (uint32_t)row * lh_rb + l16 * LS);
+            d[0] = x[u][0]; d[1] = x[u][1]; d[2] = x[u][2];
+          }
+        }
       }
     if (threadIdx.x < 4) reinterpret_cast<float *>(lh_tab + (uint32_t)n * lh_rb)[threadIdx.x] = 0.0f;
     if (threadIdx.x >= 4 && threadIdx.x < 6) reinterpret_cast<uint32_t *>(lh_tab + (uint32_t)n * lh_rb)[threadIdx.x] = (uint32_t)p.ld * 0x00010001u;
@@ -551,22 +564,36 @@ scan_sparse_kernel(const SampleParams p) {
       if (active) {
         float cost = 0.0f;
         const float *mine_d = dstage[wave][q];
-        for (int base = 1; base < n; base += 64) {
-          const int t = base + lane;
+        // (four chunks' gathers in flight together -- sixteen loads per lane -- then staged and summed chunk by chunk: one chunk at
+        // a time the phase was eight dependent gather round trips per wavefront)
+        for (int base0 = 1; base0 < n; base0 += 256) {
+          float gv[4][APW];
 #pragma unroll
-          for (int r4 = 0; r4 < APW; ++r4) {
-            const uint16_t *tr = tour_s[wave * APW + r4];
-            dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (s == 0) {
+          for (int c = 0; c < 4; ++c) {
+            const int t = base0 + 64 * c + lane, tc = t < n ? t : n - 1;
 #pragma unroll
-            for (int v4 = 0; v4 < 16; ++v4) {
-              const float4 v = *(const float4 *)(mine_d + 4 * v4);
-              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+            for (int r4 = 0; r4 < APW; ++r4) {
+              const uint16_t *tr = tour_s[wave * APW + r4];
+              gv[c][r4] = dist_b[(uint32_t)tr[tc] * (uint32_t)n + tr[tc - 1]];
             }
           }
-          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int base = base0 + 64 * c, t = base + lane;
+            if (base < n) {                                   // (uniform)
+#pragma unroll
+              for (int r4 = 0; r4 < APW; ++r4) dstage[wave][r4][lane] = t < n ? gv[c][r4] : 0.0f;
+              __builtin_amdgcn_wave_barrier();
+              if (s == 0) {
+#pragma unroll
+                for (int v4 = 0; v4 < 16; ++v4) {
+                  const float4 v = *(const float4 *)(mine_d + 4 * v4);
+                  cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
         }
         if (s == 0 && a0 + q < A) {
           const uint16_t *tm = tour_s[wave * APW + q];
