@@ -564,36 +564,25 @@ scan_sparse_kernel(const SampleParams p) {
       if (active) {
         float cost = 0.0f;
         const float *mine_d = dstage[wave][q];
-        // (four chunks' gathers in flight together -- sixteen loads per lane -- then staged and summed chunk by chunk: one chunk at
-        // a time the phase was eight dependent gather round trips per wavefront)
-        for (int base0 = 1; base0 < n; base0 += 256) {
-          float gv[4][APW];
+        // (Round 6, last session, measured and not kept: four chunks' gathers in flight together -- sixteen loads per lane -- made
+        // the headline launch SLOWER, 0.522 -> 0.532 ms on one box: the phase is bound by the L2's line rate, as DESIGN 9.1 says,
+        // and deeper bursts only disturb the loops of the workgroups still building tours.)
+        for (int base = 1; base < n; base += 64) {
+          const int t = base + lane;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int t = base0 + 64 * c + lane, tc = t < n ? t : n - 1;
+          for (int r4 = 0; r4 < APW; ++r4) {
+            const uint16_t *tr = tour_s[wave * APW + r4];
+            dstage[wave][r4][lane] = t < n ? dist_b[(uint32_t)tr[t] * (uint32_t)n + tr[t - 1]] : 0.0f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (s == 0) {
 #pragma unroll
-            for (int r4 = 0; r4 < APW; ++r4) {
-              const uint16_t *tr = tour_s[wave * APW + r4];
-              gv[c][r4] = dist_b[(uint32_t)tr[tc] * (uint32_t)n + tr[tc - 1]];
+            for (int v4 = 0; v4 < 16; ++v4) {
+              const float4 v = *(const float4 *)(mine_d + 4 * v4);
+              cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
             }
           }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int base = base0 + 64 * c, t = base + lane;
-            if (base < n) {                                   // (uniform)
-#pragma unroll
-              for (int r4 = 0; r4 < APW; ++r4) dstage[wave][r4][lane] = t < n ? gv[c][r4] : 0.0f;
-              __builtin_amdgcn_wave_barrier();
-              if (s == 0) {
-#pragma unroll
-                for (int v4 = 0; v4 < 16; ++v4) {
-                  const float4 v = *(const float4 *)(mine_d + 4 * v4);
-                  cost = cost + v.x; cost = cost + v.y; cost = cost + v.z; cost = cost + v.w;
-                }
-              }
-              __builtin_amdgcn_wave_barrier();
-            }
-          }
+          __builtin_amdgcn_wave_barrier();
         }
         if (s == 0 && a0 + q < A) {
           const uint16_t *tm = tour_s[wave * APW + q];
