@@ -695,21 +695,40 @@ gnn_t_gather_bwd(int n, const int *rowptr, const int *perm, const int *rowptr_ds
   // edge ids are fetched 32 at a time by the node's lanes and handed round by shuffles: the row loads then depend on a
   // lane exchange, not on a second trip to memory, and several of them are in flight
   float a2 = 0.0f, a3 = 0.0f, a4 = 0.0f;
-  for (int q0 = rowptr_dst[i], hi = rowptr_dst[i + 1]; q0 < hi; q0 += 32) {
-    const int m = min(32, hi - q0);
-    const int ev = o < m ? perm_dst[q0 + o] : 0;
-#pragma unroll 4
-    for (int j = 0; j < m; ++j) {
-      const int e = __shfl(ev, j, 32);
-      a2 += c2buf[(size_t)e * TU + o];
-      a4 += gzbuf[(size_t)e * TU + o];
+  // (the four row bounds together, then the first 32 ids of both lists together: read where each loop starts they were four
+  // dependent memory round trips before the first row arrived)
+  const int dlo = rowptr_dst[i], dhi = rowptr_dst[i + 1], slo = rowptr[i], shi = rowptr[i + 1];
+  int ev_d = dlo + o < dhi ? perm_dst[dlo + o] : 0;
+  int ev_s = slo + o < shi ? (perm ? perm[slo + o] : slo + o) : 0;
+  for (int q0 = dlo; q0 < dhi; q0 += 32) {
+    const int m = min(32, dhi - q0);
+    const int ev = q0 == dlo ? ev_d : (o < m ? perm_dst[q0 + o] : 0);
+    // (eight edges' rows in flight: the compiler does not unroll a loop of run-time length around a lane exchange, and one edge at a
+    // time the loop was two loads and a full wait per edge -- a memory round trip per incident edge)
+    for (int j0 = 0; j0 < m; j0 += 8) {
+      float r2[8], r4[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = __shfl(ev, j0 + u < m ? j0 + u : 0, 32);
+        r2[u] = c2buf[(size_t)e * TU + o];
+        r4[u] = gzbuf[(size_t)e * TU + o];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < m) { a2 += r2[u]; a4 += r4[u]; }
     }
   }
-  for (int q0 = rowptr[i], hi = rowptr[i + 1]; q0 < hi; q0 += 32) {
-    const int m = min(32, hi - q0);
-    const int ev = o < m ? (perm ? perm[q0 + o] : q0 + o) : 0;
-#pragma unroll 4
-    for (int j = 0; j < m; ++j) a3 += gzbuf[(size_t)__shfl(ev, j, 32) * TU + o];
+  for (int q0 = slo; q0 < shi; q0 += 32) {
+    const int m = min(32, shi - q0);
+    const int ev = q0 == slo ? ev_s : (o < m ? (perm ? perm[q0 + o] : q0 + o) : 0);
+    for (int j0 = 0; j0 < m; j0 += 8) {
+      float r3[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r3[u] = gzbuf[(size_t)__shfl(ev, j0 + u < m ? j0 + u : 0, 32) * TU + o];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < m) a3 += r3[u];
+    }
   }
   gX[(size_t)i * 128 + 32 + o] = a2;
   gX[(size_t)i * 128 + 64 + o] = a3;

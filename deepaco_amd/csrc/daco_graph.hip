@@ -23,12 +23,18 @@ knn_graph_kernel(int B, int n, int k, const float *coords, float diag, float *di
   const float *c = coords + (size_t)b * n * 2;
   const float xi = c[2 * i], yi = c[2 * i + 1];
   float dv[CPL];
+  // (the row's coordinates first, all of them, unconditionally -- a lane past the row reads node 0 and drops it: read under
+  // `if (j < n)` next to the store of the distance, every chunk's pair was a memory round trip of its own)
+  float2 cjv[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) { const int j = lane + 64 * q; cjv[q] = *reinterpret_cast<const float2 *>(c + 2 * (j < n ? j : 0)); }
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
     const int j = lane + 64 * q;
+    const float2 cj = cjv[q];
     float v = __builtin_inff();
     if (j < n) {
-      const float dx = xi - c[2 * j], dy = yi - c[2 * j + 1];
+      const float dx = xi - cj.x, dy = yi - cj.y;
       v = j == i ? diag : sqrtf(dx * dx + dy * dy);
       if (dist) dist[(size_t)row * n + j] = v;
     }
