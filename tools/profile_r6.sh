@@ -3,7 +3,7 @@
 # a training step and the siblings; counter passes (rocprofv3 --pmc, kernel trace only, one pass per counter group) of the
 # dominant kernels.  Copy what should be judged from gpurun_out/<tag>/ into profiles/; tools/make_counters.py turns the counter
 # passes into profiles/counters.json and profiles/hbm_traffic.json.
-# usage (on the GPU box, from the repo root):  bash tools/profile_r6.sh r06 [pmc|stats|hgs|gnn|nls|headline|all]
+# usage (on the GPU box, from the repo root):  bash tools/profile_r6.sh r06 [pmc|stats|hgs|gnn|nls|deposit|headline|all]
 set -u
 TAG=${1:-r06}
 WHAT=${2:-all}
@@ -45,6 +45,11 @@ fi
 if [ "$WHAT" = "nls" ]; then      # the fused NLS kernel alone at config 3 (after a change to it)
   stats nls python tools/run_nls_c3.py 64
   pmc nls python tools/run_nls_c3.py 64
+  ls $OUT
+  exit 0
+fi
+if [ "$WHAT" = "deposit" ]; then  # the update with the head rows alone (after a change to it)
+  pmc deposit_heads python bench.py --no-cpu --no-extras --min-seconds 0 --steps 5 --precondition-seconds 0
   ls $OUT
   exit 0
 fi
